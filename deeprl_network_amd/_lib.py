@@ -1,0 +1,82 @@
+"""ctypes binding of libnmarl_hip.so (include/nmarl.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module
+raises at import, and every op raises if handed a non-HIP tensor.
+torch is imported first so that the HIP runtime already mapped by torch
+(libamdhip64.so.7) is the one the library binds to -- one runtime per process.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL, see above)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libnmarl_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'deeprl_network_amd: %s not found. Build it with `python -m deeprl_network_amd.build` '
+        '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+ABI_VERSION = 1
+
+
+class CaccParams(C.Structure):
+    """nmarl_cacc_params_t (include/nmarl.h)."""
+    _fields_ = [(n, C.c_float) for n in
+                ('dt', 'h_min', 'h_star', 'h_s', 'h_g', 'v_max', 'v_star', 'u_min', 'u_max',
+                 'reward_a', 'reward_b', 'G')] + \
+               [(n, C.c_int32) for n in ('T', 'batch_size', 'scenario', 'train_mode', 'per_agent_reward')]
+
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_u64 = C.c_uint64
+_f32 = C.c_float
+
+# name -> argtypes; every symbol include/nmarl.h declares (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    'nmarl_abi_version': [],
+    'nmarl_cacc_reset': [C.POINTER(CaccParams), _i64, _p, _p, _u64, _i64, _p,
+                         _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p],
+    'nmarl_cacc_step': [C.POINTER(CaccParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                        _i32, _u64, _i64, _p, _p],
+}
+
+for _name, _args in SIGNATURES.items():
+    _fn = getattr(lib, _name)   # AttributeError here == missing export: fail loudly
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+
+if lib.nmarl_abi_version() != ABI_VERSION:
+    raise ImportError('libnmarl_hip.so ABI %d != binding ABI %d: rebuild' %
+                      (lib.nmarl_abi_version(), ABI_VERSION))
+
+
+class NmarlError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NmarlError('%s failed: %s' % (what, {-1: 'NMARL_EINVAL', -2: 'NMARL_EHIP'}.get(rc, rc)))
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NmarlError('nmarl ops need HIP device tensors (got %s); there is no CPU path' % t.device)
+    if not t.is_contiguous():
+        raise NmarlError('nmarl ops need contiguous tensors')
+    if dtype is not None and t.dtype != dtype:
+        raise NmarlError('expected dtype %s, got %s' % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

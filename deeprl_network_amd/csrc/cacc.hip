@@ -1,0 +1,321 @@
+// CACC platoon environment for E lock-stepped replicas on gfx950 (MI355X).
+//
+// Replaces envs/cacc_env.py of the reference: step (191-242), _get_accel
+// (31-38), OVMCarFollowing (346-385), _constrain_speed (24-29), _get_reward
+// (40-52), _get_state/_get_veh_state (54-79), reset/_init_* (166-189, 285-318).
+//
+// Mapping: one lane per (replica, vehicle); a replica is an aligned 8-lane
+// group, so a wave64 steps 8 replicas.  Per-vehicle state h,v,u is [E,8] fp32
+// SoA: a wave reads/writes 256 contiguous bytes per array (fully coalesced).
+// The line-graph neighbourhood (vehicle i-1 / i+1) is exchanged with wave
+// shuffles of width 8; min(h) (collision) and sum(reward) are 3-stage xor
+// butterflies over the 8-lane group -- the same tree numpy's pairwise sum
+// uses for 8 elements, so the fp32 sum order matches the oracle.  The
+// gathered observation [E,8,15] (own + 2 neighbour slots) is staged through
+// LDS so the wave writes its 3840 contiguous bytes as 16-byte stores.
+//
+// HBM-bound, no contraction: no MFMA.  Algorithmic bytes per replica-step are
+// listed in DESIGN.md (B_alg).  Compiled with -ffp-contract=off so the fp32
+// arithmetic follows the oracle operation by operation.
+#include "common.h"
+
+namespace {
+
+constexpr int N = NMARL_CACC_N;      // 8
+constexpr int NF = NMARL_CACC_NF;    // 5
+constexpr int NOBS = NMARL_CACC_OBS; // 15
+constexpr int DECEL_STEPS = 300;     // cacc_env.py:317
+constexpr float PI_F = 3.14159265358979323846f;
+
+// v0s[t], cacc_env.py:299 / 316-318 (np.linspace(v_init, v*, 300) then v*)
+__device__ __forceinline__ float lead_speed(const nmarl_cacc_params_t& p, float v0_init, int t) {
+    if (p.scenario == 0) return p.v_star;
+    const float step = (p.v_star - v0_init) / (float)(DECEL_STEPS - 1);
+    const float ramp = (float)t * step + v0_init;
+    return t >= DECEL_STEPS - 1 ? p.v_star : ramp;
+}
+
+// OVMCarFollowing.get_vh, cacc_env.py:360-369
+__device__ __forceinline__ float ovm_vh(const nmarl_cacc_params_t& p, float h) {
+    const float mid = p.v_max / 2.0f * (1.0f - cosf(PI_F * (h - p.h_s) / (p.h_g - p.h_s)));
+    return h <= p.h_s ? 0.0f : (h < p.h_g ? mid : p.v_max);
+}
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// _get_veh_state (cacc_env.py:54-65) for this lane's vehicle, then the
+// neighbour gather and the LDS-staged coalesced store of the wave's slab.
+__device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, float v, float u,
+                                         float v_lead, int a, bool valid, int lane, float* lds_wave,
+                                         float* __restrict__ obs_wave, int n_valid_lanes) {
+    float x[NF];
+    x[0] = (v - p.v_star) / p.v_star;
+    x[1] = clampf((v_lead - v) / 5.0f, -2.0f, 2.0f);
+    x[2] = clampf((ovm_vh(p, h) - v) / 5.0f, -2.0f, 2.0f);
+    x[3] = (h + (v_lead - v) * p.dt - p.h_star) / p.h_star;
+    x[4] = u / p.u_max;
+    float* row = lds_wave + lane * NOBS;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const float lo = __shfl_up(x[k], 1, N);     // vehicle a-1
+        const float hi = __shfl_down(x[k], 1, N);   // vehicle a+1
+        // slots hold the neighbours in ascending index, left-packed (cacc_env.py:72)
+        const float s1 = a == 0 ? hi : lo;
+        const float s2 = (a == 0 || a == N - 1) ? 0.0f : hi;
+        row[k] = x[k];
+        row[NF + k] = s1;
+        row[2 * NF + k] = s2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 64 lanes x 15 floats = 240 float4, contiguous in HBM
+    const float4* src = reinterpret_cast<const float4*>(lds_wave);
+    float4* dst = reinterpret_cast<float4*>(obs_wave);
+    const int n_vec = n_valid_lanes * NOBS / 4;  // n_valid_lanes is a multiple of 8 -> exact
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * NMARL_WAVE + lane;
+        if (idx < n_vec) dst[idx] = src[idx];
+    }
+    (void)valid;
+}
+
+// initial condition, cacc_env.py:285-318
+__device__ __forceinline__ void init_state(const nmarl_cacc_params_t& p, float U, int a,
+                                           float& h, float& v, float& v0i) {
+    h = p.h_star; v = p.v_star; v0i = p.v_star;
+    if (p.scenario == 0) {
+        if (a == 0) h = p.h_star * (1.5f + U);          // :294
+    } else {
+        v = p.v_star * (1.5f + U);                      // :314
+        v0i = v;                                        // :317
+    }
+}
+
+__device__ __forceinline__ float reset_uniform(uint64_t seed, int64_t env_id, int episode) {
+    const Philox4 r = philox4x32_10((uint32_t)env_id, 0u, (uint32_t)episode, NMARL_STREAM_RESET,
+                                    (uint32_t)seed, (uint32_t)(seed >> 32));
+    return u01_from_bits(r.x);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
+    const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ action,
+    float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
+    int32_t* __restrict__ ts, uint8_t* __restrict__ coll, float* __restrict__ v0_init,
+    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+    float* __restrict__ greward, const int auto_reset, const uint64_t seed,
+    const int64_t env_id_base, int32_t* __restrict__ episode) {
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * NOBS];
+    const int lane = threadIdx.x & (NMARL_WAVE - 1);
+    const int wave = threadIdx.x / NMARL_WAVE;
+    float* lds_wave = lds + wave * NMARL_WAVE * NOBS;
+    const int64_t n_lanes = E * N;
+    const int64_t waves_total = (n_lanes + NMARL_WAVE - 1) / NMARL_WAVE;
+    const int64_t wave_stride = (int64_t)gridDim.x * (BLOCK / NMARL_WAVE);
+
+    for (int64_t w = (int64_t)blockIdx.x * (BLOCK / NMARL_WAVE) + wave; w < waves_total; w += wave_stride) {
+        const int64_t gid = w * NMARL_WAVE + lane;      // = e*8 + a
+        const bool valid = gid < n_lanes;
+        const int64_t g = valid ? gid : n_lanes - 1;    // clamp: tail lanes mirror the last vehicle
+        const int64_t e = g >> 3;
+        const int a = (int)(g & 7);
+
+        float h = hs[g], v = vs[g];
+        const int act = action[g];
+        int t = ts[e];
+        bool collided = coll[e] != 0;
+        float v0i = v0_init[e];
+        const bool frozen = collided;                                   // :193
+
+        const float alpha = (act & 1) ? 0.5f : 0.0f;                    // a_map, :275
+        const float beta = (act & 2) ? 0.5f : 0.0f;
+        const float up_v = __shfl_up(v, 1, N);
+        const float v_lead = a == 0 ? lead_speed(p, v0i, t) : up_v;     // :33-37
+        const float u_raw = alpha * (ovm_vh(p, h) - v) + beta * (v_lead - v);   // :385
+        float v_next = v + clampf(u_raw, p.u_min, p.u_max) * p.dt;      // :26
+        v_next = clampf(v_next, 0.0f, p.v_max);                         // :27
+        const float u_c = (v_next - v) / p.dt;                          // :28
+        const float up_vn = __shfl_up(v_next, 1, N);
+        const float v_lead_next = a == 0 ? lead_speed(p, v0i, t + 1) : up_vn;
+        const float h_next = h + (0.5f * p.dt) * (v_lead + v_lead_next - v - v_next);  // :220
+
+        float u_new;
+        if (!frozen) { h = h_next; v = v_next; u_new = u_c; }
+        else { u_new = us[g]; }
+
+        // collision test: min over the platoon (:42)
+        float hmin = h;
+        hmin = fminf(hmin, __shfl_xor(hmin, 1, N));
+        hmin = fminf(hmin, __shfl_xor(hmin, 2, N));
+        hmin = fminf(hmin, __shfl_xor(hmin, 4, N));
+        if (!frozen && hmin < p.h_min) collided = true;
+
+        float r;
+        if (collided) {
+            r = -p.G;                                                   // :44, :194
+        } else {
+            const float dh = h - p.h_star, dv = v - p.v_star;
+            r = -(dh * dh);
+            r = r + (-p.reward_a * (dv * dv));
+            r = r + (-p.reward_b * (u_new * u_new));
+            if (p.train_mode) {
+                const float c = fminf(h - 10.0f, 0.0f);                 // COLLISION_HEADWAY, :10
+                r = r + (-5.0f * (c * c));                              // COLLISION_WT, :9
+            }
+        }
+        float rsum = r;                                                 // np.sum(reward), :229
+        rsum = rsum + __shfl_xor(rsum, 1, N);
+        rsum = rsum + __shfl_xor(rsum, 2, N);
+        rsum = rsum + __shfl_xor(rsum, 4, N);
+
+        t += 1;
+        const bool is_done = (collided && (t % p.batch_size == 0)) || (t == p.T);   // :231-235
+
+        if (valid) {
+            if (p.per_agent_reward) reward[g] = r;
+            if (a == 0) {
+                if (!p.per_agent_reward) reward[e] = rsum;
+                greward[e] = rsum;
+                done[e] = is_done ? 1 : 0;
+            }
+        }
+
+        if (auto_reset && is_done) {
+            const int ep = episode[e];
+            const float U = reset_uniform(seed, env_id_base + e, ep);
+            init_state(p, U, a, h, v, v0i);
+            u_new = 0.0f; t = 0; collided = false;
+            if (valid && a == 0) episode[e] = ep + 1;
+        }
+
+        if (valid) {
+            hs[g] = h; vs[g] = v; us[g] = u_new;
+            if (a == 0) {
+                ts[e] = t;
+                coll[e] = collided ? 1 : 0;
+                if (auto_reset && is_done) v0_init[e] = v0i;
+            }
+        }
+
+        const float up_v2 = __shfl_up(v, 1, N);
+        const float v_lead_obs = a == 0 ? lead_speed(p, v0i, t) : up_v2;   // :55, with the new t
+        const int64_t lanes_here = n_lanes - w * NMARL_WAVE;
+        const int n_valid = lanes_here >= NMARL_WAVE ? NMARL_WAVE : (int)lanes_here;
+        __builtin_amdgcn_wave_barrier();
+        emit_obs(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
+                 obs + w * NMARL_WAVE * NOBS, n_valid);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cacc_reset_kernel(
+    const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ mask,
+    const float* __restrict__ u0, const uint64_t seed, const int64_t env_id_base,
+    int32_t* __restrict__ episode, float* __restrict__ hs, float* __restrict__ vs,
+    float* __restrict__ us, int32_t* __restrict__ ts, uint8_t* __restrict__ coll,
+    float* __restrict__ v0_init, float* __restrict__ obs, float* __restrict__ fp, const int A) {
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * NOBS];
+    const int lane = threadIdx.x & (NMARL_WAVE - 1);
+    const int wave = threadIdx.x / NMARL_WAVE;
+    float* lds_wave = lds + wave * NMARL_WAVE * NOBS;
+    const int64_t n_lanes = E * N;
+    const int64_t waves_total = (n_lanes + NMARL_WAVE - 1) / NMARL_WAVE;
+    const int64_t wave_stride = (int64_t)gridDim.x * (BLOCK / NMARL_WAVE);
+
+    for (int64_t w = (int64_t)blockIdx.x * (BLOCK / NMARL_WAVE) + wave; w < waves_total; w += wave_stride) {
+        const int64_t gid = w * NMARL_WAVE + lane;
+        const bool valid = gid < n_lanes;
+        const int64_t g = valid ? gid : n_lanes - 1;
+        const int64_t e = g >> 3;
+        const int a = (int)(g & 7);
+        const bool sel = mask == nullptr || mask[e] != 0;
+
+        float h = hs[g], v = vs[g], u = us[g], v0i = v0_init[e];
+        int t = ts[e];
+        if (sel) {
+            float U;
+            if (u0 != nullptr) {
+                U = u0[e];
+            } else {
+                const int ep = episode[e];
+                U = reset_uniform(seed, env_id_base + e, ep);
+                if (valid && a == 0) episode[e] = ep + 1;
+            }
+            init_state(p, U, a, h, v, v0i);
+            u = 0.0f; t = 0;
+            if (valid) {
+                hs[g] = h; vs[g] = v; us[g] = 0.0f;
+                if (a == 0) { ts[e] = 0; coll[e] = 0; v0_init[e] = v0i; }
+                if (fp != nullptr) {
+                    const float q = 1.0f / (float)A;                    // :184
+                    for (int k = 0; k < A; ++k) fp[g * A + k] = q;
+                }
+            }
+        }
+        const float up_v = __shfl_up(v, 1, N);
+        const float v_lead = a == 0 ? lead_speed(p, v0i, t) : up_v;
+        const int64_t lanes_here = n_lanes - w * NMARL_WAVE;
+        const int n_valid = lanes_here >= NMARL_WAVE ? NMARL_WAVE : (int)lanes_here;
+        // the slab of a wave is rewritten as a whole; unselected replicas re-emit
+        // their current observation (same values), so no read-modify-write is needed
+        __builtin_amdgcn_wave_barrier();
+        emit_obs(p, h, v, u, v_lead, a, valid, lane, lds_wave, obs + w * NMARL_WAVE * NOBS, n_valid);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+inline int pick_grid(int64_t E, int block) {
+    const int64_t waves = (E * N + NMARL_WAVE - 1) / NMARL_WAVE;
+    const int64_t blocks = (waves + block / NMARL_WAVE - 1) / (block / NMARL_WAVE);
+    const int64_t cap = 256 * 16;  // 256 CUs x 16 resident blocks, grid-stride beyond
+    return (int)(blocks < cap ? blocks : cap);
+}
+
+bool params_ok(const nmarl_cacc_params_t* p) {
+    return p != nullptr && p->T > 0 && p->batch_size > 0 && (p->scenario == 0 || p->scenario == 1) &&
+           p->dt > 0.f && p->h_g > p->h_s && p->u_max != 0.f && p->v_star != 0.f && p->h_star != 0.f;
+}
+
+}  // namespace
+
+extern "C" int nmarl_abi_version(void) { return 1; }
+
+extern "C" int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* action,
+                               float* h, float* v, float* u, int32_t* t, uint8_t* collided,
+                               float* v0_init, float* obs, float* reward, uint8_t* done,
+                               float* global_reward, int32_t auto_reset, uint64_t seed,
+                               int64_t env_id_base, int32_t* episode, void* stream) {
+    if (!params_ok(p) || E < 0 || (E > 0 && (!action || !h || !v || !u || !t || !collided || !v0_init ||
+                                             !obs || !reward || !done || !global_reward)))
+        return NMARL_EINVAL;
+    if (auto_reset && !episode) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // small E is latency bound: 1-wave blocks spread the replicas over more CUs
+    if (E * N <= 256 * 4 * NMARL_WAVE) {
+        hipLaunchKernelGGL(cacc_step_kernel<64>, dim3(pick_grid(E, 64)), dim3(64), 0, s, *p, E, action, h, v, u,
+                           t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
+                           env_id_base, episode);
+    } else {
+        hipLaunchKernelGGL(cacc_step_kernel<256>, dim3(pick_grid(E, 256)), dim3(256), 0, s, *p, E, action, h, v,
+                           u, t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
+                           env_id_base, episode);
+    }
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_cacc_reset(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* mask,
+                                const float* u0, uint64_t seed, int64_t env_id_base, int32_t* episode,
+                                float* h, float* v, float* u, int32_t* t, uint8_t* collided,
+                                float* v0_init, float* obs, float* fp, int32_t A, void* stream) {
+    if (!params_ok(p) || E < 0 || (E > 0 && (!h || !v || !u || !t || !collided || !v0_init || !obs)))
+        return NMARL_EINVAL;
+    if (!u0 && !episode) return NMARL_EINVAL;
+    if (fp && A <= 0) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(cacc_reset_kernel<256>, dim3(pick_grid(E, 256)), dim3(256), 0, s, *p, E, mask, u0, seed,
+                       env_id_base, episode, h, v, u, t, collided, v0_init, obs, fp, A);
+    return nmarl_check_launch();
+}

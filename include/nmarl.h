@@ -1,0 +1,116 @@
+/*
+ * nmarl.h -- C-ABI of libnmarl_hip.so, the MI355X (gfx950) native hot path of
+ * cts198859/deeprl_network: batched multi-agent environment rollout + A2C update.
+ *
+ * The reference is pure Python and has NO FFI / plugin API; its
+ * seam is two Python duck-types.  This header is the boundary a maintainer of
+ * the reference would bind (ctypes stubs in INTEGRATION.md): every entry point
+ * names the reference function (file:line under the reference repo) whose
+ * arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`;
+ *   - the caller owns every buffer; nothing is allocated, no internal threads;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued asynchronously on it (hipGraph-capturable);
+ *   - return value: 0 = ok, NMARL_EINVAL = bad argument, NMARL_EHIP = launch
+ *     failed (hipGetLastError() != hipSuccess); no exception crosses the ABI;
+ *   - E = number of lock-stepped environment replicas, N = agents per replica,
+ *     A = actions per agent, T = n_step, H = LSTM width;
+ *   - all arrays are row-major with the LAST index fastest.
+ */
+#ifndef NMARL_H
+#define NMARL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMARL_OK 0
+#define NMARL_EINVAL (-1)
+#define NMARL_EHIP (-2)
+
+#define NMARL_CACC_N 8        /* vehicles per platoon: one 8-lane group per replica  */
+#define NMARL_CACC_NF 5       /* features per vehicle, cacc_env.py:54-65              */
+#define NMARL_CACC_OBS 15     /* own 5 + two neighbour slots of 5 (zero padded)       */
+
+int nmarl_abi_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* CACC platoon environment -- replaces envs/cacc_env.py                      */
+/* ------------------------------------------------------------------------- */
+
+/* The scalars of CACCEnv._load_config (cacc_env.py:320-343). */
+typedef struct nmarl_cacc_params {
+    float dt;            /* control_interval_sec                                  */
+    float h_min;         /* headway_min     (collision threshold, :42)            */
+    float h_star;        /* headway_target                                        */
+    float h_s;           /* headway_st      (OVM, :360-369)                       */
+    float h_g;           /* headway_go                                            */
+    float v_max;         /* speed_max                                             */
+    float v_star;        /* speed_target                                          */
+    float u_min;         /* accel_min                                             */
+    float u_max;         /* accel_max                                             */
+    float reward_a;      /* reward_v                                              */
+    float reward_b;      /* reward_u                                              */
+    float G;             /* collision_penalty                                     */
+    int32_t T;           /* episode_length_sec / dt (600)                         */
+    int32_t batch_size;  /* ENV_CONFIG batch_size: collision ends the episode only
+                            at a multiple of it (cacc_env.py:231-233)             */
+    int32_t scenario;    /* 0 = catchup (:285-299), 1 = slowdown (:306-318)       */
+    int32_t train_mode;  /* 1: add the soft-collision term (:48-49)               */
+    int32_t per_agent_reward; /* coop_gamma >= 0: reward is [E,N]; else the global
+                            scalar is broadcast, reward is [E] (:236-237)         */
+} nmarl_cacc_params_t;
+
+/*
+ * CACCEnv.reset (cacc_env.py:166-189) + _init_catchup/_init_slowdown (:285-318)
+ * + the first _get_state (:67-79), for the replicas selected by `mask`.
+ *
+ *   mask      [E] u8 or NULL (= all replicas)
+ *   u0        [E] f32 uniforms in [0,1) that stand for the reference's single
+ *             np.random.rand() draw (:294/:314), or NULL: then
+ *             U = Philox4x32-10(key=seed, ctr=(env_id_base+e, 0, episode[e], 0))
+ *             (contract: oracle/philox.py) and episode[e] is post-incremented.
+ *   episode   [E] i32 per-replica episode counter (may be NULL iff u0 != NULL)
+ *   h,v,u     [E,8] f32 headway / speed / constrained acceleration
+ *   t         [E] i32 step in episode; collided [E] u8; v0_init [E] f32 (speed
+ *             of the leading vehicle at t=0; its profile v0s[t] is analytic)
+ *   obs       [E,8,15] f32 gathered observation (see nmarl_cacc_step)
+ *   fp        [E,8,A] f32 fingerprints, set to 1/A (:184) -- may be NULL
+ */
+int nmarl_cacc_reset(const nmarl_cacc_params_t* p, int64_t E,
+                     const uint8_t* mask, const float* u0,
+                     uint64_t seed, int64_t env_id_base, int32_t* episode,
+                     float* h, float* v, float* u, int32_t* t, uint8_t* collided,
+                     float* v0_init, float* obs, float* fp, int32_t A, void* stream);
+
+/*
+ * CACCEnv.step (cacc_env.py:191-242) fused with _get_accel (:31-38),
+ * OVMCarFollowing.get_vh/get_accel (:360-385), _constrain_speed (:24-29),
+ * _get_reward (:40-52) and _get_state/_get_veh_state (:54-79) for E replicas.
+ *
+ *   action    [E,8] u8 in 0..3 -> (alpha,beta) = a_map[action] (:275)
+ *   obs       [E,8,15] f32: slot 0 = own 5 features, slots 1..2 = the
+ *             neighbours' 5 features in ascending vehicle index, zero padded
+ *             (the 'ia2c' concatenation of :70-73 and lstm_comm's xi,
+ *             agents/utils.py:192-193; the 'ma2c' 5-vector is columns 0..4)
+ *   reward    [E] f32 (global scalar) or [E,8] if per_agent_reward
+ *   done      [E] u8;  global_reward [E] f32 (the 4th return value, :229)
+ *   auto_reset != 0: a replica that reports done is re-initialised in the same
+ *             launch exactly as nmarl_cacc_reset(u0 = NULL) would; `obs` then
+ *             holds the first observation of the new episode.  (The reference
+ *             discards next_ob of a finished episode, utils.py:188-190.)
+ */
+int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* action,
+                    float* h, float* v, float* u, int32_t* t, uint8_t* collided,
+                    float* v0_init, float* obs, float* reward, uint8_t* done,
+                    float* global_reward, int32_t auto_reset, uint64_t seed,
+                    int64_t env_id_base, int32_t* episode, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMARL_H */

@@ -44,6 +44,16 @@ SIGNATURES = {
                          _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p],
     'nmarl_cacc_step': [C.POINTER(CaccParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                         _i32, _u64, _i64, _p, _p],
+    'nmarl_nbr_gather_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
+    'nmarl_nbr_gather_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
+    'nmarl_nbr_mean_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
+    'nmarl_nbr_mean_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
+    'nmarl_nbr_onehot': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
+    'nmarl_lstm_cell_fwd': [_i64, _i32, _i32, _p, _p, _i64, _p, _p, _p, _p, _p, _p],
+    'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p],
+    'nmarl_nstep_return': [_i64, _i32, _i32, _p, _p, _p, _p, C.c_double, C.c_double, _p, _p, _p, _p],
+    'nmarl_rmsprop_tf_clip': [_i32, _i64, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p],
 }
 
 for _name, _args in SIGNATURES.items():
@@ -65,13 +75,13 @@ def check(rc, what):
         raise NmarlError('%s failed: %s' % (what, {-1: 'NMARL_EINVAL', -2: 'NMARL_EHIP'}.get(rc, rc)))
 
 
-def ptr(t, dtype=None):
+def ptr(t, dtype=None, strided=False):
     """Device pointer of a contiguous HIP tensor (None -> NULL)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise NmarlError('nmarl ops need HIP device tensors (got %s); there is no CPU path' % t.device)
-    if not t.is_contiguous():
+    if not strided and not t.is_contiguous():
         raise NmarlError('nmarl ops need contiguous tensors')
     if dtype is not None and t.dtype != dtype:
         raise NmarlError('expected dtype %s, got %s' % (dtype, t.dtype))

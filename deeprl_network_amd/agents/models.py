@@ -1,0 +1,441 @@
+"""IA2C / MA2C algorithm classes on MI355X -- the reference's `agents.models` surface
+(models.py:15-309) over a batched, device-resident engine.
+
+Each class keeps the reference's constructor and methods
+    forward / add_transition / backward / reset / save / load
+with the reference's E = 1, NumPy-in / NumPy-out semantics (so the reference's
+Trainer and tests drive it unchanged), and adds the batched API the MI355X
+Trainer uses for E >> 1 replicas with everything resident in HBM:
+    act()  record()  bootstrap()  update()  reset_states()
+
+Engine (per n_step batch, E replicas, N agents):
+  rollout   2 recurrent steps per lock-step, reproducing the reference's quirk Q1
+            (utils.py:129-151 + policies.py:119-134: `forward('v')` re-steps the LSTM
+            from the state `forward('p')` just wrote);
+  buffers   [T,...] device tensors replacing OnPolicyBuffer's Python lists
+            (agents/utils.py:722-761, 819-835);
+  update    nmarl_nstep_return -> autograd unroll -> A2C loss (policies.py:20-30,
+            232-255; means over T*E, sum over agents) -> [RCCL all-reduce] ->
+            nmarl_rmsprop_tf_clip (policies.py:32-39).
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+
+from .. import ops
+from .policies import FPPolicy, IC3MultiAgentPolicy, LstmPolicy, NCMultiAgentPolicy
+from .utils import Scheduler
+
+F32 = torch.float32
+
+
+class IA2C:
+    """Independent A2C with per-agent optimisers (models.py:15-158)."""
+
+    policy_cls = LstmPolicy
+    per_agent_optimizer = True       # IA2C: one RMSProp + one clip norm per agent (models.py:148-152)
+    uses_fingerprint = False         # forward() receives neighbour policies `ps` (MA2C family)
+
+    def __init__(self, n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, model_config,
+                 seed=0, num_envs=1, device='cuda', dist_group=None, n_feat=None):
+        self.name = getattr(self, 'name', 'ia2c')
+        self._init_algo(n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, seed,
+                        model_config, num_envs, device, dist_group, n_feat)
+
+    # ------------------------------------------------------------------ construction
+    def _init_algo(self, n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, seed,
+                   model_config, num_envs, device, dist_group, n_feat):
+        if max(n_a_ls) != min(n_a_ls):
+            raise NotImplementedError('heterogeneous action spaces (Monaco net) are out of scope: SURVEY.md 8f.4')
+        self.n_s_ls, self.n_a_ls = list(n_s_ls), list(n_a_ls)
+        self.n_a = n_a_ls[0]
+        self.neighbor_mask = np.asarray(neighbor_mask)
+        self.distance_mask = np.asarray(distance_mask)
+        self.n_agent = len(self.neighbor_mask)
+        self.identical_agent = True
+        self.coop_gamma = float(coop_gamma)
+        self.reward_clip = model_config.getfloat('reward_clip')
+        self.reward_norm = model_config.getfloat('reward_norm')
+        self.n_step = model_config.getint('batch_size')
+        self.n_fc = model_config.getint('num_fc')
+        self.n_lstm = model_config.getint('num_lstm')
+        self.E = int(num_envs)
+        self.device = torch.device(device)
+        self.dist_group = dist_group
+        self.seed = seed
+        m = self.neighbor_mask.sum(axis=1)
+        if n_feat is None:
+            # MA2C envs report the own-feature width; IA2C envs report n_feat*(1+m_i)
+            n_feat = self.n_s_ls[0] if self._is_ma2c() else self.n_s_ls[0] // (1 + int(m[0]))
+        self.n_feat = int(n_feat)
+        self.policy = self.policy_cls(self.n_feat, self.n_a, self.neighbor_mask, n_fc=self.n_fc,
+                                      n_h=self.n_lstm, device=self.device)
+        self.policy.params.init_reference_order()       # consumes np.random like the reference's ortho_init
+        self.n_s = self.n_s_ls[0]
+        N, E, H, T = self.n_agent, self.E, self.n_lstm, self.n_step
+        d = self.device
+        z = lambda *s: torch.zeros(*s, dtype=F32, device=d)      # noqa: E731
+        self.h_fw, self.c_fw, self.h_bw, self.c_bw = z(N, E, H), z(N, E, H), z(N, E, H), z(N, E, H)
+        self.fp = torch.full((N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
+        self.pi_last = torch.zeros(N, E, self.n_a, dtype=F32, device=d)
+        self.total_step = total_step
+        self.sess = None                                  # the reference Trainer reads model.sess (TF leak)
+        if total_step:
+            self._init_train(model_config, self.distance_mask, coop_gamma)
+
+    def _is_ma2c(self):
+        return self.name.startswith('ma2c')
+
+    def _init_scheduler(self, model_config):
+        lr_init = model_config.getfloat('lr_init')
+        lr_decay = model_config.get('lr_decay')
+        if lr_decay == 'constant':
+            self.lr_scheduler = Scheduler(lr_init, decay=lr_decay)
+        else:
+            self.lr_scheduler = Scheduler(lr_init, model_config.getfloat('lr_min'), self.total_step, decay=lr_decay)
+
+    def _init_train(self, model_config, distance_mask, coop_gamma):
+        self._init_scheduler(model_config)
+        self.v_coef = model_config.getfloat('value_coef')
+        self.e_coef = model_config.getfloat('entropy_coef')
+        self.max_grad_norm = model_config.getfloat('max_grad_norm')
+        self.rmsp_alpha = model_config.getfloat('rmsp_alpha')
+        self.rmsp_epsilon = model_config.getfloat('rmsp_epsilon')
+        self.gamma = model_config.getfloat('gamma')
+        N, E, T, d = self.n_agent, self.E, self.n_step, self.device
+        p = self.policy
+        self.buf_x = torch.zeros(T, E, N, p.n_obs, dtype=F32, device=d)
+        self.buf_fp = torch.zeros(N, T, E, self.n_a, dtype=F32, device=d)
+        self.buf_na = torch.zeros(N, T, E, p.n_na, dtype=F32, device=d)
+        self.buf_act = torch.zeros(T, E, N, dtype=torch.uint8, device=d)
+        self.buf_v = torch.zeros(T, N, E, dtype=F32, device=d)
+        self.buf_done_pre = torch.zeros(T, E, dtype=F32, device=d)
+        self.buf_done_post = torch.zeros(T, E, dtype=torch.uint8, device=d)
+        spatial = self.coop_gamma >= 0
+        self.buf_r = torch.zeros((T, E, N) if spatial else (T, E), dtype=F32, device=d)
+        self.R = torch.zeros(N, T, E, dtype=F32, device=d)
+        self.Adv = torch.zeros(N, T, E, dtype=F32, device=d)
+        self.dist_dev = torch.from_numpy(self.distance_mask.astype(np.int32)).to(d)
+        self.t = 0
+        self.grad_norm = torch.zeros(N, dtype=F32, device=d)
+        self.last_loss = None
+
+    # ------------------------------------------------------------------ batched engine
+    def reset_states(self, mask=None):
+        """Policy._reset (policies.py:151-154, 334-336) for all replicas or those with mask != 0;
+        also restores the uniform fingerprint of a fresh episode (cacc_env.py:184)."""
+        if mask is None:
+            for s in (self.h_fw, self.c_fw, self.h_bw, self.c_bw):
+                s.zero_()
+            self.fp.fill_(1.0 / self.n_a)
+        else:
+            keep = (mask == 0).to(F32).view(1, -1, 1)
+            for s in (self.h_fw, self.c_fw, self.h_bw, self.c_bw):
+                s.mul_(keep)
+            self.fp.mul_(keep).add_((1.0 - keep) / self.n_a)
+
+    def _policy_step(self, obs, done):
+        """forward('p'): advances states_fw (policies.py:119-134)."""
+        self.h_fw, self.c_fw = self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done)
+        with torch.no_grad():
+            return self.policy.pi(self.h_fw)
+
+    def _value_step(self, obs, done, na_onehot):
+        """forward('v'): re-steps the LSTM from the state forward('p') wrote (quirk Q1),
+        without storing the result (policies.py:124-133)."""
+        h2, _ = self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done)
+        with torch.no_grad():
+            return self.policy.value(h2, na_onehot)
+
+    def act(self, obs, done, action_out, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0,
+            store=True):
+        """One lock-step decision for all replicas: pi, action draw, value; optionally stores the
+        transition inputs at buffer slot t.  obs [E,N,n_obs] f32, done [E] f32 (pre-step)."""
+        t = self.t
+        pi = self._policy_step(obs, done)
+        ops.sample_actions(pi, action_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step)
+        if store:
+            na = ops.nbr_onehot(action_out, self.policy.nbr_idx, self.n_a, out=self.buf_na[:, t])
+            v = self._value_step(obs, done, na)
+            self.buf_x[t].copy_(obs)
+            self.buf_fp[:, t].copy_(self.fp)
+            self.buf_act[t].copy_(action_out)
+            self.buf_v[t].copy_(v)
+            self.buf_done_pre[t].copy_(done)
+        self.fp = pi                                       # env.update_fingerprint(policy), utils.py:173
+        return pi
+
+    def record(self, reward, done_post):
+        """model.add_transition's reward path (models.py:26-32): normalise, clip, store."""
+        t = self.t
+        r = reward
+        if self.reward_norm > 0:
+            r = r / self.reward_norm
+        if self.reward_clip > 0:
+            r = torch.clamp(r, -self.reward_clip, self.reward_clip)
+        self.buf_r[t].copy_(r)
+        self.buf_done_post[t].copy_(done_post)
+        self.t = t + 1
+
+    def bootstrap(self, obs, done, action_scratch, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0,
+                  step=0):
+        """R for the unfinished replicas (utils.py:192-196): one more policy step (which advances
+        states_fw -- quirk Q2) and the double-stepped value; 0 where the episode just ended."""
+        pi = self._policy_step(obs, done)
+        ops.sample_actions(pi, action_scratch, mode, u=u, seed=seed, env_id_base=env_id_base, step=step)
+        na = ops.nbr_onehot(action_scratch, self.policy.nbr_idx, self.n_a)
+        return self._value_step(obs, done, na)
+
+    def _loss(self, Hs):
+        """policies.py:20-30 / 232-255 with the batch mean taken over T*E."""
+        N, T, E = self.n_agent, self.n_step, self.E
+        p = self.policy
+        pi = p.pi(Hs)                                                        # [N, T*E, A]
+        v = p.value(Hs, self.buf_na.view(N, T * E, p.n_na))                  # [N, T*E]
+        acts = self.buf_act.view(T * E, N).t().long().unsqueeze(-1)          # [N, T*E, 1]
+        log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
+        entropy = -(pi * log_pi).sum(-1)
+        logp_a = log_pi.gather(-1, acts).squeeze(-1)
+        adv = self.Adv.view(N, T * E)
+        R = self.R.view(N, T * E)
+        policy_loss = -(logp_a * adv).mean(-1)                               # [N]
+        value_loss = (R - v).pow(2).mean(-1) * 0.5 * self.v_coef
+        entropy_loss = -entropy.mean(-1) * self.e_coef
+        per_agent = policy_loss + value_loss + entropy_loss
+        self.last_loss = (policy_loss.detach(), value_loss.detach(), entropy_loss.detach(), per_agent.detach())
+        return per_agent.sum()
+
+    def update(self, R_end):
+        """model.backward (models.py:34-42 / 211-215) for all replicas: R_end [N,E]."""
+        assert self.t == self.n_step, 'update() needs a full n_step batch (got %d)' % self.t
+        cur_lr = self.lr_scheduler.get(self.n_step)
+        alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
+        ops.nstep_return(self.buf_r, self.buf_v, self.buf_done_post, R_end.contiguous(), self.gamma, alpha,
+                         self.dist_dev, self.R, self.Adv)
+        ps = self.policy.params
+        ps.grad.zero_()
+        Hs = self.policy.unroll(self.buf_x, self.buf_fp, self.buf_done_pre, self.h_bw, self.c_bw)
+        loss = self._loss(Hs)
+        loss.backward()
+        scale = 1.0
+        if self.dist_group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(ps.grad, group=self.dist_group)          # ONE flat RCCL all-reduce over xGMI
+            scale = 1.0 / dist.get_world_size(self.dist_group)
+        if self.per_agent_optimizer:
+            ops.rmsprop_tf_clip(ps.flat, ps.grad, ps.ms, ps.scratch, cur_lr, self.rmsp_alpha, self.rmsp_epsilon,
+                                self.max_grad_norm, scale, self.grad_norm)
+        else:
+            n = self.n_agent * ps.P
+            ops.rmsprop_tf_clip(ps.flat.view(1, n), ps.grad.view(1, n), ps.ms.view(1, n), ps.scratch, cur_lr,
+                                self.rmsp_alpha, self.rmsp_epsilon, self.max_grad_norm, scale, self.grad_norm)
+        # states_bw <- states_fw (policies.py:115, 211)
+        self.h_bw.copy_(self.h_fw)
+        self.c_bw.copy_(self.c_fw)
+        self.t = 0
+        self.cur_lr = cur_lr
+
+    # ------------------------------------------------------------------ reference API (E = 1)
+    def _obs_to_slab(self, obs):
+        """list of N 1-D arrays (reference env) -> [1,N,n_obs] slab (+ fingerprints for ia2c_fp)."""
+        p = self.policy
+        F = self.n_feat
+        slab = np.zeros((1, self.n_agent, p.n_obs), dtype=np.float32)
+        fp = None
+        for i in range(self.n_agent):
+            o = np.asarray(obs[i], dtype=np.float32)
+            w = F * (1 + p.nbr_cnt[i]) if not self._is_ma2c() else F
+            slab[0, i, :w] = o[:w]
+        slab = torch.from_numpy(slab).to(self.device)
+        if self._is_ma2c():
+            # MA2C envs hand over the own features only; neighbours are gathered here
+            x = slab[:, :, :F].transpose(0, 1).contiguous()                   # [N,1,F]
+            slab = torch.cat([x, ops.nbr_gather(x, p.nbr_idx)], dim=-1).transpose(0, 1).contiguous()
+        elif self.uses_fingerprint_obs():
+            fp = np.zeros((self.n_agent, 1, p.n_na), dtype=np.float32)
+            for i in range(self.n_agent):
+                w = F * (1 + p.nbr_cnt[i])
+                tail = np.asarray(obs[i], dtype=np.float32)[w:]
+                fp[i, 0, :len(tail)] = tail
+        return slab, fp
+
+    def uses_fingerprint_obs(self):
+        return False
+
+    def _done_t(self, done):
+        return torch.full((self.E,), float(bool(done)), dtype=F32, device=self.device)
+
+    def _na_onehot_from_list(self, nactions):
+        p = self.policy
+        na = np.zeros((self.n_agent, 1, p.n_na), dtype=np.float32)
+        for i in range(self.n_agent):
+            for k, a in enumerate(np.asarray(nactions[i]).reshape(-1)):
+                na[i, 0, k * self.n_a + int(a)] = 1.0
+        return torch.from_numpy(na).to(self.device)
+
+    def forward(self, obs, done, nactions=None, out_type='p'):
+        """IA2C.forward (models.py:44-51): list of N pi arrays ('p') or N scalars ('v')."""
+        slab, _ = self._obs_to_slab(obs)
+        self._cur_slab = slab
+        d = self._done_t(done)
+        if out_type.startswith('p'):
+            pi = self._policy_step(slab, d)
+            return [x for x in pi[:, 0].cpu().numpy()]
+        v = self._value_step(slab, d, self._na_onehot_from_list(nactions))
+        return [x for x in v[:, 0].cpu().numpy()]
+
+    def add_transition(self, ob, naction, action, reward, value, done):
+        """models.py:26-32 -> device buffers (slot t)."""
+        t = self.t
+        slab, fp = self._obs_to_slab(ob)
+        self.buf_x[t].copy_(slab)
+        self.buf_na[:, t].copy_(self._na_onehot_from_list(naction))
+        self.buf_act[t].copy_(torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)))
+        self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))
+        self.buf_done_pre[t].fill_(float(self._prev_done))
+        self._prev_done = bool(done)
+        r = torch.as_tensor(np.asarray(reward, dtype=np.float32)).to(self.device)
+        self.record(r.view(self.buf_r[t].shape), torch.full((self.E,), int(bool(done)), dtype=torch.uint8,
+                                                           device=self.device))
+
+    def backward(self, Rends, dt=0, summary_writer=None, global_step=None):
+        R_end = torch.as_tensor(np.asarray(Rends, dtype=np.float32).reshape(self.n_agent, 1)).to(self.device)
+        self.update(R_end)
+
+    def reset(self):
+        self.reset_states()
+        self._prev_done = True          # OnPolicyBuffer keeps the done BEFORE each step (agents/utils.py:732-739)
+
+    _prev_done = True
+
+    # ------------------------------------------------------------------ checkpoints (models.py:53-82)
+    def save(self, model_dir, global_step):
+        path = model_dir + 'checkpoint-%d.pt' % int(global_step)
+        ps = self.policy.params
+        torch.save({'variables': dict(ps.ref_variables()), 'rmsprop_ms': ps.ms.cpu(), 'name': self.name,
+                    'global_step': int(global_step), 'lr_n': getattr(self, 'lr_scheduler', None) and self.lr_scheduler.n},
+                   path)
+        # keep the 5 newest, like tf.train.Saver(max_to_keep=5)
+        found = sorted(self._list_checkpoints(model_dir))
+        for step, f in found[:-5]:
+            os.remove(os.path.join(model_dir, f))
+
+    @staticmethod
+    def _list_checkpoints(model_dir):
+        out = []
+        for f in os.listdir(model_dir):
+            if f.startswith('checkpoint'):
+                tokens = f.split('.')[0].split('-')
+                if len(tokens) == 2 and tokens[1].isdigit():
+                    out.append((int(tokens[1]), f))
+        return out
+
+    def load(self, model_dir, checkpoint=None):
+        save_file = None
+        if os.path.exists(model_dir):
+            if checkpoint is None:
+                found = sorted(self._list_checkpoints(model_dir))
+                if found:
+                    save_file = found[-1][1]
+            else:
+                save_file = 'checkpoint-%d.pt' % int(checkpoint)
+        if save_file is not None:
+            blob = torch.load(os.path.join(model_dir, save_file), weights_only=False)
+            self.policy.params.load_ref_variables(blob['variables'])
+            if 'rmsprop_ms' in blob:
+                self.policy.params.ms.copy_(blob['rmsprop_ms'])
+            logging.info('Checkpoint loaded: %s' % save_file)
+            return True
+        logging.error('Can not find old checkpoint for %s' % model_dir)
+        return False
+
+
+class IA2C_FP(IA2C):
+    """Fingerprint IA2C (models.py:161-188): neighbour policies appended to the observation."""
+    policy_cls = FPPolicy
+    name = 'ia2c_fp'
+
+    def uses_fingerprint_obs(self):
+        return True
+
+    def forward(self, obs, done, nactions=None, out_type='p'):
+        # the reference env delivers the neighbours' fingerprints inside `obs`; scatter them back
+        # into the per-agent fingerprint table the batched policy gathers from
+        _, fpg = self._obs_to_slab(obs)
+        self.fp = self._ungather_fp(fpg)
+        return super().forward(obs, done, nactions, out_type)
+
+    def _ungather_fp(self, fpg):
+        """[N,1,m_max*A] gathered neighbour fingerprints -> [N,1,A] table (every agent's
+        fingerprint appears in at least one neighbour's slot)."""
+        p = self.policy
+        tab = np.full((self.n_agent, 1, self.n_a), 1.0 / self.n_a, dtype=np.float32)
+        idx = p.nbr_idx.cpu().numpy()
+        for i in range(self.n_agent):
+            for k in range(p.m_max):
+                j = idx[i, k]
+                if j >= 0:
+                    tab[j, 0] = fpg[i, 0, k * self.n_a:(k + 1) * self.n_a]
+        return torch.from_numpy(tab).to(self.device)
+
+    def add_transition(self, ob, naction, action, reward, value, done):
+        _, fpg = self._obs_to_slab(ob)
+        self.buf_fp[:, self.t].copy_(self._ungather_fp(fpg))
+        super().add_transition(ob, naction, action, reward, value, done)
+
+
+class MA2C_NC(IA2C):
+    """NeurComm (models.py:191-258): one optimiser over the whole meta-DNN."""
+    policy_cls = NCMultiAgentPolicy
+    per_agent_optimizer = False
+    name = 'ma2c_nc'
+
+    def forward(self, obs, done, ps, actions=None, out_type='p'):
+        """MA2C_NC.forward (models.py:217-224): [N,A] ('p') or [N] ('v')."""
+        slab, _ = self._obs_to_slab(obs)
+        self.fp = torch.as_tensor(np.asarray(ps, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)).to(self.device)
+        d = self._done_t(done)
+        if out_type.startswith('p'):
+            return self._policy_step(slab, d)[:, 0].cpu().numpy()
+        a = torch.as_tensor(np.asarray(actions, dtype=np.uint8).reshape(1, -1)).to(self.device)
+        na = ops.nbr_onehot(a, self.policy.nbr_idx, self.n_a)
+        return self._value_step(slab, d, na)[:, 0].cpu().numpy()
+
+    def add_transition(self, ob, p, action, reward, value, done):
+        t = self.t
+        slab, _ = self._obs_to_slab(ob)
+        self.buf_x[t].copy_(slab)
+        self.buf_fp[:, t].copy_(torch.as_tensor(np.asarray(p, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
+        a = torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)).to(self.device)
+        ops.nbr_onehot(a, self.policy.nbr_idx, self.n_a, out=self.buf_na[:, t])
+        self.buf_act[t].copy_(a)
+        self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))
+        self.buf_done_pre[t].fill_(float(self._prev_done))
+        self._prev_done = bool(done)
+        r = torch.as_tensor(np.asarray(reward, dtype=np.float32)).to(self.device)
+        self.record(r.view(self.buf_r[t].shape), torch.full((self.E,), int(bool(done)), dtype=torch.uint8,
+                                                           device=self.device))
+
+
+class MA2C_IC3(MA2C_NC):
+    """CommNet (models.py:278-292)."""
+    policy_cls = IC3MultiAgentPolicy
+    name = 'ma2c_ic3'
+
+
+class IA2C_CU(MA2C_NC):
+    """ConseNet (models.py:261-275) -- SURVEY.md 8f.1 'next', not built in this round."""
+    name = 'ma2c_cu'
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError('IA2C_CU / ConsensusPolicy is scheduled after the hot path (SURVEY.md 8f.1)')
+
+
+class MA2C_DIAL(MA2C_NC):
+    """DIAL (models.py:295-309) -- SURVEY.md 8f.1 'next', not built in this round."""
+    name = 'ma2c_dial'
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError('MA2C_DIAL is scheduled after the hot path (SURVEY.md 8f.1)')

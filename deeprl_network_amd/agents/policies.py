@@ -1,0 +1,326 @@
+"""Batched per-agent LSTM policies on MI355X (PyTorch-ROCm GEMMs + the HIP ops of
+csrc/nbr.hip and csrc/a2c.hip), mirroring the reference's agents/policies.py.
+
+Reference -> here (all agents evaluated at once, E replicas at once):
+  LstmPolicy          policies.py:80-154   + fc/lstm      agents/utils.py:65-115
+  FPPolicy            policies.py:157-185
+  NCMultiAgentPolicy  policies.py:188-336  + lstm_comm    agents/utils.py:118-217
+  IC3MultiAgentPolicy policies.py:429-476  + lstm_ic3     agents/utils.py:344-417
+  heads               policies.py:50-77
+
+Layout.  Every agent owns its own weights (nothing is shared), so each layer is
+ONE batched GEMM with batch = agent: activations are agent-major [N, E, F]
+(rollout) / [N, T*E, F] (update), weights [N, F_in, F_out].  Agents with fewer
+neighbours than m_max are zero padded: their inputs for the missing slots are
+exactly 0, hence so are the gradients of the padded weight rows, which start at 0
+and stay 0 -- the padded network is numerically the reference's ragged one.
+
+All parameters of all agents live in ONE flat fp32 buffer [N, P] (`ParamStore`):
+row i holds agent i's parameters, every tensor is a strided view.  The gradient
+and the RMSProp slot use the same layout, so clip + RMSProp is one fused kernel
+and the data-parallel exchange is one RCCL all-reduce of the gradient buffer.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+F32 = torch.float32
+
+
+def ortho_init(shape, scale=np.sqrt(2)):
+    """agents/utils.py:10-23 -- draws from the GLOBAL np.random stream, like the reference."""
+    a = np.random.standard_normal(shape)
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == tuple(shape) else v
+    return (scale * q.reshape(shape)).astype(np.float32)
+
+
+class ParamStore:
+    """Flat [N, P] parameter / gradient / RMSProp-slot buffers with named strided views.
+
+    spec: list of phases; a phase is a list of (key, ref_name_fmt, padded_shape, ref_rows_fn)
+    created agent by agent -- the order in which the reference's tf.get_variable calls
+    consume np.random (SURVEY.md 8a footnote "Init draw order")."""
+
+    def __init__(self, n_agent, phases, device):
+        self.N = n_agent
+        self.phases = phases
+        self.device = device
+        self.index = {}
+        off = 0
+        for phase in phases:
+            for key, fmt, shape, rows_fn in phase:
+                size = int(np.prod(shape))
+                self.index[key] = (off, size, tuple(shape), fmt, rows_fn)
+                off += size
+        self.P = off
+        self.flat = torch.zeros(n_agent, self.P, dtype=F32, device=device)
+        self.grad = torch.zeros_like(self.flat)
+        self.ms = torch.ones_like(self.flat)            # TF RMSProp slot starts at 1
+        self.scratch = torch.zeros(n_agent, 64, dtype=F32, device=device)
+        self.views = {}
+        for key, (o, size, shape, _, _) in self.index.items():
+            w = self.flat[:, o:o + size].view(n_agent, *shape)
+            w.requires_grad_(True)
+            w.grad = self.grad[:, o:o + size].view(n_agent, *shape)
+            self.views[key] = w
+
+    def __getitem__(self, key):
+        return self.views[key]
+
+    def init_reference_order(self):
+        """Initialise like the reference: weights `w*` = sqrt(2)-orthogonal drawn in
+        variable-creation order from np.random, biases 0 (agents/utils.py:69-71, 95-99, 141-162)."""
+        host = np.zeros((self.N, self.P), dtype=np.float32)
+        for phase in self.phases:
+            for i in range(self.N):
+                for key, fmt, shape, rows_fn in phase:
+                    if key.endswith('_b'):
+                        continue
+                    o, size, _, _, _ = self.index[key]
+                    rows = rows_fn(i) if rows_fn else shape[0]
+                    blk = np.zeros(shape, dtype=np.float32)
+                    blk[:rows] = ortho_init((rows,) + tuple(shape[1:]))
+                    host[i, o:o + size] = blk.ravel()
+        with torch.no_grad():
+            self.flat.copy_(torch.from_numpy(host))
+        self.ms.fill_(1.0)
+        self.grad.zero_()
+
+    # ---- reference-named export / import (checkpoint + parity tests)
+    def ref_variables(self):
+        """[(reference variable name, np.ndarray with the reference's ragged shape)] in creation order."""
+        host = self.flat.detach().cpu().numpy()
+        out = []
+        for phase in self.phases:
+            for i in range(self.N):
+                for key, fmt, shape, rows_fn in phase:
+                    o, size, _, _, _ = self.index[key]
+                    rows = rows_fn(i) if rows_fn else shape[0]
+                    a = host[i, o:o + size].reshape(shape)[:rows]
+                    out.append((fmt % i, a.copy()))
+        return out
+
+    def load_ref_variables(self, named):
+        named = dict(named)
+        host = self.flat.detach().cpu().numpy().copy()
+        for phase in self.phases:
+            for i in range(self.N):
+                for key, fmt, shape, rows_fn in phase:
+                    o, size, _, _, _ = self.index[key]
+                    rows = rows_fn(i) if rows_fn else shape[0]
+                    blk = np.zeros(shape, dtype=np.float32)
+                    blk[:rows] = named[fmt % i]
+                    host[i, o:o + size] = blk.ravel()
+        with torch.no_grad():
+            self.flat.copy_(torch.from_numpy(host))
+
+
+class BatchedPolicy:
+    """Common part: heads, rollout step (Q1 double step handled by the caller), unroll."""
+
+    name = 'policy'
+
+    def __init__(self, n_feat, n_a, neighbor_mask, n_fc=64, n_h=64, device='cuda'):
+        self.device = torch.device(device)
+        self.nbr_idx, self.nbr_cnt = ops.neighbor_table(neighbor_mask, self.device)
+        self.N = len(self.nbr_cnt)
+        self.m_max = self.nbr_idx.shape[1]
+        self.n_feat, self.n_a, self.n_fc, self.n_h = n_feat, n_a, n_fc, n_h
+        self.n_obs = n_feat * (1 + self.m_max)          # gathered observation slab width
+        self.n_na = n_a * self.m_max                    # neighbour one-hot width
+        self.params = ParamStore(self.N, self._phases(), self.device)
+
+    # -- helpers for the ragged reference shapes
+    def _m(self, i):
+        return self.nbr_cnt[i]
+
+    def _head_phase(self, pi_fmt, v_fmt):
+        H, A = self.n_h, self.n_a
+        return [('pi_w', pi_fmt + '/w', (H, A), None), ('pi_b', pi_fmt + '/b', (A,), None),
+                ('v_w', v_fmt + '/w', (H + self.n_na, 1), lambda i: H + A * self._m(i)),
+                ('v_b', v_fmt + '/b', (1,), None)]
+
+    # -- heads: policies.py:50-77
+    def pi(self, h):
+        p = self.params
+        return torch.softmax(torch.baddbmm(p['pi_b'].unsqueeze(1), h, p['pi_w']), dim=-1)
+
+    def value(self, h, na_onehot):
+        p = self.params
+        H = self.n_h
+        v = torch.baddbmm(p['v_b'].unsqueeze(1), h, p['v_w'][:, :H])
+        v = torch.baddbmm(v, na_onehot, p['v_w'][:, H:])
+        return v.squeeze(-1)
+
+    # -- one recurrent step for the rollout (no autograd)
+    def step(self, x, fp_prev, h, c, done):
+        """x [E,N,n_obs] env-major slab (or any view with that shape), fp_prev [N,E,A] the
+        previous-step policies, (h, c) [N,E,H], done [E] f32 -> (h', c')."""
+        with torch.no_grad():
+            zx, h_src = self._pre(x.transpose(0, 1), fp_prev, h)
+            keep = (1.0 - done).view(1, -1, 1)
+            z = torch.baddbmm(zx, h * keep, self.params[self.k_wh])
+            c_new = torch.empty_like(c)
+            h_new = torch.empty_like(h)
+            ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_new, h_new)
+        return h_new, c_new
+
+    # -- n_step unroll for the update (autograd)
+    def unroll(self, X, FP, done, h0, c0):
+        """X [T,E,N,n_obs] env-major, FP [N,T,E,A] previous-step policies, done [T,E] f32
+        (pre-step), (h0, c0) [N,E,H] -> Hs [N,T*E,H]."""
+        T, E = done.shape
+        Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)       # [N, T*E, n_obs], no copy
+        pre = self._pre_all(Xv, FP, T, E)
+        h, c = h0, c0
+        hs = []
+        wh, b = self.params[self.k_wh], self.params[self.k_b]
+        for t in range(T):
+            zx = self._pre_t(pre, t, E, h)
+            keep = (1.0 - done[t]).view(1, -1, 1)
+            z = torch.baddbmm(zx, h * keep, wh)
+            h, c = ops.lstm_cell(z, b, c, done[t])
+            hs.append(h)
+        return torch.stack(hs, dim=1).reshape(self.N, T * E, self.n_h)
+
+
+class LstmPolicy(BatchedPolicy):
+    """IA2C: fc(n_s -> n_fc, relu) -> LSTM -> heads (policies.py:136-149)."""
+    name = 'lstm'
+    k_wh, k_b = 'lstm_wh', 'lstm_b'
+
+    def _phases(self):
+        nf, H, F = self.n_fc, self.n_h, self.n_feat
+        return [[('fc_w', 'lstm_%d/fc/w', (self.n_obs, nf), lambda i: F * (1 + self._m(i))),
+                 ('fc_b', 'lstm_%d/fc/b', (nf,), None),
+                 ('lstm_wx', 'lstm_%d/lstm/wx', (nf, 4 * H), None),
+                 ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
+                 ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
+
+    def _encode(self, xv, fpv):
+        p = self.params
+        return torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), xv, p['fc_w']))
+
+    def _pre(self, xv, fp_prev, h):
+        return torch.bmm(self._encode(xv, None), self.params['lstm_wx']), None
+
+    def _pre_all(self, Xv, FP, T, E):
+        return torch.bmm(self._encode(Xv, None), self.params['lstm_wx'])
+
+    def _pre_t(self, pre, t, E, h):
+        return pre[:, t * E:(t + 1) * E]
+
+
+class FPPolicy(LstmPolicy):
+    """IA2C_FP: fcs(obs) || fcp(neighbour fingerprints) -> LSTM(2 n_fc) (policies.py:163-185)."""
+
+    def _phases(self):
+        nf, H, F, A = self.n_fc, self.n_h, self.n_feat, self.n_a
+        return [[('fcs_w', 'lstm_%d/fcs/w', (self.n_obs, nf), lambda i: F * (1 + self._m(i))),
+                 ('fcs_b', 'lstm_%d/fcs/b', (nf,), None),
+                 ('fcp_w', 'lstm_%d/fcp/w', (self.n_na, nf), lambda i: A * self._m(i)),
+                 ('fcp_b', 'lstm_%d/fcp/b', (nf,), None),
+                 ('lstm_wx', 'lstm_%d/lstm/wx', (2 * nf, 4 * H), None),
+                 ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
+                 ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
+
+    def _zx(self, xv, pf):
+        p = self.params
+        nf = self.n_fc
+        hx = torch.relu(torch.baddbmm(p['fcs_b'].unsqueeze(1), xv, p['fcs_w']))
+        hp = torch.relu(torch.baddbmm(p['fcp_b'].unsqueeze(1), pf, p['fcp_w']))
+        # [hx, hp] @ wx  ==  hx @ wx[:nf] + hp @ wx[nf:]   (no concat buffer)
+        return torch.baddbmm(torch.bmm(hx, p['lstm_wx'][:, :nf]), hp, p['lstm_wx'][:, nf:])
+
+    def _pre(self, xv, fp_prev, h):
+        return self._zx(xv, ops.nbr_gather(fp_prev, self.nbr_idx)), None
+
+    def _pre_all(self, Xv, FP, T, E):
+        pf = ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx)
+        return self._zx(Xv, pf)
+
+
+class NCMultiAgentPolicy(BatchedPolicy):
+    """NeurComm: s = [relu(x~ W_ob), relu(p~ W_fp), relu(m~ W_msg)] -> LSTM(3H) (agents/utils.py:182-208).
+    m~ = neighbours' previous h, NOT done-masked (Q3: agents/utils.py:182-183)."""
+    name = 'nc'
+    k_wh, k_b = 'wh_hid', 'hid_b'
+    scope = 'nc/lstm_comm_%d'
+
+    def _phases(self):
+        H, F, A = self.n_h, self.n_feat, self.n_a
+        s = self.scope
+        return [[('w_msg', s + '/w_msg', (H * self.m_max, H), lambda i: H * self._m(i)),
+                 ('w_msg_b', s + '/b_msg', (H,), None),
+                 ('w_ob', s + '/w_ob', (self.n_obs, H), lambda i: F * (1 + self._m(i))),
+                 ('w_ob_b', s + '/b_ob', (H,), None),
+                 ('w_fp', s + '/w_fp', (self.n_na, H), lambda i: A * self._m(i)),
+                 ('w_fp_b', s + '/b_fp', (H,), None),
+                 ('wx_hid', s + '/wx_hid', (3 * H, 4 * H), None),
+                 ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
+                 ('hid_b', s + '/b_hid', (4 * H,), None)],
+                self._head_phase(self.name + '/pi_%d', self.name + '/v_%d')]
+
+    def _zxp(self, xv, pf):
+        p = self.params
+        H = self.n_h
+        hx = torch.relu(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob']))
+        hp = torch.relu(torch.baddbmm(p['w_fp_b'].unsqueeze(1), pf, p['w_fp']))
+        return torch.baddbmm(torch.bmm(hx, p['wx_hid'][:, :H]), hp, p['wx_hid'][:, H:2 * H])
+
+    def _msg(self, zxp, h):
+        p = self.params
+        H = self.n_h
+        m = ops.nbr_gather(h, self.nbr_idx)                                   # un-masked previous h
+        hm = torch.relu(torch.baddbmm(p['w_msg_b'].unsqueeze(1), m, p['w_msg']))
+        return torch.baddbmm(zxp, hm, p['wx_hid'][:, 2 * H:])
+
+    def _pre(self, xv, fp_prev, h):
+        return self._msg(self._zxp(xv, ops.nbr_gather(fp_prev, self.nbr_idx)), h), None
+
+    def _pre_all(self, Xv, FP, T, E):
+        return self._zxp(Xv, ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx))
+
+    def _pre_t(self, pre, t, E, h):
+        return self._msg(pre[:, t * E:(t + 1) * E], h)
+
+
+class IC3MultiAgentPolicy(BatchedPolicy):
+    """CommNet ("IC3"): s = tanh(x~ W_ob + b) + mean_nbr(h_prev) W_msg + b_msg -> LSTM(H)
+    (agents/utils.py:385-408)."""
+    name = 'ic3'
+    k_wh, k_b = 'wh_hid', 'hid_b'
+    scope = 'ic3/lstm_ic3_%d'
+
+    def _phases(self):
+        H, F = self.n_h, self.n_feat
+        s = self.scope
+        return [[('w_msg', s + '/w_msg', (H, H), None),
+                 ('w_msg_b', s + '/b_msg', (H,), None),
+                 ('w_ob', s + '/w_ob', (self.n_obs, H), lambda i: F * (1 + self._m(i))),
+                 ('w_ob_b', s + '/b_ob', (H,), None),
+                 ('wx_hid', s + '/wx_hid', (H, 4 * H), None),
+                 ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
+                 ('hid_b', s + '/b_hid', (4 * H,), None)],
+                self._head_phase(self.name + '/pi_%d', self.name + '/v_%d')]
+
+    def _sx(self, xv):
+        p = self.params
+        return torch.tanh(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob']))
+
+    def _msg(self, sx, h):
+        p = self.params
+        mm = ops.nbr_mean(h, self.nbr_idx)                                    # un-masked previous h
+        s = sx + torch.baddbmm(p['w_msg_b'].unsqueeze(1), mm, p['w_msg'])
+        return torch.bmm(s, p['wx_hid'])
+
+    def _pre(self, xv, fp_prev, h):
+        return self._msg(self._sx(xv), h), None
+
+    def _pre_all(self, Xv, FP, T, E):
+        return self._sx(Xv)
+
+    def _pre_t(self, pre, t, E, h):
+        return self._msg(pre[:, t * E:(t + 1) * E], h)

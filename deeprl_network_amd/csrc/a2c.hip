@@ -1,0 +1,251 @@
+// Pointwise / scan kernels of the A2C update path, agent-major [N, E, .] layout.
+//
+//   lstm_cell_{fwd,bwd}  gate maths of agents/utils.py:102-113 (lstm), 199-208
+//                        (lstm_comm), 401-408 (lstm_ic3): done-masked state,
+//                        gate order i,f,o,u, c' = f*c + i*u, h' = o*tanh(c').
+//   sample_actions       utils.py:135-141 (np.random.choice == inverse CDF with one
+//                        uniform; argmax in test mode), fused with the transposition
+//                        to the env-major uint8 action array.
+//   nstep_return         agents/utils.py:763-775 / 837-855 (global reward) and
+//                        800-816 / 888-912 (spatially discounted), float64 scan.
+//   rmsprop_tf_clip      policies.py:32-39, 257-264: tf.clip_by_global_norm +
+//                        tf.train.RMSPropOptimizer (TF-1.12 ApplyRMSProp: ms0 = 1,
+//                        epsilon inside the sqrt), over one flat parameter buffer.
+// All HBM-bound elementwise/scan work: no MFMA.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// z: [rows, 4H] pre-activations WITHOUT bias; bias: [N, 4H]; rows = N*E ordered (n, e).
+// gates (out): post-activation i,f,o,u; c_prev is masked by (1-done[e]) here.
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
+    const int64_t E, const int N, const int H, const float* __restrict__ z, const float* __restrict__ bias,
+    const int64_t bias_stride, const float* __restrict__ c_prev, const float* __restrict__ done, float* __restrict__ gates,
+    float* __restrict__ c_new, float* __restrict__ h_new) {
+    const int64_t total = (int64_t)N * E * H;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / H;
+        const int j = (int)(idx - row * H);
+        const int64_t n = row / E;
+        const int64_t e = row - n * E;
+        const float* zr = z + row * 4 * H;
+        const float* b = bias + n * bias_stride;
+        const float gi = sigmoidf_(zr[j] + b[j]);
+        const float gf = sigmoidf_(zr[H + j] + b[H + j]);
+        const float go = sigmoidf_(zr[2 * H + j] + b[2 * H + j]);
+        const float gu = tanhf(zr[3 * H + j] + b[3 * H + j]);
+        const float keep = 1.0f - done[e];
+        const float c = gf * (c_prev[idx] * keep) + gi * gu;
+        float* gr = gates + row * 4 * H;
+        gr[j] = gi; gr[H + j] = gf; gr[2 * H + j] = go; gr[3 * H + j] = gu;
+        c_new[idx] = c;
+        h_new[idx] = go * tanhf(c);
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
+    const int64_t E, const int N, const int H, const float* __restrict__ gates, const float* __restrict__ c_prev,
+    const float* __restrict__ c_new, const float* __restrict__ done, const float* __restrict__ dh,
+    const float* __restrict__ dc_in, float* __restrict__ dz, float* __restrict__ dc_prev) {
+    const int64_t total = (int64_t)N * E * H;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / H;
+        const int j = (int)(idx - row * H);
+        const int64_t e = row % E;
+        const float* gr = gates + row * 4 * H;
+        const float gi = gr[j], gf = gr[H + j], go = gr[2 * H + j], gu = gr[3 * H + j];
+        const float keep = 1.0f - done[e];
+        const float tc = tanhf(c_new[idx]);
+        const float g_h = dh ? dh[idx] : 0.0f;
+        const float g_c = (dc_in ? dc_in[idx] : 0.0f) + g_h * go * (1.0f - tc * tc);
+        float* dzr = dz + row * 4 * H;
+        dzr[j] = g_c * gu * gi * (1.0f - gi);
+        dzr[H + j] = g_c * (c_prev[idx] * keep) * gf * (1.0f - gf);
+        dzr[2 * H + j] = g_h * tc * go * (1.0f - go);
+        dzr[3 * H + j] = g_c * gi * (1.0f - gu * gu);
+        dc_prev[idx] = g_c * gf * keep;
+    }
+}
+
+// pi: [N, E, A] probabilities.  mode 0: inverse-CDF with uniforms u[E,N] (legacy host
+// stream); mode 1: Philox(seed; env_id, agent>>2, step, ACTION); mode 2: argmax.
+__global__ __launch_bounds__(256) void sample_kernel(
+    const int64_t E, const int N, const int A, const float* __restrict__ pi, const float* __restrict__ u,
+    const int mode, const uint64_t seed, const int64_t env_id_base, const int64_t step,
+    uint8_t* __restrict__ action) {
+    const int64_t total = E * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = idx / N;
+        const int n = (int)(idx - e * N);
+        const float* p = pi + ((int64_t)n * E + e) * A;
+        int a = 0;
+        if (mode == 2) {
+            float best = p[0];
+            for (int k = 1; k < A; ++k) if (p[k] > best) { best = p[k]; a = k; }   // np.argmax: first max
+        } else {
+            float uu;
+            if (mode == 0) {
+                uu = u[idx];
+            } else {
+                const Philox4 r = philox4x32_10((uint32_t)(env_id_base + e), (uint32_t)(n >> 2), (uint32_t)step,
+                                                NMARL_STREAM_ACTION, (uint32_t)seed, (uint32_t)(seed >> 32));
+                const uint32_t w = (n & 3) == 0 ? r.x : (n & 3) == 1 ? r.y : (n & 3) == 2 ? r.z : r.w;
+                uu = u01_from_bits(w);
+            }
+            // numpy: cdf = cumsum(double(p)); cdf /= cdf[-1]; searchsorted(cdf, u, side='right')
+            double tot = 0.0;
+            for (int k = 0; k < A; ++k) tot += (double)p[k];
+            double cum = 0.0;
+            for (int k = 0; k < A; ++k) {
+                cum += (double)p[k];
+                if (cum / tot <= (double)uu) a = k + 1;
+            }
+            if (a > A - 1) a = A - 1;
+        }
+        action[idx] = (uint8_t)a;
+    }
+}
+
+// n-step return / advantage.  r: [T,E] (global) or [T,E,N] (per-agent, spatial);
+// v: [T,N,E]; done_post: [T,E]; R_end: [N,E]; outputs R, Adv: [N,T,E].
+// alpha < 0: R = r + gamma*R*(1-d).  alpha >= 0: R = gamma*R*(1-d) + sum_d alpha^d sum_{dist(i,j)=d} r_j.
+__global__ __launch_bounds__(256) void nstep_kernel(
+    const int64_t E, const int N, const int T, const float* __restrict__ r, const float* __restrict__ v,
+    const uint8_t* __restrict__ done_post, const float* __restrict__ R_end, const double gamma,
+    const double alpha, const int32_t* __restrict__ dist, float* __restrict__ R_out, float* __restrict__ adv_out) {
+    __shared__ double s_w[64 * 64];  // alpha^dist(i,j), N <= 64
+    const bool spatial = alpha >= 0.0;
+    if (spatial) {
+        for (int p = threadIdx.x; p < N * N; p += blockDim.x) s_w[p] = pow(alpha, (double)dist[p]);
+        __syncthreads();
+    }
+    const int64_t total = (int64_t)N * E;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / E);
+        const int64_t e = idx - (int64_t)n * E;
+        double R = (double)R_end[idx];
+        for (int t = T - 1; t >= 0; --t) {
+            const double keep = 1.0 - (double)done_post[(int64_t)t * E + e];
+            if (!spatial) {
+                R = (double)r[(int64_t)t * E + e] + gamma * R * keep;
+            } else {
+                R = gamma * R * keep;
+                const float* rt = r + ((int64_t)t * E + e) * N;
+                double add = 0.0;
+                for (int j = 0; j < N; ++j) add += s_w[n * N + j] * (double)rt[j];
+                R += add;
+            }
+            const int64_t o = ((int64_t)n * T + t) * E + e;
+            R_out[o] = (float)R;
+            adv_out[o] = (float)(R - (double)v[((int64_t)t * N + n) * E + e]);
+        }
+    }
+}
+
+// ---- clip_by_global_norm + RMSProp over flat [G, P] (G groups = optimisers) ----
+constexpr int SUMSQ_BLOCKS = 64;   // partial sums per group
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const int64_t P, const float* __restrict__ g,
+                                                    float* __restrict__ partial /*[G, SUMSQ_BLOCKS]*/) {
+    const int grp = blockIdx.y;
+    const float* gp = g + (int64_t)grp * P;
+    float s = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = gp[i];
+        s += x * x;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ float sw[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sw[w] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[grp * SUMSQ_BLOCKS + blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
+}
+
+__global__ __launch_bounds__(256) void rmsprop_kernel(
+    const int64_t P, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms,
+    const float* __restrict__ partial, const float* __restrict__ lr_ptr, const float lr_host, const float rho,
+    const float eps, const float max_norm, const float grad_scale, float* __restrict__ norm_out) {
+    const int grp = blockIdx.y;
+    // every block re-reduces its group's 64 partials in the same fixed order
+    float tot = 0.0f;
+    for (int b = 0; b < SUMSQ_BLOCKS; ++b) tot += partial[grp * SUMSQ_BLOCKS + b];
+    const float norm = sqrtf(tot) * fabsf(grad_scale);
+    float scale = grad_scale;
+    if (max_norm > 0.0f) scale = grad_scale * (max_norm * fminf(1.0f / norm, 1.0f / max_norm));
+    const float lr = lr_ptr ? *lr_ptr : lr_host;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[grp] = norm;
+    const int64_t base = (int64_t)grp * P;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gc = g[base + i] * scale;
+        float m = ms[base + i];
+        m = m + (gc * gc - m) * (1.0f - rho);                 // ApplyRMSProp
+        ms[base + i] = m;
+        w[base + i] = w[base + i] - lr * gc / sqrtf(m + eps);
+    }
+}
+
+inline int grid_x(int64_t n, int cap = 2048) {
+    int64_t b = (n + 255) / 256;
+    return (int)(b < cap ? (b > 0 ? b : 1) : cap);
+}
+
+}  // namespace
+
+extern "C" int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, const float* bias,
+                                   int64_t bias_stride, const float* c_prev, const float* done, float* gates, float* c_new,
+                                   float* h_new, void* stream) {
+    if (E < 0 || N <= 0 || H <= 0 || bias_stride < 4 * (int64_t)H ||
+        (E > 0 && (!z || !bias || !c_prev || !done || !gates || !c_new || !h_new)))
+        return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_x((int64_t)N * E * H)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), E, N, H, z, bias, bias_stride, c_prev, done, gates, c_new, h_new);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, const float* c_prev,
+                                   const float* c_new, const float* done, const float* dh, const float* dc_new,
+                                   float* dz, float* dc_prev, void* stream) {
+    if (E < 0 || N <= 0 || H <= 0 || (E > 0 && (!gates || !c_prev || !c_new || !done || !dz || !dc_prev)))
+        return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_x((int64_t)N * E * H)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), E, N, H, gates, c_prev, c_new, done, dh, dc_new, dz, dc_prev);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_sample_actions(int64_t E, int32_t N, int32_t A, const float* pi, const float* u, int32_t mode,
+                                    uint64_t seed, int64_t env_id_base, int64_t step, uint8_t* action, void* stream) {
+    if (E < 0 || N <= 0 || A <= 0 || A > 255 || mode < 0 || mode > 2 || (E > 0 && (!pi || !action))) return NMARL_EINVAL;
+    if (mode == 0 && E > 0 && !u) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(sample_kernel, dim3(grid_x(E * N)), dim3(256), 0, static_cast<hipStream_t>(stream), E, N, A, pi,
+                       u, mode, seed, env_id_base, step, action);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_nstep_return(int64_t E, int32_t N, int32_t T, const float* r, const float* v,
+                                  const uint8_t* done_post, const float* R_end, double gamma, double alpha,
+                                  const int32_t* dist, float* R_out, float* adv_out, void* stream) {
+    if (E < 0 || N <= 0 || N > 64 || T <= 0 || (E > 0 && (!r || !v || !done_post || !R_end || !R_out || !adv_out)))
+        return NMARL_EINVAL;
+    if (alpha >= 0.0 && !dist) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(nstep_kernel, dim3(grid_x((int64_t)N * E)), dim3(256), 0, static_cast<hipStream_t>(stream), E, N,
+                       T, r, v, done_post, R_end, gamma, alpha, dist, R_out, adv_out);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
+                                     const float* lr_dev, float lr, float rho, float eps, float max_norm,
+                                     float grad_scale, float* grad_norm_out, void* stream) {
+    if (G <= 0 || P <= 0 || !w || !g || !ms || !scratch) return NMARL_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS, G), dim3(256), 0, s, P, g, scratch);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_x(P, 1024), G), dim3(256), 0, s, P, w, g, ms, scratch, lr_dev, lr, rho,
+                       eps, max_norm, grad_scale, grad_norm_out);
+    return nmarl_check_launch();
+}

@@ -110,6 +110,92 @@ int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* acti
                     float* global_reward, int32_t auto_reset, uint64_t seed,
                     int64_t env_id_base, int32_t* episode, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Neighbourhood aggregation over the fixed adjacency (agent-major [N,E,F])   */
+/* ------------------------------------------------------------------------- */
+/*
+ * nbr_idx [N, m_max] i32 (device): the neighbours of agent i in ascending
+ * agent index (the order of tf.boolean_mask(.., masks[i])), left packed,
+ * -1 padded.  m_max <= 8, N*m_max <= 1024.
+ *
+ * gather: y[i, e, k*F + f] = x[nbr_idx[i,k], e, f]  (0 where padded)
+ *   replaces boolean_mask + reshape of agents/utils.py:192-195 (lstm_comm:
+ *   neighbour h / fingerprints / observations) and policies.py:305.
+ * mean:   y[i, e, f] = mean_k x[nbr_idx[i,k], e, f]
+ *   replaces tf.reduce_mean(tf.boolean_mask(out_m, masks[i])) of
+ *   agents/utils.py:395 (lstm_ic3, CommNet).
+ * *_bwd:  the exact adjoints (dx overwritten, deterministic, no atomics).
+ */
+int nmarl_nbr_gather_fwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                         const float* x, float* y, void* stream);
+int nmarl_nbr_gather_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                         const float* dy, float* dx, void* stream);
+int nmarl_nbr_mean_fwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                       const float* x, float* y, void* stream);
+int nmarl_nbr_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                       const float* dy, float* dx, void* stream);
+/*
+ * One-hot of the neighbours' actions for the centralised critic:
+ * y[i, e, k*A + a] = (action[e, nbr_idx[i,k]] == a); replaces
+ * tf.one_hot(boolean_mask(action, mask_i)) of policies.py:66-68, 305 and
+ * CACCEnv.get_neighbor_action (cacc_env.py:125-129).  action is env-major [E,N] u8.
+ */
+int nmarl_nbr_onehot(int64_t E, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
+                     const uint8_t* action, float* y, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Policy / update pointwise kernels                                          */
+/* ------------------------------------------------------------------------- */
+/*
+ * LSTM cell with done reset -- agents/utils.py:102-113 (lstm), 199-208
+ * (lstm_comm), 401-408 (lstm_ic3).  z [N,E,4H] = s*Wx + (h*(1-done))*Wh (bias
+ * NOT yet added), bias [N,4H] with row stride bias_stride (floats), c_prev [N,E,H], done [E] f32 in {0,1}.
+ *   i,f,o = sigmoid(z+b), u = tanh(z+b)   (gate order i,f,o,u)
+ *   c' = f * (c_prev*(1-done)) + i*u ;  h' = o * tanh(c')
+ * gates [N,E,4H] receives the post-activation i,f,o,u (saved for backward;
+ * may alias z).  bwd: dz [N,E,4H] (= d bias before the reduction over E),
+ * dc_prev [N,E,H]; dh / dc_new may be NULL (= 0).
+ */
+int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, const float* bias,
+                        int64_t bias_stride, const float* c_prev, const float* done, float* gates, float* c_new,
+                        float* h_new, void* stream);
+int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, const float* c_prev,
+                        const float* c_new, const float* done, const float* dh, const float* dc_new,
+                        float* dz, float* dc_prev, void* stream);
+/*
+ * Action draw of Trainer._get_policy (utils.py:135-141) for all (replica, agent):
+ * pi [N,E,A] -> action [E,N] u8.
+ *   mode 0: np.random.choice == searchsorted(cumsum(pi)/sum, u, 'right') with the
+ *           caller's uniforms u [E,N] (legacy global-RNG stream, E = 1);
+ *   mode 1: same with u = Philox4x32-10(key=seed, ctr=(env_id_base+e, n>>2, step, 1))
+ *           word n&3 (contract: oracle/philox.py);
+ *   mode 2: np.argmax (deterministic test policy, utils.py:140).
+ */
+int nmarl_sample_actions(int64_t E, int32_t N, int32_t A, const float* pi, const float* u, int32_t mode,
+                         uint64_t seed, int64_t env_id_base, int64_t step, uint8_t* action, void* stream);
+/*
+ * n-step return and advantage -- OnPolicyBuffer._add_R_Adv / _add_s_R_Adv
+ * (agents/utils.py:763-775, 800-816) and the MultiAgent variants (837-855,
+ * 888-912).  r [T,E] (alpha < 0: global reward) or [T,E,N] (alpha >= 0: spatial
+ * discount over dist [N,N] i32), v [T,N,E] rollout values, done_post [T,E] u8
+ * (done AFTER each step), R_end [N,E]; outputs R, Adv [N,T,E].  float64 scan.
+ */
+int nmarl_nstep_return(int64_t E, int32_t N, int32_t T, const float* r, const float* v,
+                       const uint8_t* done_post, const float* R_end, double gamma, double alpha,
+                       const int32_t* dist, float* R_out, float* adv_out, void* stream);
+/*
+ * tf.clip_by_global_norm + tf.train.RMSPropOptimizer.apply_gradients
+ * (policies.py:32-39, 257-264; TF-1.12 ApplyRMSProp, ms0 = 1, momentum 0) on a
+ * flat [G,P] parameter buffer; G = number of independent optimisers (IA2C: one
+ * per agent, MA2C: 1).  g is first multiplied by grad_scale (data-parallel
+ * mean).  scratch: [G,64] f32.  lr_dev (device scalar) overrides lr if != NULL.
+ *   norm_g = ||g_g||;  g *= max_norm * min(1/norm_g, 1/max_norm)   (max_norm > 0)
+ *   ms += (g*g - ms)*(1-rho);  w -= lr * g / sqrt(ms + eps)
+ */
+int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
+                          const float* lr_dev, float lr, float rho, float eps, float max_norm,
+                          float grad_scale, float* grad_norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,125 @@
+"""torch-CPU restatements of every HIP op of include/nmarl.h (neighbour
+aggregation, LSTM cell, action draw, n-step return, clip + TF-RMSProp).
+TEST INFRASTRUCTURE: the GPU parity tests compare each kernel against these,
+and the CPU test-suite patches them into `deeprl_network_amd.ops` (see
+tests/cpu_emulation.py) to exercise the host logic without a GPU.  The product
+never imports this module.
+
+Each function follows the reference lines cited in include/nmarl.h.
+"""
+import numpy as np
+import torch
+
+
+def neighbor_lists(nbr_idx):
+    tab = nbr_idx.cpu().numpy()
+    return [[int(j) for j in row if j >= 0] for row in tab]
+
+
+def nbr_gather(x, nbr_idx):
+    """boolean_mask + reshape (agents/utils.py:192-195): [N,E,F] -> [N,E,m_max*F]."""
+    N, E, F = x.shape
+    m = nbr_idx.shape[1]
+    out = []
+    for i, js in enumerate(neighbor_lists(nbr_idx)):
+        parts = [x[j] for j in js] + [torch.zeros_like(x[0])] * (m - len(js))
+        out.append(torch.cat(parts, dim=-1))
+    return torch.stack(out, dim=0)
+
+
+def nbr_mean(x, nbr_idx):
+    """reduce_mean(boolean_mask(out_m, masks[i])) (agents/utils.py:395)."""
+    return torch.stack([torch.stack([x[j] for j in js], 0).mean(0) for js in neighbor_lists(nbr_idx)], 0)
+
+
+def nbr_onehot(action, nbr_idx, n_a, out=None):
+    """one_hot(boolean_mask(action, mask_i)) -> [N,E,m_max*A] (policies.py:66-68, 305)."""
+    E, N = action.shape
+    m = nbr_idx.shape[1]
+    y = torch.zeros(N, E, m * n_a, dtype=torch.float32, device=action.device)
+    for i, js in enumerate(neighbor_lists(nbr_idx)):
+        for k, j in enumerate(js):
+            y[i, torch.arange(E), k * n_a + action[:, j].long()] = 1.0
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def lstm_cell(z, bias, c_prev, done):
+    """agents/utils.py:102-113: gate order i,f,o,u; state masked by (1-done)."""
+    H = z.shape[-1] // 4
+    zb = z + bias.unsqueeze(1)
+    i, f, o, u = zb.split(H, dim=-1)
+    i, f, o, u = torch.sigmoid(i), torch.sigmoid(f), torch.sigmoid(o), torch.tanh(u)
+    keep = (1.0 - done).view(1, -1, 1)
+    c = f * (c_prev * keep) + i * u
+    h = o * torch.tanh(c)
+    return h, c
+
+
+def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out):
+    h, c = lstm_cell(z, bias, c_prev, done)
+    c_out.copy_(c)
+    h_out.copy_(h)
+    return h_out, c_out
+
+
+SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2
+
+
+def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0):
+    """np.random.choice == searchsorted(cumsum(p)/sum, u, 'right') (utils.py:138); argmax (utils.py:140)."""
+    from oracle import philox
+    N, E, A = pi.shape
+    p = pi.detach().cpu().numpy().astype(np.float64).transpose(1, 0, 2)       # [E,N,A]
+    if mode == SAMPLE_ARGMAX:
+        a = p.argmax(-1)
+    else:
+        if mode == SAMPLE_UNIFORM:
+            uu = u.detach().cpu().numpy().astype(np.float64).reshape(E, N)
+        else:
+            uu = philox.action_uniform(seed, env_id_base + np.arange(E), N, step).astype(np.float64)
+        cdf = np.cumsum(p, axis=-1)
+        cdf = cdf / cdf[..., -1:]
+        a = (cdf <= uu[..., None]).sum(-1)
+        a = np.minimum(a, A - 1)
+    out.copy_(torch.from_numpy(a.astype(np.uint8)))
+    return out
+
+
+def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, adv_out=None):
+    """OnPolicyBuffer._add_R_Adv / _add_s_R_Adv (agents/utils.py:763-775, 800-816) per (agent, replica)."""
+    T, N, E = v.shape
+    r64, v64 = r.double().cpu(), v.double().cpu()
+    keep = 1.0 - done_post.double().cpu()
+    R = R_end.double().cpu().clone()                      # [N,E]
+    Rs = torch.zeros(N, T, E, dtype=torch.float64)
+    if alpha >= 0:
+        w = torch.pow(torch.tensor(float(alpha), dtype=torch.float64), dist.double().cpu())   # [N,N]
+    for t in range(T - 1, -1, -1):
+        if alpha < 0:
+            R = r64[t].unsqueeze(0) + gamma * R * keep[t].unsqueeze(0)
+        else:
+            R = gamma * R * keep[t].unsqueeze(0) + w @ r64[t].t()            # [N,N] @ [N,E]
+        Rs[:, t] = R
+    adv = Rs - v64.permute(1, 0, 2)
+    Rs32, adv32 = Rs.float().to(v.device), adv.float().to(v.device)
+    if R_out is not None:
+        R_out.copy_(Rs32)
+        adv_out.copy_(adv32)
+        return R_out, adv_out
+    return Rs32, adv32
+
+
+def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, norm_out=None, lr_dev=None):
+    """tf.clip_by_global_norm + ApplyRMSProp (policies.py:32-39), per row (= optimiser) of [G,P]."""
+    with torch.no_grad():
+        gs = g * grad_scale
+        norm = gs.pow(2).sum(dim=1, keepdim=True).sqrt()
+        if max_norm > 0:
+            gs = gs * (max_norm * torch.minimum(1.0 / norm, torch.full_like(norm, 1.0 / max_norm)))
+        ms.add_((gs * gs - ms) * (1.0 - rho))
+        w.sub_(lr * gs / torch.sqrt(ms + eps))
+        if norm_out is not None:
+            norm_out[:norm.shape[0]].copy_(norm.view(-1))

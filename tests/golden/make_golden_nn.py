@@ -1,0 +1,199 @@
+"""Generate tests/golden/nn_*.npz by running the REAL reference model code
+(/root/reference/agents/{utils,policies,models}.py, unmodified) on the fake-TF
+shim oracle/tf1_shim (torch-CPU, float64).  See the shim's docstring for what
+this pins and what it does not (TF kernel semantics of RMSProp/clip/softmax).
+
+    python tests/golden/make_golden_nn.py
+
+"Scripted" cases drive `model.forward('p')`, `model.forward('v')`,
+`model.add_transition`, `model.backward` in exactly the order of the
+reference's Trainer.explore/run (utils.py:163-254) for three n_step batches on
+synthetic observations, and record per-step pi / v, the bootstrap R, the loss
+and global grad-norm of every update, and per-variable statistics + samples of
+the weights after every update.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle', 'tf1_shim'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import tensorflow as tf  # noqa: E402  (the shim)
+from agents.models import IA2C, IA2C_FP, MA2C_NC, MA2C_IC3  # noqa: E402  (the reference)
+from helpers import cacc_config  # noqa: E402
+
+CLS = {'ia2c': IA2C, 'ia2c_fp': IA2C_FP, 'ma2c_nc': MA2C_NC, 'ma2c_ic3': MA2C_IC3}
+N_SAMPLE = 16
+
+
+def var_stats(variables):
+    """[n_var, 3 + N_SAMPLE]: sum, abs-sum, l2, then samples at idx (k*7919) % size."""
+    rows = []
+    for v in variables:
+        a = v.numpy().astype(np.float64).ravel()
+        idx = (np.arange(N_SAMPLE) * 7919) % a.size
+        rows.append(np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], a[idx]]))
+    return np.array(rows)
+
+
+def line_masks(n):
+    idx = np.arange(n)
+    d = np.abs(idx[:, None] - idx[None, :])
+    return (d == 1).astype(int), d.astype(int)
+
+
+def grid_masks(side=5):
+    """5x5 grid neighbourhood / hop distance (large_grid_env.py:58-105 semantics: 4-neighbour lattice)."""
+    n = side * side
+    nb = np.zeros((n, n), dtype=int)
+    dist = np.zeros((n, n), dtype=int)
+    for i in range(n):
+        for j in range(n):
+            dist[i, j] = abs(i // side - j // side) + abs(i % side - j % side)
+    nb[dist == 1] = 1
+    return nb, dist
+
+
+def run_scripted(name, agent, topo, seed, n_step, n_batch=3, coop_gamma=-1):
+    cp = cacc_config(agent=agent, n_step=n_step, reward_norm=50.0, coop_gamma=coop_gamma)
+    mc = cp['MODEL_CONFIG']
+    if topo == 'line':
+        N, n_feat, A = 8, 5, 4
+        nb, dist = line_masks(N)
+    else:
+        N, n_feat, A = 25, 12, 5
+        nb, dist = grid_masks(5)
+    is_ma = agent.startswith('ma2c')
+    nbr = [np.where(nb[i] == 1)[0] for i in range(N)]
+    n_s_ls = [n_feat if is_ma else n_feat * (1 + len(nbr[i])) for i in range(N)]
+    n_a_ls = [A] * N
+    np.random.seed(seed)                      # cacc_env.py:22 -- weight init consumes this stream
+    model = CLS[agent](n_s_ls, n_a_ls, nb, dist, coop_gamma, 10000, mc, seed=seed)
+    variables = tf.global_variables()
+    policies = model.policy if isinstance(model.policy, list) else [model.policy]
+    train_to_pol = {id(p._train): p for p in policies}
+    train_log = []
+    orig_run = tf.Session.run
+
+    def logging_run(self, fetches, feed_dict=None):
+        if isinstance(fetches, list):
+            for f in fetches:
+                if getattr(f, 'is_train', False):
+                    p = train_to_pol[id(f)]
+                    train_log.append(orig_run(self, [p.loss, p.grad_norm], feed_dict))
+        return orig_run(self, fetches, feed_dict)
+    tf.Session.run = logging_run
+
+    rng = np.random.RandomState(seed + 1000)
+    X = rng.normal(0, 0.7, size=(n_batch, n_step + 1, N, n_feat))
+    ACT = rng.randint(0, A, size=(n_batch, n_step + 1, N))
+    REW = rng.normal(-30, 20, size=(n_batch, n_step, N if coop_gamma >= 0 else 1))
+    out = dict(stats0=var_stats(variables), names=np.array([v.full_name for v in variables]),
+               shapes=np.array([str(tuple(v.value.shape)) for v in variables]))
+    PI = np.zeros((n_batch, n_step + 1, N, A))
+    V = np.zeros((n_batch, n_step + 1, N))
+    RB = np.zeros((n_batch, N))
+    DONE0 = np.zeros(n_batch, dtype=bool)
+    STATS, LOSS, STATES = [], [], []
+    fp = np.ones((N, A)) / A
+
+    def make_ob(x):
+        ob = []
+        for i in range(N):
+            cur = [x[i]]
+            if not is_ma:
+                cur += [x[j] for j in nbr[i]]
+            if agent == 'ia2c_fp':
+                cur += [fp[j] for j in nbr[i]]
+            ob.append(np.concatenate(cur))
+        return ob
+
+    def get_policy(ob, done):
+        if is_ma:
+            return np.array(model.forward(ob, done, fp))
+        return np.array(model.forward(ob, done))
+
+    def get_value(ob, done, ps, action):
+        if is_ma:
+            return np.array(model.forward(ob, done, ps, np.array(action), 'v'))
+        na = [action[nb[i] == 1] for i in range(N)]
+        return np.array(model.forward(ob, done, na, 'v')), na
+
+    # episode layout: batch 0 starts an episode, batch 1 continues it and ends it, batch 2 starts anew
+    done = True
+    model.reset()
+    for b in range(n_batch):
+        DONE0[b] = done
+        if done:
+            model.reset()
+            fp = np.ones((N, A)) / A
+        for t in range(n_step):
+            ob = make_ob(X[b, t])
+            ps = fp.copy()
+            pi = get_policy(ob, done)
+            a = ACT[b, t]
+            if is_ma:
+                v = get_value(ob, done, ps, a)
+                extra = ps
+            else:
+                v, extra = get_value(ob, done, None, a)
+            fp = pi.copy()                                   # env.update_fingerprint(policy)
+            r = REW[b, t] if coop_gamma >= 0 else float(REW[b, t, 0])
+            done = (b == 1 and t == n_step - 1)              # the episode ends with batch 1
+            model.add_transition(ob, extra, a, r, v, done)
+            PI[b, t], V[b, t] = pi, v
+        if done:
+            R = np.zeros(N)
+        else:                                                # bootstrap, utils.py:192-196
+            ob = make_ob(X[b, n_step])
+            ps = fp.copy()
+            pi = get_policy(ob, done)
+            a = ACT[b, n_step]
+            res = get_value(ob, done, ps, a)
+            R = res if is_ma else res[0]
+            PI[b, n_step], V[b, n_step] = pi, R
+        RB[b] = R
+        k0 = len(train_log)
+        model.backward(R, 0)
+        LOSS.append(np.array(train_log[k0:], dtype=np.float64))
+        STATS.append(var_stats(variables))
+        sf = [p.states_fw for p in policies]
+        STATES.append(np.array(sf, dtype=np.float64).reshape(N, -1))
+    tf.Session.run = orig_run
+    out.update(X=X, ACT=ACT, REW=REW, PI=PI, V=V, RB=RB, DONE0=DONE0, LOSS=np.array(LOSS),
+               STATS=np.array(STATS), STATES=np.array(STATES), nb=nb, dist=dist, agent=agent,
+               topo=topo, seed=seed, n_step=n_step, coop_gamma=coop_gamma, reward_norm=50.0)
+    np.savez_compressed(os.path.join(HERE, 'nn_%s.npz' % name), **out)
+    nparam = sum(int(np.prod(v.value.shape)) for v in variables)
+    print('%-22s params=%7d loss=%s gnorm=%s' % (name, nparam, np.round(LOSS[0][:, 0], 5)[:3],
+                                                 np.round(LOSS[0][:, 1], 4)[:3]))
+
+
+def run_ortho():
+    from agents.utils import ortho_init
+    np.random.seed(12)
+    shapes = [(15, 64), (64, 256), (128, 256), (64, 4), (72, 1), (192, 256), (8, 64), (1, 3)]
+    out = {}
+    for k, s in enumerate(shapes):
+        out['w%d' % k] = ortho_init()(s, None)
+    out['shapes'] = np.array(shapes)
+    out['after'] = np.random.rand()
+    np.savez_compressed(os.path.join(HERE, 'ortho_init.npz'), **out)
+    print('ortho w0[0,0] = %.7f' % out['w0'][0, 0])
+
+
+if __name__ == '__main__':
+    run_ortho()
+    run_scripted('ia2c_line', 'ia2c', 'line', 12, 6)
+    run_scripted('ia2c_fp_line', 'ia2c_fp', 'line', 13, 6)
+    run_scripted('ma2c_nc_line', 'ma2c_nc', 'line', 14, 6)
+    run_scripted('ma2c_ic3_line', 'ma2c_ic3', 'line', 15, 6)
+    run_scripted('ma2c_ic3_grid', 'ma2c_ic3', 'grid', 16, 4)
+    run_scripted('ma2c_nc_grid', 'ma2c_nc', 'grid', 17, 4)
+    run_scripted('ma2c_nc_line_spatial', 'ma2c_nc', 'line', 18, 6, coop_gamma=0.9)
+    run_scripted('ia2c_line_spatial', 'ia2c', 'line', 19, 6, coop_gamma=0.8)

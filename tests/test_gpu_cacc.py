@@ -166,7 +166,9 @@ def test_full_size_properties(E):
     small.reset()
     assert torch.equal(env.h[sub], small.h)
     T = 130
-    acts = torch.from_numpy(rng.randint(0, 4, size=(T, E, 8)).astype(np.uint8)).cuda()
+    acts_np = rng.randint(0, 4, size=(T, E, 8)).astype(np.uint8)
+    acts_np[:, ::2] = 1     # constant action 1 collides before step 120 (golden catchup_nc_const1)
+    acts = torch.from_numpy(acts_np).cuda()
     ep_before = env.episode.clone()
     for k in range(T):
         coll_before = env.collided.clone().bool()

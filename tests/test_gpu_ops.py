@@ -1,0 +1,173 @@
+"""Per-kernel GPU parity (through the C-ABI) against the oracle restatements oracle/ops_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(kind):
+    if kind == 'line':
+        n = 8
+        idx = np.arange(n)
+        return (np.abs(idx[:, None] - idx[None, :]) == 1).astype(int)
+    side = 5
+    n = side * side
+    d = np.array([[abs(i // side - j // side) + abs(i % side - j % side) for j in range(n)] for i in range(n)])
+    return (d == 1).astype(int)
+
+
+@pytest.mark.parametrize('kind', ['line', 'grid'])
+@pytest.mark.parametrize('E,F', [(1, 5), (7, 4), (300, 64), (4096, 64), (33, 12)])
+def test_nbr_gather_and_mean_fwd_bwd(kind, E, F):
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    nbr, cnt = ops.neighbor_table(_masks(kind), 'cuda')
+    N = len(cnt)
+    g = torch.Generator().manual_seed(E * 131 + F)
+    x = torch.randn(N, E, F, generator=g)
+    for fn, ref in [(ops.nbr_gather, ops_ref.nbr_gather), (ops.nbr_mean, ops_ref.nbr_mean)]:
+        xg = x.cuda().requires_grad_(True)
+        xc = x.clone().requires_grad_(True)
+        y = fn(xg, nbr)
+        yr = ref(xc, nbr.cpu())
+        assert torch.equal(y.cpu(), yr) if fn is ops.nbr_gather else torch.allclose(y.cpu(), yr, rtol=1e-6, atol=1e-7)
+        w = torch.randn(yr.shape, generator=g)
+        (y * w.cuda()).sum().backward()
+        (yr * w).sum().backward()
+        torch.testing.assert_close(xg.grad.cpu(), xc.grad, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('kind,A', [('line', 4), ('grid', 5)])
+def test_nbr_onehot(kind, A):
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    nbr, cnt = ops.neighbor_table(_masks(kind), 'cuda')
+    N = len(cnt)
+    for E in (1, 50, 4096):
+        a = torch.randint(0, A, (E, N), dtype=torch.uint8)
+        y = ops.nbr_onehot(a.cuda(), nbr, A)
+        assert torch.equal(y.cpu(), ops_ref.nbr_onehot(a, nbr.cpu(), A))
+
+
+@pytest.mark.parametrize('N,E,H', [(8, 1, 64), (8, 257, 64), (25, 64, 64), (8, 4096, 64), (3, 5, 16)])
+def test_lstm_cell_fwd_bwd(N, E, H):
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N * E + H)
+    z = torch.randn(N, E, 4 * H, generator=g) * 2
+    b = torch.randn(N, 4 * H, generator=g) * 0.3
+    c = torch.randn(N, E, H, generator=g)
+    done = (torch.rand(E, generator=g) < 0.3).float()
+    ins_g = [t.cuda().requires_grad_(True) for t in (z, b, c)]
+    ins_c = [t.double().requires_grad_(True) for t in (z, b, c)]
+    h1, c1 = ops.lstm_cell(ins_g[0], ins_g[1], ins_g[2], done.cuda())
+    h2, c2 = ops_ref.lstm_cell(ins_c[0], ins_c[1], ins_c[2], done.double())
+    torch.testing.assert_close(h1.cpu().double(), h2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(c1.cpu().double(), c2, rtol=1e-5, atol=1e-6)
+    wh, wc = torch.randn(N, E, H, generator=g), torch.randn(N, E, H, generator=g)
+    ((h1 * wh.cuda()).sum() + (c1 * wc.cuda()).sum()).backward()
+    ((h2 * wh.double()).sum() + (c2 * wc.double()).sum()).backward()
+    for a, r, name in zip(ins_g, ins_c, 'zbc'):
+        torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=2e-4, atol=2e-5 * max(1, E ** 0.5), msg=name)
+    # strided bias view (row stride > 4H), as handed over by the flat parameter buffer
+    big = torch.zeros(N, 4 * H + 37, device='cuda')
+    big[:, 5:5 + 4 * H] = b.cuda()
+    h3, c3 = ops.lstm_cell(z.cuda(), big[:, 5:5 + 4 * H], c.cuda(), done.cuda())
+    assert torch.equal(h3, h1.detach()) and torch.equal(c3, c1.detach())
+
+
+def test_sample_actions_modes():
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    N, E, A = 8, 5000, 4
+    g = torch.Generator().manual_seed(0)
+    pi = torch.softmax(torch.randn(N, E, A, generator=g) * 2, -1)
+    u = torch.rand(E, N, generator=g)
+    for mode, kw in [(ops.SAMPLE_UNIFORM, dict(u=u)), (ops.SAMPLE_PHILOX, dict(seed=12345678901, env_id_base=777, step=4242)),
+                     (ops.SAMPLE_ARGMAX, {})]:
+        out = torch.zeros(E, N, dtype=torch.uint8, device='cuda')
+        ref = torch.zeros(E, N, dtype=torch.uint8)
+        kg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+        ops.sample_actions(pi.cuda(), out, mode, **kg)
+        ops_ref.sample_actions(pi, ref, mode, **kw)
+        assert torch.equal(out.cpu(), ref), mode
+    # distribution sanity at scale: empirical frequencies follow pi
+    E2 = 200000
+    p = torch.tensor([0.1, 0.2, 0.3, 0.4]).view(1, 1, 4).expand(N, E2, 4).contiguous().cuda()
+    out = torch.zeros(E2, N, dtype=torch.uint8, device='cuda')
+    ops.sample_actions(p, out, ops.SAMPLE_PHILOX, seed=3, step=9)
+    freq = torch.bincount(out.flatten().long(), minlength=4).float() / out.numel()
+    assert torch.allclose(freq.cpu(), torch.tensor([0.1, 0.2, 0.3, 0.4]), atol=3e-3)
+
+
+def test_sample_matches_numpy_choice_stream():
+    """Legacy mode == the reference's np.random.choice(arange(A), p=pi) on the same global stream."""
+    from deeprl_network_amd import ops
+    N, A = 8, 4
+    rng = np.random.RandomState(5)
+    pi = rng.dirichlet(np.ones(A), size=N).astype(np.float32)
+    np.random.seed(99)
+    want = [np.random.choice(np.arange(A), p=p) for p in pi]
+    np.random.seed(99)
+    u = torch.tensor([np.random.random_sample() for _ in range(N)], dtype=torch.float32).view(1, N)
+    out = torch.zeros(1, N, dtype=torch.uint8, device='cuda')
+    ops.sample_actions(torch.from_numpy(pi).view(N, 1, A).cuda(), out, ops.SAMPLE_UNIFORM, u=u.cuda())
+    assert out.cpu().numpy()[0].tolist() == want
+
+
+@pytest.mark.parametrize('alpha', [-1.0, 0.9])
+@pytest.mark.parametrize('N,E,T', [(8, 1, 60), (8, 4096, 60), (25, 100, 120)])
+def test_nstep_return(alpha, N, E, T):
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(T + N)
+    r = torch.randn((T, E, N) if alpha >= 0 else (T, E), generator=g)
+    v = torch.randn(T, N, E, generator=g)
+    done = (torch.rand(T, E, generator=g) < 0.05).to(torch.uint8)
+    Rend = torch.randn(N, E, generator=g)
+    idx = np.arange(N)
+    dist = torch.from_numpy(np.abs(idx[:, None] - idx[None, :]).astype(np.int32))
+    R1, A1 = ops.nstep_return(r.cuda(), v.cuda(), done.cuda(), Rend.cuda(), 0.99, alpha, dist.cuda())
+    R2, A2 = ops_ref.nstep_return(r, v, done, Rend, 0.99, alpha, dist)
+    torch.testing.assert_close(R1.cpu(), R2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(A1.cpu(), A2, rtol=1e-6, atol=1e-6)
+
+
+def test_nstep_matches_reference_buffer_golden():
+    """SURVEY.md 8(c) known answer of MultiAgentOnPolicyBuffer(0.99, -1)."""
+    from deeprl_network_amd import ops
+    r = torch.tensor([[-1.0], [-2.0], [-3.0]])
+    v = torch.tensor([[[.1], [.2], [.3]]] * 3)
+    done = torch.zeros(3, 1, dtype=torch.uint8)
+    Rend = torch.tensor([[1.0], [2.0], [3.0]])
+    R, A = ops.nstep_return(r.cuda(), v.cuda(), done.cuda(), Rend.cuda(), 0.99, -1.0, None)
+    want = np.array([[-4.950001, -3.9899, -2.01], [-3.979702, -3.0098, -1.02], [-3.009403, -2.0297, -0.03]])
+    np.testing.assert_allclose(R.cpu().numpy()[:, :, 0], want, rtol=1e-6)
+    np.testing.assert_allclose(A.cpu().numpy()[:, :, 0], want - np.array([[.1], [.2], [.3]]), rtol=1e-5)
+
+
+@pytest.mark.parametrize('G,P,max_norm', [(8, 51341, 40.0), (1, 598496, 40.0), (8, 1000, 0.5), (3, 77, -1.0)])
+def test_rmsprop_tf_clip(G, P, max_norm):
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(P)
+    w = torch.randn(G, P, generator=g)
+    gr = torch.randn(G, P, generator=g) * 0.1
+    ms = torch.ones(G, P)
+    wg, msg = w.cuda(), ms.cuda()
+    scratch = torch.zeros(G, 64, device='cuda')
+    n1, n2 = torch.zeros(G, device='cuda'), torch.zeros(G)
+    for it in range(3):
+        ops.rmsprop_tf_clip(wg, gr.cuda() * (it + 1), msg, scratch, 5e-4, 0.99, 1e-5, max_norm, 0.5, n1)
+        ops_ref.rmsprop_tf_clip(w, gr * (it + 1), ms, None, 5e-4, 0.99, 1e-5, max_norm, 0.5, n2)
+        torch.testing.assert_close(n1.cpu(), n2, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(wg.cpu(), w, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(msg.cpu(), ms, rtol=1e-5, atol=1e-7)
+
+
+def test_ops_reject_cpu_tensors():
+    from deeprl_network_amd import _lib, ops
+    nbr, _ = ops.neighbor_table(_masks('line'), 'cuda')
+    with pytest.raises(_lib.NmarlError):
+        ops.nbr_gather(torch.zeros(8, 2, 4), nbr)

@@ -1,0 +1,222 @@
+"""bench.py -- env-steps/s of the batched rollout + A2C update on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): CACC catch-up, 8 agents x 4096 lock-stepped replicas per GPU,
+IA2C-FP (config/config_ia2c_fp_catchup.ini), fp32, synthetic (Philox initial conditions, random-init
+sqrt(2)-orthogonal weights, actions sampled from the live policy).
+
+A "step" = one n_step batch of the hot path over all replicas: 60 lock-steps of
+{policy step, action draw, value re-step (reference quirk Q1), CACC env kernel, transition store},
+the bootstrap value, the n-step return scan and ONE A2C update (unroll + loss + backward +
+[RCCL all-reduce] + clip/RMSProp).  metric = agents x replicas x lock-steps / second, whole job.
+
+Extra objects on the JSON line (tier contract):
+  roofline      the CACC step kernel: algorithmic bytes per launch (B_alg) / average
+                launch duration measured live with HIP events; see `roofline.how`.
+  cpu_baseline  the reference-equivalent E=1 CPU loop (oracle/trainer_ref.py, kind "port") timed
+                on one host core on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import configparser
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_AGENT = 8
+
+
+def b_alg(obs_floats):
+    """Algorithmic HBM bytes of one replica-step of the CACC kernel:
+    per vehicle: read h,v (8) + action (1); write h,v,u (12) + observation; per replica: read
+    t, v0_init, collided (9), write t, collided, done, global_reward and the scalar reward (14)."""
+    return N_AGENT * (8 + 1 + 12) + obs_floats * 4 + 9 + 14
+
+
+# compact observation (5 floats / vehicle) = the survey's 347 B (+4: the [E] reward vector);
+# the product writes the 'ia2c' pre-gathered observation, sum n_s = 110 floats = 440 B
+# (declared variant of SURVEY.md 8d; the 2 zero pad slots of the edge vehicles are NOT counted).
+B_ALG_GATHERED = b_alg(110)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default=os.path.join(ROOT, 'config', 'config_ia2c_fp_catchup.ini'))
+    ap.add_argument('--envs', type=int, default=0, help='replicas per GPU (default: num_envs of the ini)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batches', type=int, default=20)
+    return ap.parse_args()
+
+
+def measure_step_kernel(env, actions_tape, reps=20):
+    """Average duration of one nmarl_cacc_step launch: a hipGraph of len(tape) back-to-back
+    launches (real rollout state, the batch's own action tape, auto-reset on) bracketed by two
+    HIP events on the launch stream; includes the ~1.5 us graph-node gaps, i.e. an upper bound."""
+    state = [t.clone() for t in (env.h, env.v, env.u, env.t, env.collided, env.v0_init, env.episode)]
+    n = actions_tape.shape[0]
+
+    def body():
+        for k in range(n):
+            env.step(actions_tape[k], auto_reset=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (reps * n)
+    for t, sv in zip((env.h, env.v, env.u, env.t, env.collided, env.v0_init, env.episode), state):
+        t.copy_(sv)
+    return us
+
+
+def cpu_baseline(cfg_path, n_batches):
+    """Reference-equivalent E=1 CPU loop (restated; TF-1.12 cannot run here) on ONE core."""
+    from oracle import trainer_ref
+    torch.set_num_threads(1)
+    cp = configparser.ConfigParser()
+    cp.read(cfg_path)
+    env, model, tr = trainer_ref.build(cp)
+    tr.run_batches(1)                                   # warm-up (allocator, first-touch)
+    steps, sec = tr.run_batches(n_batches)
+    return {'value': steps * N_AGENT / sec, 'unit': 'env-steps/s (agents x envs x steps/s)', 'cores': 1,
+            'kind': 'port',
+            'sample': '%d n_step batches (%d env steps, E=1) of the restated reference loop '
+                      '(oracle/trainer_ref.py: NumPy env + per-agent torch-CPU LSTMs + TF-RMSProp), %.1f s'
+                      % (n_batches, steps, sec),
+            'updates_per_s': n_batches / sec}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                             % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
+        group = dist.group.WORLD
+
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs import make_batch_env
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+
+    cp = configparser.ConfigParser()
+    cp.read(args.config)
+    E = args.envs or cp['ENV_CONFIG'].getint('num_envs', fallback=4096)
+    env = make_batch_env(cp['ENV_CONFIG'], num_envs=E, device=device, env_id_base=rank * E)
+    np.random.seed(env.seed)                               # identical initial weights on every rank
+    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC,
+           'ma2c_ic3': models.MA2C_IC3}[env.agent]
+    model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, int(1e9),
+                cp['MODEL_CONFIG'], seed=env.seed, num_envs=E, device=device, dist_group=group)
+    trainer = BatchedTrainer(env, model, Counter(int(1e18), int(1e18), int(1e18)), use_graph=not args.no_graph,
+                             rank=rank, world_size=world)
+
+    for _ in range(args.warmup):
+        trainer.run_batch()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.run_batch()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_step = model.n_step
+    env_steps = N_AGENT * E * n_step * args.steps * world
+    out = {
+        'metric': 'env-steps/sec (agents x envs x steps/s), full rollout + A2C update loop',
+        'value': env_steps / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'a2c_updates_per_s': args.steps / elapsed,
+        'lock_steps_per_s': n_step * args.steps / elapsed,
+        'config': {'workload': 'CACC catch-up, 8 agents x %d replicas/GPU, %s (%s), n_step %d'
+                               % (E, env.agent, os.path.basename(args.config), n_step),
+                   'replicas_per_gpu': E, 'global_replicas': E * world, 'parallelism': 'dp%d' % world,
+                   'hipgraph_rollout': trainer.use_graph,
+                   'step_definition': 'one n_step batch: %d lock-steps (2 LSTM steps each, quirk Q1) + bootstrap + '
+                                      '1 A2C update over all replicas' % n_step},
+    }
+    if rank == 0:
+        # ---- roofline of the env-step kernel, measured live on this rank's stream
+        tape = model.buf_act.clone()
+        us = measure_step_kernel(env, tape)
+        ach = B_ALG_GATHERED * E / us / 1e3
+        out['roofline'] = {
+            'kernel': 'cacc_step_kernel (nmarl_cacc_step)', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None,
+            'bytes_per_launch': B_ALG_GATHERED * E, 'us_per_launch': us, 'replicas_per_launch': E,
+            'how': 'hipGraph of %d back-to-back step launches on the rollout state with the batch action tape, '
+                   '20 replays between two HIP events on the launch stream (includes graph-node gaps). '
+                   'B_alg = %d B/replica-step (gathered-observation variant). At E=%d the launch moves %.2f MB: '
+                   'latency-bound and LLC-resident (SURVEY.md H1); see roofline_large_E for the HBM regime.'
+                   % (n_step, B_ALG_GATHERED, E, B_ALG_GATHERED * E / 1e6)}
+        if world == 1:
+            try:
+                big_E = 1 << 21
+                big = make_batch_env(cp['ENV_CONFIG'], num_envs=big_E, device=device, env_id_base=10 ** 7)
+                big.reset()
+                e = torch.arange(big_E, device=device)[:, None]
+                a = torch.arange(N_AGENT, device=device)[None, :]
+                big_tape = torch.stack([((e + 3 * a + s) % 4).to(torch.uint8) for s in range(8)])
+                us_b = measure_step_kernel(big, big_tape, reps=5)
+                ach_b = B_ALG_GATHERED * big_E / us_b / 1e3
+                out['roofline_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,
+                                           'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
+                                           'traffic': None, 'replicas_per_launch': big_E, 'us_per_launch': us_b,
+                                           'bytes_per_launch': B_ALG_GATHERED * big_E,
+                                           'how': 'same kernel at E=2^21 (working set 1.4 GB >> 256 MB Infinity Cache), '
+                                                  'actions (env+3*agent+step) mod 4 (SURVEY.md 8d)'}
+                del big
+            except Exception as ex:      # never lose the headline line to the side measurement
+                out['roofline_large_E'] = {'error': repr(ex)}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.config, args.cpu_batches)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

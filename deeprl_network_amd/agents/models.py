@@ -64,6 +64,10 @@ class IA2C:
         self.E = int(num_envs)
         self.device = torch.device(device)
         self.dist_group = dist_group
+        self.world_size = 1
+        if dist_group is not None:
+            import torch.distributed as dist
+            self.world_size = dist.get_world_size(dist_group)
         self.seed = seed
         m = self.neighbor_mask.sum(axis=1)
         if n_feat is None:
@@ -77,9 +81,10 @@ class IA2C:
         N, E, H, T = self.n_agent, self.E, self.n_lstm, self.n_step
         d = self.device
         z = lambda *s: torch.zeros(*s, dtype=F32, device=d)      # noqa: E731
+        # recurrent state [c,h] of policies.py:151-154; static buffers (hipGraph-friendly), updated in place
         self.h_fw, self.c_fw, self.h_bw, self.c_bw = z(N, E, H), z(N, E, H), z(N, E, H), z(N, E, H)
+        self._h2, self._c2 = z(N, E, H), z(N, E, H)        # scratch of the value re-step (quirk Q1)
         self.fp = torch.full((N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
-        self.pi_last = torch.zeros(N, E, self.n_a, dtype=F32, device=d)
         self.total_step = total_step
         self.sess = None                                  # the reference Trainer reads model.sess (TF leak)
         if total_step:
@@ -138,24 +143,25 @@ class IA2C:
 
     def _policy_step(self, obs, done):
         """forward('p'): advances states_fw (policies.py:119-134)."""
-        self.h_fw, self.c_fw = self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done)
+        self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw)
         with torch.no_grad():
             return self.policy.pi(self.h_fw)
 
     def _value_step(self, obs, done, na_onehot):
         """forward('v'): re-steps the LSTM from the state forward('p') wrote (quirk Q1),
         without storing the result (policies.py:124-133)."""
-        h2, _ = self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done)
+        self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done, self._h2, self._c2)
         with torch.no_grad():
-            return self.policy.value(h2, na_onehot)
+            return self.policy.value(self._h2, na_onehot)
 
     def act(self, obs, done, action_out, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0,
-            store=True):
+            step_dev=None, store=True):
         """One lock-step decision for all replicas: pi, action draw, value; optionally stores the
         transition inputs at buffer slot t.  obs [E,N,n_obs] f32, done [E] f32 (pre-step)."""
         t = self.t
         pi = self._policy_step(obs, done)
-        ops.sample_actions(pi, action_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step)
+        ops.sample_actions(pi, action_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
+                           step_dev=step_dev)
         if store:
             na = ops.nbr_onehot(action_out, self.policy.nbr_idx, self.n_a, out=self.buf_na[:, t])
             v = self._value_step(obs, done, na)
@@ -164,7 +170,7 @@ class IA2C:
             self.buf_act[t].copy_(action_out)
             self.buf_v[t].copy_(v)
             self.buf_done_pre[t].copy_(done)
-        self.fp = pi                                       # env.update_fingerprint(policy), utils.py:173
+        self.fp.copy_(pi)                                  # env.update_fingerprint(policy), utils.py:173
         return pi
 
     def record(self, reward, done_post):
@@ -180,11 +186,12 @@ class IA2C:
         self.t = t + 1
 
     def bootstrap(self, obs, done, action_scratch, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0,
-                  step=0):
+                  step=0, step_dev=None):
         """R for the unfinished replicas (utils.py:192-196): one more policy step (which advances
         states_fw -- quirk Q2) and the double-stepped value; 0 where the episode just ended."""
         pi = self._policy_step(obs, done)
-        ops.sample_actions(pi, action_scratch, mode, u=u, seed=seed, env_id_base=env_id_base, step=step)
+        ops.sample_actions(pi, action_scratch, mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
+                           step_dev=step_dev)
         na = ops.nbr_onehot(action_scratch, self.policy.nbr_idx, self.n_a)
         return self._value_step(obs, done, na)
 
@@ -210,7 +217,8 @@ class IA2C:
     def update(self, R_end):
         """model.backward (models.py:34-42 / 211-215) for all replicas: R_end [N,E]."""
         assert self.t == self.n_step, 'update() needs a full n_step batch (got %d)' % self.t
-        cur_lr = self.lr_scheduler.get(self.n_step)
+        # the schedule counts environment steps: n_step per replica (E = 1: the reference's get(n_step))
+        cur_lr = self.lr_scheduler.get(self.n_step * self.E * self.world_size)
         alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
         ops.nstep_return(self.buf_r, self.buf_v, self.buf_done_post, R_end.contiguous(), self.gamma, alpha,
                          self.dist_dev, self.R, self.Adv)
@@ -364,7 +372,7 @@ class IA2C_FP(IA2C):
         # the reference env delivers the neighbours' fingerprints inside `obs`; scatter them back
         # into the per-agent fingerprint table the batched policy gathers from
         _, fpg = self._obs_to_slab(obs)
-        self.fp = self._ungather_fp(fpg)
+        self.fp.copy_(self._ungather_fp(fpg))
         return super().forward(obs, done, nactions, out_type)
 
     def _ungather_fp(self, fpg):
@@ -395,7 +403,7 @@ class MA2C_NC(IA2C):
     def forward(self, obs, done, ps, actions=None, out_type='p'):
         """MA2C_NC.forward (models.py:217-224): [N,A] ('p') or [N] ('v')."""
         slab, _ = self._obs_to_slab(obs)
-        self.fp = torch.as_tensor(np.asarray(ps, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)).to(self.device)
+        self.fp.copy_(torch.as_tensor(np.asarray(ps, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
         d = self._done_t(done)
         if out_type.startswith('p'):
             return self._policy_step(slab, d)[:, 0].cpu().numpy()

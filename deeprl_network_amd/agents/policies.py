@@ -155,17 +155,17 @@ class BatchedPolicy:
         return v.squeeze(-1)
 
     # -- one recurrent step for the rollout (no autograd)
-    def step(self, x, fp_prev, h, c, done):
+    def step(self, x, fp_prev, h, c, done, h_out, c_out):
         """x [E,N,n_obs] env-major slab (or any view with that shape), fp_prev [N,E,A] the
-        previous-step policies, (h, c) [N,E,H], done [E] f32 -> (h', c')."""
+        previous-step policies, (h, c) [N,E,H], done [E] f32 -> writes (h', c') into
+        (h_out, c_out), which MAY alias (h, c): every read of h precedes the cell kernel on
+        the stream and the cell kernel is index-wise in place."""
         with torch.no_grad():
-            zx, h_src = self._pre(x.transpose(0, 1), fp_prev, h)
+            zx = self._pre(x.transpose(0, 1), fp_prev, h)
             keep = (1.0 - done).view(1, -1, 1)
             z = torch.baddbmm(zx, h * keep, self.params[self.k_wh])
-            c_new = torch.empty_like(c)
-            h_new = torch.empty_like(h)
-            ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_new, h_new)
-        return h_new, c_new
+            ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_out, h_out)
+        return h_out, c_out
 
     # -- n_step unroll for the update (autograd)
     def unroll(self, X, FP, done, h0, c0):
@@ -204,7 +204,7 @@ class LstmPolicy(BatchedPolicy):
         return torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), xv, p['fc_w']))
 
     def _pre(self, xv, fp_prev, h):
-        return torch.bmm(self._encode(xv, None), self.params['lstm_wx']), None
+        return torch.bmm(self._encode(xv, None), self.params['lstm_wx'])
 
     def _pre_all(self, Xv, FP, T, E):
         return torch.bmm(self._encode(Xv, None), self.params['lstm_wx'])
@@ -235,7 +235,7 @@ class FPPolicy(LstmPolicy):
         return torch.baddbmm(torch.bmm(hx, p['lstm_wx'][:, :nf]), hp, p['lstm_wx'][:, nf:])
 
     def _pre(self, xv, fp_prev, h):
-        return self._zx(xv, ops.nbr_gather(fp_prev, self.nbr_idx)), None
+        return self._zx(xv, ops.nbr_gather(fp_prev, self.nbr_idx))
 
     def _pre_all(self, Xv, FP, T, E):
         pf = ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx)
@@ -278,7 +278,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
         return torch.baddbmm(zxp, hm, p['wx_hid'][:, 2 * H:])
 
     def _pre(self, xv, fp_prev, h):
-        return self._msg(self._zxp(xv, ops.nbr_gather(fp_prev, self.nbr_idx)), h), None
+        return self._msg(self._zxp(xv, ops.nbr_gather(fp_prev, self.nbr_idx)), h)
 
     def _pre_all(self, Xv, FP, T, E):
         return self._zxp(Xv, ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx))
@@ -317,7 +317,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         return torch.bmm(s, p['wx_hid'])
 
     def _pre(self, xv, fp_prev, h):
-        return self._msg(self._sx(xv), h), None
+        return self._msg(self._sx(xv), h)
 
     def _pre_all(self, Xv, FP, T, E):
         return self._sx(Xv)

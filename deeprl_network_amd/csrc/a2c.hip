@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
 // stream); mode 1: Philox(seed; env_id, agent>>2, step, ACTION); mode 2: argmax.
 __global__ __launch_bounds__(256) void sample_kernel(
     const int64_t E, const int N, const int A, const float* __restrict__ pi, const float* __restrict__ u,
-    const int mode, const uint64_t seed, const int64_t env_id_base, const int64_t step,
-    uint8_t* __restrict__ action) {
+    const int mode, const uint64_t seed, const int64_t env_id_base, const int64_t step_host,
+    const int64_t* __restrict__ step_dev, uint8_t* __restrict__ action) {
     const int64_t total = E * N;
+    const int64_t step = step_dev ? *step_dev : step_host;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = idx / N;
         const int n = (int)(idx - e * N);
@@ -218,12 +219,13 @@ extern "C" int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float*
 }
 
 extern "C" int nmarl_sample_actions(int64_t E, int32_t N, int32_t A, const float* pi, const float* u, int32_t mode,
-                                    uint64_t seed, int64_t env_id_base, int64_t step, uint8_t* action, void* stream) {
+                                    uint64_t seed, int64_t env_id_base, int64_t step, const int64_t* step_dev,
+                                    uint8_t* action, void* stream) {
     if (E < 0 || N <= 0 || A <= 0 || A > 255 || mode < 0 || mode > 2 || (E > 0 && (!pi || !action))) return NMARL_EINVAL;
     if (mode == 0 && E > 0 && !u) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipLaunchKernelGGL(sample_kernel, dim3(grid_x(E * N)), dim3(256), 0, static_cast<hipStream_t>(stream), E, N, A, pi,
-                       u, mode, seed, env_id_base, step, action);
+                       u, mode, seed, env_id_base, step, step_dev, action);
     return nmarl_check_launch();
 }
 

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void mean_bwd_kernel(
 // one-hot of the neighbours' actions for the centralised critic (policies.py:66-68, 305)
 __global__ __launch_bounds__(256) void nbr_onehot_kernel(
     const int64_t E, const int N, const int A, const int m_max, const int32_t* __restrict__ nbr,
-    const uint8_t* __restrict__ action /*[E,N]*/, float* __restrict__ y /*[N,E,m_max*A]*/) {
+    const uint8_t* __restrict__ action /*[E,N]*/, float* __restrict__ y /*[N,E,m_max*A]*/,
+    const int64_t y_agent_stride) {
     const int i = blockIdx.y;
     const int W = m_max * A;
     const int64_t n = E * W;
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void nbr_onehot_kernel(
         const int j = nbr[i * m_max + k];
         float val = 0.0f;
         if (j >= 0) val = action[e * N + j] == a ? 1.0f : 0.0f;
-        y[(int64_t)i * n + idx] = val;
+        y[(int64_t)i * y_agent_stride + idx] = val;
     }
 }
 
@@ -202,10 +203,10 @@ extern "C" int nmarl_nbr_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max
 }
 
 extern "C" int nmarl_nbr_onehot(int64_t E, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
-                                const uint8_t* action, float* y, void* stream) {
-    if (!args_ok(E, N, A, m_max, nbr_idx, action, y)) return NMARL_EINVAL;
+                                const uint8_t* action, float* y, int64_t y_agent_stride, void* stream) {
+    if (!args_ok(E, N, A, m_max, nbr_idx, action, y) || y_agent_stride < E * m_max * A) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipLaunchKernelGGL(nbr_onehot_kernel, dim3(grid_x(E * m_max * A), N), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), E, N, A, m_max, nbr_idx, action, y);
+                       static_cast<hipStream_t>(stream), E, N, A, m_max, nbr_idx, action, y, y_agent_stride);
     return nmarl_check_launch();
 }

@@ -86,8 +86,10 @@ def nbr_onehot(action, nbr_idx, n_a, out=None):
     m = nbr_idx.shape[1]
     if out is None:
         out = torch.empty(N, E, m * n_a, dtype=F32, device=action.device)
-    check(lib.nmarl_nbr_onehot(E, N, n_a, m, ptr(nbr_idx, torch.int32), ptr(action, torch.uint8), ptr(out, F32),
-                               stream()), 'nmarl_nbr_onehot')
+    if out.stride(2) != 1 or out.stride(1) != m * n_a:
+        raise _lib.NmarlError('nbr_onehot: out must be [N,E,W] with contiguous [E,W] panels')
+    check(lib.nmarl_nbr_onehot(E, N, n_a, m, ptr(nbr_idx, torch.int32), ptr(action, torch.uint8),
+                               ptr(out, F32, strided=True), out.stride(0), stream()), 'nmarl_nbr_onehot')
     return out
 
 
@@ -144,11 +146,13 @@ def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out):
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2
 
 
-def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0):
-    """pi [N,E,A] -> out [E,N] uint8 (utils.py:135-141)."""
+def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+    """pi [N,E,A] -> out [E,N] uint8 (utils.py:135-141).  step_dev: optional device int64 scalar
+    holding the global lock-step (Philox counter) -- used inside captured hipGraphs."""
     N, E, A = pi.shape
-    check(lib.nmarl_sample_actions(E, N, A, ptr(pi, F32), ptr(u, F32), mode, seed, env_id_base, step,
-                                   ptr(out, torch.uint8), stream()), 'nmarl_sample_actions')
+    check(lib.nmarl_sample_actions(E, N, A, ptr(pi, F32), ptr(u, F32), mode, seed, env_id_base, int(step),
+                                   ptr(step_dev, torch.int64), ptr(out, torch.uint8), stream()),
+          'nmarl_sample_actions')
     return out
 
 

@@ -1,0 +1,462 @@
+"""Rollout / training loops -- the reference's root utils.py (Counter 70-97,
+Trainer 100-254, Evaluator 311-336) plus the batched MI355X trainer.
+
+  * `Trainer`         the reference's single-replica loop, semantics unchanged
+                      (quirks Q1-Q5 of SURVEY.md 3.2, global np.random action draws,
+                      CACC test episode after every training episode,
+                      train_reward.csv).  It drives any env with the reference
+                      duck-type (envs.cacc_env.CACCEnv is the GPU E=1 adapter).
+  * `BatchedTrainer`  E lock-stepped replicas, everything resident in HBM: the
+                      n_step rollout (policy step x2, action draw, env step) is
+                      one captured hipGraph, the A2C update runs once per batch,
+                      data-parallel ranks exchange one flat gradient all-reduce.
+  * `Evaluator`       the reference's evaluation loop over test seeds.
+"""
+import itertools
+import logging
+import os
+import subprocess
+import time
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import ops
+
+
+# ------------------------------------------------------------------ small helpers (utils.py:11-60)
+def check_dir(cur_dir):
+    return os.path.exists(cur_dir)
+
+
+def copy_file(src_dir, tar_dir):
+    subprocess.check_call('cp %s %s' % (src_dir, tar_dir), shell=True)
+
+
+def find_file(cur_dir, suffix='.ini'):
+    for file in os.listdir(cur_dir):
+        if file.endswith(suffix):
+            return cur_dir + '/' + file
+    logging.error('Cannot find %s file' % suffix)
+    return None
+
+
+def init_dir(base_dir, pathes=('log', 'data', 'model')):
+    if not os.path.exists(base_dir):
+        os.makedirs(base_dir)
+    dirs = {}
+    for path in pathes:
+        cur_dir = base_dir + '/%s/' % path
+        if not os.path.exists(cur_dir):
+            os.mkdir(cur_dir)
+        dirs[path] = cur_dir
+    return dirs
+
+
+def init_log(log_dir):
+    logging.basicConfig(format='%(asctime)s [%(levelname)s] %(message)s', level=logging.INFO,
+                        handlers=[logging.FileHandler('%s/%d.log' % (log_dir, time.time())),
+                                  logging.StreamHandler()])
+
+
+class Counter:
+    """utils.py:70-97."""
+
+    def __init__(self, total_step, test_step, log_step):
+        self.counter = itertools.count(1)
+        self.cur_step = 0
+        self.cur_test_step = 0
+        self.total_step = total_step
+        self.test_step = test_step
+        self.log_step = log_step
+        self.stop = False
+
+    def next(self):
+        self.cur_step = next(self.counter)
+        return self.cur_step
+
+    def advance(self, n):
+        """Batched path: n environment steps at once."""
+        self.cur_step += n
+        self.counter = itertools.count(self.cur_step + 1)
+        return self.cur_step
+
+    def should_test(self):
+        test = False
+        if (self.cur_step - self.cur_test_step) >= self.test_step:
+            test = True
+            self.cur_test_step = self.cur_step
+        return test
+
+    def should_log(self):
+        return self.cur_step % self.log_step == 0
+
+    def should_stop(self):
+        if self.cur_step >= self.total_step:
+            return True
+        return self.stop
+
+
+class SummaryWriter:
+    """Stand-in for tf.summary.FileWriter (tensorboard is not part of this path): scalars go to
+    a JSON-lines file `<log_dir>/scalars.jsonl`."""
+
+    def __init__(self, log_dir=None):
+        self.path = None if log_dir is None else os.path.join(log_dir, 'scalars.jsonl')
+        self._rows = []
+
+    def add_scalar(self, tag, value, global_step):
+        self._rows.append('{"tag": "%s", "value": %.9g, "step": %d}' % (tag, float(value), int(global_step)))
+
+    def flush(self):
+        if self.path and self._rows:
+            with open(self.path, 'a') as f:
+                f.write('\n'.join(self._rows) + '\n')
+        self._rows = []
+
+
+# ------------------------------------------------------------------ reference-compatible loop
+class Trainer:
+    """The reference's Trainer (utils.py:100-254) for ONE replica."""
+
+    def __init__(self, env, model, global_counter, summary_writer, output_path=None):
+        self.cur_step = 0
+        self.global_counter = global_counter
+        self.env = env
+        self.agent = self.env.agent
+        self.model = model
+        self.n_step = self.model.n_step
+        self.summary_writer = summary_writer
+        assert self.env.T % self.n_step == 0
+        self.data = []
+        self.output_path = output_path
+        self.env.train_mode = True
+
+    def _add_summary(self, reward, global_step, is_train=True):
+        if self.summary_writer is not None:
+            self.summary_writer.add_scalar('train_reward' if is_train else 'test_reward', reward, global_step)
+
+    def _get_policy(self, ob, done, mode='train'):
+        if self.agent.startswith('ma2c'):
+            self.ps = self.env.get_fingerprint()
+            policy = self.model.forward(ob, done, self.ps)
+        else:
+            policy = self.model.forward(ob, done)
+        action = []
+        for pi in policy:
+            if mode == 'train':
+                action.append(np.random.choice(np.arange(len(pi)), p=pi))     # global MT19937 stream (Q5)
+            else:
+                action.append(np.argmax(pi))
+        return policy, np.array(action)
+
+    def _get_value(self, ob, done, action):
+        if self.agent.startswith('ma2c'):
+            value = self.model.forward(ob, done, self.ps, np.array(action), 'v')
+        else:
+            self.naction = self.env.get_neighbor_action(action)
+            value = self.model.forward(ob, done, self.naction, 'v')
+        return value
+
+    def _log_episode(self, global_step, mean_reward, std_reward):
+        self.data.append({'agent': self.agent, 'step': global_step, 'test_id': -1,
+                          'avg_reward': mean_reward, 'std_reward': std_reward})
+        self._add_summary(mean_reward, global_step)
+        if self.summary_writer is not None:
+            self.summary_writer.flush()
+
+    def explore(self, prev_ob, prev_done):
+        ob, done = prev_ob, prev_done
+        for _ in range(self.n_step):
+            policy, action = self._get_policy(ob, done)          # pre-decision
+            value = self._get_value(ob, done, action)            # post-decision (double-stepped LSTM: Q1)
+            self.env.update_fingerprint(policy)
+            next_ob, reward, done, global_reward = self.env.step(action)
+            self.episode_rewards.append(global_reward)
+            global_step = self.global_counter.next()
+            self.cur_step += 1
+            if self.agent.startswith('ma2c'):
+                self.model.add_transition(ob, self.ps, action, reward, value, done)
+            else:
+                self.model.add_transition(ob, self.naction, action, reward, value, done)
+            if self.global_counter.should_log():
+                logging.info('Training: global step %d, episode step %d, a: %s, r: %.2f, train r: %.2f, done: %r' %
+                             (global_step, self.cur_step, str(action), global_reward, np.mean(reward), done))
+            if done:                                             # terminal check inside the batch loop
+                break
+            ob = next_ob
+        if done:
+            R = np.zeros(self.model.n_agent)
+        else:
+            _, action = self._get_policy(ob, done)               # advances the LSTM state once more (Q2)
+            R = self._get_value(ob, done, action)
+        return ob, done, R
+
+    def perform(self, test_ind, gui=False):
+        ob = self.env.reset(gui=gui, test_ind=test_ind)
+        rewards = []
+        done = True                                              # pre-decision done resets the LSTM (Q3)
+        self.model.reset()
+        while True:
+            if self.env.name.startswith('atsc'):
+                policy, action = self._get_policy(ob, done)
+            else:
+                policy, action = self._get_policy(ob, done, mode='test')   # CACC: deterministic test policy
+            self.env.update_fingerprint(policy)
+            next_ob, reward, done, global_reward = self.env.step(action)
+            rewards.append(global_reward)
+            if done:
+                break
+            ob = next_ob
+        return np.mean(np.array(rewards)), np.std(np.array(rewards))
+
+    def run(self):
+        while not self.global_counter.should_stop():
+            ob = self.env.reset()
+            done = True
+            self.model.reset()
+            self.cur_step = 0
+            self.episode_rewards = []
+            while True:
+                ob, done, R = self.explore(ob, done)
+                dt = self.env.T - self.cur_step
+                global_step = self.global_counter.cur_step
+                self.model.backward(R, dt, self.summary_writer, global_step)
+                if done:
+                    self.env.terminate()
+                    break
+            rewards = np.array(self.episode_rewards)
+            mean_reward, std_reward = np.mean(rewards), np.std(rewards)
+            if not self.env.name.startswith('atsc'):
+                # CACC: the logged reward is that of a deterministic TEST episode (utils.py:246-251)
+                self.env.train_mode = False
+                mean_reward, std_reward = self.perform(-1)
+                self.env.train_mode = True
+            self._log_episode(global_step, mean_reward, std_reward)
+        if self.output_path is not None:
+            pd.DataFrame(self.data).to_csv(self.output_path + 'train_reward.csv')
+
+
+class Evaluator(Trainer):
+    """utils.py:311-336: one `perform` per test seed, then env.output_data()."""
+
+    def __init__(self, env, model, output_path, gui=False):
+        self.env = env
+        self.model = model
+        self.agent = self.env.agent
+        self.env.train_mode = False
+        self.test_num = self.env.test_num
+        self.output_path = output_path
+        self.gui = gui
+
+    def run(self):
+        is_record = not self.gui
+        self.env.cur_episode = 0
+        self.env.init_data(is_record, False, self.output_path)
+        rewards = []
+        for test_ind in range(self.test_num):
+            reward, _ = self.perform(test_ind, gui=self.gui)
+            self.env.terminate()
+            logging.info('test %i, avg reward %.2f' % (test_ind, reward))
+            rewards.append(reward)
+            self.env.collect_tripinfo()
+        self.env.output_data()
+        return rewards
+
+
+# ------------------------------------------------------------------ the MI355X loop
+class BatchedTrainer:
+    """E lock-stepped replicas on one GPU (one process per GPU under torch.distributed).
+
+    One `run_batch()` = the reference's `explore` + `model.backward` for every replica:
+    n_step lock-steps (each: policy step, Philox action draw, value re-step, env kernel,
+    transition store), the bootstrap value, then one A2C update.  Episodes end only at batch
+    boundaries (Q4) so every replica contributes exactly n_step transitions; finished
+    replicas are re-initialised by the env kernel's fused auto-reset at the last step and
+    their LSTM state / fingerprints are cleared after the update, which is what the
+    reference does at the next `env.reset(); model.reset()`.
+    """
+
+    def __init__(self, env, model, global_counter=None, summary_writer=None, output_path=None,
+                 use_graph=True, rank=0, world_size=1):
+        self.env, self.model = env, model
+        self.E, self.N = env.E, env.n_agent
+        self.n_step = model.n_step
+        assert env.T % self.n_step == 0
+        assert getattr(env, 'batch_size', self.n_step) == self.n_step, \
+            'ENV_CONFIG batch_size must equal MODEL_CONFIG batch_size (episodes end at batch boundaries)'
+        self.global_counter = global_counter
+        self.summary_writer = summary_writer
+        self.output_path = output_path
+        self.rank, self.world_size = rank, world_size
+        d = env.device
+        self.device = d
+        self.action = torch.zeros(self.E, self.N, dtype=torch.uint8, device=d)
+        self.action_boot = torch.zeros(self.E, self.N, dtype=torch.uint8, device=d)
+        self.done_pre = torch.ones(self.E, dtype=torch.float32, device=d)       # episode start (Q3)
+        self.zero_done = torch.zeros(self.E, dtype=torch.float32, device=d)
+        self.step_dev = torch.zeros((), dtype=torch.int64, device=d)            # global lock-step (Philox counter)
+        self.R_end = torch.zeros(self.N, self.E, dtype=torch.float32, device=d)
+        self.buf_g = torch.zeros(self.n_step, self.E, dtype=torch.float32, device=d)
+        self.last_done = torch.zeros(self.E, dtype=torch.uint8, device=d)
+        # per-replica running episode statistics (sum, sum of squares, length) of the global reward
+        self.ep_sum = torch.zeros(self.E, dtype=torch.float64, device=d)
+        self.ep_sq = torch.zeros(self.E, dtype=torch.float64, device=d)
+        self.ep_len = torch.zeros(self.E, dtype=torch.float64, device=d)
+        self.fin = torch.zeros(4, dtype=torch.float64, device=d)   # episodes, sum(mean), sum(std), collisions
+        self.use_graph = use_graph and d.type == 'cuda'
+        self.graph = None
+        self.data = []
+        self.n_batches = 0
+        env.train_mode = True
+        env.reset()
+        model.reset_states()
+
+    # -- the n_step rollout (graph body)
+    def _rollout(self):
+        env, model = self.env, self.model
+        model.t = 0
+        for t in range(self.n_step):
+            done_in = self.done_pre if t == 0 else self.zero_done
+            model.act(env.obs, done_in, self.action, mode=ops.SAMPLE_PHILOX, seed=env.seed,
+                      env_id_base=env.env_id_base, step_dev=self.step_dev)
+            _, r, d, g = env.step(self.action, auto_reset=(t == self.n_step - 1))
+            model.record(r, d)
+            self.buf_g[t].copy_(g)
+            self.step_dev.add_(1)
+        self.last_done.copy_(env.done)
+        # bootstrap value for unfinished replicas (utils.py:192-196); finished ones get R = 0
+        v = model.bootstrap(env.obs, self.zero_done, self.action_boot, mode=ops.SAMPLE_PHILOX, seed=env.seed,
+                            env_id_base=env.env_id_base, step_dev=self.step_dev)
+        self.step_dev.add_(1)
+        self.R_end.copy_(v * (1.0 - self.last_done.to(torch.float32)).view(1, -1))
+
+    def rollout(self):
+        if not self.use_graph:
+            self._rollout()
+            return
+        if self.graph is None:
+            # warm-up on a side stream (allocator + rocBLAS handles), restoring all mutated state after
+            snap = self._snapshot()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._rollout()
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._restore(snap)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._rollout()
+            self._restore(snap)
+        self.model.t = 0
+        self.graph.replay()
+        self.model.t = self.n_step
+
+    def _state_tensors(self):
+        env, m = self.env, self.model
+        ts = [env.h, env.v, env.u, env.t, env.collided, env.v0_init, env.obs, env.episode, env.done,
+              m.h_fw, m.c_fw, m.fp, self.step_dev, self.done_pre]
+        return [t for t in ts if t is not None]
+
+    def _snapshot(self):
+        return [t.clone() for t in self._state_tensors()]
+
+    def _restore(self, snap):
+        for t, s in zip(self._state_tensors(), snap):
+            t.copy_(s)
+
+    def run_batch(self):
+        """One rollout + update.  Returns nothing; statistics stay on the device until `stats()`."""
+        self.rollout()
+        self.model.update(self.R_end)
+        done = self.last_done
+        # episode bookkeeping, all on device
+        g = self.buf_g.double()
+        self.ep_sum += g.sum(0)
+        self.ep_sq += (g * g).sum(0)
+        self.ep_len += self.n_step
+        dm = done.bool()
+        mean = self.ep_sum / self.ep_len
+        std = (self.ep_sq / self.ep_len - mean * mean).clamp_min(0).sqrt()
+        dmf = dm.double()
+        coll = (self.ep_len < self.env.T).double() * dmf          # ended early == collision (cacc_env.py:231-233)
+        self.fin += torch.stack([dmf.sum(), (mean * dmf).sum(), (std * dmf).sum(), coll.sum()])
+        keep = 1.0 - dmf
+        self.ep_sum *= keep
+        self.ep_sq *= keep
+        self.ep_len *= keep
+        # next batch: finished replicas start a new episode (env already auto-reset)
+        self.model.reset_states(mask=done)
+        self.done_pre.copy_(done.to(torch.float32))
+        self.n_batches += 1
+        if self.global_counter is not None:
+            self.global_counter.advance(self.n_step * self.E * self.world_size)
+
+    def stats(self, reset=True):
+        """(episodes finished, mean of episode-mean reward, mean of episode-std, collisions) since last call."""
+        f = self.fin.cpu().numpy().copy()
+        if reset:
+            self.fin.zero_()
+        n = max(f[0], 1.0)
+        return dict(episodes=int(f[0]), avg_reward=f[1] / n, std_reward=f[2] / n, collisions=int(f[3]))
+
+    def evaluate(self, n_envs=64, seed=None):
+        """Deterministic (argmax) test episodes, the batched analogue of `perform(-1)` after a CACC
+        training episode (utils.py:199-223, 246-251): train_mode False -> no soft-collision term."""
+        from .envs import make_batch_env
+        env = make_batch_env(self.env.config, num_envs=n_envs, device=self.device,
+                             seed=self.env.seed - 1 if seed is None else seed, env_id_base=10 ** 9)
+        env.train_mode = False
+        model = self.model
+        saved = [t.clone() for t in (model.h_fw, model.c_fw, model.fp)]
+        E0 = model.E
+        h, c = (torch.zeros(self.N, n_envs, model.n_lstm, device=self.device) for _ in range(2))
+        fp = torch.full((self.N, n_envs, model.n_a), 1.0 / model.n_a, device=self.device)
+        env.reset()
+        done = torch.ones(n_envs, device=self.device)
+        act = torch.zeros(n_envs, self.N, dtype=torch.uint8, device=self.device)
+        total = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
+        alive = torch.ones(n_envs, dtype=torch.float64, device=self.device)
+        steps = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
+        for _ in range(env.T):
+            model.policy.step(env.obs, fp, h, c, done, h, c)
+            with torch.no_grad():
+                pi = model.policy.pi(h)
+            ops.sample_actions(pi, act, ops.SAMPLE_ARGMAX)
+            fp.copy_(pi)
+            _, _, d, g = env.step(act)
+            total += g.double() * alive
+            steps += alive
+            alive = alive * (1.0 - d.double())
+            done.zero_()
+        for t, s in zip((model.h_fw, model.c_fw, model.fp), saved):
+            t.copy_(s)
+        assert model.E == E0
+        per_ep = (total / steps.clamp_min(1)).cpu().numpy()
+        return float(per_ep.mean()), float(per_ep.std()), int((steps < env.T).sum().item())
+
+    def run(self, log_every=10, eval_every=0):
+        """Train until the counter says stop; logs one row per `log_every` batches."""
+        t0 = time.time()
+        while not self.global_counter.should_stop():
+            self.run_batch()
+            if self.n_batches % log_every == 0:
+                st = self.stats()
+                step = self.global_counter.cur_step
+                row = {'agent': self.env.agent, 'step': step, 'test_id': -1, 'avg_reward': st['avg_reward'],
+                       'std_reward': st['std_reward'], 'episodes': st['episodes'], 'collisions': st['collisions']}
+                if eval_every and (self.n_batches // log_every) % eval_every == 0:
+                    m, s, c = self.evaluate()
+                    row.update(test_avg_reward=m, test_std_reward=s, test_collisions=c)
+                self.data.append(row)
+                if self.rank == 0:
+                    logging.info('Training: env-steps %d, batches %d, %.0f env-steps/s, episodes %d, avg r %.2f, collisions %d'
+                                 % (step, self.n_batches, step / max(time.time() - t0, 1e-9), st['episodes'],
+                                    st['avg_reward'], st['collisions']))
+                    if self.summary_writer is not None:
+                        self.summary_writer.add_scalar('train_reward', st['avg_reward'], step)
+                        self.summary_writer.flush()
+        if self.output_path is not None and self.rank == 0:
+            pd.DataFrame(self.data).to_csv(self.output_path + 'train_reward.csv')

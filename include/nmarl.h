@@ -138,10 +138,12 @@ int nmarl_nbr_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int
  * One-hot of the neighbours' actions for the centralised critic:
  * y[i, e, k*A + a] = (action[e, nbr_idx[i,k]] == a); replaces
  * tf.one_hot(boolean_mask(action, mask_i)) of policies.py:66-68, 305 and
- * CACCEnv.get_neighbor_action (cacc_env.py:125-129).  action is env-major [E,N] u8.
+ * CACCEnv.get_neighbor_action (cacc_env.py:125-129).  action is env-major [E,N] u8;
+ * y_agent_stride = floats between consecutive agents of y (>= E*m_max*A; lets y be
+ * slot t of an [N,T,E,m_max*A] rollout buffer).
  */
 int nmarl_nbr_onehot(int64_t E, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
-                     const uint8_t* action, float* y, void* stream);
+                     const uint8_t* action, float* y, int64_t y_agent_stride, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Policy / update pointwise kernels                                          */
@@ -170,9 +172,12 @@ int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, con
  *   mode 1: same with u = Philox4x32-10(key=seed, ctr=(env_id_base+e, n>>2, step, 1))
  *           word n&3 (contract: oracle/philox.py);
  *   mode 2: np.argmax (deterministic test policy, utils.py:140).
+ * step_dev (device i64, may be NULL) overrides `step`: lets a captured hipGraph of the
+ * rollout advance the Philox counter without re-capturing.
  */
 int nmarl_sample_actions(int64_t E, int32_t N, int32_t A, const float* pi, const float* u, int32_t mode,
-                         uint64_t seed, int64_t env_id_base, int64_t step, uint8_t* action, void* stream);
+                         uint64_t seed, int64_t env_id_base, int64_t step, const int64_t* step_dev,
+                         uint8_t* action, void* stream);
 /*
  * n-step return and advantage -- OnPolicyBuffer._add_R_Adv / _add_s_R_Adv
  * (agents/utils.py:763-775, 800-816) and the MultiAgent variants (837-855,

@@ -68,10 +68,12 @@ def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out):
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2
 
 
-def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0):
+def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None):
     """np.random.choice == searchsorted(cumsum(p)/sum, u, 'right') (utils.py:138); argmax (utils.py:140)."""
     from oracle import philox
     N, E, A = pi.shape
+    if step_dev is not None:
+        step = int(step_dev.item())
     p = pi.detach().cpu().numpy().astype(np.float64).transpose(1, 0, 2)       # [E,N,A]
     if mode == SAMPLE_ARGMAX:
         a = p.argmax(-1)

@@ -24,3 +24,65 @@ def cpu_ops():
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
+
+
+class CpuCaccBatchEnv:
+    """TEST-ONLY stand-in for envs.cacc_env.CACCBatchEnv on CPU tensors, built on the oracle
+    (oracle/cacc_ref.py fp32 + oracle/philox.py): same attributes / reset / step contract."""
+
+    def __init__(self, config, num_envs=1, device='cpu', env_id_base=0, seed=None):
+        import numpy as np
+        import torch
+        from oracle.cacc_ref import CaccBatchRef, CaccParams
+        self.config, self.E, self.device = config, num_envs, torch.device(device)
+        self.p = CaccParams(config=config)
+        self.ref = CaccBatchRef(self.p, E=num_envs, dtype=np.float32)
+        self.n_agent, self.agent, self.name = self.p.n_agent, self.p.agent, self.p.name
+        self.coop_gamma, self.T, self.batch_size = self.p.coop_gamma, self.p.T, self.p.batch_size
+        self.seed = self.p.seed if seed is None else seed
+        self.env_id_base = env_id_base
+        self.neighbor_mask, self.distance_mask = self.ref.neighbor_mask, self.ref.distance_mask
+        self.n_a, self.n_a_ls = 4, [4] * self.n_agent
+        self.n_s_ls = [5 if self.agent.startswith('ma2c') else 5 * (1 + int(self.neighbor_mask[i].sum()))
+                       for i in range(self.n_agent)]
+        self.episode = torch.zeros(num_envs, dtype=torch.int32)
+        self.obs = torch.zeros(num_envs, self.n_agent, 15)
+        self.done = torch.zeros(num_envs, dtype=torch.uint8)
+        self.reward = torch.zeros(num_envs)
+        self.global_reward = torch.zeros(num_envs)
+
+    train_mode = property(lambda self: self.ref.train_mode, lambda self, f: setattr(self.ref, 'train_mode', bool(f)))
+
+    def _emit(self):
+        import torch
+        from oracle.cacc_ref import gather_line
+        self.obs.copy_(torch.from_numpy(gather_line(self.ref.veh_state())))
+        return self.obs
+
+    def reset(self, mask=None, u0=None):
+        import numpy as np
+        from oracle import philox
+        m = np.ones(self.E, bool) if mask is None else mask.numpy().astype(bool)
+        ep = self.episode.numpy()
+        U = philox.reset_uniform(self.seed, self.env_id_base + np.arange(self.E), ep) if u0 is None else u0.numpy()
+        if u0 is None:
+            ep[m] += 1
+        self.ref.reset(U, mask=None if mask is None and not hasattr(self.ref, 'h') else m)
+        return self._emit()
+
+    def step(self, action, auto_reset=False):
+        import torch
+        _, r, d, g = self.ref.step(action.numpy())
+        self.reward.copy_(torch.from_numpy(np_f32(r)))
+        self.global_reward.copy_(torch.from_numpy(np_f32(g)))
+        self.done.copy_(torch.from_numpy(d.astype('uint8')))
+        if auto_reset and d.any():
+            self.reset(mask=torch.from_numpy(d.astype('uint8')))
+        else:
+            self._emit()
+        return self.obs, self.reward, self.done, self.global_reward
+
+
+def np_f32(x):
+    import numpy as np
+    return np.asarray(x, dtype=np.float32)

@@ -1,0 +1,72 @@
+"""Host logic of the batched trainer on CPU (HIP ops and the env replaced by their oracle
+restatements, tests/cpu_emulation.py): buffer slots, batch-boundary resets, bootstrap masking,
+episode statistics, and E=1 equivalence of the batched engine with the reference-API path."""
+import numpy as np
+import pytest
+import torch
+
+from cpu_emulation import CpuCaccBatchEnv, cpu_ops
+from helpers import cacc_config
+
+
+def build(agent, E, n_step=10, seed=12, scenario='catchup'):
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    cp = cacc_config(agent=agent, n_step=n_step, scenario=scenario, seed=seed, reward_norm=800.0)
+    # shorten the episode so the test sees episode boundaries: T = 3 batches
+    cp['ENV_CONFIG']['episode_length_sec'] = '3'
+    env = CpuCaccBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+    assert env.T == 3 * n_step
+    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3}[agent]
+    np.random.seed(seed)
+    model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 6,
+                cp['MODEL_CONFIG'], seed=seed, num_envs=E, device='cpu')
+    tr = BatchedTrainer(env, model, Counter(10 ** 6, 10 ** 7, 10 ** 4), use_graph=False)
+    return env, model, tr
+
+
+@pytest.mark.parametrize('agent', ['ia2c', 'ia2c_fp', 'ma2c_nc', 'ma2c_ic3'])
+def test_batched_trainer_runs_and_learns_something(agent):
+    with cpu_ops():
+        env, model, tr = build(agent, E=5)
+        w0 = model.policy.params.flat.clone()
+        for _ in range(7):
+            tr.run_batch()
+        assert torch.isfinite(model.policy.params.flat).all()
+        assert not torch.equal(w0, model.policy.params.flat)
+        st = tr.stats()
+        assert st['episodes'] == 5 * 2          # 7 batches = 2 full episodes (+1 batch) per replica
+        assert np.isfinite(st['avg_reward'])
+        assert tr.global_counter.cur_step == 7 * 10 * 5
+        assert int(tr.step_dev.item()) == 7 * 11   # n_step draws + 1 bootstrap draw per batch
+
+
+def test_batch_invariance_of_rollout():
+    """Replica e of an E-replica rollout == the same replica rolled out alone (same Philox ids)."""
+    with cpu_ops():
+        env, model, tr = build('ma2c_nc', E=4)
+        tr._rollout()
+        big = (model.buf_act.clone(), model.buf_v.clone(), tr.R_end.clone(), env.obs.clone())
+        for e in (0, 3):
+            cp_env, m1, t1 = build('ma2c_nc', E=1)
+            cp_env.env_id_base = e
+            cp_env.episode.zero_()
+            cp_env.reset()
+            t1._rollout()
+            assert torch.equal(m1.buf_act[:, 0], big[0][:, e])
+            torch.testing.assert_close(m1.buf_v[:, :, 0], big[1][:, :, e], rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(t1.R_end[:, 0], big[2][:, e], rtol=1e-5, atol=1e-6)
+
+
+def test_finished_replicas_restart_clean():
+    with cpu_ops():
+        env, model, tr = build('ia2c_fp', E=3)
+        for _ in range(3):
+            tr.run_batch()
+        # T = 3 batches: every replica just finished its first episode
+        assert torch.all(tr.done_pre == 1) and torch.all(env.episode == 2)
+        assert torch.all(model.h_fw == 0) and torch.all(model.c_bw == 0)
+        assert torch.allclose(model.fp, torch.full_like(model.fp, 0.25))
+        assert torch.all(tr.R_end == 0)
+        tr.run_batch()
+        assert torch.all(tr.done_pre == 0) and not torch.all(model.h_fw == 0)

@@ -174,11 +174,14 @@ class BatchedPolicy:
         T, E = done.shape
         Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)       # [N, T*E, n_obs], no copy
         pre = self._pre_all(Xv, FP, T, E)
+        # per-step views via ONE unbind: its backward is a single stack, whereas slicing `pre` inside
+        # the loop would make autograd materialise and add T full-size zero tensors (O(T^2) traffic)
+        pre_steps = pre.view(self.N, T, E, pre.shape[-1]).unbind(1)
         h, c = h0, c0
         hs = []
         wh, b = self.params[self.k_wh], self.params[self.k_b]
         for t in range(T):
-            zx = self._pre_t(pre, t, E, h)
+            zx = self._pre_t(pre_steps[t], h)
             keep = (1.0 - done[t]).view(1, -1, 1)
             z = torch.baddbmm(zx, h * keep, wh)
             h, c = ops.lstm_cell(z, b, c, done[t])
@@ -209,8 +212,8 @@ class LstmPolicy(BatchedPolicy):
     def _pre_all(self, Xv, FP, T, E):
         return torch.bmm(self._encode(Xv, None), self.params['lstm_wx'])
 
-    def _pre_t(self, pre, t, E, h):
-        return pre[:, t * E:(t + 1) * E]
+    def _pre_t(self, pre_t, h):
+        return pre_t
 
 
 class FPPolicy(LstmPolicy):
@@ -283,8 +286,8 @@ class NCMultiAgentPolicy(BatchedPolicy):
     def _pre_all(self, Xv, FP, T, E):
         return self._zxp(Xv, ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx))
 
-    def _pre_t(self, pre, t, E, h):
-        return self._msg(pre[:, t * E:(t + 1) * E], h)
+    def _pre_t(self, pre_t, h):
+        return self._msg(pre_t, h)
 
 
 class IC3MultiAgentPolicy(BatchedPolicy):
@@ -322,5 +325,5 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     def _pre_all(self, Xv, FP, T, E):
         return self._sx(Xv)
 
-    def _pre_t(self, pre, t, E, h):
-        return self._msg(pre[:, t * E:(t + 1) * E], h)
+    def _pre_t(self, pre_t, h):
+        return self._msg(pre_t, h)

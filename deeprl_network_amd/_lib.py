@@ -31,6 +31,12 @@ class CaccParams(C.Structure):
                [(n, C.c_int32) for n in ('T', 'batch_size', 'scenario', 'train_mode', 'per_agent_reward')]
 
 
+class GridParams(C.Structure):
+    """nmarl_grid_params_t (include/nmarl.h)."""
+    _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('peak1', C.c_float), ('peak2', C.c_float),
+                ('T', C.c_int32), ('per_agent_reward', C.c_int32)]
+
+
 _p = C.c_void_p
 _i64 = C.c_int64
 _i32 = C.c_int32
@@ -44,6 +50,8 @@ SIGNATURES = {
                          _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p],
     'nmarl_cacc_step': [C.POINTER(CaccParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                         _i32, _u64, _i64, _p, _p],
+    'nmarl_grid_reset': [C.POINTER(GridParams), _i64, _p, _p, _u64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
+    'nmarl_grid_step': [C.POINTER(GridParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _u64, _i64, _p, _p],
     'nmarl_nbr_gather_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_gather_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_mean_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],

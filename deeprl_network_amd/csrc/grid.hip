@@ -1,0 +1,312 @@
+// Synthetic (SUMO-free) 5x5 ATSC grid for E lock-stepped replicas on gfx950.
+//
+// Contract taken from the reference (envs/atsc_env.py:181-207 step, 216-240 yellow,
+// 383-462 reward/state; envs/large_grid_env.py:23-27 phases, 58-105 topology;
+// envs/large_grid_data/build_file.py:268-326 demand).  The dynamics are the
+// store-and-forward model SPECIFIED in oracle/grid_ref.py (SUMO is not available,
+// so the dynamics are "parity unpinned" w.r.t. the reference; the oracle is the spec).
+//
+// Mapping: one replica per 32-lane half wave, lane = intersection (25 of 32 lanes
+// active), two replicas per wave64, 8 per 256-thread block.  A replica's state
+// (q, transit: 2 x 25 x 6 fp32 = 1200 B, contiguous) is loaded with coalesced
+// accesses into LDS; the neighbour exchange (desired link flows D, receiving space,
+// spill-back scale) goes through LDS with wave barriers -- the 4-neighbourhood of the
+// lattice never leaves the half wave; the gathered observation slab [25, 5*12]
+// (own + up to 4 neighbours in ascending node index) is assembled in LDS and written
+// with 16-byte coalesced stores (6000 contiguous bytes per replica).
+// HBM-bound (about 8.5 KB per replica-step); no MFMA.
+#include "common.h"
+
+namespace {
+
+constexpr int NN = NMARL_GRID_N;        // 25
+constexpr int SIDE = 5;
+constexpr int NL = 12;                  // signal links per node
+constexpr int NLANE = 6;
+constexpr int NSLOT = 5;                // own + 4 neighbour slots
+constexpr int OBSW = NSLOT * NL;        // 60
+constexpr float DT = 5.0f, YELLOW = 2.0f, SAT = 0.5f, Q_MAX = 26.0f, DET_CAP = 7.0f, YELLOW_EFF = 1.0f;
+
+// large_grid_env.py:25-26   0 = r, 1 = G, 2 = g
+__constant__ uint8_t c_green[5][NL] = {
+    {1, 1, 2, 0, 0, 0, 1, 1, 2, 0, 0, 0}, {0, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 1}, {0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1, 0},
+    {0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1}};
+__constant__ int8_t c_link_lane[NL] = {0, 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5};
+__constant__ float c_link_share[NL] = {.2f, .6f, .2f, .15f / .85f, .7f / .85f, 1.0f,
+                                       .2f, .6f, .2f, .15f / .85f, .7f / .85f, 1.0f};
+__constant__ int8_t c_lane_approach[NLANE] = {0, 1, 1, 2, 3, 3};
+__constant__ float c_split[NLANE] = {1.0f, 0.85f, 0.15f, 1.0f, 0.85f, 0.15f};
+// link -> (drow, dcol, receiving approach)
+__constant__ int8_t c_dest[NL][3] = {{0, -1, 1}, {-1, 0, 0}, {0, 1, 3}, {1, 0, 2}, {0, -1, 1}, {-1, 0, 0},
+                                     {0, 1, 3}, {1, 0, 2}, {0, -1, 1}, {-1, 0, 0}, {0, 1, 3}, {1, 0, 2}};
+__constant__ int8_t c_from[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
+__constant__ int8_t c_feed[4][3] = {{1, 5, 9}, {0, 4, 8}, {3, 7, 11}, {2, 6, 10}};
+__constant__ float c_ratio1[7] = {0.4f, 0.7f, 0.9f, 1.0f, 0.75f, 0.5f, 0.25f};
+__constant__ float c_ratio2[7] = {0.3f, 0.8f, 0.9f, 1.0f, 0.8f, 0.6f, 0.2f};
+// entry group (+1) per (node, approach); 0 = no external entry          build_file.py:285-295
+__constant__ int8_t c_entry[NN][4] = {
+    {0, 0, 0, 2}, {0, 0, 3, 0}, {0, 0, 3, 0}, {0, 0, 3, 0}, {0, 4, 0, 0},
+    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
+    {0, 0, 0, 2}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 4, 0, 0},
+    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
+    {0, 0, 0, 2}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {0, 4, 0, 0}};
+
+__device__ __forceinline__ float demand_rate(int group, int sec, float peak1, float peak2) {
+    const int piece = sec / 300;
+    if (group < 2) {
+        if (piece >= 7) return 0.0f;
+        return peak1 * (group == 0 ? 0.6f : 1.0f) * c_ratio1[piece];
+    }
+    if (piece < 3 || piece >= 10) return 0.0f;
+    return peak2 * (group == 2 ? 0.6f : 1.0f) * c_ratio2[piece - 3];
+}
+
+struct Lds {           // per replica
+    float q[NN * NLANE];
+    float tr[NN * NLANE];
+    float D[NN * NL];
+    float space[NN * 4];
+    float scale[NN * 4];
+    float inflow[NN * 4];
+    float wave[NN * NL];
+};
+
+__device__ __forceinline__ void half_barrier() { __builtin_amdgcn_wave_barrier(); }
+
+// ascending-index neighbour k of node n (or -1): order S(n-5), W(n-1), E(n+1), N(n+5)
+__device__ __forceinline__ int nbr_of(int n, int k) {
+    const int r = n / SIDE, c = n - r * SIDE;
+    int cand[4] = {r > 0 ? n - SIDE : -1, c > 0 ? n - 1 : -1, c < SIDE - 1 ? n + 1 : -1, r < SIDE - 1 ? n + SIDE : -1};
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (cand[i] >= 0) {
+            if (cnt == k) return cand[i];
+            ++cnt;
+        }
+    }
+    return -1;
+}
+
+__device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ obs_env, int l32) {
+    // 25 x 60 floats = 375 float4, coalesced
+    float4* dst = reinterpret_cast<float4*>(obs_env);
+    for (int v = l32; v < NN * OBSW / 4; v += 32) {
+        const int node = v / (OBSW / 4);
+        const int w = (v - node * (OBSW / 4)) * 4;          // first float within the 60-wide row
+        const int slot = w / NL, f = w - slot * NL;          // 12 % 4 == 0: a float4 never straddles slots
+        const int src = slot == 0 ? node : nbr_of(node, slot - 1);
+        float4 val = float4{0.f, 0.f, 0.f, 0.f};
+        if (src >= 0) {
+            const float* p = s.wave + src * NL + f;
+            val = float4{p[0], p[1], p[2], p[3]};
+        }
+        dst[v] = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_step_kernel(
+    const nmarl_grid_params_t p, const int64_t E, const uint8_t* __restrict__ action,
+    float* __restrict__ qs, float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts,
+    float* __restrict__ xi, float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+    float* __restrict__ greward, const int auto_reset, const uint64_t seed, const int64_t env_id_base,
+    int32_t* __restrict__ episode) {
+    __shared__ __attribute__((aligned(16))) Lds lds[8];
+    const int l32 = threadIdx.x & 31;
+    const int sub = threadIdx.x >> 5;                       // replica slot in the block (0..7)
+    Lds& s = lds[sub];
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    for (int64_t e0 = (int64_t)blockIdx.x * 8; e0 < E; e0 += stride) {
+        const int64_t e = e0 + sub;
+        const bool live = e < E;
+        const int64_t ec = live ? e : E - 1;
+        // ---- A. coalesced load of the replica's state into LDS
+        const float* qg = qs + ec * NN * NLANE;
+        const float* tg = trs + ec * NN * NLANE;
+        for (int i = l32; i < NN * NLANE; i += 32) { s.q[i] = qg[i]; s.tr[i] = tg[i]; }
+        const int t = ts[ec];
+        half_barrier();
+        const int n = l32;
+        const bool node = n < NN;
+        const int row = n / SIDE, col = n - row * SIDE;
+        int a = 0, pa = 0;
+        float q[NLANE], tr[NLANE], D[NL];
+        if (node) {
+            a = action[ec * NN + n];
+            pa = prev[ec * NN + n];
+            a = a > 4 ? 4 : a;
+#pragma unroll
+            for (int l = 0; l < NLANE; ++l) { q[l] = s.q[n * NLANE + l]; tr[l] = s.tr[n * NLANE + l]; }
+            // ---- B. desired link flows and receiving space
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int gc = c_green[a][k], gp = c_green[pa][k];
+                float g = gc ? (gp ? DT : DT - YELLOW) : (gp ? YELLOW_EFF : 0.0f);
+                if (a == pa) g = gc ? DT : 0.0f;
+                if (gc == 2) g *= 0.5f;
+                const float sh = c_link_share[k];
+                D[k] = fminf(q[c_link_lane[k]] * sh, SAT * g * sh);
+                s.D[n * NL + k] = D[k];
+            }
+            float sp[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int l = 0; l < NLANE; ++l) sp[c_lane_approach[l]] += fmaxf(Q_MAX - q[l] - tr[l], 0.0f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s.space[n * 4 + r] = sp[r];
+        }
+        half_barrier();
+        // ---- C. spill-back scale of every receiving approach
+        if (node) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = row + c_from[r][0], cc = col + c_from[r][1];
+                float in = 0.0f;
+                if (rr >= 0 && rr < SIDE && cc >= 0 && cc < SIDE) {
+                    const float* Dm = s.D + (rr * SIDE + cc) * NL;
+                    in = Dm[c_feed[r][0]] + Dm[c_feed[r][1]] + Dm[c_feed[r][2]];
+                }
+                const float sc = fminf(1.0f, s.space[n * 4 + r] / fmaxf(in, 1e-6f));
+                s.scale[n * 4 + r] = sc;
+                s.inflow[n * 4 + r] = in * sc;
+            }
+        }
+        half_barrier();
+        // ---- D. served flows, queue update, arrivals, reward, wave
+        float r_node = 0.0f;
+        if (node) {
+            float served[NLANE] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const int rr = row + c_dest[k][0], cc = col + c_dest[k][1];
+                float fl = D[k];
+                if (rr >= 0 && rr < SIDE && cc >= 0 && cc < SIDE) fl = D[k] * s.scale[(rr * SIDE + cc) * 4 + c_dest[k][2]];
+                served[c_link_lane[k]] += fl;
+            }
+            float inflow[4];
+            const int sec = t * 5;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                inflow[r] = s.inflow[n * 4 + r];
+                const int grp = c_entry[n][r];
+                if (grp) inflow[r] += demand_rate(grp - 1, sec, p.peak1, p.peak2) / 3600.0f * DT * xi[ec * 4 + grp - 1];
+            }
+#pragma unroll
+            for (int l = 0; l < NLANE; ++l) {
+                q[l] = q[l] - served[l] + tr[l];
+                tr[l] = inflow[c_lane_approach[l]] * c_split[l];
+            }
+#pragma unroll
+            for (int k = 0; k < NL; ++k) {
+                const float c = fminf(q[c_link_lane[k]], DET_CAP);
+                r_node -= c;
+                float w = c / p.norm_wave;
+                if (p.clip_wave >= 0.0f) w = fminf(fmaxf(w, 0.0f), p.clip_wave);
+                s.wave[n * NL + k] = w;
+            }
+        }
+        float gsum = r_node;                     // sum over the 25 nodes of the half wave
+        for (int off = 16; off > 0; off >>= 1) gsum += __shfl_xor(gsum, off, 32);
+        const int t_new = t + 1;
+        const bool is_done = t_new >= p.T;       // atsc_env.py:189-191
+        const bool rst = auto_reset && is_done;
+        if (node) {
+            if (rst) {
+#pragma unroll
+                for (int l = 0; l < NLANE; ++l) { q[l] = 0.0f; tr[l] = 0.0f; }
+#pragma unroll
+                for (int k = 0; k < NL; ++k) s.wave[n * NL + k] = 0.0f;
+                a = 0;                            // _reset_state: prev_action = 0 (atsc_env.py:509-513)
+            }
+#pragma unroll
+            for (int l = 0; l < NLANE; ++l) { s.q[n * NLANE + l] = q[l]; s.tr[n * NLANE + l] = tr[l]; }
+        }
+        half_barrier();
+        // ---- E. coalesced write-back
+        if (live) {
+            float* qo = qs + e * NN * NLANE;
+            float* to = trs + e * NN * NLANE;
+            for (int i = l32; i < NN * NLANE; i += 32) { qo[i] = s.q[i]; to[i] = s.tr[i]; }
+            if (node) {
+                prev[e * NN + n] = (uint8_t)a;
+                if (p.per_agent_reward) reward[e * NN + n] = r_node;
+            }
+            if (l32 == 0) {
+                if (!p.per_agent_reward) reward[e] = gsum;
+                greward[e] = gsum;
+                done[e] = is_done ? 1 : 0;
+                ts[e] = rst ? 0 : t_new;
+            }
+            if (rst && l32 < 4) {
+                const int ep = episode[e];
+                const Philox4 r4 = philox4x32_10((uint32_t)(env_id_base + e), 0u, (uint32_t)ep, NMARL_STREAM_RESET,
+                                                 (uint32_t)seed, (uint32_t)(seed >> 32));
+                const uint32_t w = l32 == 0 ? r4.x : l32 == 1 ? r4.y : l32 == 2 ? r4.z : r4.w;
+                xi[e * 4 + l32] = 0.8f + 0.4f * u01_from_bits(w);
+            }
+            if (rst && l32 == 4) episode[e] = episode[e] + 1;
+            emit_obs_slab(s, obs + e * NN * OBSW, l32);
+        }
+        half_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void grid_reset_kernel(
+    const int64_t E, const uint8_t* __restrict__ mask, const float* __restrict__ u0, float* __restrict__ qs,
+    float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts, float* __restrict__ xi,
+    float* __restrict__ obs, const uint64_t seed, const int64_t env_id_base, int32_t* __restrict__ episode) {
+    const int l32 = threadIdx.x & 31;
+    const int sub = threadIdx.x >> 5;
+    for (int64_t e = (int64_t)blockIdx.x * 8 + sub; e < E; e += (int64_t)gridDim.x * 8) {
+        if (mask != nullptr && mask[e] == 0) continue;
+        for (int i = l32; i < NN * NLANE; i += 32) { qs[e * NN * NLANE + i] = 0.0f; trs[e * NN * NLANE + i] = 0.0f; }
+        for (int i = l32; i < NN * OBSW; i += 32) obs[e * NN * OBSW + i] = 0.0f;
+        if (l32 < NN) prev[e * NN + l32] = 0;
+        if (l32 == 0) ts[e] = 0;
+        if (l32 < 4) {
+            float U;
+            if (u0 != nullptr) {
+                U = u0[e * 4 + l32];
+            } else {
+                const Philox4 r4 = philox4x32_10((uint32_t)(env_id_base + e), 0u, (uint32_t)episode[e], NMARL_STREAM_RESET,
+                                                 (uint32_t)seed, (uint32_t)(seed >> 32));
+                const uint32_t w = l32 == 0 ? r4.x : l32 == 1 ? r4.y : l32 == 2 ? r4.z : r4.w;
+                U = u01_from_bits(w);
+            }
+            xi[e * 4 + l32] = 0.8f + 0.4f * U;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (u0 == nullptr && l32 == 4) episode[e] = episode[e] + 1;
+    }
+}
+
+inline int grid_blocks(int64_t E) {
+    const int64_t b = (E + 7) / 8;
+    return (int)(b < 4096 ? b : 4096);
+}
+
+}  // namespace
+
+extern "C" int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const uint8_t* action, float* q,
+                               float* transit, uint8_t* prev_action, int32_t* t, float* xi, float* obs,
+                               float* reward, uint8_t* done, float* global_reward, int32_t auto_reset,
+                               uint64_t seed, int64_t env_id_base, int32_t* episode, void* stream) {
+    if (!p || p->T <= 0 || p->norm_wave <= 0.f || E < 0 ||
+        (E > 0 && (!action || !q || !transit || !prev_action || !t || !xi || !obs || !reward || !done || !global_reward)))
+        return NMARL_EINVAL;
+    if (auto_reset && !episode) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(grid_step_kernel, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p, E,
+                       action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset, seed,
+                       env_id_base, episode);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_grid_reset(const nmarl_grid_params_t* p, int64_t E, const uint8_t* mask, const float* u0,
+                                uint64_t seed, int64_t env_id_base, int32_t* episode, float* q, float* transit,
+                                uint8_t* prev_action, int32_t* t, float* xi, float* obs, void* stream) {
+    if (!p || E < 0 || (E > 0 && (!q || !transit || !prev_action || !t || !xi || !obs))) return NMARL_EINVAL;
+    if (!u0 && !episode) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(grid_reset_kernel, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), E, mask,
+                       u0, q, transit, prev_action, t, xi, obs, seed, env_id_base, episode);
+    return nmarl_check_launch();
+}

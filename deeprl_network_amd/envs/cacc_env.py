@@ -102,6 +102,10 @@ class CACCBatchEnv:
         self.episode = torch.zeros(E, dtype=torch.int32, device=d)
         self.fp = torch.full((E, N, self.n_a), 1.0 / self.n_a, **f32)
 
+    def state_tensors(self):
+        """Everything a step mutates (snapshot / restore around hipGraph capture)."""
+        return [self.h, self.v, self.u, self.t, self.collided, self.v0_init, self.obs, self.episode, self.done]
+
     @property
     def train_mode(self):
         return self._train_mode

@@ -1,0 +1,179 @@
+"""Synthetic (SUMO-free) 5x5 ATSC grid on MI355X -- host mirror of the reference's
+envs/large_grid_env.py + envs/atsc_env.py for the `atsc_large_grid` scenario.
+
+The reference drives an external SUMO process over TraCI; this path keeps the reference's
+*contract* (25 agents, 5 phases, 12-wide `wave` observation, queue reward, 5 s control / 2 s
+yellow, 720-step episodes, the peak_flow demand schedule, neighbour / distance masks) and
+replaces the microsimulation by the store-and-forward model specified in
+oracle/grid_ref.py, stepped by csrc/grid.hip for E lock-stepped replicas.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+N_NODE, N_FEAT, N_OBS, N_PHASE = 25, 12, 60, 5
+
+
+def grid_masks():
+    """neighbor_mask / distance_mask of large_grid_env.py:58-105 (node i = nt{i+1})."""
+    idx = np.arange(N_NODE)
+    r, c = idx // 5, idx % 5
+    dist = (np.abs(r[:, None] - r[None, :]) + np.abs(c[:, None] - c[None, :])).astype(int)
+    return (dist == 1).astype(int), dist
+
+
+class LargeGridBatchEnv:
+    def __init__(self, config, num_envs=1, device='cuda', env_id_base=0, seed=None):
+        self.config = config
+        self.E = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.NmarlError('LargeGridBatchEnv needs a HIP device; there is no CPU path')
+        if config.getint('control_interval_sec') != 5 or config.getint('yellow_interval_sec') != 2:
+            raise _lib.NmarlError('the synthetic grid is specified for control 5 s / yellow 2 s')
+        if config.get('objective') != 'queue':
+            raise NotImplementedError('only the `queue` objective of the shipped grid configs is modelled')
+        self.name = config.get('scenario')
+        self.agent = config.get('agent')
+        self.coop_gamma = config.getfloat('coop_gamma')
+        self.seed = config.getint('seed') if seed is None else int(seed)
+        self.env_id_base = int(env_id_base)
+        p = _lib.GridParams()
+        p.norm_wave = config.getfloat('norm_wave')
+        p.clip_wave = config.getfloat('clip_wave')
+        p.peak1 = config.getfloat('peak_flow1')
+        p.peak2 = config.getfloat('peak_flow2')
+        p.T = int(np.ceil(config.getint('episode_length_sec') / config.getint('control_interval_sec')))
+        p.per_agent_reward = 0 if self.coop_gamma < 0 else 1
+        self.params = p
+        self.T = p.T
+        self.n_agent = N_NODE
+        self.n_a = N_PHASE
+        self.n_a_ls = [N_PHASE] * N_NODE
+        self.neighbor_mask, self.distance_mask = grid_masks()
+        self.n_s_ls = [N_FEAT if self.agent.startswith('ma2c') else N_FEAT * (1 + int(self.neighbor_mask[i].sum()))
+                       for i in range(N_NODE)]
+        self.train_mode = True
+        E, d = self.E, self.device
+        f32 = dict(dtype=torch.float32, device=d)
+        self.q = torch.zeros(E, N_NODE, 6, **f32)
+        self.transit = torch.zeros(E, N_NODE, 6, **f32)
+        self.prev_action = torch.zeros(E, N_NODE, dtype=torch.uint8, device=d)
+        self.t = torch.zeros(E, dtype=torch.int32, device=d)
+        self.xi = torch.ones(E, 4, **f32)
+        self.obs = torch.zeros(E, N_NODE, N_OBS, **f32)
+        self.reward = torch.zeros((E, N_NODE) if p.per_agent_reward else (E,), **f32)
+        self.done = torch.zeros(E, dtype=torch.uint8, device=d)
+        self.global_reward = torch.zeros(E, **f32)
+        self.episode = torch.zeros(E, dtype=torch.int32, device=d)
+        self.batch_size = None     # episodes end at T only; any n_step dividing T works
+
+    def state_tensors(self):
+        return [self.q, self.transit, self.prev_action, self.t, self.xi, self.obs, self.episode, self.done]
+
+    def reset(self, mask=None, u0=None):
+        P = _lib.ptr
+        rc = _lib.lib.nmarl_grid_reset(ctypes.byref(self.params), self.E, P(mask, torch.uint8), P(u0, torch.float32),
+                                       self.seed, self.env_id_base, P(self.episode), P(self.q), P(self.transit),
+                                       P(self.prev_action), P(self.t), P(self.xi), P(self.obs), _lib.stream())
+        _lib.check(rc, 'nmarl_grid_reset')
+        return self.obs
+
+    def step(self, action, auto_reset=False):
+        P = _lib.ptr
+        rc = _lib.lib.nmarl_grid_step(ctypes.byref(self.params), self.E, P(action, torch.uint8), P(self.q),
+                                      P(self.transit), P(self.prev_action), P(self.t), P(self.xi), P(self.obs),
+                                      P(self.reward), P(self.done), P(self.global_reward), 1 if auto_reset else 0,
+                                      self.seed, self.env_id_base, P(self.episode), _lib.stream())
+        _lib.check(rc, 'nmarl_grid_step')
+        return self.obs, self.reward, self.done, self.global_reward
+
+
+class LargeGridEnv:
+    """Reference duck-type (atsc_env.py:77-524 / large_grid_env.py:48-137) for ONE replica.
+    Observation lists: `ma2c*` 12 wave features; `ia2c*` own + neighbours' (ascending node index --
+    the reference uses its N,E,S,W list order there, atsc_env.py:263-269: a fixed permutation of the
+    input columns) (+ neighbour fingerprints for ia2c_fp)."""
+
+    def __init__(self, config, port=0, device='cuda', **_):
+        self.batch = LargeGridBatchEnv(config, num_envs=1, device=device)
+        b = self.batch
+        self.name, self.agent, self.coop_gamma, self.T = b.name, b.agent, b.coop_gamma, b.T
+        self.n_agent, self.n_a, self.n_a_ls, self.n_s_ls = b.n_agent, b.n_a, b.n_a_ls, b.n_s_ls
+        self.neighbor_mask, self.distance_mask = b.neighbor_mask, b.distance_mask
+        self.seed = config.getint('seed')
+        self.control_interval_sec = config.getint('control_interval_sec')
+        self.init_test_seeds([int(s) for s in config.get('test_seeds').split(',')])
+        self.cur_episode = 0
+        self.train_mode = True
+        self.is_record = False
+        self._nbr = [np.where(self.neighbor_mask[i] == 1)[0] for i in range(self.n_agent)]
+
+    def init_data(self, is_record, record_stats, output_path):
+        self.is_record, self.output_path = is_record, output_path
+        if is_record:
+            self.control_data = []
+
+    def init_test_seeds(self, test_seeds):
+        self.test_num, self.test_seeds = len(test_seeds), test_seeds
+
+    def get_neighbor_action(self, action):
+        action = np.asarray(action)
+        return [action[self.neighbor_mask[i] == 1] for i in range(self.n_agent)]
+
+    def get_fingerprint(self):
+        return self.fp
+
+    def update_fingerprint(self, policy):
+        self.fp = policy
+
+    def terminate(self):
+        return
+
+    def collect_tripinfo(self):
+        return
+
+    def output_data(self):
+        if self.is_record:
+            import pandas as pd
+            pd.DataFrame(self.control_data).to_csv(self.output_path + ('%s_%s_control.csv' % (self.name, self.agent)))
+
+    def _state_list(self):
+        x = self.batch.obs[0].cpu().numpy().astype(np.float64)
+        out = []
+        for i in range(self.n_agent):
+            w = N_FEAT * (1 + len(self._nbr[i])) if self.agent.startswith('ia2c') else N_FEAT
+            cur = [x[i, :w]]
+            if self.agent == 'ia2c_fp':
+                cur += [np.asarray(self.fp[j]) for j in self._nbr[i]]
+            out.append(np.concatenate(cur))
+        return out
+
+    def reset(self, gui=False, test_ind=0):
+        seed = self.seed if self.train_mode else self.test_seeds[test_ind]      # atsc_env.py:167-170
+        self.batch.seed = seed
+        self.batch.episode.zero_()
+        self.batch.reset()
+        self.cur_episode += 1
+        self.fp = [np.ones(self.n_a) / self.n_a for _ in range(self.n_agent)]
+        self.seed += 1
+        return self._state_list()
+
+    def step(self, action):
+        a = torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1), device=self.batch.device)
+        _, reward, done, g = self.batch.step(a)
+        global_reward = float(g.item())
+        done = bool(done.item())
+        if self.coop_gamma < 0 and self.train_mode:
+            reward = global_reward
+        else:
+            reward = reward[0].cpu().numpy().astype(np.float64) if self.coop_gamma >= 0 else global_reward
+        if self.is_record:
+            sec = int(self.batch.t.item()) * self.control_interval_sec
+            self.control_data.append({'episode': self.cur_episode, 'time_sec': sec,
+                                      'step': sec / self.control_interval_sec,
+                                      'action': ','.join('%d' % x for x in action), 'reward': global_reward})
+        return self._state_list(), reward, done, global_reward

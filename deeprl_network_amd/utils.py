@@ -284,7 +284,7 @@ class BatchedTrainer:
         self.E, self.N = env.E, env.n_agent
         self.n_step = model.n_step
         assert env.T % self.n_step == 0
-        assert getattr(env, 'batch_size', self.n_step) == self.n_step, \
+        assert getattr(env, 'batch_size', None) in (None, self.n_step), \
             'ENV_CONFIG batch_size must equal MODEL_CONFIG batch_size (episodes end at batch boundaries)'
         self.global_counter = global_counter
         self.summary_writer = summary_writer
@@ -355,10 +355,8 @@ class BatchedTrainer:
         self.model.t = self.n_step
 
     def _state_tensors(self):
-        env, m = self.env, self.model
-        ts = [env.h, env.v, env.u, env.t, env.collided, env.v0_init, env.obs, env.episode, env.done,
-              m.h_fw, m.c_fw, m.fp, self.step_dev, self.done_pre]
-        return [t for t in ts if t is not None]
+        m = self.model
+        return self.env.state_tensors() + [m.h_fw, m.c_fw, m.fp, self.step_dev, self.done_pre]
 
     def _snapshot(self):
         return [t.clone() for t in self._state_tensors()]

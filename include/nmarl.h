@@ -111,6 +111,46 @@ int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* acti
                     int64_t env_id_base, int32_t* episode, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Synthetic (SUMO-free) 5x5 ATSC grid -- contract of envs/atsc_env.py +      */
+/* envs/large_grid_env.py; dynamics specified in oracle/grid_ref.py           */
+/* ------------------------------------------------------------------------- */
+#define NMARL_GRID_N 25       /* intersections, node i = row*5+col = nt{i+1}           */
+#define NMARL_GRID_NF 12      /* wave features = signal links per node (:25-26)         */
+#define NMARL_GRID_OBS 60     /* own 12 + 4 neighbour slots (ascending index, 0 padded) */
+#define NMARL_GRID_LANES 6    /* physical incoming lanes per node                       */
+
+typedef struct nmarl_grid_params {
+    float norm_wave;          /* atsc_env.py:91-92                                       */
+    float clip_wave;          /* atsc_env.py:93-94 (< 0: no clip)                        */
+    float peak1;              /* peak_flow1, large_grid_env.py:50                        */
+    float peak2;              /* peak_flow2                                              */
+    int32_t T;                /* ceil(episode_length_sec / control_interval_sec) = 720   */
+    int32_t per_agent_reward; /* coop_gamma >= 0 -> reward [E,25], else global [E]       */
+} nmarl_grid_params_t;
+
+/*
+ * TrafficSimulator.reset (atsc_env.py:164-179) for the replicas selected by mask: empty
+ * network (init_density = 0), prev_action = 0 (:509-513), t = 0, and the per-replica
+ * demand scale xi[e,g] = 0.8 + 0.4*U for the 4 flow groups; U from u0 [E,4] or from
+ * Philox4x32-10(key=seed, ctr=(env_id_base+e, 0, episode[e], 0)) words 0..3.
+ * q, transit [E,25,6] f32; prev_action [E,25] u8; t [E] i32; xi [E,4]; obs [E,25,60].
+ */
+int nmarl_grid_reset(const nmarl_grid_params_t* p, int64_t E, const uint8_t* mask, const float* u0,
+                     uint64_t seed, int64_t env_id_base, int32_t* episode, float* q, float* transit,
+                     uint8_t* prev_action, int32_t* t, float* xi, float* obs, void* stream);
+/*
+ * TrafficSimulator.step (atsc_env.py:181-207): phase = action[e,i] in 0..4, 2 s yellow
+ * handling (:216-240), 5 s of store-and-forward traffic, `wave` observation (:420-462,
+ * :502-504) and queue reward (:383-418).  obs [E,25,60]: slot 0 own 12 features, slots
+ * 1..4 the neighbours' in ascending node index (lstm_ic3 / lstm_comm concatenation).
+ * reward [E] (global) or [E,25]; done [E] u8 when t reaches T; auto_reset as for CACC.
+ */
+int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const uint8_t* action, float* q,
+                    float* transit, uint8_t* prev_action, int32_t* t, float* xi, float* obs,
+                    float* reward, uint8_t* done, float* global_reward, int32_t auto_reset,
+                    uint64_t seed, int64_t env_id_base, int32_t* episode, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Neighbourhood aggregation over the fixed adjacency (agent-major [N,E,F])   */
 /* ------------------------------------------------------------------------- */
 /*

@@ -189,3 +189,14 @@ def compare_scripted(out, z, rtol_fw=1e-4, rtol_w=1e-3):
     s, g = out['STATS'], z['STATS']
     np.testing.assert_allclose(s[..., 1:3], g[..., 1:3], rtol=rtol_w, err_msg='|w| / l2')
     np.testing.assert_allclose(s[..., 3:], g[..., 3:], rtol=rtol_w, atol=2e-6, err_msg='weight samples')
+
+
+def grid_config(agent='ma2c_ic3', coop_gamma=-1, seed=12, n_step=120):
+    cp = configparser.ConfigParser()
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config', 'config_ma2c_cnet_grid.ini')
+    cp.read(path)
+    cp['ENV_CONFIG']['agent'] = agent
+    cp['ENV_CONFIG']['coop_gamma'] = str(coop_gamma)
+    cp['ENV_CONFIG']['seed'] = str(seed)
+    cp['MODEL_CONFIG']['batch_size'] = str(n_step)
+    return cp

@@ -1,0 +1,58 @@
+"""The C-ABI boundary: every entry point declared in include/nmarl.h is exported by the built
+libnmarl_hip.so and bound (with the right arity) by deeprl_network_amd/_lib.py, and vice versa.
+No compute call is made (runs without a GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'nmarl.h')
+
+
+def declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\bint\s+(nmarl_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args == 'void' else args.count(',') + 1
+    return out
+
+
+def test_header_symbols_are_exported_and_bound():
+    from deeprl_network_amd import _lib
+    decl = declared()
+    assert len(decl) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), 'declared but not exported: %s' % name
+        assert name in _lib.SIGNATURES, 'declared but not bound: %s' % name
+        assert len(_lib.SIGNATURES[name]) == nargs, '%s: header has %d args, binding %d' % (
+            name, nargs, len(_lib.SIGNATURES[name]))
+    assert set(_lib.SIGNATURES) == set(decl), 'bound but not declared: %r' % (set(_lib.SIGNATURES) - set(decl))
+
+
+def test_exports_are_plain_c_symbols():
+    from deeprl_network_amd import _lib
+    nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if ' T ' in line}
+    assert set(declared()) <= exported
+    assert not [s for s in exported if s.startswith('_Z') and 'nmarl' in s and 'kernel' not in s]
+
+
+def test_struct_layouts_match_header():
+    from deeprl_network_amd import _lib
+    assert ctypes.sizeof(_lib.CaccParams) == 12 * 4 + 5 * 4
+    assert ctypes.sizeof(_lib.GridParams) == 4 * 4 + 2 * 4
+    assert _lib.lib.nmarl_abi_version() == _lib.ABI_VERSION
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    import pytest
+    import torch
+    from deeprl_network_amd import _lib, ops
+    with pytest.raises(_lib.NmarlError):
+        ops.nbr_onehot(torch.zeros(2, 8, dtype=torch.uint8), torch.zeros(8, 2, dtype=torch.int32), 4)
+    with pytest.raises(_lib.NmarlError):
+        ops.rmsprop_tf_clip(torch.zeros(1, 4), torch.zeros(1, 4), torch.ones(1, 4), torch.zeros(1, 64), 1e-3, .99, 1e-5, 40)

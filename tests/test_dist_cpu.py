@@ -1,0 +1,59 @@
+"""Data-parallel path with world_size 2 on the gloo backend (CPU; HIP ops + env emulated by their
+oracle restatements): two ranks with 3 replicas each must end with bit-identical weights on both
+ranks, equal (to fp32 rounding) to ONE process stepping the same 6 replicas -- i.e. the single flat
+gradient all-reduce + 1/world scaling implements the global batch mean."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(agent, E, env_id_base, group, n_batches):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    from cpu_emulation import CpuCaccBatchEnv, cpu_ops
+    from helpers import cacc_config
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    cp = cacc_config(agent=agent, n_step=10, reward_norm=800.0)
+    cp['ENV_CONFIG']['episode_length_sec'] = '2'
+    with cpu_ops():
+        env = CpuCaccBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
+        np.random.seed(12)
+        cls = {'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC}[agent]
+        model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 6,
+                    cp['MODEL_CONFIG'], seed=12, num_envs=E, device='cpu', dist_group=group)
+        world = 1 if group is None else dist.get_world_size(group)
+        tr = BatchedTrainer(env, model, Counter(10 ** 9, 10 ** 9, 10 ** 9), use_graph=False,
+                            rank=0 if group is None else dist.get_rank(group), world_size=world)
+        for _ in range(n_batches):
+            tr.run_batch()
+        return model.policy.params.flat.clone(), tr.global_counter.cur_step
+
+
+def _worker(rank, world, port, agent, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    w, steps = _run(agent, 3, rank * 3, dist.group.WORLD, 3)
+    torch.save((w, steps), os.path.join(out, 'rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+def test_two_ranks_equal_one_process(agent, tmp_path):
+    port = 29500 + (os.getpid() % 2000) + (7 if agent == 'ma2c_nc' else 0)
+    mp.spawn(_worker, args=(2, port, agent, str(tmp_path)), nprocs=2, join=True)
+    w0, s0 = torch.load(tmp_path / 'rank0.pt')
+    w1, s1 = torch.load(tmp_path / 'rank1.pt')
+    assert torch.equal(w0, w1), 'ranks diverged'
+    assert s0 == s1 == 3 * 10 * 3 * 2           # batches x n_step x replicas x world
+    single, _ = _run(agent, 6, 0, None, 3)
+    torch.testing.assert_close(w0, single, rtol=2e-5, atol=2e-6)

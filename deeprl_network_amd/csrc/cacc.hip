@@ -35,13 +35,48 @@ __device__ __forceinline__ float lead_speed(const nmarl_cacc_params_t& p, float 
     return t >= DECEL_STEPS - 1 ? p.v_star : ramp;
 }
 
+// fp32 cos on [0, pi] (the only range the OVM ramp produces): cos(t) = -sin(t - pi/2) with a
+// two-piece pi/2 and an odd polynomial to r^13 (truncation 7e-10 at |r| = pi/2, i.e. < 1 ulp).
+// libm's cosf carries a large-argument reduction path that costs ~25 VGPRs this kernel never needs.
+__device__ __forceinline__ float cosf_0_pi(float t) {
+    const float r = (t - 1.57079637050628662109375f) + 4.37113900018624283e-8f;
+    const float r2 = r * r;
+    float q = 1.6059044e-10f;                 //  1/13!
+    q = fmaf(q, r2, -2.5052108e-08f);         // -1/11!
+    q = fmaf(q, r2, 2.7557319e-06f);          //  1/9!
+    q = fmaf(q, r2, -1.9841270e-04f);         // -1/7!
+    q = fmaf(q, r2, 8.3333333e-03f);          //  1/5!
+    q = fmaf(q, r2, -1.6666667e-01f);         // -1/3!
+    return -(r + r * r2 * q);                 // -sin r
+}
+
 // OVMCarFollowing.get_vh, cacc_env.py:360-369
 __device__ __forceinline__ float ovm_vh(const nmarl_cacc_params_t& p, float h) {
-    const float mid = p.v_max / 2.0f * (1.0f - cosf(PI_F * (h - p.h_s) / (p.h_g - p.h_s)));
+    const float mid = p.v_max / 2.0f * (1.0f - cosf_0_pi(PI_F * (h - p.h_s) / (p.h_g - p.h_s)));
     return h <= p.h_s ? 0.0f : (h < p.h_g ? mid : p.v_max);
 }
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// float64 cos on [0, pi] (the OVM ramp argument) without libm's register-hungry general path:
+// cos(t) = -sin(t - pi/2), pi/2 subtracted in two pieces so that cos(double(pi/2)) = 6.123e-17 like
+// libm / NumPy; odd Taylor polynomial to r^21 (|r| <= pi/2: truncation < 3e-16).
+__device__ __forceinline__ double cos_0_pi(double t) {
+    const double r = (t - 1.5707963267948966) - 6.123233995736766e-17;
+    const double r2 = r * r;
+    double q = -1.9572941063391263e-20;                   // -1/21!
+    q = fma(q, r2, 8.22063524662433e-18);                 //  1/19!
+    q = fma(q, r2, -2.8114572543455206e-15);              // -1/17!
+    q = fma(q, r2, 7.647163731819816e-13);                //  1/15!
+    q = fma(q, r2, -1.6059043836821613e-10);              // -1/13!
+    q = fma(q, r2, 2.505210838544172e-08);                //  1/11!
+    q = fma(q, r2, -2.7557319223985893e-06);              // -1/9!
+    q = fma(q, r2, 1.984126984126984e-04);                //  1/7!
+    q = fma(q, r2, -8.333333333333333e-03);               // -1/5!
+    q = fma(q, r2, 1.6666666666666666e-01);               //  1/3!
+    const double sin_r = r - r * r2 * q;                  // sin r = r - r^3/3! + ...
+    return -sin_r;
+}
 
 // _get_veh_state (cacc_env.py:54-65) for this lane's vehicle, then the
 // neighbour gather and the LDS-staged coalesced store of the wave's slab.
@@ -51,7 +86,22 @@ __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, 
     float x[NF];
     x[0] = (v - p.v_star) / p.v_star;
     x[1] = clampf((v_lead - v) / 5.0f, -2.0f, 2.0f);
-    x[2] = clampf((ovm_vh(p, h) - v) / 5.0f, -2.0f, 2.0f);
+    // The platoon's equilibrium (h = h*, v = v*) makes vh(h) - v vanish, and the reference's float64
+    // cos(pi/2) = 6.1e-17 leaves this feature a NEGATIVE 3.6e-16; an fp32 cosf gives +1.3e-7.  The
+    // feature multiplies O(1) weights into a relu whose mask (hence the bias gradient) depends on that
+    // sign, so where the fp32 difference is below its own resolution the term is re-evaluated in
+    // float64 like the reference (cacc_env.py:58-59, 365-366).  Rare outside episode starts.
+    {
+        const float d32 = ovm_vh(p, h) - v;
+        x[2] = clampf(d32 / 5.0f, -2.0f, 2.0f);
+        if (fabsf(d32) < 1e-3f) {
+            const double hd = (double)h;
+            const double th = 3.141592653589793 * (hd - (double)p.h_s) / ((double)p.h_g - (double)p.h_s);
+            const double mid = (double)p.v_max / 2.0 * (1.0 - cos_0_pi(th));
+            const double vh64 = hd <= (double)p.h_s ? 0.0 : (hd < (double)p.h_g ? mid : (double)p.v_max);
+            x[2] = (float)((vh64 - (double)v) / 5.0);
+        }
+    }
     x[3] = (h + (v_lead - v) * p.dt - p.h_star) / p.h_star;
     x[4] = u / p.u_max;
     float* row = lds_wave + lane * NOBS;

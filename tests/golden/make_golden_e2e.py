@@ -1,0 +1,60 @@
+"""End-to-end golden: the REAL reference Trainer (utils.py:100-254) + REAL CACCEnv + REAL model code
+(on the fake-TF shim, float64) for one training episode and its deterministic test episode, E = 1,
+global NumPy RNG -- exactly what `python main.py train` does for the first episode.
+
+    python tests/golden/make_golden_e2e.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, 'oracle', 'tf1_shim'))
+sys.path.insert(0, '/root/reference')
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+import tensorflow as tf  # noqa: E402  (shim)
+from envs.cacc_env import CACCEnv  # noqa: E402  (reference)
+from agents.models import IA2C, IA2C_FP, MA2C_NC, MA2C_IC3  # noqa: E402
+from utils import Counter, Trainer  # noqa: E402  (reference root utils.py)
+from helpers import cacc_config  # noqa: E402
+from make_golden_nn import var_stats  # noqa: E402
+
+CLS = {'ia2c': IA2C, 'ia2c_fp': IA2C_FP, 'ma2c_nc': MA2C_NC, 'ma2c_ic3': MA2C_IC3}
+
+
+def run(name, agent, scenario, seed, reward_norm):
+    cp = cacc_config(agent=agent, scenario=scenario, seed=seed, n_step=60, reward_norm=reward_norm, total_step=60)
+    env = CACCEnv(cp['ENV_CONFIG'])                      # seeds np.random (cacc_env.py:22)
+    counter = Counter(60, 10 ** 9, 10 ** 9)              # total_step 60 -> exactly one episode (+ its test episode)
+    model = CLS[agent](env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 60,
+                       cp['MODEL_CONFIG'], seed=seed)
+    log = {'a': [], 'g': [], 'train': []}
+    orig_step = env.step
+
+    def step(action):
+        out = orig_step(action)
+        log['a'].append(np.array(action).copy())
+        log['g'].append(out[3])
+        log['train'].append(env.train_mode)
+        return out
+    env.step = step
+    trainer = Trainer(env, model, counter, tf.summary.FileWriter(None), output_path=None)
+    trainer.output_path = '/tmp/e2e_'
+    trainer.run()
+    tr = np.array(log['train'])
+    acts, g = np.array(log['a']), np.array(log['g'])
+    out = dict(train_actions=acts[tr], train_rewards=g[tr], test_actions=acts[~tr], test_rewards=g[~tr],
+               logged_mean=trainer.data[0]['avg_reward'], logged_std=trainer.data[0]['std_reward'],
+               logged_step=trainer.data[0]['step'], stats=var_stats(tf.global_variables()),
+               agent=agent, scenario=scenario, seed=seed, reward_norm=reward_norm)
+    np.savez_compressed(os.path.join(HERE, 'e2e_%s.npz' % name), **out)
+    print('%-18s train steps %d (sum g %.3f) test steps %d mean %.4f' % (
+        name, tr.sum(), g[tr].sum(), (~tr).sum(), out['logged_mean']))
+
+
+if __name__ == '__main__':
+    run('ia2c_fp_catchup', 'ia2c_fp', 'catchup', 12, 800.0)
+    run('ma2c_nc_slowdown', 'ma2c_nc', 'slowdown', 12, 5000.0)

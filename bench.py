@@ -65,7 +65,8 @@ def measure_step_kernel(env, actions_tape, reps=20):
     """Average duration of one nmarl_cacc_step launch: a hipGraph of len(tape) back-to-back
     launches (real rollout state, the batch's own action tape, auto-reset on) bracketed by two
     HIP events on the launch stream; includes the ~1.5 us graph-node gaps, i.e. an upper bound."""
-    state = [t.clone() for t in (env.h, env.v, env.u, env.t, env.collided, env.v0_init, env.episode)]
+    tensors = env.state_tensors()
+    state = [t.clone() for t in tensors]
     n = actions_tape.shape[0]
 
     def body():
@@ -87,7 +88,7 @@ def measure_step_kernel(env, actions_tape, reps=20):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (reps * n)
-    for t, sv in zip((env.h, env.v, env.u, env.t, env.collided, env.v0_init, env.episode), state):
+    for t, sv in zip(tensors, state):
         t.copy_(sv)
     return us
 

@@ -84,7 +84,8 @@ class IA2C:
         # recurrent state [c,h] of policies.py:151-154; static buffers (hipGraph-friendly), updated in place
         self.h_fw, self.c_fw, self.h_bw, self.c_bw = z(N, E, H), z(N, E, H), z(N, E, H), z(N, E, H)
         self._h2, self._c2 = z(N, E, H), z(N, E, H)        # scratch of the value re-step (quirk Q1)
-        self.fp = torch.full((N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
+        self._fp_eval = torch.full((N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
+        self.t = 0
         self.total_step = total_step
         self.sess = None                                  # the reference Trainer reads model.sess (TF leak)
         if total_step:
@@ -92,6 +93,12 @@ class IA2C:
 
     def _is_ma2c(self):
         return self.name.startswith('ma2c')
+
+    @property
+    def fp(self):
+        """Current fingerprints (previous-step policies) [N,E,A]: slot t of the rollout buffer while
+        training, a standalone tensor for evaluation-only models (total_step = 0)."""
+        return self.buf_fp[self.t] if self.total_step else self._fp_eval
 
     def _init_scheduler(self, model_config):
         lr_init = model_config.getfloat('lr_init')
@@ -111,9 +118,13 @@ class IA2C:
         self.gamma = model_config.getfloat('gamma')
         N, E, T, d = self.n_agent, self.E, self.n_step, self.device
         p = self.policy
-        self.buf_x = torch.zeros(T, E, N, p.n_obs, dtype=F32, device=d)
-        self.buf_fp = torch.zeros(N, T, E, self.n_a, dtype=F32, device=d)
-        self.buf_na = torch.zeros(N, T, E, p.n_na, dtype=F32, device=d)
+        # rollout buffers (replace OnPolicyBuffer's lists); every slot [t] is contiguous so kernels and
+        # GEMMs write their results straight into it.  buf_x / buf_fp carry T+1 slots: slot t+1 receives
+        # the observation / policy produced at lock-step t, slot T is the bootstrap input and becomes
+        # slot 0 of the next batch.
+        self.buf_x = torch.zeros(T + 1, E, N, p.n_obs, dtype=F32, device=d)
+        self.buf_fp = torch.full((T + 1, N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
+        self.buf_na = torch.zeros(T, N, E, p.n_na, dtype=F32, device=d)
         self.buf_act = torch.zeros(T, E, N, dtype=torch.uint8, device=d)
         self.buf_v = torch.zeros(T, N, E, dtype=F32, device=d)
         self.buf_done_pre = torch.zeros(T, E, dtype=F32, device=d)
@@ -141,66 +152,76 @@ class IA2C:
                 s.mul_(keep)
             self.fp.mul_(keep).add_((1.0 - keep) / self.n_a)
 
-    def _policy_step(self, obs, done):
-        """forward('p'): advances states_fw (policies.py:119-134)."""
-        self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw)
+    def _policy_step(self, obs, done, done_is_zero=False):
+        """forward('p'): advances states_fw (policies.py:119-134); returns the pi LOGITS' softmax."""
+        self._enc = self.policy.encode(obs, self.fp)
+        self.policy.step(self._enc, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw, done_is_zero)
         with torch.no_grad():
             return self.policy.pi(self.h_fw)
 
-    def _value_step(self, obs, done, na_onehot):
-        """forward('v'): re-steps the LSTM from the state forward('p') wrote (quirk Q1),
-        without storing the result (policies.py:124-133)."""
-        self.policy.step(obs, self.fp, self.h_fw, self.c_fw, done, self._h2, self._c2)
+    def _value_step(self, obs, done, na_onehot, done_is_zero=False, out=None, reuse_enc=False):
+        """forward('v'): re-steps the LSTM from the state forward('p') wrote (quirk Q1), without
+        storing the result (policies.py:124-133).  `reuse_enc`: obs / fingerprints are those of the
+        preceding _policy_step, whose encoding is shared."""
+        enc = self._enc if reuse_enc else self.policy.encode(obs, self.fp)
+        self.policy.step(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, done_is_zero)
         with torch.no_grad():
-            return self.policy.value(self._h2, na_onehot)
+            return self.policy.value(self._h2, na_onehot, out=out)
 
-    def act(self, obs, done, action_out, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0,
-            step_dev=None, store=True):
-        """One lock-step decision for all replicas: pi, action draw, value; optionally stores the
-        transition inputs at buffer slot t.  obs [E,N,n_obs] f32, done [E] f32 (pre-step)."""
+    def act(self, done, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0, step_dev=None,
+            done_is_zero=False):
+        """One lock-step decision for all replicas at buffer slot t: reads the observation buf_x[t]
+        and fingerprints buf_fp[t]; writes the action into buf_act[t], the neighbour one-hots into
+        buf_na[t], the value into buf_v[t] and the new policy into buf_fp[t+1].  done [E] f32 is the
+        pre-step flag.  Returns the action slot (input of the env kernel)."""
         t = self.t
-        pi = self._policy_step(obs, done)
-        ops.sample_actions(pi, action_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
+        obs = self.buf_x[t]
+        pi = self._policy_step(obs, done, done_is_zero)
+        ops.sample_actions(pi, self.buf_act[t], mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
                            step_dev=step_dev)
-        if store:
-            na = ops.nbr_onehot(action_out, self.policy.nbr_idx, self.n_a, out=self.buf_na[:, t])
-            v = self._value_step(obs, done, na)
-            self.buf_x[t].copy_(obs)
-            self.buf_fp[:, t].copy_(self.fp)
-            self.buf_act[t].copy_(action_out)
-            self.buf_v[t].copy_(v)
-            self.buf_done_pre[t].copy_(done)
-        self.fp.copy_(pi)                                  # env.update_fingerprint(policy), utils.py:173
-        return pi
+        ops.nbr_onehot(self.buf_act[t], self.policy.nbr_idx, self.n_a, out=self.buf_na[t])
+        self._value_step(obs, done, self.buf_na[t], done_is_zero, out=self.buf_v[t], reuse_enc=True)
+        self.buf_fp[t + 1].copy_(pi)                       # env.update_fingerprint(policy), utils.py:173
+        return self.buf_act[t]
 
     def record(self, reward, done_post):
-        """model.add_transition's reward path (models.py:26-32): normalise, clip, store."""
+        """model.add_transition's reward path (models.py:26-32) for slot t: normalise, clip, store."""
         t = self.t
-        r = reward
+        self.buf_r[t].copy_(self._norm_reward(reward))
+        self.buf_done_post[t].copy_(done_post)
+        self.t = t + 1
+
+    def _norm_reward(self, r):
         if self.reward_norm > 0:
             r = r / self.reward_norm
         if self.reward_clip > 0:
             r = torch.clamp(r, -self.reward_clip, self.reward_clip)
-        self.buf_r[t].copy_(r)
-        self.buf_done_post[t].copy_(done_post)
-        self.t = t + 1
+        return r
 
-    def bootstrap(self, obs, done, action_scratch, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0,
-                  step=0, step_dev=None):
-        """R for the unfinished replicas (utils.py:192-196): one more policy step (which advances
-        states_fw -- quirk Q2) and the double-stepped value; 0 where the episode just ended."""
-        pi = self._policy_step(obs, done)
+    def load_rewards(self, raw_rewards):
+        """Batched path: the env kernel wrote raw rewards for all T slots (and done flags straight
+        into buf_done_post); normalise them in one pass and mark the batch complete."""
+        self.buf_r.copy_(self._norm_reward(raw_rewards))
+        self.t = self.n_step
+
+    def bootstrap(self, done, action_scratch, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0,
+                  step=0, step_dev=None, done_is_zero=False):
+        """R for the unfinished replicas (utils.py:192-196) from buf_x[T] / buf_fp[T]: one more policy
+        step (which advances states_fw -- quirk Q2) and the double-stepped value."""
+        assert self.t == self.n_step
+        obs = self.buf_x[self.n_step]
+        pi = self._policy_step(obs, done, done_is_zero)
         ops.sample_actions(pi, action_scratch, mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
                            step_dev=step_dev)
         na = ops.nbr_onehot(action_scratch, self.policy.nbr_idx, self.n_a)
-        return self._value_step(obs, done, na)
+        return self._value_step(obs, done, na, done_is_zero, reuse_enc=True)
 
     def _loss(self, Hs):
         """policies.py:20-30 / 232-255 with the batch mean taken over T*E."""
         N, T, E = self.n_agent, self.n_step, self.E
         p = self.policy
         pi = p.pi(Hs)                                                        # [N, T*E, A]
-        v = p.value(Hs, self.buf_na.view(N, T * E, p.n_na))                  # [N, T*E]
+        v = p.value(Hs, self.buf_na.permute(1, 0, 2, 3).reshape(N, T * E, p.n_na))   # [N, T*E]
         acts = self.buf_act.view(T * E, N).t().long().unsqueeze(-1)          # [N, T*E, 1]
         log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
         entropy = -(pi * log_pi).sum(-1)
@@ -224,7 +245,9 @@ class IA2C:
                          self.dist_dev, self.R, self.Adv)
         ps = self.policy.params
         ps.grad.zero_()
-        Hs = self.policy.unroll(self.buf_x, self.buf_fp, self.buf_done_pre, self.h_bw, self.c_bw)
+        T = self.n_step
+        FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
+        Hs = self.policy.unroll(self.buf_x[:T], FP, self.buf_done_pre, self.h_bw, self.c_bw)
         loss = self._loss(Hs)
         loss.backward()
         scale = 1.0
@@ -242,6 +265,9 @@ class IA2C:
         # states_bw <- states_fw (policies.py:115, 211)
         self.h_bw.copy_(self.h_fw)
         self.c_bw.copy_(self.c_fw)
+        # slot T (bootstrap inputs) is slot 0 of the next batch
+        self.buf_x[0].copy_(self.buf_x[T])
+        self.buf_fp[0].copy_(self.buf_fp[T])
         self.t = 0
         self.cur_lr = cur_lr
 
@@ -299,7 +325,7 @@ class IA2C:
         t = self.t
         slab, fp = self._obs_to_slab(ob)
         self.buf_x[t].copy_(slab)
-        self.buf_na[:, t].copy_(self._na_onehot_from_list(naction))
+        self.buf_na[t].copy_(self._na_onehot_from_list(naction))
         self.buf_act[t].copy_(torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)))
         self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))
         self.buf_done_pre[t].fill_(float(self._prev_done))
@@ -390,7 +416,7 @@ class IA2C_FP(IA2C):
 
     def add_transition(self, ob, naction, action, reward, value, done):
         _, fpg = self._obs_to_slab(ob)
-        self.buf_fp[:, self.t].copy_(self._ungather_fp(fpg))
+        self.buf_fp[self.t].copy_(self._ungather_fp(fpg))
         super().add_transition(ob, naction, action, reward, value, done)
 
 
@@ -415,9 +441,9 @@ class MA2C_NC(IA2C):
         t = self.t
         slab, _ = self._obs_to_slab(ob)
         self.buf_x[t].copy_(slab)
-        self.buf_fp[:, t].copy_(torch.as_tensor(np.asarray(p, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
+        self.buf_fp[t].copy_(torch.as_tensor(np.asarray(p, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
         a = torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)).to(self.device)
-        ops.nbr_onehot(a, self.policy.nbr_idx, self.n_a, out=self.buf_na[:, t])
+        ops.nbr_onehot(a, self.policy.nbr_idx, self.n_a, out=self.buf_na[t])
         self.buf_act[t].copy_(a)
         self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))
         self.buf_done_pre[t].fill_(float(self._prev_done))

@@ -49,12 +49,13 @@ class ParamStore:
         self.device = device
         self.index = {}
         off = 0
-        for phase in phases:
+        ALIGN = 16            # floats: every tensor (and every agent row) starts on a 64-byte boundary,
+        for phase in phases:  # as the float4 bias loads of the cell kernel and the GEMMs like it
             for key, fmt, shape, rows_fn in phase:
                 size = int(np.prod(shape))
                 self.index[key] = (off, size, tuple(shape), fmt, rows_fn)
-                off += size
-        self.P = off
+                off += -(-size // ALIGN) * ALIGN
+        self.P = off          # padding floats stay 0 (zero gradient), they never enter a norm or an export
         self.flat = torch.zeros(n_agent, self.P, dtype=F32, device=device)
         self.grad = torch.zeros_like(self.flat)
         self.ms = torch.ones_like(self.flat)            # TF RMSProp slot starts at 1
@@ -147,41 +148,65 @@ class BatchedPolicy:
         p = self.params
         return torch.softmax(torch.baddbmm(p['pi_b'].unsqueeze(1), h, p['pi_w']), dim=-1)
 
-    def value(self, h, na_onehot):
+    def value(self, h, na_onehot, out=None):
+        """v = [h, onehot(neighbour actions)] @ Wv + b (policies.py:59-77), without the concat;
+        `out` [N,rows] (no-grad rollout) receives the result in place."""
         p = self.params
         H = self.n_h
         v = torch.baddbmm(p['v_b'].unsqueeze(1), h, p['v_w'][:, :H])
-        v = torch.baddbmm(v, na_onehot, p['v_w'][:, H:])
-        return v.squeeze(-1)
+        if out is not None:
+            torch.baddbmm(v, na_onehot, p['v_w'][:, H:], out=out.unsqueeze(-1))
+            return out
+        return torch.baddbmm(v, na_onehot, p['v_w'][:, H:]).squeeze(-1)
 
-    # -- one recurrent step for the rollout (no autograd)
-    def step(self, x, fp_prev, h, c, done, h_out, c_out):
-        """x [E,N,n_obs] env-major slab (or any view with that shape), fp_prev [N,E,A] the
-        previous-step policies, (h, c) [N,E,H], done [E] f32 -> writes (h', c') into
-        (h_out, c_out), which MAY alias (h, c): every read of h precedes the cell kernel on
-        the stream and the cell kernel is index-wise in place."""
+    # -- rollout (no autograd): encode once per lock-step, then one recurrent step per call
+    def encode(self, x, fp_prev):
+        """The h-independent part of the LSTM input for one lock-step: x [E,N,n_obs] env-major slab
+        (any view with that shape), fp_prev [N,E,A] previous-step policies.  Both the policy step and
+        the value re-step (quirk Q1) of a lock-step share it."""
         with torch.no_grad():
-            zx = self._pre(x.transpose(0, 1), fp_prev, h)
-            keep = (1.0 - done).view(1, -1, 1)
-            z = torch.baddbmm(zx, h * keep, self.params[self.k_wh])
-            ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_out, h_out)
+            return self._enc_infer(x.transpose(0, 1), fp_prev)
+
+    def step(self, enc, h, c, done, h_out, c_out, done_is_zero=False):
+        """One LSTM step from (h, c) [N,E,H] with done [E] f32 -> writes (h', c') into (h_out, c_out),
+        which MAY alias (h, c): every read of h precedes the cell kernel on the stream and the cell
+        kernel is index-wise in place.  No GEMM here carries a copy: the recurrent product is a plain
+        (or in-place accumulating) batched GEMM and the x-side part enters the cell kernel as a second
+        addend."""
+        with torch.no_grad():
+            hk = h if done_is_zero else h * (1.0 - done).view(1, -1, 1)
+            z, z2 = self._recur_infer(enc, h, hk)
+            ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_out, h_out, z2=z2)
         return h_out, c_out
+
+    def _fc_infer(self, x, w_key, b_key, act):
+        """act(x @ W + b) with the bias/activation fused in one in-place pass (no autograd)."""
+        return ops.bias_act_(torch.bmm(x, self.params[w_key]), self.params[b_key], act)
+
+    def _recur_infer(self, enc, h, hk):
+        return torch.bmm(hk, self.params[self.k_wh]), enc
 
     # -- n_step unroll for the update (autograd)
     def unroll(self, X, FP, done, h0, c0):
-        """X [T,E,N,n_obs] env-major, FP [N,T,E,A] previous-step policies, done [T,E] f32
+        """X [T,E,N,n_obs] env-major, FP [N,T*E,A] previous-step policies, done [T,E] f32
         (pre-step), (h0, c0) [N,E,H] -> Hs [N,T*E,H]."""
         T, E = done.shape
         Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)       # [N, T*E, n_obs], no copy
-        pre = self._pre_all(Xv, FP, T, E)
-        # per-step views via ONE unbind: its backward is a single stack, whereas slicing `pre` inside
+        enc = self._enc(Xv, FP)
+        if not self.coupled:
+            # no cross-agent term inside the recurrence: fused sequence op (one wgrad GEMM, one bias
+            # reduction, no per-step autograd nodes)
+            Hs = ops.lstm_sequence(enc.view(self.N, T, E, enc.shape[-1]), self.params[self.k_wh],
+                                   self.params[self.k_b], h0, c0, done)
+            return Hs.reshape(self.N, T * E, self.n_h)
+        # per-step views via ONE unbind: its backward is a single stack, whereas slicing `enc` inside
         # the loop would make autograd materialise and add T full-size zero tensors (O(T^2) traffic)
-        pre_steps = pre.view(self.N, T, E, pre.shape[-1]).unbind(1)
+        enc_steps = enc.view(self.N, T, E, enc.shape[-1]).unbind(1)
         h, c = h0, c0
         hs = []
         wh, b = self.params[self.k_wh], self.params[self.k_b]
         for t in range(T):
-            zx = self._pre_t(pre_steps[t], h)
+            zx = self._recur_in(enc_steps[t], h)
             keep = (1.0 - done[t]).view(1, -1, 1)
             z = torch.baddbmm(zx, h * keep, wh)
             h, c = ops.lstm_cell(z, b, c, done[t])
@@ -193,6 +218,7 @@ class LstmPolicy(BatchedPolicy):
     """IA2C: fc(n_s -> n_fc, relu) -> LSTM -> heads (policies.py:136-149)."""
     name = 'lstm'
     k_wh, k_b = 'lstm_wh', 'lstm_b'
+    coupled = False               # the recurrence has no cross-agent term -> fused sequence op
 
     def _phases(self):
         nf, H, F = self.n_fc, self.n_h, self.n_feat
@@ -202,18 +228,16 @@ class LstmPolicy(BatchedPolicy):
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
-    def _encode(self, xv, fpv):
+    def _enc(self, xv, fp):
+        """x-side LSTM pre-activation [N,rows,4H] (bias is added in the cell kernel)."""
         p = self.params
-        return torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), xv, p['fc_w']))
+        return torch.bmm(torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), xv, p['fc_w'])), p['lstm_wx'])
 
-    def _pre(self, xv, fp_prev, h):
-        return torch.bmm(self._encode(xv, None), self.params['lstm_wx'])
+    def _enc_infer(self, xv, fp):
+        return torch.bmm(self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
 
-    def _pre_all(self, Xv, FP, T, E):
-        return torch.bmm(self._encode(Xv, None), self.params['lstm_wx'])
-
-    def _pre_t(self, pre_t, h):
-        return pre_t
+    def _recur_in(self, enc, h):
+        return enc
 
 
 class FPPolicy(LstmPolicy):
@@ -229,20 +253,21 @@ class FPPolicy(LstmPolicy):
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
-    def _zx(self, xv, pf):
+    def _enc(self, xv, fp):
         p = self.params
         nf = self.n_fc
+        pf = ops.nbr_gather(fp, self.nbr_idx)
         hx = torch.relu(torch.baddbmm(p['fcs_b'].unsqueeze(1), xv, p['fcs_w']))
         hp = torch.relu(torch.baddbmm(p['fcp_b'].unsqueeze(1), pf, p['fcp_w']))
         # [hx, hp] @ wx  ==  hx @ wx[:nf] + hp @ wx[nf:]   (no concat buffer)
         return torch.baddbmm(torch.bmm(hx, p['lstm_wx'][:, :nf]), hp, p['lstm_wx'][:, nf:])
 
-    def _pre(self, xv, fp_prev, h):
-        return self._zx(xv, ops.nbr_gather(fp_prev, self.nbr_idx))
-
-    def _pre_all(self, Xv, FP, T, E):
-        pf = ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx)
-        return self._zx(Xv, pf)
+    def _enc_infer(self, xv, fp):
+        p = self.params
+        nf = self.n_fc
+        hx = self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU)
+        hp = self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU)
+        return torch.bmm(hx, p['lstm_wx'][:, :nf]).baddbmm_(hp, p['lstm_wx'][:, nf:])
 
 
 class NCMultiAgentPolicy(BatchedPolicy):
@@ -251,6 +276,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
     name = 'nc'
     k_wh, k_b = 'wh_hid', 'hid_b'
     scope = 'nc/lstm_comm_%d'
+    coupled = True                # messages: neighbours' h_{t-1} enter every step
 
     def _phases(self):
         H, F, A = self.n_h, self.n_feat, self.n_a
@@ -266,28 +292,34 @@ class NCMultiAgentPolicy(BatchedPolicy):
                  ('hid_b', s + '/b_hid', (4 * H,), None)],
                 self._head_phase(self.name + '/pi_%d', self.name + '/v_%d')]
 
-    def _zxp(self, xv, pf):
+    def _enc(self, xv, fp):
+        """Observation + fingerprint thirds of s, already multiplied by their rows of wx_hid."""
         p = self.params
         H = self.n_h
+        pf = ops.nbr_gather(fp, self.nbr_idx)
         hx = torch.relu(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob']))
         hp = torch.relu(torch.baddbmm(p['w_fp_b'].unsqueeze(1), pf, p['w_fp']))
         return torch.baddbmm(torch.bmm(hx, p['wx_hid'][:, :H]), hp, p['wx_hid'][:, H:2 * H])
 
-    def _msg(self, zxp, h):
+    def _recur_in(self, enc, h):
         p = self.params
         H = self.n_h
         m = ops.nbr_gather(h, self.nbr_idx)                                   # un-masked previous h
         hm = torch.relu(torch.baddbmm(p['w_msg_b'].unsqueeze(1), m, p['w_msg']))
-        return torch.baddbmm(zxp, hm, p['wx_hid'][:, 2 * H:])
+        return torch.baddbmm(enc, hm, p['wx_hid'][:, 2 * H:])
 
-    def _pre(self, xv, fp_prev, h):
-        return self._msg(self._zxp(xv, ops.nbr_gather(fp_prev, self.nbr_idx)), h)
+    def _enc_infer(self, xv, fp):
+        p = self.params
+        H = self.n_h
+        hx = self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU)
+        hp = self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU)
+        return torch.bmm(hx, p['wx_hid'][:, :H]).baddbmm_(hp, p['wx_hid'][:, H:2 * H])
 
-    def _pre_all(self, Xv, FP, T, E):
-        return self._zxp(Xv, ops.nbr_gather(FP.reshape(self.N, T * E, self.n_a), self.nbr_idx))
-
-    def _pre_t(self, pre_t, h):
-        return self._msg(pre_t, h)
+    def _recur_infer(self, enc, h, hk):
+        p = self.params
+        H = self.n_h
+        hm = self._fc_infer(ops.nbr_gather(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU)
+        return torch.bmm(hm, p['wx_hid'][:, 2 * H:]).baddbmm_(hk, p[self.k_wh]), enc
 
 
 class IC3MultiAgentPolicy(BatchedPolicy):
@@ -296,6 +328,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     name = 'ic3'
     k_wh, k_b = 'wh_hid', 'hid_b'
     scope = 'ic3/lstm_ic3_%d'
+    coupled = True
 
     def _phases(self):
         H, F = self.n_h, self.n_feat
@@ -309,21 +342,20 @@ class IC3MultiAgentPolicy(BatchedPolicy):
                  ('hid_b', s + '/b_hid', (4 * H,), None)],
                 self._head_phase(self.name + '/pi_%d', self.name + '/v_%d')]
 
-    def _sx(self, xv):
+    def _enc(self, xv, fp):
         p = self.params
         return torch.tanh(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob']))
 
-    def _msg(self, sx, h):
+    def _recur_in(self, enc, h):
         p = self.params
         mm = ops.nbr_mean(h, self.nbr_idx)                                    # un-masked previous h
-        s = sx + torch.baddbmm(p['w_msg_b'].unsqueeze(1), mm, p['w_msg'])
+        s = enc + torch.baddbmm(p['w_msg_b'].unsqueeze(1), mm, p['w_msg'])
         return torch.bmm(s, p['wx_hid'])
 
-    def _pre(self, xv, fp_prev, h):
-        return self._msg(self._sx(xv), h)
+    def _enc_infer(self, xv, fp):
+        return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH)
 
-    def _pre_all(self, Xv, FP, T, E):
-        return self._sx(Xv)
-
-    def _pre_t(self, pre_t, h):
-        return self._msg(pre_t, h)
+    def _recur_infer(self, enc, h, hk):
+        p = self.params
+        s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
+        return torch.bmm(s, p['wx_hid']).baddbmm_(hk, p[self.k_wh]), None

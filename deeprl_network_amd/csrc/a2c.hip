@@ -18,54 +18,115 @@ namespace {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// z: [rows, 4H] pre-activations WITHOUT bias; bias: [N, 4H]; rows = N*E ordered (n, e).
-// gates (out): post-activation i,f,o,u; c_prev is masked by (1-done[e]) here.
+// Every tensor is [N, E, W] with contiguous [E, W] panels and its own agent stride (floats), so that
+// slot t of an [N, T, E, W] sequence buffer can be passed without a copy.
+struct CellStrides { int64_t z, z2, bias, c_prev, gates, c_new, h_new, dh, dc, dz, dc_prev; };
+
+// z: pre-activations WITHOUT bias; gates (out, optional): post-activation i,f,o,u;
+// c_prev is masked by (1-done[e]) here.  4 hidden units per thread, 16-byte accesses.
 __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
-    const int64_t E, const int N, const int H, const float* __restrict__ z, const float* __restrict__ bias,
-    const int64_t bias_stride, const float* __restrict__ c_prev, const float* __restrict__ done, float* __restrict__ gates,
-    float* __restrict__ c_new, float* __restrict__ h_new) {
-    const int64_t total = (int64_t)N * E * H;
+    const int64_t E, const int N, const int H, const CellStrides st, const float* __restrict__ z,
+    const float* __restrict__ z2, const float* __restrict__ bias, const float* __restrict__ c_prev,
+    const float* __restrict__ done, float* __restrict__ gates, float* __restrict__ c_new,
+    float* __restrict__ h_new) {
+    const int H4 = H >> 2;                                   // float4 groups per row
+    const int64_t total = (int64_t)N * E * H4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / H;
-        const int j = (int)(idx - row * H);
+        const int64_t row = idx / H4;
+        const int j = (int)(idx - row * H4) * 4;
         const int64_t n = row / E;
         const int64_t e = row - n * E;
-        const float* zr = z + row * 4 * H;
-        const float* b = bias + n * bias_stride;
-        const float gi = sigmoidf_(zr[j] + b[j]);
-        const float gf = sigmoidf_(zr[H + j] + b[H + j]);
-        const float go = sigmoidf_(zr[2 * H + j] + b[2 * H + j]);
-        const float gu = tanhf(zr[3 * H + j] + b[3 * H + j]);
+        const float* zr = z + n * st.z + e * 4 * H;
+        const float* b = bias + n * st.bias;
+        float4 zi = *reinterpret_cast<const float4*>(zr + j), zf = *reinterpret_cast<const float4*>(zr + H + j);
+        float4 zo = *reinterpret_cast<const float4*>(zr + 2 * H + j), zu = *reinterpret_cast<const float4*>(zr + 3 * H + j);
+        if (z2 != nullptr) {      // x-side pre-activation kept separate: no copy+accumulate GEMM needed
+            const float* yr = z2 + n * st.z2 + e * 4 * H;
+            const float4 a = *reinterpret_cast<const float4*>(yr + j), b2 = *reinterpret_cast<const float4*>(yr + H + j);
+            const float4 c2 = *reinterpret_cast<const float4*>(yr + 2 * H + j), d2 = *reinterpret_cast<const float4*>(yr + 3 * H + j);
+            zi.x += a.x; zi.y += a.y; zi.z += a.z; zi.w += a.w;  zf.x += b2.x; zf.y += b2.y; zf.z += b2.z; zf.w += b2.w;
+            zo.x += c2.x; zo.y += c2.y; zo.z += c2.z; zo.w += c2.w;  zu.x += d2.x; zu.y += d2.y; zu.z += d2.z; zu.w += d2.w;
+        }
+        const float4 bi = *reinterpret_cast<const float4*>(b + j), bf = *reinterpret_cast<const float4*>(b + H + j);
+        const float4 bo = *reinterpret_cast<const float4*>(b + 2 * H + j), bu = *reinterpret_cast<const float4*>(b + 3 * H + j);
+        const float4 cp = *reinterpret_cast<const float4*>(c_prev + n * st.c_prev + e * H + j);
         const float keep = 1.0f - done[e];
-        const float c = gf * (c_prev[idx] * keep) + gi * gu;
-        float* gr = gates + row * 4 * H;
-        gr[j] = gi; gr[H + j] = gf; gr[2 * H + j] = go; gr[3 * H + j] = gu;
-        c_new[idx] = c;
-        h_new[idx] = go * tanhf(c);
+        float4 gi, gf, go, gu, c, h;
+#define NMARL_CELL(k)                                              \
+        gi.k = sigmoidf_(zi.k + bi.k); gf.k = sigmoidf_(zf.k + bf.k); \
+        go.k = sigmoidf_(zo.k + bo.k); gu.k = tanhf(zu.k + bu.k);    \
+        c.k = gf.k * (cp.k * keep) + gi.k * gu.k; h.k = go.k * tanhf(c.k);
+        NMARL_CELL(x) NMARL_CELL(y) NMARL_CELL(z) NMARL_CELL(w)
+#undef NMARL_CELL
+        if (gates != nullptr) {
+            float* gr = gates + n * st.gates + e * 4 * H;
+            *reinterpret_cast<float4*>(gr + j) = gi; *reinterpret_cast<float4*>(gr + H + j) = gf;
+            *reinterpret_cast<float4*>(gr + 2 * H + j) = go; *reinterpret_cast<float4*>(gr + 3 * H + j) = gu;
+        }
+        *reinterpret_cast<float4*>(c_new + n * st.c_new + e * H + j) = c;
+        *reinterpret_cast<float4*>(h_new + n * st.h_new + e * H + j) = h;
     }
 }
 
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
-    const int64_t E, const int N, const int H, const float* __restrict__ gates, const float* __restrict__ c_prev,
-    const float* __restrict__ c_new, const float* __restrict__ done, const float* __restrict__ dh,
-    const float* __restrict__ dc_in, float* __restrict__ dz, float* __restrict__ dc_prev) {
-    const int64_t total = (int64_t)N * E * H;
+    const int64_t E, const int N, const int H, const CellStrides st, const float* __restrict__ gates,
+    const float* __restrict__ c_prev, const float* __restrict__ c_new, const float* __restrict__ done,
+    const float* __restrict__ dh, const float* __restrict__ dc_in, float* __restrict__ dz,
+    float* __restrict__ dc_prev) {
+    const int H4 = H >> 2;
+    const int64_t total = (int64_t)N * E * H4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / H;
-        const int j = (int)(idx - row * H);
-        const int64_t e = row % E;
-        const float* gr = gates + row * 4 * H;
-        const float gi = gr[j], gf = gr[H + j], go = gr[2 * H + j], gu = gr[3 * H + j];
+        const int64_t row = idx / H4;
+        const int j = (int)(idx - row * H4) * 4;
+        const int64_t n = row / E;
+        const int64_t e = row - n * E;
+        const float* gr = gates + n * st.gates + e * 4 * H;
+        const float4 gi = *reinterpret_cast<const float4*>(gr + j), gf = *reinterpret_cast<const float4*>(gr + H + j);
+        const float4 go = *reinterpret_cast<const float4*>(gr + 2 * H + j), gu = *reinterpret_cast<const float4*>(gr + 3 * H + j);
+        const float4 cp = *reinterpret_cast<const float4*>(c_prev + n * st.c_prev + e * H + j);
+        const float4 cn = *reinterpret_cast<const float4*>(c_new + n * st.c_new + e * H + j);
+        const float4 zero = float4{0.f, 0.f, 0.f, 0.f};
+        const float4 gh = dh ? *reinterpret_cast<const float4*>(dh + n * st.dh + e * H + j) : zero;
+        const float4 gcin = dc_in ? *reinterpret_cast<const float4*>(dc_in + n * st.dc + e * H + j) : zero;
         const float keep = 1.0f - done[e];
-        const float tc = tanhf(c_new[idx]);
-        const float g_h = dh ? dh[idx] : 0.0f;
-        const float g_c = (dc_in ? dc_in[idx] : 0.0f) + g_h * go * (1.0f - tc * tc);
-        float* dzr = dz + row * 4 * H;
-        dzr[j] = g_c * gu * gi * (1.0f - gi);
-        dzr[H + j] = g_c * (c_prev[idx] * keep) * gf * (1.0f - gf);
-        dzr[2 * H + j] = g_h * tc * go * (1.0f - go);
-        dzr[3 * H + j] = g_c * gi * (1.0f - gu * gu);
-        dc_prev[idx] = g_c * gf * keep;
+        float4 di, df, dO, du, dcp;
+#define NMARL_CELLB(k)                                                          \
+        { const float tc = tanhf(cn.k);                                          \
+          const float g_c = gcin.k + gh.k * go.k * (1.0f - tc * tc);             \
+          di.k = g_c * gu.k * gi.k * (1.0f - gi.k);                              \
+          df.k = g_c * (cp.k * keep) * gf.k * (1.0f - gf.k);                     \
+          dO.k = gh.k * tc * go.k * (1.0f - go.k);                               \
+          du.k = g_c * gi.k * (1.0f - gu.k * gu.k);                              \
+          dcp.k = g_c * gf.k * keep; }
+        NMARL_CELLB(x) NMARL_CELLB(y) NMARL_CELLB(z) NMARL_CELLB(w)
+#undef NMARL_CELLB
+        float* dzr = dz + n * st.dz + e * 4 * H;
+        *reinterpret_cast<float4*>(dzr + j) = di; *reinterpret_cast<float4*>(dzr + H + j) = df;
+        *reinterpret_cast<float4*>(dzr + 2 * H + j) = dO; *reinterpret_cast<float4*>(dzr + 3 * H + j) = du;
+        *reinterpret_cast<float4*>(dc_prev + n * st.dc_prev + e * H + j) = dcp;
+    }
+}
+
+// x [N, rows, W] (agent stride x_sn) += bias [N, W] (stride bias_sn), then act: 0 none, 1 relu, 2 tanh.
+// Replaces broadcast-copy + beta=1 GEMM + activation (3 passes) after a plain batched GEMM (fc of
+// agents/utils.py:65-73 and the encoders of lstm_comm / lstm_ic3) in the no-grad rollout.
+__global__ __launch_bounds__(256) void bias_act_kernel(const int64_t rows, const int N, const int W, float* __restrict__ x,
+                                                       const int64_t x_sn, const float* __restrict__ bias,
+                                                       const int64_t bias_sn, const int act) {
+    const int W4 = W >> 2;
+    const int64_t total = (int64_t)N * rows * W4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / W4;
+        const int j = (int)(idx - row * W4) * 4;
+        const int64_t n = row / rows;
+        const int64_t r = row - n * rows;
+        float4* px = reinterpret_cast<float4*>(x + n * x_sn + r * W + j);
+        const float4 b = *reinterpret_cast<const float4*>(bias + n * bias_sn + j);
+        float4 v = *px;
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (act == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        *px = v;
     }
 }
 
@@ -195,26 +256,56 @@ inline int grid_x(int64_t n, int cap = 2048) {
 
 }  // namespace
 
-extern "C" int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, const float* bias,
-                                   int64_t bias_stride, const float* c_prev, const float* done, float* gates, float* c_new,
-                                   float* h_new, void* stream) {
-    if (E < 0 || N <= 0 || H <= 0 || bias_stride < 4 * (int64_t)H ||
-        (E > 0 && (!z || !bias || !c_prev || !done || !gates || !c_new || !h_new)))
+static bool strides_ok(int64_t E, int H, const int64_t* st4, int n4, const int64_t* st1, int n1) {
+    for (int i = 0; i < n4; ++i) if (st4[i] < E * 4 * (int64_t)H || st4[i] % 4) return false;
+    for (int i = 0; i < n1; ++i) if (st1[i] < E * (int64_t)H || st1[i] % 4) return false;
+    return true;
+}
+
+extern "C" int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, int64_t z_sn,
+                                   const float* z2, int64_t z2_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,
+                                   const float* done, float* gates, int64_t gates_sn, float* c_new,
+                                   int64_t c_new_sn, float* h_new, int64_t h_new_sn, void* stream) {
+    if (E < 0 || N <= 0 || H <= 0 || H % 4 || bias_sn < 4 * (int64_t)H || bias_sn % 4 ||
+        (E > 0 && (!z || !bias || !c_prev || !done || !c_new || !h_new)))
         return NMARL_EINVAL;
+    const int64_t s4[3] = {z_sn, gates ? gates_sn : z_sn, z2 ? z2_sn : z_sn}, s1[3] = {c_prev_sn, c_new_sn, h_new_sn};
+    if (!strides_ok(E, H, s4, 3, s1, 3)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_x((int64_t)N * E * H)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), E, N, H, z, bias, bias_stride, c_prev, done, gates, c_new, h_new);
+    CellStrides st{};
+    st.z = z_sn; st.z2 = z2_sn; st.bias = bias_sn; st.c_prev = c_prev_sn; st.gates = gates_sn; st.c_new = c_new_sn; st.h_new = h_new_sn;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_x((int64_t)N * E * H / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), E, N, H, st, z, z2, bias, c_prev, done, gates, c_new, h_new);
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, const float* c_prev,
-                                   const float* c_new, const float* done, const float* dh, const float* dc_new,
-                                   float* dz, float* dc_prev, void* stream) {
-    if (E < 0 || N <= 0 || H <= 0 || (E > 0 && (!gates || !c_prev || !c_new || !done || !dz || !dc_prev)))
+extern "C" int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int64_t gates_sn,
+                                   const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
+                                   const float* done, const float* dh, int64_t dh_sn, const float* dc_new,
+                                   int64_t dc_sn, float* dz, int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn,
+                                   void* stream) {
+    if (E < 0 || N <= 0 || H <= 0 || H % 4 || (E > 0 && (!gates || !c_prev || !c_new || !done || !dz || !dc_prev)))
         return NMARL_EINVAL;
+    const int64_t s4[2] = {gates_sn, dz_sn};
+    const int64_t s1[5] = {c_prev_sn, c_new_sn, dc_prev_sn, dh ? dh_sn : c_new_sn, dc_new ? dc_sn : c_new_sn};
+    if (!strides_ok(E, H, s4, 2, s1, 5)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_x((int64_t)N * E * H)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), E, N, H, gates, c_prev, c_new, done, dh, dc_new, dz, dc_prev);
+    CellStrides st{};
+    st.gates = gates_sn; st.c_prev = c_prev_sn; st.c_new = c_new_sn; st.dh = dh_sn; st.dc = dc_sn; st.dz = dz_sn;
+    st.dc_prev = dc_prev_sn;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_x((int64_t)N * E * H / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), E, N, H, st, gates, c_prev, c_new, done, dh, dc_new, dz, dc_prev);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, float* x, int64_t x_sn, const float* bias,
+                              int64_t bias_sn, int32_t act, void* stream) {
+    if (rows < 0 || N <= 0 || W <= 0 || W % 4 || act < 0 || act > 2 || x_sn < rows * W || x_sn % 4 || bias_sn < W ||
+        bias_sn % 4 || (rows > 0 && (!x || !bias)))
+        return NMARL_EINVAL;
+    if (rows == 0) return NMARL_OK;
+    hipLaunchKernelGGL(bias_act_kernel, dim3(grid_x((int64_t)N * rows * W / 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), rows, N, W, x, x_sn, bias, bias_sn, act);
     return nmarl_check_launch();
 }
 

@@ -127,17 +127,22 @@ class CACCBatchEnv:
         _lib.check(rc, 'nmarl_cacc_reset')
         return self.obs
 
-    def step(self, action, auto_reset=False):
+    def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
         """action [E,8] uint8 -> (obs [E,8,15], reward [E]|[E,8], done [E] u8, global_reward [E]).
-        The returned tensors are this env's persistent buffers (overwritten every step)."""
+        By default the results land in this env's persistent buffers (overwritten every step); the
+        `*_out` tensors redirect them, e.g. straight into slot t of the trainer's rollout buffers."""
         P = _lib.ptr
+        obs = self.obs if obs_out is None else obs_out
+        reward = self.reward if reward_out is None else reward_out
+        done = self.done if done_out is None else done_out
+        greward = self.global_reward if greward_out is None else greward_out
         rc = _lib.lib.nmarl_cacc_step(
             ctypes.byref(self.params), self.E, P(action, torch.uint8), P(self.h), P(self.v), P(self.u),
-            P(self.t), P(self.collided), P(self.v0_init), P(self.obs), P(self.reward), P(self.done),
-            P(self.global_reward), 1 if auto_reset else 0, self.seed, self.env_id_base,
-            P(self.episode), _lib.stream())
+            P(self.t), P(self.collided), P(self.v0_init), P(obs, torch.float32), P(reward, torch.float32),
+            P(done, torch.uint8), P(greward, torch.float32), 1 if auto_reset else 0, self.seed,
+            self.env_id_base, P(self.episode), _lib.stream())
         _lib.check(rc, 'nmarl_cacc_step')
-        return self.obs, self.reward, self.done, self.global_reward
+        return obs, reward, done, greward
 
     def update_fingerprint(self, fp):
         self.fp = fp

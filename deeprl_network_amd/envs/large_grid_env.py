@@ -82,14 +82,19 @@ class LargeGridBatchEnv:
         _lib.check(rc, 'nmarl_grid_reset')
         return self.obs
 
-    def step(self, action, auto_reset=False):
+    def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
         P = _lib.ptr
+        obs = self.obs if obs_out is None else obs_out
+        reward = self.reward if reward_out is None else reward_out
+        done = self.done if done_out is None else done_out
+        greward = self.global_reward if greward_out is None else greward_out
         rc = _lib.lib.nmarl_grid_step(ctypes.byref(self.params), self.E, P(action, torch.uint8), P(self.q),
-                                      P(self.transit), P(self.prev_action), P(self.t), P(self.xi), P(self.obs),
-                                      P(self.reward), P(self.done), P(self.global_reward), 1 if auto_reset else 0,
-                                      self.seed, self.env_id_base, P(self.episode), _lib.stream())
+                                      P(self.transit), P(self.prev_action), P(self.t), P(self.xi),
+                                      P(obs, torch.float32), P(reward, torch.float32), P(done, torch.uint8),
+                                      P(greward, torch.float32), 1 if auto_reset else 0, self.seed,
+                                      self.env_id_base, P(self.episode), _lib.stream())
         _lib.check(rc, 'nmarl_grid_step')
-        return self.obs, self.reward, self.done, self.global_reward
+        return obs, reward, done, greward
 
 
 class LargeGridEnv:

@@ -93,6 +93,16 @@ def nbr_onehot(action, nbr_idx, n_a, out=None):
     return out
 
 
+def _pn(t, dtype=F32):
+    """[N,E,W] tensor with contiguous [E,W] panels (e.g. slot t of an [N,T,E,W] buffer) -> (ptr, agent stride)."""
+    if t is None:
+        return None, 0
+    if t.dim() != 3 or t.stride(2) != 1 or (t.shape[1] > 1 and t.stride(1) != t.shape[2]):
+        raise _lib.NmarlError('expected [N,E,W] with contiguous [E,W] panels, got shape %s strides %s'
+                              % (tuple(t.shape), t.stride()))
+    return ptr(t, dtype, strided=True), t.stride(0)
+
+
 def _bias(bias):
     """[N,4H] bias, possibly a strided view of the flat parameter buffer -> (ptr, row stride)."""
     if bias.stride(1) != 1:
@@ -100,34 +110,53 @@ def _bias(bias):
     return ptr(bias, F32, strided=True), bias.stride(0)
 
 
+def cell_fwd(z, bias, c_prev, done, gates, c_new, h_new, z2=None):
+    """Raw launch of nmarl_lstm_cell_fwd on (possibly strided) [N,E,*] panels; gates / z2 may be None."""
+    N, E, H4 = z.shape
+    check(lib.nmarl_lstm_cell_fwd(E, N, H4 // 4, *_pn(z), *_pn(z2), *_bias(bias), *_pn(c_prev), ptr(done, F32),
+                                  *_pn(gates), *_pn(c_new), *_pn(h_new), stream()), 'nmarl_lstm_cell_fwd')
+
+
+BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
+
+
+def bias_act_(x, bias, act):
+    """In-place x = act(x + bias[:, None, :]) for x [N,rows,W] (no autograd: rollout only)."""
+    N, rows, W = x.shape
+    xp, xs = _pn(x)
+    bp, bs = _bias(bias)
+    check(lib.nmarl_bias_act(rows, N, W, xp, xs, bp, bs, act, stream()), 'nmarl_bias_act')
+    return x
+
+
+def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev):
+    N, E, H4 = gates.shape
+    check(lib.nmarl_lstm_cell_bwd(E, N, H4 // 4, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh),
+                                  *_pn(dc), *_pn(dz), *_pn(dc_prev), stream()), 'nmarl_lstm_cell_bwd')
+
+
 class _LstmCell(torch.autograd.Function):
     """(z [N,E,4H], bias [N,4H], c_prev [N,E,H], done [E]) -> (h_new, c_new)."""
 
     @staticmethod
     def forward(ctx, z, bias, c_prev, done):
-        N, E, H4 = z.shape
-        H = H4 // 4
         z = z.contiguous()
         c_prev = c_prev.contiguous()
         gates = torch.empty_like(z)
         c_new = torch.empty_like(c_prev)
         h_new = torch.empty_like(c_prev)
-        check(lib.nmarl_lstm_cell_fwd(E, N, H, ptr(z, F32), *_bias(bias), ptr(c_prev, F32), ptr(done, F32),
-                                      ptr(gates), ptr(c_new), ptr(h_new), stream()), 'nmarl_lstm_cell_fwd')
+        cell_fwd(z, bias, c_prev, done, gates, c_new, h_new)
         ctx.save_for_backward(gates, c_prev, c_new, done)
         return h_new, c_new
 
     @staticmethod
     def backward(ctx, dh, dc):
         gates, c_prev, c_new, done = ctx.saved_tensors
-        N, E, H4 = gates.shape
-        H = H4 // 4
         dz = torch.empty_like(gates)
         dc_prev = torch.empty_like(c_prev)
         dh = None if dh is None else dh.contiguous()
         dc = None if dc is None else dc.contiguous()
-        check(lib.nmarl_lstm_cell_bwd(E, N, H, ptr(gates), ptr(c_prev), ptr(c_new), ptr(done), ptr(dh), ptr(dc),
-                                      ptr(dz), ptr(dc_prev), stream()), 'nmarl_lstm_cell_bwd')
+        cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev)
         return dz, dz.sum(dim=1), dc_prev, None
 
 
@@ -135,12 +164,68 @@ def lstm_cell(z, bias, c_prev, done):
     return _LstmCell.apply(z, bias, c_prev, done)
 
 
-def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out):
-    """No-autograd cell for the rollout: gates are written over z, c/h into the given buffers."""
-    N, E, H4 = z.shape
-    check(lib.nmarl_lstm_cell_fwd(E, N, H4 // 4, ptr(z, F32), *_bias(bias), ptr(c_prev, F32), ptr(done, F32),
-                                  ptr(z), ptr(c_out, F32), ptr(h_out, F32), stream()), 'nmarl_lstm_cell_fwd')
+def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out, z2=None):
+    """No-autograd cell for the rollout: gates are not materialised; c/h go to the given buffers
+    (which may alias c_prev / the previous h); z2 is an optional second pre-activation addend."""
+    cell_fwd(z, bias, c_prev, done, None, c_out, h_out, z2=z2)
     return h_out, c_out
+
+
+class _LstmSequence(torch.autograd.Function):
+    """cuDNN-style fused recurrence for agent-batched LSTMs without cross-agent coupling
+    (LstmPolicy / FPPolicy, agents/utils.py:87-115 unrolled over n_step):
+
+        z_t = pre[:, t] + (h_{t-1} * (1 - done_t)) @ wh ;  (h_t, c_t) = cell(z_t + b, c_{t-1}, done_t)
+
+    pre [N,T,E,4H] (x-side pre-activations, no bias), wh [N,H,4H], b [N,4H], h0/c0 [N,E,H],
+    done [T,E] f32 -> Hs [N,T,E,H].  Forward keeps gates / c / h for all steps in three sequence
+    buffers; backward is ONE reverse loop of (cell_bwd, dgrad GEMM) plus, after the loop, a single
+    wgrad GEMM over all T*E rows and a single bias reduction -- instead of T small ones."""
+
+    @staticmethod
+    def forward(ctx, pre, wh, b, h0, c0, done):
+        N, T, E, H4 = pre.shape
+        H = H4 // 4
+        G = torch.empty(N, T, E, H4, dtype=F32, device=pre.device)
+        Hall = torch.empty(N, T + 1, E, H, dtype=F32, device=pre.device)
+        Call = torch.empty(N, T + 1, E, H, dtype=F32, device=pre.device)
+        Hall[:, 0].copy_(h0)
+        Call[:, 0].copy_(c0)
+        keep = (1.0 - done)                                                   # [T,E]
+        for t in range(T):
+            hk = Hall[:, t] * keep[t].view(1, E, 1)
+            z = torch.baddbmm(pre[:, t], hk, wh)
+            cell_fwd(z, b, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1])
+        ctx.save_for_backward(G, Hall, Call, wh, done)
+        return Hall[:, 1:]
+
+    @staticmethod
+    def backward(ctx, dHs):
+        G, Hall, Call, wh, done = ctx.saved_tensors
+        N, T, E, H4 = G.shape
+        H = H4 // 4
+        dHs = dHs.contiguous()
+        dZ = torch.empty_like(G)
+        keep = (1.0 - done)
+        dh_rec = None
+        dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
+        dc_next = torch.empty_like(dc)
+        wh_t = wh.transpose(1, 2)
+        for t in range(T - 1, -1, -1):
+            dh = dHs[:, t] if dh_rec is None else dHs[:, t] + dh_rec      # strided slot is fine for the kernel
+            cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dh, dc, dZ[:, t], dc_next)
+            dc, dc_next = dc_next, dc
+            dh_rec = torch.bmm(dZ[:, t], wh_t) * keep[t].view(1, E, 1)
+        dZf = dZ.view(N, T * E, H4)
+        # h_{t-1} * keep_t for all t: Hall[:, :T] is a strided view (agent stride (T+1)*E*H)
+        Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+        dwh = torch.bmm(Hprev.transpose(1, 2), dZf)
+        db = dZf.sum(dim=1)
+        return dZ, dwh, db, dh_rec, dc, None
+
+
+def lstm_sequence(pre, wh, b, h0, c0, done):
+    return _LstmSequence.apply(pre, wh, b, h0, c0, done)
 
 
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2

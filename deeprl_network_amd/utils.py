@@ -292,14 +292,15 @@ class BatchedTrainer:
         self.rank, self.world_size = rank, world_size
         d = env.device
         self.device = d
-        self.action = torch.zeros(self.E, self.N, dtype=torch.uint8, device=d)
         self.action_boot = torch.zeros(self.E, self.N, dtype=torch.uint8, device=d)
-        self.done_pre = torch.ones(self.E, dtype=torch.float32, device=d)       # episode start (Q3)
+        self.done_pre = model.buf_done_pre[0]                                    # [E] f32, episode start (Q3)
+        self.done_pre.fill_(1.0)
         self.zero_done = torch.zeros(self.E, dtype=torch.float32, device=d)
         self.step_dev = torch.zeros((), dtype=torch.int64, device=d)            # global lock-step (Philox counter)
         self.R_end = torch.zeros(self.N, self.E, dtype=torch.float32, device=d)
         self.buf_g = torch.zeros(self.n_step, self.E, dtype=torch.float32, device=d)
-        self.last_done = torch.zeros(self.E, dtype=torch.uint8, device=d)
+        self.buf_rraw = torch.zeros_like(model.buf_r)                            # raw rewards written by the env kernel
+        self.last_done = model.buf_done_post[self.n_step - 1]                    # view: done flags of the last lock-step
         # per-replica running episode statistics (sum, sum of squares, length) of the global reward
         self.ep_sum = torch.zeros(self.E, dtype=torch.float64, device=d)
         self.ep_sq = torch.zeros(self.E, dtype=torch.float64, device=d)
@@ -310,25 +311,25 @@ class BatchedTrainer:
         self.data = []
         self.n_batches = 0
         env.train_mode = True
-        env.reset()
         model.reset_states()
+        model.t = 0
+        model.buf_x[0].copy_(env.reset())
 
-    # -- the n_step rollout (graph body)
+    # -- the n_step rollout (graph body): every kernel reads / writes rollout-buffer slots directly
     def _rollout(self):
         env, model = self.env, self.model
+        T = self.n_step
         model.t = 0
-        for t in range(self.n_step):
-            done_in = self.done_pre if t == 0 else self.zero_done
-            model.act(env.obs, done_in, self.action, mode=ops.SAMPLE_PHILOX, seed=env.seed,
-                      env_id_base=env.env_id_base, step_dev=self.step_dev)
-            _, r, d, g = env.step(self.action, auto_reset=(t == self.n_step - 1))
-            model.record(r, d)
-            self.buf_g[t].copy_(g)
+        for t in range(T):
+            action = model.act(self.done_pre if t == 0 else self.zero_done, mode=ops.SAMPLE_PHILOX, seed=env.seed,
+                               env_id_base=env.env_id_base, step_dev=self.step_dev, done_is_zero=(t > 0))
+            env.step(action, auto_reset=(t == T - 1), obs_out=model.buf_x[t + 1], reward_out=self.buf_rraw[t],
+                     done_out=model.buf_done_post[t], greward_out=self.buf_g[t])
+            model.t = t + 1
             self.step_dev.add_(1)
-        self.last_done.copy_(env.done)
         # bootstrap value for unfinished replicas (utils.py:192-196); finished ones get R = 0
-        v = model.bootstrap(env.obs, self.zero_done, self.action_boot, mode=ops.SAMPLE_PHILOX, seed=env.seed,
-                            env_id_base=env.env_id_base, step_dev=self.step_dev)
+        v = model.bootstrap(self.zero_done, self.action_boot, mode=ops.SAMPLE_PHILOX, seed=env.seed,
+                            env_id_base=env.env_id_base, step_dev=self.step_dev, done_is_zero=True)
         self.step_dev.add_(1)
         self.R_end.copy_(v * (1.0 - self.last_done.to(torch.float32)).view(1, -1))
 
@@ -356,7 +357,7 @@ class BatchedTrainer:
 
     def _state_tensors(self):
         m = self.model
-        return self.env.state_tensors() + [m.h_fw, m.c_fw, m.fp, self.step_dev, self.done_pre]
+        return self.env.state_tensors() + [m.h_fw, m.c_fw, m.buf_x[0], m.buf_fp[0], self.step_dev, self.done_pre]
 
     def _snapshot(self):
         return [t.clone() for t in self._state_tensors()]
@@ -368,8 +369,9 @@ class BatchedTrainer:
     def run_batch(self):
         """One rollout + update.  Returns nothing; statistics stay on the device until `stats()`."""
         self.rollout()
+        self.model.load_rewards(self.buf_rraw)
+        done = self.last_done.clone()            # update() recycles nothing here, but keep a stable copy
         self.model.update(self.R_end)
-        done = self.last_done
         # episode bookkeeping, all on device
         g = self.buf_g.double()
         self.ep_sum += g.sum(0)
@@ -408,7 +410,6 @@ class BatchedTrainer:
                              seed=self.env.seed - 1 if seed is None else seed, env_id_base=10 ** 9)
         env.train_mode = False
         model = self.model
-        saved = [t.clone() for t in (model.h_fw, model.c_fw, model.fp)]
         E0 = model.E
         h, c = (torch.zeros(self.N, n_envs, model.n_lstm, device=self.device) for _ in range(2))
         fp = torch.full((self.N, n_envs, model.n_a), 1.0 / model.n_a, device=self.device)
@@ -419,7 +420,7 @@ class BatchedTrainer:
         alive = torch.ones(n_envs, dtype=torch.float64, device=self.device)
         steps = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
         for _ in range(env.T):
-            model.policy.step(env.obs, fp, h, c, done, h, c)
+            model.policy.step(model.policy.encode(env.obs, fp), h, c, done, h, c)
             with torch.no_grad():
                 pi = model.policy.pi(h)
             ops.sample_actions(pi, act, ops.SAMPLE_ARGMAX)
@@ -429,9 +430,7 @@ class BatchedTrainer:
             steps += alive
             alive = alive * (1.0 - d.double())
             done.zero_()
-        for t, s in zip((model.h_fw, model.c_fw, model.fp), saved):
-            t.copy_(s)
-        assert model.E == E0
+        assert model.E == E0                      # evaluation used its own state tensors only
         per_ep = (total / steps.clamp_min(1)).cpu().numpy()
         return float(per_ep.mean()), float(per_ep.std()), int((steps < env.T).sum().item())
 

@@ -191,19 +191,34 @@ int nmarl_nbr_onehot(int64_t E, int32_t N, int32_t A, int32_t m_max, const int32
 /*
  * LSTM cell with done reset -- agents/utils.py:102-113 (lstm), 199-208
  * (lstm_comm), 401-408 (lstm_ic3).  z [N,E,4H] = s*Wx + (h*(1-done))*Wh (bias
- * NOT yet added), bias [N,4H] with row stride bias_stride (floats), c_prev [N,E,H], done [E] f32 in {0,1}.
+ * NOT yet added), bias [N,4H], c_prev [N,E,H], done [E] f32 in {0,1}.
  *   i,f,o = sigmoid(z+b), u = tanh(z+b)   (gate order i,f,o,u)
  *   c' = f * (c_prev*(1-done)) + i*u ;  h' = o * tanh(c')
- * gates [N,E,4H] receives the post-activation i,f,o,u (saved for backward;
- * may alias z).  bwd: dz [N,E,4H] (= d bias before the reduction over E),
- * dc_prev [N,E,H]; dh / dc_new may be NULL (= 0).
+ * Every tensor has contiguous [E,W] panels and its own AGENT STRIDE `*_sn` in floats
+ * (multiple of 4), so slot t of an [N,T,E,W] sequence buffer is passed in place.
+ * z2 (may be NULL) is a second addend of the pre-activation (the x-side part s*Wx kept apart so
+ * that the recurrent GEMM needs no copy+accumulate).
+ * gates [N,E,4H] receives the post-activation i,f,o,u (saved for backward; may
+ * alias z; NULL = inference, not written).  H % 4 == 0, 16-byte aligned panels.
+ * bwd: dz [N,E,4H] (= d bias before the reduction over E), dc_prev [N,E,H];
+ * dh / dc_new may be NULL (= 0).
  */
-int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, const float* bias,
-                        int64_t bias_stride, const float* c_prev, const float* done, float* gates, float* c_new,
-                        float* h_new, void* stream);
-int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, const float* c_prev,
-                        const float* c_new, const float* done, const float* dh, const float* dc_new,
-                        float* dz, float* dc_prev, void* stream);
+int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, int64_t z_sn,
+                        const float* z2, int64_t z2_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,
+                        const float* done, float* gates, int64_t gates_sn, float* c_new,
+                        int64_t c_new_sn, float* h_new, int64_t h_new_sn, void* stream);
+int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int64_t gates_sn,
+                        const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
+                        const float* done, const float* dh, int64_t dh_sn, const float* dc_new,
+                        int64_t dc_sn, float* dz, int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn,
+                        void* stream);
+/*
+ * In-place x[n,r,:] = act(x[n,r,:] + bias[n,:]) on [N,rows,W] (agent strides in floats, W % 4 == 0);
+ * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the
+ * lstm_comm / lstm_ic3 encoders (agents/utils.py:196-198, 400) after a plain batched GEMM.
+ */
+int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, float* x, int64_t x_sn, const float* bias,
+                   int64_t bias_sn, int32_t act, void* stream);
 /*
  * Action draw of Trainer._get_policy (utils.py:135-141) for all (replica, agent):
  * pi [N,E,A] -> action [E,N] u8.

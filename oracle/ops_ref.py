@@ -58,11 +58,34 @@ def lstm_cell(z, bias, c_prev, done):
     return h, c
 
 
-def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out):
-    h, c = lstm_cell(z, bias, c_prev, done)
+BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
+
+
+def bias_act_(x, bias, act):
+    """fc's bias + activation (agents/utils.py:65-73), in place."""
+    y = x + bias.unsqueeze(1)
+    x.copy_(torch.relu(y) if act == BIAS_RELU else torch.tanh(y) if act == BIAS_TANH else y)
+    return x
+
+
+def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out, z2=None):
+    h, c = lstm_cell(z if z2 is None else z + z2, bias, c_prev, done)
     c_out.copy_(c)
     h_out.copy_(h)
     return h_out, c_out
+
+
+def lstm_sequence(pre, wh, b, h0, c0, done):
+    """agents/utils.py:102-113 over T steps for all agents: plain autograd loop."""
+    N, T, E, H4 = pre.shape
+    h, c = h0, c0
+    hs = []
+    for t in range(T):
+        keep = (1.0 - done[t]).view(1, E, 1)
+        z = pre[:, t] + torch.bmm(h * keep, wh)
+        h, c = lstm_cell(z, b, c, done[t])
+        hs.append(h)
+    return torch.stack(hs, dim=1)
 
 
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2

@@ -10,7 +10,7 @@ import contextlib
 from deeprl_network_amd import ops
 from oracle import ops_ref
 
-_NAMES = ['nbr_gather', 'nbr_mean', 'nbr_onehot', 'lstm_cell', 'lstm_cell_infer', 'sample_actions',
+_NAMES = ['nbr_gather', 'nbr_mean', 'nbr_onehot', 'lstm_cell', 'lstm_cell_infer', 'lstm_sequence', 'bias_act_', 'sample_actions',
           'nstep_return', 'rmsprop_tf_clip']
 
 
@@ -70,17 +70,22 @@ class CpuCaccBatchEnv:
         self.ref.reset(U, mask=None if mask is None and not hasattr(self.ref, 'h') else m)
         return self._emit()
 
-    def step(self, action, auto_reset=False):
+    def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
         import torch
         _, r, d, g = self.ref.step(action.numpy())
-        self.reward.copy_(torch.from_numpy(np_f32(r)))
-        self.global_reward.copy_(torch.from_numpy(np_f32(g)))
-        self.done.copy_(torch.from_numpy(d.astype('uint8')))
+        reward = self.reward if reward_out is None else reward_out
+        greward = self.global_reward if greward_out is None else greward_out
+        done = self.done if done_out is None else done_out
+        reward.copy_(torch.from_numpy(np_f32(r)))
+        greward.copy_(torch.from_numpy(np_f32(g)))
+        done.copy_(torch.from_numpy(d.astype('uint8')))
         if auto_reset and d.any():
             self.reset(mask=torch.from_numpy(d.astype('uint8')))
         else:
             self._emit()
-        return self.obs, self.reward, self.done, self.global_reward
+        if obs_out is not None:
+            obs_out.copy_(self.obs)
+        return (self.obs if obs_out is None else obs_out), reward, done, greward
 
 
 def np_f32(x):

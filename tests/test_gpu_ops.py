@@ -71,10 +71,54 @@ def test_lstm_cell_fwd_bwd(N, E, H):
     for a, r, name in zip(ins_g, ins_c, 'zbc'):
         torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=2e-4, atol=2e-5 * max(1, E ** 0.5), msg=name)
     # strided bias view (row stride > 4H), as handed over by the flat parameter buffer
-    big = torch.zeros(N, 4 * H + 37, device='cuda')
-    big[:, 5:5 + 4 * H] = b.cuda()
-    h3, c3 = ops.lstm_cell(z.cuda(), big[:, 5:5 + 4 * H], c.cuda(), done.cuda())
+    big = torch.zeros(N, 4 * H + 40, device='cuda')        # 16-byte aligned rows, like the ParamStore views
+    big[:, 8:8 + 4 * H] = b.cuda()
+    h3, c3 = ops.lstm_cell(z.cuda(), big[:, 8:8 + 4 * H], c.cuda(), done.cuda())
     assert torch.equal(h3, h1.detach()) and torch.equal(c3, c1.detach())
+
+
+@pytest.mark.parametrize('N,T,E,H', [(8, 6, 33, 64), (3, 4, 128, 16)])
+def test_lstm_sequence_fwd_bwd(N, T, E, H):
+    """Fused recurrence (one wgrad GEMM / one bias reduction) == plain per-step autograd loop."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(7)
+    pre = torch.randn(N, T, E, 4 * H, generator=g)
+    wh = torch.randn(N, H, 4 * H, generator=g) * 0.2
+    b = torch.randn(N, 4 * H, generator=g) * 0.1
+    h0, c0 = torch.randn(N, E, H, generator=g) * 0.5, torch.randn(N, E, H, generator=g) * 0.5
+    done = (torch.rand(T, E, generator=g) < 0.2).float()
+    w = torch.randn(N, T, E, H, generator=g)
+    ins_g = [t.cuda().requires_grad_(True) for t in (pre, wh, b, h0, c0)]
+    ins_c = [t.double().requires_grad_(True) for t in (pre, wh, b, h0, c0)]
+    Hg = ops.lstm_sequence(*ins_g, done.cuda())
+    Hc = ops_ref.lstm_sequence(*ins_c, done.double())
+    torch.testing.assert_close(Hg.cpu().double(), Hc, rtol=1e-4, atol=1e-5)
+    (Hg * w.cuda()).sum().backward()
+    (Hc * w.double()).sum().backward()
+    for a, r, name in zip(ins_g, ins_c, ['pre', 'wh', 'b', 'h0', 'c0']):
+        torch.testing.assert_close(a.grad.cpu().double(), r.grad, rtol=1e-3, atol=2e-4, msg=name)
+
+
+def test_bias_act_and_cell_second_addend():
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(11)
+    N, E, H = 8, 77, 64
+    for act in (ops.BIAS_NONE, ops.BIAS_RELU, ops.BIAS_TANH):
+        x = torch.randn(N, E, H, generator=g)
+        b = torch.randn(N, H, generator=g)
+        y = ops.bias_act_(x.clone().cuda(), b.cuda(), act)
+        torch.testing.assert_close(y.cpu(), ops_ref.bias_act_(x.clone(), b, act), rtol=1e-6, atol=1e-6)
+    z, z2 = torch.randn(N, E, 4 * H, generator=g), torch.randn(N, E, 4 * H, generator=g)
+    b = torch.randn(N, 4 * H, generator=g)
+    c = torch.randn(N, E, H, generator=g)
+    done = (torch.rand(E, generator=g) < 0.3).float()
+    co, ho = torch.empty(N, E, H, device='cuda'), torch.empty(N, E, H, device='cuda')
+    ops.lstm_cell_infer(z.cuda(), b.cuda(), c.cuda(), done.cuda(), co, ho, z2=z2.cuda())
+    hr, cr = ops_ref.lstm_cell(z + z2, b, c, done)
+    torch.testing.assert_close(ho.cpu(), hr, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(co.cpu(), cr, rtol=1e-5, atol=1e-6)
 
 
 def test_sample_actions_modes():

@@ -93,6 +93,19 @@ def measure_step_kernel(env, actions_tape, reps=20):
     return us
 
 
+def pmc_traffic(key):
+    """HBM bytes per replica-step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of tools/pmc_env.py, FETCH x2 per MI355X_MICROARCH.md, calibrated on a known copy).
+    PMC counters cannot be read from inside this process, so the newest committed measurement is reported."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    k = d['kernels'].get(key)
+    return (k['traffic_bytes_per_replica'], os.path.basename(files[-1])) if k else (None, None)
+
+
 def cpu_baseline(cfg_path, n_batches):
     """Reference-equivalent E=1 CPU loop (restated; TF-1.12 cannot run here) on ONE core."""
     from oracle import trainer_ref
@@ -183,9 +196,11 @@ def main():
         tape = model.buf_act.clone()
         us = measure_step_kernel(env, tape)
         ach = B_ALG_GATHERED * E / us / 1e3
+        tr_small, tr_src = pmc_traffic('cacc_step_E4096')
         out['roofline'] = {
             'kernel': 'cacc_step_kernel (nmarl_cacc_step)', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
-            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None,
+            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None if tr_small is None else tr_small * E,
+            'traffic_source': tr_src,
             'bytes_per_launch': B_ALG_GATHERED * E, 'us_per_launch': us, 'replicas_per_launch': E,
             'how': 'hipGraph of %d back-to-back step launches on the rollout state with the batch action tape, '
                    '20 replays between two HIP events on the launch stream (includes graph-node gaps). '
@@ -200,11 +215,16 @@ def main():
                 e = torch.arange(big_E, device=device)[:, None]
                 a = torch.arange(N_AGENT, device=device)[None, :]
                 big_tape = torch.stack([((e + 3 * a + s) % 4).to(torch.uint8) for s in range(8)])
+                for k in range(60):                      # leave the all-equilibrium start of the episode
+                    big.step(big_tape[k % 8], auto_reset=True)
                 us_b = measure_step_kernel(big, big_tape, reps=5)
                 ach_b = B_ALG_GATHERED * big_E / us_b / 1e3
+                tr_big, tr_src_b = pmc_traffic('cacc_step_E2p21')
                 out['roofline_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,
                                            'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
-                                           'traffic': None, 'replicas_per_launch': big_E, 'us_per_launch': us_b,
+                                           'traffic': None if tr_big is None else tr_big * big_E,
+                                           'traffic_source': tr_src_b,
+                                           'replicas_per_launch': big_E, 'us_per_launch': us_b,
                                            'bytes_per_launch': B_ALG_GATHERED * big_E,
                                            'how': 'same kernel at E=2^21 (working set 1.4 GB >> 256 MB Infinity Cache), '
                                                   'actions (env+3*agent+step) mod 4 (SURVEY.md 8d)'}

@@ -19,6 +19,26 @@
 // arithmetic follows the oracle operation by operation.
 #include "common.h"
 
+// ---- tuning knobs (defaults = shipped configuration; tools/ab_env.py builds variants with -D...)
+#ifndef NMARL_CACC_GRIDCAP
+#define NMARL_CACC_GRIDCAP (256 * 32)      // resident blocks, grid-stride beyond (A/B: 16 -> 32: +3 %)
+#endif
+#ifndef NMARL_CACC_BLOCK_LARGE
+#define NMARL_CACC_BLOCK_LARGE 256
+#endif
+#ifndef NMARL_CACC_NT_LARGE
+#define NMARL_CACC_NT_LARGE 2              // non-temporal stores when the working set exceeds the caches:
+#endif                                     //   1 = observation slab, 2 = also h, v, u.  A/B at E = 2^21
+#ifndef NMARL_CACC_NT_SMALL                //   (tools/ab_env.py): NT 0 / 1 / 2 = 363 / 303 / 209 us per launch
+#define NMARL_CACC_NT_SMALL 0              // small E lives in L2 / Infinity Cache between steps: plain stores
+#endif
+#ifndef NMARL_CACC_BLOCK_SMALL
+#define NMARL_CACC_BLOCK_SMALL 64
+#endif
+#ifndef NMARL_CACC_NOOBS
+#define NMARL_CACC_NOOBS 0                 // diagnostic only: skip the slab store
+#endif
+
 namespace {
 
 constexpr int N = NMARL_CACC_N;      // 8
@@ -61,25 +81,26 @@ __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fm
 // float64 cos on [0, pi] (the OVM ramp argument) without libm's register-hungry general path:
 // cos(t) = -sin(t - pi/2), pi/2 subtracted in two pieces so that cos(double(pi/2)) = 6.123e-17 like
 // libm / NumPy; odd Taylor polynomial to r^21 (|r| <= pi/2: truncation < 3e-16).
-__device__ __forceinline__ double cos_0_pi(double t) {
+__constant__ double c_sin_taylor[10] = {
+    -1.9572941063391263e-20, 8.22063524662433e-18, -2.8114572543455206e-15, 7.647163731819816e-13,
+    -1.6059043836821613e-10, 2.505210838544172e-08, -2.7557319223985893e-06, 1.984126984126984e-04,
+    -8.333333333333333e-03, 1.6666666666666666e-01};     // -1/21!, 1/19!, ..., -1/5!, 1/3!
+
+// Rarely executed (equilibrium states only): a rolled loop over scalar-loaded coefficients costs ~6
+// VGPRs instead of ~26 (an unrolled fp64 Horner chain keeps every literal in a register pair, which
+// cost the whole kernel two waves per SIMD of occupancy).
+__device__ __noinline__ double cos_0_pi(double t) {
     const double r = (t - 1.5707963267948966) - 6.123233995736766e-17;
     const double r2 = r * r;
-    double q = -1.9572941063391263e-20;                   // -1/21!
-    q = fma(q, r2, 8.22063524662433e-18);                 //  1/19!
-    q = fma(q, r2, -2.8114572543455206e-15);              // -1/17!
-    q = fma(q, r2, 7.647163731819816e-13);                //  1/15!
-    q = fma(q, r2, -1.6059043836821613e-10);              // -1/13!
-    q = fma(q, r2, 2.505210838544172e-08);                //  1/11!
-    q = fma(q, r2, -2.7557319223985893e-06);              // -1/9!
-    q = fma(q, r2, 1.984126984126984e-04);                //  1/7!
-    q = fma(q, r2, -8.333333333333333e-03);               // -1/5!
-    q = fma(q, r2, 1.6666666666666666e-01);               //  1/3!
-    const double sin_r = r - r * r2 * q;                  // sin r = r - r^3/3! + ...
-    return -sin_r;
+    double q = c_sin_taylor[0];
+#pragma unroll 1
+    for (int k = 1; k < 10; ++k) q = fma(q, r2, c_sin_taylor[k]);
+    return -(r - r * r2 * q);                             // -sin r
 }
 
 // _get_veh_state (cacc_env.py:54-65) for this lane's vehicle, then the
 // neighbour gather and the LDS-staged coalesced store of the wave's slab.
+template <int NT>
 __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, float v, float u,
                                          float v_lead, int a, bool valid, int lane, float* lds_wave,
                                          float* __restrict__ obs_wave, int n_valid_lanes) {
@@ -89,12 +110,12 @@ __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, 
     // The platoon's equilibrium (h = h*, v = v*) makes vh(h) - v vanish, and the reference's float64
     // cos(pi/2) = 6.1e-17 leaves this feature a NEGATIVE 3.6e-16; an fp32 cosf gives +1.3e-7.  The
     // feature multiplies O(1) weights into a relu whose mask (hence the bias gradient) depends on that
-    // sign, so where the fp32 difference is below its own resolution the term is re-evaluated in
-    // float64 like the reference (cacc_env.py:58-59, 365-366).  Rare outside episode starts.
+    // sign, so where the fp32 difference is within its own rounding noise (sign not trustworthy) the term is
+    // re-evaluated in float64 like the reference (cacc_env.py:58-59, 365-366).  Only near-exact equilibria.
     {
         const float d32 = ovm_vh(p, h) - v;
         x[2] = clampf(d32 / 5.0f, -2.0f, 2.0f);
-        if (fabsf(d32) < 1e-3f) {
+        if (fabsf(d32) < 2e-5f) {      // ~10x the fp32 error of vh - v (cos poly 1.2e-7 * 15, ulp(15) = 9.5e-7)
             const double hd = (double)h;
             const double th = 3.141592653589793 * (hd - (double)p.h_s) / ((double)p.h_g - (double)p.h_s);
             const double mid = (double)p.v_max / 2.0 * (1.0 - cos_0_pi(th));
@@ -124,7 +145,19 @@ __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = i * NMARL_WAVE + lane;
-        if (idx < n_vec) dst[idx] = src[idx];
+#if NMARL_CACC_NOOBS
+        (void)dst;
+#else
+        if (idx < n_vec) {
+            if (NT >= 1) {
+                const float4 val = src[idx];
+                __builtin_nontemporal_store(val.x, &dst[idx].x); __builtin_nontemporal_store(val.y, &dst[idx].y);
+                __builtin_nontemporal_store(val.z, &dst[idx].z); __builtin_nontemporal_store(val.w, &dst[idx].w);
+            } else {
+                dst[idx] = src[idx];
+            }
+        }
+#endif
     }
     (void)valid;
 }
@@ -147,7 +180,7 @@ __device__ __forceinline__ float reset_uniform(uint64_t seed, int64_t env_id, in
     return u01_from_bits(r.x);
 }
 
-template <int BLOCK>
+template <int BLOCK, int NT>
 __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
     const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ action,
     float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
@@ -239,7 +272,12 @@ __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
         }
 
         if (valid) {
-            hs[g] = h; vs[g] = v; us[g] = u_new;
+            if (NT >= 2) {
+                __builtin_nontemporal_store(h, &hs[g]); __builtin_nontemporal_store(v, &vs[g]);
+                __builtin_nontemporal_store(u_new, &us[g]);
+            } else {
+                hs[g] = h; vs[g] = v; us[g] = u_new;
+            }
             if (a == 0) {
                 ts[e] = t;
                 coll[e] = collided ? 1 : 0;
@@ -252,8 +290,8 @@ __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
         const int64_t lanes_here = n_lanes - w * NMARL_WAVE;
         const int n_valid = lanes_here >= NMARL_WAVE ? NMARL_WAVE : (int)lanes_here;
         __builtin_amdgcn_wave_barrier();
-        emit_obs(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
-                 obs + w * NMARL_WAVE * NOBS, n_valid);
+        emit_obs<NT>(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
+                     obs + w * NMARL_WAVE * NOBS, n_valid);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -310,7 +348,7 @@ __global__ __launch_bounds__(BLOCK) void cacc_reset_kernel(
         // the slab of a wave is rewritten as a whole; unselected replicas re-emit
         // their current observation (same values), so no read-modify-write is needed
         __builtin_amdgcn_wave_barrier();
-        emit_obs(p, h, v, u, v_lead, a, valid, lane, lds_wave, obs + w * NMARL_WAVE * NOBS, n_valid);
+        emit_obs<0>(p, h, v, u, v_lead, a, valid, lane, lds_wave, obs + w * NMARL_WAVE * NOBS, n_valid);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -318,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void cacc_reset_kernel(
 inline int pick_grid(int64_t E, int block) {
     const int64_t waves = (E * N + NMARL_WAVE - 1) / NMARL_WAVE;
     const int64_t blocks = (waves + block / NMARL_WAVE - 1) / (block / NMARL_WAVE);
-    const int64_t cap = 256 * 16;  // 256 CUs x 16 resident blocks, grid-stride beyond
+    const int64_t cap = NMARL_CACC_GRIDCAP;
     return (int)(blocks < cap ? blocks : cap);
 }
 
@@ -342,13 +380,16 @@ extern "C" int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const ui
     if (auto_reset && !episode) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // small E is latency bound: 1-wave blocks spread the replicas over more CUs
+    // small E is latency bound and cache resident: 1-wave blocks spread the replicas over more CUs and
+    // plain stores keep the state in L2 for the next step; large E streams (non-temporal stores)
     if (E * N <= 256 * 4 * NMARL_WAVE) {
-        hipLaunchKernelGGL(cacc_step_kernel<64>, dim3(pick_grid(E, 64)), dim3(64), 0, s, *p, E, action, h, v, u,
+        hipLaunchKernelGGL((cacc_step_kernel<NMARL_CACC_BLOCK_SMALL, NMARL_CACC_NT_SMALL>), dim3(pick_grid(E, NMARL_CACC_BLOCK_SMALL)),
+                           dim3(NMARL_CACC_BLOCK_SMALL), 0, s, *p, E, action, h, v, u,
                            t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
                            env_id_base, episode);
     } else {
-        hipLaunchKernelGGL(cacc_step_kernel<256>, dim3(pick_grid(E, 256)), dim3(256), 0, s, *p, E, action, h, v,
+        hipLaunchKernelGGL((cacc_step_kernel<NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE>), dim3(pick_grid(E, NMARL_CACC_BLOCK_LARGE)),
+                           dim3(NMARL_CACC_BLOCK_LARGE), 0, s, *p, E, action, h, v,
                            u, t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
                            env_id_base, episode);
     }

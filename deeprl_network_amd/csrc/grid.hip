@@ -87,6 +87,7 @@ __device__ __forceinline__ int nbr_of(int n, int k) {
     return -1;
 }
 
+template <int NT>
 __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ obs_env, int l32) {
     // 25 x 60 floats = 375 float4, coalesced
     float4* dst = reinterpret_cast<float4*>(obs_env);
@@ -100,10 +101,18 @@ __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ 
             const float* p = s.wave + src * NL + f;
             val = float4{p[0], p[1], p[2], p[3]};
         }
-        dst[v] = val;
+        if (NT) {
+            __builtin_nontemporal_store(val.x, &dst[v].x); __builtin_nontemporal_store(val.y, &dst[v].y);
+            __builtin_nontemporal_store(val.z, &dst[v].z); __builtin_nontemporal_store(val.w, &dst[v].w);
+        } else {
+            dst[v] = val;
+        }
     }
 }
 
+// NT = 1: non-temporal stores for state and slab when the working set exceeds the caches (same effect as
+// in csrc/cacc.hip: streaming writes at the fill ceiling instead of ~60 % of it).
+template <int NT>
 __global__ __launch_bounds__(256) void grid_step_kernel(
     const nmarl_grid_params_t p, const int64_t E, const uint8_t* __restrict__ action,
     float* __restrict__ qs, float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts,
@@ -224,7 +233,10 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
         if (live) {
             float* qo = qs + e * NN * NLANE;
             float* to = trs + e * NN * NLANE;
-            for (int i = l32; i < NN * NLANE; i += 32) { qo[i] = s.q[i]; to[i] = s.tr[i]; }
+            for (int i = l32; i < NN * NLANE; i += 32) {
+                if (NT) { __builtin_nontemporal_store(s.q[i], &qo[i]); __builtin_nontemporal_store(s.tr[i], &to[i]); }
+                else { qo[i] = s.q[i]; to[i] = s.tr[i]; }
+            }
             if (node) {
                 prev[e * NN + n] = (uint8_t)a;
                 if (p.per_agent_reward) reward[e * NN + n] = r_node;
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
                 xi[e * 4 + l32] = 0.8f + 0.4f * u01_from_bits(w);
             }
             if (rst && l32 == 4) episode[e] = episode[e] + 1;
-            emit_obs_slab(s, obs + e * NN * OBSW, l32);
+            emit_obs_slab<NT>(s, obs + e * NN * OBSW, l32);
         }
         half_barrier();
     }
@@ -294,9 +306,15 @@ extern "C" int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const ui
         return NMARL_EINVAL;
     if (auto_reset && !episode) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
-    hipLaunchKernelGGL(grid_step_kernel, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p, E,
-                       action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset, seed,
-                       env_id_base, episode);
+    if (E * 8800 > (int64_t)256 << 20) {     // beyond the 256 MB Infinity Cache: stream the writes
+        hipLaunchKernelGGL(grid_step_kernel<1>, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p,
+                           E, action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset,
+                           seed, env_id_base, episode);
+    } else {
+        hipLaunchKernelGGL(grid_step_kernel<0>, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p,
+                           E, action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset,
+                           seed, env_id_base, episode);
+    }
     return nmarl_check_launch();
 }
 

@@ -1,0 +1,58 @@
+"""Turn the rocprofv3 --pmc passes of tools/pmc_env.py (FETCH_SIZE and WRITE_SIZE, collected in SEPARATE runs as
+MI355X_MICROARCH.md prescribes) into profiles/<tag>_pmc_traffic.{json,md}.
+Corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports half of the bytes
+of a coalesced stream -> x2; verified here on a known 1 GiB copy in the same run (`calibration`).  WRITE_SIZE is
+used as reported (the same 1 GiB copy reads back exactly 1 GiB)."""
+import collections
+import csv
+import json
+import sys
+
+d, tag = sys.argv[1], sys.argv[2]
+
+
+def load(counter):
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open('%s/pmc_%s_counter_collection.csv' % (d, counter))):
+        out[r['Kernel_Name']].append((float(r['Counter_Value']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    return out
+
+
+F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
+
+
+def stat(name_part, skip=2):
+    ks = [k for k in F if name_part in k]
+    assert len(ks) == 1, (name_part, ks)
+    k = ks[0]
+    f = [x for x, _ in F[k]][skip:]
+    w = [x for x, _ in W[k]][skip:]
+    us = [t / 1e3 for _, t in F[k]][skip:]
+    return dict(kernel=k[:80], launches=len(f), fetch_KiB=sum(f) / len(f), write_KiB=sum(w) / len(w),
+                us_per_launch_profiled=sum(us) / len(us))
+
+
+cal = stat('__amd_rocclr_copyBuffer', skip=0)
+fetch_corr = (1 << 20) / cal['fetch_KiB']          # known: 1 GiB read per launch
+write_corr = (1 << 20) / cal['write_KiB']
+res = {'calibration': dict(cal, known_bytes_each_way=1 << 30, fetch_correction=fetch_corr, write_correction=write_corr),
+       'fetch_factor_used': 2.0, 'write_factor_used': 1.0, 'kernels': {}}
+for key, part, E, balg in (('cacc_step_E2p21', 'cacc_step_kernel<256', 1 << 21, 631), ('cacc_step_E4096', 'cacc_step_kernel<64', 4096, 631),
+                           ('grid_step_E2p17', 'grid_step_kernel', 1 << 17, 7548)):
+    s = stat(part)
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    s.update(replicas=E, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / E,
+             algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / E / balg)
+    res['kernels'][key] = s
+json.dump(res, open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
+with open('profiles/%s_pmc_traffic.md' % tag, 'w') as f:
+    f.write('# HBM traffic of the env-step kernels from rocprofv3 PMC passes\n\n'
+            'commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/pmc_env.py` and the same with '
+            '`--pmc WRITE_SIZE` (separate runs).\n\ncalibration on a 1 GiB `copy_` in the same runs: FETCH_SIZE = %.0f KiB '
+            '(x%.2f needed), WRITE_SIZE = %.0f KiB (x%.2f) -> the guide\'s gfx950 x2 FETCH correction is applied, WRITE as is.\n\n'
+            % (cal['fetch_KiB'], fetch_corr, cal['write_KiB'], write_corr))
+    f.write('| kernel | replicas | FETCH KiB | WRITE KiB | traffic B/replica | algorithmic B/replica | ratio | us/launch (profiled) |\n|---|---:|---:|---:|---:|---:|---:|---:|\n')
+    for k, s in res['kernels'].items():
+        f.write('| %s | %d | %.0f | %.0f | %.1f | %d | %.3f | %.1f |\n' % (k, s['replicas'], s['fetch_KiB'], s['write_KiB'],
+                s['traffic_bytes_per_replica'], s['algorithmic_bytes_per_replica'], s['traffic_over_algorithmic'], s['us_per_launch_profiled']))
+print(json.dumps(res['kernels'], indent=1))

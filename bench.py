@@ -115,7 +115,7 @@ def cpu_baseline(cfg_path, n_batches):
     env, model, tr = trainer_ref.build(cp)
     tr.run_batches(1)                                   # warm-up (allocator, first-touch)
     steps, sec = tr.run_batches(n_batches)
-    return {'value': steps * N_AGENT / sec, 'unit': 'env-steps/s (agents x envs x steps/s)', 'cores': 1,
+    return {'value': steps * env.n_agent / sec, 'unit': 'env-steps/s (agents x envs x steps/s)', 'cores': 1,
             'kind': 'port',
             'sample': '%d n_step batches (%d env steps, E=1) of the restated reference loop '
                       '(oracle/trainer_ref.py: NumPy env + per-agent torch-CPU LSTMs + TF-RMSProp), %.1f s'
@@ -149,8 +149,8 @@ def main():
     E = args.envs or cp['ENV_CONFIG'].getint('num_envs', fallback=4096)
     env = make_batch_env(cp['ENV_CONFIG'], num_envs=E, device=device, env_id_base=rank * E)
     np.random.seed(env.seed)                               # identical initial weights on every rank
-    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC,
-           'ma2c_ic3': models.MA2C_IC3}[env.agent]
+    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3,
+           'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[env.agent]
     model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, int(1e9),
                 cp['MODEL_CONFIG'], seed=env.seed, num_envs=E, device=device, dist_group=group)
     trainer = BatchedTrainer(env, model, Counter(int(1e18), int(1e18), int(1e18)), use_graph=not args.no_graph,
@@ -176,7 +176,12 @@ def main():
         elapsed = float(t.item())
 
     n_step = model.n_step
-    env_steps = N_AGENT * E * n_step * args.steps * world
+    is_grid = env.name.startswith('atsc')
+    n_agent = env.n_agent
+    # algorithmic bytes per replica-step of the env kernel
+    balg = 7548 if is_grid else B_ALG_GATHERED
+    kname = 'grid_step_kernel (nmarl_grid_step)' if is_grid else 'cacc_step_kernel (nmarl_cacc_step)'
+    env_steps = n_agent * E * n_step * args.steps * world
     out = {
         'metric': 'env-steps/sec (agents x envs x steps/s), full rollout + A2C update loop',
         'value': env_steps / elapsed, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
@@ -184,8 +189,9 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'a2c_updates_per_s': args.steps / elapsed,
         'lock_steps_per_s': n_step * args.steps / elapsed,
-        'config': {'workload': 'CACC catch-up, 8 agents x %d replicas/GPU, %s (%s), n_step %d'
-                               % (E, env.agent, os.path.basename(args.config), n_step),
+        'config': {'workload': '%s, %d agents x %d replicas/GPU, %s (%s), n_step %d'
+                               % ('ATSC 5x5 grid (synthetic)' if is_grid else 'CACC ' + env.name, n_agent, E, env.agent,
+                                  os.path.basename(args.config), n_step),
                    'replicas_per_gpu': E, 'global_replicas': E * world, 'parallelism': 'dp%d' % world,
                    'hipgraph_rollout': trainer.use_graph,
                    'step_definition': 'one n_step batch: %d lock-steps (2 LSTM steps each, quirk Q1) + bootstrap + '
@@ -195,19 +201,19 @@ def main():
         # ---- roofline of the env-step kernel, measured live on this rank's stream
         tape = model.buf_act.clone()
         us = measure_step_kernel(env, tape)
-        ach = B_ALG_GATHERED * E / us / 1e3
-        tr_small, tr_src = pmc_traffic('cacc_step_E4096')
+        ach = balg * E / us / 1e3
+        tr_small, tr_src = pmc_traffic('cacc_step_E4096') if (not is_grid and E == 4096) else (None, None)
         out['roofline'] = {
-            'kernel': 'cacc_step_kernel (nmarl_cacc_step)', 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
+            'kernel': kname, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
             'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None if tr_small is None else tr_small * E,
             'traffic_source': tr_src,
-            'bytes_per_launch': B_ALG_GATHERED * E, 'us_per_launch': us, 'replicas_per_launch': E,
+            'bytes_per_launch': balg * E, 'us_per_launch': us, 'replicas_per_launch': E,
             'how': 'hipGraph of %d back-to-back step launches on the rollout state with the batch action tape, '
                    '20 replays between two HIP events on the launch stream (includes graph-node gaps). '
                    'B_alg = %d B/replica-step (gathered-observation variant). At E=%d the launch moves %.2f MB: '
                    'latency-bound and LLC-resident (SURVEY.md H1); see roofline_large_E for the HBM regime.'
-                   % (n_step, B_ALG_GATHERED, E, B_ALG_GATHERED * E / 1e6)}
-        if world == 1:
+                   % (n_step, balg, E, balg * E / 1e6)}
+        if world == 1 and not is_grid:
             try:
                 big_E = 1 << 21
                 big = make_batch_env(cp['ENV_CONFIG'], num_envs=big_E, device=device, env_id_base=10 ** 7)
@@ -231,7 +237,7 @@ def main():
                 del big
             except Exception as ex:      # never lose the headline line to the side measurement
                 out['roofline_large_E'] = {'error': repr(ex)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not is_grid:
             out['cpu_baseline'] = cpu_baseline(args.config, args.cpu_batches)
         print(json.dumps(out))
     if world > 1:

@@ -25,7 +25,8 @@ import numpy as np
 import torch
 
 from .. import ops
-from .policies import FPPolicy, IC3MultiAgentPolicy, LstmPolicy, NCMultiAgentPolicy
+from .policies import (ConsensusPolicy, DIALMultiAgentPolicy, FPPolicy, IC3MultiAgentPolicy, LstmPolicy,
+                       NCMultiAgentPolicy)
 from .utils import Scheduler
 
 F32 = torch.float32
@@ -460,16 +461,17 @@ class MA2C_IC3(MA2C_NC):
 
 
 class IA2C_CU(MA2C_NC):
-    """ConseNet (models.py:261-275) -- SURVEY.md 8f.1 'next', not built in this round."""
+    """ConseNet (models.py:261-275): MA2C-style single optimiser + consensus averaging of the LSTM weights
+    over each neighbourhood after every update (policies.py:351-364)."""
+    policy_cls = ConsensusPolicy
     name = 'ma2c_cu'
 
-    def __init__(self, *a, **k):
-        raise NotImplementedError('IA2C_CU / ConsensusPolicy is scheduled after the hot path (SURVEY.md 8f.1)')
+    def update(self, R_end):
+        super().update(R_end)
+        self.policy.consensus_update()
 
 
 class MA2C_DIAL(MA2C_NC):
-    """DIAL (models.py:295-309) -- SURVEY.md 8f.1 'next', not built in this round."""
+    """DIAL (models.py:295-309)."""
+    policy_cls = DIALMultiAgentPolicy
     name = 'ma2c_dial'
-
-    def __init__(self, *a, **k):
-        raise NotImplementedError('MA2C_DIAL is scheduled after the hot path (SURVEY.md 8f.1)')

@@ -359,3 +359,90 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         p = self.params
         s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
         return torch.bmm(s, p['wx_hid']).baddbmm_(hk, p[self.k_wh]), None
+
+
+class ConsensusPolicy(LstmPolicy):
+    """ConseNet ("IA2C_CU", policies.py:339-426): per agent fc(own obs) -> LSTM -> heads inside ONE
+    optimiser; after every update each agent's LSTM weights are replaced by the mean over itself and its
+    neighbours (`_get_critic_wts` averages only the `lstm_%da` scope)."""
+    name = 'cu'
+
+    def _phases(self):
+        H, F = self.n_h, self.n_feat
+        return [[('fc_w', 'cu/fc_%da/w', (F, H), None), ('fc_b', 'cu/fc_%da/b', (H,), None),
+                 ('lstm_wx', 'cu/lstm_%da/wx', (H, 4 * H), None),
+                 ('lstm_wh', 'cu/lstm_%da/wh', (H, 4 * H), None),
+                 ('lstm_b', 'cu/lstm_%da/b', (4 * H,), None)] + self._head_phase('cu/pi_%d', 'cu/v_%da')]
+
+    def _own(self, xv):
+        return xv[:, :, :self.n_feat]        # the consensus net sees the agent's own features only
+
+    def _enc(self, xv, fp):
+        p = self.params
+        return torch.bmm(torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), self._own(xv), p['fc_w'])), p['lstm_wx'])
+
+    def _enc_infer(self, xv, fp):
+        return torch.bmm(self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
+
+    def consensus_update(self):
+        """policies.py:357-364, 403-426: simultaneous neighbourhood average of (wx, wh, b) of every agent's LSTM.
+        The three tensors are adjacent in the flat buffer: ONE [N,N] x [N,K] product."""
+        ps = self.params
+        o0 = ps.index['lstm_wx'][0]
+        o1 = ps.index['lstm_b'][0] + ps.index['lstm_b'][1]
+        if not hasattr(self, '_avg'):
+            tab = self.nbr_idx.cpu().numpy()
+            A = np.eye(self.N, dtype=np.float32)
+            for i in range(self.N):
+                for j in tab[i]:
+                    if j >= 0:
+                        A[i, j] = 1.0
+            self._avg = torch.from_numpy(A / A.sum(1, keepdims=True)).to(self.device)
+        with torch.no_grad():
+            blk = ps.flat[:, o0:o1]
+            blk.copy_(self._avg @ blk)
+
+
+class DIALMultiAgentPolicy(BatchedPolicy):
+    """DIAL (policies.py:479-525 + lstm_dial agents/utils.py:515-599):
+    s_i = relu(x~_i W_ob) + relu([mfc_j(h_j) for j in nbr(i)] W_msg) + onehot_H(argmax pi_i(t-1)) -> LSTM(H);
+    the message encoder mfc_j = relu(h_j W + b) acts on the sender's un-masked previous h."""
+    name = 'dial'
+    k_wh, k_b = 'wh_hid', 'hid_b'
+    coupled = True
+
+    def _phases(self):
+        H, F = self.n_h, self.n_feat
+        s = 'dial/lstm_comm_%d'
+        return [[('w_msg', s + '/w_msg', (H * self.m_max, H), lambda i: H * self._m(i)),
+                 ('w_msg_b', s + '/b_msg', (H,), None),
+                 ('w_ob', s + '/w_ob', (self.n_obs, H), lambda i: F * (1 + self._m(i))),
+                 ('w_ob_b', s + '/b_ob', (H,), None),
+                 ('wx_hid', s + '/wx_hid', (H, 4 * H), None),
+                 ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
+                 ('hid_b', s + '/b_hid', (4 * H,), None)],
+                [('mfc_w', 'dial/mfc_%d/w', (H, H), None), ('mfc_b', 'dial/mfc_%d/b', (H,), None)],
+                self._head_phase('dial/pi_%d', 'dial/v_%d')]
+
+    def _own_action_onehot(self, fp):
+        """one_hot(argmax(p_i), n_h) (agents/utils.py:577): first maximum, like tf.argmax."""
+        return torch.nn.functional.one_hot(torch.argmax(fp, dim=-1), self.n_h).to(fp.dtype)
+
+    def _enc(self, xv, fp):
+        p = self.params
+        return torch.relu(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob'])) + self._own_action_onehot(fp)
+
+    def _recur_in(self, enc, h):
+        p = self.params
+        msg = torch.relu(torch.baddbmm(p['mfc_b'].unsqueeze(1), h, p['mfc_w']))        # sender side, un-masked h
+        hm = torch.relu(torch.baddbmm(p['w_msg_b'].unsqueeze(1), ops.nbr_gather(msg, self.nbr_idx), p['w_msg']))
+        return torch.bmm(enc + hm, p['wx_hid'])
+
+    def _enc_infer(self, xv, fp):
+        return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU).add_(self._own_action_onehot(fp))
+
+    def _recur_infer(self, enc, h, hk):
+        p = self.params
+        msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU)
+        hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU).add_(enc)
+        return torch.bmm(hm, p['wx_hid']).baddbmm_(hk, p[self.k_wh]), None

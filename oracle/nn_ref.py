@@ -388,4 +388,113 @@ class MA2CIC3Ref(MA2CNCRef):
     scope, kind = 'ic3', 'ic3'
 
 
-REF_MODELS = {'ia2c': IA2CRef, 'ia2c_fp': IA2CFPRef, 'ma2c_nc': MA2CNCRef, 'ma2c_ic3': MA2CIC3Ref}
+class MA2CDIALRef(MA2CNCRef):
+    """MA2C_DIAL (models.py:295-309, policies.py:479-525, lstm_dial agents/utils.py:515-599)."""
+    scope, kind = 'dial', 'dial'
+
+    def __init__(self, *a, **k):
+        _ModelBase.__init__(self, *a, **k)
+        v, H, A = self.vars, self.H, self.A
+        F = self.n_s_ls[0]
+        for i in range(self.N):
+            m = len(self.nbr[i])
+            s = 'dial/lstm_comm_%d' % i
+            v.w(s + '/w_msg', (H * m, H)); v.b(s + '/b_msg', H)
+            v.w(s + '/w_ob', (F * (m + 1), H)); v.b(s + '/b_ob', H)
+            v.w(s + '/wx_hid', (H, 4 * H)); v.w(s + '/wh_hid', (H, 4 * H)); v.b(s + '/b_hid', 4 * H)
+        for i in range(self.N):                 # created inside the first unrolled step (agents/utils.py:561-564)
+            v.w('dial/mfc_%d/w' % i, (H, H)); v.b('dial/mfc_%d/b' % i, H)
+        for i in range(self.N):
+            m = len(self.nbr[i])
+            v.w('dial/pi_%d/w' % i, (H, A)); v.b('dial/pi_%d/b' % i, A)
+            v.w('dial/v_%d/w' % i, (H + A * m, 1)); v.b('dial/v_%d/b' % i, 1)
+        self.opt = TFRMSProp(v.scope('dial'), *self.rms)
+        self.buf = OnPolicyBufferRef(self.gamma, self.coop_gamma, self.dist, multi=True)
+        self.reset()
+
+    def _net(self, obs, ps, acts, dones, states):
+        v, H = self.vars, self.H
+        xs, pp = self.t(obs), self.t(ps)
+        T = xs.shape[1]
+        c, h = states[:, :H], states[:, H:]
+        hs = []
+        for t in range(T):
+            done = float(dones[t])
+            out_m = torch.cat([torch.relu(h[i:i + 1] @ v['dial/mfc_%d/w' % i] + v['dial/mfc_%d/b' % i])
+                               for i in range(self.N)], 0)
+            nc, nh = [], []
+            for i in range(self.N):
+                js = self.nbr[i]
+                s = 'dial/lstm_comm_%d' % i
+                mi = torch.cat([out_m[j] for j in js]).unsqueeze(0)
+                ai = torch.nn.functional.one_hot(torch.argmax(pp[i, t]), H).to(self.dtype).unsqueeze(0)
+                xi = torch.cat([xs[i, t]] + [xs[j, t] for j in js]).unsqueeze(0)
+                si = torch.relu(xi @ v[s + '/w_ob'] + v[s + '/b_ob']) + torch.relu(mi @ v[s + '/w_msg'] + v[s + '/b_msg']) + ai
+                ci, hi = lstm_cell(si, c[i:i + 1], h[i:i + 1], done, v[s + '/wx_hid'], v[s + '/wh_hid'], v[s + '/b_hid'])
+                nc.append(ci); nh.append(hi)
+            c, h = torch.cat(nc, 0), torch.cat(nh, 0)
+            hs.append(h)
+        return self._heads(torch.stack(hs, dim=1), acts, T, torch.cat([c, h], dim=1))
+
+    def _heads(self, hs, acts, T, st):
+        pis, vals = [], []
+        for i in range(self.N):
+            if acts is not None:
+                na = self._onehot(np.asarray(acts)[self.nb[i] == 1].T)
+            else:
+                na = torch.zeros(T, self.A * len(self.nbr[i]), dtype=self.dtype)
+            pi, val = self._head('%s/pi_%d' % (self.scope, i), '%s/v_%d%s' % (self.scope, i, self.v_suffix), hs[i], na)
+            pis.append(pi); vals.append(val)
+        return torch.stack(pis), torch.stack(vals), st
+
+    v_suffix = ''
+
+
+class MA2CCURef(MA2CDIALRef):
+    """IA2C_CU / ConseNet (models.py:261-275, policies.py:339-426)."""
+    scope, kind, v_suffix = 'cu', 'cu', 'a'
+
+    def __init__(self, *a, **k):
+        _ModelBase.__init__(self, *a, **k)
+        v, H, A = self.vars, self.H, self.A
+        F = self.n_s_ls[0]
+        for i in range(self.N):
+            m = len(self.nbr[i])
+            v.w('cu/fc_%da/w' % i, (F, H)); v.b('cu/fc_%da/b' % i, H)
+            v.w('cu/lstm_%da/wx' % i, (H, 4 * H)); v.w('cu/lstm_%da/wh' % i, (H, 4 * H)); v.b('cu/lstm_%da/b' % i, 4 * H)
+            v.w('cu/pi_%d/w' % i, (H, A)); v.b('cu/pi_%d/b' % i, A)
+            v.w('cu/v_%da/w' % i, (H + A * m, 1)); v.b('cu/v_%da/b' % i, 1)
+        self.opt = TFRMSProp(v.scope('cu'), *self.rms)
+        self.buf = OnPolicyBufferRef(self.gamma, self.coop_gamma, self.dist, multi=True)
+        self.reset()
+
+    def _net(self, obs, ps, acts, dones, states):
+        v, H = self.vars, self.H
+        xs = self.t(obs)
+        T = xs.shape[1]
+        hs, cs, hl = [], [], []
+        for i in range(self.N):
+            x = torch.relu(xs[i] @ v['cu/fc_%da/w' % i] + v['cu/fc_%da/b' % i])
+            c, h = states[i:i + 1, :H], states[i:i + 1, H:]
+            out = []
+            for t in range(T):
+                c, h = lstm_cell(x[t:t + 1], c, h, float(dones[t]), v['cu/lstm_%da/wx' % i], v['cu/lstm_%da/wh' % i],
+                                 v['cu/lstm_%da/b' % i])
+                out.append(h)
+            hs.append(torch.cat(out, 0)); cs.append(c); hl.append(h)
+        st = torch.cat([torch.cat(cs, 0), torch.cat(hl, 0)], dim=1)
+        return self._heads(torch.stack(hs, 0), acts, T, st)
+
+    def backward(self, Rends, dt=0):
+        super().backward(Rends, dt)
+        # _consensus_update (policies.py:357-364): simultaneous mean over {i} + neighbours of the lstm_%da variables
+        with torch.no_grad():
+            for key in ('wx', 'wh', 'b'):
+                old = [self.vars['cu/lstm_%da/%s' % (i, key)].detach().clone() for i in range(self.N)]
+                for i in range(self.N):
+                    grp = [old[i]] + [old[j] for j in self.nbr[i]]
+                    self.vars['cu/lstm_%da/%s' % (i, key)].copy_(torch.stack(grp, -1).mean(-1))
+
+
+REF_MODELS = {'ia2c': IA2CRef, 'ia2c_fp': IA2CFPRef, 'ma2c_nc': MA2CNCRef, 'ma2c_ic3': MA2CIC3Ref,
+              'ma2c_cu': MA2CCURef, 'ma2c_dial': MA2CDIALRef}

@@ -151,7 +151,9 @@ class Variable(Node):
             self.value.copy_(torch.as_tensor(np.asarray(arr), dtype=_FDT))
 
     def assign(self, other):
-        return _Op(lambda cache: self.set(_value_of(other, cache).detach().numpy()), [other])
+        op = _Op(lambda cache: self.set(_value_of(other, cache).detach().numpy()), [other])
+        op.assign_target, op.assign_source = self, other
+        return op
 
 
 class _ScopeCtx:
@@ -275,6 +277,10 @@ def clip_by_value(x, lo, hi):
     return Node(lambda t: torch.clamp(t, lo, hi), [x])
 
 
+def argmax(x, axis=None):
+    return Node(lambda t: torch.argmax(t) if axis is None else torch.argmax(t, dim=axis), [x])
+
+
 def one_hot(x, depth, axis=-1):
     return Node(lambda t: torch.nn.functional.one_hot(t.long(), int(depth)).to(_FDT), [x])
 
@@ -285,7 +291,18 @@ def slice(x, begin, size):  # noqa: A001
 
 
 def group(*ops):
-    return _Op(lambda cache: [o.run(cache) for o in ops], [])
+    """tf.group of assigns: TF gives no ordering between the grouped reads and writes; this shim defines the
+    update as SIMULTANEOUS -- every source is evaluated (and copied) before any target is written."""
+    def run(cache):
+        staged = []
+        for o in ops:
+            if hasattr(o, 'assign_target'):
+                staged.append((o.assign_target, _value_of(o.assign_source, cache).detach().clone().numpy()))
+            else:
+                o.run(cache)
+        for target, val in staged:
+            target.set(val)
+    return _Op(run, [])
 
 
 class _nn:

@@ -24,10 +24,11 @@ sys.path.insert(0, '/root/reference')
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import tensorflow as tf  # noqa: E402  (the shim)
-from agents.models import IA2C, IA2C_FP, MA2C_NC, MA2C_IC3  # noqa: E402  (the reference)
+from agents.models import IA2C, IA2C_FP, IA2C_CU, MA2C_NC, MA2C_IC3, MA2C_DIAL  # noqa: E402  (the reference)
 from helpers import cacc_config  # noqa: E402
 
-CLS = {'ia2c': IA2C, 'ia2c_fp': IA2C_FP, 'ma2c_nc': MA2C_NC, 'ma2c_ic3': MA2C_IC3}
+CLS = {'ia2c': IA2C, 'ia2c_fp': IA2C_FP, 'ma2c_nc': MA2C_NC, 'ma2c_ic3': MA2C_IC3, 'ma2c_cu': IA2C_CU,
+       'ma2c_dial': MA2C_DIAL}
 N_SAMPLE = 16
 
 
@@ -188,6 +189,12 @@ def run_ortho():
 
 
 if __name__ == '__main__':
+    if '--only-new' in sys.argv:
+        run_scripted('ma2c_cu_line', 'ma2c_cu', 'line', 20, 6)
+        run_scripted('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6)
+        run_scripted('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4)
+        run_scripted('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4)
+        sys.exit(0)
     run_ortho()
     run_scripted('ia2c_line', 'ia2c', 'line', 12, 6)
     run_scripted('ia2c_fp_line', 'ia2c_fp', 'line', 13, 6)
@@ -197,3 +204,7 @@ if __name__ == '__main__':
     run_scripted('ma2c_nc_grid', 'ma2c_nc', 'grid', 17, 4)
     run_scripted('ma2c_nc_line_spatial', 'ma2c_nc', 'line', 18, 6, coop_gamma=0.9)
     run_scripted('ia2c_line_spatial', 'ia2c', 'line', 19, 6, coop_gamma=0.8)
+    run_scripted('ma2c_cu_line', 'ma2c_cu', 'line', 20, 6)
+    run_scripted('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6)
+    run_scripted('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4)
+    run_scripted('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4)

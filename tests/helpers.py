@@ -85,7 +85,8 @@ def build_product_model(z, device):
     """Instantiate the product model exactly like tests/golden/make_golden_nn.py built the reference one."""
     from deeprl_network_amd.agents import models
     agent, topo = str(z['agent']), str(z['topo'])
-    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3}[agent]
+    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3,
+           'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[agent]
     n_step, coop_gamma, seed = int(z['n_step']), float(z['coop_gamma']), int(z['seed'])
     cp = cacc_config(agent=agent, n_step=n_step, reward_norm=float(z['reward_norm']), coop_gamma=coop_gamma)
     nb, dist = z['nb'], z['dist']

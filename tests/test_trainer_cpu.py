@@ -17,7 +17,8 @@ def build(agent, E, n_step=10, seed=12, scenario='catchup', env_id_base=0):
     cp['ENV_CONFIG']['episode_length_sec'] = '3'
     env = CpuCaccBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
     assert env.T == 3 * n_step
-    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3}[agent]
+    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3,
+           'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[agent]
     np.random.seed(seed)
     model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 6,
                 cp['MODEL_CONFIG'], seed=seed, num_envs=E, device='cpu')
@@ -25,7 +26,7 @@ def build(agent, E, n_step=10, seed=12, scenario='catchup', env_id_base=0):
     return env, model, tr
 
 
-@pytest.mark.parametrize('agent', ['ia2c', 'ia2c_fp', 'ma2c_nc', 'ma2c_ic3'])
+@pytest.mark.parametrize('agent', ['ia2c', 'ia2c_fp', 'ma2c_nc', 'ma2c_ic3', 'ma2c_cu', 'ma2c_dial'])
 def test_batched_trainer_runs_and_learns_something(agent):
     with cpu_ops():
         env, model, tr = build(agent, E=5)

@@ -20,10 +20,15 @@ row i holds agent i's parameters, every tensor is a strided view.  The gradient
 and the RMSProp slot use the same layout, so clip + RMSProp is one fused kernel
 and the data-parallel exchange is one RCCL all-reduce of the gradient buffer.
 """
+import warnings
+
 import numpy as np
 import torch
 
 from .. import ops
+
+# parameters and their gradients are deliberate strided views of the flat [N,P] buffers (see ParamStore)
+warnings.filterwarnings('ignore', message='grad and param do not obey the gradient layout contract')
 
 F32 = torch.float32
 

@@ -133,11 +133,18 @@ def main():
             raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
                              % (args.gpus, args.gpus))
     import torch.distributed as dist
+    # test hooks (1-GPU boxes): NMARL_BENCH_ONE_DEVICE=1 maps every rank to cuda:0, NMARL_DIST_BACKEND=gloo swaps RCCL
+    if os.environ.get('NMARL_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)      # RCCL over xGMI
+        backend = os.environ.get('NMARL_DIST_BACKEND', 'nccl')   # 'nccl' IS RCCL on ROCm (xGMI)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     from deeprl_network_amd.agents import models

@@ -25,6 +25,22 @@ def grid_masks():
     return (dist == 1).astype(int), dist
 
 
+def grid_params_from_config(config):
+    """ENV_CONFIG section -> nmarl_grid_params_t; keys of atsc_env.py:79-99 + large_grid_env.py:50-52."""
+    if config.getint('control_interval_sec') != 5 or config.getint('yellow_interval_sec') != 2:
+        raise _lib.NmarlError('the synthetic grid is specified for control 5 s / yellow 2 s')
+    if config.get('objective') != 'queue':
+        raise NotImplementedError('only the `queue` objective of the shipped grid configs is modelled')
+    p = _lib.GridParams()
+    p.norm_wave = config.getfloat('norm_wave')
+    p.clip_wave = config.getfloat('clip_wave')
+    p.peak1 = config.getfloat('peak_flow1')
+    p.peak2 = config.getfloat('peak_flow2')
+    p.T = int(np.ceil(config.getint('episode_length_sec') / config.getint('control_interval_sec')))
+    p.per_agent_reward = 0 if config.getfloat('coop_gamma') < 0 else 1
+    return p
+
+
 class LargeGridBatchEnv:
     def __init__(self, config, num_envs=1, device='cuda', env_id_base=0, seed=None):
         self.config = config
@@ -32,22 +48,12 @@ class LargeGridBatchEnv:
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise _lib.NmarlError('LargeGridBatchEnv needs a HIP device; there is no CPU path')
-        if config.getint('control_interval_sec') != 5 or config.getint('yellow_interval_sec') != 2:
-            raise _lib.NmarlError('the synthetic grid is specified for control 5 s / yellow 2 s')
-        if config.get('objective') != 'queue':
-            raise NotImplementedError('only the `queue` objective of the shipped grid configs is modelled')
         self.name = config.get('scenario')
         self.agent = config.get('agent')
         self.coop_gamma = config.getfloat('coop_gamma')
         self.seed = config.getint('seed') if seed is None else int(seed)
         self.env_id_base = int(env_id_base)
-        p = _lib.GridParams()
-        p.norm_wave = config.getfloat('norm_wave')
-        p.clip_wave = config.getfloat('clip_wave')
-        p.peak1 = config.getfloat('peak_flow1')
-        p.peak2 = config.getfloat('peak_flow2')
-        p.T = int(np.ceil(config.getint('episode_length_sec') / config.getint('control_interval_sec')))
-        p.per_agent_reward = 0 if self.coop_gamma < 0 else 1
+        p = grid_params_from_config(config)
         self.params = p
         self.T = p.T
         self.n_agent = N_NODE

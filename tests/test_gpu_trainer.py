@@ -1,0 +1,77 @@
+"""Batched trainer on the GPU at the BASELINE size (8 agents x 4096 replicas): size-independent properties of the
+whole rollout + update path -- hipGraph replay == eager launch, run-to-run determinism (no atomics anywhere),
+batch invariance of the rollout (replica e of 4096 == the same replica in a batch of 16), finite updates."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import cacc_config
+
+pytestmark = pytest.mark.gpu
+
+
+def build(agent, E, use_graph, env_id_base=0, scenario='catchup', n_step=60):
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    cp = cacc_config(agent=agent, scenario=scenario, n_step=n_step, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
+    env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
+    cls = {'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3, 'ia2c': models.IA2C,
+           'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[agent]
+    np.random.seed(12)
+    model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                cp['MODEL_CONFIG'], seed=12, num_envs=E)
+    return env, model, BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=use_graph)
+
+
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+def test_graph_equals_eager_and_is_deterministic(agent):
+    E = 4096
+    runs = []
+    for use_graph in (True, False, True):
+        env, model, tr = build(agent, E, use_graph)
+        for _ in range(3):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        runs.append((model.policy.params.flat.clone(), env.h.clone(), model.buf_act.clone(), tr.R_end.clone()))
+        del env, model, tr
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b), 'hipGraph replay differs from eager launches'
+    for a, b in zip(runs[0], runs[2]):
+        assert torch.equal(a, b), 'two identical runs differ (non-deterministic kernel?)'
+    assert torch.isfinite(runs[0][0]).all()
+
+
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_ic3'])
+def test_rollout_batch_invariance_at_full_size(agent):
+    env, model, tr = build(agent, 4096, False)
+    tr._rollout()
+    senv, smodel, str_ = build(agent, 16, False, env_id_base=2000)
+    str_._rollout()
+    sl = slice(2000, 2016)
+    assert torch.equal(model.buf_act[:, sl], smodel.buf_act), 'sampled actions depend on the batch size'
+    torch.testing.assert_close(model.buf_v[:, :, sl], smodel.buf_v, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(tr.R_end[:, sl], str_.R_end, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(tr.buf_rraw[:, sl], str_.buf_rraw, rtol=1e-5, atol=1e-3)
+    assert torch.equal(model.buf_done_post[:, sl], smodel.buf_done_post)
+
+
+def test_episode_bookkeeping_on_gpu():
+    """T = 3 batches: after 3 batches every replica finished one episode and restarted clean."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    cp = cacc_config(agent='ma2c_cu', n_step=10, reward_norm=5000.0)
+    cp['ENV_CONFIG']['episode_length_sec'] = '3'
+    env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=512)
+    np.random.seed(3)
+    model = models.IA2C_CU(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                           cp['MODEL_CONFIG'], seed=3, num_envs=512)
+    tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
+    for _ in range(3):
+        tr.run_batch()
+    st = tr.stats()
+    assert st['episodes'] == 512 and torch.all(env.episode == 2) and torch.all(tr.done_pre == 1)
+    assert torch.all(model.h_fw == 0) and torch.allclose(model.fp, torch.full_like(model.fp, 0.25))
+    m, s, c = tr.evaluate(n_envs=32)
+    assert np.isfinite(m) and 0 <= c <= 32

@@ -138,6 +138,9 @@ class IA2C:
         self.t = 0
         self.grad_norm = torch.zeros(N, dtype=F32, device=d)
         self.last_loss = None
+        # steps whose pre-step done flag may be non-zero (None = any, the reference API); the batched trainer
+        # sets (0,) because episodes start only at batch boundaries (quirk Q4)
+        self.masked_steps = None
 
     # ------------------------------------------------------------------ batched engine
     def reset_states(self, mask=None):
@@ -248,7 +251,8 @@ class IA2C:
         ps.grad.zero_()
         T = self.n_step
         FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
-        Hs = self.policy.unroll(self.buf_x[:T], FP, self.buf_done_pre, self.h_bw, self.c_bw)
+        Hs = self.policy.unroll(self.buf_x[:T], FP, self.buf_done_pre, self.h_bw, self.c_bw,
+                                masked_steps=self.masked_steps)
         loss = self._loss(Hs)
         loss.backward()
         scale = 1.0

@@ -192,7 +192,7 @@ class BatchedPolicy:
         return torch.bmm(hk, self.params[self.k_wh]), enc
 
     # -- n_step unroll for the update (autograd)
-    def unroll(self, X, FP, done, h0, c0):
+    def unroll(self, X, FP, done, h0, c0, masked_steps=None):
         """X [T,E,N,n_obs] env-major, FP [N,T*E,A] previous-step policies, done [T,E] f32
         (pre-step), (h0, c0) [N,E,H] -> Hs [N,T*E,H]."""
         T, E = done.shape
@@ -202,7 +202,7 @@ class BatchedPolicy:
             # no cross-agent term inside the recurrence: fused sequence op (one wgrad GEMM, one bias
             # reduction, no per-step autograd nodes)
             Hs = ops.lstm_sequence(enc.view(self.N, T, E, enc.shape[-1]), self.params[self.k_wh],
-                                   self.params[self.k_b], h0, c0, done)
+                                   self.params[self.k_b], h0, c0, done, masked_steps)
             return Hs.reshape(self.N, T * E, self.n_h)
         # per-step views via ONE unbind: its backward is a single stack, whereas slicing `enc` inside
         # the loop would make autograd materialise and add T full-size zero tensors (O(T^2) traffic)

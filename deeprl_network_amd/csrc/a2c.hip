@@ -20,7 +20,7 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // Every tensor is [N, E, W] with contiguous [E, W] panels and its own agent stride (floats), so that
 // slot t of an [N, T, E, W] sequence buffer can be passed without a copy.
-struct CellStrides { int64_t z, z2, bias, c_prev, gates, c_new, h_new, dh, dc, dz, dc_prev; };
+struct CellStrides { int64_t z, z2, bias, c_prev, gates, c_new, h_new, dh, dh2, dc, dz, dc_prev; };
 
 // z: pre-activations WITHOUT bias; gates (out, optional): post-activation i,f,o,u;
 // c_prev is masked by (1-done[e]) here.  4 hidden units per thread, 16-byte accesses.
@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
     const int64_t E, const int N, const int H, const CellStrides st, const float* __restrict__ gates,
     const float* __restrict__ c_prev, const float* __restrict__ c_new, const float* __restrict__ done,
-    const float* __restrict__ dh, const float* __restrict__ dc_in, float* __restrict__ dz,
-    float* __restrict__ dc_prev) {
+    const float* __restrict__ dh, const float* __restrict__ dh2, const float* __restrict__ dc_in,
+    float* __restrict__ dz, float* __restrict__ dc_prev) {
     const int H4 = H >> 2;
     const int64_t total = (int64_t)N * E * H4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -86,7 +86,11 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
         const float4 cp = *reinterpret_cast<const float4*>(c_prev + n * st.c_prev + e * H + j);
         const float4 cn = *reinterpret_cast<const float4*>(c_new + n * st.c_new + e * H + j);
         const float4 zero = float4{0.f, 0.f, 0.f, 0.f};
-        const float4 gh = dh ? *reinterpret_cast<const float4*>(dh + n * st.dh + e * H + j) : zero;
+        float4 gh = dh ? *reinterpret_cast<const float4*>(dh + n * st.dh + e * H + j) : zero;
+        if (dh2 != nullptr) {     // recurrent part of dL/dh_t, kept apart from the head's part: no add pass
+            const float4 g2 = *reinterpret_cast<const float4*>(dh2 + n * st.dh2 + e * H + j);
+            gh.x += g2.x; gh.y += g2.y; gh.z += g2.z; gh.w += g2.w;
+        }
         const float4 gcin = dc_in ? *reinterpret_cast<const float4*>(dc_in + n * st.dc + e * H + j) : zero;
         const float keep = 1.0f - done[e];
         float4 di, df, dO, du, dcp;
@@ -281,20 +285,21 @@ extern "C" int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float*
 
 extern "C" int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int64_t gates_sn,
                                    const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
-                                   const float* done, const float* dh, int64_t dh_sn, const float* dc_new,
-                                   int64_t dc_sn, float* dz, int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn,
-                                   void* stream) {
+                                   const float* done, const float* dh, int64_t dh_sn, const float* dh2,
+                                   int64_t dh2_sn, const float* dc_new, int64_t dc_sn, float* dz, int64_t dz_sn,
+                                   float* dc_prev, int64_t dc_prev_sn, void* stream) {
     if (E < 0 || N <= 0 || H <= 0 || H % 4 || (E > 0 && (!gates || !c_prev || !c_new || !done || !dz || !dc_prev)))
         return NMARL_EINVAL;
     const int64_t s4[2] = {gates_sn, dz_sn};
-    const int64_t s1[5] = {c_prev_sn, c_new_sn, dc_prev_sn, dh ? dh_sn : c_new_sn, dc_new ? dc_sn : c_new_sn};
-    if (!strides_ok(E, H, s4, 2, s1, 5)) return NMARL_EINVAL;
+    const int64_t s1[6] = {c_prev_sn, c_new_sn, dc_prev_sn, dh ? dh_sn : c_new_sn, dc_new ? dc_sn : c_new_sn,
+                           dh2 ? dh2_sn : c_new_sn};
+    if (!strides_ok(E, H, s4, 2, s1, 6)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     CellStrides st{};
-    st.gates = gates_sn; st.c_prev = c_prev_sn; st.c_new = c_new_sn; st.dh = dh_sn; st.dc = dc_sn; st.dz = dz_sn;
+    st.gates = gates_sn; st.c_prev = c_prev_sn; st.c_new = c_new_sn; st.dh = dh_sn; st.dh2 = dh2_sn; st.dc = dc_sn; st.dz = dz_sn;
     st.dc_prev = dc_prev_sn;
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_x((int64_t)N * E * H / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), E, N, H, st, gates, c_prev, c_new, done, dh, dc_new, dz, dc_prev);
+                       static_cast<hipStream_t>(stream), E, N, H, st, gates, c_prev, c_new, done, dh, dh2, dc_new, dz, dc_prev);
     return nmarl_check_launch();
 }
 

@@ -129,10 +129,10 @@ def bias_act_(x, bias, act):
     return x
 
 
-def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev):
+def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
     N, E, H4 = gates.shape
     check(lib.nmarl_lstm_cell_bwd(E, N, H4 // 4, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh),
-                                  *_pn(dc), *_pn(dz), *_pn(dc_prev), stream()), 'nmarl_lstm_cell_bwd')
+                                  *_pn(dh2), *_pn(dc), *_pn(dz), *_pn(dc_prev), stream()), 'nmarl_lstm_cell_bwd')
 
 
 class _LstmCell(torch.autograd.Function):
@@ -183,7 +183,7 @@ class _LstmSequence(torch.autograd.Function):
     wgrad GEMM over all T*E rows and a single bias reduction -- instead of T small ones."""
 
     @staticmethod
-    def forward(ctx, pre, wh, b, h0, c0, done):
+    def forward(ctx, pre, wh, b, h0, c0, done, masked_steps):
         N, T, E, H4 = pre.shape
         H = H4 // 4
         G = torch.empty(N, T, E, H4, dtype=F32, device=pre.device)
@@ -192,11 +192,13 @@ class _LstmSequence(torch.autograd.Function):
         Hall[:, 0].copy_(h0)
         Call[:, 0].copy_(c0)
         keep = (1.0 - done)                                                   # [T,E]
+        masked = set(range(T)) if masked_steps is None else set(masked_steps)
         for t in range(T):
-            hk = Hall[:, t] * keep[t].view(1, E, 1)
-            z = torch.baddbmm(pre[:, t], hk, wh)
-            cell_fwd(z, b, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1])
+            hk = Hall[:, t] * keep[t].view(1, E, 1) if t in masked else Hall[:, t]
+            # recurrent product as a plain GEMM; the x-side pre-activation enters the cell kernel as 2nd addend
+            cell_fwd(torch.bmm(hk, wh), b, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1], z2=pre[:, t])
         ctx.save_for_backward(G, Hall, Call, wh, done)
+        ctx.masked = masked
         return Hall[:, 1:]
 
     @staticmethod
@@ -212,20 +214,30 @@ class _LstmSequence(torch.autograd.Function):
         dc_next = torch.empty_like(dc)
         wh_t = wh.transpose(1, 2)
         for t in range(T - 1, -1, -1):
-            dh = dHs[:, t] if dh_rec is None else dHs[:, t] + dh_rec      # strided slot is fine for the kernel
-            cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dh, dc, dZ[:, t], dc_next)
+            # dL/dh_t = head part dHs[:, t] (strided slot) + recurrent part dh_rec, summed inside the kernel
+            cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
             dc, dc_next = dc_next, dc
-            dh_rec = torch.bmm(dZ[:, t], wh_t) * keep[t].view(1, E, 1)
+            dh_rec = torch.bmm(dZ[:, t], wh_t)
+            if t in ctx.masked:
+                dh_rec = dh_rec * keep[t].view(1, E, 1)
         dZf = dZ.view(N, T * E, H4)
         # h_{t-1} * keep_t for all t: Hall[:, :T] is a strided view (agent stride (T+1)*E*H)
-        Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+        if len(ctx.masked) == T:
+            Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+        else:
+            Hprev = Hall[:, :T].clone()
+            for t in ctx.masked:
+                Hprev[:, t].mul_(keep[t].view(1, E, 1))
+            Hprev = Hprev.view(N, T * E, H)
         dwh = torch.bmm(Hprev.transpose(1, 2), dZf)
         db = dZf.sum(dim=1)
-        return dZ, dwh, db, dh_rec, dc, None
+        return dZ, dwh, db, dh_rec, dc, None, None
 
 
-def lstm_sequence(pre, wh, b, h0, c0, done):
-    return _LstmSequence.apply(pre, wh, b, h0, c0, done)
+def lstm_sequence(pre, wh, b, h0, c0, done, masked_steps=None):
+    """masked_steps: the steps t whose done[t] can be non-zero (None = any); the others skip the state-mask
+    multiplies (in the batched trainer only t = 0 can start an episode, quirk Q4)."""
+    return _LstmSequence.apply(pre, wh, b, h0, c0, done, masked_steps)
 
 
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2

@@ -312,6 +312,7 @@ class BatchedTrainer:
         self.n_batches = 0
         env.train_mode = True
         model.reset_states()
+        model.masked_steps = (0,)             # only the first lock-step of a batch can start an episode (Q4)
         model.t = 0
         model.buf_x[0].copy_(env.reset())
 

@@ -201,7 +201,7 @@ int nmarl_nbr_onehot(int64_t E, int32_t N, int32_t A, int32_t m_max, const int32
  * gates [N,E,4H] receives the post-activation i,f,o,u (saved for backward; may
  * alias z; NULL = inference, not written).  H % 4 == 0, 16-byte aligned panels.
  * bwd: dz [N,E,4H] (= d bias before the reduction over E), dc_prev [N,E,H];
- * dh / dc_new may be NULL (= 0).
+ * dh / dh2 / dc_new may be NULL (= 0); dL/dh' = dh + dh2 (head part + recurrent part).
  */
 int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, int64_t z_sn,
                         const float* z2, int64_t z2_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,
@@ -209,9 +209,9 @@ int nmarl_lstm_cell_fwd(int64_t E, int32_t N, int32_t H, const float* z, int64_t
                         int64_t c_new_sn, float* h_new, int64_t h_new_sn, void* stream);
 int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int64_t gates_sn,
                         const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
-                        const float* done, const float* dh, int64_t dh_sn, const float* dc_new,
-                        int64_t dc_sn, float* dz, int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn,
-                        void* stream);
+                        const float* done, const float* dh, int64_t dh_sn, const float* dh2,
+                        int64_t dh2_sn, const float* dc_new, int64_t dc_sn, float* dz, int64_t dz_sn,
+                        float* dc_prev, int64_t dc_prev_sn, void* stream);
 /*
  * In-place x[n,r,:] = act(x[n,r,:] + bias[n,:]) on [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the

@@ -75,7 +75,7 @@ def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out, z2=None):
     return h_out, c_out
 
 
-def lstm_sequence(pre, wh, b, h0, c0, done):
+def lstm_sequence(pre, wh, b, h0, c0, done, masked_steps=None):
     """agents/utils.py:102-113 over T steps for all agents: plain autograd loop."""
     N, T, E, H4 = pre.shape
     h, c = h0, c0

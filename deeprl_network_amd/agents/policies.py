@@ -184,9 +184,10 @@ class BatchedPolicy:
             ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_out, h_out, z2=z2)
         return h_out, c_out
 
-    def _fc_infer(self, x, w_key, b_key, act):
-        """act(x @ W + b) with the bias/activation fused in one in-place pass (no autograd)."""
-        return ops.bias_act_(torch.bmm(x, self.params[w_key]), self.params[b_key], act)
+    def _fc_infer(self, x, w_key, b_key, act, out=None):
+        """act(x @ W + b) with the bias/activation fused in one pass (no autograd); `out` may be a column
+        block of a wider buffer, which concatenates partial encodings without a copy."""
+        return ops.bias_act_(torch.bmm(x, self.params[w_key]), self.params[b_key], act, out=out)
 
     def _recur_infer(self, enc, h, hk):
         return torch.bmm(hk, self.params[self.k_wh]), enc
@@ -270,9 +271,10 @@ class FPPolicy(LstmPolicy):
     def _enc_infer(self, xv, fp):
         p = self.params
         nf = self.n_fc
-        hx = self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU)
-        hp = self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU)
-        return torch.bmm(hx, p['lstm_wx'][:, :nf]).baddbmm_(hp, p['lstm_wx'][:, nf:])
+        s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device)      # [hx | hp], policies.py:181
+        self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
+        self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
+        return torch.bmm(s, p['lstm_wx'])                                               # ONE K = 2 nf GEMM
 
 
 class NCMultiAgentPolicy(BatchedPolicy):
@@ -316,9 +318,10 @@ class NCMultiAgentPolicy(BatchedPolicy):
     def _enc_infer(self, xv, fp):
         p = self.params
         H = self.n_h
-        hx = self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU)
-        hp = self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU)
-        return torch.bmm(hx, p['wx_hid'][:, :H]).baddbmm_(hp, p['wx_hid'][:, H:2 * H])
+        s = torch.empty(self.N, xv.shape[1], 2 * H, dtype=F32, device=xv.device)       # [hx | hp] of agents/utils.py:199
+        self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
+        self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
+        return torch.bmm(s, p['wx_hid'][:, :2 * H])
 
     def _recur_infer(self, enc, h, hk):
         p = self.params

@@ -114,9 +114,10 @@ __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(
 // x [N, rows, W] (agent stride x_sn) += bias [N, W] (stride bias_sn), then act: 0 none, 1 relu, 2 tanh.
 // Replaces broadcast-copy + beta=1 GEMM + activation (3 passes) after a plain batched GEMM (fc of
 // agents/utils.py:65-73 and the encoders of lstm_comm / lstm_ic3) in the no-grad rollout.
-__global__ __launch_bounds__(256) void bias_act_kernel(const int64_t rows, const int N, const int W, float* __restrict__ x,
+__global__ __launch_bounds__(256) void bias_act_kernel(const int64_t rows, const int N, const int W, const float* __restrict__ x,
                                                        const int64_t x_sn, const float* __restrict__ bias,
-                                                       const int64_t bias_sn, const int act) {
+                                                       const int64_t bias_sn, const int act, float* __restrict__ y,
+                                                       const int64_t y_sn, const int64_t y_row) {
     const int W4 = W >> 2;
     const int64_t total = (int64_t)N * rows * W4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -124,13 +125,12 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const int64_t rows, const
         const int j = (int)(idx - row * W4) * 4;
         const int64_t n = row / rows;
         const int64_t r = row - n * rows;
-        float4* px = reinterpret_cast<float4*>(x + n * x_sn + r * W + j);
         const float4 b = *reinterpret_cast<const float4*>(bias + n * bias_sn + j);
-        float4 v = *px;
+        float4 v = *reinterpret_cast<const float4*>(x + n * x_sn + r * W + j);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         else if (act == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-        *px = v;
+        *reinterpret_cast<float4*>(y + n * y_sn + r * y_row + j) = v;
     }
 }
 
@@ -303,14 +303,14 @@ extern "C" int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float*
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, float* x, int64_t x_sn, const float* bias,
-                              int64_t bias_sn, int32_t act, void* stream) {
+extern "C" int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x_sn, const float* bias,
+                              int64_t bias_sn, int32_t act, float* y, int64_t y_sn, int64_t y_row, void* stream) {
     if (rows < 0 || N <= 0 || W <= 0 || W % 4 || act < 0 || act > 2 || x_sn < rows * W || x_sn % 4 || bias_sn < W ||
-        bias_sn % 4 || (rows > 0 && (!x || !bias)))
+        bias_sn % 4 || y_row < W || y_row % 4 || y_sn < rows * y_row || y_sn % 4 || (rows > 0 && (!x || !bias || !y)))
         return NMARL_EINVAL;
     if (rows == 0) return NMARL_OK;
     hipLaunchKernelGGL(bias_act_kernel, dim3(grid_x((int64_t)N * rows * W / 4)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), rows, N, W, x, x_sn, bias, bias_sn, act);
+                       static_cast<hipStream_t>(stream), rows, N, W, x, x_sn, bias, bias_sn, act, y, y_sn, y_row);
     return nmarl_check_launch();
 }
 

@@ -120,13 +120,20 @@ def cell_fwd(z, bias, c_prev, done, gates, c_new, h_new, z2=None):
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 
-def bias_act_(x, bias, act):
-    """In-place x = act(x + bias[:, None, :]) for x [N,rows,W] (no autograd: rollout only)."""
+def bias_act_(x, bias, act, out=None):
+    """x = act(x + bias[:, None, :]) for x [N,rows,W] (no autograd: rollout only).  In place by default;
+    `out` [N,rows,W] may be a column block of a wider [N,rows,Wtot] buffer (concat without a copy)."""
     N, rows, W = x.shape
     xp, xs = _pn(x)
     bp, bs = _bias(bias)
-    check(lib.nmarl_bias_act(rows, N, W, xp, xs, bp, bs, act, stream()), 'nmarl_bias_act')
-    return x
+    if out is None:
+        yp, ys, yrow = xp, xs, W
+    else:
+        if out.stride(2) != 1 or out.shape != x.shape:
+            raise _lib.NmarlError('bias_act_: out must be [N,rows,W] with unit column stride')
+        yp, ys, yrow = ptr(out, F32, strided=True), out.stride(0), out.stride(1)
+    check(lib.nmarl_bias_act(rows, N, W, xp, xs, bp, bs, act, yp, ys, yrow, stream()), 'nmarl_bias_act')
+    return x if out is None else out
 
 
 def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):

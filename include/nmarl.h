@@ -213,12 +213,15 @@ int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int
                         int64_t dh2_sn, const float* dc_new, int64_t dc_sn, float* dz, int64_t dz_sn,
                         float* dc_prev, int64_t dc_prev_sn, void* stream);
 /*
- * In-place x[n,r,:] = act(x[n,r,:] + bias[n,:]) on [N,rows,W] (agent strides in floats, W % 4 == 0);
+ * y[n,r,:W] = act(x[n,r,:] + bias[n,:]) for x [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the
  * lstm_comm / lstm_ic3 encoders (agents/utils.py:196-198, 400) after a plain batched GEMM.
+ * y may alias x (in place) or be a column block of a wider buffer (row pitch y_row >= W floats):
+ * FPPolicy / lstm_comm write their partial encodings side by side so that the LSTM input product is
+ * ONE GEMM over the concatenation (tf.concat of policies.py:181 / agents/utils.py:199) without a copy.
  */
-int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, float* x, int64_t x_sn, const float* bias,
-                   int64_t bias_sn, int32_t act, void* stream);
+int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x_sn, const float* bias,
+                   int64_t bias_sn, int32_t act, float* y, int64_t y_sn, int64_t y_row, void* stream);
 /*
  * Action draw of Trainer._get_policy (utils.py:135-141) for all (replica, agent):
  * pi [N,E,A] -> action [E,N] u8.

@@ -61,11 +61,12 @@ def lstm_cell(z, bias, c_prev, done):
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 
-def bias_act_(x, bias, act):
-    """fc's bias + activation (agents/utils.py:65-73), in place."""
+def bias_act_(x, bias, act, out=None):
+    """fc's bias + activation (agents/utils.py:65-73), in place or into `out`."""
     y = x + bias.unsqueeze(1)
-    x.copy_(torch.relu(y) if act == BIAS_RELU else torch.tanh(y) if act == BIAS_TANH else y)
-    return x
+    y = torch.relu(y) if act == BIAS_RELU else torch.tanh(y) if act == BIAS_TANH else y
+    (x if out is None else out).copy_(y)
+    return x if out is None else out
 
 
 def lstm_cell_infer(z, bias, c_prev, done, c_out, h_out, z2=None):

@@ -110,6 +110,13 @@ def test_bias_act_and_cell_second_addend():
         b = torch.randn(N, H, generator=g)
         y = ops.bias_act_(x.clone().cuda(), b.cuda(), act)
         torch.testing.assert_close(y.cpu(), ops_ref.bias_act_(x.clone(), b, act), rtol=1e-6, atol=1e-6)
+    # out = column block of a wider buffer (concat without copy)
+    x = torch.randn(N, E, H, generator=g)
+    b = torch.randn(N, H, generator=g)
+    wide = torch.zeros(N, E, 2 * H, device='cuda')
+    ops.bias_act_(x.cuda(), b.cuda(), ops.BIAS_RELU, out=wide[:, :, H:])
+    assert torch.all(wide[:, :, :H] == 0)
+    torch.testing.assert_close(wide[:, :, H:].cpu(), torch.relu(x + b[:, None]), rtol=1e-6, atol=1e-6)
     z, z2 = torch.randn(N, E, 4 * H, generator=g), torch.randn(N, E, 4 * H, generator=g)
     b = torch.randn(N, 4 * H, generator=g)
     c = torch.randn(N, E, H, generator=g)

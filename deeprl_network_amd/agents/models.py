@@ -224,8 +224,7 @@ class IA2C:
         """policies.py:20-30 / 232-255 with the batch mean taken over T*E."""
         N, T, E = self.n_agent, self.n_step, self.E
         p = self.policy
-        pi = p.pi(Hs)                                                        # [N, T*E, A]
-        v = p.value(Hs, self.buf_na.permute(1, 0, 2, 3).reshape(N, T * E, p.n_na))   # [N, T*E]
+        pi, v = p.heads(Hs, self.buf_na.permute(1, 0, 2, 3).reshape(N, T * E, p.n_na))   # [N,T*E,A], [N,T*E]
         acts = self.buf_act.view(T * E, N).t().long().unsqueeze(-1)          # [N, T*E, 1]
         log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
         entropy = -(pi * log_pi).sum(-1)

@@ -153,6 +153,18 @@ class BatchedPolicy:
         p = self.params
         return torch.softmax(torch.baddbmm(p['pi_b'].unsqueeze(1), h, p['pi_w']), dim=-1)
 
+    def heads(self, h, na_onehot):
+        """Actor and critic heads of the update in ONE skinny GEMM: [pi_w | v_w[:H]] is concatenated on the fly
+        (64 x (A+1) per agent), so Hs (the large operand) is read once forward and its gradient is produced by
+        one dgrad GEMM instead of two plus an add.  Returns (pi [N,rows,A], v [N,rows])."""
+        p = self.params
+        H, A = self.n_h, self.n_a
+        w = torch.cat([p['pi_w'], p['v_w'][:, :H]], dim=2)
+        b = torch.cat([p['pi_b'], p['v_b']], dim=1)
+        out = torch.baddbmm(b.unsqueeze(1), h, w)
+        v = out[..., A] + torch.bmm(na_onehot, p['v_w'][:, H:]).squeeze(-1)
+        return torch.softmax(out[..., :A], dim=-1), v
+
     def value(self, h, na_onehot, out=None):
         """v = [h, onehot(neighbour actions)] @ Wv + b (policies.py:59-77), without the concat;
         `out` [N,rows] (no-grad rollout) receives the result in place."""

@@ -58,6 +58,8 @@ SIGNATURES = {
     'nmarl_nbr_mean_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_onehot': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
     'nmarl_lstm_cell_fwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_lstm_step_fused': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p,
+                              _i64, _p, _i64, _p],
     'nmarl_bias_act': [_i64, _i32, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],

@@ -186,14 +186,18 @@ class BatchedPolicy:
 
     def step(self, enc, h, c, done, h_out, c_out, done_is_zero=False):
         """One LSTM step from (h, c) [N,E,H] with done [E] f32 -> writes (h', c') into (h_out, c_out),
-        which MAY alias (h, c): every read of h precedes the cell kernel on the stream and the cell
-        kernel is index-wise in place.  No GEMM here carries a copy: the recurrent product is a plain
-        (or in-place accumulating) batched GEMM and the x-side part enters the cell kernel as a second
-        addend."""
+        which MAY alias (h, c).  H = 64: ONE fused MFMA kernel computes (h*(1-done)) @ Wh on top of the
+        x-side addends and applies the cell in its epilogue (csrc/lstm_mfma.hip).  Other widths: a plain
+        batched GEMM + the cell kernel (which takes the x-side part as a second addend: no copy GEMM)."""
         with torch.no_grad():
-            hk = h if done_is_zero else h * (1.0 - done).view(1, -1, 1)
-            z, z2 = self._recur_infer(enc, h, hk)
-            ops.lstm_cell_infer(z, self.params[self.k_b], c, done, c_out, h_out, z2=z2)
+            z1, z2 = self._recur_addends(enc, h)
+            wh, b = self.params[self.k_wh], self.params[self.k_b]
+            if self.n_h == ops.FUSED_H:
+                ops.lstm_step_fused(h, wh, b, z1, z2, c, done, None, c_out, h_out)
+            else:
+                hk = h if done_is_zero else h * (1.0 - done).view(1, -1, 1)
+                z = torch.bmm(hk, wh) if z2 is None else torch.baddbmm(z2, hk, wh)
+                ops.lstm_cell_infer(z, b, c, done, c_out, h_out, z2=z1)
         return h_out, c_out
 
     def _fc_infer(self, x, w_key, b_key, act, out=None):
@@ -201,8 +205,9 @@ class BatchedPolicy:
         block of a wider buffer, which concatenates partial encodings without a copy."""
         return ops.bias_act_(torch.bmm(x, self.params[w_key]), self.params[b_key], act, out=out)
 
-    def _recur_infer(self, enc, h, hk):
-        return torch.bmm(hk, self.params[self.k_wh]), enc
+    def _recur_addends(self, enc, h):
+        """(zadd1, zadd2): everything of the LSTM pre-activation except (h*(1-done)) @ Wh and the bias."""
+        return enc, None
 
     # -- n_step unroll for the update (autograd)
     def unroll(self, X, FP, done, h0, c0, masked_steps=None):
@@ -336,11 +341,11 @@ class NCMultiAgentPolicy(BatchedPolicy):
         self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
         return torch.bmm(s, p['wx_hid'][:, :2 * H])
 
-    def _recur_infer(self, enc, h, hk):
+    def _recur_addends(self, enc, h):
         p = self.params
         H = self.n_h
         hm = self._fc_infer(ops.nbr_gather(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU)
-        return torch.bmm(hm, p['wx_hid'][:, 2 * H:]).baddbmm_(hk, p[self.k_wh]), enc
+        return torch.bmm(hm, p['wx_hid'][:, 2 * H:]), enc
 
 
 class IC3MultiAgentPolicy(BatchedPolicy):
@@ -376,10 +381,10 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     def _enc_infer(self, xv, fp):
         return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH)
 
-    def _recur_infer(self, enc, h, hk):
+    def _recur_addends(self, enc, h):
         p = self.params
         s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
-        return torch.bmm(s, p['wx_hid']).baddbmm_(hk, p[self.k_wh]), None
+        return torch.bmm(s, p['wx_hid']), None
 
 
 class ConsensusPolicy(LstmPolicy):
@@ -462,8 +467,8 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     def _enc_infer(self, xv, fp):
         return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU).add_(self._own_action_onehot(fp))
 
-    def _recur_infer(self, enc, h, hk):
+    def _recur_addends(self, enc, h):
         p = self.params
         msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU)
         hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU).add_(enc)
-        return torch.bmm(hm, p['wx_hid']).baddbmm_(hk, p[self.k_wh]), None
+        return torch.bmm(hm, p['wx_hid']), None

@@ -1,0 +1,201 @@
+// Fused LSTM step for agent-batched 64-unit cells on gfx950 matrix cores:
+//
+//     z = zadd1 (+ zadd2) + (h * (1 - done)) @ Wh      [rows x 256], fp32 MFMA
+//     i,f,o = sigmoid(z + b), u = tanh(z + b);  c' = f * (c * (1 - done)) + i * u;  h' = o * tanh(c')
+//
+// i.e. the recurrent half of agents/utils.py:102-113 (lstm), 199-208 (lstm_comm), 401-408 (lstm_ic3)
+// with the cell fused into the GEMM epilogue: the [rows x 256] pre-activation never goes to HBM
+// (the separate GEMM + cell pair writes and re-reads it: 2 x 33.5 MB per step at E = 4096).
+//
+// Mapping (H = 64 -> 256 gate columns).  One 256-thread block = 4 waves = 128 rows of ONE agent and ALL
+// 256 columns, because unit j needs columns j, 64+j, 128+j, 192+j together.  Wh (64 x 256 fp32 = 64 KB) is
+// staged once per block in LDS, each wave's 32 x 64 tile of h in a padded LDS tile (row pitch 65: the 32
+// rows a wave reads per MFMA operand fall in 32 different banks).  A wave owns a 32 x 256 strip =
+// 8 accumulator tiles of v_mfma_f32_32x32x2_f32 (128 accumulator registers), K = 64 -> 32 MFMAs per tile.
+// The accumulators are INITIALISED with zadd1 (+ zadd2) + bias (C operand), so the epilogue needs no
+// further loads except c; in the C/D layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+// a lane holds all four gates of its (row, unit) pairs in registers: the cell is lane-local.
+// fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md): 256 MFMAs x 64 cycles
+// per 32 rows and wave -> 6.8 us of matrix time for 32768 rows on 256 CUs.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int H = 64;
+constexpr int G4 = 4 * H;          // 256 gate columns
+constexpr int ROWS_W = 32;         // rows per wave
+constexpr int WAVES = 4;
+constexpr int ROWS_B = ROWS_W * WAVES;
+constexpr int APITCH = H + 1;      // 65
+
+struct FusedArgs {
+    const float *h_in, *wh, *bias, *zadd1, *zadd2, *c_prev, *done;
+    float *gates, *c_new, *h_new;
+    int64_t h_sn, wh_sn, bias_sn, zadd1_sn, zadd2_sn, c_prev_sn, gates_sn, c_new_sn, h_new_sn;
+    int64_t E;
+    int blocks_per_agent;
+};
+
+// Epilogue transcendentals: 160 per lane with ONE wave per SIMD, so their latency is fully exposed.
+// sigmoid(x) = rcp(1 + 2^(-x log2 e)) on the hardware exp2 / rcp units (about 1 ulp each, relative error of the
+// result <= ~1e-6 for |x| < 20; both saturate correctly), tanh(x) = 2 sigmoid(2x) - 1 (absolute error <= 2.4e-7).
+// The separate cell kernel (other H, backward checks) keeps libm's expf / tanhf; both agree within 1e-6.
+__device__ __forceinline__ float sigm(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigm(2.0f * x) - 1.0f; }
+
+template <bool HAS_Z2>
+__global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w_lds = lds;                                   // [64][256]
+    float* a_lds = lds + H * G4;                          // [WAVES][32][65]
+    const int n = blockIdx.x / a.blocks_per_agent;
+    const int64_t row_blk = (int64_t)(blockIdx.x - n * a.blocks_per_agent) * ROWS_B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = row_blk + wave * ROWS_W;         // first row of this wave's strip
+    const int col = lane & 31, half = lane >> 5;
+    float* a_tile = a_lds + wave * ROWS_W * APITCH;
+
+    // ---- accumulators <- zadd1: 128 independent loads per lane, nothing consumes them before the K loop, so
+    // they all stay in flight behind the LDS staging (an add right after each load serialised them: 29 us)
+    f32x16 acc[8];
+    const float* z1 = a.zadd1 + (int64_t)n * a.zadd1_sn;
+    int64_t rofs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        rofs[r] = (row < a.E ? row : a.E - 1);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = z1[rofs[r] * G4 + t * 32 + col];
+    // ---- c_prev of this lane's (row, unit) pairs
+    float cp[2][16];
+    const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            cp[jj][r] = cpn[rofs[r] * H + jj * 32 + col];
+        }
+
+    // ---- stage Wh (64 KB, whole block) and this wave's h tile (masked by 1 - done) in LDS
+    {
+        const float4* wg = reinterpret_cast<const float4*>(a.wh + (int64_t)n * a.wh_sn);
+        float4* wl = reinterpret_cast<float4*>(w_lds);
+#pragma unroll
+        for (int i = 0; i < (H * G4 / 4) / 256; ++i) wl[i * 256 + threadIdx.x] = wg[i * 256 + threadIdx.x];
+        const float* hn = a.h_in + (int64_t)n * a.h_sn;
+#pragma unroll
+        for (int i = 0; i < (ROWS_W * H / 4) / 64; ++i) {       // 8 float4 per lane, coalesced
+            const int v = i * 64 + lane;
+            const int r = v >> 4, k4 = (v & 15) * 4;
+            int64_t row = row0 + r;
+            row = row < a.E ? row : a.E - 1;
+            const float keep = 1.0f - a.done[row];
+            const float4 x = *reinterpret_cast<const float4*>(hn + row * H + k4);
+            float* d = a_tile + r * APITCH + k4;
+            d[0] = x.x * keep; d[1] = x.y * keep; d[2] = x.z * keep; d[3] = x.w * keep;
+        }
+    }
+    __syncthreads();
+
+    // ---- + bias (+ zadd2): C operand of the first MFMA of every tile
+    {
+        const float* bn = a.bias + (int64_t)n * a.bias_sn;
+        const float* z2 = HAS_Z2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float b = bn[t * 32 + col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r] + b;
+                if (HAS_Z2) v += z2[rofs[r] * G4 + t * 32 + col];
+                acc[t][r] = v;
+            }
+        }
+    }
+
+    // ---- K loop: 32 steps of K = 2, 8 column tiles each
+#pragma unroll 4
+    for (int kk = 0; kk < H / 2; ++kk) {
+        const float av = a_tile[col * APITCH + 2 * kk + half];          // A[i = lane & 31][k = lane >> 5]
+        const float* wrow = w_lds + (2 * kk + half) * G4 + col;          // B[k = lane >> 5][j = lane & 31]
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wrow[t * 32], acc[t], 0, 0, 0);
+    }
+
+    // ---- lane-local cell epilogue
+    float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
+    float* cn = a.c_new + (int64_t)n * a.c_new_sn;
+    float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool ok = row < a.E;
+            const float keep = 1.0f - a.done[rofs[r]];
+            const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[2 + jj][r]);
+            const float go = sigm(acc[4 + jj][r]), gu = tanh_fast(acc[6 + jj][r]);
+            const float c = gf * (cp[jj][r] * keep) + gi * gu;
+            const float hv = go * tanh_fast(c);
+            if (ok) {
+                const int j = jj * 32 + col;
+                cn[row * H + j] = c;
+                hn_out[row * H + j] = hv;
+                if (gn) {
+                    float* g = gn + row * G4 + j;
+                    g[0] = gi; g[H] = gf; g[2 * H] = go; g[3 * H] = gu;
+                }
+            }
+        }
+    }
+}
+
+inline bool stride_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
+
+}  // namespace
+
+extern "C" int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int64_t h_sn,
+                                     const float* wh, int64_t wh_sn, const float* bias, int64_t bias_sn,
+                                     const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                                     const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                                     int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
+                                     int64_t h_new_sn, void* stream) {
+    if (Hh != H || E < 0 || N <= 0 || (E > 0 && (!h_in || !wh || !bias || !zadd1 || !c_prev || !done || !c_new || !h_new)))
+        return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    if (!stride_ok(h_sn, E * H) || !stride_ok(wh_sn, H * G4) || !stride_ok(bias_sn, G4) || !stride_ok(zadd1_sn, E * G4) ||
+        (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
+        !stride_ok(h_new_sn, E * H) || (gates && !stride_ok(gates_sn, E * G4)) || ((uintptr_t)wh % 16) || ((uintptr_t)h_in % 16))
+        return NMARL_EINVAL;
+    FusedArgs a{};
+    a.h_in = h_in; a.wh = wh; a.bias = bias; a.zadd1 = zadd1; a.zadd2 = zadd2; a.c_prev = c_prev; a.done = done;
+    a.gates = gates; a.c_new = c_new; a.h_new = h_new;
+    a.h_sn = h_sn; a.wh_sn = wh_sn; a.bias_sn = bias_sn; a.zadd1_sn = zadd1_sn; a.zadd2_sn = zadd2_sn;
+    a.c_prev_sn = c_prev_sn; a.gates_sn = gates_sn; a.c_new_sn = c_new_sn; a.h_new_sn = h_new_sn;
+    a.E = E;
+    a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
+    const size_t lds_bytes = (size_t)(H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return NMARL_EHIP;
+        attr_set = true;
+    }
+    if (zadd2)
+        hipLaunchKernelGGL(lstm_step_mfma_kernel<true>, dim3(a.blocks_per_agent * N), dim3(256), lds_bytes,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(lstm_step_mfma_kernel<false>, dim3(a.blocks_per_agent * N), dim3(256), lds_bytes,
+                           static_cast<hipStream_t>(stream), a);
+    return nmarl_check_launch();
+}

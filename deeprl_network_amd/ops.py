@@ -117,6 +117,21 @@ def cell_fwd(z, bias, c_prev, done, gates, c_new, h_new, z2=None):
                                   *_pn(gates), *_pn(c_new), *_pn(h_new), stream()), 'nmarl_lstm_cell_fwd')
 
 
+FUSED_H = 64      # nmarl_lstm_step_fused is specialised for 64-unit cells (256 gate columns per MFMA strip)
+
+
+def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out):
+    """(gates, c', h') = cell(zadd1 (+ zadd2) + (h*(1-done)) @ wh + bias, c_prev, done) in ONE MFMA kernel
+    (H = 64).  All operands [N,E,*] panels (strided slots allowed); h_out / c_out may alias h / c_prev."""
+    N, E, H = h.shape
+    if wh.stride(2) != 1 or wh.stride(1) != 4 * H:
+        raise _lib.NmarlError('lstm_step_fused: wh must be [N,H,4H] with contiguous [H,4H] panels')
+    check(lib.nmarl_lstm_step_fused(E, N, H, *_pn(h), ptr(wh, F32, strided=True), wh.stride(0), *_bias(bias),
+                                    *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
+                                    *_pn(c_out), *_pn(h_out), stream()), 'nmarl_lstm_step_fused')
+    return h_out, c_out
+
+
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 
@@ -200,7 +215,12 @@ class _LstmSequence(torch.autograd.Function):
         Call[:, 0].copy_(c0)
         keep = (1.0 - done)                                                   # [T,E]
         masked = set(range(T)) if masked_steps is None else set(masked_steps)
+        fused = H == FUSED_H and wh.stride(2) == 1 and wh.stride(1) == H4
         for t in range(T):
+            if fused:     # recurrent GEMM + cell in one MFMA kernel, pre-activation never leaves the CU
+                lstm_step_fused(Hall[:, t], wh, b, pre[:, t], None, Call[:, t], done[t], G[:, t], Call[:, t + 1],
+                                Hall[:, t + 1])
+                continue
             hk = Hall[:, t] * keep[t].view(1, E, 1) if t in masked else Hall[:, t]
             # recurrent product as a plain GEMM; the x-side pre-activation enters the cell kernel as 2nd addend
             cell_fwd(torch.bmm(hk, wh), b, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1], z2=pre[:, t])

@@ -213,6 +213,21 @@ int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int
                         int64_t dh2_sn, const float* dc_new, int64_t dc_sn, float* dz, int64_t dz_sn,
                         float* dc_prev, int64_t dc_prev_sn, void* stream);
 /*
+ * Fused recurrent GEMM + cell on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32), H = 64 only:
+ *   z = zadd1 (+ zadd2) + (h_in * (1-done)) @ wh ;  (gates, c_new, h_new) = cell(z + bias, c_prev, done)
+ * Same maths as a batched GEMM followed by nmarl_lstm_cell_fwd, but the [rows,4H] pre-activation never
+ * reaches HBM.  h_in [N,E,H], wh [N,H,4H], bias [N,4H], zadd1/zadd2 [N,E,4H] (zadd2 may be NULL: the
+ * x-side product s*Wx, and for NeurComm additionally the message term), c_prev/c_new/h_new [N,E,H],
+ * gates [N,E,4H] or NULL; agent strides `*_sn` in floats (multiples of 4); h_new may alias h_in and c_new
+ * may alias c_prev.  Returns NMARL_EINVAL for H != 64 (callers then use GEMM + nmarl_lstm_cell_fwd).
+ */
+int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t H, const float* h_in, int64_t h_sn,
+                          const float* wh, int64_t wh_sn, const float* bias, int64_t bias_sn,
+                          const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                          const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                          int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
+                          int64_t h_new_sn, void* stream);
+/*
  * y[n,r,:W] = act(x[n,r,:] + bias[n,:]) for x [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the
  * lstm_comm / lstm_ic3 encoders (agents/utils.py:196-198, 400) after a plain batched GEMM.

@@ -58,6 +58,21 @@ def lstm_cell(z, bias, c_prev, done):
     return h, c
 
 
+FUSED_H = 64
+
+
+def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out):
+    """agents/utils.py:102-113 with z = zadd1 (+ zadd2) + (h*(1-done)) @ wh."""
+    keep = (1.0 - done).view(1, -1, 1)
+    z = zadd1 + torch.bmm(h * keep, wh)
+    if zadd2 is not None:
+        z = z + zadd2
+    hn, cn = lstm_cell(z, bias, c_prev, done)
+    c_out.copy_(cn)
+    h_out.copy_(hn)
+    return h_out, c_out
+
+
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 

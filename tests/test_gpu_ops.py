@@ -128,6 +128,50 @@ def test_bias_act_and_cell_second_addend():
     torch.testing.assert_close(co.cpu(), cr, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize('N,E', [(8, 4096), (8, 1), (25, 130), (3, 127), (8, 257)])
+@pytest.mark.parametrize('two_addends', [False, True])
+def test_lstm_step_fused_mfma(N, E, two_addends):
+    """MFMA GEMM + cell in one kernel == (h*(1-done)) @ Wh + addends -> cell, incl. ragged row counts, strided
+    sequence slots, gates output and in-place state update."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 1000 + E)
+    h = torch.randn(N, E, H, generator=g) * 0.7
+    c = torch.randn(N, E, H, generator=g)
+    z1 = torch.randn(N, E, 4 * H, generator=g)
+    z2 = torch.randn(N, E, 4 * H, generator=g) if two_addends else None
+    done = (torch.rand(E, generator=g) < 0.3).float()
+    # asymmetric weights (a swapped A/B or row/col mapping cannot pass) inside a wider flat row, like ParamStore
+    flat = torch.zeros(N, H * 4 * H + 4 * H + 48)
+    wh = flat[:, 16:16 + H * 4 * H].view(N, H, 4 * H)
+    wh.copy_(torch.randn(N, H, 4 * H, generator=g) * 0.2 + torch.arange(4 * H).view(1, 1, -1) * 1e-3)
+    b = flat[:, 16 + H * 4 * H + 16:16 + H * 4 * H + 16 + 4 * H]
+    b.copy_(torch.randn(N, 4 * H, generator=g) * 0.1)
+    hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
+    ops_ref.lstm_step_fused(h.double(), wh.double(), b.double(), z1.double(), None if z2 is None else z2.double(),
+                            c.double(), done.double(), None, cr, hr)
+    fg = flat.cuda()
+    whg = fg[:, 16:16 + H * 4 * H].view(N, H, 4 * H)
+    bg = fg[:, 16 + H * 4 * H + 16:16 + H * 4 * H + 16 + 4 * H]
+    # outputs into slot 1 of [N,3,E,*] sequence buffers, gates requested
+    Hbuf = torch.zeros(N, 3, E, H, device='cuda'); Cbuf = torch.zeros(N, 3, E, H, device='cuda')
+    Gbuf = torch.zeros(N, 3, E, 4 * H, device='cuda')
+    Hbuf[:, 0].copy_(h); Cbuf[:, 0].copy_(c)
+    ops.lstm_step_fused(Hbuf[:, 0], whg, bg, z1.cuda(), None if z2 is None else z2.cuda(), Cbuf[:, 0], done.cuda(),
+                        Gbuf[:, 1], Cbuf[:, 1], Hbuf[:, 1])
+    torch.testing.assert_close(Hbuf[:, 1].cpu().double(), hr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(Cbuf[:, 1].cpu().double(), cr, rtol=2e-5, atol=2e-6)
+    assert torch.all(Hbuf[:, 2] == 0) and torch.all(Gbuf[:, 2] == 0) and torch.all(Gbuf[:, 0] == 0)
+    gi = Gbuf[:, 1, :, :H].cpu().double()
+    assert torch.all((gi > 0) & (gi < 1))
+    # in place (rollout): h_out aliases h, c_out aliases c, no gates
+    hg, cg = h.cuda(), c.cuda()
+    ops.lstm_step_fused(hg, whg, bg, z1.cuda(), None if z2 is None else z2.cuda(), cg, done.cuda(), None, cg, hg)
+    torch.testing.assert_close(hg.cpu().double(), hr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(cg.cpu().double(), cr, rtol=2e-5, atol=2e-6)
+
+
 def test_sample_actions_modes():
     from deeprl_network_amd import ops
     from oracle import ops_ref

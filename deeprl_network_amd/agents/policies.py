@@ -26,6 +26,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from . import sequence
 
 # parameters and their gradients are deliberate strided views of the flat [N,P] buffers (see ParamStore)
 warnings.filterwarnings('ignore', message='grad and param do not obey the gradient layout contract')
@@ -127,6 +128,7 @@ class BatchedPolicy:
     """Common part: heads, rollout step (Q1 double step handled by the caller), unroll."""
 
     name = 'policy'
+    fused_coupled = True          # coupled policies: use agents/sequence.py in the update
 
     def __init__(self, n_feat, n_a, neighbor_mask, n_fc=64, n_h=64, device='cuda'):
         self.device = torch.device(device)
@@ -222,8 +224,16 @@ class BatchedPolicy:
             Hs = ops.lstm_sequence(enc.view(self.N, T, E, enc.shape[-1]), self.params[self.k_wh],
                                    self.params[self.k_b], h0, c0, done, masked_steps)
             return Hs.reshape(self.N, T * E, self.n_h)
-        # per-step views via ONE unbind: its backward is a single stack, whereas slicing `enc` inside
-        # the loop would make autograd materialise and add T full-size zero tensors (O(T^2) traffic)
+        if self.fused_coupled:
+            # cross-agent recurrences: manual BPTT in one autograd node (agents/sequence.py)
+            kind, wx, w_msg, b_msg, mfc_w, mfc_b = self._seq_args()
+            Hs = sequence.coupled_sequence(kind, self.nbr_idx, masked_steps, enc.view(self.N, T, E, enc.shape[-1]), h0, c0,
+                                           done, wx, self.params[self.k_wh], self.params[self.k_b], w_msg, b_msg,
+                                           mfc_w, mfc_b)
+            return Hs.reshape(self.N, T * E, self.n_h)
+        # reference path (kept for cross-checking the fused one): per-step autograd nodes.  Per-step views
+        # via ONE unbind: its backward is a single stack, whereas slicing `enc` inside the loop would make
+        # autograd materialise and add T full-size zero tensors (O(T^2) traffic)
         enc_steps = enc.view(self.N, T, E, enc.shape[-1]).unbind(1)
         h, c = h0, c0
         hs = []
@@ -347,6 +357,10 @@ class NCMultiAgentPolicy(BatchedPolicy):
         hm = self._fc_infer(ops.nbr_gather(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU)
         return torch.bmm(hm, p['wx_hid'][:, 2 * H:]), enc
 
+    def _seq_args(self):
+        p = self.params
+        return 'nc', p['wx_hid'][:, 2 * self.n_h:], p['w_msg'], p['w_msg_b'], None, None
+
 
 class IC3MultiAgentPolicy(BatchedPolicy):
     """CommNet ("IC3"): s = tanh(x~ W_ob + b) + mean_nbr(h_prev) W_msg + b_msg -> LSTM(H)
@@ -385,6 +399,10 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         p = self.params
         s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
         return torch.bmm(s, p['wx_hid']), None
+
+    def _seq_args(self):
+        p = self.params
+        return 'ic3', p['wx_hid'], p['w_msg'], p['w_msg_b'], None, None
 
 
 class ConsensusPolicy(LstmPolicy):
@@ -472,3 +490,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU)
         hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU).add_(enc)
         return torch.bmm(hm, p['wx_hid']), None
+
+    def _seq_args(self):
+        p = self.params
+        return 'dial', p['wx_hid'], p['w_msg'], p['w_msg_b'], p['mfc_w'], p['mfc_b']

@@ -1,0 +1,155 @@
+"""Fused n_step recurrences with CROSS-AGENT coupling (NeurComm, CommNet, DIAL) for the update: manual BPTT as one
+torch.autograd.Function instead of ~15 autograd nodes per step.
+
+Reference recurrences (agents/utils.py): lstm_comm 182-208, lstm_ic3 385-408, lstm_dial 561-593.  Per step t, with
+h = h_{t-1} (un-masked for the messages, quirk Q3), `enc_t` the h-independent part computed for all T beforehand:
+
+  nc    hm = relu(gather(h) W_msg + b_msg);                     z = enc_t + hm Wx[2H:3H] + (h keep) Wh
+  ic3   s  = enc_t + mean_nbr(h) W_msg + b_msg;                 z = s Wx + (h keep) Wh
+  dial  hm = relu(gather(relu(h W_mfc + b_mfc)) W_msg + b_msg); z = (enc_t + hm) Wx + (h keep) Wh
+
+followed by the cell (fused MFMA step kernel when H = 64).  Backward: one reverse loop of {cell_bwd, ONE dgrad GEMM
+against the adjacent [Wx-part; Wh] rows of the flat parameter buffer, message adjoints}, then every weight gradient as
+a SINGLE GEMM over all T*E rows and every bias gradient as a single reduction.
+"""
+import torch
+
+from .. import ops
+
+F32 = torch.float32
+
+
+def _stack_rows(w_top, w_bot):
+    """[w_top; w_bot] as one [N, rows, 4H] view when the two tensors are adjacent rows of the flat buffer."""
+    if (w_top.stride() == w_bot.stride() and w_top.shape[2] == w_bot.shape[2] and w_top.stride(2) == 1 and
+            w_top.stride(1) == w_top.shape[2] and
+            w_top.data_ptr() + w_top.shape[1] * w_top.shape[2] * 4 == w_bot.data_ptr()):
+        return torch.as_strided(w_top, (w_top.shape[0], w_top.shape[1] + w_bot.shape[1], w_top.shape[2]), w_top.stride())
+    return None
+
+
+class CoupledSequence(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, nbr_idx, masked_steps, enc, h0, c0, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b):
+        N, T, E, _ = enc.shape
+        H = h0.shape[-1]
+        dev = enc.device
+        G = torch.empty(N, T, E, 4 * H, dtype=F32, device=dev)
+        Hall = torch.empty(N, T + 1, E, H, dtype=F32, device=dev)
+        Call = torch.empty(N, T + 1, E, H, dtype=F32, device=dev)
+        Hall[:, 0].copy_(h0)
+        Call[:, 0].copy_(c0)
+        A1 = torch.empty(N, T, E, H, dtype=F32, device=dev)          # nc/dial: hm (post-relu); ic3: s
+        A2 = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None   # dial: msg (post-relu)
+        S = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None    # dial: enc + hm
+        masked = set(range(T)) if masked_steps is None else set(masked_steps)
+        fused = H == ops.FUSED_H
+        keep = 1.0 - done
+        for t in range(T):
+            hp = Hall[:, t].contiguous()
+            if kind == 'nc':
+                ops.bias_act_(torch.bmm(ops.nbr_gather(hp, nbr_idx), w_msg), b_msg, ops.BIAS_RELU, out=A1[:, t])
+                z1, z2 = enc[:, t], torch.bmm(A1[:, t], wx)
+            elif kind == 'ic3':
+                s = ops.bias_act_(torch.bmm(ops.nbr_mean(hp, nbr_idx), w_msg), b_msg, ops.BIAS_NONE)
+                torch.add(s, enc[:, t], out=A1[:, t])
+                z1, z2 = torch.bmm(A1[:, t], wx), None
+            else:
+                ops.bias_act_(torch.bmm(hp, mfc_w), mfc_b, ops.BIAS_RELU, out=A2[:, t])
+                ops.bias_act_(torch.bmm(ops.nbr_gather(A2[:, t].contiguous(), nbr_idx), w_msg), b_msg, ops.BIAS_RELU,
+                              out=A1[:, t])
+                torch.add(A1[:, t], enc[:, t], out=S[:, t])
+                z1, z2 = torch.bmm(S[:, t], wx), None
+            if fused:
+                ops.lstm_step_fused(Hall[:, t], wh, b, z1, z2, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1])
+            else:
+                hk = hp * keep[t].view(1, E, 1) if t in masked else hp
+                z = torch.bmm(hk, wh) if z2 is None else torch.baddbmm(z2, hk, wh)
+                ops.cell_fwd(z, b, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1], z2=z1)
+        ctx.save_for_backward(G, Hall, Call, A1, A2 if A2 is not None else G.new_empty(0), S if S is not None else G.new_empty(0),
+                              done, wx, wh, w_msg, mfc_w if mfc_w is not None else G.new_empty(0), nbr_idx)
+        ctx.kind, ctx.masked = kind, masked
+        return Hall[:, 1:]
+
+    @staticmethod
+    def backward(ctx, dHs):
+        G, Hall, Call, A1, A2, S, done, wx, wh, w_msg, mfc_w, nbr_idx = ctx.saved_tensors
+        kind, masked = ctx.kind, ctx.masked
+        N, T, E, H4 = G.shape
+        H = H4 // 4
+        dev = G.device
+        dHs = dHs.contiguous()
+        dZ = torch.empty_like(G)
+        D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
+        D2 = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None   # dial: d(pre-relu of msg)
+        DS = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None   # dial: ds
+        keep = 1.0 - done
+        w2 = _stack_rows(wx, wh)                              # [N, 2H, 4H]: one dgrad GEMM gives [d(wx input) | d(h keep)]
+        w2_t = None if w2 is None else w2.transpose(1, 2)
+        wx_t, wh_t, wmsg_t = wx.transpose(1, 2), wh.transpose(1, 2), w_msg.transpose(1, 2)
+        dh_rec = None
+        dc = torch.zeros(N, E, H, dtype=F32, device=dev)
+        dc_next = torch.empty_like(dc)
+        for t in range(T - 1, -1, -1):
+            ops.cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
+            dc, dc_next = dc_next, dc
+            if w2_t is not None:
+                d2 = torch.bmm(dZ[:, t], w2_t)
+                dx, dhd = d2[..., :H], d2[..., H:]
+            else:
+                dx, dhd = torch.bmm(dZ[:, t], wx_t), torch.bmm(dZ[:, t], wh_t)
+            if t in masked:
+                dhd = dhd * keep[t].view(1, E, 1)
+            if kind == 'nc':
+                torch.mul(dx, (A1[:, t] > 0), out=D1[:, t])
+                dh_msg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
+            elif kind == 'ic3':
+                D1[:, t].copy_(dx)
+                dh_msg = ops.nbr_mean_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx)
+            else:
+                DS[:, t].copy_(dx)
+                torch.mul(dx, (A1[:, t] > 0), out=D1[:, t])
+                dmsg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
+                torch.mul(dmsg, (A2[:, t] > 0), out=D2[:, t])
+                dh_msg = torch.bmm(D2[:, t], mfc_w.transpose(1, 2))
+            dh_rec = dh_msg + dhd
+        R = T * E
+        dZf = dZ.view(N, R, H4)
+        Hprev = Hall[:, :T]
+        if len(masked) == T:
+            Hk = (Hprev * keep.view(1, T, E, 1)).reshape(N, R, H)
+        else:
+            Hk = Hprev.clone()
+            for t in masked:
+                Hk[:, t].mul_(keep[t].view(1, E, 1))
+            Hk = Hk.view(N, R, H)
+        dwh = torch.bmm(Hk.transpose(1, 2), dZf)
+        db = dZf.sum(dim=1)
+        Hp = Hprev.reshape(N, R, H)                            # un-masked h_{t-1} of all steps (message inputs)
+        dmfc_w = dmfc_b = None
+        if kind == 'nc':
+            dwx = torch.bmm(A1.view(N, R, H).transpose(1, 2), dZf)
+            D1f = D1.view(N, R, H)
+            dwmsg = torch.bmm(ops.nbr_gather(Hp, nbr_idx).transpose(1, 2), D1f)
+            dbmsg = D1f.sum(dim=1)
+            denc = dZ
+        elif kind == 'ic3':
+            dwx = torch.bmm(A1.view(N, R, H).transpose(1, 2), dZf)
+            D1f = D1.view(N, R, H)
+            dwmsg = torch.bmm(ops.nbr_mean(Hp, nbr_idx).transpose(1, 2), D1f)
+            dbmsg = D1f.sum(dim=1)
+            denc = D1
+        else:
+            dwx = torch.bmm(S.view(N, R, H).transpose(1, 2), dZf)
+            D1f, D2f = D1.view(N, R, H), D2.view(N, R, H)
+            dwmsg = torch.bmm(ops.nbr_gather(A2.view(N, R, H), nbr_idx).transpose(1, 2), D1f)
+            dbmsg = D1f.sum(dim=1)
+            dmfc_w = torch.bmm(Hp.transpose(1, 2), D2f)
+            dmfc_b = D2f.sum(dim=1)
+            denc = DS
+        return None, None, None, denc, dh_rec, dc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b
+
+
+def coupled_sequence(kind, nbr_idx, masked_steps, enc, h0, c0, done, wx, wh, b, w_msg, b_msg, mfc_w=None, mfc_b=None):
+    """enc [N,T,E,W] -> Hs [N,T,E,H]; see the module docstring."""
+    return CoupledSequence.apply(kind, nbr_idx, masked_steps, enc, h0, c0, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b)

@@ -75,6 +75,26 @@ def nbr_gather(x, nbr_idx):
     return _NbrGather.apply(x, nbr_idx)
 
 
+def nbr_gather_bwd(dy, nbr_idx, F):
+    """Adjoint of nbr_gather as a plain function (manual BPTT): dy [N,E,m_max*F] -> dx [N,E,F]."""
+    N, E, _ = dy.shape
+    dy = dy.contiguous()
+    dx = torch.empty(N, E, F, dtype=F32, device=dy.device)
+    check(lib.nmarl_nbr_gather_bwd(E, N, F, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(dy, F32), ptr(dx), stream()),
+          'nmarl_nbr_gather_bwd')
+    return dx
+
+
+def nbr_mean_bwd(dy, nbr_idx):
+    """Adjoint of nbr_mean as a plain function: dy [N,E,F] -> dx [N,E,F]."""
+    N, E, F = dy.shape
+    dy = dy.contiguous()
+    dx = torch.empty_like(dy)
+    check(lib.nmarl_nbr_mean_bwd(E, N, F, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(dy, F32), ptr(dx), stream()),
+          'nmarl_nbr_mean_bwd')
+    return dx
+
+
 def nbr_mean(x, nbr_idx):
     """x [N,E,F] -> [N,E,F]: mean over the neighbours of each agent."""
     return _NbrMean.apply(x, nbr_idx)

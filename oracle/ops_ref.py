@@ -32,6 +32,37 @@ def nbr_mean(x, nbr_idx):
     return torch.stack([torch.stack([x[j] for j in js], 0).mean(0) for js in neighbor_lists(nbr_idx)], 0)
 
 
+def nbr_gather_bwd(dy, nbr_idx, F):
+    """Adjoint of nbr_gather (by autograd of the forward restatement)."""
+    N, E, _ = dy.shape
+    x = torch.zeros(N, E, F, dtype=dy.dtype, requires_grad=True)
+    with torch.enable_grad():
+        y = nbr_gather(x, nbr_idx)
+    return torch.autograd.grad(y, x, dy)[0]
+
+
+def nbr_mean_bwd(dy, nbr_idx):
+    x = torch.zeros_like(dy, requires_grad=True)
+    with torch.enable_grad():
+        y = nbr_mean(x, nbr_idx)
+    return torch.autograd.grad(y, x, dy)[0]
+
+
+def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
+    """Backward of the LSTM cell from the saved post-activation gates (agents/utils.py:102-113)."""
+    H = c_prev.shape[-1]
+    gi, gf, go, gu = gates.split(H, dim=-1)
+    keep = (1.0 - done).view(1, -1, 1)
+    tc = torch.tanh(c_new)
+    g_h = torch.zeros_like(c_new) if dh is None else dh
+    if dh2 is not None:
+        g_h = g_h + dh2
+    g_c = (torch.zeros_like(c_new) if dc is None else dc) + g_h * go * (1 - tc * tc)
+    dz.copy_(torch.cat([g_c * gu * gi * (1 - gi), g_c * (c_prev * keep) * gf * (1 - gf), g_h * tc * go * (1 - go),
+                        g_c * gi * (1 - gu * gu)], dim=-1))
+    dc_prev.copy_(g_c * gf * keep)
+
+
 def nbr_onehot(action, nbr_idx, n_a, out=None):
     """one_hot(boolean_mask(action, mask_i)) -> [N,E,m_max*A] (policies.py:66-68, 305)."""
     E, N = action.shape
@@ -68,6 +99,10 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
     if zadd2 is not None:
         z = z + zadd2
     hn, cn = lstm_cell(z, bias, c_prev, done)
+    if gates is not None:
+        H = h.shape[-1]
+        zb = z + bias.unsqueeze(1)
+        gates.copy_(torch.cat([torch.sigmoid(zb[..., :3 * H]), torch.tanh(zb[..., 3 * H:])], dim=-1))
     c_out.copy_(cn)
     h_out.copy_(hn)
     return h_out, c_out

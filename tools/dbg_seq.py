@@ -11,7 +11,7 @@ T, E = 5, int(sys.argv[1]) if len(sys.argv) > 1 else 300
 g = torch.Generator().manual_seed(1)
 def build(dev):
     np.random.seed(5)
-    pol = policies.NCMultiAgentPolicy(n_feat, A, nb, device=dev)
+    pol = getattr(policies, sys.argv[3] if len(sys.argv) > 3 else 'NCMultiAgentPolicy')(n_feat, A, nb, device=dev)
     pol.params.init_reference_order()
     return pol
 pol = build('cuda'); N = pol.N
@@ -30,6 +30,9 @@ def run(pol, dev, fused):
 gm = run(pol, 'cuda', True); ga = run(pol, 'cuda', False)
 with cpu_ops():
     pc = build('cpu'); gc = run(pc, 'cpu', False)
+for key, (o, size, shape, fmt, _) in pol.params.index.items():
+    sl = slice(o, o + size)
+    print('   %-10s scale %9.3e  manual-vs-cpu %9.3e  autograd-vs-cpu %9.3e' % (key, gc[:, sl].abs().max().item(), (gm[:, sl] - gc[:, sl]).abs().max().item(), (ga[:, sl] - gc[:, sl]).abs().max().item()))
 print(topo, 'E', E, 'scale %.3e manual-vs-cpu %.3e autograd-vs-cpu %.3e' % (gc.abs().max().item(), (gm - gc).abs().max().item(), (ga - gc).abs().max().item()))
 ga2 = run(pol, 'cuda', False)
 print('   autograd run-to-run diff %.3e' % (ga - ga2).abs().max().item())

@@ -18,9 +18,10 @@
 // fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md): 256 MFMAs x 64 cycles
 // per 32 rows and wave -> 6.8 us of matrix time for 32768 rows on 256 CUs.
 #include "../deeprl_network_amd/csrc/common.h"
+#include <stdlib.h>
 
-__device__ unsigned long long g_dbg[8];
-#define STAMP(i) if (blockIdx.x == 7 && threadIdx.x == 64) g_dbg[i] = __builtin_readcyclecounter();
+__device__ unsigned long long g_dbg[32];
+#define STAMP(i) if (blockIdx.x == 7 && (threadIdx.x == 0 || threadIdx.x == 256)) g_dbg[(threadIdx.x >> 8) * 8 + i] = __builtin_readcyclecounter();
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -61,7 +62,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
     const int col = lane & 31, half = lane >> 5;
     float* a_tile = a_lds + wave * ROWS_W * APITCH;
 
-    STAMP(0)
     // ---- accumulators <- zadd1: 128 independent loads per lane, nothing consumes them before the K loop, so
     // they all stay in flight behind the LDS staging (an add right after each load serialised them: 29 us)
     f32x16 acc[8];
@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
     for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = z1[rofs[r] * G4 + t * 32 + col];
-    STAMP(1)
     // ---- c_prev of this lane's (row, unit) pairs
     float cp[2][16];
     const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
@@ -87,7 +86,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
             cp[jj][r] = cpn[rofs[r] * H + jj * 32 + col];
         }
 
-    STAMP(2)
     // ---- stage Wh (64 KB, whole block) and this wave's h tile (masked by 1 - done) in LDS
     {
         const float4* wg = reinterpret_cast<const float4*>(a.wh + (int64_t)n * a.wh_sn);
@@ -107,8 +105,8 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
             d[0] = x.x * keep; d[1] = x.y * keep; d[2] = x.z * keep; d[3] = x.w * keep;
         }
     }
-    STAMP(3)
     __syncthreads();
+
     // ---- + bias (+ zadd2): C operand of the first MFMA of every tile
     {
         const float* bn = a.bias + (int64_t)n * a.bias_sn;
@@ -125,7 +123,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
         }
     }
 
-    STAMP(4)
     // ---- K loop: 32 steps of K = 2, 8 column tiles each
 #pragma unroll 4
     for (int kk = 0; kk < H / 2; ++kk) {
@@ -135,7 +132,6 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
         for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wrow[t * 32], acc[t], 0, 0, 0);
     }
 
-    STAMP(5)
     // ---- lane-local cell epilogue
     float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
     float* cn = a.c_new + (int64_t)n * a.c_new_sn;
@@ -161,8 +157,169 @@ __global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs 
                 }
             }
         }
-        STAMP(6)
+    }
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// v2: 16-row wave strips on v_mfma_f32_16x16x4_f32, two waves per SIMD, staggered halves.
+//
+// v1 above runs ONE wave per SIMD, so its phases (HBM loads ~11 us chip-wide, MFMA 8 us, epilogue 5.6 us) add up
+// (26-28 us per call at E = 4096).  Here a 512-thread block = 8 waves x 16 rows (same 128 rows per block, same
+// grid); waves 0-3 ("A") issue their input loads at once while waves 4-7 ("B") stage Wh into LDS; after the one
+// block barrier B issues its loads.  Each SIMD hosts one A and one B wave: B's loads overlap A's MFMAs, and B's
+// MFMAs overlap A's (VALU) epilogue.  Wh sits in LDS as [k][lane c][tile t] with pitch 20 floats per lane, so a
+// lane fetches the B operands of all 16 column tiles of one k with four conflict-free ds_read_b128.
+// C/D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + reg -> the four gates of unit j = 16 jj + col
+// are acc[jj], acc[4 + jj], acc[8 + jj], acc[12 + jj] at the same reg: the cell stays lane-local.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int R16 = 16;                 // rows per wave
+constexpr int WAVES2 = 8;
+constexpr int WPITCH = 16 * 20;         // floats per k row of the permuted W image
+constexpr int LDS2_FLOATS = H * WPITCH + WAVES2 * R16 * APITCH;
+
+template <bool HAS_Z2>
+__global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* w_lds = lds;                                   // [64][16][20]
+    const int n = blockIdx.x / a.blocks_per_agent;
+    const int64_t row_blk = (int64_t)(blockIdx.x - n * a.blocks_per_agent) * ROWS_B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = row_blk + wave * R16;
+    const int c = lane & 15, grp = lane >> 4;
+    float* a_tile = lds + H * WPITCH + wave * R16 * APITCH;
+    const bool groupA = wave < 4;
+
+    int64_t rofs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * grp + r;
+        rofs[r] = row < a.E ? row : a.E - 1;
+    }
+    f32x4 acc[16];
+    float cp[4][4];
+    float4 hreg[4];
+    float hkeep[4];
+    const float* z1 = a.zadd1 + (int64_t)n * a.zadd1_sn;
+    const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
+    const float* hn = a.h_in + (int64_t)n * a.h_sn;
+
+    auto issue_loads = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                      // this wave's 16 x 64 tile of h: 4 float4 per lane, coalesced
+            const int v = i * 64 + lane;
+            int64_t row = row0 + (v >> 4);
+            row = row < a.E ? row : a.E - 1;
+            hreg[i] = *reinterpret_cast<const float4*>(hn + row * H + (v & 15) * 4);
+            hkeep[i] = 1.0f - a.done[row];
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = z1[rofs[r] * G4 + t * 16 + c];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[jj][r] = cpn[rofs[r] * H + jj * 16 + c];
+    };
+
+    STAMP(0)
+    if (groupA) {
+        issue_loads();
+    } else {
+        // stage Wh (64 x 256) as [k][c][t]: thread -> 16 float4 of 4 consecutive columns (same tile, lanes c..c+3)
+        const float* wg = a.wh + (int64_t)n * a.wh_sn;
+        const int tid = threadIdx.x - 256;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int v = i * 256 + tid;                   // float4 index in the 64 x 64 float4 image
+            const int k = v >> 6, col = (v & 63) * 4;
+            const float4 x = *reinterpret_cast<const float4*>(wg + k * G4 + col);
+            float* d = w_lds + k * WPITCH + (col & 15) * 20 + (col >> 4);
+            d[0] = x.x; d[20] = x.y; d[40] = x.z; d[60] = x.w;
+        }
+    }
+    STAMP(1)
+    __syncthreads();
+    STAMP(2)
+    if (!groupA) issue_loads();
+
+    // own h tile -> LDS (wave-private region), masked by 1 - done
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = i * 64 + lane;
+        float* d = a_tile + (v >> 4) * APITCH + (v & 15) * 4;
+        d[0] = hreg[i].x * hkeep[i]; d[1] = hreg[i].y * hkeep[i]; d[2] = hreg[i].z * hkeep[i]; d[3] = hreg[i].w * hkeep[i];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    STAMP(3)
+    {   // + bias (+ zadd2)
+        const float* bn = a.bias + (int64_t)n * a.bias_sn;
+        const float* z2 = HAS_Z2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float b = bn[t * 16 + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[t][r] + b;
+                if (HAS_Z2) v += z2[rofs[r] * G4 + t * 16 + c];
+                acc[t][r] = v;
+            }
+        }
+    }
+
+    STAMP(4)
+    // K loop: 16 steps of K = 4;  A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15]
+#pragma unroll 2
+    for (int kk = 0; kk < H / 4; ++kk) {
+        const float av = a_tile[c * APITCH + 4 * kk + grp];
+        const float4* wq = reinterpret_cast<const float4*>(w_lds + (4 * kk + grp) * WPITCH + c * 20);
+        const float4 b0 = wq[0], b1 = wq[1], b2 = wq[2], b3 = wq[3];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.w, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.x, acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.y, acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.z, acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.w, acc[7], 0, 0, 0);
+        acc[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.x, acc[8], 0, 0, 0);
+        acc[9] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.y, acc[9], 0, 0, 0);
+        acc[10] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.z, acc[10], 0, 0, 0);
+        acc[11] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.w, acc[11], 0, 0, 0);
+        acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.x, acc[12], 0, 0, 0);
+        acc[13] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.y, acc[13], 0, 0, 0);
+        acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.z, acc[14], 0, 0, 0);
+        acc[15] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.w, acc[15], 0, 0, 0);
+    }
+
+    STAMP(5)
+    float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
+    float* cn = a.c_new + (int64_t)n * a.c_new_sn;
+    float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * grp + r;
+            const bool ok = row < a.E;
+            const float keep = 1.0f - a.done[rofs[r]];
+            const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
+            const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
+            const float cv = gf * (cp[jj][r] * keep) + gi * gu;
+            const float hv = go * tanh_fast(cv);
+            if (ok) {
+                const int j = jj * 16 + c;
+                cn[row * H + j] = cv;
+                hn_out[row * H + j] = hv;
+                if (gn) {
+                    float* g = gn + row * G4 + j;
+                    g[0] = gi; g[H] = gf; g[2 * H] = go; g[3 * H] = gu;
+                }
+            }
+        }
+    }
+    STAMP(6)
 }
 
 inline bool stride_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
@@ -189,25 +346,31 @@ extern "C" int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t Hh, const flo
     a.c_prev_sn = c_prev_sn; a.gates_sn = gates_sn; a.c_new_sn = c_new_sn; a.h_new_sn = h_new_sn;
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
-    const size_t lds_bytes = (size_t)(H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+    static int variant = -1;        // NMARL_FUSED_VARIANT=1 selects the one-wave-per-SIMD 32x32x2 kernel (A/B comparisons)
+    if (variant < 0) {
+        const char* ev = getenv("NMARL_FUSED_VARIANT");
+        variant = (ev && ev[0] == '1') ? 1 : 2;
+        const int l1 = (int)((H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float)), l2 = (int)(LDS2_FLOATS * sizeof(float));
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l2) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l2) != hipSuccess)
             return NMARL_EHIP;
-        attr_set = true;
     }
-    if (zadd2)
-        hipLaunchKernelGGL(lstm_step_mfma_kernel<true>, dim3(a.blocks_per_agent * N), dim3(256), lds_bytes,
-                           static_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(lstm_step_mfma_kernel<false>, dim3(a.blocks_per_agent * N), dim3(256), lds_bytes,
-                           static_cast<hipStream_t>(stream), a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(a.blocks_per_agent * N);
+    if (variant == 1) {
+        const size_t lds_bytes = (size_t)(H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float);
+        if (zadd2) hipLaunchKernelGGL(lstm_step_mfma_kernel<true>, grid, dim3(256), lds_bytes, st, a);
+        else hipLaunchKernelGGL(lstm_step_mfma_kernel<false>, grid, dim3(256), lds_bytes, st, a);
+    } else {
+        const size_t lds_bytes = (size_t)LDS2_FLOATS * sizeof(float);
+        if (zadd2) hipLaunchKernelGGL(lstm_step_mfma16_kernel<true>, grid, dim3(512), lds_bytes, st, a);
+        else hipLaunchKernelGGL(lstm_step_mfma16_kernel<false>, grid, dim3(512), lds_bytes, st, a);
+    }
     return nmarl_check_launch();
 }
 
 extern "C" int nmarl_debug_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), 32 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
 }

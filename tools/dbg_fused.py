@@ -20,10 +20,12 @@ t0.record()
 for _ in range(50): run()
 t1.record(); torch.cuda.synchronize()
 print('us per call', t0.elapsed_time(t1) * 1e3 / 50)
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 32)()
 L.nmarl_debug_read(out)
 v = list(out)
-names = ['acc loads issue', 'c loads issue', 'W+A staging', 'barrier+bias', 'MFMA loop', 'epilogue']
-for i, n in enumerate(names):
-    print('%-16s %8d cycles' % (n, v[i + 1] - v[i]))
-print('total', v[6] - v[0])
+names = ['issue loads / stage W', 'barrier wait', 'B issues loads', 'h tile + wait data', 'bias add', 'MFMA loop', 'epilogue']
+base = v[0]
+for grp, off in (('A (wave 0)', 0), ('B (wave 4)', 8)):
+    print(grp, 'start at +%d' % (v[off] - base))
+    for i, n in enumerate(names[:6]):
+        print('   %-24s %8d cycles (ends at +%d)' % (names[i] if i != 2 else names[2], v[off + i + 1] - v[off + i], v[off + i + 1] - base))

@@ -93,6 +93,39 @@ def measure_step_kernel(env, actions_tape, reps=20):
     return us
 
 
+def measure_lstm_step(model, n=60, reps=10):
+    """Average duration of one fused MFMA LSTM step (nmarl_lstm_step_fused, the kernel with the largest share of
+    the batch time) on the model's own [N,E,64] state shapes and weights: hipGraph of n launches between HIP events.
+    Algorithmic bytes per (agent, replica) row: read h 256 + pre-activation addend 1024 + c 256, write c' 256 + h' 256."""
+    from deeprl_network_amd import ops
+    p = model.policy
+    N, E, H = model.h_fw.shape
+    h, c = torch.randn(N, E, H, device=model.device) * 0.3, torch.randn(N, E, H, device=model.device) * 0.3
+    z = torch.randn(N, E, 4 * H, device=model.device)
+    done = torch.zeros(E, device=model.device)
+    wh, b = p.params[p.k_wh], p.params[p.k_b]
+
+    def body():
+        for _ in range(n):
+            ops.lstm_step_fused(h, wh, b, z, None, c, done, None, c, h)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * n), N * E * (3 * H + 4 * H + H) * 4      # 2048 B / row at H = 64
+
+
 def pmc_traffic(key):
     """HBM bytes per replica-step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE runs of tools/pmc_env.py, FETCH x2 per MI355X_MICROARCH.md, calibrated on a known copy).
@@ -244,6 +277,21 @@ def main():
                 del big
             except Exception as ex:      # never lose the headline line to the side measurement
                 out['roofline_large_E'] = {'error': repr(ex)}
+        if model.n_lstm == 64:
+            try:
+                us_l, bytes_l = measure_lstm_step(model)
+                out['roofline_lstm_step'] = {
+                    'kernel': 'lstm_step_mfma16_kernel (nmarl_lstm_step_fused[_head])', 'bound': 'hbm',
+                    'achieved': bytes_l / us_l / 1e3, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': bytes_l,
+                    'us_per_launch': us_l, 'launches_per_batch': 3 * n_step + 2,
+                    'mfma_flops_per_launch': 2 * n_agent * E * 64 * 256,
+                    'how': 'hipGraph of 60 in-place fused steps on [N,E,64] state with the model weights, 10 replays '
+                           'between HIP events; 2048 B per (agent, replica) row; the fp32 MFMA work is %.1f GFLOP per '
+                           'launch (157 TFLOP/s peak -> %.1f us), so the kernel is HBM-side'
+                           % (2 * n_agent * E * 64 * 256 / 1e9, 2 * n_agent * E * 64 * 256 / 157e12 * 1e6)}
+            except Exception as ex:
+                out['roofline_lstm_step'] = {'error': repr(ex)}
         if world == 1 and not args.no_cpu_baseline and not is_grid:
             out['cpu_baseline'] = cpu_baseline(args.config, args.cpu_batches)
         print(json.dumps(out))

@@ -18,6 +18,13 @@ if not os.path.exists(LIB_PATH):
         'deeprl_network_amd: %s not found. Build it with `python -m deeprl_network_amd.build` '
         '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
 
+from . import build as _build  # noqa: E402
+
+if _build.built_hash() != _build.source_hash():
+    raise ImportError(
+        'deeprl_network_amd: %s is stale (built from sources %s, current sources %s). Rebuild it with '
+        '`python -m deeprl_network_amd.build`.' % (LIB_PATH, _build.built_hash(), _build.source_hash()))
+
 lib = C.CDLL(LIB_PATH)
 
 ABI_VERSION = 1
@@ -29,6 +36,15 @@ class CaccParams(C.Structure):
                 ('dt', 'h_min', 'h_star', 'h_s', 'h_g', 'v_max', 'v_star', 'u_min', 'u_max',
                  'reward_a', 'reward_b', 'G')] + \
                [(n, C.c_int32) for n in ('T', 'batch_size', 'scenario', 'train_mode', 'per_agent_reward')]
+
+
+class Head(C.Structure):
+    """nmarl_head_t (include/nmarl.h): actor / critic head of the fused step's epilogue."""
+    _fields_ = [('kind', C.c_int32), ('A', C.c_int32), ('mode', C.c_int32), ('m_max', C.c_int32),
+                ('w', C.c_void_p), ('w_sn', C.c_int64), ('b', C.c_void_p), ('b_sn', C.c_int64),
+                ('pi_out', C.c_void_p), ('pi_sn', C.c_int64), ('act_out', C.c_void_p), ('u', C.c_void_p),
+                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('step', C.c_int64), ('step_dev', C.c_void_p),
+                ('act_in', C.c_void_p), ('nbr_idx', C.c_void_p), ('v_out', C.c_void_p), ('v_sn', C.c_int64)]
 
 
 class GridParams(C.Structure):
@@ -60,6 +76,8 @@ SIGNATURES = {
     'nmarl_lstm_cell_fwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_step_fused': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p,
                               _i64, _p, _i64, _p],
+    'nmarl_lstm_step_fused_head': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64,
+                                   _p, _i64, _p, _i64, C.POINTER(Head), _p],
     'nmarl_bias_act': [_i64, _i32, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],

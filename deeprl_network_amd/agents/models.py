@@ -125,7 +125,8 @@ class IA2C:
         # slot 0 of the next batch.
         self.buf_x = torch.zeros(T + 1, E, N, p.n_obs, dtype=F32, device=d)
         self.buf_fp = torch.full((T + 1, N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
-        self.buf_na = torch.zeros(T, N, E, p.n_na, dtype=F32, device=d)
+        self.na_all = torch.zeros(N, T * E, p.n_na, dtype=F32, device=d)   # critic one-hots, filled by update()
+        self._pi_boot, self._v_boot = torch.zeros(N, E, self.n_a, dtype=F32, device=d), torch.zeros(N, E, dtype=F32, device=d)
         self.buf_act = torch.zeros(T, E, N, dtype=torch.uint8, device=d)
         self.buf_v = torch.zeros(T, N, E, dtype=F32, device=d)
         self.buf_done_pre = torch.zeros(T, E, dtype=F32, device=d)
@@ -175,17 +176,16 @@ class IA2C:
     def act(self, done, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0, step_dev=None,
             done_is_zero=False):
         """One lock-step decision for all replicas at buffer slot t: reads the observation buf_x[t]
-        and fingerprints buf_fp[t]; writes the action into buf_act[t], the neighbour one-hots into
-        buf_na[t], the value into buf_v[t] and the new policy into buf_fp[t+1].  done [E] f32 is the
-        pre-step flag.  Returns the action slot (input of the env kernel)."""
+        and fingerprints buf_fp[t]; writes the action into buf_act[t], the value into buf_v[t] and the
+        new policy into buf_fp[t+1] (env.update_fingerprint, utils.py:173).  done [E] f32 is the pre-step
+        flag.  Two kernels after the encoder when the heads fuse (H = 64).  Returns the action slot (input
+        of the env kernel)."""
         t = self.t
-        obs = self.buf_x[t]
-        pi = self._policy_step(obs, done, done_is_zero)
-        ops.sample_actions(pi, self.buf_act[t], mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
-                           step_dev=step_dev)
-        ops.nbr_onehot(self.buf_act[t], self.policy.nbr_idx, self.n_a, out=self.buf_na[t])
-        self._value_step(obs, done, self.buf_na[t], done_is_zero, out=self.buf_v[t], reuse_enc=True)
-        self.buf_fp[t + 1].copy_(pi)                       # env.update_fingerprint(policy), utils.py:173
+        p = self.policy
+        enc = p.encode(self.buf_x[t], self.fp)             # shared by the policy step and the value re-step (Q1)
+        p.step_policy(enc, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw, self.buf_fp[t + 1], self.buf_act[t],
+                      done_is_zero, mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+        p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, self.buf_act[t], self.buf_v[t], done_is_zero)
         return self.buf_act[t]
 
     def record(self, reward, done_post):
@@ -213,18 +213,20 @@ class IA2C:
         """R for the unfinished replicas (utils.py:192-196) from buf_x[T] / buf_fp[T]: one more policy
         step (which advances states_fw -- quirk Q2) and the double-stepped value."""
         assert self.t == self.n_step
-        obs = self.buf_x[self.n_step]
-        pi = self._policy_step(obs, done, done_is_zero)
-        ops.sample_actions(pi, action_scratch, mode, u=u, seed=seed, env_id_base=env_id_base, step=step,
-                           step_dev=step_dev)
-        na = ops.nbr_onehot(action_scratch, self.policy.nbr_idx, self.n_a)
-        return self._value_step(obs, done, na, done_is_zero, reuse_enc=True)
+        p = self.policy
+        enc = p.encode(self.buf_x[self.n_step], self.fp)
+        p.step_policy(enc, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw, self._pi_boot, action_scratch,
+                      done_is_zero, mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+        return p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, action_scratch, self._v_boot,
+                            done_is_zero)
 
     def _loss(self, Hs):
         """policies.py:20-30 / 232-255 with the batch mean taken over T*E."""
         N, T, E = self.n_agent, self.n_step, self.E
         p = self.policy
-        pi, v = p.heads(Hs, self.buf_na.permute(1, 0, 2, 3).reshape(N, T * E, p.n_na))   # [N,T*E,A], [N,T*E]
+        # the critic's neighbour one-hots of all T*E rows in one launch, from the action bytes (policies.py:66-68)
+        ops.nbr_onehot(self.buf_act.view(T * E, N), p.nbr_idx, self.n_a, out=self.na_all)
+        pi, v = p.heads(Hs, self.na_all)                                      # [N,T*E,A], [N,T*E]
         acts = self.buf_act.view(T * E, N).t().long().unsqueeze(-1)          # [N, T*E, 1]
         log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
         entropy = -(pi * log_pi).sum(-1)
@@ -325,11 +327,12 @@ class IA2C:
         return [x for x in v[:, 0].cpu().numpy()]
 
     def add_transition(self, ob, naction, action, reward, value, done):
-        """models.py:26-32 -> device buffers (slot t)."""
+        """models.py:26-32 -> device buffers (slot t).  `naction` is not stored: it is
+        env.get_neighbor_action(action) (utils.py:172, cacc_env.py:125-129), i.e. a function of `action`, and
+        update() rebuilds the critic's one-hots from the action bytes."""
         t = self.t
         slab, fp = self._obs_to_slab(ob)
         self.buf_x[t].copy_(slab)
-        self.buf_na[t].copy_(self._na_onehot_from_list(naction))
         self.buf_act[t].copy_(torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)))
         self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))
         self.buf_done_pre[t].fill_(float(self._prev_done))
@@ -447,7 +450,6 @@ class MA2C_NC(IA2C):
         self.buf_x[t].copy_(slab)
         self.buf_fp[t].copy_(torch.as_tensor(np.asarray(p, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
         a = torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)).to(self.device)
-        ops.nbr_onehot(a, self.policy.nbr_idx, self.n_a, out=self.buf_na[t])
         self.buf_act[t].copy_(a)
         self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))
         self.buf_done_pre[t].fill_(float(self._prev_done))

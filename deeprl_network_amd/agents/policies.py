@@ -202,6 +202,41 @@ class BatchedPolicy:
                 ops.lstm_cell_infer(z, b, c, done, c_out, h_out, z2=z1)
         return h_out, c_out
 
+    @property
+    def fused_heads(self):
+        """The actor / critic heads can ride in the fused step's epilogue (csrc/lstm_mfma.hip)."""
+        return self.n_h == ops.FUSED_H and self.n_a <= ops.HEAD_MAX_A
+
+    def step_policy(self, enc, h, c, done, h_out, c_out, pi_out, act_out, done_is_zero=False, **draw):
+        """forward('p') + the action draw of one lock-step (policies.py:119-123, utils.py:135-141): one LSTM step,
+        pi -> pi_out [N,E,A], actions -> act_out [E,N] u8.  `draw`: sample_actions' mode / u / seed / env_id_base /
+        step / step_dev.  One kernel when `fused_heads`."""
+        with torch.no_grad():
+            if self.fused_heads:
+                z1, z2 = self._recur_addends(enc, h)
+                p = self.params
+                ops.lstm_step_policy(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['pi_w'], p['pi_b'],
+                                     pi_out, act_out, **draw)
+            else:
+                self.step(enc, h, c, done, h_out, c_out, done_is_zero)
+                pi_out.copy_(self.pi(h_out))
+                ops.sample_actions(pi_out, act_out, **draw)
+        return pi_out, act_out
+
+    def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):
+        """forward('v') of one lock-step (policies.py:124-133): the LSTM re-step and the critic on
+        [h', onehot(neighbours' actions)], actions given as the env-major byte array action [E,N] -> v_out [N,E]."""
+        with torch.no_grad():
+            if self.fused_heads:
+                z1, z2 = self._recur_addends(enc, h)
+                p = self.params
+                ops.lstm_step_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['v_w'], p['v_b'],
+                                    action, self.nbr_idx, self.n_a, v_out)
+            else:
+                self.step(enc, h, c, done, h_out, c_out, done_is_zero)
+                self.value(h_out, ops.nbr_onehot(action, self.nbr_idx, self.n_a), out=v_out)
+        return v_out
+
     def _fc_infer(self, x, w_key, b_key, act, out=None):
         """act(x @ W + b) with the bias/activation fused in one pass (no autograd); `out` may be a column
         block of a wider buffer, which concatenates partial encodings without a copy."""

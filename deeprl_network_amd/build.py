@@ -5,6 +5,7 @@ repo snapshot (a JIT cache under ~/.cache would not).  hipcc cross-compiles
 without a GPU, so this also is the CPU-side "does it build" check.
 """
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -21,20 +22,39 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
 
-def stale():
+def dependencies():
+    return sources() + sorted(glob.glob(os.path.join(CSRC, '*.h'))) + [os.path.join(os.path.dirname(PKG), 'include', 'nmarl.h')]
+
+
+def source_hash():
+    """sha256 over every file the library is compiled from; baked into the .so (nmarl_source_hash) and compared
+    by _lib at import, so a library older than its sources is refused instead of silently mis-binding."""
+    h = hashlib.sha256()
+    for f in dependencies():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:32]
+
+
+def built_hash():
+    """The hash string baked into the existing library, read from the file (no dlopen)."""
     if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
-        [os.path.join(os.path.dirname(PKG), 'include', 'nmarl.h'), os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+        return None
+    blob = open(LIB, 'rb').read()
+    i = blob.find(b'NMARL_SRC_HASH=')
+    return blob[i + 15:i + 47].decode('ascii', 'replace') if i >= 0 else None
+
+
+def stale():
+    return built_hash() != source_hash()
 
 
 def build_native(force=False, verbose=True):
     if not force and not stale():
         return LIB
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=' + ARCH] + FLAGS + sources() + ['-o', LIB + '.tmp']
+    cmd = [hipcc, '--offload-arch=' + ARCH] + FLAGS + ['-DNMARL_SRC_HASH_STR="NMARL_SRC_HASH=%s"' % source_hash()] + \
+        sources() + ['-o', LIB + '.tmp']
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -135,13 +135,13 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const int64_t rows, const
 }
 
 // pi: [N, E, A] probabilities.  mode 0: inverse-CDF with uniforms u[E,N] (legacy host
-// stream); mode 1: Philox(seed; env_id, agent>>2, step, ACTION); mode 2: argmax.
+// stream); mode 1: Philox(seed; env_id, agent>>2, step, ACTION); mode 2: argmax.  step = step_host + *step_dev.
 __global__ __launch_bounds__(256) void sample_kernel(
     const int64_t E, const int N, const int A, const float* __restrict__ pi, const float* __restrict__ u,
     const int mode, const uint64_t seed, const int64_t env_id_base, const int64_t step_host,
     const int64_t* __restrict__ step_dev, uint8_t* __restrict__ action) {
     const int64_t total = E * N;
-    const int64_t step = step_dev ? *step_dev : step_host;
+    const int64_t step = step_host + (step_dev ? *step_dev : 0);
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t e = idx / N;
         const int n = (int)(idx - e * N);

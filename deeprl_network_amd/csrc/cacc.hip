@@ -369,6 +369,12 @@ bool params_ok(const nmarl_cacc_params_t* p) {
 
 extern "C" int nmarl_abi_version(void) { return 1; }
 
+#ifndef NMARL_SRC_HASH_STR
+#define NMARL_SRC_HASH_STR "NMARL_SRC_HASH=unknown"
+#endif
+// "NMARL_SRC_HASH=<sha256 prefix of csrc/* + include/nmarl.h>", set by deeprl_network_amd/build.py
+extern "C" const char* nmarl_source_hash(void) { return NMARL_SRC_HASH_STR; }
+
 extern "C" int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* action,
                                float* h, float* v, float* u, int32_t* t, uint8_t* collided,
                                float* v0_init, float* obs, float* reward, uint8_t* done,

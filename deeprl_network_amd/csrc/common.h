@@ -33,3 +33,40 @@ __device__ __forceinline__ float u01_from_bits(uint32_t w) {
 #define NMARL_STREAM_RESET 0u
 #define NMARL_STREAM_ACTION 1u
 #define NMARL_STREAM_GRID 2u
+
+// The draw of nmarl_sample_actions (a2c.hip: sample_kernel) on a register-resident probability row of at
+// most MAXA entries: argmax (mode 2) or numpy's choice = searchsorted(cumsum(p)/sum, u, 'right') with the
+// caller's uniform (mode 0) or the Philox word of (env_id, agent, step) (mode 1).
+template <int MAXA>
+__device__ __forceinline__ int nmarl_draw_action(const float (&p)[MAXA], const int A, const int mode, const float u_host,
+                                                 const uint64_t seed, const int64_t env_id, const int n,
+                                                 const int64_t step) {
+    int a = 0;
+    if (mode == 2) {
+        float best = p[0];
+#pragma unroll
+        for (int k = 1; k < MAXA; ++k)
+            if (k < A && p[k] > best) { best = p[k]; a = k; }
+        return a;
+    }
+    float uu = u_host;
+    if (mode == 1) {
+        const Philox4 r = philox4x32_10((uint32_t)env_id, (uint32_t)(n >> 2), (uint32_t)step, NMARL_STREAM_ACTION,
+                                        (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t w = (n & 3) == 0 ? r.x : (n & 3) == 1 ? r.y : (n & 3) == 2 ? r.z : r.w;
+        uu = u01_from_bits(w);
+    }
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k)
+        if (k < A) tot += (double)p[k];
+    double cum = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k)
+        if (k < A) {
+            cum += (double)p[k];
+            if (cum / tot <= (double)uu) a = k + 1;
+        }
+    return a > A - 1 ? A - 1 : a;
+}
+

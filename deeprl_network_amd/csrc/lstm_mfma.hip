@@ -37,7 +37,10 @@ struct FusedArgs {
     int64_t h_sn, wh_sn, bias_sn, zadd1_sn, zadd2_sn, c_prev_sn, gates_sn, c_new_sn, h_new_sn;
     int64_t E;
     int blocks_per_agent;
+    nmarl_head_t hd;               // actor / critic head of the epilogue (kind 0: none)
 };
+
+constexpr int MAXA = 8;            // widest action set the head epilogue keeps in registers
 
 // Epilogue transcendentals: 160 per lane with ONE wave per SIMD, so their latency is fully exposed.
 // sigmoid(x) = rcp(1 + 2^(-x log2 e)) on the hardware exp2 / rcp units (about 1 ulp each, relative error of the
@@ -175,7 +178,75 @@ constexpr int WAVES2 = 8;
 constexpr int WPITCH = 16 * 20;         // floats per k row of the permuted W image
 constexpr int LDS2_FLOATS = H * WPITCH + WAVES2 * R16 * APITCH;
 
-template <bool HAS_Z2>
+// Head epilogue of one wave: its 16 fresh rows of h' sit in the wave's (now idle) LDS tile.  Lane
+// (row = lane & 15, quarter = lane >> 4) accumulates the quarter's 16 k of every output, two xor-shuffles
+// finish the 64-long dots; lanes 0..15 then own one row each: softmax + action draw (kind 1) or the
+// critic's one-hot rows gathered from the neighbours' action bytes (kind 2).
+template <int KIND>
+__device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, const int N, const int64_t row0,
+                                              const int lane, const float* a_tile) {
+    const nmarl_head_t& hd = a.hd;
+    const int A = hd.A;
+    const int nout = KIND == 1 ? A : 1;
+    const float* w = hd.w + (int64_t)n * hd.w_sn;
+    const int rl = lane & 15, q = lane >> 4;
+    float acc[MAXA];
+#pragma unroll
+    for (int o = 0; o < MAXA; ++o) acc[o] = 0.0f;
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = q * 16 + kk;
+        const float hk = a_tile[rl * APITCH + k];
+        if (KIND == 1) {
+#pragma unroll
+            for (int o = 0; o < MAXA; ++o)
+                if (o < nout) acc[o] += hk * w[k * nout + o];
+        } else {
+            acc[0] += hk * w[k];
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < (KIND == 1 ? MAXA : 1); ++o) {
+        acc[o] += __shfl_xor(acc[o], 16, 64);
+        acc[o] += __shfl_xor(acc[o], 32, 64);
+    }
+    const int64_t row = row0 + rl;
+    if (q != 0 || row >= a.E) return;
+    const float* b = hd.b + (int64_t)n * hd.b_sn;
+    if (KIND == 1) {
+        float p[MAXA];
+        float m = -INFINITY;
+#pragma unroll
+        for (int o = 0; o < MAXA; ++o) {
+            p[o] = o < A ? acc[o] + b[o] : -INFINITY;
+            m = fmaxf(m, p[o]);
+        }
+        float ssum = 0.0f;
+#pragma unroll
+        for (int o = 0; o < MAXA; ++o) {
+            p[o] = o < A ? expf(p[o] - m) : 0.0f;
+            ssum += p[o];
+        }
+        float* po = hd.pi_out + (int64_t)n * hd.pi_sn + row * A;
+#pragma unroll
+        for (int o = 0; o < MAXA; ++o) {
+            p[o] = p[o] / ssum;
+            if (o < A) po[o] = p[o];
+        }
+        const int64_t step = hd.step + (hd.step_dev ? *hd.step_dev : 0);
+        const float uh = hd.mode == 0 ? hd.u[row * N + n] : 0.0f;
+        hd.act_out[row * N + n] = (uint8_t)nmarl_draw_action<MAXA>(p, A, hd.mode, uh, hd.seed, hd.env_id_base + row, n, step);
+    } else {
+        float v = acc[0] + b[0];
+        for (int k = 0; k < hd.m_max; ++k) {
+            const int j = hd.nbr_idx[n * hd.m_max + k];
+            if (j >= 0) v += w[H + k * A + (int)hd.act_in[row * N + j]];
+        }
+        hd.v_out[(int64_t)n * hd.v_sn + row] = v;
+    }
+}
+
+template <bool HAS_Z2, int HEAD>
 __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* w_lds = lds;                                   // [64][16][20]
@@ -300,6 +371,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
             const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
             const float cv = gf * (cp[jj][r] * keep) + gi * gu;
             const float hv = go * tanh_fast(cv);
+            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;      // K loop done: the tile is free
             if (ok) {
                 const int j = jj * 16 + c;
                 cn[row * H + j] = cv;
@@ -311,20 +383,36 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
             }
         }
     }
+    if (HEAD != 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        head_epilogue<HEAD>(a, n, (int)(gridDim.x / a.blocks_per_agent), row0, lane, a_tile);
+    }
 }
 
 inline bool stride_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
 
 }  // namespace
 
-extern "C" int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int64_t h_sn,
-                                     const float* wh, int64_t wh_sn, const float* bias, int64_t bias_sn,
-                                     const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
-                                     const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
-                                     int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
-                                     int64_t h_new_sn, void* stream) {
+static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int64_t h_sn, const float* wh,
+                        int64_t wh_sn, const float* bias, int64_t bias_sn, const float* zadd1, int64_t zadd1_sn,
+                        const float* zadd2, int64_t zadd2_sn, const float* c_prev, int64_t c_prev_sn,
+                        const float* done, float* gates, int64_t gates_sn, float* c_new, int64_t c_new_sn,
+                        float* h_new, int64_t h_new_sn, const nmarl_head_t* head, void* stream) {
     if (Hh != H || E < 0 || N <= 0 || (E > 0 && (!h_in || !wh || !bias || !zadd1 || !c_prev || !done || !c_new || !h_new)))
         return NMARL_EINVAL;
+    const int kind = head ? head->kind : 0;
+    if (kind < 0 || kind > 2) return NMARL_EINVAL;
+    if (kind != 0 && E > 0) {
+        if (head->A <= 0 || head->A > MAXA || !head->w || !head->b || head->b_sn < (kind == 1 ? head->A : 1)) return NMARL_EINVAL;
+        if (kind == 1 && (head->w_sn < (int64_t)H * head->A || !head->pi_out || head->pi_sn < E * head->A || !head->act_out ||
+                          head->mode < 0 || head->mode > 2 || (head->mode == 0 && !head->u)))
+            return NMARL_EINVAL;
+        if (kind == 2 && (head->m_max < 0 || head->w_sn < H + (int64_t)head->m_max * head->A || !head->v_out || head->v_sn < E ||
+                          (head->m_max > 0 && (!head->act_in || !head->nbr_idx))))
+            return NMARL_EINVAL;
+    }
     if (E == 0) return NMARL_OK;
     if (!stride_ok(h_sn, E * H) || !stride_ok(wh_sn, H * G4) || !stride_ok(bias_sn, G4) || !stride_ok(zadd1_sn, E * G4) ||
         (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
@@ -337,27 +425,52 @@ extern "C" int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t Hh, const flo
     a.c_prev_sn = c_prev_sn; a.gates_sn = gates_sn; a.c_new_sn = c_new_sn; a.h_new_sn = h_new_sn;
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
+    if (kind != 0) a.hd = *head;
     static int variant = -1;        // NMARL_FUSED_VARIANT=1 selects the one-wave-per-SIMD 32x32x2 kernel (A/B comparisons)
     if (variant < 0) {
         const char* ev = getenv("NMARL_FUSED_VARIANT");
-        variant = (ev && ev[0] == '1') ? 1 : 2;
         const int l1 = (int)((H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float)), l2 = (int)(LDS2_FLOATS * sizeof(float));
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l1) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, l2) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_mfma16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, l2) != hipSuccess)
-            return NMARL_EHIP;
+#define NMARL_SET_LDS(k, bytes) \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return NMARL_EHIP;
+        NMARL_SET_LDS(lstm_step_mfma_kernel<false>, l1) NMARL_SET_LDS(lstm_step_mfma_kernel<true>, l1)
+        NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 0>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 0>), l2)
+        NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 1>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 1>), l2)
+        NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 2>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 2>), l2)
+#undef NMARL_SET_LDS
+        variant = (ev && ev[0] == '1') ? 1 : 2;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.blocks_per_agent * N);
-    if (variant == 1) {
+    if (variant == 1 && kind == 0) {
         const size_t lds_bytes = (size_t)(H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float);
         if (zadd2) hipLaunchKernelGGL(lstm_step_mfma_kernel<true>, grid, dim3(256), lds_bytes, st, a);
         else hipLaunchKernelGGL(lstm_step_mfma_kernel<false>, grid, dim3(256), lds_bytes, st, a);
     } else {
         const size_t lds_bytes = (size_t)LDS2_FLOATS * sizeof(float);
-        if (zadd2) hipLaunchKernelGGL(lstm_step_mfma16_kernel<true>, grid, dim3(512), lds_bytes, st, a);
-        else hipLaunchKernelGGL(lstm_step_mfma16_kernel<false>, grid, dim3(512), lds_bytes, st, a);
+#define NMARL_LAUNCH16(Z2, HD) hipLaunchKernelGGL((lstm_step_mfma16_kernel<Z2, HD>), grid, dim3(512), lds_bytes, st, a)
+        if (zadd2) { if (kind == 0) NMARL_LAUNCH16(true, 0); else if (kind == 1) NMARL_LAUNCH16(true, 1); else NMARL_LAUNCH16(true, 2); }
+        else       { if (kind == 0) NMARL_LAUNCH16(false, 0); else if (kind == 1) NMARL_LAUNCH16(false, 1); else NMARL_LAUNCH16(false, 2); }
+#undef NMARL_LAUNCH16
     }
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int64_t h_sn,
+                                     const float* wh, int64_t wh_sn, const float* bias, int64_t bias_sn,
+                                     const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                                     const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                                     int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
+                                     int64_t h_new_sn, void* stream) {
+    return launch_fused(E, N, Hh, h_in, h_sn, wh, wh_sn, bias, bias_sn, zadd1, zadd1_sn, zadd2, zadd2_sn, c_prev, c_prev_sn,
+                        done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, nullptr, stream);
+}
+
+extern "C" int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t Hh, const float* h_in, int64_t h_sn,
+                                          const float* wh, int64_t wh_sn, const float* bias, int64_t bias_sn,
+                                          const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                                          const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                                          int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
+                                          int64_t h_new_sn, const nmarl_head_t* head, void* stream) {
+    return launch_fused(E, N, Hh, h_in, h_sn, wh, wh_sn, bias, bias_sn, zadd1, zadd1_sn, zadd2, zadd2_sn, c_prev, c_prev_sn,
+                        done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, stream);
 }

@@ -3,6 +3,8 @@ shape checks, output allocation, torch.autograd integration.  Every function
 launches on torch's current HIP stream (so the rollout can be captured in a
 hipGraph) and raises if given CPU tensors -- there is no fallback path.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -150,6 +152,60 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
                                     *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
                                     *_pn(c_out), *_pn(h_out), stream()), 'nmarl_lstm_step_fused')
     return h_out, c_out
+
+
+HEAD_MAX_A = 8      # widest action set the fused head epilogue supports (csrc/lstm_mfma.hip: MAXA)
+
+
+def _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, head, what):
+    N, E, H = h.shape
+    if wh.stride(2) != 1 or wh.stride(1) != 4 * H:
+        raise _lib.NmarlError('%s: wh must be [N,H,4H] with contiguous [H,4H] panels' % what)
+    check(lib.nmarl_lstm_step_fused_head(E, N, H, *_pn(h), ptr(wh, F32, strided=True), wh.stride(0), *_bias(bias),
+                                         *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), None, 0,
+                                         *_pn(c_out), *_pn(h_out), C.byref(head), stream()), what)
+
+
+def _head_param(w, what):
+    """[N,rows,cols] parameter view with contiguous [rows,cols] panels -> (ptr, agent stride)."""
+    if w.stride(2) != 1 or (w.shape[1] > 1 and w.stride(1) != w.shape[2]):
+        raise _lib.NmarlError('%s: head weights need contiguous per-agent panels' % what)
+    return ptr(w, F32, strided=True), w.stride(0)
+
+
+def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode,
+                     u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+    """forward('p') of one lock-step in ONE kernel: the fused step (lstm_step_fused), then in its epilogue
+    pi = softmax(h' @ pi_w + pi_b) -> pi_out [N,E,A] and the action draw of sample_actions -> act_out [E,N]."""
+    N, E, H = h.shape
+    A = pi_w.shape[2]
+    hd = _lib.Head()
+    hd.kind, hd.A, hd.mode = 1, A, mode
+    hd.w, hd.w_sn = _head_param(pi_w, 'lstm_step_policy')
+    hd.b, hd.b_sn = _bias(pi_b)
+    hd.pi_out, hd.pi_sn = _pn(pi_out)
+    hd.act_out, hd.u = ptr(act_out, torch.uint8), ptr(u, F32)
+    hd.seed, hd.env_id_base, hd.step, hd.step_dev = seed, env_id_base, int(step), ptr(step_dev, torch.int64)
+    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[p]')
+    return pi_out, act_out
+
+
+def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, v_b, action, nbr_idx, n_a, v_out):
+    """forward('v') of one lock-step in ONE kernel: the fused step, then v = [h', onehot(neighbour actions)] @ v_w
+    + v_b -> v_out [N,E]; the one-hot rows are gathered from action [E,N] u8 (no one-hot tensor)."""
+    N, E, H = h.shape
+    hd = _lib.Head()
+    hd.kind, hd.A, hd.m_max = 2, n_a, nbr_idx.shape[1]
+    if v_w.shape[1] != H + nbr_idx.shape[1] * n_a or v_w.shape[2] != 1:
+        raise _lib.NmarlError('lstm_step_value: v_w must be [N,H+m_max*A,1]')
+    hd.w, hd.w_sn = _head_param(v_w, 'lstm_step_value')
+    hd.b, hd.b_sn = _bias(v_b)
+    hd.act_in, hd.nbr_idx = ptr(action, torch.uint8), ptr(nbr_idx, torch.int32)
+    if v_out.dim() != 2 or v_out.stride(1) != 1:
+        raise _lib.NmarlError('lstm_step_value: v_out must be [N,E] with unit column stride')
+    hd.v_out, hd.v_sn = ptr(v_out, F32, strided=True), v_out.stride(0)
+    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[v]')
+    return v_out
 
 
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2

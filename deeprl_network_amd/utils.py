@@ -321,17 +321,17 @@ class BatchedTrainer:
         env, model = self.env, self.model
         T = self.n_step
         model.t = 0
+        # Philox step = batch base (device counter, advanced once per batch) + slot offset baked into the graph
         for t in range(T):
             action = model.act(self.done_pre if t == 0 else self.zero_done, mode=ops.SAMPLE_PHILOX, seed=env.seed,
-                               env_id_base=env.env_id_base, step_dev=self.step_dev, done_is_zero=(t > 0))
+                               env_id_base=env.env_id_base, step=t, step_dev=self.step_dev, done_is_zero=(t > 0))
             env.step(action, auto_reset=(t == T - 1), obs_out=model.buf_x[t + 1], reward_out=self.buf_rraw[t],
                      done_out=model.buf_done_post[t], greward_out=self.buf_g[t])
             model.t = t + 1
-            self.step_dev.add_(1)
         # bootstrap value for unfinished replicas (utils.py:192-196); finished ones get R = 0
         v = model.bootstrap(self.zero_done, self.action_boot, mode=ops.SAMPLE_PHILOX, seed=env.seed,
-                            env_id_base=env.env_id_base, step_dev=self.step_dev, done_is_zero=True)
-        self.step_dev.add_(1)
+                            env_id_base=env.env_id_base, step=T, step_dev=self.step_dev, done_is_zero=True)
+        self.step_dev.add_(T + 1)
         self.R_end.copy_(v * (1.0 - self.last_done.to(torch.float32)).view(1, -1))
 
     def rollout(self):

@@ -108,6 +108,23 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
     return h_out, c_out
 
 
+def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode,
+                     u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+    """forward('p') (policies.py:119-123, 50-57) + the action draw (utils.py:135-141) after one LSTM step."""
+    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out)
+    pi_out.copy_(torch.softmax(torch.bmm(h_out, pi_w) + pi_b.unsqueeze(1), dim=-1))
+    sample_actions(pi_out, act_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+    return pi_out, act_out
+
+
+def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, v_b, action, nbr_idx, n_a, v_out):
+    """forward('v') (policies.py:124-133, 59-77): v = [h', one_hot(neighbour actions)] @ w + b."""
+    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out)
+    na = nbr_onehot(action, nbr_idx, n_a)
+    v_out.copy_((torch.bmm(torch.cat([h_out, na], dim=-1), v_w) + v_b.unsqueeze(1)).squeeze(-1))
+    return v_out
+
+
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 
@@ -147,7 +164,7 @@ def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0, step_de
     from oracle import philox
     N, E, A = pi.shape
     if step_dev is not None:
-        step = int(step_dev.item())
+        step = int(step) + int(step_dev.item())       # slot offset + device batch base
     p = pi.detach().cpu().numpy().astype(np.float64).transpose(1, 0, 2)       # [E,N,A]
     if mode == SAMPLE_ARGMAX:
         a = p.argmax(-1)

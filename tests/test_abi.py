@@ -48,6 +48,33 @@ def test_struct_layouts_match_header():
     assert _lib.lib.nmarl_abi_version() == _lib.ABI_VERSION
 
 
+def test_library_is_built_from_the_current_sources():
+    """The hash baked into the .so equals the hash of csrc/* + include/nmarl.h: a stale library (struct layouts
+    or kernels older than the binding) is refused at import, and caught here before any GPU time is spent."""
+    from deeprl_network_amd import _lib, build
+    assert build.built_hash() == build.source_hash()
+    fn = _lib.lib.nmarl_source_hash
+    fn.restype = ctypes.c_char_p
+    assert fn().decode() == 'NMARL_SRC_HASH=' + build.source_hash()
+
+
+def test_head_struct_layout_matches_c_compiler(tmp_path):
+    """nmarl_head_t as gcc lays it out == the ctypes mirror, field by field."""
+    from deeprl_network_amd import _lib
+    fields = [n for n, _ in _lib.Head._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu", sizeof(nmarl_head_t));\n' % HEADER
+    for f in fields:
+        src += 'printf(" %%zu", offsetof(nmarl_head_t, %s));\n' % f
+    src += 'return 0;}\n'
+    c = tmp_path / 'off.c'
+    c.write_text(src)
+    exe = str(tmp_path / 'off')
+    subprocess.check_call(['gcc', str(c), '-o', exe])
+    nums = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
+    assert nums[0] == ctypes.sizeof(_lib.Head)
+    assert nums[1:] == [getattr(_lib.Head, f).offset for f in fields]
+
+
 def test_ops_fail_loudly_without_gpu_tensors():
     import pytest
     import torch

@@ -172,6 +172,92 @@ def test_lstm_step_fused_mfma(N, E, two_addends):
     torch.testing.assert_close(cg.cpu().double(), cr, rtol=2e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (3, 127, 8, 2), (8, 1, 4, 2)])
+@pytest.mark.parametrize('two_addends', [False, True])
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_lstm_step_fused_heads(N, E, A, m_max, two_addends, mode):
+    """The actor / critic epilogues of the fused step (forward 'p' + draw, forward 'v') == step, then
+    softmax(h' W + b) + sample_actions, resp. [h', onehot(nbr actions)] W + b, incl. ragged rows, in-place
+    state, parameters living in a wider flat row, -1 padded neighbour tables and all draw modes."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 1000 + E + 7 * A)
+    h = torch.randn(N, E, H, generator=g) * 0.7
+    c = torch.randn(N, E, H, generator=g)
+    z1 = torch.randn(N, E, 4 * H, generator=g)
+    z2 = torch.randn(N, E, 4 * H, generator=g) if two_addends else None
+    done = (torch.rand(E, generator=g) < 0.3).float()
+    n_na = m_max * A
+    offs, sizes, o = {}, dict(wh=H * 4 * H, b=4 * H, pi_w=H * A, pi_b=A, v_w=H + n_na, v_b=1), 16
+    for k, n in sizes.items():
+        offs[k] = o
+        o += (n + 15) // 16 * 16
+    flat = torch.zeros(N, o + 16)
+    view = lambda f, k, *shape: f[:, offs[k]:offs[k] + sizes[k]].view(N, *shape)      # noqa: E731
+    view(flat, 'wh', H, 4 * H).copy_(torch.randn(N, H, 4 * H, generator=g) * 0.2)
+    view(flat, 'b', 4 * H).copy_(torch.randn(N, 4 * H, generator=g) * 0.1)
+    view(flat, 'pi_w', H, A).copy_(torch.randn(N, H, A, generator=g) * 0.5)
+    view(flat, 'pi_b', A).copy_(torch.randn(N, A, generator=g) * 0.3)
+    view(flat, 'v_w', H + n_na, 1).copy_(torch.randn(N, H + n_na, 1, generator=g))
+    view(flat, 'v_b', 1).copy_(torch.randn(N, 1, generator=g))
+    # ragged neighbour table: agent i has (i % m_max) + 1 neighbours, ascending, -1 padded
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + 1]
+        idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    u = torch.rand(E, N, generator=g)
+    draw = dict(mode=mode, u=u if mode == 0 else None, seed=77, env_id_base=1000, step=5)
+    step_dev = torch.tensor(37, dtype=torch.int64)
+    d64 = lambda t: None if t is None else t.double()                                  # noqa: E731
+    f64 = flat.double()
+    hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
+    pir, actr = torch.empty(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.lstm_step_policy(h.double(), view(f64, 'wh', H, 4 * H), view(f64, 'b', 4 * H), z1.double(), d64(z2), c.double(),
+                             done.double(), cr, hr, view(f64, 'pi_w', H, A), view(f64, 'pi_b', A), pir, actr,
+                             step_dev=step_dev, **draw)
+    fg = flat.cuda()
+    hg, cg = h.cuda(), c.cuda()
+    pig, actg = torch.zeros(N, 2, E, A, device='cuda'), torch.full((E, N), 255, dtype=torch.uint8, device='cuda')
+    dg = dict(draw, u=None if draw['u'] is None else u.cuda())
+    z2g = None if z2 is None else z2.cuda()
+    ops.lstm_step_policy(hg, view(fg, 'wh', H, 4 * H), view(fg, 'b', 4 * H), z1.cuda(), z2g, cg, done.cuda(), cg, hg,
+                         view(fg, 'pi_w', H, A), view(fg, 'pi_b', A), pig[:, 1], actg, step_dev=step_dev.cuda(), **dg)
+    torch.testing.assert_close(hg.cpu().double(), hr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(cg.cpu().double(), cr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(pig[:, 1].cpu().double(), pir, rtol=2e-5, atol=2e-6)
+    assert torch.all(pig[:, 0] == 0)
+    torch.testing.assert_close(pig[:, 1].sum(-1).cpu(), torch.ones(N, E), rtol=0, atol=1e-6)
+    # the draw, bit-exact given the kernel's own probabilities (a cdf boundary within 1 ulp of u may differ from the
+    # float64 softmax' draw, which is the case for ~1e-7 of the samples)
+    act_chk = torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.sample_actions(pig[:, 1].cpu(), act_chk, step_dev=step_dev, **draw)
+    assert torch.equal(actg.cpu(), act_chk)
+    assert (actg.cpu() != actr).float().mean() < 1e-3
+    # critic re-step from the new state (quirk Q1), out of place
+    vr = torch.empty(N, E, dtype=torch.float64)
+    h2r, c2r = torch.empty_like(hr), torch.empty_like(cr)
+    ops_ref.lstm_step_value(hr, view(f64, 'wh', H, 4 * H), view(f64, 'b', 4 * H), z1.double(), d64(z2), cr, done.double(),
+                            c2r, h2r, view(f64, 'v_w', H + n_na, 1), view(f64, 'v_b', 1), act_chk, idx, A, vr)
+    vbuf = torch.zeros(3, N, E, device='cuda')
+    h2, c2 = torch.zeros_like(hg), torch.zeros_like(cg)
+    ops.lstm_step_value(hg, view(fg, 'wh', H, 4 * H), view(fg, 'b', 4 * H), z1.cuda(), z2g, cg, done.cuda(), c2, h2,
+                        view(fg, 'v_w', H + n_na, 1), view(fg, 'v_b', 1), actg, idx.cuda(), A, vbuf[1])
+    torch.testing.assert_close(h2.cpu().double(), h2r, rtol=5e-5, atol=5e-6)
+    torch.testing.assert_close(vbuf[1].cpu().double(), vr, rtol=1e-4, atol=2e-5)
+    assert torch.all(vbuf[0] == 0) and torch.all(vbuf[2] == 0)
+
+
+def test_lstm_step_fused_head_rejects_wide_action_sets():
+    from deeprl_network_amd import _lib, ops
+    N, E, H, A = 2, 4, 64, 9
+    z = lambda *s: torch.zeros(*s, device='cuda')                                       # noqa: E731
+    with pytest.raises(_lib.NmarlError):
+        ops.lstm_step_policy(z(N, E, H), z(N, H, 4 * H), z(N, 4 * H), z(N, E, 4 * H), None, z(N, E, H), z(E), z(N, E, H),
+                             z(N, E, H), z(N, H, A), z(N, A), z(N, E, A), torch.zeros(E, N, dtype=torch.uint8, device='cuda'),
+                             mode=2)
+
+
 def test_sample_actions_modes():
     from deeprl_network_amd import ops
     from oracle import ops_ref

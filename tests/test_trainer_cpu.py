@@ -42,6 +42,27 @@ def test_batched_trainer_runs_and_learns_something(agent):
         assert int(tr.step_dev.item()) == 7 * 11   # n_step draws + 1 bootstrap draw per batch
 
 
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ma2c_dial'])
+def test_fused_heads_branch_equals_composed_branch(agent, monkeypatch):
+    """BatchedPolicy.step_policy / step_value: the one-kernel branch (H = 64, A <= 8) and the composed branch
+    (step + pi + sample_actions; step + nbr_onehot + value) are the same computation."""
+    from deeprl_network_amd.agents.policies import BatchedPolicy
+    with cpu_ops():
+        _, m_fused, t_fused = build(agent, E=3)
+        assert m_fused.policy.fused_heads
+        for _ in range(2):
+            t_fused.run_batch()
+        monkeypatch.setattr(BatchedPolicy, 'fused_heads', property(lambda self: False))
+        _, m_comp, t_comp = build(agent, E=3)
+        assert not m_comp.policy.fused_heads
+        for _ in range(2):
+            t_comp.run_batch()
+        assert torch.equal(m_fused.buf_act, m_comp.buf_act)
+        torch.testing.assert_close(m_fused.buf_v, m_comp.buf_v, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m_fused.buf_fp, m_comp.buf_fp, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m_fused.policy.params.flat, m_comp.policy.params.flat, rtol=1e-4, atol=1e-6)
+
+
 def test_batch_invariance_of_rollout():
     """Replica e of an E-replica rollout == the same replica rolled out alone (same Philox ids)."""
     with cpu_ops():

@@ -78,6 +78,9 @@ SIGNATURES = {
                               _i64, _p, _i64, _p],
     'nmarl_lstm_step_fused_head': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64,
                                    _p, _i64, _p, _i64, C.POINTER(Head), _p],
+    'nmarl_fc_fwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
+    'nmarl_fc_bwd_chunks': [_i64, _i32],
+    'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_bias_act': [_i64, _i32, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],

@@ -240,7 +240,10 @@ class BatchedPolicy:
     def _fc_infer(self, x, w_key, b_key, act, out=None):
         """act(x @ W + b) with the bias/activation fused in one pass (no autograd); `out` may be a column
         block of a wider buffer, which concatenates partial encodings without a copy."""
-        return ops.bias_act_(torch.bmm(x, self.params[w_key]), self.params[b_key], act, out=out)
+        w, b = self.params[w_key], self.params[b_key]
+        if ops.fc_supported(x, w):
+            return ops.fc_fwd(x, w, b, act, out=out)          # small-K layer: one streaming kernel (csrc/fc.hip)
+        return ops.bias_act_(torch.bmm(x, w), b, act, out=out)
 
     def _recur_addends(self, enc, h):
         """(zadd1, zadd2): everything of the LSTM pre-activation except (h*(1-done)) @ Wh and the bias."""
@@ -299,7 +302,7 @@ class LstmPolicy(BatchedPolicy):
     def _enc(self, xv, fp):
         """x-side LSTM pre-activation [N,rows,4H] (bias is added in the cell kernel)."""
         p = self.params
-        return torch.bmm(torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), xv, p['fc_w'])), p['lstm_wx'])
+        return torch.bmm(ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         return torch.bmm(self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
@@ -325,11 +328,9 @@ class FPPolicy(LstmPolicy):
         p = self.params
         nf = self.n_fc
         pf = ops.nbr_gather(fp, self.nbr_idx)
-        hx = torch.relu(torch.baddbmm(p['fcs_b'].unsqueeze(1), xv, p['fcs_w']))
-        hp = torch.relu(torch.baddbmm(p['fcp_b'].unsqueeze(1), pf, p['fcp_w']))
-        # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM (the concat copy is cheaper than a second pass over
-        # the [rows, 4H] output and two dgrad / wgrad GEMMs in the backward)
-        return torch.bmm(torch.cat([hx, hp], dim=-1), p['lstm_wx'])
+        # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place
+        s = ops.fc_concat([(xv, p['fcs_w'], p['fcs_b']), (pf, p['fcp_w'], p['fcp_b'])], ops.BIAS_RELU)
+        return torch.bmm(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         p = self.params
@@ -367,9 +368,8 @@ class NCMultiAgentPolicy(BatchedPolicy):
         p = self.params
         H = self.n_h
         pf = ops.nbr_gather(fp, self.nbr_idx)
-        hx = torch.relu(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob']))
-        hp = torch.relu(torch.baddbmm(p['w_fp_b'].unsqueeze(1), pf, p['w_fp']))
-        return torch.bmm(torch.cat([hx, hp], dim=-1), p['wx_hid'][:, :2 * H])
+        s = ops.fc_concat([(xv, p['w_ob'], p['w_ob_b']), (pf, p['w_fp'], p['w_fp_b'])], ops.BIAS_RELU)
+        return torch.bmm(s, p['wx_hid'][:, :2 * H])
 
     def _recur_in(self, enc, h):
         p = self.params
@@ -419,7 +419,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return torch.tanh(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob']))
+        return ops.fc_concat([(xv, p['w_ob'], p['w_ob_b'])], ops.BIAS_TANH)
 
     def _recur_in(self, enc, h):
         p = self.params
@@ -458,7 +458,7 @@ class ConsensusPolicy(LstmPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return torch.bmm(torch.relu(torch.baddbmm(p['fc_b'].unsqueeze(1), self._own(xv), p['fc_w'])), p['lstm_wx'])
+        return torch.bmm(ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         return torch.bmm(self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
@@ -509,7 +509,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return torch.relu(torch.baddbmm(p['w_ob_b'].unsqueeze(1), xv, p['w_ob'])) + self._own_action_onehot(fp)
+        return ops.fc_concat([(xv, p['w_ob'], p['w_ob_b'])], ops.BIAS_RELU) + self._own_action_onehot(fp)
 
     def _recur_in(self, enc, h):
         p = self.params

@@ -1,0 +1,207 @@
+// Per-agent fully connected encoder layers with a SMALL input width (F <= 64) and 64 outputs:
+//
+//     y[n, r, :] = act(x[n, r, :F] @ w[n] + b[n])            fc of agents/utils.py:65-73
+//
+// i.e. `fc(ob, 'fcs' / 'fcp' / 'fc', n_fc, relu)` of LstmPolicy / FPPolicy (policies.py:145, 177-180) and the
+// w_ob / w_fp encoders of lstm_comm / lstm_ic3 / lstm_dial (agents/utils.py:186-198, 395-400, 566-575) on the
+// observation slab (F = 15 CACC, 60 grid) and the gathered neighbour fingerprints (F = 8 / 20), for all
+// agents and rows (rows = E in the rollout, T*E in the update) in one launch.
+//
+// K = F is far too small for the matrix cores to matter (the GEMM library picks 16x16 tiles and runs the
+// wgrad x^T dy at a few % of anything), and the layer is HBM-bound on its 64-wide output anyway: these
+// kernels stream y (and dy) once at full width and keep everything else on chip.
+//   fwd: thread = (output column j, row lane); w[:, j] lives in registers, a 64-row tile of x is staged in LDS and
+//        read back as wave-wide broadcasts (float4); bias + activation fused; y may be a column block of a
+//        wider buffer (row pitch y_row), which is how tf.concat([hx, hp]) (policies.py:181) costs no copy.
+//   bwd: same mapping; g = dy * act'(y) is formed in registers (never stored), dW[f, j] += x[r, f] * g and
+//        db[j] += g accumulate in registers over the block's rows; blocks write partial sums that a second
+//        kernel adds in a fixed order (deterministic: no atomics).  dx is not produced: x is data.
+// HBM bytes per row: fwd 4 (F + 64), bwd 4 (F + 128).
+#include "common.h"
+
+namespace {
+
+constexpr int J = 64;            // outputs per layer (n_fc / n_h of every shipped config)
+constexpr int TILE = 64;         // rows staged per LDS tile
+
+__device__ __forceinline__ float act_fwd(const float v, const int act) {
+    return act == 1 ? fmaxf(v, 0.0f) : act == 2 ? tanhf(v) : v;
+}
+
+// d act / d pre-activation expressed through the OUTPUT y (relu: y > 0; tanh: 1 - y^2)
+__device__ __forceinline__ float act_bwd(const float g, const float y, const int act) {
+    return act == 1 ? (y > 0.0f ? g : 0.0f) : act == 2 ? g * (1.0f - y * y) : g;
+}
+
+template <int FMAX>
+__device__ __forceinline__ void stage_tile(float* xs, const float* __restrict__ xn, const int64_t x_row, const int64_t row0,
+                                           const int64_t rows, const int F) {
+    constexpr int FP = FMAX + 4;
+    for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
+        const int r = idx / FMAX, f = idx - r * FMAX;
+        const int64_t row = row0 + r;
+        xs[r * FP + f] = (f < F && row < rows) ? xn[row * x_row + f] : 0.0f;
+    }
+}
+
+template <int FMAX>
+__global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const int F, const int tiles_per_block,
+                                                     const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
+                                                     const float* __restrict__ w, const int64_t w_sn,
+                                                     const float* __restrict__ b, const int64_t b_sn, const int act,
+                                                     float* __restrict__ y, const int64_t y_sn, const int64_t y_row) {
+    constexpr int FP = FMAX + 4;
+    __shared__ __attribute__((aligned(16))) float xs[TILE * FP];
+    const int n = blockIdx.y, j = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    float wr[FMAX];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f) wr[f] = f < F ? w[(int64_t)n * w_sn + f * J + j] : 0.0f;
+    const float bj = b[(int64_t)n * b_sn + j];
+    const float* xn = x + (int64_t)n * x_sn;
+    float* yn = y + (int64_t)n * y_sn;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+        stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = rl; rr < TILE; rr += 4) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int f4 = 0; f4 < FMAX / 4; ++f4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + rr * FP + 4 * f4);
+                acc = fmaf(xv.x, wr[4 * f4 + 0], acc);
+                acc = fmaf(xv.y, wr[4 * f4 + 1], acc);
+                acc = fmaf(xv.z, wr[4 * f4 + 2], acc);
+                acc = fmaf(xv.w, wr[4 * f4 + 3], acc);
+            }
+            const int64_t row = row0 + rr;
+            if (row < rows) yn[row * y_row + j] = act_fwd(acc + bj, act);
+        }
+        __syncthreads();
+    }
+}
+
+// partial: [N, gridDim.x, F + 1, 64] (rows 0..F-1: dW, row F: db)
+template <int FMAX>
+__global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const int F, const int tiles_per_block,
+                                                     const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
+                                                     const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
+                                                     const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
+                                                     const int act, float* __restrict__ partial) {
+    constexpr int FP = FMAX + 4;
+    __shared__ __attribute__((aligned(16))) float xs[TILE * FP];        // later reused as the [FMAX + 1, 64] reduction pad
+    const int n = blockIdx.y, j = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    float acc[FMAX];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f) acc[f] = 0.0f;
+    float db = 0.0f;
+    const float* xn = x + (int64_t)n * x_sn;
+    const float* yn = y + (int64_t)n * y_sn;
+    const float* dyn = dy + (int64_t)n * dy_sn;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+        stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = rl; rr < TILE; rr += 4) {
+            const int64_t row = row0 + rr;
+            float g = 0.0f;
+            if (row < rows) g = act_bwd(dyn[row * dy_row + j], yn[row * y_row + j], act);
+            db += g;
+#pragma unroll
+            for (int f4 = 0; f4 < FMAX / 4; ++f4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + rr * FP + 4 * f4);
+                acc[4 * f4 + 0] = fmaf(xv.x, g, acc[4 * f4 + 0]);
+                acc[4 * f4 + 1] = fmaf(xv.y, g, acc[4 * f4 + 1]);
+                acc[4 * f4 + 2] = fmaf(xv.z, g, acc[4 * f4 + 2]);
+                acc[4 * f4 + 3] = fmaf(xv.w, g, acc[4 * f4 + 3]);
+            }
+        }
+        __syncthreads();
+    }
+    // the four row lanes add up in a fixed order through LDS
+    float* red = xs;
+    for (int k = 0; k < 4; ++k) {
+        if (rl == k) {
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f)
+                if (f < F) red[f * J + j] = (k == 0 ? 0.0f : red[f * J + j]) + acc[f];
+            red[FMAX * J + j] = (k == 0 ? 0.0f : red[FMAX * J + j]) + db;
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)(F + 1) * J;
+    for (int idx = threadIdx.x; idx < (F + 1) * J; idx += 256) {
+        const int f = idx >> 6;
+        out[idx] = red[(f < F ? f : FMAX) * J + (idx & 63)];
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const int C, const int F, const float* __restrict__ partial,
+                                                            float* __restrict__ dw, const int64_t dw_sn,
+                                                            float* __restrict__ db, const int64_t db_sn) {
+    const int n = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = (F + 1) * J;
+    if (idx >= per) return;
+    const float* p = partial + (int64_t)n * C * per + idx;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += p[(int64_t)c * per];
+    if (idx < F * J) dw[(int64_t)n * dw_sn + idx] = s;
+    else db[(int64_t)n * db_sn + idx - F * J] = s;
+}
+
+inline bool view_ok(const void* p, int64_t sn, int64_t row, int64_t rows, int W) {
+    return p != nullptr && row >= W && sn >= (rows > 0 ? (rows - 1) * row + W : 0);
+}
+
+}  // namespace
+
+extern "C" int nmarl_fc_bwd_chunks(int64_t rows, int32_t N) {
+    if (rows <= 0 || N <= 0) return 0;
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    int64_t tpb = tiles * N / 1024;                 // about 1024 blocks; at most 32 tiles (2048 rows) per block
+    tpb = tpb < 1 ? 1 : (tpb > 32 ? 32 : tpb);
+    return (int)((tiles + tpb - 1) / tpb);
+}
+
+extern "C" int nmarl_fc_fwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const float* x, int64_t x_sn, int64_t x_row,
+                            const float* w, int64_t w_sn, const float* b, int64_t b_sn, int32_t act, float* y,
+                            int64_t y_sn, int64_t y_row, void* stream) {
+    if (rows < 0 || N <= 0 || F <= 0 || F > 64 || Jw != J || act < 0 || act > 2 || w_sn < (int64_t)F * J || b_sn < J)
+        return NMARL_EINVAL;
+    if (rows == 0) return NMARL_OK;
+    if (!view_ok(x, x_sn, x_row, 1, F) || !view_ok(y, y_sn, y_row, rows, J) || !w || !b) return NMARL_EINVAL;
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    int64_t tpb = tiles * N / 2048;
+    tpb = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
+    const dim3 grid((unsigned)((tiles + tpb - 1) / tpb), N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NMARL_FC_FWD(FM) hipLaunchKernelGGL(fc_fwd_kernel<FM>, grid, dim3(256), 0, st, rows, F, (int)tpb, x, x_sn, x_row, w, w_sn, \
+                                            b, b_sn, act, y, y_sn, y_row)
+    if (F <= 16) NMARL_FC_FWD(16); else if (F <= 32) NMARL_FC_FWD(32); else NMARL_FC_FWD(64);
+#undef NMARL_FC_FWD
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const float* x, int64_t x_sn, int64_t x_row,
+                            const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
+                            int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream) {
+    if (rows <= 0 || N <= 0 || F <= 0 || F > 64 || Jw != J || act < 0 || act > 2 || dw_sn < (int64_t)F * J || db_sn < J ||
+        !partial || !dw || !db)
+        return NMARL_EINVAL;
+    if (!view_ok(x, x_sn, x_row, 1, F) || !view_ok(y, y_sn, y_row, rows, J) || !view_ok(dy, dy_sn, dy_row, rows, J)) return NMARL_EINVAL;
+    const int C = nmarl_fc_bwd_chunks(rows, N);
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    const int tpb = (int)((tiles + C - 1) / C);
+    const dim3 grid(C, N);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NMARL_FC_BWD(FM) hipLaunchKernelGGL(fc_bwd_kernel<FM>, grid, dim3(256), 0, st, rows, F, tpb, x, x_sn, x_row, y, y_sn, y_row, \
+                                            dy, dy_sn, dy_row, act, partial)
+    if (F <= 16) NMARL_FC_BWD(16); else if (F <= 32) NMARL_FC_BWD(32); else NMARL_FC_BWD(64);
+#undef NMARL_FC_BWD
+    hipLaunchKernelGGL(fc_bwd_reduce_kernel, dim3(((F + 1) * J + 255) / 256, N), dim3(256), 0, st, C, F, partial, dw, dw_sn, db, db_sn);
+    return nmarl_check_launch();
+}

@@ -227,6 +227,86 @@ def bias_act_(x, bias, act, out=None):
     return x if out is None else out
 
 
+FC_MAX_F, FC_J = 64, 64          # csrc/fc.hip: input widths up to 64, exactly 64 outputs
+
+
+def _rows_view(t, W, what):
+    """[N,rows,W] view with unit column stride (any agent stride / row pitch) -> (ptr, agent stride, row pitch)."""
+    if t.dim() != 3 or t.shape[2] != W or t.stride(2) != 1:
+        raise _lib.NmarlError('%s: expected [N,rows,%d] with unit column stride, got %s / %s' % (what, W, tuple(t.shape), t.stride()))
+    return ptr(t, F32, strided=True), t.stride(0), t.stride(1)
+
+
+def fc_supported(x, w):
+    return x.shape[2] <= FC_MAX_F and w.shape[2] == FC_J
+
+
+def fc_fwd(x, w, b, act, out=None):
+    """act(x @ w + b) for x [N,rows,F<=64] (strided views allowed, e.g. the env-major slab transposed), w [N,F,64],
+    b [N,64] -> out [N,rows,64] (may be a column block of a wider buffer).  No autograd."""
+    N, rows, F = x.shape
+    if out is None:
+        out = torch.empty(N, rows, FC_J, dtype=F32, device=x.device)
+    xp, xs, xr = _rows_view(x, F, 'fc_fwd x')
+    yp, ys, yr = _rows_view(out, FC_J, 'fc_fwd out')
+    wp, ws = _head_param(w, 'fc_fwd')
+    check(lib.nmarl_fc_fwd(rows, N, F, w.shape[2], xp, xs, xr, wp, ws, *_bias(b), act, yp, ys, yr, stream()), 'nmarl_fc_fwd')
+    return out
+
+
+def fc_bwd(x, y, dy, act):
+    """(dw [N,F,64], db [N,64]) of y = act(x @ w + b) given the layer OUTPUT y and dL/dy (column-block views allowed)."""
+    N, rows, F = x.shape
+    xp, xs, xr = _rows_view(x, F, 'fc_bwd x')
+    yp, ys, yr = _rows_view(y, FC_J, 'fc_bwd y')
+    gp, gs, gr = _rows_view(dy, FC_J, 'fc_bwd dy')
+    C_ = lib.nmarl_fc_bwd_chunks(rows, N)
+    partial = torch.empty(N, C_, F + 1, FC_J, dtype=F32, device=x.device)
+    dw = torch.empty(N, F, FC_J, dtype=F32, device=x.device)
+    db = torch.empty(N, FC_J, dtype=F32, device=x.device)
+    check(lib.nmarl_fc_bwd(rows, N, F, FC_J, xp, xs, xr, yp, ys, yr, gp, gs, gr, act, ptr(partial), ptr(dw), F * FC_J,
+                           ptr(db), FC_J, stream()), 'nmarl_fc_bwd')
+    return dw, db
+
+
+class _FcConcat(torch.autograd.Function):
+    """S = [act(x_1 w_1 + b_1) | act(x_2 w_2 + b_2) | ...]  (tf.concat of per-input fc layers, policies.py:176-181,
+    agents/utils.py:186-199) for DATA inputs x_i (no dx): each block is written in place into S, and the backward
+    streams S and dS once per block (fc_bwd) instead of relu-mask + skinny wgrad GEMM + bias reduction."""
+
+    @staticmethod
+    def forward(ctx, act, *args):
+        xs, ws, bs = args[0::3], args[1::3], args[2::3]
+        N, rows = xs[0].shape[:2]
+        S = torch.empty(N, rows, FC_J * len(xs), dtype=F32, device=xs[0].device)
+        for i, (x, w, b) in enumerate(zip(xs, ws, bs)):
+            fc_fwd(x, w, b, act, out=S[:, :, i * FC_J:(i + 1) * FC_J])
+        ctx.act = act
+        ctx.save_for_backward(S, *xs)
+        return S
+
+    @staticmethod
+    def backward(ctx, dS):
+        S, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        if dS.stride(2) != 1:
+            dS = dS.contiguous()
+        grads = [None]
+        for i, x in enumerate(xs):
+            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act)
+            grads += [None, dw, db]
+        return tuple(grads)
+
+
+def fc_concat(parts, act):
+    """parts: [(x_i [N,rows,F_i], w_i [N,F_i,64], b_i [N,64]), ...] with data inputs -> [N,rows,64*len(parts)]
+    (differentiable w.r.t. w_i, b_i).  Inputs wider than 64 or layers not 64 wide: plain batched GEMMs."""
+    if all(fc_supported(x, w) and not x.requires_grad for x, w, _ in parts):
+        return _FcConcat.apply(act, *[t for part in parts for t in part])
+    f = {BIAS_NONE: lambda t: t, BIAS_RELU: torch.relu, BIAS_TANH: torch.tanh}[act]
+    ys = [f(torch.baddbmm(b.unsqueeze(1), x, w)) for x, w, b in parts]
+    return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
+
+
 def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
     N, E, H4 = gates.shape
     check(lib.nmarl_lstm_cell_bwd(E, N, H4 // 4, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh),

@@ -274,6 +274,23 @@ int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t H, const float* h_i
 int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x_sn, const float* bias,
                    int64_t bias_sn, int32_t act, float* y, int64_t y_sn, int64_t y_row, void* stream);
 /*
+ * Small-input fully connected encoder layer for all agents and rows in one launch (fc, agents/utils.py:65-73;
+ * call sites policies.py:145, 177-180 and agents/utils.py:186-198, 395-400, 566-575):
+ *   fwd:  y[n,r,:64] = act(x[n,r,:F] @ w[n] + b[n]),  F <= 64, J = 64 outputs, act as in nmarl_bias_act.
+ *   bwd:  g = dy * act'(y);  dw[n] = x[n]^T g  [F,64],  db[n] = sum_r g  [64]   (x is data: no dx).
+ * x [N,rows,F] with agent stride x_sn and row pitch x_row (so the env-major observation slab [rows,N,F] is read in
+ * place: x_sn = F, x_row = N*F); y / dy [N,rows,64] with row pitch >= 64 (a column block of the concatenated
+ * encoding, tf.concat of policies.py:181); w [N,F,64], b [N,64] with agent strides.  bwd is deterministic: blocks
+ * write partial sums into `partial` [N, nmarl_fc_bwd_chunks(rows,N), F+1, 64] and a second kernel adds them in order.
+ */
+int nmarl_fc_fwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, int64_t x_sn, int64_t x_row,
+                 const float* w, int64_t w_sn, const float* b, int64_t b_sn, int32_t act, float* y,
+                 int64_t y_sn, int64_t y_row, void* stream);
+int nmarl_fc_bwd_chunks(int64_t rows, int32_t N);
+int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, int64_t x_sn, int64_t x_row,
+                 const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
+                 int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
+/*
  * Action draw of Trainer._get_policy (utils.py:135-141) for all (replica, agent):
  * pi [N,E,A] -> action [E,N] u8.
  *   mode 0: np.random.choice == searchsorted(cumsum(pi)/sum, u, 'right') with the

@@ -128,6 +128,38 @@ def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, 
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 
+FC_MAX_F, FC_J = 64, 64
+
+
+def _act(t, act):
+    return torch.relu(t) if act == BIAS_RELU else torch.tanh(t) if act == BIAS_TANH else t
+
+
+def fc_supported(x, w):
+    return x.shape[2] <= FC_MAX_F and w.shape[2] == FC_J
+
+
+def fc_fwd(x, w, b, act, out=None):
+    """fc (agents/utils.py:65-73): act(x @ w + b) per agent."""
+    y = _act(torch.bmm(x, w) + b.unsqueeze(1), act)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
+def fc_bwd(x, y, dy, act):
+    """Gradient of fc w.r.t. (w, b), the activation derivative taken from the layer output y."""
+    g = dy * (y > 0).to(dy.dtype) if act == BIAS_RELU else dy * (1.0 - y * y) if act == BIAS_TANH else dy
+    return torch.bmm(x.transpose(1, 2), g), g.sum(1)
+
+
+def fc_concat(parts, act):
+    """tf.concat of per-input fc layers (policies.py:176-181, agents/utils.py:186-199), plain autograd."""
+    ys = [_act(torch.baddbmm(b.unsqueeze(1), x, w), act) for x, w, b in parts]
+    return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
+
+
 def bias_act_(x, bias, act, out=None):
     """fc's bias + activation (agents/utils.py:65-73), in place or into `out`."""
     y = x + bias.unsqueeze(1)

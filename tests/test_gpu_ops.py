@@ -258,6 +258,67 @@ def test_lstm_step_fused_head_rejects_wide_action_sets():
                              mode=2)
 
 
+@pytest.mark.parametrize('N,rows,F', [(8, 4096, 15), (8, 4103, 8), (25, 130, 60), (25, 1, 20), (3, 257, 64), (8, 70000, 15)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_fc_small_layer_fwd_bwd(N, rows, F, act):
+    """csrc/fc.hip: act(x w + b) and its (dw, db) for small input widths == the float64 restatement, with x read in
+    place from the env-major slab (transposed view), y / dy as column blocks of a wider buffer, parameters as
+    views of a flat row, ragged row counts and multi-chunk partial sums."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N * 31 + rows + F)
+    slab = torch.randn(rows, N, F, generator=g)
+    x = slab.transpose(0, 1)                                   # [N,rows,F], strides (F, N*F, 1)
+    flat = torch.zeros(N, 16 + F * 64 + 16 + 64 + 16)
+    w = flat[:, 16:16 + F * 64].view(N, F, 64)
+    b = flat[:, 32 + F * 64:32 + F * 64 + 64]
+    w.copy_(torch.randn(N, F, 64, generator=g) * 0.4)
+    b.copy_(torch.randn(N, 64, generator=g) * 0.2)
+    yr = ops_ref.fc_fwd(x.double(), w.double(), b.double(), act)
+    fg, sg = flat.cuda(), slab.cuda()
+    xg = sg.transpose(0, 1)
+    wg, bg = fg[:, 16:16 + F * 64].view(N, F, 64), fg[:, 32 + F * 64:32 + F * 64 + 64]
+    S = torch.zeros(N, rows, 192, device='cuda')
+    ops.fc_fwd(xg, wg, bg, act, out=S[:, :, 64:128])
+    torch.testing.assert_close(S[:, :, 64:128].cpu().double(), yr, rtol=1e-5, atol=1e-5)
+    assert torch.all(S[:, :, :64] == 0) and torch.all(S[:, :, 128:] == 0)
+    torch.testing.assert_close(ops.fc_fwd(xg, wg, bg, act).cpu().double(), yr, rtol=1e-5, atol=1e-5)
+    dS = torch.randn(N, rows, 192, generator=g)
+    dwr, dbr = ops_ref.fc_bwd(x.double(), yr, dS[:, :, 64:128].double(), act)
+    dw, db = ops.fc_bwd(xg, S[:, :, 64:128], dS.cuda()[:, :, 64:128], act)
+    scale = float(rows) ** 0.5
+    torch.testing.assert_close(dw.cpu().double(), dwr, rtol=1e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(db.cpu().double(), dbr, rtol=1e-4, atol=2e-5 * scale)
+    # determinism: fixed-order partial sums
+    dw2, db2 = ops.fc_bwd(xg, S[:, :, 64:128], dS.cuda()[:, :, 64:128], act)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_fc_concat_autograd_matches_torch():
+    from deeprl_network_amd import ops
+    N, rows = 8, 1000
+    g = torch.Generator().manual_seed(5)
+    x1, x2 = torch.randn(N, rows, 15, generator=g).cuda(), torch.randn(N, rows, 8, generator=g).cuda()
+    ps = [(torch.randn(N, F, 64, generator=g) * 0.3).cuda().requires_grad_() for F in (15, 8)]
+    bs = [(torch.randn(N, 64, generator=g) * 0.1).cuda().requires_grad_() for _ in range(2)]
+    wx = (torch.randn(N, 128, 32, generator=g) * 0.1).cuda()
+    R = torch.randn(N, rows, 32, generator=g).cuda()
+    s = ops.fc_concat([(x1, ps[0], bs[0]), (x2, ps[1], bs[1])], ops.BIAS_RELU)
+    (torch.bmm(s, wx) * R).sum().backward()
+    got = [t.grad.clone() for t in ps + bs]
+    for t in ps + bs:
+        t.grad = None
+    ref = torch.cat([torch.relu(torch.baddbmm(bs[i].unsqueeze(1), x, ps[i])) for i, x in enumerate((x1, x2))], dim=-1)
+    torch.testing.assert_close(s, ref, rtol=1e-5, atol=1e-5)
+    (torch.bmm(ref, wx) * R).sum().backward()
+    for a, t in zip(got, ps + bs):
+        torch.testing.assert_close(a, t.grad, rtol=1e-4, atol=1e-4)
+    # inputs wider than 64: the plain GEMM path, same result
+    xw = torch.randn(N, rows, 128, generator=g).cuda()
+    ww, bw = (torch.randn(N, 128, 64, generator=g) * 0.1).cuda(), torch.zeros(N, 64).cuda()
+    torch.testing.assert_close(ops.fc_concat([(xw, ww, bw)], ops.BIAS_TANH), torch.tanh(torch.bmm(xw, ww)), rtol=1e-5, atol=1e-5)
+
+
 def test_sample_actions_modes():
     from deeprl_network_amd import ops
     from oracle import ops_ref

@@ -163,7 +163,7 @@ class BatchedPolicy:
         H, A = self.n_h, self.n_a
         w = torch.cat([p['pi_w'], p['v_w'][:, :H]], dim=2)
         b = torch.cat([p['pi_b'], p['v_b']], dim=1)
-        out = torch.baddbmm(b.unsqueeze(1), h, w)
+        out = ops.thin_linear(h, w, b)
         v = out[..., A] + torch.bmm(na_onehot, p['v_w'][:, H:]).squeeze(-1)
         return torch.softmax(out[..., :A], dim=-1), v
 

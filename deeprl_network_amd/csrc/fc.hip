@@ -153,6 +153,90 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const int C, const i
     else db[(int64_t)n * db_sn + idx - F * J] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of a THIN linear layer y[n,r,:O] = h[n,r,:64] @ w[n] + b[n] with O <= 8 outputs: the actor / critic
+// heads (policies.py:50-77: fc(h, 'pi', n_a) and fc([h, na], 'v', 1)) over all T*E rows of the update.
+// The GEMM library runs the dgrad (K = O) and the wgrad (64 x O, K = rows) at ~1 ms each; both are one
+// streaming pass over h and dy here: thread = (hidden unit k, row lane) keeps w[k, :] and the dW[k, :] / db
+// accumulators in registers, reads h[r, k] and writes dh[r, k] coalesced, and gets dy[r, :] as an LDS broadcast.
+// partial: [N, gridDim.x, 65, O] (rows 0..63 dW, row 64 db), summed in fixed order by thin_bwd_reduce_kernel.
+constexpr int MAXO = 8;
+
+__global__ __launch_bounds__(256) void thin_bwd_kernel(const int64_t rows, const int O, const int tiles_per_block,
+                                                       const float* __restrict__ h, const int64_t h_sn,
+                                                       const float* __restrict__ dy, const int64_t dy_sn,
+                                                       const float* __restrict__ w, const int64_t w_sn,
+                                                       float* __restrict__ dh, const int64_t dh_sn,
+                                                       float* __restrict__ partial) {
+    __shared__ float ds[TILE * MAXO];
+    __shared__ float red[65 * MAXO];
+    const int n = blockIdx.y, k = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    float wk[MAXO], acc[MAXO], dbacc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        wk[o] = o < O ? w[(int64_t)n * w_sn + k * O + o] : 0.0f;
+        acc[o] = 0.0f;
+        dbacc[o] = 0.0f;
+    }
+    const float* hn = h + (int64_t)n * h_sn;
+    const float* dyn = dy + (int64_t)n * dy_sn;
+    float* dhn = dh + (int64_t)n * dh_sn;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+        for (int idx = threadIdx.x; idx < TILE * O; idx += 256) {          // the tile's dy rows are contiguous
+            const int64_t g = row0 * O + idx;
+            ds[idx] = g < rows * O ? dyn[g] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = rl; rr < TILE; rr += 4) {
+            const int64_t row = row0 + rr;
+            if (row < rows) {
+                const float hv = hn[row * J + k];
+                float g = 0.0f;
+#pragma unroll
+                for (int o = 0; o < MAXO; ++o)
+                    if (o < O) {
+                        const float d = ds[rr * O + o];
+                        g = fmaf(d, wk[o], g);
+                        acc[o] = fmaf(hv, d, acc[o]);
+                        dbacc[o] += d;
+                    }
+                dhn[row * J + k] = g;
+            }
+        }
+        __syncthreads();
+    }
+    for (int q = 0; q < 4; ++q) {
+        if (rl == q) {
+#pragma unroll
+            for (int o = 0; o < MAXO; ++o)
+                if (o < O) {
+                    red[k * O + o] = (q == 0 ? 0.0f : red[k * O + o]) + acc[o];
+                    if (k == 0) red[64 * O + o] = (q == 0 ? 0.0f : red[64 * O + o]) + dbacc[o];
+                }
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)65 * O;
+    for (int idx = threadIdx.x; idx < 65 * O; idx += 256) out[idx] = red[idx];
+}
+
+__global__ __launch_bounds__(256) void thin_bwd_reduce_kernel(const int C, const int O, const float* __restrict__ partial,
+                                                              float* __restrict__ dw, const int64_t dw_sn,
+                                                              float* __restrict__ db, const int64_t db_sn) {
+    const int n = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 65 * O;
+    if (idx >= per) return;
+    const float* p = partial + (int64_t)n * C * per + idx;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += p[(int64_t)c * per];
+    if (idx < 64 * O) dw[(int64_t)n * dw_sn + idx] = s;
+    else db[(int64_t)n * db_sn + idx - 64 * O] = s;
+}
+
 inline bool view_ok(const void* p, int64_t sn, int64_t row, int64_t rows, int W) {
     return p != nullptr && row >= W && sn >= (rows > 0 ? (rows - 1) * row + W : 0);
 }
@@ -203,5 +287,21 @@ extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, cons
     if (F <= 16) NMARL_FC_BWD(16); else if (F <= 32) NMARL_FC_BWD(32); else NMARL_FC_BWD(64);
 #undef NMARL_FC_BWD
     hipLaunchKernelGGL(fc_bwd_reduce_kernel, dim3(((F + 1) * J + 255) / 256, N), dim3(256), 0, st, C, F, partial, dw, dw_sn, db, db_sn);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const float* h, int64_t h_sn,
+                                     const float* dy, int64_t dy_sn, const float* w, int64_t w_sn, float* partial,
+                                     float* dh, int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn,
+                                     void* stream) {
+    if (rows <= 0 || N <= 0 || H != J || O <= 0 || O > MAXO || !h || !dy || !w || !partial || !dh || !dw || !db ||
+        h_sn < rows * J || dh_sn < rows * J || dy_sn < rows * O || w_sn < (int64_t)J * O || dw_sn < (int64_t)J * O || db_sn < O)
+        return NMARL_EINVAL;
+    const int C = nmarl_fc_bwd_chunks(rows, N);
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    const int tpb = (int)((tiles + C - 1) / C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(thin_bwd_kernel, dim3(C, N), dim3(256), 0, st, rows, O, tpb, h, h_sn, dy, dy_sn, w, w_sn, dh, dh_sn, partial);
+    hipLaunchKernelGGL(thin_bwd_reduce_kernel, dim3((65 * O + 255) / 256, N), dim3(256), 0, st, C, O, partial, dw, dw_sn, db, db_sn);
     return nmarl_check_launch();
 }

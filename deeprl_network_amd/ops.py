@@ -307,6 +307,46 @@ def fc_concat(parts, act):
     return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
 
 
+THIN_MAX_O = 8
+
+
+def thin_linear_bwd(h, dy, w):
+    """Backward of y = h @ w + b for h [N,rows,64], dy [N,rows,O<=8], w [N,64,O] -> (dh, dw [N,64,O], db [N,O])."""
+    N, rows, H = h.shape
+    O = dy.shape[2]
+    h, dy = h.contiguous(), dy.contiguous()
+    C_ = lib.nmarl_fc_bwd_chunks(rows, N)
+    partial = torch.empty(N, C_, H + 1, O, dtype=F32, device=h.device)
+    dh = torch.empty_like(h)
+    dw = torch.empty(N, H, O, dtype=F32, device=h.device)
+    db = torch.empty(N, O, dtype=F32, device=h.device)
+    wp, ws = _head_param(w, 'thin_linear_bwd')
+    check(lib.nmarl_thin_linear_bwd(rows, N, H, O, ptr(h, F32), rows * H, ptr(dy, F32), rows * O, wp, ws, ptr(partial),
+                                    ptr(dh), rows * H, ptr(dw), H * O, ptr(db), O, stream()), 'nmarl_thin_linear_bwd')
+    return dh, dw, db
+
+
+class _ThinLinear(torch.autograd.Function):
+    """y = h @ w + b with few outputs (the heads): library GEMM forward, one streaming HIP pass backward."""
+
+    @staticmethod
+    def forward(ctx, h, w, b):
+        ctx.save_for_backward(h, w)
+        return torch.baddbmm(b.unsqueeze(1), h, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, w = ctx.saved_tensors
+        return thin_linear_bwd(h, dy, w)
+
+
+def thin_linear(h, w, b):
+    """h [N,rows,H] @ w [N,H,O] + b [N,O]; H = 64 and O <= 8 take the fused backward."""
+    if h.shape[2] == FC_J and w.shape[2] <= THIN_MAX_O and w.stride(2) == 1 and w.stride(1) == w.shape[2]:
+        return _ThinLinear.apply(h, w, b)
+    return torch.baddbmm(b.unsqueeze(1), h, w)
+
+
 def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
     N, E, H4 = gates.shape
     check(lib.nmarl_lstm_cell_bwd(E, N, H4 // 4, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh),

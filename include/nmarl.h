@@ -291,6 +291,14 @@ int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, 
                  const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
                  int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
 /*
+ * Backward of the thin actor / critic head layers y = h @ w + b over all rows of the update (policies.py:50-77):
+ * h [N,rows,64], dy [N,rows,O] (O <= 8, contiguous rows), w [N,64,O]  ->  dh = dy @ w^T [N,rows,64],
+ * dw = h^T dy [N,64,O], db = sum_r dy [N,O].  One streaming pass; deterministic (partial [N, nmarl_fc_bwd_chunks(rows,N), 65, O]).
+ */
+int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const float* h, int64_t h_sn,
+                          const float* dy, int64_t dy_sn, const float* w, int64_t w_sn, float* partial,
+                          float* dh, int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
+/*
  * Action draw of Trainer._get_policy (utils.py:135-141) for all (replica, agent):
  * pi [N,E,A] -> action [E,N] u8.
  *   mode 0: np.random.choice == searchsorted(cumsum(pi)/sum, u, 'right') with the

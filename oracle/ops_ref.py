@@ -160,6 +160,15 @@ def fc_concat(parts, act):
     return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
 
 
+def thin_linear_bwd(h, dy, w):
+    """Gradient of y = h @ w + b (the heads, policies.py:50-77)."""
+    return torch.bmm(dy, w.transpose(1, 2)), torch.bmm(h.transpose(1, 2), dy), dy.sum(1)
+
+
+def thin_linear(h, w, b):
+    return torch.baddbmm(b.unsqueeze(1), h, w)
+
+
 def bias_act_(x, bias, act, out=None):
     """fc's bias + activation (agents/utils.py:65-73), in place or into `out`."""
     y = x + bias.unsqueeze(1)

@@ -321,6 +321,30 @@ def test_fc_concat_autograd_matches_torch():
     torch.testing.assert_close(ops.fc_concat([(xw, ww, bw)], ops.BIAS_TANH), torch.tanh(torch.bmm(xw, ww)), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('N,rows,O', [(8, 4096, 5), (25, 131, 6), (3, 1, 1), (8, 70001, 5), (2, 300, 8)])
+def test_thin_linear_bwd(N, rows, O):
+    """Heads backward in one streaming pass == dy w^T, h^T dy, sum dy (float64), deterministic."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N + rows + O)
+    h, dy = torch.randn(N, rows, 64, generator=g), torch.randn(N, rows, O, generator=g)
+    w = torch.randn(N, 64, O, generator=g)
+    dhr, dwr, dbr = ops_ref.thin_linear_bwd(h.double(), dy.double(), w.double())
+    dh, dw, db = ops.thin_linear_bwd(h.cuda(), dy.cuda(), w.cuda())
+    scale = float(rows) ** 0.5
+    torch.testing.assert_close(dh.cpu().double(), dhr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dw.cpu().double(), dwr, rtol=1e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(db.cpu().double(), dbr, rtol=1e-4, atol=2e-5 * scale)
+    dh2, dw2, db2 = ops.thin_linear_bwd(h.cuda(), dy.cuda(), w.cuda())
+    assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dh, dh2)
+    # through autograd
+    hg, wg, bg = h.cuda().requires_grad_(), w.cuda().requires_grad_(), torch.zeros(N, O).cuda().requires_grad_()
+    (ops.thin_linear(hg, wg, bg) * dy.cuda()).sum().backward()
+    torch.testing.assert_close(hg.grad, dh)
+    torch.testing.assert_close(wg.grad, dw)
+    torch.testing.assert_close(bg.grad, db)
+
+
 def test_sample_actions_modes():
     from deeprl_network_amd import ops
     from oracle import ops_ref

@@ -81,7 +81,9 @@ SIGNATURES = {
     'nmarl_fc_fwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
-    'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_nbr_action_value_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _p],
+    'nmarl_nbr_action_value_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p],
     'nmarl_bias_act': [_i64, _i32, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],

@@ -125,7 +125,6 @@ class IA2C:
         # slot 0 of the next batch.
         self.buf_x = torch.zeros(T + 1, E, N, p.n_obs, dtype=F32, device=d)
         self.buf_fp = torch.full((T + 1, N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
-        self.na_all = torch.zeros(N, T * E, p.n_na, dtype=F32, device=d)   # critic one-hots, filled by update()
         self._pi_boot, self._v_boot = torch.zeros(N, E, self.n_a, dtype=F32, device=d), torch.zeros(N, E, dtype=F32, device=d)
         self.buf_act = torch.zeros(T, E, N, dtype=torch.uint8, device=d)
         self.buf_v = torch.zeros(T, N, E, dtype=F32, device=d)
@@ -224,9 +223,8 @@ class IA2C:
         """policies.py:20-30 / 232-255 with the batch mean taken over T*E."""
         N, T, E = self.n_agent, self.n_step, self.E
         p = self.policy
-        # the critic's neighbour one-hots of all T*E rows in one launch, from the action bytes (policies.py:66-68)
-        ops.nbr_onehot(self.buf_act.view(T * E, N), p.nbr_idx, self.n_a, out=self.na_all)
-        pi, v = p.heads(Hs, self.na_all)                                      # [N,T*E,A], [N,T*E]
+        # the critic's neighbour one-hots (policies.py:66-68) are gathered from the action bytes inside the op
+        pi, v = p.heads(Hs, self.buf_act.view(T * E, N))                      # [N,T*E,A], [N,T*E]
         acts = self.buf_act.view(T * E, N).t().long().unsqueeze(-1)          # [N, T*E, 1]
         log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
         entropy = -(pi * log_pi).sum(-1)

@@ -155,16 +155,20 @@ class BatchedPolicy:
         p = self.params
         return torch.softmax(torch.baddbmm(p['pi_b'].unsqueeze(1), h, p['pi_w']), dim=-1)
 
-    def heads(self, h, na_onehot):
-        """Actor and critic heads of the update in ONE skinny GEMM: [pi_w | v_w[:H]] is concatenated on the fly
-        (64 x (A+1) per agent), so Hs (the large operand) is read once forward and its gradient is produced by
-        one dgrad GEMM instead of two plus an add.  Returns (pi [N,rows,A], v [N,rows])."""
+    def heads(self, h, action):
+        """Actor and critic heads of the update for all rows: h [N,rows,H], action [rows,N] u8 (env-major bytes; the
+        critic's neighbour one-hots are gathered from them) -> (pi [N,rows,A], v [N,rows]).  H = 64: one skinny
+        GEMM forward, one streaming pass backward (ops.heads); otherwise plain batched GEMMs."""
         p = self.params
         H, A = self.n_h, self.n_a
+        if ops.heads_supported(h, A, self.nbr_idx):
+            logits, v = ops.heads(h, p['pi_w'], p['pi_b'], p['v_w'], p['v_b'], action, self.nbr_idx, A)
+            return torch.softmax(logits, dim=-1), v
         w = torch.cat([p['pi_w'], p['v_w'][:, :H]], dim=2)
         b = torch.cat([p['pi_b'], p['v_b']], dim=1)
-        out = ops.thin_linear(h, w, b)
-        v = out[..., A] + torch.bmm(na_onehot, p['v_w'][:, H:]).squeeze(-1)
+        out = torch.baddbmm(b.unsqueeze(1), h, w)
+        na = ops.nbr_onehot(action, self.nbr_idx, A)
+        v = out[..., A] + torch.bmm(na, p['v_w'][:, H:]).squeeze(-1)
         return torch.softmax(out[..., :A], dim=-1), v
 
     def value(self, h, na_onehot, out=None):

@@ -165,6 +165,7 @@ constexpr int MAXO = 8;
 __global__ __launch_bounds__(256) void thin_bwd_kernel(const int64_t rows, const int O, const int tiles_per_block,
                                                        const float* __restrict__ h, const int64_t h_sn,
                                                        const float* __restrict__ dy, const int64_t dy_sn,
+                                                       const float* __restrict__ dy2, const int64_t dy2_sn,
                                                        const float* __restrict__ w, const int64_t w_sn,
                                                        float* __restrict__ dh, const int64_t dh_sn,
                                                        float* __restrict__ partial) {
@@ -180,14 +181,18 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const int64_t rows, const
     }
     const float* hn = h + (int64_t)n * h_sn;
     const float* dyn = dy + (int64_t)n * dy_sn;
+    const float* dy2n = dy2 ? dy2 + (int64_t)n * dy2_sn : nullptr;
+    const int O1 = dy2 ? O - 1 : O;          // dy holds the first O1 columns, dy2 (optional, [rows]) the last one
     float* dhn = dh + (int64_t)n * dh_sn;
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
-        for (int idx = threadIdx.x; idx < TILE * O; idx += 256) {          // the tile's dy rows are contiguous
-            const int64_t g = row0 * O + idx;
-            ds[idx] = g < rows * O ? dyn[g] : 0.0f;
+        for (int idx = threadIdx.x; idx < TILE * O1; idx += 256) {         // the tile's dy rows are contiguous
+            const int64_t g = row0 * O1 + idx;
+            const int r = idx / O1;
+            ds[r * O + (idx - r * O1)] = g < rows * O1 ? dyn[g] : 0.0f;
         }
+        if (dy2n && threadIdx.x < TILE) ds[threadIdx.x * O + O1] = row0 + threadIdx.x < rows ? dy2n[row0 + threadIdx.x] : 0.0f;
         __syncthreads();
 #pragma unroll 4
         for (int rr = rl; rr < TILE; rr += 4) {
@@ -235,6 +240,74 @@ __global__ __launch_bounds__(256) void thin_bwd_reduce_kernel(const int C, const
     for (int c = 0; c < C; ++c) s += p[(int64_t)c * per];
     if (idx < 64 * O) dw[(int64_t)n * dw_sn + idx] = s;
     else db[(int64_t)n * db_sn + idx - 64 * O] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Neighbour-action term of the centralised critic (policies.py:59-77): v += onehot(neighbours' actions) @ w_a,
+// with the one-hot never materialised: a gather of w_a rows by the action bytes (fwd) and a histogram of dv
+// (bwd: dw_a[k*A + a] = sum of dv over the rows whose k-th neighbour played a).  act [rows,N] u8,
+// nbr [N,m_max] (-1 padded), w_a [N, m_max*A], va / dv [N,rows].
+constexpr int MAXW = 32;
+
+__global__ __launch_bounds__(256) void nbr_action_value_kernel(const int64_t rows, const int N, const int A, const int m_max,
+                                                               const int32_t* __restrict__ nbr, const uint8_t* __restrict__ act,
+                                                               const float* __restrict__ w, const int64_t w_sn,
+                                                               float* __restrict__ va) {
+    const int64_t total = (int64_t)N * rows;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(idx / rows);
+        const int64_t r = idx - (int64_t)n * rows;
+        float v = 0.0f;
+        for (int k = 0; k < m_max; ++k) {
+            const int j = nbr[n * m_max + k];
+            if (j >= 0) v += w[(int64_t)n * w_sn + k * A + act[r * N + j]];
+        }
+        va[idx] = v;
+    }
+}
+
+// partial: [N, gridDim.x, m_max*A]
+__global__ __launch_bounds__(256) void nbr_action_value_bwd_kernel(const int64_t rows, const int N, const int A, const int m_max,
+                                                                   const int rows_per_block, const int32_t* __restrict__ nbr,
+                                                                   const uint8_t* __restrict__ act, const float* __restrict__ dv,
+                                                                   float* __restrict__ partial) {
+    __shared__ float red[4 * MAXW];
+    const int n = blockIdx.y, W = m_max * A;
+    float acc[MAXW];
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) acc[i] = 0.0f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float d = dv[(int64_t)n * rows + r];
+        for (int k = 0; k < m_max; ++k) {
+            const int j = nbr[n * m_max + k];
+            if (j < 0) continue;
+            const int hit = k * A + act[r * N + j];
+#pragma unroll
+            for (int i = 0; i < MAXW; ++i) acc[i] += (i == hit) ? d : 0.0f;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < MAXW; ++i) {
+        float s = acc[i];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) red[wv * MAXW + i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < W)
+        partial[((int64_t)n * gridDim.x + blockIdx.x) * W + threadIdx.x] =
+            ((red[threadIdx.x] + red[MAXW + threadIdx.x]) + red[2 * MAXW + threadIdx.x]) + red[3 * MAXW + threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void nbr_action_value_reduce_kernel(const int C, const int W, const float* __restrict__ partial,
+                                                                     float* __restrict__ dw, const int64_t dw_sn) {
+    const int n = blockIdx.x, i = threadIdx.x;
+    if (i >= W) return;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += partial[((int64_t)n * C + c) * W + i];
+    dw[(int64_t)n * dw_sn + i] = s;
 }
 
 inline bool view_ok(const void* p, int64_t sn, int64_t row, int64_t rows, int W) {
@@ -291,17 +364,46 @@ extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, cons
 }
 
 extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const float* h, int64_t h_sn,
-                                     const float* dy, int64_t dy_sn, const float* w, int64_t w_sn, float* partial,
-                                     float* dh, int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn,
-                                     void* stream) {
-    if (rows <= 0 || N <= 0 || H != J || O <= 0 || O > MAXO || !h || !dy || !w || !partial || !dh || !dw || !db ||
-        h_sn < rows * J || dh_sn < rows * J || dy_sn < rows * O || w_sn < (int64_t)J * O || dw_sn < (int64_t)J * O || db_sn < O)
+                                     const float* dy, int64_t dy_sn, const float* dy2, int64_t dy2_sn, const float* w,
+                                     int64_t w_sn, float* partial, float* dh, int64_t dh_sn, float* dw, int64_t dw_sn,
+                                     float* db, int64_t db_sn, void* stream) {
+    const int O1 = dy2 ? O - 1 : O;
+    if (rows <= 0 || N <= 0 || H != J || O <= 0 || O > MAXO || O1 <= 0 || !h || !dy || !w || !partial || !dh || !dw || !db ||
+        h_sn < rows * J || dh_sn < rows * J || dy_sn < rows * O1 || (dy2 && dy2_sn < rows) || w_sn < (int64_t)J * O ||
+        dw_sn < (int64_t)J * O || db_sn < O)
         return NMARL_EINVAL;
     const int C = nmarl_fc_bwd_chunks(rows, N);
     const int64_t tiles = (rows + TILE - 1) / TILE;
     const int tpb = (int)((tiles + C - 1) / C);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(thin_bwd_kernel, dim3(C, N), dim3(256), 0, st, rows, O, tpb, h, h_sn, dy, dy_sn, w, w_sn, dh, dh_sn, partial);
+    hipLaunchKernelGGL(thin_bwd_kernel, dim3(C, N), dim3(256), 0, st, rows, O, tpb, h, h_sn, dy, dy_sn, dy2, dy2_sn, w, w_sn, dh,
+                       dh_sn, partial);
     hipLaunchKernelGGL(thin_bwd_reduce_kernel, dim3((65 * O + 255) / 256, N), dim3(256), 0, st, C, O, partial, dw, dw_sn, db, db_sn);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_nbr_action_value_fwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
+                                          const uint8_t* action, const float* w, int64_t w_sn, float* va, void* stream) {
+    if (rows < 0 || N <= 0 || A <= 0 || m_max <= 0 || w_sn < (int64_t)m_max * A || (rows > 0 && (!nbr_idx || !action || !w || !va)))
+        return NMARL_EINVAL;
+    if (rows == 0) return NMARL_OK;
+    int64_t blocks = ((int64_t)N * rows + 255) / 256;
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(nbr_action_value_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows, N, A,
+                       m_max, nbr_idx, action, w, w_sn, va);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_nbr_action_value_bwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
+                                          const uint8_t* action, const float* dv, float* partial, float* dw, int64_t dw_sn,
+                                          void* stream) {
+    const int W = m_max * A;
+    if (rows <= 0 || N <= 0 || A <= 0 || m_max <= 0 || W > MAXW || dw_sn < W || !nbr_idx || !action || !dv || !partial || !dw)
+        return NMARL_EINVAL;
+    const int C = nmarl_fc_bwd_chunks(rows, N);
+    const int rpb = (int)((rows + C - 1) / C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(nbr_action_value_bwd_kernel, dim3(C, N), dim3(256), 0, st, rows, N, A, m_max, rpb, nbr_idx, action, dv, partial);
+    hipLaunchKernelGGL(nbr_action_value_reduce_kernel, dim3(N), dim3(64), 0, st, C, W, partial, dw, dw_sn);
     return nmarl_check_launch();
 }

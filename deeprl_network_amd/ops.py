@@ -310,24 +310,29 @@ def fc_concat(parts, act):
 THIN_MAX_O = 8
 
 
-def thin_linear_bwd(h, dy, w):
-    """Backward of y = h @ w + b for h [N,rows,64], dy [N,rows,O<=8], w [N,64,O] -> (dh, dw [N,64,O], db [N,O])."""
+def thin_linear_bwd(h, dy, w, dy2=None):
+    """Backward of y = h @ w + b for h [N,rows,64], w [N,64,O<=8] -> (dh, dw [N,64,O], db [N,O]).  dL/dy is dy
+    [N,rows,O], or dy [N,rows,O-1] for the leading columns plus dy2 [N,rows] for the last one."""
     N, rows, H = h.shape
-    O = dy.shape[2]
+    O = w.shape[2]
     h, dy = h.contiguous(), dy.contiguous()
+    if dy.shape[2] + (0 if dy2 is None else 1) != O:
+        raise _lib.NmarlError('thin_linear_bwd: dy columns do not add up to w columns')
     C_ = lib.nmarl_fc_bwd_chunks(rows, N)
     partial = torch.empty(N, C_, H + 1, O, dtype=F32, device=h.device)
     dh = torch.empty_like(h)
     dw = torch.empty(N, H, O, dtype=F32, device=h.device)
     db = torch.empty(N, O, dtype=F32, device=h.device)
     wp, ws = _head_param(w, 'thin_linear_bwd')
-    check(lib.nmarl_thin_linear_bwd(rows, N, H, O, ptr(h, F32), rows * H, ptr(dy, F32), rows * O, wp, ws, ptr(partial),
-                                    ptr(dh), rows * H, ptr(dw), H * O, ptr(db), O, stream()), 'nmarl_thin_linear_bwd')
+    d2 = None if dy2 is None else dy2.contiguous()
+    check(lib.nmarl_thin_linear_bwd(rows, N, H, O, ptr(h, F32), rows * H, ptr(dy, F32), rows * dy.shape[2], ptr(d2, F32), rows,
+                                    wp, ws, ptr(partial), ptr(dh), rows * H, ptr(dw), H * O, ptr(db), O, stream()),
+          'nmarl_thin_linear_bwd')
     return dh, dw, db
 
 
 class _ThinLinear(torch.autograd.Function):
-    """y = h @ w + b with few outputs (the heads): library GEMM forward, one streaming HIP pass backward."""
+    """y = h @ w + b with few outputs: library GEMM forward, one streaming HIP pass backward."""
 
     @staticmethod
     def forward(ctx, h, w, b):
@@ -345,6 +350,69 @@ def thin_linear(h, w, b):
     if h.shape[2] == FC_J and w.shape[2] <= THIN_MAX_O and w.stride(2) == 1 and w.stride(1) == w.shape[2]:
         return _ThinLinear.apply(h, w, b)
     return torch.baddbmm(b.unsqueeze(1), h, w)
+
+
+NBR_ACT_MAX_W = 32
+
+
+def nbr_action_value(action, nbr_idx, w_a, n_a):
+    """va [N,rows] = onehot(neighbours' actions) @ w_a without the one-hot: action [rows,N] u8, w_a [N,m_max*A,(1)]."""
+    rows, N = action.shape
+    va = torch.empty(N, rows, dtype=F32, device=action.device)
+    wp, ws = _head_param(w_a.view(N, -1, 1), 'nbr_action_value')
+    check(lib.nmarl_nbr_action_value_fwd(rows, N, n_a, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(action, torch.uint8),
+                                         wp, ws, ptr(va), stream()), 'nmarl_nbr_action_value_fwd')
+    return va
+
+
+def nbr_action_value_bwd(action, nbr_idx, dv, n_a):
+    """dw_a [N,m_max*A]: histogram of dv [N,rows] over (neighbour slot, action played)."""
+    rows, N = action.shape
+    W = nbr_idx.shape[1] * n_a
+    C_ = lib.nmarl_fc_bwd_chunks(rows, N)
+    partial = torch.empty(N, C_, W, dtype=F32, device=action.device)
+    dw = torch.empty(N, W, dtype=F32, device=action.device)
+    check(lib.nmarl_nbr_action_value_bwd(rows, N, n_a, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(action, torch.uint8),
+                                         ptr(dv.contiguous(), F32), ptr(partial), ptr(dw), W, stream()),
+          'nmarl_nbr_action_value_bwd')
+    return dw
+
+
+class _Heads(torch.autograd.Function):
+    """Actor logits and critic value of the update for all rows (policies.py:50-77):
+        logits = h @ pi_w + pi_b ;  v = [h, onehot(neighbours' actions)] @ v_w + v_b
+    Forward: ONE skinny GEMM over [pi_w | v_w[:H]] (h is read once) + the gathered neighbour-action term.
+    Backward: one streaming pass for dh / d[pi_w | v_w[:H]] / db (thin_linear_bwd, the two incoming gradients read
+    in place) and a histogram for d v_w[H:]; the parameter gradients come out per tensor (no cat / slice nodes)."""
+
+    @staticmethod
+    def forward(ctx, h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
+        H = h.shape[2]
+        w = torch.cat([pi_w, v_w[:, :H]], dim=2)
+        out = torch.baddbmm(torch.cat([pi_b, v_b], dim=1).unsqueeze(1), h, w)
+        v = out[..., n_a] + nbr_action_value(action, nbr_idx, v_w[:, H:], n_a)
+        ctx.save_for_backward(h, w, action, nbr_idx)
+        ctx.n_a = n_a
+        return out[..., :n_a], v
+
+    @staticmethod
+    def backward(ctx, dlogits, dv):
+        h, w, action, nbr_idx = ctx.saved_tensors
+        A = ctx.n_a
+        dv = dv.contiguous()
+        dh, dw, db = thin_linear_bwd(h, dlogits, w, dy2=dv)
+        dwa = nbr_action_value_bwd(action, nbr_idx, dv, A)
+        dv_w = torch.cat([dw[:, :, A:], dwa.unsqueeze(-1)], dim=1)
+        return dh, dw[:, :, :A], db[:, :A], dv_w, db[:, A:], None, None, None
+
+
+def heads_supported(h, n_a, nbr_idx):
+    return h.shape[2] == FC_J and n_a + 1 <= THIN_MAX_O and nbr_idx.shape[1] * n_a <= NBR_ACT_MAX_W
+
+
+def heads(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
+    """(logits [N,rows,A], v [N,rows]) from h [N,rows,64] and the env-major action bytes action [rows,N]."""
+    return _Heads.apply(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a)
 
 
 def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):

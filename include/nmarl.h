@@ -292,12 +292,27 @@ int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, 
                  int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
 /*
  * Backward of the thin actor / critic head layers y = h @ w + b over all rows of the update (policies.py:50-77):
- * h [N,rows,64], dy [N,rows,O] (O <= 8, contiguous rows), w [N,64,O]  ->  dh = dy @ w^T [N,rows,64],
- * dw = h^T dy [N,64,O], db = sum_r dy [N,O].  One streaming pass; deterministic (partial [N, nmarl_fc_bwd_chunks(rows,N), 65, O]).
+ * h [N,rows,64], w [N,64,O] (O <= 8), dL/dy given as dy [N,rows,O1] (contiguous rows) plus, optionally, dy2 [N,rows]
+ * for the last column (O = O1 + 1: the actor's logits and the critic's value arrive as separate gradients)
+ *   ->  dh = dy @ w^T [N,rows,64],  dw = h^T dy [N,64,O],  db = sum_r dy [N,O].
+ * One streaming pass; deterministic (partial [N, nmarl_fc_bwd_chunks(rows,N), 65, O]).
  */
 int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const float* h, int64_t h_sn,
-                          const float* dy, int64_t dy_sn, const float* w, int64_t w_sn, float* partial,
-                          float* dh, int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
+                          const float* dy, int64_t dy_sn, const float* dy2, int64_t dy2_sn, const float* w, int64_t w_sn,
+                          float* partial, float* dh, int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn,
+                          void* stream);
+/*
+ * Neighbour-action term of the centralised critic, v += one_hot(neighbours' actions) @ w_a (policies.py:59-77),
+ * without the one-hot tensor: action [rows,N] u8, nbr_idx [N,m_max] (-1 padded), w_a [N,m_max*A].
+ *   fwd: va[n,r] = sum_k w_a[n, k*A + action[r, nbr_idx[n,k]]]
+ *   bwd: dw_a[n, k*A + a] = sum of dv[n,r] over the rows with action[r, nbr_idx[n,k]] == a   (m_max*A <= 32;
+ *        partial [N, nmarl_fc_bwd_chunks(rows,N), m_max*A], fixed-order sums)
+ */
+int nmarl_nbr_action_value_fwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
+                               const uint8_t* action, const float* w, int64_t w_sn, float* va, void* stream);
+int nmarl_nbr_action_value_bwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
+                               const uint8_t* action, const float* dv, float* partial, float* dw, int64_t dw_sn,
+                               void* stream);
 /*
  * Action draw of Trainer._get_policy (utils.py:135-141) for all (replica, agent):
  * pi [N,E,A] -> action [E,N] u8.

@@ -160,13 +160,38 @@ def fc_concat(parts, act):
     return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
 
 
-def thin_linear_bwd(h, dy, w):
-    """Gradient of y = h @ w + b (the heads, policies.py:50-77)."""
+def thin_linear_bwd(h, dy, w, dy2=None):
+    """Gradient of y = h @ w + b (the heads, policies.py:50-77); dy2: separate gradient of the last column."""
+    if dy2 is not None:
+        dy = torch.cat([dy, dy2.unsqueeze(-1)], dim=-1)
     return torch.bmm(dy, w.transpose(1, 2)), torch.bmm(h.transpose(1, 2), dy), dy.sum(1)
 
 
 def thin_linear(h, w, b):
     return torch.baddbmm(b.unsqueeze(1), h, w)
+
+
+def nbr_action_value(action, nbr_idx, w_a, n_a):
+    """one_hot(neighbour actions) @ w_a (policies.py:66-72)."""
+    N = action.shape[1]
+    return torch.bmm(nbr_onehot(action, nbr_idx, n_a).to(w_a.dtype), w_a.reshape(N, -1, 1)).squeeze(-1)
+
+
+def nbr_action_value_bwd(action, nbr_idx, dv, n_a):
+    return torch.bmm(nbr_onehot(action, nbr_idx, n_a).to(dv.dtype).transpose(1, 2), dv.unsqueeze(-1)).squeeze(-1)
+
+
+def heads_supported(h, n_a, nbr_idx):
+    return True
+
+
+def heads(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
+    """policies.py:50-77, plain autograd: logits = h pi_w + pi_b; v = [h, one_hot(na)] v_w + v_b."""
+    H = h.shape[2]
+    logits = torch.baddbmm(pi_b.unsqueeze(1), h, pi_w)
+    na = nbr_onehot(action, nbr_idx, n_a).to(h.dtype)
+    v = torch.baddbmm(v_b.unsqueeze(1), torch.cat([h, na], dim=-1), v_w).squeeze(-1)
+    return logits, v
 
 
 def bias_act_(x, bias, act, out=None):

@@ -337,12 +337,51 @@ def test_thin_linear_bwd(N, rows, O):
     torch.testing.assert_close(db.cpu().double(), dbr, rtol=1e-4, atol=2e-5 * scale)
     dh2, dw2, db2 = ops.thin_linear_bwd(h.cuda(), dy.cuda(), w.cuda())
     assert torch.equal(dw, dw2) and torch.equal(db, db2) and torch.equal(dh, dh2)
+    if O > 1:    # last column's gradient handed over separately (actor logits + critic value)
+        dh3, dw3, db3 = ops.thin_linear_bwd(h.cuda(), dy[..., :O - 1].cuda(), w.cuda(), dy2=dy[..., O - 1].cuda())
+        assert torch.equal(dh3, dh) and torch.equal(dw3, dw) and torch.equal(db3, db)
     # through autograd
     hg, wg, bg = h.cuda().requires_grad_(), w.cuda().requires_grad_(), torch.zeros(N, O).cuda().requires_grad_()
     (ops.thin_linear(hg, wg, bg) * dy.cuda()).sum().backward()
     torch.testing.assert_close(hg.grad, dh)
     torch.testing.assert_close(wg.grad, dw)
     torch.testing.assert_close(bg.grad, db)
+
+
+@pytest.mark.parametrize('N,rows,A,m_max', [(8, 4096, 4, 2), (25, 1000, 5, 4), (3, 70001, 4, 2), (5, 1, 7, 4)])
+def test_heads_and_neighbour_action_value(N, rows, A, m_max):
+    """ops.heads (skinny GEMM + gathered neighbour-action term; streaming backward + histogram) == the plain
+    autograd restatement with an explicit one-hot, values and all five gradients."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N * 7 + rows + A)
+    H = 64
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + 1]
+        idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    act = torch.randint(0, A, (rows, N), generator=g).to(torch.uint8)
+    h = torch.randn(N, rows, H, generator=g)
+    prm = [torch.randn(N, H, A, generator=g) * 0.3, torch.randn(N, A, generator=g) * 0.1,
+           torch.randn(N, H + m_max * A, 1, generator=g) * 0.3, torch.randn(N, 1, generator=g)]
+    R1, R2 = torch.randn(N, rows, A, generator=g), torch.randn(N, rows, generator=g)
+    w_a = prm[2][:, H:]
+    torch.testing.assert_close(ops.nbr_action_value(act.cuda(), idx.cuda(), w_a.cuda(), A).cpu().double(),
+                               ops_ref.nbr_action_value(act, idx, w_a.double(), A), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ops.nbr_action_value_bwd(act.cuda(), idx.cuda(), R2.cuda(), A).cpu().double(),
+                               ops_ref.nbr_action_value_bwd(act, idx, R2.double(), A), rtol=1e-4, atol=2e-5 * rows ** 0.5)
+
+    def run(mod, tensors, dev):
+        ts = [t.to(dev).clone().requires_grad_() for t in tensors]
+        logits, v = mod.heads(ts[0], ts[1], ts[2], ts[3], ts[4], act.to(dev), idx.to(dev), A)
+        ((torch.softmax(logits, -1) * R1.to(ts[0])).sum() + (v * R2.to(ts[0])).sum()).backward()
+        return logits.detach(), v.detach(), [t.grad for t in ts]
+    lr, vr, gr = run(ops_ref, [t.double() for t in [h] + prm], 'cpu')
+    lg, vg, gg = run(ops, [h] + prm, 'cuda')
+    torch.testing.assert_close(lg.cpu().double(), lr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(vg.cpu().double(), vr, rtol=1e-5, atol=2e-5)
+    for a, b in zip(gg, gr):
+        torch.testing.assert_close(a.cpu().double(), b, rtol=1e-4, atol=3e-5 * rows ** 0.5)
 
 
 def test_sample_actions_modes():

@@ -306,7 +306,7 @@ class LstmPolicy(BatchedPolicy):
     def _enc(self, xv, fp):
         """x-side LSTM pre-activation [N,rows,4H] (bias is added in the cell kernel)."""
         p = self.params
-        return torch.bmm(ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
+        return ops.linear(ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         return torch.bmm(self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
@@ -334,7 +334,7 @@ class FPPolicy(LstmPolicy):
         pf = ops.nbr_gather(fp, self.nbr_idx)
         # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place
         s = ops.fc_concat([(xv, p['fcs_w'], p['fcs_b']), (pf, p['fcp_w'], p['fcp_b'])], ops.BIAS_RELU)
-        return torch.bmm(s, p['lstm_wx'])
+        return ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         p = self.params
@@ -373,7 +373,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
         H = self.n_h
         pf = ops.nbr_gather(fp, self.nbr_idx)
         s = ops.fc_concat([(xv, p['w_ob'], p['w_ob_b']), (pf, p['w_fp'], p['w_fp_b'])], ops.BIAS_RELU)
-        return torch.bmm(s, p['wx_hid'][:, :2 * H])
+        return ops.linear(s, p['wx_hid'][:, :2 * H])
 
     def _recur_in(self, enc, h):
         p = self.params
@@ -462,7 +462,7 @@ class ConsensusPolicy(LstmPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return torch.bmm(ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
+        return ops.linear(ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         return torch.bmm(self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])

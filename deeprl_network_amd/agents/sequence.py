@@ -123,28 +123,28 @@ class CoupledSequence(torch.autograd.Function):
             for t in masked:
                 Hk[:, t].mul_(keep[t].view(1, E, 1))
             Hk = Hk.view(N, R, H)
-        dwh = torch.bmm(Hk.transpose(1, 2), dZf)
+        dwh = ops.wgrad(Hk, dZf)
         db = dZf.sum(dim=1)
         Hp = Hprev.reshape(N, R, H)                            # un-masked h_{t-1} of all steps (message inputs)
         dmfc_w = dmfc_b = None
         if kind == 'nc':
-            dwx = torch.bmm(A1.view(N, R, H).transpose(1, 2), dZf)
+            dwx = ops.wgrad(A1.view(N, R, H), dZf)
             D1f = D1.view(N, R, H)
-            dwmsg = torch.bmm(ops.nbr_gather(Hp, nbr_idx).transpose(1, 2), D1f)
+            dwmsg = ops.wgrad(ops.nbr_gather(Hp, nbr_idx), D1f)
             dbmsg = D1f.sum(dim=1)
             denc = dZ
         elif kind == 'ic3':
-            dwx = torch.bmm(A1.view(N, R, H).transpose(1, 2), dZf)
+            dwx = ops.wgrad(A1.view(N, R, H), dZf)
             D1f = D1.view(N, R, H)
-            dwmsg = torch.bmm(ops.nbr_mean(Hp, nbr_idx).transpose(1, 2), D1f)
+            dwmsg = ops.wgrad(ops.nbr_mean(Hp, nbr_idx), D1f)
             dbmsg = D1f.sum(dim=1)
             denc = D1
         else:
-            dwx = torch.bmm(S.view(N, R, H).transpose(1, 2), dZf)
+            dwx = ops.wgrad(S.view(N, R, H), dZf)
             D1f, D2f = D1.view(N, R, H), D2.view(N, R, H)
-            dwmsg = torch.bmm(ops.nbr_gather(A2.view(N, R, H), nbr_idx).transpose(1, 2), D1f)
+            dwmsg = ops.wgrad(ops.nbr_gather(A2.view(N, R, H), nbr_idx), D1f)
             dbmsg = D1f.sum(dim=1)
-            dmfc_w = torch.bmm(Hp.transpose(1, 2), D2f)
+            dmfc_w = ops.wgrad(Hp, D2f)
             dmfc_b = D2f.sum(dim=1)
             denc = DS
         return None, None, None, denc, dh_rec, dc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b

@@ -415,6 +415,43 @@ def heads(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
     return _Heads.apply(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a)
 
 
+WGRAD_SPLIT = 16
+
+
+def wgrad(a, g):
+    """a^T g for a [N,rows,M], g [N,rows,K] -> [N,M,K]: the weight gradient of a batched layer, whose contraction
+    runs over ALL rows (T*E of the update).  One GEMM per agent gives the library 8 tall-K problems (it reaches
+    ~75 TFLOP/s fp32); splitting the rows into WGRAD_SPLIT slabs per agent (a free view) makes it 128 ordinary
+    ones plus a fixed-order sum of the partial products (measured 1745 -> 936 us for 128 x 256, 1056 -> 532 us for
+    64 x 256 at rows = 245760; tools/wgrad_split.py).  Deterministic."""
+    N, rows, M = a.shape
+    S = WGRAD_SPLIT
+    if rows % S or rows < 64 * S or not a.is_contiguous() or not g.is_contiguous():
+        return torch.bmm(a.transpose(1, 2), g)
+    part = torch.bmm(a.view(N * S, rows // S, M).transpose(1, 2), g.view(N * S, rows // S, g.shape[2]))
+    return part.view(N, S, M, g.shape[2]).sum(1)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ w for x [N,rows,M] (rows = T*E): plain GEMMs, with the row-split weight gradient (wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.bmm(x, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.bmm(dy, w.transpose(1, 2)) if ctx.needs_input_grad[0] else None
+        return dx, wgrad(x, dy)
+
+
+def linear(x, w):
+    return _Linear.apply(x, w)
+
+
 def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
     N, E, H4 = gates.shape
     check(lib.nmarl_lstm_cell_bwd(E, N, H4 // 4, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh),
@@ -520,7 +557,7 @@ class _LstmSequence(torch.autograd.Function):
             for t in ctx.masked:
                 Hprev[:, t].mul_(keep[t].view(1, E, 1))
             Hprev = Hprev.view(N, T * E, H)
-        dwh = torch.bmm(Hprev.transpose(1, 2), dZf)
+        dwh = wgrad(Hprev, dZf)
         db = dZf.sum(dim=1)
         return dZ, dwh, db, dh_rec, dc, None, None
 

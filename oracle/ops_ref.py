@@ -194,6 +194,15 @@ def heads(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
     return logits, v
 
 
+def wgrad(a, g):
+    """a^T g over all rows (the weight gradient of a batched layer)."""
+    return torch.bmm(a.transpose(1, 2), g)
+
+
+def linear(x, w):
+    return torch.bmm(x, w)
+
+
 def bias_act_(x, bias, act, out=None):
     """fc's bias + activation (agents/utils.py:65-73), in place or into `out`."""
     y = x + bias.unsqueeze(1)

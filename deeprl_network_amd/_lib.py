@@ -47,6 +47,16 @@ class Head(C.Structure):
                 ('act_in', C.c_void_p), ('nbr_idx', C.c_void_p), ('v_out', C.c_void_p), ('v_sn', C.c_int64)]
 
 
+class FcPart(C.Structure):
+    """nmarl_fc_part_t (include/nmarl.h): one layer of nmarl_fc_fwd_multi."""
+    _fields_ = [('x', C.c_void_p), ('x_sn', C.c_int64), ('x_row', C.c_int64), ('F', C.c_int32), ('gather_A', C.c_int32),
+                ('m_max', C.c_int32), ('pad_', C.c_int32), ('nbr_idx', C.c_void_p), ('w', C.c_void_p), ('w_sn', C.c_int64),
+                ('b', C.c_void_p), ('b_sn', C.c_int64)]
+
+
+FC_MAX_PARTS = 4
+
+
 class GridParams(C.Structure):
     """nmarl_grid_params_t (include/nmarl.h)."""
     _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('peak1', C.c_float), ('peak2', C.c_float),
@@ -79,6 +89,7 @@ SIGNATURES = {
     'nmarl_lstm_step_fused_head': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64,
                                    _p, _i64, _p, _i64, C.POINTER(Head), _p],
     'nmarl_fc_fwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
+    'nmarl_fc_fwd_multi': [_i64, _i32, _i32, C.POINTER(FcPart), _i32, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],

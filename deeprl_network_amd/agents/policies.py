@@ -241,6 +241,10 @@ class BatchedPolicy:
                 self.value(h_out, ops.nbr_onehot(action, self.nbr_idx, self.n_a), out=v_out)
         return v_out
 
+    def _enc_one_launch(self, xv, width):
+        """Observation and fingerprint encoders fit the multi-layer fc kernel (inputs <= 64 wide, 64 outputs)."""
+        return width == ops.FC_J and xv.shape[2] <= ops.FC_MAX_F and self.n_na <= ops.FC_MAX_F
+
     def _fc_infer(self, x, w_key, b_key, act, out=None):
         """act(x @ W + b) with the bias/activation fused in one pass (no autograd); `out` may be a column
         block of a wider buffer, which concatenates partial encodings without a copy."""
@@ -339,9 +343,14 @@ class FPPolicy(LstmPolicy):
     def _enc_infer(self, xv, fp):
         p = self.params
         nf = self.n_fc
-        s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device)      # [hx | hp], policies.py:181
-        self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
-        self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
+        if self._enc_one_launch(xv, nf):
+            # [hx | hp] (policies.py:181) by ONE kernel: both layers, the fingerprint gather folded into the second
+            s = ops.fc_fwd_multi([(xv, p['fcs_w'], p['fcs_b'], None), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)],
+                                 ops.BIAS_RELU)
+        else:
+            s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device)
+            self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
+            self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
         return torch.bmm(s, p['lstm_wx'])                                               # ONE K = 2 nf GEMM
 
 
@@ -385,9 +394,14 @@ class NCMultiAgentPolicy(BatchedPolicy):
     def _enc_infer(self, xv, fp):
         p = self.params
         H = self.n_h
-        s = torch.empty(self.N, xv.shape[1], 2 * H, dtype=F32, device=xv.device)       # [hx | hp] of agents/utils.py:199
-        self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
-        self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
+        if self._enc_one_launch(xv, H):
+            # [hx | hp] of agents/utils.py:199 by ONE kernel (fingerprint gather folded in)
+            s = ops.fc_fwd_multi([(xv, p['w_ob'], p['w_ob_b'], None), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)],
+                                 ops.BIAS_RELU)
+        else:
+            s = torch.empty(self.N, xv.shape[1], 2 * H, dtype=F32, device=xv.device)
+            self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
+            self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
         return torch.bmm(s, p['wx_hid'][:, :2 * H])
 
     def _recur_addends(self, enc, h):

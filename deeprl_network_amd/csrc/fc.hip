@@ -82,6 +82,65 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const i
     }
 }
 
+// Several encoder layers of one lock-step in ONE launch (blockIdx.z = layer): layer p writes columns
+// [64 p, 64 p + 64) of the concatenated encoding.  A layer may take its input through the neighbour table:
+// x~[n, r, k*A + a] = x[nbr[n,k], r, a] (0 where padded) -- the fingerprint gather of FPPolicy / lstm_comm
+// (policies.py:171-179, agents/utils.py:188-193) folded into the tile staging, so that the whole h-independent
+// encoding of the rollout is one kernel before the s @ Wx GEMM.
+struct FcParts { nmarl_fc_part_t p[NMARL_FC_MAX_PARTS]; };
+
+template <int FMAX>
+__global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, const int tiles_per_block, const FcParts parts,
+                                                           const int act, float* __restrict__ y, const int64_t y_sn,
+                                                           const int64_t y_row) {
+    constexpr int FP = FMAX + 4;
+    __shared__ __attribute__((aligned(16))) float xs[TILE * FP];
+    const nmarl_fc_part_t& pt = parts.p[blockIdx.z];
+    const int F = pt.F;
+    const int n = blockIdx.y, j = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    float wr[FMAX];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f) wr[f] = f < F ? pt.w[(int64_t)n * pt.w_sn + f * J + j] : 0.0f;
+    const float bj = pt.b[(int64_t)n * pt.b_sn + j];
+    float* yn = y + (int64_t)n * y_sn + blockIdx.z * J;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+        if (pt.nbr_idx == nullptr) {
+            stage_tile<FMAX>(xs, pt.x + (int64_t)n * pt.x_sn, pt.x_row, row0, rows, F);
+        } else {
+            const int A = pt.gather_A;
+            for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
+                const int r = idx / FMAX, f = idx - r * FMAX;
+                const int64_t row = row0 + r;
+                float v = 0.0f;
+                if (f < F && row < rows) {
+                    const int k = f / A;
+                    const int src = pt.nbr_idx[n * pt.m_max + k];
+                    if (src >= 0) v = pt.x[(int64_t)src * pt.x_sn + row * pt.x_row + (f - k * A)];
+                }
+                xs[r * FP + f] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = rl; rr < TILE; rr += 4) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int f4 = 0; f4 < FMAX / 4; ++f4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + rr * FP + 4 * f4);
+                acc = fmaf(xv.x, wr[4 * f4 + 0], acc);
+                acc = fmaf(xv.y, wr[4 * f4 + 1], acc);
+                acc = fmaf(xv.z, wr[4 * f4 + 2], acc);
+                acc = fmaf(xv.w, wr[4 * f4 + 3], acc);
+            }
+            const int64_t row = row0 + rr;
+            if (row < rows) yn[row * y_row + j] = act_fwd(acc + bj, act);
+        }
+        __syncthreads();
+    }
+}
+
 // partial: [N, gridDim.x, F + 1, 64] (rows 0..F-1: dW, row F: db)
 template <int FMAX>
 __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const int F, const int tiles_per_block,
@@ -340,6 +399,33 @@ extern "C" int nmarl_fc_fwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, cons
                                             b, b_sn, act, y, y_sn, y_row)
     if (F <= 16) NMARL_FC_FWD(16); else if (F <= 32) NMARL_FC_FWD(32); else NMARL_FC_FWD(64);
 #undef NMARL_FC_FWD
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, const nmarl_fc_part_t* parts, int32_t act,
+                                  float* y, int64_t y_sn, int64_t y_row, void* stream) {
+    if (rows < 0 || N <= 0 || n_parts <= 0 || n_parts > NMARL_FC_MAX_PARTS || !parts || act < 0 || act > 2) return NMARL_EINVAL;
+    if (rows == 0) return NMARL_OK;
+    if (!view_ok(y, y_sn, y_row, rows, J * n_parts)) return NMARL_EINVAL;
+    FcParts ps{};
+    int fmax = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        const nmarl_fc_part_t& p = parts[i];
+        if (p.F <= 0 || p.F > 64 || !p.x || !p.w || !p.b || p.w_sn < (int64_t)p.F * J || p.b_sn < J) return NMARL_EINVAL;
+        if (p.nbr_idx ? (p.gather_A <= 0 || p.m_max <= 0 || p.F != p.gather_A * p.m_max || p.x_row < p.gather_A)
+                      : p.x_row < p.F)
+            return NMARL_EINVAL;
+        ps.p[i] = p;
+        fmax = p.F > fmax ? p.F : fmax;
+    }
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    int64_t tpb = tiles * N * n_parts / 2048;
+    tpb = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
+    const dim3 grid((unsigned)((tiles + tpb - 1) / tpb), N, n_parts);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NMARL_FC_MULTI(FM) hipLaunchKernelGGL(fc_fwd_multi_kernel<FM>, grid, dim3(256), 0, st, rows, (int)tpb, ps, act, y, y_sn, y_row)
+    if (fmax <= 16) NMARL_FC_MULTI(16); else if (fmax <= 32) NMARL_FC_MULTI(32); else NMARL_FC_MULTI(64);
+#undef NMARL_FC_MULTI
     return nmarl_check_launch();
 }
 

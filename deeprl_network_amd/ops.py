@@ -254,6 +254,32 @@ def fc_fwd(x, w, b, act, out=None):
     return out
 
 
+def fc_fwd_multi(parts, act, out=None):
+    """Several small-K layers in ONE launch: parts = [(x, w, b, nbr_idx or None), ...]; layer p writes columns
+    [64p, 64p+64) of out [N,rows,64*len(parts)].  With nbr_idx the layer's input is gather(x) over the neighbour table
+    (x [N,rows,A] -> F = m_max*A) without materialising it.  No autograd (rollout)."""
+    N, rows = parts[0][0].shape[:2]
+    n = len(parts)
+    if out is None:
+        out = torch.empty(N, rows, FC_J * n, dtype=F32, device=parts[0][0].device)
+    arr = (_lib.FcPart * n)()
+    for i, (x, w, b, nbr_idx) in enumerate(parts):
+        pt = arr[i]
+        pt.x, pt.x_sn, pt.x_row = _rows_view(x, x.shape[2], 'fc_fwd_multi x')
+        if nbr_idx is None:
+            pt.F = x.shape[2]
+        else:
+            pt.gather_A, pt.m_max, pt.F = x.shape[2], nbr_idx.shape[1], x.shape[2] * nbr_idx.shape[1]
+            pt.nbr_idx = ptr(nbr_idx, torch.int32)
+        if w.shape[1] != pt.F or w.shape[2] != FC_J:
+            raise _lib.NmarlError('fc_fwd_multi: layer %d weight shape %s does not match input width %d' % (i, tuple(w.shape), pt.F))
+        pt.w, pt.w_sn = _head_param(w, 'fc_fwd_multi')
+        pt.b, pt.b_sn = _bias(b)
+    yp, ys, yr = _rows_view(out, FC_J * n, 'fc_fwd_multi out')
+    check(lib.nmarl_fc_fwd_multi(rows, N, n, arr, act, yp, ys, yr, stream()), 'nmarl_fc_fwd_multi')
+    return out
+
+
 def fc_bwd(x, y, dy, act):
     """(dw [N,F,64], db [N,64]) of y = act(x @ w + b) given the layer OUTPUT y and dL/dy (column-block views allowed)."""
     N, rows, F = x.shape

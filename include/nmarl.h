@@ -286,6 +286,21 @@ int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x
 int nmarl_fc_fwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, int64_t x_sn, int64_t x_row,
                  const float* w, int64_t w_sn, const float* b, int64_t b_sn, int32_t act, float* y,
                  int64_t y_sn, int64_t y_row, void* stream);
+/* Up to NMARL_FC_MAX_PARTS such layers in one launch, layer p writing columns [64p, 64p+64) of y (the whole
+ * h-independent encoding of a lock-step: fcs || fcp of policies.py:176-181, w_ob || w_fp of agents/utils.py:186-199).
+ * nbr_idx != NULL: the layer's input is gathered through the neighbour table, x~[n,r,k*A+a] = x[nbr_idx[n,k],r,a]
+ * with x [N,rows,gather_A] (the previous-step policies), F = m_max*gather_A  (cacc_env.py:244-248 get_fingerprint +
+ * models.py:171-179). */
+#define NMARL_FC_MAX_PARTS 4
+typedef struct nmarl_fc_part {
+    const float* x; int64_t x_sn, x_row;
+    int32_t F, gather_A, m_max, pad_;
+    const int32_t* nbr_idx;
+    const float* w; int64_t w_sn;
+    const float* b; int64_t b_sn;
+} nmarl_fc_part_t;
+int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, const nmarl_fc_part_t* parts, int32_t act,
+                       float* y, int64_t y_sn, int64_t y_row, void* stream);
 int nmarl_fc_bwd_chunks(int64_t rows, int32_t N);
 int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, int64_t x_sn, int64_t x_row,
                  const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,

@@ -148,6 +148,16 @@ def fc_fwd(x, w, b, act, out=None):
     return y
 
 
+def fc_fwd_multi(parts, act, out=None):
+    """tf.concat of fc layers, a layer's input optionally gathered over the neighbour table (models.py:171-179)."""
+    ys = [fc_fwd(x if nbr_idx is None else nbr_gather(x, nbr_idx), w, b, act) for x, w, b, nbr_idx in parts]
+    y = torch.cat(ys, dim=-1)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def fc_bwd(x, y, dy, act):
     """Gradient of fc w.r.t. (w, b), the activation derivative taken from the layer output y."""
     g = dy * (y > 0).to(dy.dtype) if act == BIAS_RELU else dy * (1.0 - y * y) if act == BIAS_TANH else dy

@@ -6,6 +6,8 @@ import os
 import re
 import subprocess
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, 'include', 'nmarl.h')
 
@@ -58,21 +60,24 @@ def test_library_is_built_from_the_current_sources():
     assert fn().decode() == 'NMARL_SRC_HASH=' + build.source_hash()
 
 
-def test_head_struct_layout_matches_c_compiler(tmp_path):
-    """nmarl_head_t as gcc lays it out == the ctypes mirror, field by field."""
+@pytest.mark.parametrize('ctype,cls', [('nmarl_head_t', 'Head'), ('nmarl_fc_part_t', 'FcPart'),
+                                       ('nmarl_cacc_params_t', 'CaccParams'), ('nmarl_grid_params_t', 'GridParams')])
+def test_struct_layouts_match_c_compiler(tmp_path, ctype, cls):
+    """Every struct of the C-ABI as gcc lays it out == its ctypes mirror, field by field."""
     from deeprl_network_amd import _lib
-    fields = [n for n, _ in _lib.Head._fields_]
-    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu", sizeof(nmarl_head_t));\n' % HEADER
+    mirror = getattr(_lib, cls)
+    fields = [n for n, _ in mirror._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(){printf("%%zu", sizeof(%s));\n' % (HEADER, ctype)
     for f in fields:
-        src += 'printf(" %%zu", offsetof(nmarl_head_t, %s));\n' % f
+        src += 'printf(" %%zu", offsetof(%s, %s));\n' % (ctype, f)
     src += 'return 0;}\n'
     c = tmp_path / 'off.c'
     c.write_text(src)
     exe = str(tmp_path / 'off')
     subprocess.check_call(['gcc', str(c), '-o', exe])
     nums = [int(x) for x in subprocess.run([exe], capture_output=True, text=True).stdout.split()]
-    assert nums[0] == ctypes.sizeof(_lib.Head)
-    assert nums[1:] == [getattr(_lib.Head, f).offset for f in fields]
+    assert nums[0] == ctypes.sizeof(mirror)
+    assert nums[1:] == [getattr(mirror, f).offset for f in fields]
 
 
 def test_ops_fail_loudly_without_gpu_tensors():

@@ -296,6 +296,29 @@ def test_fc_small_layer_fwd_bwd(N, rows, F, act):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+@pytest.mark.parametrize('N,rows,Fx,A,m_max', [(8, 4096, 15, 4, 2), (25, 1030, 60, 5, 4), (3, 1, 5, 4, 2)])
+def test_fc_fwd_multi_with_gathered_fingerprints(N, rows, Fx, A, m_max):
+    """Both encoder layers of a lock-step in one launch, the second reading the previous-step policies through the
+    neighbour table == gather + two fc layers + concat (float64)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N + rows + Fx)
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + 1]
+        idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    slab = torch.randn(rows, N, Fx, generator=g)
+    fp = torch.softmax(torch.randn(N, rows, A, generator=g), -1)
+    w1, b1 = torch.randn(N, Fx, 64, generator=g) * 0.3, torch.randn(N, 64, generator=g) * 0.1
+    w2, b2 = torch.randn(N, m_max * A, 64, generator=g) * 0.3, torch.randn(N, 64, generator=g) * 0.1
+    d = lambda t: t.double()                                                             # noqa: E731
+    ref = ops_ref.fc_fwd_multi([(d(slab.transpose(0, 1)), d(w1), d(b1), None), (d(fp), d(w2), d(b2), idx)], 1)
+    c = lambda t: t.cuda()                                                               # noqa: E731
+    got = ops.fc_fwd_multi([(c(slab).transpose(0, 1), c(w1), c(b1), None), (c(fp), c(w2), c(b2), c(idx))], 1)
+    assert got.shape == (N, rows, 128)
+    torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
 def test_fc_concat_autograd_matches_torch():
     from deeprl_network_amd import ops
     N, rows = 8, 1000

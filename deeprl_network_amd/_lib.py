@@ -97,6 +97,9 @@ SIGNATURES = {
     'nmarl_nbr_action_value_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p],
     'nmarl_bias_act': [_i64, _i32, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_a2c_loss_chunks': [_i64, _i32],
+    'nmarl_a2c_loss_fwd': [_i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p],
+    'nmarl_a2c_loss_bwd': [_i64, _i32, _i32, _p, _i64, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p],
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],
     'nmarl_nstep_return': [_i64, _i32, _i32, _p, _p, _p, _p, C.c_double, C.c_double, _p, _p, _p, _p],
     'nmarl_rmsprop_tf_clip': [_i32, _i64, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p],

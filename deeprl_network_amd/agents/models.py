@@ -224,13 +224,19 @@ class IA2C:
         N, T, E = self.n_agent, self.n_step, self.E
         p = self.policy
         # the critic's neighbour one-hots (policies.py:66-68) are gathered from the action bytes inside the op
-        pi, v = p.heads(Hs, self.buf_act.view(T * E, N))                      # [N,T*E,A], [N,T*E]
-        acts = self.buf_act.view(T * E, N).t().long().unsqueeze(-1)          # [N, T*E, 1]
+        action = self.buf_act.view(T * E, N)
+        logits, v = p.heads(Hs, action)                                       # [N,T*E,A], [N,T*E]
+        adv = self.Adv.view(N, T * E)
+        R = self.R.view(N, T * E)
+        if ops.a2c_loss_supported(self.n_a):
+            per_agent, terms = ops.a2c_loss(logits, v, action, adv, R, self.v_coef, self.e_coef)
+            self.last_loss = (terms[:, 0], terms[:, 1], terms[:, 2], per_agent.detach())
+            return per_agent.sum()
+        pi = torch.softmax(logits, dim=-1)
+        acts = action.t().long().unsqueeze(-1)                               # [N, T*E, 1]
         log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
         entropy = -(pi * log_pi).sum(-1)
         logp_a = log_pi.gather(-1, acts).squeeze(-1)
-        adv = self.Adv.view(N, T * E)
-        R = self.R.view(N, T * E)
         policy_loss = -(logp_a * adv).mean(-1)                               # [N]
         value_loss = (R - v).pow(2).mean(-1) * 0.5 * self.v_coef
         entropy_loss = -entropy.mean(-1) * self.e_coef

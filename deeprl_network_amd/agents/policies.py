@@ -157,19 +157,17 @@ class BatchedPolicy:
 
     def heads(self, h, action):
         """Actor and critic heads of the update for all rows: h [N,rows,H], action [rows,N] u8 (env-major bytes; the
-        critic's neighbour one-hots are gathered from them) -> (pi [N,rows,A], v [N,rows]).  H = 64: one skinny
+        critic's neighbour one-hots are gathered from them) -> (logits [N,rows,A], v [N,rows]).  H = 64: one skinny
         GEMM forward, one streaming pass backward (ops.heads); otherwise plain batched GEMMs."""
         p = self.params
         H, A = self.n_h, self.n_a
         if ops.heads_supported(h, A, self.nbr_idx):
-            logits, v = ops.heads(h, p['pi_w'], p['pi_b'], p['v_w'], p['v_b'], action, self.nbr_idx, A)
-            return torch.softmax(logits, dim=-1), v
+            return ops.heads(h, p['pi_w'], p['pi_b'], p['v_w'], p['v_b'], action, self.nbr_idx, A)
         w = torch.cat([p['pi_w'], p['v_w'][:, :H]], dim=2)
         b = torch.cat([p['pi_b'], p['v_b']], dim=1)
         out = torch.baddbmm(b.unsqueeze(1), h, w)
         na = ops.nbr_onehot(action, self.nbr_idx, A)
-        v = out[..., A] + torch.bmm(na, p['v_w'][:, H:]).squeeze(-1)
-        return torch.softmax(out[..., :A], dim=-1), v
+        return out[..., :A], out[..., A] + torch.bmm(na, p['v_w'][:, H:]).squeeze(-1)
 
     def value(self, h, na_onehot, out=None):
         """v = [h, onehot(neighbour actions)] @ Wv + b (policies.py:59-77), without the concat;

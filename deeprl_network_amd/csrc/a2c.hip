@@ -253,6 +253,104 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(
     }
 }
 
+// A2C loss of Policy.prepare_loss (policies.py:20-30; NCMultiAgentPolicy 232-255) for all agents and rows:
+//   pi = softmax(logits); log_pi = log(clip(pi, 1e-10, 1)); H = -sum pi log_pi
+//   policy = -mean(log_pi[a] ADV);  value = 0.5 v_coef mean((R - v)^2);  entropy = -e_coef mean(H)
+// fwd: per-block partial sums of the three terms -> a2c_loss_reduce_kernel (fixed order).  bwd: the closed-form
+// gradient w.r.t. logits and v (clip passes the gradient where 1e-10 <= pi), scaled by the per-agent upstream g.
+// logits [N,rows,A] with row pitch l_row (a column block of the heads' GEMM output), everything else [N,rows];
+// action [rows,N] u8.  One pass each instead of ~35 elementwise / reduction launches over [N,rows,A].
+constexpr int LOSS_MAXA = 8;
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void a2c_loss_kernel(const int64_t rows, const int N, const int A, const int rows_per_block,
+                                                       const float* __restrict__ logits, const int64_t l_sn, const int64_t l_row,
+                                                       const float* __restrict__ v, const uint8_t* __restrict__ action,
+                                                       const float* __restrict__ adv, const float* __restrict__ R,
+                                                       const float v_coef, const float e_coef, const float* __restrict__ g_up,
+                                                       float* __restrict__ partial, float* __restrict__ dlogits,
+                                                       float* __restrict__ dv) {
+    const int n = blockIdx.y;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    const float inv_m = 1.0f / (float)rows;
+    const float gn = BWD ? g_up[n] * inv_m : 0.0f;
+    float s_pol = 0.0f, s_val = 0.0f, s_ent = 0.0f;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) {
+        const float* l = logits + (int64_t)n * l_sn + r * l_row;
+        float p[LOSS_MAXA], lp[LOSS_MAXA];
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < LOSS_MAXA; ++k) {
+            p[k] = k < A ? l[k] : -INFINITY;
+            m = fmaxf(m, p[k]);
+        }
+        float z = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LOSS_MAXA; ++k) {
+            p[k] = k < A ? expf(p[k] - m) : 0.0f;
+            z += p[k];
+        }
+        const int a = action[r * N + n];
+        float H = 0.0f, lpa = 0.0f, pa = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LOSS_MAXA; ++k) {
+            p[k] = p[k] / z;
+            lp[k] = logf(fminf(fmaxf(p[k], 1e-10f), 1.0f));
+            if (k < A) H -= p[k] * lp[k];
+            if (k == a) { lpa = lp[k]; pa = p[k]; }
+        }
+        const int64_t i = (int64_t)n * rows + r;
+        const float ad = adv[i], dR = R[i] - v[i];
+        if (!BWD) {
+            s_pol -= lpa * ad;
+            s_val += dR * dR;
+            s_ent += H;
+        } else {
+            // g_k = dH/dpi_k = -(log_pi_k + c_k), c_k = [pi_k >= 1e-10];  dH/dlogit_j = pi_j (g_j - sum_k pi_k g_k)
+            float gbar = 0.0f;
+#pragma unroll
+            for (int k = 0; k < LOSS_MAXA; ++k)
+                if (k < A) gbar += p[k] * -(lp[k] + (p[k] >= 1e-10f ? 1.0f : 0.0f));
+            const float ca = pa >= 1e-10f ? 1.0f : 0.0f;
+            float* dl = dlogits + i * A;
+#pragma unroll
+            for (int k = 0; k < LOSS_MAXA; ++k)
+                if (k < A) {
+                    const float gk = -(lp[k] + (p[k] >= 1e-10f ? 1.0f : 0.0f));
+                    const float d_pol = -ad * ca * ((k == a ? 1.0f : 0.0f) - p[k]);
+                    const float d_ent = -e_coef * p[k] * (gk - gbar);
+                    dl[k] = gn * (d_pol + d_ent);
+                }
+            dv[i] = -gn * v_coef * dR;
+        }
+    }
+    if (!BWD) {
+        __shared__ float red[4][3];
+        for (int off = 32; off > 0; off >>= 1) {
+            s_pol += __shfl_down(s_pol, off, 64);
+            s_val += __shfl_down(s_val, off, 64);
+            s_ent += __shfl_down(s_ent, off, 64);
+        }
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) { red[w][0] = s_pol; red[w][1] = s_val; red[w][2] = s_ent; }
+        __syncthreads();
+        if (threadIdx.x < 3)
+            partial[((int64_t)n * gridDim.x + blockIdx.x) * 3 + threadIdx.x] =
+                ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(64) void a2c_loss_reduce_kernel(const int C, const int64_t rows, const float v_coef, const float e_coef,
+                                                             const float* __restrict__ partial, float* __restrict__ out /*[N,3]*/) {
+    const int n = blockIdx.x, k = threadIdx.x;
+    if (k >= 3) return;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += partial[((int64_t)n * C + c) * 3 + k];
+    s /= (float)rows;
+    out[n * 3 + k] = k == 0 ? s : k == 1 ? s * 0.5f * v_coef : -s * e_coef;
+}
+
 inline int grid_x(int64_t n, int cap = 2048) {
     int64_t b = (n + 255) / 256;
     return (int)(b < cap ? (b > 0 ? b : 1) : cap);
@@ -345,5 +443,40 @@ extern "C" int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float
     hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS, G), dim3(256), 0, s, P, g, scratch);
     hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_x(P, 1024), G), dim3(256), 0, s, P, w, g, ms, scratch, lr_dev, lr, rho,
                        eps, max_norm, grad_scale, grad_norm_out);
+    return nmarl_check_launch();
+}
+
+static int loss_chunks(int64_t rows, int N) {
+    int64_t c = (rows * N + 4095) / 4096;            // ~16 rows per thread
+    const int64_t cap = 2048 / (N > 0 ? N : 1) + 1;
+    c = c > cap ? cap : c;
+    return (int)(c < 1 ? 1 : c);
+}
+
+extern "C" int nmarl_a2c_loss_chunks(int64_t rows, int32_t N) { return rows > 0 && N > 0 ? loss_chunks(rows, N) : 0; }
+
+extern "C" int nmarl_a2c_loss_fwd(int64_t rows, int32_t N, int32_t A, const float* logits, int64_t l_sn, int64_t l_row,
+                                  const float* v, const uint8_t* action, const float* adv, const float* R, float v_coef,
+                                  float e_coef, float* partial, float* loss_out, void* stream) {
+    if (rows <= 0 || N <= 0 || A <= 0 || A > LOSS_MAXA || l_row < A || !logits || !v || !action || !adv || !R || !partial || !loss_out)
+        return NMARL_EINVAL;
+    const int C = loss_chunks(rows, N);
+    const int rpb = (int)((rows + C - 1) / C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(a2c_loss_kernel<false>, dim3(C, N), dim3(256), 0, st, rows, N, A, rpb, logits, l_sn, l_row, v, action, adv, R,
+                       v_coef, e_coef, (const float*)nullptr, partial, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(a2c_loss_reduce_kernel, dim3(N), dim3(64), 0, st, C, rows, v_coef, e_coef, partial, loss_out);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_a2c_loss_bwd(int64_t rows, int32_t N, int32_t A, const float* logits, int64_t l_sn, int64_t l_row,
+                                  const float* v, const uint8_t* action, const float* adv, const float* R, float v_coef,
+                                  float e_coef, const float* g_up, float* dlogits, float* dv, void* stream) {
+    if (rows <= 0 || N <= 0 || A <= 0 || A > LOSS_MAXA || l_row < A || !logits || !v || !action || !adv || !R || !g_up || !dlogits || !dv)
+        return NMARL_EINVAL;
+    const int C = loss_chunks(rows, N);
+    const int rpb = (int)((rows + C - 1) / C);
+    hipLaunchKernelGGL(a2c_loss_kernel<true>, dim3(C, N), dim3(256), 0, static_cast<hipStream_t>(stream), rows, N, A, rpb, logits,
+                       l_sn, l_row, v, action, adv, R, v_coef, e_coef, g_up, (float*)nullptr, dlogits, dv);
     return nmarl_check_launch();
 }

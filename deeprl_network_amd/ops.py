@@ -341,17 +341,19 @@ def thin_linear_bwd(h, dy, w, dy2=None):
     [N,rows,O], or dy [N,rows,O-1] for the leading columns plus dy2 [N,rows] for the last one."""
     N, rows, H = h.shape
     O = w.shape[2]
-    h, dy = h.contiguous(), dy.contiguous()
+    if h.stride(2) != 1 or h.stride(1) != H:       # agent-strided panels are read in place (the sequence buffer's slots)
+        h = h.contiguous()
+    dy = dy.contiguous()
     if dy.shape[2] + (0 if dy2 is None else 1) != O:
         raise _lib.NmarlError('thin_linear_bwd: dy columns do not add up to w columns')
     C_ = lib.nmarl_fc_bwd_chunks(rows, N)
     partial = torch.empty(N, C_, H + 1, O, dtype=F32, device=h.device)
-    dh = torch.empty_like(h)
+    dh = torch.empty(N, rows, H, dtype=F32, device=h.device)
     dw = torch.empty(N, H, O, dtype=F32, device=h.device)
     db = torch.empty(N, O, dtype=F32, device=h.device)
     wp, ws = _head_param(w, 'thin_linear_bwd')
     d2 = None if dy2 is None else dy2.contiguous()
-    check(lib.nmarl_thin_linear_bwd(rows, N, H, O, ptr(h, F32), rows * H, ptr(dy, F32), rows * dy.shape[2], ptr(d2, F32), rows,
+    check(lib.nmarl_thin_linear_bwd(rows, N, H, O, ptr(h, F32, strided=True), h.stride(0), ptr(dy, F32), rows * dy.shape[2], ptr(d2, F32), rows,
                                     wp, ws, ptr(partial), ptr(dh), rows * H, ptr(dw), H * O, ptr(db), O, stream()),
           'nmarl_thin_linear_bwd')
     return dh, dw, db
@@ -605,6 +607,53 @@ def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0, step_de
                                    ptr(step_dev, torch.int64), ptr(out, torch.uint8), stream()),
           'nmarl_sample_actions')
     return out
+
+
+A2C_LOSS_MAX_A = 8
+
+
+class _A2CLoss(torch.autograd.Function):
+    """(total [N], terms [N,3]) = per-agent (policy, value, entropy) loss terms of Policy.prepare_loss (policies.py:20-30) from logits
+    [N,rows,A] (any row pitch), v / adv / R [N,rows] and the env-major action bytes [rows,N]: one streaming pass
+    forward, one backward (closed-form d/dlogits, d/dv), instead of the softmax / log / clamp / gather / mean chain."""
+
+    @staticmethod
+    def forward(ctx, logits, v, action, adv, R, v_coef, e_coef):
+        N, rows, A = logits.shape
+        if logits.stride(2) != 1:
+            logits = logits.contiguous()
+        v, adv, R = v.contiguous(), adv.contiguous(), R.contiguous()
+        C_ = lib.nmarl_a2c_loss_chunks(rows, N)
+        partial = torch.empty(N, C_, 3, dtype=F32, device=logits.device)
+        out = torch.empty(N, 3, dtype=F32, device=logits.device)
+        check(lib.nmarl_a2c_loss_fwd(rows, N, A, ptr(logits, F32, strided=True), logits.stride(0), logits.stride(1), ptr(v, F32),
+                                     ptr(action, torch.uint8), ptr(adv, F32), ptr(R, F32), v_coef, e_coef, ptr(partial), ptr(out),
+                                     stream()), 'nmarl_a2c_loss_fwd')
+        ctx.save_for_backward(logits, v, action, adv, R)
+        ctx.coefs = (v_coef, e_coef)
+        ctx.mark_non_differentiable(out)
+        return out.sum(dim=1), out            # (differentiable per-agent total [N], the three terms for logging)
+
+    @staticmethod
+    def backward(ctx, g, _):
+        logits, v, action, adv, R = ctx.saved_tensors
+        N, rows, A = logits.shape
+        gn = g.contiguous()
+        dlogits = torch.empty(N, rows, A, dtype=F32, device=logits.device)
+        dv = torch.empty(N, rows, dtype=F32, device=logits.device)
+        check(lib.nmarl_a2c_loss_bwd(rows, N, A, ptr(logits, F32, strided=True), logits.stride(0), logits.stride(1), ptr(v, F32),
+                                     ptr(action, torch.uint8), ptr(adv, F32), ptr(R, F32), ctx.coefs[0], ctx.coefs[1],
+                                     ptr(gn, F32), ptr(dlogits), ptr(dv), stream()), 'nmarl_a2c_loss_bwd')
+        return dlogits, dv, None, None, None, None, None
+
+
+def a2c_loss_supported(n_a):
+    return n_a <= A2C_LOSS_MAX_A
+
+
+def a2c_loss(logits, v, action, adv, R, v_coef, e_coef):
+    """-> per-agent total loss [N] (differentiable) and the detached (policy, value, entropy) terms [N,3]."""
+    return _A2CLoss.apply(logits, v, action, adv, R, float(v_coef), float(e_coef))
 
 
 def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, adv_out=None):

@@ -344,6 +344,21 @@ int nmarl_sample_actions(int64_t E, int32_t N, int32_t A, const float* pi, const
                          uint64_t seed, int64_t env_id_base, int64_t step, const int64_t* step_dev,
                          uint8_t* action, void* stream);
 /*
+ * A2C loss of Policy.prepare_loss (policies.py:20-30, 232-255) for all agents over rows = T*E:
+ *   pi = softmax(logits); log_pi = log(clip(pi,1e-10,1)); H = -sum pi log_pi
+ *   loss_out[n] = { -mean(log_pi[a] ADV),  0.5 v_coef mean((R-v)^2),  -e_coef mean(H) }
+ * logits [N,rows,A] (A <= 8; agent stride l_sn, row pitch l_row: a column block of the heads' output), v / adv / R
+ * [N,rows], action [rows,N] u8.  bwd: dlogits [N,rows,A], dv [N,rows] = g_up[n] * d(sum of the three terms), the
+ * clip passing the gradient where pi >= 1e-10 (tf.clip_by_value).  partial: [N, nmarl_a2c_loss_chunks(rows,N), 3].
+ */
+int nmarl_a2c_loss_chunks(int64_t rows, int32_t N);
+int nmarl_a2c_loss_fwd(int64_t rows, int32_t N, int32_t A, const float* logits, int64_t l_sn, int64_t l_row,
+                       const float* v, const uint8_t* action, const float* adv, const float* R, float v_coef,
+                       float e_coef, float* partial, float* loss_out, void* stream);
+int nmarl_a2c_loss_bwd(int64_t rows, int32_t N, int32_t A, const float* logits, int64_t l_sn, int64_t l_row,
+                       const float* v, const uint8_t* action, const float* adv, const float* R, float v_coef,
+                       float e_coef, const float* g_up, float* dlogits, float* dv, void* stream);
+/*
  * n-step return and advantage -- OnPolicyBuffer._add_R_Adv / _add_s_R_Adv
  * (agents/utils.py:763-775, 800-816) and the MultiAgent variants (837-855,
  * 888-912).  r [T,E] (alpha < 0: global reward) or [T,E,N] (alpha >= 0: spatial

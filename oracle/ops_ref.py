@@ -266,6 +266,24 @@ def sample_actions(pi, out, mode, u=None, seed=0, env_id_base=0, step=0, step_de
     return out
 
 
+def a2c_loss_supported(n_a):
+    return True
+
+
+def a2c_loss(logits, v, action, adv, R, v_coef, e_coef):
+    """Policy.prepare_loss (policies.py:20-30; 232-255), per agent, batch mean over rows; plain autograd."""
+    pi = torch.softmax(logits, dim=-1)
+    acts = action.t().long().unsqueeze(-1)                               # [N, rows, 1]
+    log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
+    entropy = -(pi * log_pi).sum(-1)
+    logp_a = log_pi.gather(-1, acts).squeeze(-1)
+    policy_loss = -(logp_a * adv).mean(-1)
+    value_loss = (R - v).pow(2).mean(-1) * 0.5 * v_coef
+    entropy_loss = -entropy.mean(-1) * e_coef
+    terms = torch.stack([policy_loss, value_loss, entropy_loss], dim=1)
+    return terms.sum(dim=1), terms.detach()
+
+
 def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, adv_out=None):
     """OnPolicyBuffer._add_R_Adv / _add_s_R_Adv (agents/utils.py:763-775, 800-816) per (agent, replica)."""
     T, N, E = v.shape

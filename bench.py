@@ -283,7 +283,10 @@ def main():
                 out['roofline_lstm_step'] = {
                     'kernel': 'lstm_step_mfma16_kernel (nmarl_lstm_step_fused[_head])', 'bound': 'hbm',
                     'achieved': bytes_l / us_l / 1e3, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                    'frac': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS, 'traffic': None, 'bytes_per_launch': bytes_l,
+                    'frac': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
+                    'traffic': (lambda t: None if t[0] is None or n_agent * E != 8 * 4096 else t[0] * n_agent * E)(
+                        pmc_traffic('lstm_step_N8_E4096')),
+                    'traffic_source': pmc_traffic('lstm_step_N8_E4096')[1], 'bytes_per_launch': bytes_l,
                     'us_per_launch': us_l, 'launches_per_batch': 3 * n_step + 2,
                     'mfma_flops_per_launch': 2 * n_agent * E * 64 * 256,
                     'how': 'hipGraph of 60 in-place fused steps on [N,E,64] state with the model weights, 10 replays '

@@ -45,4 +45,15 @@ ga = [torch.randint(0, 5, (Eg, 25), dtype=torch.uint8, device='cuda') for _ in r
 for s in range(6):
     genv.step(ga[s % 2], auto_reset=True)
 torch.cuda.synchronize()
+# the fused MFMA LSTM step at the bench shape ([8, 4096, 64] state; in place like the rollout) and its head variants
+from deeprl_network_amd import ops
+N, El, H, A = 8, 4096, 64, 4
+g = torch.Generator().manual_seed(0)
+r = lambda *s: torch.randn(*s, generator=g).cuda()                                   # noqa: E731
+h, c, z = r(N, El, H) * 0.3, r(N, El, H) * 0.3, r(N, El, 4 * H)
+wh, b = r(N, H, 4 * H) * 0.1, r(N, 4 * H) * 0.1
+done = torch.zeros(El, device='cuda')
+for s in range(12):
+    ops.lstm_step_fused(h, wh, b, z, None, c, done, None, c, h)
+torch.cuda.synchronize()
 print('done', E, Eg)

@@ -44,9 +44,18 @@ for key, part, E, balg in (('cacc_step_E2p21', 'cacc_step_kernel<256', 1 << 21, 
     s.update(replicas=E, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / E,
              algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / E / balg)
     res['kernels'][key] = s
+try:        # fused MFMA LSTM step: "replica" = one (agent, replica) row of 64 units, 2048 algorithmic bytes
+    s = stat('lstm_step_mfma16_kernel<false, 0>')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 8 * 4096
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=2048, traffic_over_algorithmic=traffic / rows / 2048)
+    res['kernels']['lstm_step_N8_E4096'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no lstm step in this collection:', ex)
 json.dump(res, open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
 with open('profiles/%s_pmc_traffic.md' % tag, 'w') as f:
-    f.write('# HBM traffic of the env-step kernels from rocprofv3 PMC passes\n\n'
+    f.write('# HBM traffic of the env-step kernels (and the fused LSTM step) from rocprofv3 PMC passes\n\n'
             'commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/pmc_env.py` and the same with '
             '`--pmc WRITE_SIZE` (separate runs).\n\ncalibration on a 1 GiB `copy_` in the same runs: FETCH_SIZE = %.0f KiB '
             '(x%.2f needed), WRITE_SIZE = %.0f KiB (x%.2f) -> the guide\'s gfx950 x2 FETCH correction is applied, WRITE as is.\n\n'

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const i
         if (row0 >= rows) break;
         stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll(FMAX <= 16 ? 4 : FMAX <= 32 ? 2 : 1)
         for (int rr = rl; rr < TILE; rr += 4) {
             float acc = 0.0f;
 #pragma unroll
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
             }
         }
         __syncthreads();
-#pragma unroll 4
+#pragma unroll(FMAX <= 16 ? 4 : FMAX <= 32 ? 2 : 1)
         for (int rr = rl; rr < TILE; rr += 4) {
             float acc = 0.0f;
 #pragma unroll
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
         if (row0 >= rows) break;
         stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
         __syncthreads();
-#pragma unroll 4
+#pragma unroll(FMAX <= 16 ? 4 : FMAX <= 32 ? 2 : 1)
         for (int rr = rl; rr < TILE; rr += 4) {
             const int64_t row = row0 + rr;
             float g = 0.0f;

@@ -40,22 +40,28 @@ class IA2C:
     uses_fingerprint = False         # forward() receives neighbour policies `ps` (MA2C family)
 
     def __init__(self, n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, model_config,
-                 seed=0, num_envs=1, device='cuda', dist_group=None, n_feat=None):
+                 seed=0, num_envs=1, device='cuda', dist_group=None, n_feat=None, n_feat_ls=None):
+        """The reference's constructor (models.py:20-24) + batching arguments.  n_feat_ls: per-agent OWN observation
+        widths of heterogeneous systems (agents with different action counts, `identical_agent = False`,
+        models.py:89-96).  MA2C envs report them as n_s_ls; the IA2C family's n_s_ls are the concatenated widths, from
+        which the own widths are recovered when the system (I + neighbor_mask) x = n_s_ls determines them."""
         self.name = getattr(self, 'name', 'ia2c')
         self._init_algo(n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, seed,
-                        model_config, num_envs, device, dist_group, n_feat)
+                        model_config, num_envs, device, dist_group, n_feat, n_feat_ls)
 
     # ------------------------------------------------------------------ construction
     def _init_algo(self, n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, seed,
-                   model_config, num_envs, device, dist_group, n_feat):
-        if max(n_a_ls) != min(n_a_ls):
-            raise NotImplementedError('heterogeneous action spaces (Monaco net) are out of scope: SURVEY.md 8f.4')
-        self.n_s_ls, self.n_a_ls = list(n_s_ls), list(n_a_ls)
-        self.n_a = n_a_ls[0]
+                   model_config, num_envs, device, dist_group, n_feat, n_feat_ls=None):
+        self.n_s_ls, self.n_a_ls = [int(x) for x in n_s_ls], [int(x) for x in n_a_ls]
+        self.n_a = max(self.n_a_ls)
         self.neighbor_mask = np.asarray(neighbor_mask)
         self.distance_mask = np.asarray(distance_mask)
         self.n_agent = len(self.neighbor_mask)
-        self.identical_agent = True
+        self.identical_agent = max(self.n_a_ls) == min(self.n_a_ls)          # models.py:89-96
+        self.n_feat_ls = None
+        if not self.identical_agent:
+            self.n_feat_ls = self._own_widths(n_feat_ls)
+            n_feat = max(self.n_feat_ls)
         self.coop_gamma = float(coop_gamma)
         self.reward_clip = model_config.getfloat('reward_clip')
         self.reward_norm = model_config.getfloat('reward_norm')
@@ -76,7 +82,8 @@ class IA2C:
             n_feat = self.n_s_ls[0] if self._is_ma2c() else self.n_s_ls[0] // (1 + int(m[0]))
         self.n_feat = int(n_feat)
         self.policy = self.policy_cls(self.n_feat, self.n_a, self.neighbor_mask, n_fc=self.n_fc,
-                                      n_h=self.n_lstm, device=self.device)
+                                      n_h=self.n_lstm, device=self.device, n_feat_ls=self.n_feat_ls,
+                                      n_a_ls=None if self.identical_agent else self.n_a_ls)
         self.policy.params.init_reference_order()       # consumes np.random like the reference's ortho_init
         self.n_s = self.n_s_ls[0]
         N, E, H, T = self.n_agent, self.E, self.n_lstm, self.n_step
@@ -85,7 +92,12 @@ class IA2C:
         # recurrent state [c,h] of policies.py:151-154; static buffers (hipGraph-friendly), updated in place
         self.h_fw, self.c_fw, self.h_bw, self.c_bw = z(N, E, H), z(N, E, H), z(N, E, H), z(N, E, H)
         self._h2, self._c2 = z(N, E, H), z(N, E, H)        # scratch of the value re-step (quirk Q1)
-        self._fp_eval = torch.full((N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
+        # a fresh episode's fingerprint: uniform over the agent's OWN actions (cacc_env.py:184, atsc_env.py:498-499)
+        fp0 = np.zeros((N, 1, self.n_a), dtype=np.float32)
+        for i in range(N):
+            fp0[i, 0, :self.n_a_ls[i]] = 1.0 / self.n_a_ls[i]
+        self.fp_uniform = torch.from_numpy(fp0).to(d)
+        self._fp_eval = self.fp_uniform.expand(N, E, self.n_a).clone()
         self.t = 0
         self.total_step = total_step
         self.sess = None                                  # the reference Trainer reads model.sess (TF leak)
@@ -94,6 +106,34 @@ class IA2C:
 
     def _is_ma2c(self):
         return self.name.startswith('ma2c')
+
+    def _own_widths(self, n_feat_ls):
+        """Own observation width of every agent of a heterogeneous system."""
+        if n_feat_ls is not None:
+            return [int(x) for x in n_feat_ls]
+        if self._is_ma2c():
+            return list(self.n_s_ls)                       # MA2C envs hand over the own features only
+        a = np.eye(self.n_agent) + (self.neighbor_mask == 1)
+        if abs(np.linalg.det(a)) < 1e-9:
+            raise ValueError('heterogeneous IA2C: own observation widths are not determined by n_s_ls; pass n_feat_ls')
+        x = np.linalg.solve(a, np.asarray(self.n_s_ls, dtype=np.float64))
+        if np.abs(x - np.round(x)).max() > 1e-6 or x.min() < 1:
+            raise ValueError('heterogeneous IA2C: n_s_ls is not a sum of own + neighbour widths; pass n_feat_ls')
+        return [int(round(v)) for v in x]
+
+    def _pad_policies(self, ps):
+        """list of N probability vectors (ragged for heterogeneous agents, models.py:229-236) -> [N,1,A] f32."""
+        out = np.zeros((self.n_agent, 1, self.n_a), dtype=np.float32)
+        for i in range(self.n_agent):
+            v = np.asarray(ps[i], dtype=np.float32).reshape(-1)
+            out[i, 0, :len(v)] = v
+        return torch.from_numpy(out).to(self.device)
+
+    def _unpad_policies(self, pi):
+        """[N,A] -> what the reference returns: an [N,A] array, or a list of ragged vectors (policies.py:314-316)."""
+        if self.identical_agent:
+            return pi
+        return [pi[i, :self.n_a_ls[i]] for i in range(self.n_agent)]
 
     @property
     def fp(self):
@@ -124,7 +164,7 @@ class IA2C:
         # the observation / policy produced at lock-step t, slot T is the bootstrap input and becomes
         # slot 0 of the next batch.
         self.buf_x = torch.zeros(T + 1, E, N, p.n_obs, dtype=F32, device=d)
-        self.buf_fp = torch.full((T + 1, N, E, self.n_a), 1.0 / self.n_a, dtype=F32, device=d)
+        self.buf_fp = self.fp_uniform.expand(T + 1, N, E, self.n_a).clone()
         self._pi_boot, self._v_boot = torch.zeros(N, E, self.n_a, dtype=F32, device=d), torch.zeros(N, E, dtype=F32, device=d)
         self.buf_act = torch.zeros(T, E, N, dtype=torch.uint8, device=d)
         self.buf_v = torch.zeros(T, N, E, dtype=F32, device=d)
@@ -149,12 +189,12 @@ class IA2C:
         if mask is None:
             for s in (self.h_fw, self.c_fw, self.h_bw, self.c_bw):
                 s.zero_()
-            self.fp.fill_(1.0 / self.n_a)
+            self.fp.copy_(self.fp_uniform.expand_as(self.fp))
         else:
             keep = (mask == 0).to(F32).view(1, -1, 1)
             for s in (self.h_fw, self.c_fw, self.h_bw, self.c_bw):
                 s.mul_(keep)
-            self.fp.mul_(keep).add_((1.0 - keep) / self.n_a)
+            self.fp.mul_(keep).add_((1.0 - keep) * self.fp_uniform)
 
     def _policy_step(self, obs, done, done_is_zero=False):
         """forward('p'): advances states_fw (policies.py:119-134); returns the pi LOGITS' softmax."""
@@ -228,6 +268,11 @@ class IA2C:
         logits, v = p.heads(Hs, action)                                       # [N,T*E,A], [N,T*E]
         adv = self.Adv.view(N, T * E)
         R = self.R.view(N, T * E)
+        if not self.identical_agent and not self.per_agent_optimizer:
+            # quirk Q6 (heterogeneous MA2C nets only, policies.py:241-254): the hetero branch builds prob_pi as
+            # [N,1,T], so `prob_pi * ADV` broadcasts to [N,N,T] and every agent's log-probability is weighted by the
+            # advantages of ALL agents: policy_loss = -sum_i mean_t(log pi_i[a] * sum_j ADV_j)
+            adv = adv.sum(dim=0, keepdim=True).expand(N, T * E).contiguous()
         if ops.a2c_loss_supported(self.n_a):
             per_agent, terms = ops.a2c_loss(logits, v, action, adv, R, self.v_coef, self.e_coef)
             self.last_loss = (terms[:, 0], terms[:, 1], terms[:, 2], per_agent.detach())
@@ -260,6 +305,8 @@ class IA2C:
                                 masked_steps=self.masked_steps)
         loss = self._loss(Hs)
         loss.backward()
+        if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)
+            ps.grad.mul_(ps.mask)
         scale = 1.0
         if self.dist_group is not None:
             import torch.distributed as dist
@@ -283,26 +330,33 @@ class IA2C:
 
     # ------------------------------------------------------------------ reference API (E = 1)
     def _obs_to_slab(self, obs):
-        """list of N 1-D arrays (reference env) -> [1,N,n_obs] slab (+ fingerprints for ia2c_fp)."""
+        """list of N 1-D arrays (reference env) -> [1,N,n_obs] slab (+ fingerprints for ia2c_fp).  The slab has one
+        n_feat-wide slot per (own, neighbour 1, ..): agents with narrower observations are zero padded inside their
+        slots (heterogeneous systems), the reference's tightly concatenated vectors are scattered accordingly."""
         p = self.policy
-        F = self.n_feat
+        F, A = self.n_feat, self.n_a
         slab = np.zeros((1, self.n_agent, p.n_obs), dtype=np.float32)
         fp = None
+        if not self._is_ma2c() and self.uses_fingerprint_obs():
+            fp = np.zeros((self.n_agent, 1, p.n_na), dtype=np.float32)
         for i in range(self.n_agent):
             o = np.asarray(obs[i], dtype=np.float32)
-            w = F * (1 + p.nbr_cnt[i]) if not self._is_ma2c() else F
-            slab[0, i, :w] = o[:w]
+            slab[0, i, :p.n_own[i]] = o[:p.n_own[i]]
+            if self._is_ma2c():
+                continue
+            pos = p.n_own[i]
+            for k, j in enumerate(p.nbrs[i]):
+                slab[0, i, (k + 1) * F:(k + 1) * F + p.n_own[j]] = o[pos:pos + p.n_own[j]]
+                pos += p.n_own[j]
+            if fp is not None:
+                for k, j in enumerate(p.nbrs[i]):
+                    fp[i, 0, k * A:k * A + p.n_a_ls[j]] = o[pos:pos + p.n_a_ls[j]]
+                    pos += p.n_a_ls[j]
         slab = torch.from_numpy(slab).to(self.device)
         if self._is_ma2c():
             # MA2C envs hand over the own features only; neighbours are gathered here
             x = slab[:, :, :F].transpose(0, 1).contiguous()                   # [N,1,F]
             slab = torch.cat([x, ops.nbr_gather(x, p.nbr_idx)], dim=-1).transpose(0, 1).contiguous()
-        elif self.uses_fingerprint_obs():
-            fp = np.zeros((self.n_agent, 1, p.n_na), dtype=np.float32)
-            for i in range(self.n_agent):
-                w = F * (1 + p.nbr_cnt[i])
-                tail = np.asarray(obs[i], dtype=np.float32)[w:]
-                fp[i, 0, :len(tail)] = tail
         return slab, fp
 
     def uses_fingerprint_obs(self):
@@ -326,7 +380,7 @@ class IA2C:
         d = self._done_t(done)
         if out_type.startswith('p'):
             pi = self._policy_step(slab, d)
-            return [x for x in pi[:, 0].cpu().numpy()]
+            return [x[:self.n_a_ls[i]] for i, x in enumerate(pi[:, 0].cpu().numpy())]
         v = self._value_step(slab, d, self._na_onehot_from_list(nactions))
         return [x for x in v[:, 0].cpu().numpy()]
 
@@ -416,7 +470,7 @@ class IA2C_FP(IA2C):
         """[N,1,m_max*A] gathered neighbour fingerprints -> [N,1,A] table (every agent's
         fingerprint appears in at least one neighbour's slot)."""
         p = self.policy
-        tab = np.full((self.n_agent, 1, self.n_a), 1.0 / self.n_a, dtype=np.float32)
+        tab = self.fp_uniform.cpu().numpy().copy()
         idx = p.nbr_idx.cpu().numpy()
         for i in range(self.n_agent):
             for k in range(p.m_max):
@@ -440,10 +494,10 @@ class MA2C_NC(IA2C):
     def forward(self, obs, done, ps, actions=None, out_type='p'):
         """MA2C_NC.forward (models.py:217-224): [N,A] ('p') or [N] ('v')."""
         slab, _ = self._obs_to_slab(obs)
-        self.fp.copy_(torch.as_tensor(np.asarray(ps, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
+        self.fp.copy_(self._pad_policies(ps))
         d = self._done_t(done)
         if out_type.startswith('p'):
-            return self._policy_step(slab, d)[:, 0].cpu().numpy()
+            return self._unpad_policies(self._policy_step(slab, d)[:, 0].cpu().numpy())
         a = torch.as_tensor(np.asarray(actions, dtype=np.uint8).reshape(1, -1)).to(self.device)
         na = ops.nbr_onehot(a, self.policy.nbr_idx, self.n_a)
         return self._value_step(slab, d, na)[:, 0].cpu().numpy()
@@ -452,7 +506,7 @@ class MA2C_NC(IA2C):
         t = self.t
         slab, _ = self._obs_to_slab(ob)
         self.buf_x[t].copy_(slab)
-        self.buf_fp[t].copy_(torch.as_tensor(np.asarray(p, dtype=np.float32).reshape(self.n_agent, 1, self.n_a)))
+        self.buf_fp[t].copy_(self._pad_policies(p))
         a = torch.as_tensor(np.asarray(action, dtype=np.uint8).reshape(1, -1)).to(self.device)
         self.buf_act[t].copy_(a)
         self.buf_v[t].copy_(torch.as_tensor(np.asarray(value, dtype=np.float32).reshape(-1, 1)))

@@ -42,10 +42,30 @@ def ortho_init(shape, scale=np.sqrt(2)):
     return (scale * q.reshape(shape)).astype(np.float32)
 
 
+class Layout:
+    """Where agent i's (ragged) reference variable sits inside its padded tensor: `rows` / `cols` = padded indices
+    in the reference's order (None = all), `exists` = the reference creates the variable at all, `fill` = value of
+    the padded entries (0; -1e30 for the logit bias of actions an agent does not have)."""
+
+    def __init__(self, rows=None, cols=None, exists=True, fill=0.0):
+        self.rows, self.cols, self.exists, self.fill = rows, cols, exists, fill
+
+
+def _layout(spec, i, shape):
+    """Normalise a phase entry's 4th field: None (full tensor), a callable returning an int (valid leading rows:
+    the homogeneous nets, where missing neighbours are trailing slots) or a Layout."""
+    lay = spec(i) if callable(spec) else spec
+    if lay is None:
+        return Layout()
+    if isinstance(lay, Layout):
+        return lay
+    return Layout(rows=np.arange(int(lay)))
+
+
 class ParamStore:
     """Flat [N, P] parameter / gradient / RMSProp-slot buffers with named strided views.
 
-    spec: list of phases; a phase is a list of (key, ref_name_fmt, padded_shape, ref_rows_fn)
+    spec: list of phases; a phase is a list of (key, ref_name_fmt, padded_shape, layout_fn)
     created agent by agent -- the order in which the reference's tf.get_variable calls
     consume np.random (SURVEY.md 8a footnote "Init draw order")."""
 
@@ -72,24 +92,60 @@ class ParamStore:
             w.requires_grad_(True)
             w.grad = self.grad[:, o:o + size].view(n_agent, *shape)
             self.views[key] = w
+        # trainable-entry mask: needed only when some padded entry could receive a gradient (a variable the reference
+        # does not create for an agent); None for the homogeneous nets, whose padded rows see zero inputs
+        self.mask = None
+        if any(not _layout(fn, i, shape).exists for phase in phases for _, _, shape, fn in phase for i in range(n_agent)):
+            host = np.zeros((n_agent, self.P), dtype=np.float32)
+            for i, key, o, size, shape, lay in self._entries():
+                if lay.exists:
+                    blk = np.zeros(shape, dtype=np.float32)
+                    self._region(blk, lay)[...] = 1.0
+                    host[i, o:o + size] = blk.ravel()
+            self.mask = torch.from_numpy(host).to(device)
 
     def __getitem__(self, key):
         return self.views[key]
+
+    def _entries(self):
+        """(agent, key, offset, size, padded shape, Layout) in the reference's variable creation order."""
+        for phase in self.phases:
+            for i in range(self.N):
+                for key, fmt, shape, fn in phase:
+                    o, size, _, _, _ = self.index[key]
+                    yield i, key, o, size, tuple(shape), _layout(fn, i, shape)
+
+    @staticmethod
+    def _region(blk, lay):
+        """View-like index of the reference-shaped part of a padded block (assignable through np.ix_)."""
+        rows = np.arange(blk.shape[0]) if lay.rows is None else np.asarray(lay.rows)
+        if blk.ndim == 1:
+            return _Region(blk, (rows,))
+        cols = np.arange(blk.shape[1]) if lay.cols is None else np.asarray(lay.cols)
+        return _Region(blk, np.ix_(rows, cols))
+
+    @staticmethod
+    def _ref_shape(shape, lay):
+        rows = shape[0] if lay.rows is None else len(lay.rows)
+        if len(shape) == 1:
+            return (rows,)
+        return (rows, shape[1] if lay.cols is None else len(lay.cols))
+
+    def _fmt_of(self, key):
+        return self.index[key][3]
 
     def init_reference_order(self):
         """Initialise like the reference: weights `w*` = sqrt(2)-orthogonal drawn in
         variable-creation order from np.random, biases 0 (agents/utils.py:69-71, 95-99, 141-162)."""
         host = np.zeros((self.N, self.P), dtype=np.float32)
-        for phase in self.phases:
-            for i in range(self.N):
-                for key, fmt, shape, rows_fn in phase:
-                    if key.endswith('_b'):
-                        continue
-                    o, size, _, _, _ = self.index[key]
-                    rows = rows_fn(i) if rows_fn else shape[0]
-                    blk = np.zeros(shape, dtype=np.float32)
-                    blk[:rows] = ortho_init((rows,) + tuple(shape[1:]))
-                    host[i, o:o + size] = blk.ravel()
+        for i, key, o, size, shape, lay in self._entries():
+            blk = np.full(shape, lay.fill, dtype=np.float32) if lay.fill else np.zeros(shape, dtype=np.float32)
+            if lay.exists:
+                if key.endswith('_b'):
+                    self._region(blk, lay)[...] = 0.0
+                else:
+                    self._region(blk, lay)[...] = ortho_init(self._ref_shape(shape, lay))
+            host[i, o:o + size] = blk.ravel()
         with torch.no_grad():
             self.flat.copy_(torch.from_numpy(host))
         self.ms.fill_(1.0)
@@ -100,28 +156,35 @@ class ParamStore:
         """[(reference variable name, np.ndarray with the reference's ragged shape)] in creation order."""
         host = self.flat.detach().cpu().numpy()
         out = []
-        for phase in self.phases:
-            for i in range(self.N):
-                for key, fmt, shape, rows_fn in phase:
-                    o, size, _, _, _ = self.index[key]
-                    rows = rows_fn(i) if rows_fn else shape[0]
-                    a = host[i, o:o + size].reshape(shape)[:rows]
-                    out.append((fmt % i, a.copy()))
+        for i, key, o, size, shape, lay in self._entries():
+            if lay.exists:
+                blk = host[i, o:o + size].reshape(shape)
+                out.append((self._fmt_of(key) % i, np.array(self._region(blk, lay).get())))
         return out
 
     def load_ref_variables(self, named):
         named = dict(named)
         host = self.flat.detach().cpu().numpy().copy()
-        for phase in self.phases:
-            for i in range(self.N):
-                for key, fmt, shape, rows_fn in phase:
-                    o, size, _, _, _ = self.index[key]
-                    rows = rows_fn(i) if rows_fn else shape[0]
-                    blk = np.zeros(shape, dtype=np.float32)
-                    blk[:rows] = named[fmt % i]
-                    host[i, o:o + size] = blk.ravel()
+        for i, key, o, size, shape, lay in self._entries():
+            blk = np.full(shape, lay.fill, dtype=np.float32) if lay.fill else np.zeros(shape, dtype=np.float32)
+            if lay.exists:
+                self._region(blk, lay)[...] = np.asarray(named[self._fmt_of(key) % i]).reshape(self._ref_shape(shape, lay))
+            host[i, o:o + size] = blk.ravel()
         with torch.no_grad():
             self.flat.copy_(torch.from_numpy(host))
+
+
+class _Region:
+    """blk[idx] with assignment and read through one object (np.ix_ fancy indices are not views)."""
+
+    def __init__(self, blk, idx):
+        self.blk, self.idx = blk, idx
+
+    def __setitem__(self, _, value):
+        self.blk[self.idx] = value
+
+    def get(self):
+        return self.blk[self.idx]
 
 
 class BatchedPolicy:
@@ -130,12 +193,28 @@ class BatchedPolicy:
     name = 'policy'
     fused_coupled = True          # coupled policies: use agents/sequence.py in the update
 
-    def __init__(self, n_feat, n_a, neighbor_mask, n_fc=64, n_h=64, device='cuda'):
+    def __init__(self, n_feat, n_a, neighbor_mask, n_fc=64, n_h=64, device='cuda', n_feat_ls=None, n_a_ls=None):
+        """n_feat / n_a: own observation width / action count of an agent -- the maxima when agents differ.
+        n_feat_ls / n_a_ls: the per-agent values of heterogeneous systems (`identical=False` nets of the reference:
+        agents/utils.py:220-341, 420-512, 602-719; policies.py:59-77 with na_dim_ls).  Those run as the SAME padded
+        batched network: observations, fingerprints, logits and one-hots are padded to the maxima, the reference's
+        ragged variables occupy the matching rows / columns of the padded tensors (ParamStore Layouts), actions an agent
+        does not have carry a -1e30 logit bias (probability exactly 0: never drawn, no entropy, no gradient), and
+        entries of variables the reference does not create (fingerprint / message layers of an agent without
+        neighbours) are masked out of the update."""
         self.device = torch.device(device)
         self.nbr_idx, self.nbr_cnt = ops.neighbor_table(neighbor_mask, self.device)
         self.N = len(self.nbr_cnt)
         self.m_max = self.nbr_idx.shape[1]
         self.n_feat, self.n_a, self.n_fc, self.n_h = n_feat, n_a, n_fc, n_h
+        self.n_own = [int(x) for x in n_feat_ls] if n_feat_ls is not None else [n_feat] * self.N
+        self.n_a_ls = [int(x) for x in n_a_ls] if n_a_ls is not None else [n_a] * self.N
+        # the reference's criterion (models.py:89-96): agents are "identical" iff their action counts agree
+        self.hetero = max(self.n_a_ls) != min(self.n_a_ls)
+        if self.hetero and (max(self.n_own) != n_feat or max(self.n_a_ls) != n_a):
+            raise ValueError('heterogeneous agents: n_feat / n_a must be the maxima of n_feat_ls / n_a_ls')
+        tab = self.nbr_idx.cpu().numpy()
+        self.nbrs = [[int(j) for j in tab[i] if j >= 0] for i in range(self.N)]
         self.n_obs = n_feat * (1 + self.m_max)          # gathered observation slab width
         self.n_na = n_a * self.m_max                    # neighbour one-hot width
         self.params = ParamStore(self.N, self._phases(), self.device)
@@ -144,10 +223,52 @@ class BatchedPolicy:
     def _m(self, i):
         return self.nbr_cnt[i]
 
+    def _L_slots(self, i):
+        """Rows of a weight over the gathered observation slab [own | nbr_1 | ... ] (slots n_feat wide)."""
+        F = self.n_feat
+        if not self.hetero:
+            return F * (1 + self._m(i))
+        rows = list(range(self.n_own[i]))
+        for k, j in enumerate(self.nbrs[i]):
+            rows += [(k + 1) * F + f for f in range(self.n_own[j])]
+        return Layout(rows=rows)
+
+    def _L_fp(self, i):
+        """Rows of a weight over the gathered neighbour fingerprints / action one-hots (slots n_a wide)."""
+        A = self.n_a
+        if not self.hetero:
+            return A * self._m(i)
+        return Layout(rows=[k * A + a for k, j in enumerate(self.nbrs[i]) for a in range(self.n_a_ls[j])],
+                      exists=self._m(i) > 0)
+
+    def _L_nbr(self, rows_per_nbr=None):
+        """A variable of the neighbour-facing layers: `rows_per_nbr` leading rows per neighbour (None: full tensor);
+        in heterogeneous nets it exists only for agents that have neighbours."""
+        def f(i):
+            m = self._m(i)
+            if not self.hetero:
+                return None if rows_per_nbr is None else rows_per_nbr * m
+            return Layout(rows=None if rows_per_nbr is None else list(range(rows_per_nbr * m)), exists=m > 0)
+        return f
+
+    def _L_blocks(self, width, n_blocks):
+        """LSTM input weight over `n_blocks` concatenated encodings: an agent without neighbours has the first only."""
+        def f(i):
+            if not self.hetero or self._m(i) > 0:
+                return None
+            return Layout(rows=list(range(width)))
+        return f
+
     def _head_phase(self, pi_fmt, v_fmt):
         H, A = self.n_h, self.n_a
-        return [('pi_w', pi_fmt + '/w', (H, A), None), ('pi_b', pi_fmt + '/b', (A,), None),
-                ('v_w', v_fmt + '/w', (H + self.n_na, 1), lambda i: H + A * self._m(i)),
+        if not self.hetero:
+            return [('pi_w', pi_fmt + '/w', (H, A), None), ('pi_b', pi_fmt + '/b', (A,), None),
+                    ('v_w', v_fmt + '/w', (H + self.n_na, 1), lambda i: H + A * self._m(i)),
+                    ('v_b', v_fmt + '/b', (1,), None)]
+        return [('pi_w', pi_fmt + '/w', (H, A), lambda i: Layout(cols=list(range(self.n_a_ls[i])))),
+                ('pi_b', pi_fmt + '/b', (A,), lambda i: Layout(rows=list(range(self.n_a_ls[i])), fill=-1e30)),
+                ('v_w', v_fmt + '/w', (H + self.n_na, 1),
+                 lambda i: Layout(rows=list(range(H)) + [H + r for r in self._L_fp(i).rows])),
                 ('v_b', v_fmt + '/b', (1,), None)]
 
     # -- heads: policies.py:50-77
@@ -299,7 +420,7 @@ class LstmPolicy(BatchedPolicy):
 
     def _phases(self):
         nf, H, F = self.n_fc, self.n_h, self.n_feat
-        return [[('fc_w', 'lstm_%d/fc/w', (self.n_obs, nf), lambda i: F * (1 + self._m(i))),
+        return [[('fc_w', 'lstm_%d/fc/w', (self.n_obs, nf), self._L_slots),
                  ('fc_b', 'lstm_%d/fc/b', (nf,), None),
                  ('lstm_wx', 'lstm_%d/lstm/wx', (nf, 4 * H), None),
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
@@ -322,11 +443,11 @@ class FPPolicy(LstmPolicy):
 
     def _phases(self):
         nf, H, F, A = self.n_fc, self.n_h, self.n_feat, self.n_a
-        return [[('fcs_w', 'lstm_%d/fcs/w', (self.n_obs, nf), lambda i: F * (1 + self._m(i))),
+        return [[('fcs_w', 'lstm_%d/fcs/w', (self.n_obs, nf), self._L_slots),
                  ('fcs_b', 'lstm_%d/fcs/b', (nf,), None),
-                 ('fcp_w', 'lstm_%d/fcp/w', (self.n_na, nf), lambda i: A * self._m(i)),
-                 ('fcp_b', 'lstm_%d/fcp/b', (nf,), None),
-                 ('lstm_wx', 'lstm_%d/lstm/wx', (2 * nf, 4 * H), None),
+                 ('fcp_w', 'lstm_%d/fcp/w', (self.n_na, nf), self._L_fp),
+                 ('fcp_b', 'lstm_%d/fcp/b', (nf,), self._L_nbr()),
+                 ('lstm_wx', 'lstm_%d/lstm/wx', (2 * nf, 4 * H), self._L_blocks(nf, 2)),
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
@@ -363,16 +484,14 @@ class NCMultiAgentPolicy(BatchedPolicy):
     def _phases(self):
         H, F, A = self.n_h, self.n_feat, self.n_a
         s = self.scope
-        return [[('w_msg', s + '/w_msg', (H * self.m_max, H), lambda i: H * self._m(i)),
-                 ('w_msg_b', s + '/b_msg', (H,), None),
-                 ('w_ob', s + '/w_ob', (self.n_obs, H), lambda i: F * (1 + self._m(i))),
-                 ('w_ob_b', s + '/b_ob', (H,), None),
-                 ('w_fp', s + '/w_fp', (self.n_na, H), lambda i: A * self._m(i)),
-                 ('w_fp_b', s + '/b_fp', (H,), None),
-                 ('wx_hid', s + '/wx_hid', (3 * H, 4 * H), None),
-                 ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
-                 ('hid_b', s + '/b_hid', (4 * H,), None)],
-                self._head_phase(self.name + '/pi_%d', self.name + '/v_%d')]
+        msg = [('w_msg', s + '/w_msg', (H * self.m_max, H), self._L_nbr(H)), ('w_msg_b', s + '/b_msg', (H,), self._L_nbr())]
+        ob = [('w_ob', s + '/w_ob', (self.n_obs, H), self._L_slots), ('w_ob_b', s + '/b_ob', (H,), None)]
+        fp = [('w_fp', s + '/w_fp', (self.n_na, H), self._L_fp), ('w_fp_b', s + '/b_fp', (H,), self._L_nbr())]
+        hid = [('wx_hid', s + '/wx_hid', (3 * H, 4 * H), self._L_blocks(H, 3)), ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
+               ('hid_b', s + '/b_hid', (4 * H,), None)]
+        # creation order: lstm_comm (agents/utils.py:141-162) msg, ob, fp; lstm_comm_hetero (258-281) ob, fp, msg
+        first = ob + fp + msg if self.hetero else msg + ob + fp
+        return [first + hid, self._head_phase(self.name + '/pi_%d', self.name + '/v_%d')]
 
     def _enc(self, xv, fp):
         """Observation + fingerprint thirds of s, already multiplied by their rows of wx_hid."""
@@ -424,9 +543,9 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     def _phases(self):
         H, F = self.n_h, self.n_feat
         s = self.scope
-        return [[('w_msg', s + '/w_msg', (H, H), None),
-                 ('w_msg_b', s + '/b_msg', (H,), None),
-                 ('w_ob', s + '/w_ob', (self.n_obs, H), lambda i: F * (1 + self._m(i))),
+        return [[('w_msg', s + '/w_msg', (H, H), self._L_nbr()),
+                 ('w_msg_b', s + '/b_msg', (H,), self._L_nbr()),
+                 ('w_ob', s + '/w_ob', (self.n_obs, H), self._L_slots),
                  ('w_ob_b', s + '/b_ob', (H,), None),
                  ('wx_hid', s + '/wx_hid', (H, 4 * H), None),
                  ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
@@ -467,7 +586,7 @@ class ConsensusPolicy(LstmPolicy):
         return [[('fc_w', 'cu/fc_%da/w', (F, H), None), ('fc_b', 'cu/fc_%da/b', (H,), None),
                  ('lstm_wx', 'cu/lstm_%da/wx', (H, 4 * H), None),
                  ('lstm_wh', 'cu/lstm_%da/wh', (H, 4 * H), None),
-                 ('lstm_b', 'cu/lstm_%da/b', (4 * H,), None)] + self._head_phase('cu/pi_%d', 'cu/v_%da')]
+                 ('lstm_b', 'cu/lstm_%da/b', (4 * H,), None)] + self._head_phase('cu/pi_%da' if self.hetero else 'cu/pi_%d', 'cu/v_%da')]   # policies.py:381-390: the identical branch names the actor head pi_<i>, the hetero one pi_<i>a
 
     def _own(self, xv):
         return xv[:, :, :self.n_feat]        # the consensus net sees the agent's own features only
@@ -509,9 +628,9 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     def _phases(self):
         H, F = self.n_h, self.n_feat
         s = 'dial/lstm_comm_%d'
-        return [[('w_msg', s + '/w_msg', (H * self.m_max, H), lambda i: H * self._m(i)),
-                 ('w_msg_b', s + '/b_msg', (H,), None),
-                 ('w_ob', s + '/w_ob', (self.n_obs, H), lambda i: F * (1 + self._m(i))),
+        return [[('w_msg', s + '/w_msg', (H * self.m_max, H), self._L_nbr(H)),
+                 ('w_msg_b', s + '/b_msg', (H,), self._L_nbr()),
+                 ('w_ob', s + '/w_ob', (self.n_obs, H), self._L_slots),
                  ('w_ob_b', s + '/b_ob', (H,), None),
                  ('wx_hid', s + '/wx_hid', (H, 4 * H), None),
                  ('wh_hid', s + '/wh_hid', (H, 4 * H), None),
@@ -521,7 +640,14 @@ class DIALMultiAgentPolicy(BatchedPolicy):
 
     def _own_action_onehot(self, fp):
         """one_hot(argmax(p_i), n_h) (agents/utils.py:577): first maximum, like tf.argmax."""
-        return torch.nn.functional.one_hot(torch.argmax(fp, dim=-1), self.n_h).to(fp.dtype)
+        oh = torch.nn.functional.one_hot(torch.argmax(fp, dim=-1), self.n_h).to(fp.dtype)
+        if self.hetero:
+            # lstm_dial_hetero (agents/utils.py:676-688): an agent without neighbours gets neither messages nor `ai`
+            if not hasattr(self, '_has_nbr'):
+                self._has_nbr = torch.tensor([float(self._m(i) > 0) for i in range(self.N)], dtype=fp.dtype,
+                                             device=fp.device).view(self.N, 1, 1)
+            oh = oh * self._has_nbr
+        return oh
 
     def _enc(self, xv, fp):
         p = self.params

@@ -29,7 +29,9 @@ def nbr_gather(x, nbr_idx):
 
 def nbr_mean(x, nbr_idx):
     """reduce_mean(boolean_mask(out_m, masks[i])) (agents/utils.py:395)."""
-    return torch.stack([torch.stack([x[j] for j in js], 0).mean(0) for js in neighbor_lists(nbr_idx)], 0)
+    # an agent without neighbours receives no message (lstm_ic3_hetero, agents/utils.py:481-493: `if n_m:`) -> 0
+    return torch.stack([torch.stack([x[j] for j in js], 0).mean(0) if len(js) else torch.zeros_like(x[0]) * x[0]
+                        for js in neighbor_lists(nbr_idx)], 0)
 
 
 def nbr_gather_bwd(dy, nbr_idx, F):

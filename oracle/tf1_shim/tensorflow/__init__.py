@@ -488,12 +488,15 @@ class Session:
         for ph, val in (feed_dict or {}).items():
             cache[ph.id] = ph.convert(val)
         # values first (pre-update), stateful ops afterwards -- like one TF step
-        out = [None] * len(fl)
-        for i, f in enumerate(fl):
+        def value(f):              # nested fetch structures come back with the same nesting (tf.Session.run)
+            if isinstance(f, (list, tuple)):
+                return [value(g) for g in f]
             if isinstance(f, Node):
-                out[i] = _value_of(f, cache)
-        for i, f in enumerate(fl):
+                o = _value_of(f, cache)
+                return o.detach().numpy().copy() if torch.is_tensor(o) else o
+            return None
+        res = [value(f) for f in fl]
+        for f in fl:
             if isinstance(f, _Op):
                 f.run(cache)
-        res = [o.detach().numpy().copy() if torch.is_tensor(o) else o for o in out]
         return res[0] if single else res

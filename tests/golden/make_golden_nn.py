@@ -60,6 +60,144 @@ def grid_masks(side=5):
     return nb, dist
 
 
+def ragged_graph():
+    """5 heterogeneous agents (identical=False nets): own observation widths / action counts differ,
+    the neighbourhood is irregular and agent 4 is isolated (no fingerprint / message inputs at all, like Monaco's
+    '8996', real_net_env.py:24)."""
+    n = 5
+    nb = np.zeros((n, n), dtype=int)
+    for i, j in [(0, 1), (1, 2), (2, 3), (0, 2)]:
+        nb[i, j] = nb[j, i] = 1
+    dist = np.full((n, n), n, dtype=int)                 # hop distance; unreachable pairs: n (never used: coop_gamma < 0)
+    for i in range(n):
+        dist[i, i] = 0
+    for i in range(n):
+        for j in range(n):
+            if nb[i, j]:
+                dist[i, j] = 1
+    for k in range(n):
+        for i in range(n):
+            for j in range(n):
+                dist[i, j] = min(dist[i, j], dist[i, k] + dist[k, j])
+    return nb, dist, [3, 5, 4, 6, 2], [2, 3, 4, 2, 5]
+
+
+def run_ragged(name, agent, seed, n_step, n_batch=3):
+    """The scripted three-batch run of run_scripted for the reference's heterogeneous nets (identical=False:
+    agents/utils.py:220-341, 420-512, 602-719; policies.py:59-77 with na_dim_ls; models.py:118-131, 229-244)."""
+    cp = cacc_config(agent=agent, n_step=n_step, reward_norm=50.0, coop_gamma=-1)
+    mc = cp['MODEL_CONFIG']
+    nb, dist, n_own, n_a_ls = ragged_graph()
+    N, F, A = len(n_own), max(n_own), max(n_a_ls)
+    is_ma = agent.startswith('ma2c')
+    nbr = [np.where(nb[i] == 1)[0] for i in range(N)]
+    # IA2C_FP adds the neighbours' fingerprint widths itself (models.py:176-187)
+    n_s_ls = list(n_own) if is_ma else [n_own[i] + sum(n_own[j] for j in nbr[i]) for i in range(N)]
+    np.random.seed(seed)
+    model = CLS[agent](n_s_ls, n_a_ls, nb, dist, -1, 10000, mc, seed=seed)
+    assert not model.identical_agent
+    variables = tf.global_variables()
+    policies = model.policy if isinstance(model.policy, list) else [model.policy]
+    train_to_pol = {id(p._train): p for p in policies}
+    train_log = []
+    orig_run = tf.Session.run
+
+    def logging_run(self, fetches, feed_dict=None):
+        if isinstance(fetches, list):
+            for f in fetches:
+                if getattr(f, 'is_train', False):
+                    p = train_to_pol[id(f)]
+                    train_log.append(orig_run(self, [p.loss, p.grad_norm], feed_dict))
+        return orig_run(self, fetches, feed_dict)
+    tf.Session.run = logging_run
+
+    rng = np.random.RandomState(seed + 1000)
+    X = rng.normal(0, 0.7, size=(n_batch, n_step + 1, N, F))
+    for i in range(N):
+        X[:, :, i, n_own[i]:] = 0.0
+    ACT = np.stack([rng.randint(0, n_a_ls[i], size=(n_batch, n_step + 1)) for i in range(N)], axis=-1)
+    REW = rng.normal(-30, 20, size=(n_batch, n_step, 1))
+    out = dict(stats0=var_stats(variables), names=np.array([v.full_name for v in variables]),
+               shapes=np.array([str(tuple(v.value.shape)) for v in variables]))
+    PI = np.zeros((n_batch, n_step + 1, N, A))
+    V = np.zeros((n_batch, n_step + 1, N))
+    RB = np.zeros((n_batch, N))
+    STATS, LOSS, STATES = [], [], []
+    uniform = lambda: [np.ones(n_a_ls[i]) / n_a_ls[i] for i in range(N)]          # noqa: E731
+    fp = uniform()
+
+    def make_ob(x):
+        ob = []
+        for i in range(N):
+            cur = [x[i, :n_own[i]]]
+            if not is_ma:
+                cur += [x[j, :n_own[j]] for j in nbr[i]]
+            if agent == 'ia2c_fp':
+                cur += [fp[j] for j in nbr[i]]
+            ob.append(np.concatenate(cur))
+        return ob
+
+    def get_policy(ob, done):
+        pi = model.forward(ob, done, fp) if is_ma else model.forward(ob, done)
+        return [np.asarray(p, dtype=np.float64).reshape(-1) for p in pi]
+
+    def get_value(ob, done, ps, action):
+        if is_ma:
+            return np.array(model.forward(ob, done, ps, np.array(action), 'v')).reshape(N), ps
+        na = [action[nb[i] == 1] for i in range(N)]
+        return np.array(model.forward(ob, done, na, 'v'), dtype=np.float64).reshape(N), na
+
+    def pad(pi):
+        o = np.zeros((N, A))
+        for i in range(N):
+            o[i, :n_a_ls[i]] = pi[i]
+        return o
+
+    done = True
+    model.reset()
+    for b in range(n_batch):
+        if done:
+            model.reset()
+            fp = uniform()
+        for t in range(n_step):
+            ob = make_ob(X[b, t])
+            ps = [f.copy() for f in fp]
+            pi = get_policy(ob, done)
+            a = ACT[b, t]
+            v, extra = get_value(ob, done, ps, a)
+            fp = [p.copy() for p in pi]
+            done = (b == 1 and t == n_step - 1)
+            model.add_transition(ob, extra, a, float(REW[b, t, 0]), v, done)
+            PI[b, t], V[b, t] = pad(pi), v
+        if done:
+            R = np.zeros(N)
+        else:
+            ob = make_ob(X[b, n_step])
+            ps = [f.copy() for f in fp]
+            pi = get_policy(ob, done)
+            R, _ = get_value(ob, done, ps, ACT[b, n_step])
+            PI[b, n_step], V[b, n_step] = pad(pi), R
+        RB[b] = R
+        k0 = len(train_log)
+        model.backward(R, 0)
+        LOSS.append(np.array(train_log[k0:], dtype=np.float64))
+        STATS.append(var_stats(variables))
+        sf = [p.states_fw for p in policies]
+        STATES.append(np.array(sf, dtype=np.float64).reshape(N, -1))
+    tf.Session.run = orig_run
+    out.update(X=X, ACT=ACT, REW=REW, PI=PI, V=V, RB=RB, LOSS=np.array(LOSS), STATS=np.array(STATS),
+               STATES=np.array(STATES), nb=nb, dist=dist, agent=agent, topo='ragged', seed=seed, n_step=n_step,
+               coop_gamma=-1, reward_norm=50.0, n_own=np.array(n_own), n_a_ls=np.array(n_a_ls), n_s_ls=np.array(n_s_ls))
+    np.savez_compressed(os.path.join(HERE, 'nn_%s.npz' % name), **out)
+    nparam = sum(int(np.prod(v.value.shape)) for v in variables)
+    print('%-22s params=%7d loss=%s gnorm=%s' % (name, nparam, np.round(LOSS[0][:, 0], 5)[:3],
+                                                 np.round(LOSS[0][:, 1], 4)[:3]))
+
+
+RAGGED = [('ia2c_ragged', 'ia2c', 30), ('ia2c_fp_ragged', 'ia2c_fp', 31), ('ma2c_nc_ragged', 'ma2c_nc', 32),
+          ('ma2c_ic3_ragged', 'ma2c_ic3', 33), ('ma2c_cu_ragged', 'ma2c_cu', 34), ('ma2c_dial_ragged', 'ma2c_dial', 35)]
+
+
 def run_scripted(name, agent, topo, seed, n_step, n_batch=3, coop_gamma=-1):
     cp = cacc_config(agent=agent, n_step=n_step, reward_norm=50.0, coop_gamma=coop_gamma)
     mc = cp['MODEL_CONFIG']
@@ -189,11 +327,17 @@ def run_ortho():
 
 
 if __name__ == '__main__':
+    if '--ragged' in sys.argv:
+        for nm, ag, sd in RAGGED:
+            run_ragged(nm, ag, sd, 4)
+        sys.exit(0)
     if '--only-new' in sys.argv:
         run_scripted('ma2c_cu_line', 'ma2c_cu', 'line', 20, 6)
         run_scripted('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6)
         run_scripted('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4)
         run_scripted('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4)
+    for nm, ag, sd in RAGGED:
+        run_ragged(nm, ag, sd, 4)
         sys.exit(0)
     run_ortho()
     run_scripted('ia2c_line', 'ia2c', 'line', 12, 6)
@@ -208,3 +352,5 @@ if __name__ == '__main__':
     run_scripted('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6)
     run_scripted('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4)
     run_scripted('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4)
+    for nm, ag, sd in RAGGED:
+        run_ragged(nm, ag, sd, 4)

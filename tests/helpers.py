@@ -91,18 +91,21 @@ def build_product_model(z, device):
     cp = cacc_config(agent=agent, n_step=n_step, reward_norm=float(z['reward_norm']), coop_gamma=coop_gamma)
     nb, dist = z['nb'], z['dist']
     N = nb.shape[0]
+    np.random.seed(seed)
+    if topo == 'ragged':        # heterogeneous agents: own widths / action counts recorded by make_golden_nn.run_ragged
+        return cls([int(x) for x in z['n_s_ls']], [int(x) for x in z['n_a_ls']], nb, dist, coop_gamma, 10000,
+                   cp['MODEL_CONFIG'], seed=seed, num_envs=1, device=device, n_feat_ls=[int(x) for x in z['n_own']])
     n_feat, A = (5, 4) if topo == 'line' else (12, 5)
     is_ma = agent.startswith('ma2c')
     n_s_ls = [n_feat if is_ma else n_feat * (1 + int(nb[i].sum())) for i in range(N)]
-    np.random.seed(seed)
     model = cls(n_s_ls, [A] * N, nb, dist, coop_gamma, 10000, cp['MODEL_CONFIG'], seed=seed, num_envs=1,
                 device=device)
     return model
 
 
 def drive_scripted(model, z):
-    """Replays the scripted three-batch run of make_golden_nn.run_scripted through the product's
-    reference-compatible API and returns the same record."""
+    """Replays the scripted three-batch run of make_golden_nn.run_scripted / run_ragged through the product's
+    reference-compatible API and returns the same record (ragged policies zero padded to the widest action set)."""
     agent = str(z['agent'])
     is_ma = agent.startswith('ma2c')
     nb = z['nb']
@@ -112,59 +115,72 @@ def drive_scripted(model, z):
     X, ACT, REW = z['X'], z['ACT'], z['REW']
     n_batch, n_step = X.shape[0], int(z['n_step'])
     coop_gamma = float(z['coop_gamma'])
+    ragged = str(z['topo']) == 'ragged'
+    n_own = [int(v) for v in z['n_own']] if ragged else [X.shape[-1]] * N
+    n_a_ls = [int(v) for v in z['n_a_ls']] if ragged else [A] * N
     PI = np.zeros_like(z['PI'])
     V = np.zeros_like(z['V'])
     RB = np.zeros_like(z['RB'])
     STATS, LOSS, GN, STATES = [], [], [], []
-    fp = np.ones((N, A)) / A
+    uniform = lambda: [np.ones(n_a_ls[i]) / n_a_ls[i] for i in range(N)]          # noqa: E731
+    fp = uniform()
 
     def make_ob(x):
         ob = []
         for i in range(N):
-            cur = [x[i]]
+            cur = [x[i, :n_own[i]]]
             if not is_ma:
-                cur += [x[j] for j in nbr[i]]
+                cur += [x[j, :n_own[j]] for j in nbr[i]]
             if agent == 'ia2c_fp':
                 cur += [fp[j] for j in nbr[i]]
             ob.append(np.concatenate(cur))
         return ob
+
+    def pad(pi):
+        o = np.zeros((N, A))
+        for i in range(N):
+            o[i, :n_a_ls[i]] = np.asarray(pi[i]).reshape(-1)
+        return o
+
+    def as_list(ps):
+        return ps if ragged else np.array(ps)
 
     done = True
     model.reset()
     for b in range(n_batch):
         if done:
             model.reset()
-            fp = np.ones((N, A)) / A
+            fp = uniform()
         for t in range(n_step):
             ob = make_ob(X[b, t])
-            ps = fp.copy()
+            ps = [f.copy() for f in fp]
             a = ACT[b, t]
             if is_ma:
-                pi = np.array(model.forward(ob, done, fp))
-                v = np.array(model.forward(ob, done, ps, np.array(a), 'v'))
-                extra = ps
+                pi = model.forward(ob, done, as_list(fp))
+                v = np.array(model.forward(ob, done, as_list(ps), np.array(a), 'v'))
+                extra = as_list(ps)
             else:
-                pi = np.array(model.forward(ob, done))
+                pi = model.forward(ob, done)
                 extra = [a[nb[i] == 1] for i in range(N)]
                 v = np.array(model.forward(ob, done, extra, 'v'))
-            fp = pi.copy()
+            fp = [np.asarray(p, dtype=np.float64).reshape(-1).copy() for p in pi]
             r = REW[b, t] if coop_gamma >= 0 else float(REW[b, t, 0])
             done = (b == 1 and t == n_step - 1)
             model.add_transition(ob, extra, a, r, v, done)
-            PI[b, t], V[b, t] = pi, v
+            PI[b, t], V[b, t] = pad(pi), v
         if done:
             R = np.zeros(N)
         else:
             ob = make_ob(X[b, n_step])
-            ps = fp.copy()
+            ps = [f.copy() for f in fp]
             a = ACT[b, n_step]
             if is_ma:
-                pi = np.array(model.forward(ob, done, fp))
-                R = np.array(model.forward(ob, done, ps, np.array(a), 'v'))
+                pi = model.forward(ob, done, as_list(fp))
+                R = np.array(model.forward(ob, done, as_list(ps), np.array(a), 'v'))
             else:
-                pi = np.array(model.forward(ob, done))
+                pi = model.forward(ob, done)
                 R = np.array(model.forward(ob, done, [a[nb[i] == 1] for i in range(N)], 'v'))
-            PI[b, n_step], V[b, n_step] = pi, R
+            PI[b, n_step], V[b, n_step] = pad(pi), R
         RB[b] = R
         model.backward(R, 0)
         tot = model.last_loss[3].cpu().numpy().astype(np.float64)

@@ -192,7 +192,8 @@ def main():
     cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3,
            'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[env.agent]
     model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, int(1e9),
-                cp['MODEL_CONFIG'], seed=env.seed, num_envs=E, device=device, dist_group=group)
+                cp['MODEL_CONFIG'], seed=env.seed, num_envs=E, device=device, dist_group=group,
+                n_feat_ls=getattr(env, 'n_feat_ls', None))
     trainer = BatchedTrainer(env, model, Counter(int(1e18), int(1e18), int(1e18)), use_graph=not args.no_graph,
                              rank=rank, world_size=world)
 
@@ -221,6 +222,11 @@ def main():
     # algorithmic bytes per replica-step of the env kernel
     balg = 7548 if is_grid else B_ALG_GATHERED
     kname = 'grid_step_kernel (nmarl_grid_step)' if is_grid else 'cacc_step_kernel (nmarl_cacc_step)'
+    if env.name.endswith('real_net'):
+        # q, transit in and out (4 B x 2 x 2 x 264 links) + action / prev bytes + scalars + the padded neighbour slab
+        tp = env.topo
+        balg = 16 * sum(tp.n_s_ls) + 3 * tp.N + 24 + 4 * tp.L * (1 + tp.m_max) * tp.N
+        kname = 'net_step_kernel (nmarl_net_step)'
     env_steps = n_agent * E * n_step * args.steps * world
     out = {
         'metric': 'env-steps/sec (agents x envs x steps/s), full rollout + A2C update loop',
@@ -230,7 +236,7 @@ def main():
         'a2c_updates_per_s': args.steps / elapsed,
         'lock_steps_per_s': n_step * args.steps / elapsed,
         'config': {'workload': '%s, %d agents x %d replicas/GPU, %s (%s), n_step %d'
-                               % ('ATSC 5x5 grid (synthetic)' if is_grid else 'CACC ' + env.name, n_agent, E, env.agent,
+                               % (('ATSC Monaco-like network (synthetic, heterogeneous agents)' if env.name.endswith('real_net') else 'ATSC 5x5 grid (synthetic)') if is_grid else 'CACC ' + env.name, n_agent, E, env.agent,
                                   os.path.basename(args.config), n_step),
                    'replicas_per_gpu': E, 'global_replicas': E * world, 'parallelism': 'dp%d' % world,
                    'hipgraph_rollout': trainer.use_graph,

@@ -47,6 +47,18 @@ class Head(C.Structure):
                 ('act_in', C.c_void_p), ('nbr_idx', C.c_void_p), ('v_out', C.c_void_p), ('v_sn', C.c_int64)]
 
 
+class NetParams(C.Structure):
+    """nmarl_net_params_t (include/nmarl.h)."""
+    _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('flow_rate', C.c_float), ('T', C.c_int32),
+                ('per_agent_reward', C.c_int32)]
+
+
+class NetTopo(C.Structure):
+    """nmarl_net_topo_t (include/nmarl.h): device pointers of the static network tables."""
+    _fields_ = [('N', C.c_int32), ('L', C.c_int32), ('A', C.c_int32), ('m_max', C.c_int32)] + \
+               [(n, C.c_void_p) for n in ('n_s', 'green', 'src', 'fan', 'group', 'ext_share', 'dn_ptr', 'dn_pair', 'nbr_idx')]
+
+
 class FcPart(C.Structure):
     """nmarl_fc_part_t (include/nmarl.h): one layer of nmarl_fc_fwd_multi."""
     _fields_ = [('x', C.c_void_p), ('x_sn', C.c_int64), ('x_row', C.c_int64), ('F', C.c_int32), ('gather_A', C.c_int32),
@@ -78,6 +90,9 @@ SIGNATURES = {
                         _i32, _u64, _i64, _p, _p],
     'nmarl_grid_reset': [C.POINTER(GridParams), _i64, _p, _p, _u64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     'nmarl_grid_step': [C.POINTER(GridParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _u64, _i64, _p, _p],
+    'nmarl_net_reset': [C.POINTER(NetTopo), _i64, _p, _p, _u64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
+    'nmarl_net_step': [C.POINTER(NetParams), C.POINTER(NetTopo), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _u64, _i64,
+                       _p, _p],
     'nmarl_nbr_gather_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_gather_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_mean_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void nstep_kernel(
     __shared__ double s_w[64 * 64];  // alpha^dist(i,j), N <= 64
     const bool spatial = alpha >= 0.0;
     if (spatial) {
-        for (int p = threadIdx.x; p < N * N; p += blockDim.x) s_w[p] = pow(alpha, (double)dist[p]);
+        // unreachable pairs (distance -1: directed Monaco graph, real_net_env.py:152-187) match no hop count -> weight 0
+        for (int p = threadIdx.x; p < N * N; p += blockDim.x) s_w[p] = dist[p] < 0 ? 0.0 : pow(alpha, (double)dist[p]);
         __syncthreads();
     }
     const int64_t total = (int64_t)N * E;

@@ -23,6 +23,8 @@ namespace {
 
 constexpr int J = 64;            // outputs per layer (n_fc / n_h of every shipped config)
 constexpr int TILE = 64;         // rows staged per LDS tile
+// row-loop unroll by input width: the compiler hoists the LDS reads of all unrolled rows (registers ~ unroll * FMAX)
+template <int FM> struct RowUnroll { static constexpr int value = FM <= 16 ? 4 : FM <= 32 ? 2 : 1; };
 
 __device__ __forceinline__ float act_fwd(const float v, const int act) {
     return act == 1 ? fmaxf(v, 0.0f) : act == 2 ? tanhf(v) : v;
@@ -51,6 +53,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const i
                                                      const float* __restrict__ b, const int64_t b_sn, const int act,
                                                      float* __restrict__ y, const int64_t y_sn, const int64_t y_row) {
     constexpr int FP = FMAX + 4;
+    constexpr int RU = RowUnroll<FMAX>::value;
     __shared__ __attribute__((aligned(16))) float xs[TILE * FP];
     const int n = blockIdx.y, j = threadIdx.x & 63, rl = threadIdx.x >> 6;
     float wr[FMAX];
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const i
         if (row0 >= rows) break;
         stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
         __syncthreads();
-#pragma unroll(FMAX <= 16 ? 4 : FMAX <= 32 ? 2 : 1)
+#pragma unroll RU
         for (int rr = rl; rr < TILE; rr += 4) {
             float acc = 0.0f;
 #pragma unroll
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
                                                            const int act, float* __restrict__ y, const int64_t y_sn,
                                                            const int64_t y_row) {
     constexpr int FP = FMAX + 4;
+    constexpr int RU = RowUnroll<FMAX>::value;
     __shared__ __attribute__((aligned(16))) float xs[TILE * FP];
     const nmarl_fc_part_t& pt = parts.p[blockIdx.z];
     const int F = pt.F;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
             }
         }
         __syncthreads();
-#pragma unroll(FMAX <= 16 ? 4 : FMAX <= 32 ? 2 : 1)
+#pragma unroll RU
         for (int rr = rl; rr < TILE; rr += 4) {
             float acc = 0.0f;
 #pragma unroll
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
                                                      const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
                                                      const int act, float* __restrict__ partial) {
     constexpr int FP = FMAX + 4;
+    constexpr int RU = RowUnroll<FMAX>::value;
     __shared__ __attribute__((aligned(16))) float xs[TILE * FP];        // later reused as the [FMAX + 1, 64] reduction pad
     const int n = blockIdx.y, j = threadIdx.x & 63, rl = threadIdx.x >> 6;
     float acc[FMAX];
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
         if (row0 >= rows) break;
         stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
         __syncthreads();
-#pragma unroll(FMAX <= 16 ? 4 : FMAX <= 32 ? 2 : 1)
+#pragma unroll RU
         for (int rr = rl; rr < TILE; rr += 4) {
             const int64_t row = row0 + rr;
             float g = 0.0f;

@@ -1,0 +1,252 @@
+// Synthetic signalised NETWORK environment with heterogeneous intersections (the Monaco scenario of
+// envs/real_net_env.py: 28 nodes, 2..6 phases over 2..22 signal links, directed neighbour lists), batched over
+// replicas.  Contract (actions, yellow logic, `wave` observation, queue reward, episode timing) from
+// envs/atsc_env.py:181-240, 383-462; dynamics specified in oracle/realnet_ref.py (SUMO is not available).
+//
+// The topology is DATA (nmarl_net_topo_t, built by the host from the reference's NODES / PHASES tables), so the
+// same kernel serves any network with N <= 32 nodes and L <= 24 links per node.
+//
+// Mapping (as csrc/grid.hip): one replica per 32-lane half wave, lane = intersection; a lane keeps the queues of
+// its <= 24 links in registers.  Cross-node quantities go through LDS between half-wave barriers:
+//   out[j]      what node j could discharge this step
+//   acc[i][k]   what link k of node i accepts from its feeder (spill-back: limited by the free space)
+//   cnt[i][k]   detector counts, from which the neighbour-gathered observation slab is assembled and written
+//               with coalesced stores.
+// All sums run in a fixed order (the feeder adds up its fan-out list in ascending (node, link)): bit-reproducible.
+// HBM-bound: per replica-step reads q, transit 2*4*sum(n_s) + action/prev N + 20 B and writes the same state back
+// plus the slab 4*L*(1+m_max)*N (12.3 KB for Monaco, of which 4*sum_i(n_s_i + sum_nbr n_s_j) = 5.0 KB are non-padding).
+#include "common.h"
+
+namespace {
+
+constexpr int NMAX = 32;          // nodes (lanes of a half wave)
+constexpr int LMAX = 24;          // links per node kept in registers
+constexpr int REPS = 8;           // replicas per 256-thread block
+constexpr float DT = 5.0f, YELLOW = 2.0f, YELLOW_EFF = 1.0f, SAT = 0.5f, Q_MAX = 26.0f, DET_CAP = 7.0f;
+
+struct RepShared {
+    float out[NMAX];
+    float acc[NMAX * LMAX];
+    float cnt[NMAX * LMAX];
+};
+
+__device__ __forceinline__ void half_barrier() { __syncthreads(); }   // the 8 replicas of a block run in lock step
+
+__device__ __forceinline__ float activity(const int grp, const int sec) {
+    // real_net_data/build_file.py:70-72: number of active flows per 5-minute piece
+    const int piece = sec / 300;
+    if (piece > 10) return 0.0f;
+    const int a[11] = {1, 2, 4, 4, 4, 4, 2, 1, 0, 0, 0};
+    const int b[11] = {0, 0, 0, 1, 2, 4, 4, 4, 4, 2, 1};
+    return (float)(grp < 2 ? a[piece] : b[piece]);
+}
+
+__global__ __launch_bounds__(256) void net_step_kernel(
+    const nmarl_net_params_t p, const nmarl_net_topo_t tp, const int64_t E, const uint8_t* __restrict__ action,
+    float* __restrict__ qs, float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts,
+    float* __restrict__ xi, float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+    float* __restrict__ greward, const int auto_reset, const uint64_t seed, const int64_t env_id_base,
+    int32_t* __restrict__ episode) {
+    __shared__ RepShared sh[REPS];
+    const int l32 = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    RepShared& s = sh[sub];
+    const int N = tp.N, L = tp.L, W = L * (1 + tp.m_max);
+    const int n = l32;
+    const bool node = n < N;
+    const int ns = node ? tp.n_s[n] : 0;
+    const int64_t rounds = (E + (int64_t)gridDim.x * REPS - 1) / ((int64_t)gridDim.x * REPS);
+    for (int64_t rd = 0; rd < rounds; ++rd) {
+        const int64_t e = (rd * gridDim.x + blockIdx.x) * REPS + sub;
+        const bool live = e < E;
+        const int64_t ec = live ? e : E - 1;
+        float q[LMAX], tr[LMAX], D[LMAX];
+        int a = 0, pa = 0;
+        const int t = ts[ec];
+        if (node) {
+            a = action[ec * N + n];
+            pa = prev[ec * N + n];
+        }
+        // ---- A. effective green, desired discharge
+        float out = 0.0f;
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k) {
+            q[k] = 0.0f; tr[k] = 0.0f; D[k] = 0.0f;
+            if (k < ns) {
+                q[k] = qs[(ec * N + n) * L + k];
+                tr[k] = trs[(ec * N + n) * L + k];
+                const int gc = tp.green[(n * tp.A + a) * L + k], gp = tp.green[(n * tp.A + pa) * L + k];
+                float g;
+                if (a == pa) g = gc ? DT : 0.0f;
+                else g = gc ? (gp ? DT : DT - YELLOW) : (gp ? YELLOW_EFF : 0.0f);
+                if (gc == 2) g *= 0.5f;
+                D[k] = fminf(q[k], SAT * g);
+                out += D[k];
+            }
+        }
+        if (node) s.out[n] = out;
+        half_barrier();
+        // ---- B. what every fed link accepts
+#pragma unroll
+        for (int k = 0; k < LMAX; ++k)
+            if (k < ns) {
+                const int src = tp.src[n * L + k];
+                float acc = 0.0f;
+                if (src >= 0) acc = fminf(s.out[src] / (float)tp.fan[src], fmaxf(Q_MAX - q[k] - tr[k], 0.0f));
+                s.acc[n * LMAX + k] = acc;
+            }
+        half_barrier();
+        // ---- C. delivered per feeder (fixed order), served flows, queue update, arrivals, counts, reward
+        float r_node = 0.0f;
+        if (node) {
+            float delivered = out;                           // a node feeding nothing discharges out of the network
+            const int f0 = tp.dn_ptr[n], f1 = tp.dn_ptr[n + 1];
+            if (f1 > f0) {
+                delivered = 0.0f;
+                for (int f = f0; f < f1; ++f) {
+                    const int pr = tp.dn_pair[f];
+                    delivered += s.acc[(pr >> 8) * LMAX + (pr & 255)];
+                }
+            }
+            const float scale = out > 1e-6f ? delivered / fmaxf(out, 1e-6f) : 0.0f;
+            const int sec = t * 5;
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k)
+                if (k < ns) {
+                    const float served = D[k] * scale;
+                    q[k] = q[k] - served + tr[k];
+                    const int grp = tp.group[n * L + k];
+                    float in = s.acc[n * LMAX + k];
+                    if (grp >= 0) in += p.flow_rate * activity(grp, sec) * tp.ext_share[n * L + k] / 3600.0f * DT * xi[ec * 4 + grp];
+                    tr[k] = in;
+                    const float c = fminf(q[k], DET_CAP);
+                    r_node -= c;
+                }
+        }
+        float gsum = r_node;
+        for (int off = 16; off > 0; off >>= 1) gsum += __shfl_xor(gsum, off, 32);
+        const int t_new = t + 1;
+        const bool is_done = t_new >= p.T;                   // atsc_env.py:189-191
+        const bool rst = auto_reset && is_done;
+        if (node) {
+#pragma unroll
+            for (int k = 0; k < LMAX; ++k)
+                if (k < L) {
+                    float w = 0.0f;
+                    if (k < ns) {
+                        if (rst) { q[k] = 0.0f; tr[k] = 0.0f; }
+                        w = fminf(q[k], DET_CAP) / p.norm_wave;
+                        if (p.clip_wave >= 0.0f) w = fminf(fmaxf(w, 0.0f), p.clip_wave);
+                        if (live) {
+                            qs[(e * N + n) * L + k] = q[k];
+                            trs[(e * N + n) * L + k] = tr[k];
+                        }
+                    }
+                    s.cnt[n * LMAX + k] = w;
+                }
+            if (live) {
+                prev[e * N + n] = (uint8_t)(rst ? 0 : a);
+                if (p.per_agent_reward) reward[e * N + n] = r_node;
+            }
+        }
+        if (live && l32 == 0) {
+            if (!p.per_agent_reward) reward[e] = gsum;
+            greward[e] = gsum;
+            done[e] = is_done ? 1 : 0;
+            ts[e] = rst ? 0 : t_new;
+        }
+        if (live && rst && l32 < 4) {
+            const int ep = episode[e];
+            const Philox4 r4 = philox4x32_10((uint32_t)(env_id_base + e), 0u, (uint32_t)ep, NMARL_STREAM_RESET,
+                                             (uint32_t)seed, (uint32_t)(seed >> 32));
+            const uint32_t w = l32 == 0 ? r4.x : l32 == 1 ? r4.y : l32 == 2 ? r4.z : r4.w;
+            xi[e * 4 + l32] = 0.8f + 0.4f * u01_from_bits(w);
+        }
+        half_barrier();
+        if (live && rst && l32 == 4) episode[e] = episode[e] + 1;
+        // ---- D. the neighbour-gathered observation slab [N, (1 + m_max) * L], coalesced
+        if (live) {
+            float* o = obs + e * N * W;
+            for (int idx = l32; idx < N * W; idx += 32) {
+                const int i = idx / W, r = idx - i * W;
+                const int slot = r / L, f = r - slot * L;
+                float v = 0.0f;
+                if (slot == 0) v = s.cnt[i * LMAX + f];
+                else {
+                    const int j = tp.nbr_idx[i * tp.m_max + slot - 1];
+                    if (j >= 0) v = s.cnt[j * LMAX + f];
+                }
+                o[idx] = v;
+            }
+        }
+        half_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void net_reset_kernel(
+    const nmarl_net_topo_t tp, const int64_t E, const uint8_t* __restrict__ mask, const float* __restrict__ u0,
+    float* __restrict__ qs, float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts,
+    float* __restrict__ xi, float* __restrict__ obs, const uint64_t seed, const int64_t env_id_base,
+    int32_t* __restrict__ episode) {
+    const int l32 = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const int NL = tp.N * tp.L, NW = tp.N * tp.L * (1 + tp.m_max);
+    for (int64_t e = (int64_t)blockIdx.x * REPS + sub; e < E; e += (int64_t)gridDim.x * REPS) {
+        if (mask != nullptr && mask[e] == 0) continue;
+        for (int i = l32; i < NL; i += 32) { qs[e * NL + i] = 0.0f; trs[e * NL + i] = 0.0f; }
+        for (int i = l32; i < NW; i += 32) obs[e * NW + i] = 0.0f;
+        if (l32 < tp.N) prev[e * tp.N + l32] = 0;
+        if (l32 == 0) ts[e] = 0;
+        if (l32 < 4) {
+            float U;
+            if (u0 != nullptr) {
+                U = u0[e * 4 + l32];
+            } else {
+                const Philox4 r4 = philox4x32_10((uint32_t)(env_id_base + e), 0u, (uint32_t)episode[e], NMARL_STREAM_RESET,
+                                                 (uint32_t)seed, (uint32_t)(seed >> 32));
+                const uint32_t w = l32 == 0 ? r4.x : l32 == 1 ? r4.y : l32 == 2 ? r4.z : r4.w;
+                U = u01_from_bits(w);
+            }
+            xi[e * 4 + l32] = 0.8f + 0.4f * U;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (u0 == nullptr && l32 == 4) episode[e] = episode[e] + 1;
+    }
+}
+
+inline int net_blocks(int64_t E) {
+    const int64_t b = (E + REPS - 1) / REPS;
+    return (int)(b < 4096 ? b : 4096);
+}
+
+inline bool topo_ok(const nmarl_net_topo_t* tp) {
+    return tp && tp->N > 0 && tp->N <= NMAX && tp->L > 0 && tp->L <= LMAX && tp->A > 0 && tp->A <= 255 && tp->m_max > 0 &&
+           tp->m_max <= 8 && tp->n_s && tp->green && tp->src && tp->fan && tp->group && tp->ext_share && tp->dn_ptr &&
+           tp->dn_pair && tp->nbr_idx;
+}
+
+}  // namespace
+
+extern "C" int nmarl_net_step(const nmarl_net_params_t* p, const nmarl_net_topo_t* tp, int64_t E, const uint8_t* action,
+                              float* q, float* transit, uint8_t* prev_action, int32_t* t, float* xi, float* obs,
+                              float* reward, uint8_t* done, float* global_reward, int32_t auto_reset, uint64_t seed,
+                              int64_t env_id_base, int32_t* episode, void* stream) {
+    if (!p || !topo_ok(tp) || p->T <= 0 || p->norm_wave <= 0.f || E < 0 ||
+        (E > 0 && (!action || !q || !transit || !prev_action || !t || !xi || !obs || !reward || !done || !global_reward)))
+        return NMARL_EINVAL;
+    if (auto_reset && !episode) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(net_step_kernel, dim3(net_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p, *tp, E,
+                       action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset, seed,
+                       env_id_base, episode);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_net_reset(const nmarl_net_topo_t* tp, int64_t E, const uint8_t* mask, const float* u0, uint64_t seed,
+                               int64_t env_id_base, int32_t* episode, float* q, float* transit, uint8_t* prev_action,
+                               int32_t* t, float* xi, float* obs, void* stream) {
+    if (!topo_ok(tp) || E < 0 || (E > 0 && (!q || !transit || !prev_action || !t || !xi || !obs))) return NMARL_EINVAL;
+    if (!u0 && !episode) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    hipLaunchKernelGGL(net_reset_kernel, dim3(net_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *tp, E, mask,
+                       u0, q, transit, prev_action, t, xi, obs, seed, env_id_base, episode);
+    return nmarl_check_launch();
+}

@@ -8,7 +8,8 @@ def make_batch_env(config, num_envs, device='cuda', seed=None, env_id_base=0):
         if scenario.endswith('large_grid'):
             from .large_grid_env import LargeGridBatchEnv
             return LargeGridBatchEnv(config, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base)
-        raise NotImplementedError('atsc_real_net (Monaco, SUMO) is out of scope: SURVEY.md section 2 row 11')
+        from .real_net_env import RealNetBatchEnv
+        return RealNetBatchEnv(config, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base)
     from .cacc_env import CACCBatchEnv
     return CACCBatchEnv(config, num_envs=num_envs, device=device, seed=seed, env_id_base=env_id_base)
 
@@ -20,6 +21,7 @@ def init_env(config, port=0, device='cuda'):
         if scenario.endswith('large_grid'):
             from .large_grid_env import LargeGridEnv
             return LargeGridEnv(config, port=port, device=device)
-        raise NotImplementedError('atsc_real_net (Monaco, SUMO) is out of scope: SURVEY.md section 2 row 11')
+        from .real_net_env import RealNetEnv
+        return RealNetEnv(config, port=port, device=device)
     from .cacc_env import CACCEnv
     return CACCEnv(config, device=device)

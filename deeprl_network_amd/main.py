@@ -42,7 +42,7 @@ def init_agent(env, config, total_step, seed, **kw):
     if cls is None:
         return None
     return cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, total_step, config,
-               seed=seed, **kw)
+               seed=seed, n_feat_ls=getattr(env, 'n_feat_ls', None), **kw)
 
 
 def _dist():

@@ -154,6 +154,50 @@ int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const uint8_t* acti
                     uint64_t seed, int64_t env_id_base, int32_t* episode, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Synthetic signalised NETWORK with heterogeneous intersections -- contract   */
+/* of envs/atsc_env.py + envs/real_net_env.py (Monaco: 28 nodes, 2..6 phases   */
+/* over 2..22 signal links); dynamics specified in oracle/realnet_ref.py       */
+/* ------------------------------------------------------------------------- */
+typedef struct nmarl_net_params {
+    float norm_wave;          /* atsc_env.py:91-92 (config_*_net.ini: 1.0)               */
+    float clip_wave;          /* < 0: no clip (config_*_net.ini: -1)                     */
+    float flow_rate;          /* veh/h of one flow, real_net_env.py:147                  */
+    int32_t T;                /* ceil(episode_length_sec / control_interval_sec) = 720   */
+    int32_t per_agent_reward; /* coop_gamma >= 0 -> reward [E,N], else global [E]        */
+} nmarl_net_params_t;
+
+/* The static network as device arrays (built by the host from the reference's NODES / PHASES tables):
+ * N <= 32 nodes, L <= 24 = widest phase string, A = most phases, m_max = most listed neighbours;
+ * n_s [N] links per node; green [N,A,L] u8 0 r / 1 G / 2 g (r padded); src [N,L] feeding node or -1 (external
+ * entry); fan [N] number of links a node feeds; group [N,L] flow group of an external link (else -1); ext_share
+ * [N,L] its share of the group's demand; dn_ptr [N+1] / dn_pair [(node << 8) | link] the links fed by each node
+ * in ascending order; nbr_idx [N,m_max] the neighbour table of the nets (ascending index, -1 padded). */
+typedef struct nmarl_net_topo {
+    int32_t N, L, A, m_max;
+    const int32_t* n_s;
+    const uint8_t* green;
+    const int32_t* src;
+    const int32_t* fan;
+    const int32_t* group;
+    const float* ext_share;
+    const int32_t* dn_ptr;
+    const int32_t* dn_pair;
+    const int32_t* nbr_idx;
+} nmarl_net_topo_t;
+
+/* TrafficSimulator.reset / step (atsc_env.py:164-207) as nmarl_grid_reset / nmarl_grid_step, for the network:
+ * q, transit [E,N,L] f32; prev_action [E,N] u8; t [E]; xi [E,4]; obs [E,N,L*(1+m_max)] (slot 0 own `wave`, slots
+ * 1.. the listed neighbours' in ascending node index, each L wide and zero padded -- the padded input layout of the
+ * heterogeneous nets); action[e,i] in 0..n_a_i-1; reward [E] or [E,N]. */
+int nmarl_net_reset(const nmarl_net_topo_t* tp, int64_t E, const uint8_t* mask, const float* u0, uint64_t seed,
+                    int64_t env_id_base, int32_t* episode, float* q, float* transit, uint8_t* prev_action,
+                    int32_t* t, float* xi, float* obs, void* stream);
+int nmarl_net_step(const nmarl_net_params_t* p, const nmarl_net_topo_t* tp, int64_t E, const uint8_t* action,
+                   float* q, float* transit, uint8_t* prev_action, int32_t* t, float* xi, float* obs,
+                   float* reward, uint8_t* done, float* global_reward, int32_t auto_reset, uint64_t seed,
+                   int64_t env_id_base, int32_t* episode, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Neighbourhood aggregation over the fixed adjacency (agent-major [N,E,F])   */
 /* ------------------------------------------------------------------------- */
 /*

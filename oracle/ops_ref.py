@@ -295,6 +295,7 @@ def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, ad
     Rs = torch.zeros(N, T, E, dtype=torch.float64)
     if alpha >= 0:
         w = torch.pow(torch.tensor(float(alpha), dtype=torch.float64), dist.double().cpu())   # [N,N]
+        w = torch.where(dist.cpu() < 0, torch.zeros_like(w), w)     # unreachable pairs (-1) match no hop count t
     for t in range(T - 1, -1, -1):
         if alpha < 0:
             R = r64[t].unsqueeze(0) + gamma * R * keep[t].unsqueeze(0)

@@ -217,3 +217,14 @@ def grid_config(agent='ma2c_ic3', coop_gamma=-1, seed=12, n_step=120):
     cp['ENV_CONFIG']['seed'] = str(seed)
     cp['MODEL_CONFIG']['batch_size'] = str(n_step)
     return cp
+
+
+def net_config(agent='ma2c_nc', coop_gamma=0.9, seed=12, n_step=120):
+    cp = configparser.ConfigParser()
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'config', 'config_ma2c_nc_net.ini')
+    cp.read(path)
+    cp['ENV_CONFIG']['agent'] = agent
+    cp['ENV_CONFIG']['coop_gamma'] = str(coop_gamma)
+    cp['ENV_CONFIG']['seed'] = str(seed)
+    cp['MODEL_CONFIG']['batch_size'] = str(n_step)
+    return cp

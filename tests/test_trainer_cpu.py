@@ -89,3 +89,37 @@ def test_finished_replicas_restart_clean():
         assert torch.all(tr.R_end == 0)
         tr.run_batch()
         assert torch.all(tr.done_pre == 0) and not torch.all(model.h_fw == 0)
+
+
+@pytest.mark.parametrize('agent', ['ma2c_nc', 'ia2c_fp', 'ma2c_dial'])
+def test_heterogeneous_agents_on_the_network_cpu(agent):
+    """Host logic of the batched engine for the Monaco-like network (28 agents with 2..6 actions, 2..22 own features,
+    0..4 neighbours) on the CPU emulation: per-agent action ranges, padded fingerprints, frozen padded parameters,
+    the spatially discounted per-agent rewards with unreachable pairs (distance -1)."""
+    from cpu_emulation import CpuRealNetBatchEnv
+    from helpers import net_config
+    from deeprl_network_amd.main import AGENTS
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    with cpu_ops():
+        cp = net_config(agent=agent, n_step=6)
+        cp['ENV_CONFIG']['episode_length_sec'] = '60'                 # T = 12 = 2 batches
+        env = CpuRealNetBatchEnv(cp['ENV_CONFIG'], num_envs=3)
+        np.random.seed(4)
+        model = AGENTS[agent](env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 6,
+                              cp['MODEL_CONFIG'], seed=4, num_envs=3, device='cpu', n_feat_ls=env.n_feat_ls)
+        ps = model.policy.params
+        w0, pad0 = ps.flat.clone(), ps['pi_b'].detach().clone()
+        tr = BatchedTrainer(env, model, Counter(10 ** 6, 10 ** 7, 10 ** 4), use_graph=False)
+        for _ in range(5):
+            tr.run_batch()
+        acts = model.buf_act.numpy()
+        fp = model.buf_fp.numpy()
+        for i, n in enumerate(env.n_a_ls):
+            assert acts[:, :, i].max() < n
+            assert (fp[:, i, :, n:] == 0).all()
+            np.testing.assert_allclose(fp[:, i, :, :n].sum(-1), 1.0, rtol=1e-5)
+            assert torch.equal(ps['pi_b'].detach()[i, n:], pad0[i, n:])
+        assert torch.isfinite(ps.flat).all() and not torch.equal(w0, ps.flat)
+        if ps.mask is not None:
+            assert torch.equal(ps.flat[ps.mask == 0], w0[ps.mask == 0])
+        assert tr.stats()['episodes'] == 3 * 2

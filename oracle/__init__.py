@@ -19,6 +19,12 @@ Pinning status (see DESIGN.md "Oracle"):
                      torch-CPU); TF-1.12 *kernel* semantics (RMSProp slots,
                      clip_by_global_norm, softmax) are restated, not executed:
                      "parity unpinned at the TF kernel boundary".
+                     The heterogeneous (identical=False) nets are not restated
+                     here: the product is compared directly with goldens produced
+                     by the reference's own hetero code (nn_*_ragged.npz).
   * grid_ref      -- PARITY UNPINNED: SUMO is absent; the synthetic grid is
                      specified in this repo and grid_ref is its own oracle.
+  * realnet_ref   -- topology / masks / widths PINNED against the reference's
+                     real_net_env.py tables and map builders; dynamics PARITY
+                     UNPINNED (SUMO + net file absent): own specification.
 """

@@ -54,9 +54,14 @@ class NetParams(C.Structure):
 
 
 class NetTopo(C.Structure):
-    """nmarl_net_topo_t (include/nmarl.h): device pointers of the static network tables."""
-    _fields_ = [('N', C.c_int32), ('L', C.c_int32), ('A', C.c_int32), ('m_max', C.c_int32)] + \
-               [(n, C.c_void_p) for n in ('n_s', 'green', 'src', 'fan', 'group', 'ext_share', 'dn_ptr', 'dn_pair', 'nbr_idx')]
+    """nmarl_net_topo_t (include/nmarl.h): sizes, links per node and the packed table image (device pointers)."""
+    _fields_ = [('N', C.c_int32), ('L', C.c_int32), ('A', C.c_int32), ('m_max', C.c_int32), ('n_s', C.c_void_p),
+                ('image', C.c_void_p)]
+
+
+# layout of the packed network image (include/nmarl.h NMARL_NET_OFF_*)
+NET_OFF = dict(green=0, src=6144, group=7680, share=8448, fan=11520, dnptr=11648, dnpair=11728, nbr=13264)
+NET_IMAGE_BYTES = 13568
 
 
 class FcPart(C.Structure):

@@ -128,11 +128,44 @@ class NetTopology:
         self.host = dict(n_s=np.array(self.n_s_ls, dtype=np.int32), green=green, src=src, fan=fan, group=group,
                          ext_share=ext_share, dn_ptr=np.array(dn_ptr, dtype=np.int32),
                          dn_pair=np.array(dn_pair if dn_pair else [0], dtype=np.int32), nbr_idx=nbr_idx)
-        self.dev = {k: torch.from_numpy(v).to(device) for k, v in self.host.items()}
+        # the packed image the step kernel copies into LDS (include/nmarl.h NMARL_NET_OFF_*: rows padded to 24 links)
+        NM, LM, AM = 32, 24, 8
+        if N > NM or self.L > LM or self.A > AM or self.m_max > 8:
+            raise _lib.NmarlError('network exceeds the kernel limits (32 nodes, 24 links, 8 phases, 8 neighbours)')
+        img = np.zeros(_lib.NET_IMAGE_BYTES, dtype=np.uint8)
+        off = _lib.NET_OFF
+
+        def put(name, arr):
+            b = np.ascontiguousarray(arr).view(np.uint8).ravel()
+            img[off[name]:off[name] + b.size] = b
+        g = np.zeros((NM, AM, LM), dtype=np.uint8)
+        g[:N, :self.A, :self.L] = green
+        put('green', g)
+        a16 = -np.ones((NM, LM), dtype=np.int16)
+        a16[:N, :self.L] = src
+        put('src', a16)
+        a8 = -np.ones((NM, LM), dtype=np.int8)
+        a8[:N, :self.L] = group
+        put('group', a8)
+        f = np.zeros((NM, LM), dtype=np.float32)
+        f[:N, :self.L] = ext_share
+        put('share', f)
+        ff = np.zeros(NM, dtype=np.float32)
+        ff[:N] = fan
+        put('fan', ff)
+        put('dnptr', np.array(dn_ptr + [dn_ptr[-1]] * (NM + 1 - len(dn_ptr)), dtype=np.int16))
+        pairs = np.zeros(NM * LM, dtype=np.int16)
+        pairs[:len(dn_pair)] = [(v >> 8) * LM + (v & 255) for v in dn_pair]
+        put('dnpair', pairs)
+        nb8 = -np.ones((NM, 8), dtype=np.int8)
+        nb8[:N, :self.m_max] = nbr_idx
+        put('nbr', nb8)
+        self.host['image'] = img
+        self.dev = {'n_s': torch.from_numpy(self.host['n_s']).to(device), 'image': torch.from_numpy(img).to(device),
+                    'nbr_idx': torch.from_numpy(nbr_idx).to(device)}
         t = self.c = _lib.NetTopo()
         t.N, t.L, t.A, t.m_max = N, self.L, self.A, self.m_max
-        for k, v in self.dev.items():
-            setattr(t, k, v.data_ptr())
+        t.n_s, t.image = self.dev['n_s'].data_ptr(), self.dev['image'].data_ptr()
 
 
 def net_params_from_config(config):

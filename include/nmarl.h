@@ -166,23 +166,30 @@ typedef struct nmarl_net_params {
     int32_t per_agent_reward; /* coop_gamma >= 0 -> reward [E,N], else global [E]        */
 } nmarl_net_params_t;
 
-/* The static network as device arrays (built by the host from the reference's NODES / PHASES tables):
- * N <= 32 nodes, L <= 24 = widest phase string, A = most phases, m_max = most listed neighbours;
- * n_s [N] links per node; green [N,A,L] u8 0 r / 1 G / 2 g (r padded); src [N,L] feeding node or -1 (external
- * entry); fan [N] number of links a node feeds; group [N,L] flow group of an external link (else -1); ext_share
- * [N,L] its share of the group's demand; dn_ptr [N+1] / dn_pair [(node << 8) | link] the links fed by each node
- * in ascending order; nbr_idx [N,m_max] the neighbour table of the nets (ascending index, -1 padded). */
+/* The static network (built by the host from the reference's NODES / PHASES tables): N <= 32 nodes, L <= 24 = widest
+ * phase string, A <= 8 = most phases, m_max <= 8 = most listed neighbours.
+ * n_s [N] (device) links per node.  image (device, 16-byte aligned, NMARL_NET_IMAGE_BYTES): all other tables packed in
+ * the layout the step kernel keeps in LDS (rows padded to 24 links):
+ *   OFF_GREEN  u8  [32][8][24]   0 r / 1 G / 2 g, indexed [node][phase][link]
+ *   OFF_SRC    i16 [32][24]      feeding node of a link or -1 (external entry)
+ *   OFF_GROUP  i8  [32][24]      flow group of an external link, else -1
+ *   OFF_SHARE  f32 [32][24]      its share of the group's demand
+ *   OFF_FAN    f32 [32]          number of links a node feeds
+ *   OFF_DNPTR  i16 [33], OFF_DNPAIR i16 [768]   the links fed by each node, ascending, as node*24 + link
+ *   OFF_NBR    i8  [32][8]       neighbour table of the nets (ascending index, -1 padded) */
+#define NMARL_NET_OFF_GREEN 0
+#define NMARL_NET_OFF_SRC 6144
+#define NMARL_NET_OFF_GROUP 7680
+#define NMARL_NET_OFF_SHARE 8448
+#define NMARL_NET_OFF_FAN 11520
+#define NMARL_NET_OFF_DNPTR 11648
+#define NMARL_NET_OFF_DNPAIR 11728
+#define NMARL_NET_OFF_NBR 13264
+#define NMARL_NET_IMAGE_BYTES 13568
 typedef struct nmarl_net_topo {
     int32_t N, L, A, m_max;
     const int32_t* n_s;
-    const uint8_t* green;
-    const int32_t* src;
-    const int32_t* fan;
-    const int32_t* group;
-    const float* ext_share;
-    const int32_t* dn_ptr;
-    const int32_t* dn_pair;
-    const int32_t* nbr_idx;
+    const uint8_t* image;
 } nmarl_net_topo_t;
 
 /* TrafficSimulator.reset / step (atsc_env.py:164-207) as nmarl_grid_reset / nmarl_grid_step, for the network:

@@ -80,6 +80,14 @@ def test_struct_layouts_match_c_compiler(tmp_path, ctype, cls):
     assert nums[1:] == [getattr(mirror, f).offset for f in fields]
 
 
+def test_net_image_layout_matches_header():
+    from deeprl_network_amd import _lib
+    src = open(HEADER).read()
+    defs = dict(re.findall(r'#define NMARL_NET_(OFF_\w+|IMAGE_BYTES) (\d+)', src))
+    assert int(defs['IMAGE_BYTES']) == _lib.NET_IMAGE_BYTES
+    assert {k[4:].lower(): int(v) for k, v in defs.items() if k.startswith('OFF_')} == _lib.NET_OFF
+
+
 def test_ops_fail_loudly_without_gpu_tensors():
     import pytest
     import torch

@@ -77,3 +77,33 @@ def test_cli_train_and_evaluate(tmp_path):
     tdf = pd.read_csv(eva + 'catchup_ma2c_nc_traffic.csv')
     assert {'episode', 'time_sec', 'reward', 'lead_headway_m', 'avg_headway_m', 'headway_1_m', 'velocity_8_mps',
             'accel_8_mps2'} <= set(tdf.columns)
+
+
+def test_cli_train_on_the_heterogeneous_network(tmp_path):
+    """main.py train on `atsc_real_net` (28 heterogeneous agents): the reference's E = 1 loop with ragged observation /
+    policy lists, and the batched loop; checkpoints carry the reference's ragged variable shapes."""
+    import torch
+    from helpers import net_config
+    from deeprl_network_amd.main import main
+    for agent, num_envs, sub in (('ma2c_nc', 1, 'single'), ('ia2c_fp', 1, 'single_fp'), ('ma2c_nc', 32, 'batched')):
+        cp = net_config(agent=agent, n_step=12)
+        cp['ENV_CONFIG']['episode_length_sec'] = '120'                 # T = 24 = 2 batches
+        cp['ENV_CONFIG']['num_envs'] = str(num_envs)
+        cp['TRAIN_CONFIG']['total_step'] = str(48 * num_envs)
+        ini = tmp_path / ('config_%s.ini' % sub)
+        with open(ini, 'w') as f:
+            cp.write(f)
+        base = str(tmp_path / sub)
+        main(['--base-dir', base, 'train', '--config-dir', str(ini)])
+        # ATSC scenarios are evaluated only every test_interval steps (utils.py:236-247): no test episode in this run
+        assert os.path.exists(base + '/data/train_reward.csv')
+        ck = [f for f in os.listdir(base + '/model') if f.startswith('checkpoint-')]
+        assert len(ck) == 1
+        blob = torch.load(os.path.join(base, 'model', ck[0]), weights_only=False)
+        shapes = {k: tuple(v.shape) for k, v in blob['variables'].items()}
+        if agent == 'ma2c_nc':
+            assert shapes['nc/pi_0/w'] == (64, 6) and shapes['nc/pi_2/w'] == (64, 2)        # 10026: 6 phases, 8940: 2
+            assert shapes['nc/lstm_comm_3/wx_hid'] == (64, 256) and 'nc/lstm_comm_3/w_fp' not in shapes   # 8996: no neighbours
+            assert shapes['nc/lstm_comm_0/w_ob'] == (14 + 6 + 4 + 12 + 12, 64)
+        else:
+            assert shapes['lstm_0/pi/w'] == (64, 6) and shapes['lstm_3/lstm/wx'] == (64, 256)

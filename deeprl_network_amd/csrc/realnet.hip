@@ -33,13 +33,13 @@ struct RepShared {
 
 __device__ __forceinline__ void half_barrier() { __syncthreads(); }   // the 8 replicas of a block run in lock step
 
-__device__ __forceinline__ float activity(const int grp, const int sec) {
-    // real_net_data/build_file.py:70-72: number of active flows per 5-minute piece
-    const int piece = sec / 300;
-    if (piece > 10) return 0.0f;
-    const int a[11] = {1, 2, 4, 4, 4, 4, 2, 1, 0, 0, 0};
-    const int b[11] = {0, 0, 0, 1, 2, 4, 4, 4, 4, 2, 1};
-    return (float)(grp < 2 ? a[piece] : b[piece]);
+// real_net_data/build_file.py:70-72: number of active flows per 5-minute piece, groups 0,1 (a) and 2,3 (b); pure
+// arithmetic (a table lookup per link put one constant-memory round trip per link on the critical path)
+__device__ __forceinline__ float activity_a(const int piece) {
+    return piece > 7 ? 0.0f : (piece == 0 || piece == 7) ? 1.0f : (piece == 1 || piece == 6) ? 2.0f : 4.0f;
+}
+__device__ __forceinline__ float activity_b(const int piece) {
+    return (piece < 3 || piece > 10) ? 0.0f : (piece == 3 || piece == 10) ? 1.0f : (piece == 4 || piece == 9) ? 2.0f : 4.0f;
 }
 
 template <int REPS>
@@ -148,7 +148,10 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
         half_barrier();
         // ---- C. delivered per feeder (fixed order), served flows, queue update, arrivals, counts, reward
         float r_node = 0.0f;
-        const float xig[4] = {xi[ec * 4], xi[ec * 4 + 1], xi[ec * 4 + 2], xi[ec * 4 + 3]};
+        // external arrivals of this step per flow group: flow_rate * activity_g(t) / 3600 * DT * xi_g  (x the link's share)
+        const int piece = (t * 5) / 300;
+        const float ra = p.flow_rate * activity_a(piece), rb = p.flow_rate * activity_b(piece);
+        const float xg0 = xi[ec * 4], xg1 = xi[ec * 4 + 1], xg2 = xi[ec * 4 + 2], xg3 = xi[ec * 4 + 3];
         if (node) {
             float delivered = out;                           // a node feeding nothing discharges out of the network
             const int f0 = t_dnptr[n], f1 = t_dnptr[n + 1];
@@ -157,7 +160,6 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
                 for (int f = f0; f < f1; ++f) delivered += s.acc[t_dnpair[f]];
             }
             const float scale = out > 1e-6f ? delivered / fmaxf(out, 1e-6f) : 0.0f;
-            const int sec = t * 5;
 #pragma unroll
             for (int k = 0; k < LMAX; ++k)
                 if (k < ns) {
@@ -165,7 +167,9 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
                     q[k] = q[k] - served + tr[k];
                     const int grp = t_group[n * LMAX + k];
                     float in = s.acc[n * LMAX + k];
-                    if (grp >= 0) in += p.flow_rate * activity(grp, sec) * t_share[n * LMAX + k] / 3600.0f * DT * xig[grp];
+                    if (grp >= 0)
+                        in += (grp < 2 ? ra : rb) * t_share[n * LMAX + k] / 3600.0f * DT *
+                              (grp == 0 ? xg0 : grp == 1 ? xg1 : grp == 2 ? xg2 : xg3);
                     tr[k] = in;
                     const float c = fminf(q[k], DET_CAP);
                     r_node -= c;

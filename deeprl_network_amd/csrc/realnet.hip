@@ -81,6 +81,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
         }
     }
     __syncthreads();
+    const int Lmagic = (65536 + L - 1) / L;     // i / L == (i * Lmagic) >> 16 for i < 768, L <= 24 (tests/test_abi.py)
     const int n = l32;
     const bool node = n < N;
     const int ns = node ? tp.n_s[n] : 0;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
             for (int it = 0; it < NMAX * LMAX / 32; ++it) {
                 const int i = it * 32 + l32;
                 if (i < N * L) {
-                    const int r = i / L;
+                    const int r = (i * Lmagic) >> 16;
                     s.acc[r * LMAX + (i - r * L)] = lq[it];
                     s.cnt[r * LMAX + (i - r * L)] = lt[it];
                 }
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
             }
         }
         half_barrier();                                      // everybody has read its staged rows
-        if (node) s.out[n] = out;
+        if (node) s.out[n] = t_fan[n] > 0.0f ? out / t_fan[n] : 0.0f;      // what each fed link is offered
         half_barrier();
         // ---- B. what every fed link accepts
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
             if (k < ns) {
                 const int src = t_src[n * LMAX + k];
                 float acc = 0.0f;
-                if (src >= 0) acc = fminf(s.out[src] / t_fan[src], fmaxf(Q_MAX - q[k] - tr[k], 0.0f));
+                if (src >= 0) acc = fminf(s.out[src], fmaxf(Q_MAX - q[k] - tr[k], 0.0f));
                 s.acc[n * LMAX + k] = acc;
             }
         half_barrier();
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
         float r_node = 0.0f;
         // external arrivals of this step per flow group: flow_rate * activity_g(t) / 3600 * DT * xi_g  (x the link's share)
         const int piece = (t * 5) / 300;
-        const float ra = p.flow_rate * activity_a(piece), rb = p.flow_rate * activity_b(piece);
-        const float xg0 = xi[ec * 4], xg1 = xi[ec * 4 + 1], xg2 = xi[ec * 4 + 2], xg3 = xi[ec * 4 + 3];
+        const float ra = p.flow_rate * activity_a(piece) / 3600.0f * DT, rb = p.flow_rate * activity_b(piece) / 3600.0f * DT;
+        const float xg0 = ra * xi[ec * 4], xg1 = ra * xi[ec * 4 + 1], xg2 = rb * xi[ec * 4 + 2], xg3 = rb * xi[ec * 4 + 3];
         if (node) {
             float delivered = out;                           // a node feeding nothing discharges out of the network
             const int f0 = t_dnptr[n], f1 = t_dnptr[n + 1];
@@ -167,9 +168,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
                     q[k] = q[k] - served + tr[k];
                     const int grp = t_group[n * LMAX + k];
                     float in = s.acc[n * LMAX + k];
-                    if (grp >= 0)
-                        in += (grp < 2 ? ra : rb) * t_share[n * LMAX + k] / 3600.0f * DT *
-                              (grp == 0 ? xg0 : grp == 1 ? xg1 : grp == 2 ? xg2 : xg3);
+                    if (grp >= 0) in += (grp == 0 ? xg0 : grp == 1 ? xg1 : grp == 2 ? xg2 : xg3) * t_share[n * LMAX + k];
                     tr[k] = in;
                     const float c = fminf(q[k], DET_CAP);
                     r_node -= c;
@@ -187,7 +186,8 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
                 wv[k] = 0.0f;
                 if (k < ns) {
                     if (rst) { q[k] = 0.0f; tr[k] = 0.0f; }
-                    float w = fminf(q[k], DET_CAP) / p.norm_wave;
+                    float w = fminf(q[k], DET_CAP);
+                    if (p.norm_wave != 1.0f) w = w / p.norm_wave;
                     if (p.clip_wave >= 0.0f) w = fminf(fmaxf(w, 0.0f), p.clip_wave);
                     wv[k] = w;
                 }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
             for (int it = 0; it < NMAX * LMAX / 32; ++it) {
                 const int i = it * 32 + l32;
                 if (i < N * L) {
-                    const int r = i / L;
+                    const int r = (i * Lmagic) >> 16;
                     qs[e * N * L + i] = s.acc[r * LMAX + (i - r * L)];
                 }
             }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(32 * REPS) void net_step_kernel(
             for (int it = 0; it < NMAX * LMAX / 32; ++it) {
                 const int i = it * 32 + l32;
                 if (i < N * L) {
-                    const int r = i / L;
+                    const int r = (i * Lmagic) >> 16;
                     trs[e * N * L + i] = s.acc[r * LMAX + (i - r * L)];
                 }
             }

@@ -233,8 +233,8 @@ class NetBatchRef:
         sec = self.t * self.p.control
         act = np.array([[activity(g, s) for g in range(N_GROUP)] for s in sec], dtype=f)   # [E,4]
         grp = np.maximum(tp.group, 0)
-        ext = (f(self.p.flow_rate) * act[:, grp] * tp.ext_share[None].astype(f) / f(3600) * f(DT)
-               * self.xi[:, grp]) * (tp.group >= 0)[None]
+        gfac = (f(self.p.flow_rate) * act / f(3600) * f(DT) * self.xi).astype(f)       # [E,4] arrivals of each flow group
+        ext = gfac[:, grp] * tp.ext_share[None].astype(f) * (tp.group >= 0)[None]
         self.q = (self.q - served + self.tr).astype(f)
         self.tr = (acc + ext).astype(f)
         self.prev = a

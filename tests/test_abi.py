@@ -88,6 +88,13 @@ def test_net_image_layout_matches_header():
     assert {k[4:].lower(): int(v) for k, v in defs.items() if k.startswith('OFF_')} == _lib.NET_OFF
 
 
+def test_net_kernel_row_index_magic_is_exact():
+    """csrc/realnet.hip maps a flat state index to its node row by (i * ceil(65536 / L)) >> 16."""
+    for L in range(1, 25):
+        m = (65536 + L - 1) // L
+        assert all((i * m) >> 16 == i // L for i in range(32 * 24))
+
+
 def test_ops_fail_loudly_without_gpu_tensors():
     import pytest
     import torch

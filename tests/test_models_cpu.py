@@ -37,3 +37,30 @@ def test_ortho_init_matches_reference():
         w = ortho_init(tuple(int(x) for x in s))
         assert w.dtype == np.float32 and np.array_equal(w, z['w%d' % k])
     assert np.random.rand() == float(z['after'])
+
+
+@pytest.mark.parametrize('name', ['ma2c_nc_ragged', 'ia2c_fp_ragged', 'ma2c_ic3_ragged'])
+def test_heterogeneous_checkpoint_roundtrip_and_layout(name, tmp_path):
+    """Heterogeneous nets: variables are exported / re-imported under the reference's ragged shapes, padded entries
+    keep their fill (0, -1e30 for absent actions), and the update mask covers exactly the exported entries."""
+    import torch
+    z = load_npz(os.path.join(GOLDEN, 'nn_%s.npz' % name))
+    with cpu_ops():
+        m1 = build_product_model(z, 'cpu')
+        ps = m1.policy.params
+        named = ps.ref_variables()
+        assert [str(tuple(a.shape)) for _, a in named] == [str(s) for s in z['shapes']]
+        n_exported = sum(a.size for _, a in named)
+        if ps.mask is not None:
+            # mask == 1 exactly on entries of existing variables; padded-but-existing tensors are larger than the export
+            assert int(ps.mask.sum().item()) == n_exported
+        m1.save(str(tmp_path) + '/', 7)
+        m2 = build_product_model(z, 'cpu')
+        with torch.no_grad():
+            m2.policy.params.flat.add_(0.5)              # scramble, incl. the padding
+        assert m2.load(str(tmp_path) + '/')
+        for key in m1.policy.params.index:                   # every tensor incl. its padded entries (alignment gaps aside)
+            assert torch.equal(m1.policy.params[key], m2.policy.params[key]), key
+        pb = m2.policy.params['pi_b'].detach()
+        for i, n in enumerate(m2.n_a_ls):
+            assert (pb[i, n:] == -1e30).all() and (pb[i, :n] == 0).all()

@@ -413,7 +413,7 @@ class BatchedTrainer:
         model = self.model
         E0 = model.E
         h, c = (torch.zeros(self.N, n_envs, model.n_lstm, device=self.device) for _ in range(2))
-        fp = torch.full((self.N, n_envs, model.n_a), 1.0 / model.n_a, device=self.device)
+        fp = model.fp_uniform.expand(self.N, n_envs, model.n_a).clone()       # uniform over each agent's own actions
         env.reset()
         done = torch.ones(n_envs, device=self.device)
         act = torch.zeros(n_envs, self.N, dtype=torch.uint8, device=self.device)

@@ -20,11 +20,21 @@ agent = sys.argv[1] if len(sys.argv) > 1 else 'ia2c_fp'
 scenario = sys.argv[2] if len(sys.argv) > 2 else 'catchup'
 E = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
 n_batches = int(sys.argv[4]) if len(sys.argv) > 4 else 400
-cp = cacc_config(agent=agent, scenario=scenario, n_step=60, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
-env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+every = int(sys.argv[5]) if len(sys.argv) > 5 else 50
+if scenario.endswith('.ini'):                     # any shipped config: python tools/learn_curve.py ma2c_nc config/x.ini E batches
+    import configparser
+    from deeprl_network_amd.envs import make_batch_env
+    cp = configparser.ConfigParser()
+    cp.read(scenario)
+    cp['ENV_CONFIG']['agent'] = agent
+    env = make_batch_env(cp['ENV_CONFIG'], num_envs=E)
+    scenario = os.path.basename(scenario)[:-4]
+else:
+    cp = cacc_config(agent=agent, scenario=scenario, n_step=60, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
+    env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
 np.random.seed(12)
 model = AGENTS[agent](env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
-                      cp['MODEL_CONFIG'], seed=12, num_envs=E)
+                      cp['MODEL_CONFIG'], seed=12, num_envs=E, n_feat_ls=getattr(env, 'n_feat_ls', None))
 tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
 rows = []
 t0 = time.time()
@@ -33,7 +43,7 @@ rows.append(dict(batch=0, env_steps=0, test_avg_reward=m, test_collisions=c))
 print(json.dumps(rows[-1]))
 for b in range(1, n_batches + 1):
     tr.run_batch()
-    if b % 50 == 0:
+    if b % every == 0:
         st = tr.stats()
         m, s, c = tr.evaluate(n_envs=64)
         rows.append(dict(batch=b, env_steps=tr.global_counter.cur_step, train_episodes=st['episodes'],

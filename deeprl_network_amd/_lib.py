@@ -44,7 +44,8 @@ class Head(C.Structure):
                 ('w', C.c_void_p), ('w_sn', C.c_int64), ('b', C.c_void_p), ('b_sn', C.c_int64),
                 ('pi_out', C.c_void_p), ('pi_sn', C.c_int64), ('act_out', C.c_void_p), ('u', C.c_void_p),
                 ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('step', C.c_int64), ('step_dev', C.c_void_p),
-                ('act_in', C.c_void_p), ('nbr_idx', C.c_void_p), ('v_out', C.c_void_p), ('v_sn', C.c_int64)]
+                ('act_in', C.c_void_p), ('nbr_idx', C.c_void_p), ('v_out', C.c_void_p), ('v_sn', C.c_int64),
+                ('w2', C.c_void_p), ('w2_sn', C.c_int64), ('b2', C.c_void_p), ('b2_sn', C.c_int64)]
 
 
 class NetParams(C.Structure):
@@ -113,7 +114,7 @@ SIGNATURES = {
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
-    'nmarl_nbr_action_value_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _p],
+    'nmarl_nbr_action_value_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p],
     'nmarl_nbr_action_value_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p],
     'nmarl_bias_act': [_i64, _i32, _i32, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_lstm_cell_bwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],

@@ -222,8 +222,12 @@ class IA2C:
         t = self.t
         p = self.policy
         enc = p.encode(self.buf_x[t], self.fp)             # shared by the policy step and the value re-step (Q1)
+        draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+        if p.fused_pv:
+            p.step_policy_value(enc, self.h_fw, self.c_fw, done, self.buf_fp[t + 1], self.buf_act[t], self.buf_v[t], **draw)
+            return self.buf_act[t]
         p.step_policy(enc, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw, self.buf_fp[t + 1], self.buf_act[t],
-                      done_is_zero, mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+                      done_is_zero, **draw)
         p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, self.buf_act[t], self.buf_v[t], done_is_zero)
         return self.buf_act[t]
 
@@ -254,6 +258,10 @@ class IA2C:
         assert self.t == self.n_step
         p = self.policy
         enc = p.encode(self.buf_x[self.n_step], self.fp)
+        if p.fused_pv:
+            p.step_policy_value(enc, self.h_fw, self.c_fw, done, self._pi_boot, action_scratch, self._v_boot, mode=mode, u=u,
+                                seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+            return self._v_boot
         p.step_policy(enc, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw, self._pi_boot, action_scratch,
                       done_is_zero, mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
         return p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, action_scratch, self._v_boot,

@@ -346,6 +346,22 @@ class BatchedPolicy:
                 ops.sample_actions(pi_out, act_out, **draw)
         return pi_out, act_out
 
+    @property
+    def fused_pv(self):
+        """forward('p') and forward('v') of a lock-step fit ONE kernel: heads fuse and the recurrence has no
+        cross-agent term (the value re-step of a coupled net needs the other agents' new h)."""
+        return self.fused_heads and not self.coupled
+
+    def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, **draw):
+        """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) for uncoupled nets:
+        advances (h, c) in place by the policy step; the value comes from the re-stepped copy (quirk Q1)."""
+        with torch.no_grad():
+            z1, z2 = self._recur_addends(enc, h)
+            p = self.params
+            ops.lstm_step_policy_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, p['pi_w'], p['pi_b'], pi_out, act_out,
+                                       p['v_w'], p['v_b'], self.nbr_idx, self.n_a, v_out, **draw)
+        return act_out
+
     def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):
         """forward('v') of one lock-step (policies.py:124-133): the LSTM re-step and the critic on
         [h', onehot(neighbours' actions)], actions given as the env-major byte array action [E,N] -> v_out [N,E]."""

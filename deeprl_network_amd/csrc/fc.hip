@@ -316,7 +316,7 @@ constexpr int MAXW = 32;
 __global__ __launch_bounds__(256) void nbr_action_value_kernel(const int64_t rows, const int N, const int A, const int m_max,
                                                                const int32_t* __restrict__ nbr, const uint8_t* __restrict__ act,
                                                                const float* __restrict__ w, const int64_t w_sn,
-                                                               float* __restrict__ va) {
+                                                               float* __restrict__ va, const int accumulate) {
     const int64_t total = (int64_t)N * rows;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(idx / rows);
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void nbr_action_value_kernel(const int64_t row
             const int j = nbr[n * m_max + k];
             if (j >= 0) v += w[(int64_t)n * w_sn + k * A + act[r * N + j]];
         }
-        va[idx] = v;
+        va[idx] = accumulate ? va[idx] + v : v;
     }
 }
 
@@ -474,14 +474,15 @@ extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t
 }
 
 extern "C" int nmarl_nbr_action_value_fwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
-                                          const uint8_t* action, const float* w, int64_t w_sn, float* va, void* stream) {
+                                          const uint8_t* action, const float* w, int64_t w_sn, float* va,
+                                          int32_t accumulate, void* stream) {
     if (rows < 0 || N <= 0 || A <= 0 || m_max <= 0 || w_sn < (int64_t)m_max * A || (rows > 0 && (!nbr_idx || !action || !w || !va)))
         return NMARL_EINVAL;
     if (rows == 0) return NMARL_OK;
     int64_t blocks = ((int64_t)N * rows + 255) / 256;
     blocks = blocks > 4096 ? 4096 : blocks;
     hipLaunchKernelGGL(nbr_action_value_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), rows, N, A,
-                       m_max, nbr_idx, action, w, w_sn, va);
+                       m_max, nbr_idx, action, w, w_sn, va, accumulate);
     return nmarl_check_launch();
 }
 

@@ -188,7 +188,7 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
     const nmarl_head_t& hd = a.hd;
     const int A = hd.A;
     const int nout = KIND == 1 ? A : 1;
-    const float* w = hd.w + (int64_t)n * hd.w_sn;
+    const float* w = KIND == 3 ? hd.w2 + (int64_t)n * hd.w2_sn : hd.w + (int64_t)n * hd.w_sn;
     const int rl = lane & 15, q = lane >> 4;
     float acc[MAXA];
 #pragma unroll
@@ -212,7 +212,7 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
     }
     const int64_t row = row0 + rl;
     if (q != 0 || row >= a.E) return;
-    const float* b = hd.b + (int64_t)n * hd.b_sn;
+    const float* b = KIND == 3 ? hd.b2 + (int64_t)n * hd.b2_sn : hd.b + (int64_t)n * hd.b_sn;
     if (KIND == 1) {
         float p[MAXA];
         float m = -INFINITY;
@@ -238,10 +238,11 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
         hd.act_out[row * N + n] = (uint8_t)nmarl_draw_action<MAXA>(p, A, hd.mode, uh, hd.seed, hd.env_id_base + row, n, step);
     } else {
         float v = acc[0] + b[0];
-        for (int k = 0; k < hd.m_max; ++k) {
-            const int j = hd.nbr_idx[n * hd.m_max + k];
-            if (j >= 0) v += w[H + k * A + (int)hd.act_in[row * N + j]];
-        }
+        if (KIND == 2)                      // kind 3 leaves the neighbour-action term to nmarl_nbr_action_value_fwd (the
+            for (int k = 0; k < hd.m_max; ++k) {       // other agents' draws of this lock-step are made by other blocks)
+                const int j = hd.nbr_idx[n * hd.m_max + k];
+                if (j >= 0) v += w[H + k * A + (int)hd.act_in[row * N + j]];
+            }
         hd.v_out[(int64_t)n * hd.v_sn + row] = v;
     }
 }
@@ -333,6 +334,14 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
         }
     }
 
+    // HEAD 3 (forward 'p' + forward 'v' of one lock-step in one launch, uncoupled nets): the value re-step (quirk Q1)
+    // starts from the state this step produces and adds the SAME x-side addend, so keep a copy of it
+    f32x4 zs[HEAD == 3 ? 16 : 1];
+    if (HEAD == 3) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) zs[t] = acc[t];
+    }
+
     // K loop: 16 steps of K = 4;  A[i = lane & 15][k = lane >> 4],  B[k = lane >> 4][j = lane & 15]
 #pragma unroll 2
     for (int kk = 0; kk < H / 4; ++kk) {
@@ -372,6 +381,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
             const float cv = gf * (cp[jj][r] * keep) + gi * gu;
             const float hv = go * tanh_fast(cv);
             if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;      // K loop done: the tile is free
+            if (HEAD == 3) cp[jj][r] = cv;                                         // c' = the re-step's previous cell
             if (ok) {
                 const int j = jj * 16 + c;
                 cn[row * H + j] = cv;
@@ -387,7 +397,50 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        head_epilogue<HEAD>(a, n, (int)(gridDim.x / a.blocks_per_agent), row0, lane, a_tile);
+        head_epilogue<(HEAD == 3 ? 1 : HEAD)>(a, n, (int)(gridDim.x / a.blocks_per_agent), row0, lane, a_tile);
+    }
+    if (HEAD == 3) {
+        // ---- the value re-step: z = addend + (h' * keep) @ Wh, cell from c' * keep, critic on h'' (nothing stored but v)
+        const float keepA = 1.0f - a.done[row0 + c < a.E ? row0 + c : a.E - 1];      // row of this lane's A operand
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = zs[t];
+#pragma unroll 2
+        for (int kk = 0; kk < H / 4; ++kk) {
+            const float av = a_tile[c * APITCH + 4 * kk + grp] * keepA;
+            const float4* wq = reinterpret_cast<const float4*>(w_lds + (4 * kk + grp) * WPITCH + c * 20);
+            const float4 b0 = wq[0], b1 = wq[1], b2 = wq[2], b3 = wq[3];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.w, acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.x, acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.y, acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.z, acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.w, acc[7], 0, 0, 0);
+            acc[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.x, acc[8], 0, 0, 0);
+            acc[9] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.y, acc[9], 0, 0, 0);
+            acc[10] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.z, acc[10], 0, 0, 0);
+            acc[11] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.w, acc[11], 0, 0, 0);
+            acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.x, acc[12], 0, 0, 0);
+            acc[13] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.y, acc[13], 0, 0, 0);
+            acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.z, acc[14], 0, 0, 0);
+            acc[15] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.w, acc[15], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();                 // every lane has read its A operands: the tile may be overwritten
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float keep = 1.0f - a.done[rofs[r]];
+                const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
+                const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
+                const float cv = gf * (cp[jj][r] * keep) + gi * gu;
+                a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = go * tanh_fast(cv);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        head_epilogue<3>(a, n, (int)(gridDim.x / a.blocks_per_agent), row0, lane, a_tile);
     }
 }
 
@@ -403,11 +456,13 @@ static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int
     if (Hh != H || E < 0 || N <= 0 || (E > 0 && (!h_in || !wh || !bias || !zadd1 || !c_prev || !done || !c_new || !h_new)))
         return NMARL_EINVAL;
     const int kind = head ? head->kind : 0;
-    if (kind < 0 || kind > 2) return NMARL_EINVAL;
+    if (kind < 0 || kind > 3) return NMARL_EINVAL;
     if (kind != 0 && E > 0) {
-        if (head->A <= 0 || head->A > MAXA || !head->w || !head->b || head->b_sn < (kind == 1 ? head->A : 1)) return NMARL_EINVAL;
-        if (kind == 1 && (head->w_sn < (int64_t)H * head->A || !head->pi_out || head->pi_sn < E * head->A || !head->act_out ||
+        if (head->A <= 0 || head->A > MAXA || !head->w || !head->b || head->b_sn < (kind == 2 ? 1 : head->A)) return NMARL_EINVAL;
+        if ((kind == 1 || kind == 3) && (head->w_sn < (int64_t)H * head->A || !head->pi_out || head->pi_sn < E * head->A || !head->act_out ||
                           head->mode < 0 || head->mode > 2 || (head->mode == 0 && !head->u)))
+            return NMARL_EINVAL;
+        if (kind == 3 && (!head->w2 || !head->b2 || head->w2_sn < H || head->b2_sn < 1 || !head->v_out || head->v_sn < E))
             return NMARL_EINVAL;
         if (kind == 2 && (head->m_max < 0 || head->w_sn < H + (int64_t)head->m_max * head->A || !head->v_out || head->v_sn < E ||
                           (head->m_max > 0 && (!head->act_in || !head->nbr_idx))))
@@ -436,6 +491,7 @@ static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 0>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 0>), l2)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 1>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 1>), l2)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 2>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 2>), l2)
+        NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 3>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 3>), l2)
 #undef NMARL_SET_LDS
         variant = (ev && ev[0] == '1') ? 1 : 2;
     }
@@ -448,8 +504,8 @@ static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int
     } else {
         const size_t lds_bytes = (size_t)LDS2_FLOATS * sizeof(float);
 #define NMARL_LAUNCH16(Z2, HD) hipLaunchKernelGGL((lstm_step_mfma16_kernel<Z2, HD>), grid, dim3(512), lds_bytes, st, a)
-        if (zadd2) { if (kind == 0) NMARL_LAUNCH16(true, 0); else if (kind == 1) NMARL_LAUNCH16(true, 1); else NMARL_LAUNCH16(true, 2); }
-        else       { if (kind == 0) NMARL_LAUNCH16(false, 0); else if (kind == 1) NMARL_LAUNCH16(false, 1); else NMARL_LAUNCH16(false, 2); }
+        if (zadd2) { if (kind == 0) NMARL_LAUNCH16(true, 0); else if (kind == 1) NMARL_LAUNCH16(true, 1); else if (kind == 2) NMARL_LAUNCH16(true, 2); else NMARL_LAUNCH16(true, 3); }
+        else       { if (kind == 0) NMARL_LAUNCH16(false, 0); else if (kind == 1) NMARL_LAUNCH16(false, 1); else if (kind == 2) NMARL_LAUNCH16(false, 2); else NMARL_LAUNCH16(false, 3); }
 #undef NMARL_LAUNCH16
     }
     return nmarl_check_launch();

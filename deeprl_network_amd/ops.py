@@ -208,6 +208,30 @@ def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, 
     return v_out
 
 
+def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
+                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+    """forward('p') AND forward('v') of one lock-step (quirk Q1) for nets without a cross-agent recurrence, the state
+    (h, c) [N,E,64] advanced IN PLACE by the policy step only: one MFMA kernel (policy step + pi + draw, then the value
+    re-step from the new state with the same addend and the critic on h'') + the critic's neighbour-action term, which
+    needs all agents' draws, added by one small launch.  v_out [N,E] contiguous."""
+    N, E, H = h.shape
+    hd = _lib.Head()
+    hd.kind, hd.A, hd.mode = 3, pi_w.shape[2], mode
+    hd.w, hd.w_sn = _head_param(pi_w, 'lstm_step_policy_value')
+    hd.b, hd.b_sn = _bias(pi_b)
+    hd.pi_out, hd.pi_sn = _pn(pi_out)
+    hd.act_out, hd.u = ptr(act_out, torch.uint8), ptr(u, F32)
+    hd.seed, hd.env_id_base, hd.step, hd.step_dev = seed, env_id_base, int(step), ptr(step_dev, torch.int64)
+    hd.w2, hd.w2_sn = _head_param(v_w, 'lstm_step_policy_value')
+    hd.b2, hd.b2_sn = _bias(v_b)
+    if not v_out.is_contiguous() or v_out.shape != (N, E):
+        raise _lib.NmarlError('lstm_step_policy_value: v_out must be a contiguous [N,E] tensor')
+    hd.v_out, hd.v_sn = ptr(v_out, F32), E
+    _fused_head(h, wh, bias, zadd1, zadd2, c, done, c, h, hd, 'nmarl_lstm_step_fused_head[pv]')
+    nbr_action_value(act_out, nbr_idx, v_w[:, H:], n_a, out=v_out, accumulate=True)
+    return pi_out, act_out, v_out
+
+
 BIAS_NONE, BIAS_RELU, BIAS_TANH = 0, 1, 2
 
 
@@ -383,13 +407,14 @@ def thin_linear(h, w, b):
 NBR_ACT_MAX_W = 32
 
 
-def nbr_action_value(action, nbr_idx, w_a, n_a):
-    """va [N,rows] = onehot(neighbours' actions) @ w_a without the one-hot: action [rows,N] u8, w_a [N,m_max*A,(1)]."""
+def nbr_action_value(action, nbr_idx, w_a, n_a, out=None, accumulate=False):
+    """va [N,rows] = onehot(neighbours' actions) @ w_a without the one-hot: action [rows,N] u8, w_a [N,m_max*A,(1)].
+    `out` [N,rows] contiguous receives the result, or has it ADDED when `accumulate`."""
     rows, N = action.shape
-    va = torch.empty(N, rows, dtype=F32, device=action.device)
-    wp, ws = _head_param(w_a.view(N, -1, 1), 'nbr_action_value')
+    va = torch.empty(N, rows, dtype=F32, device=action.device) if out is None else out
+    wp, ws = _head_param(w_a.reshape(N, -1, 1) if w_a.dim() == 2 else w_a, 'nbr_action_value')
     check(lib.nmarl_nbr_action_value_fwd(rows, N, n_a, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(action, torch.uint8),
-                                         wp, ws, ptr(va), stream()), 'nmarl_nbr_action_value_fwd')
+                                         wp, ws, ptr(va, F32), 1 if accumulate else 0, stream()), 'nmarl_nbr_action_value_fwd')
     return va
 
 

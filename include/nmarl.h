@@ -291,6 +291,11 @@ int nmarl_lstm_step_fused(int64_t E, int32_t N, int32_t H, const float* h_in, in
  *       v = [h', onehot(neighbour actions)] @ w + b, w [N,H+m_max*A] (neighbour-major one-hot block, rows
  *       of absent neighbours unused), b [N,1]; neighbour actions are read from act_in [E,Ntot] u8 through
  *       nbr_idx [N,m_max] (-1 padded, as in nmarl_nbr_onehot)  -> v_out [N,E]
+ *   kind 3 (forward 'p' AND forward 'v' of one lock-step, quirk Q1, for nets whose recurrence has no cross-agent
+ *       term): kind 1, then the value re-step from the state just produced -- z = the same addend + (h'(1-done)) @ wh,
+ *       cell from c'(1-done) -- and v_h = h'' @ w2[:H] + b2 -> v_out [N,E]; h'' / c'' are not stored (the reference
+ *       discards them, policies.py:124-133).  The critic's neighbour-action term needs the other agents' draws of
+ *       this lock-step: add it with nmarl_nbr_action_value_fwd(accumulate = 1).
  * Agent strides in floats; `u` as in nmarl_sample_actions (mode 0).  A NULL head or kind 0 is
  * nmarl_lstm_step_fused.  NMARL_EINVAL for A > 8 (callers compose GEMM + softmax + nmarl_sample_actions).
  */
@@ -307,6 +312,8 @@ typedef struct nmarl_head {
     const uint8_t* act_in;
     const int32_t* nbr_idx;
     float* v_out; int64_t v_sn;
+    const float* w2; int64_t w2_sn;      /* kind 3: the critic's weights / bias (w, b are the actor's) */
+    const float* b2; int64_t b2_sn;
 } nmarl_head_t;
 int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t H, const float* h_in, int64_t h_sn,
                                const float* wh, int64_t wh_sn, const float* bias, int64_t bias_sn,
@@ -370,12 +377,13 @@ int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const f
 /*
  * Neighbour-action term of the centralised critic, v += one_hot(neighbours' actions) @ w_a (policies.py:59-77),
  * without the one-hot tensor: action [rows,N] u8, nbr_idx [N,m_max] (-1 padded), w_a [N,m_max*A].
- *   fwd: va[n,r] = sum_k w_a[n, k*A + action[r, nbr_idx[n,k]]]
+ *   fwd: va[n,r] (+)= sum_k w_a[n, k*A + action[r, nbr_idx[n,k]]]   (accumulate != 0: added to va)
  *   bwd: dw_a[n, k*A + a] = sum of dv[n,r] over the rows with action[r, nbr_idx[n,k]] == a   (m_max*A <= 32;
  *        partial [N, nmarl_fc_bwd_chunks(rows,N), m_max*A], fixed-order sums)
  */
 int nmarl_nbr_action_value_fwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
-                               const uint8_t* action, const float* w, int64_t w_sn, float* va, void* stream);
+                               const uint8_t* action, const float* w, int64_t w_sn, float* va, int32_t accumulate,
+                               void* stream);
 int nmarl_nbr_action_value_bwd(int64_t rows, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,
                                const uint8_t* action, const float* dv, float* partial, float* dw, int64_t dw_sn,
                                void* stream);

@@ -183,10 +183,25 @@ def thin_linear(h, w, b):
     return torch.baddbmm(b.unsqueeze(1), h, w)
 
 
-def nbr_action_value(action, nbr_idx, w_a, n_a):
+def nbr_action_value(action, nbr_idx, w_a, n_a, out=None, accumulate=False):
     """one_hot(neighbour actions) @ w_a (policies.py:66-72)."""
     N = action.shape[1]
-    return torch.bmm(nbr_onehot(action, nbr_idx, n_a).to(w_a.dtype), w_a.reshape(N, -1, 1)).squeeze(-1)
+    va = torch.bmm(nbr_onehot(action, nbr_idx, n_a).to(w_a.dtype), w_a.reshape(N, -1, 1)).squeeze(-1)
+    if out is None:
+        return va
+    out.copy_(out + va if accumulate else va)
+    return out
+
+
+def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
+                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+    """Trainer._get_policy + _get_value of one lock-step (utils.py:129-149): forward('p') advances the state, forward('v')
+    re-steps a COPY of it (policies.py:119-133, quirk Q1)."""
+    lstm_step_policy(h, wh, bias, zadd1, zadd2, c, done, c, h, pi_w, pi_b, pi_out, act_out, mode, u=u, seed=seed,
+                     env_id_base=env_id_base, step=step, step_dev=step_dev)
+    lstm_step_value(h, wh, bias, zadd1, zadd2, c, done, torch.empty_like(c), torch.empty_like(h), v_w, v_b, act_out,
+                    nbr_idx, n_a, v_out)
+    return pi_out, act_out, v_out
 
 
 def nbr_action_value_bwd(action, nbr_idx, dv, n_a):

@@ -248,6 +248,52 @@ def test_lstm_step_fused_heads(N, E, A, m_max, two_addends, mode):
     assert torch.all(vbuf[0] == 0) and torch.all(vbuf[2] == 0)
 
 
+@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (3, 127, 8, 2), (8, 1, 4, 2)])
+@pytest.mark.parametrize('two_addends', [False, True])
+@pytest.mark.parametrize('mode', [1, 2])
+def test_lstm_step_policy_value_one_kernel(N, E, A, m_max, two_addends, mode):
+    """forward('p') + forward('v') of a lock-step in one kernel (+ the neighbour-action add) == policy step, then the
+    value re-step from the new state (float64), with some replicas starting an episode (done = 1 masks BOTH steps)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 77 + E + A)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    h, c, z1 = r(N, E, H) * 0.7, r(N, E, H), r(N, E, 4 * H)
+    z2 = r(N, E, 4 * H) if two_addends else None
+    done = (torch.rand(E, generator=g) < 0.3).float()
+    wh, b = r(N, H, 4 * H) * 0.2, r(N, 4 * H) * 0.1
+    pi_w, pi_b = r(N, H, A) * 0.5, r(N, A) * 0.3
+    v_w, v_b = r(N, H + m_max * A, 1), r(N, 1)
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + 1]
+        idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    d = lambda t: None if t is None else t.double()                                     # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                      # noqa: E731
+    draw = dict(mode=mode, seed=5, env_id_base=40, step=3)
+    # product
+    hg, cg = h.cuda(), c.cuda()
+    pig, actg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda')
+    vg = torch.zeros(N, E, device='cuda')
+    ops.lstm_step_policy_value(hg, cu(wh), cu(b), cu(z1), cu(z2), cg, cu(done), cu(pi_w), cu(pi_b), pig, actg, cu(v_w), cu(v_b),
+                               cu(idx), A, vg, **draw)
+    # oracle: the policy half in float64, the draw from the kernel's own probabilities, then the value half
+    hr, cr = h.double(), c.double()
+    pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.lstm_step_policy(hr, d(wh), d(b), d(z1), d(z2), cr, d(done), cr, hr, d(pi_w), d(pi_b), pir, actr, **draw)
+    torch.testing.assert_close(hg.cpu().double(), hr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(cg.cpu().double(), cr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(pig.cpu().double(), pir, rtol=2e-5, atol=2e-6)
+    act_chk = torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.sample_actions(pig.cpu(), act_chk, **draw)
+    assert torch.equal(actg.cpu(), act_chk)
+    vr = torch.zeros(N, E, dtype=torch.float64)
+    ops_ref.lstm_step_value(hr, d(wh), d(b), d(z1), d(z2), cr, d(done), torch.empty_like(cr), torch.empty_like(hr), d(v_w),
+                            d(v_b), act_chk, idx, A, vr)
+    torch.testing.assert_close(vg.cpu().double(), vr, rtol=1e-4, atol=3e-5)
+
+
 def test_lstm_step_fused_head_rejects_wide_action_sets():
     from deeprl_network_amd import _lib, ops
     N, E, H, A = 2, 4, 64, 9

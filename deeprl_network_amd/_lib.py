@@ -68,8 +68,8 @@ NET_IMAGE_BYTES = 13568
 class FcPart(C.Structure):
     """nmarl_fc_part_t (include/nmarl.h): one layer of nmarl_fc_fwd_multi."""
     _fields_ = [('x', C.c_void_p), ('x_sn', C.c_int64), ('x_row', C.c_int64), ('F', C.c_int32), ('gather_A', C.c_int32),
-                ('m_max', C.c_int32), ('mean', C.c_int32), ('nbr_idx', C.c_void_p), ('w', C.c_void_p), ('w_sn', C.c_int64),
-                ('b', C.c_void_p), ('b_sn', C.c_int64), ('add', C.c_void_p), ('add_sn', C.c_int64), ('add_row', C.c_int64)]
+                ('m_max', C.c_int32), ('pad_', C.c_int32), ('nbr_idx', C.c_void_p), ('w', C.c_void_p), ('w_sn', C.c_int64),
+                ('b', C.c_void_p), ('b_sn', C.c_int64)]
 
 
 FC_MAX_PARTS = 4

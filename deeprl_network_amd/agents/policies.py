@@ -583,11 +583,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
 
     def _recur_addends(self, enc, h):
         p = self.params
-        if self.n_h == ops.FC_J:
-            # s = tanh-encoding + mean_nbr(h) W_msg + b_msg (agents/utils.py:395-400) in ONE launch
-            s = ops.fc_fwd_multi([(h, p['w_msg'], p['w_msg_b'], self.nbr_idx)], ops.BIAS_NONE, mean=True, addend=enc)
-        else:
-            s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
+        s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
         return torch.bmm(s, p['wx_hid']), None
 
     def _seq_args(self):

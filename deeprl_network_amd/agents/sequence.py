@@ -51,11 +51,8 @@ class CoupledSequence(torch.autograd.Function):
                 ops.bias_act_(torch.bmm(ops.nbr_gather(hp, nbr_idx), w_msg), b_msg, ops.BIAS_RELU, out=A1[:, t])
                 z1, z2 = enc[:, t], torch.bmm(A1[:, t], wx)
             elif kind == 'ic3':
-                if H == ops.FC_J:      # mean over the neighbours + message layer + the encoding, one launch into A1[:, t]
-                    ops.fc_fwd_multi([(hp, w_msg, b_msg, nbr_idx)], ops.BIAS_NONE, out=A1[:, t], mean=True, addend=enc[:, t])
-                else:
-                    s = ops.bias_act_(torch.bmm(ops.nbr_mean(hp, nbr_idx), w_msg), b_msg, ops.BIAS_NONE)
-                    torch.add(s, enc[:, t], out=A1[:, t])
+                s = ops.bias_act_(torch.bmm(ops.nbr_mean(hp, nbr_idx), w_msg), b_msg, ops.BIAS_NONE)
+                torch.add(s, enc[:, t], out=A1[:, t])
                 z1, z2 = torch.bmm(A1[:, t], wx), None
             else:
                 ops.bias_act_(torch.bmm(hp, mfc_w), mfc_b, ops.BIAS_RELU, out=A2[:, t])

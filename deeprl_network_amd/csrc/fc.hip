@@ -114,35 +114,16 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
             stage_tile<FMAX>(xs, pt.x + (int64_t)n * pt.x_sn, pt.x_row, row0, rows, F);
         } else {
             const int A = pt.gather_A;
-            if (pt.mean) {                                   // mean over the listed neighbours (fixed order: ascending slot)
-                int js[8], cnt = 0;
-                for (int k = 0; k < pt.m_max && k < 8; ++k) {
-                    const int j = pt.nbr_idx[n * pt.m_max + k];
-                    if (j >= 0) js[cnt++] = j;
+            for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
+                const int r = idx / FMAX, f = idx - r * FMAX;
+                const int64_t row = row0 + r;
+                float v = 0.0f;
+                if (f < F && row < rows) {
+                    const int k = f / A;
+                    const int src = pt.nbr_idx[n * pt.m_max + k];
+                    if (src >= 0) v = pt.x[(int64_t)src * pt.x_sn + row * pt.x_row + (f - k * A)];
                 }
-                const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
-                for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
-                    const int r = idx / FMAX, f = idx - r * FMAX;
-                    const int64_t row = row0 + r;
-                    float v = 0.0f;
-                    if (f < F && row < rows) {
-                        for (int q = 0; q < cnt; ++q) v += pt.x[(int64_t)js[q] * pt.x_sn + row * pt.x_row + f];
-                        v *= inv;
-                    }
-                    xs[r * FP + f] = v;
-                }
-            } else {
-                for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
-                    const int r = idx / FMAX, f = idx - r * FMAX;
-                    const int64_t row = row0 + r;
-                    float v = 0.0f;
-                    if (f < F && row < rows) {
-                        const int k = f / A;
-                        const int src = pt.nbr_idx[n * pt.m_max + k];
-                        if (src >= 0) v = pt.x[(int64_t)src * pt.x_sn + row * pt.x_row + (f - k * A)];
-                    }
-                    xs[r * FP + f] = v;
-                }
+                xs[r * FP + f] = v;
             }
         }
         __syncthreads();
@@ -158,11 +139,7 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
                 acc = fmaf(xv.w, wr[4 * f4 + 3], acc);
             }
             const int64_t row = row0 + rr;
-            if (row < rows) {
-                float v = act_fwd(acc + bj, act);
-                if (pt.add) v += pt.add[(int64_t)n * pt.add_sn + row * pt.add_row + j];
-                yn[row * y_row + j] = v;
-            }
+            if (row < rows) yn[row * y_row + j] = act_fwd(acc + bj, act);
         }
         __syncthreads();
     }
@@ -440,11 +417,9 @@ extern "C" int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, cons
     for (int i = 0; i < n_parts; ++i) {
         const nmarl_fc_part_t& p = parts[i];
         if (p.F <= 0 || p.F > 64 || !p.x || !p.w || !p.b || p.w_sn < (int64_t)p.F * J || p.b_sn < J) return NMARL_EINVAL;
-        if (p.nbr_idx ? (p.gather_A <= 0 || p.m_max <= 0 || p.F != (p.mean ? p.gather_A : p.gather_A * p.m_max) ||
-                         p.x_row < p.gather_A)
-                      : (p.x_row < p.F || p.mean))
+        if (p.nbr_idx ? (p.gather_A <= 0 || p.m_max <= 0 || p.F != p.gather_A * p.m_max || p.x_row < p.gather_A)
+                      : p.x_row < p.F)
             return NMARL_EINVAL;
-        if (p.add && (p.add_row < J || p.add_sn < (rows - 1) * p.add_row + J)) return NMARL_EINVAL;
         ps.p[i] = p;
         fmax = p.F > fmax ? p.F : fmax;
     }

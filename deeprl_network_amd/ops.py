@@ -278,11 +278,10 @@ def fc_fwd(x, w, b, act, out=None):
     return out
 
 
-def fc_fwd_multi(parts, act, out=None, mean=False, addend=None):
+def fc_fwd_multi(parts, act, out=None):
     """Several small-K layers in ONE launch: parts = [(x, w, b, nbr_idx or None), ...]; layer p writes columns
     [64p, 64p+64) of out [N,rows,64*len(parts)].  With nbr_idx the layer's input is gather(x) over the neighbour table
-    (x [N,rows,A] -> F = m_max*A) without materialising it -- or, with `mean`, the MEAN over the neighbours (F = A).
-    `addend` [N,rows,64] (single layer) is added to the layer's output.  No autograd."""
+    (x [N,rows,A] -> F = m_max*A) without materialising it.  No autograd (rollout)."""
     N, rows = parts[0][0].shape[:2]
     n = len(parts)
     if out is None:
@@ -294,14 +293,8 @@ def fc_fwd_multi(parts, act, out=None, mean=False, addend=None):
         if nbr_idx is None:
             pt.F = x.shape[2]
         else:
-            pt.gather_A, pt.m_max = x.shape[2], nbr_idx.shape[1]
-            pt.mean = 1 if mean else 0
-            pt.F = x.shape[2] if mean else x.shape[2] * nbr_idx.shape[1]
+            pt.gather_A, pt.m_max, pt.F = x.shape[2], nbr_idx.shape[1], x.shape[2] * nbr_idx.shape[1]
             pt.nbr_idx = ptr(nbr_idx, torch.int32)
-        if addend is not None:
-            if n != 1:
-                raise _lib.NmarlError('fc_fwd_multi: an addend needs a single layer')
-            pt.add, pt.add_sn, pt.add_row = _rows_view(addend, FC_J, 'fc_fwd_multi addend')
         if w.shape[1] != pt.F or w.shape[2] != FC_J:
             raise _lib.NmarlError('fc_fwd_multi: layer %d weight shape %s does not match input width %d' % (i, tuple(w.shape), pt.F))
         pt.w, pt.w_sn = _head_param(w, 'fc_fwd_multi')

@@ -348,17 +348,14 @@ int nmarl_fc_fwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, 
  * h-independent encoding of a lock-step: fcs || fcp of policies.py:176-181, w_ob || w_fp of agents/utils.py:186-199).
  * nbr_idx != NULL: the layer's input is gathered through the neighbour table, x~[n,r,k*A+a] = x[nbr_idx[n,k],r,a]
  * with x [N,rows,gather_A] (the previous-step policies), F = m_max*gather_A  (cacc_env.py:244-248 get_fingerprint +
- * models.py:171-179).  mean != 0: the input is the MEAN over the listed neighbours instead, x~[n,r,f] = mean_k
- * x[nbr_idx[n,k],r,f] (0 without neighbours), F = gather_A: with act = none and add = tanh(x W_ob + b) this is CommNet's
- * s = tanh(..) + mean_nbr(h) W_msg + b_msg (lstm_ic3, agents/utils.py:395-400) in one launch. */
+ * models.py:171-179). */
 #define NMARL_FC_MAX_PARTS 4
 typedef struct nmarl_fc_part {
     const float* x; int64_t x_sn, x_row;
-    int32_t F, gather_A, m_max, mean;
+    int32_t F, gather_A, m_max, pad_;
     const int32_t* nbr_idx;
     const float* w; int64_t w_sn;
     const float* b; int64_t b_sn;
-    const float* add; int64_t add_sn, add_row;   /* optional [N,rows,64] addend of the layer's OUTPUT (after act) */
 } nmarl_fc_part_t;
 int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, const nmarl_fc_part_t* parts, int32_t act,
                        float* y, int64_t y_sn, int64_t y_row, void* stream);

@@ -150,14 +150,10 @@ def fc_fwd(x, w, b, act, out=None):
     return y
 
 
-def fc_fwd_multi(parts, act, out=None, mean=False, addend=None):
-    """tf.concat of fc layers, a layer's input optionally gathered (models.py:171-179) or averaged (agents/utils.py:395)
-    over the neighbour table; `addend` is added to the single layer's output (lstm_ic3's s, agents/utils.py:399-400)."""
-    ys = [fc_fwd(x if nbr_idx is None else (nbr_mean(x, nbr_idx) if mean else nbr_gather(x, nbr_idx)), w, b, act)
-          for x, w, b, nbr_idx in parts]
+def fc_fwd_multi(parts, act, out=None):
+    """tf.concat of fc layers, a layer's input optionally gathered over the neighbour table (models.py:171-179)."""
+    ys = [fc_fwd(x if nbr_idx is None else nbr_gather(x, nbr_idx), w, b, act) for x, w, b, nbr_idx in parts]
     y = torch.cat(ys, dim=-1)
-    if addend is not None:
-        y = y + addend
     if out is not None:
         out.copy_(y)
         return out

@@ -365,29 +365,6 @@ def test_fc_fwd_multi_with_gathered_fingerprints(N, rows, Fx, A, m_max):
     torch.testing.assert_close(got.cpu().double(), ref, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('N,rows,m_max', [(8, 4096, 2), (25, 1030, 4), (5, 3, 2)])
-def test_fc_fwd_multi_mean_message_with_addend(N, rows, m_max):
-    """CommNet's s = enc + mean_nbr(h) W_msg + b_msg in one launch (isolated agents receive no message), reading h and
-    writing s as slots of sequence buffers."""
-    from deeprl_network_amd import ops
-    from oracle import ops_ref
-    g = torch.Generator().manual_seed(N + rows)
-    idx = -torch.ones(N, m_max, dtype=torch.int32)
-    for i in range(N - 1):                                   # the last agent has no neighbours
-        others = [j for j in range(N) if j != i][:(i % m_max) + 1]
-        idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
-    h = torch.randn(N, 3, rows, 64, generator=g)
-    enc = torch.randn(N, 3, rows, 64, generator=g)
-    w, b = torch.randn(N, 64, 64, generator=g) * 0.2, torch.randn(N, 64, generator=g) * 0.1
-    ref = ops_ref.fc_fwd_multi([(h[:, 1].double(), w.double(), b.double(), idx)], 0, mean=True, addend=enc[:, 1].double())
-    hg, eg = h.cuda(), enc.cuda()
-    out = torch.zeros(N, 3, rows, 64, device='cuda')
-    ops.fc_fwd_multi([(hg[:, 1].contiguous(), w.cuda(), b.cuda(), idx.cuda())], 0, out=out[:, 2], mean=True, addend=eg[:, 1])
-    torch.testing.assert_close(out[:, 2].cpu().double(), ref, rtol=1e-5, atol=1e-5)
-    assert torch.all(out[:, 0] == 0) and torch.all(out[:, 1] == 0)
-    torch.testing.assert_close(out[N - 1, 2].cpu(), enc[N - 1, 1] + b[N - 1], rtol=1e-6, atol=1e-6)
-
-
 def test_fc_concat_autograd_matches_torch():
     from deeprl_network_amd import ops
     N, rows = 8, 1000

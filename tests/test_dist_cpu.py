@@ -21,14 +21,23 @@ def _run(agent, E, env_id_base, group, n_batches):
     from helpers import cacc_config
     from deeprl_network_amd.agents import models
     from deeprl_network_amd.utils import BatchedTrainer, Counter
-    cp = cacc_config(agent=agent, n_step=10, reward_norm=800.0)
-    cp['ENV_CONFIG']['episode_length_sec'] = '2'
     with cpu_ops():
-        env = CpuCaccBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
+        if agent.endswith('@net'):       # the heterogeneous network (28 agents, masked padded parameters)
+            from cpu_emulation import CpuRealNetBatchEnv
+            from helpers import net_config
+            agent = agent[:-4]
+            cp = net_config(agent=agent, n_step=10)
+            cp['ENV_CONFIG']['episode_length_sec'] = '100'                # T = 20 = 2 batches
+            env = CpuRealNetBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
+        else:
+            cp = cacc_config(agent=agent, n_step=10, reward_norm=800.0)
+            cp['ENV_CONFIG']['episode_length_sec'] = '2'
+            env = CpuCaccBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
         np.random.seed(12)
         cls = {'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC}[agent]
         model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 6,
-                    cp['MODEL_CONFIG'], seed=12, num_envs=E, device='cpu', dist_group=group)
+                    cp['MODEL_CONFIG'], seed=12, num_envs=E, device='cpu', dist_group=group,
+                    n_feat_ls=getattr(env, 'n_feat_ls', None))
         world = 1 if group is None else dist.get_world_size(group)
         tr = BatchedTrainer(env, model, Counter(10 ** 9, 10 ** 9, 10 ** 9), use_graph=False,
                             rank=0 if group is None else dist.get_rank(group), world_size=world)
@@ -47,9 +56,9 @@ def _worker(rank, world, port, agent, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ma2c_nc@net'])
 def test_two_ranks_equal_one_process(agent, tmp_path):
-    port = 29500 + (os.getpid() % 2000) + (7 if agent == 'ma2c_nc' else 0)
+    port = 29500 + (os.getpid() % 2000) + {'ia2c_fp': 0, 'ma2c_nc': 7, 'ma2c_nc@net': 13}[agent]
     mp.spawn(_worker, args=(2, port, agent, str(tmp_path)), nprocs=2, join=True)
     w0, s0 = torch.load(tmp_path / 'rank0.pt')
     w1, s1 = torch.load(tmp_path / 'rank1.pt')

@@ -8,13 +8,15 @@
 //
 // Mapping (as csrc/grid.hip): one replica per 32-lane half wave, lane = intersection; a lane keeps the queues of
 // its <= 24 links in registers.  Cross-node quantities go through LDS between half-wave barriers:
-//   out[j]      what node j could discharge this step
+//   out[j]      what node j offers to each link it feeds (its discharge / its fan-out)
 //   acc[i][k]   what link k of node i accepts from its feeder (spill-back: limited by the free space)
 //   cnt[i][k]   detector counts, from which the neighbour-gathered observation slab is assembled and written
 //               with coalesced stores.
 // All sums run in a fixed order (the feeder adds up its fan-out list in ascending (node, link)): bit-reproducible.
-// HBM-bound: per replica-step reads q, transit 2*4*sum(n_s) + action/prev N + 20 B and writes the same state back
-// plus the slab 4*L*(1+m_max)*N (12.3 KB for Monaco, of which 4*sum_i(n_s_i + sum_nbr n_s_j) = 5.0 KB are non-padding).
+// The static tables are copied into LDS once per block from a host-packed image; the replica's state rows are staged
+// through LDS with coalesced accesses.  Algorithmic bytes per replica-step: q, transit 2*4*sum(n_s) in and out +
+// action/prev N + 20 B + the slab 4*L*(1+m_max)*N (12.3 KB for Monaco, of which 4*sum_i(n_s_i + sum_nbr n_s_j) =
+// 5.0 KB are non-padding).  The intended bound is HBM; today the kernel is instruction-bound.
 #include "common.h"
 #include <stdlib.h>
 
@@ -31,7 +33,7 @@ struct RepShared {
     float cnt[NMAX * LMAX];          // also the staging area of transit
 };
 
-__device__ __forceinline__ void half_barrier() { __syncthreads(); }   // the 8 replicas of a block run in lock step
+__device__ __forceinline__ void half_barrier() { __syncthreads(); }   // the replicas of a block run in lock step
 
 // real_net_data/build_file.py:70-72: number of active flows per 5-minute piece, groups 0,1 (a) and 2,3 (b); pure
 // arithmetic (a table lookup per link put one constant-memory round trip per link on the critical path)

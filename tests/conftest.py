@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
+    # the binding refuses a missing or stale libnmarl_hip.so: (re)build it once per session when the sources changed
+    # (hipcc cross-compiles gfx950 without a GPU; on the GPU box the shipped library matches and nothing is built)
+    from deeprl_network_amd import build
+    if build.stale() and os.path.exists(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')):
+        build.build_native(verbose=False)
 
 
 @pytest.fixture(scope='session')

@@ -25,6 +25,13 @@ import os
 import sys
 import time
 
+# GEMM auto-tuning of the library products (PyTorch TunableOp over hipBLASLt / rocBLAS): each distinct GEMM shape is
+# tuned once, at its first (untimed, warm-up) occurrence; the choices go to a per-device scratch file.  Must be set before
+# torch initialises its BLAS handles.  `NMARL_BENCH_TUNABLEOP=0` (or --no-tunableop) measures the untuned library.
+if os.environ.get('NMARL_BENCH_TUNABLEOP', '1') != '0' and '--no-tunableop' not in sys.argv:
+    os.environ.setdefault('PYTORCH_TUNABLEOP_ENABLED', '1')
+    os.environ.setdefault('PYTORCH_TUNABLEOP_FILENAME', '/tmp/nmarl_tunableop_%d.csv')
+
 import numpy as np
 import torch
 
@@ -57,6 +64,7 @@ def parse():
     ap.add_argument('--envs', type=int, default=0, help='replicas per GPU (default: num_envs of the ini)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-tunableop', action='store_true', help='do not auto-tune the library GEMMs (PyTorch TunableOp)')
     ap.add_argument('--cpu-batches', type=int, default=100,
                     help='n_step batches of the E=1 CPU baseline (100 = 6000 env steps, about 13 s on one core)')
     return ap.parse_args()
@@ -241,6 +249,7 @@ def main():
                                   os.path.basename(args.config), n_step),
                    'replicas_per_gpu': E, 'global_replicas': E * world, 'parallelism': 'dp%d' % world,
                    'hipgraph_rollout': trainer.use_graph,
+                   'gemm_autotune': os.environ.get('PYTORCH_TUNABLEOP_ENABLED', '0') == '1',
                    'step_definition': 'one n_step batch: %d lock-steps (2 LSTM steps each, quirk Q1) + bootstrap + '
                                       '1 A2C update over all replicas' % n_step},
     }

@@ -1,7 +1,8 @@
 """bench.py -- env-steps/s of the batched rollout + A2C update on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+     or plainly -- without a torchrun environment the script re-launches itself with N ranks)
 
 Workload (BASELINE.json configs[1]): CACC catch-up, 8 agents x 4096 lock-stepped replicas per GPU,
 IA2C-FP (config/config_ia2c_fp_catchup.ini), fp32, synthetic (Philox initial conditions, random-init
@@ -165,36 +166,28 @@ def cpu_baseline(cfg_path, n_batches):
             'updates_per_s': n_batches / sec}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                             % (args.gpus, args.gpus))
-    import torch.distributed as dist
-    # test hooks (1-GPU boxes): NMARL_BENCH_ONE_DEVICE=1 maps every rank to cuda:0, NMARL_DIST_BACKEND=gloo swaps RCCL
-    if os.environ.get('NMARL_BENCH_ONE_DEVICE') == '1':
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    group = None
-    if world > 1:
-        backend = os.environ.get('NMARL_DIST_BACKEND', 'nccl')   # 'nccl' IS RCCL on ROCm (xGMI)
-        if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=device)
-        else:
-            dist.init_process_group(backend)
-        group = dist.group.WORLD
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-exec this script under
+    torch.distributed.run with N ranks on this node (one rank per GPU, rendezvous on 127.0.0.1)
+    and pass its exit code through.  Rank 0 of the child job prints the ONE JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
+
+def make_job(args, cp, device, rank, world, group):
+    """(env, model, trainer) of one rank: E replicas with global replica ids rank*E ... (Philox streams)."""
     from deeprl_network_amd.agents import models
     from deeprl_network_amd.envs import make_batch_env
     from deeprl_network_amd.utils import BatchedTrainer, Counter
-
-    cp = configparser.ConfigParser()
-    cp.read(args.config)
     E = args.envs or cp['ENV_CONFIG'].getint('num_envs', fallback=4096)
     env = make_batch_env(cp['ENV_CONFIG'], num_envs=E, device=device, env_id_base=rank * E)
     np.random.seed(env.seed)                               # identical initial weights on every rank
@@ -205,12 +198,74 @@ def main():
                 n_feat_ls=getattr(env, 'n_feat_ls', None))
     trainer = BatchedTrainer(env, model, Counter(int(1e18), int(1e18), int(1e18)), use_graph=not args.no_graph,
                              rank=rank, world_size=world)
+    return E, env, model, trainer
 
+
+def tune_once(args, cp, device, rank, world):
+    """N > 1: the library GEMMs are tuned ONCE, by rank 0 on a throw-away single-rank job (no collective inside),
+    while the other ranks wait at a barrier; rank 0 writes the TunableOp file and every other rank reads it -- instead
+    of N ranks tuning the same shapes concurrently inside --warmup."""
+    import torch.cuda.tunable as tunable
+    import torch.distributed as dist
+    if not tunable.is_enabled():
+        return
+    path = os.environ.get('NMARL_TUNABLEOP_SHARED', '/tmp/nmarl_tunableop_shared_%d.csv' % os.getppid())
+    if rank == 0:
+        tunable.tuning_enable(True)
+        _, _, _, tr = make_job(args, cp, device, 0, 1, None)
+        tr.run_batch()
+        torch.cuda.synchronize()
+        del tr
+        tunable.write_file(path)
+    else:
+        tunable.tuning_enable(False)
+    dist.barrier()
+    if rank != 0:
+        tunable.read_file(path)
+    tunable.tuning_enable(False)                           # every rank now replays rank 0's choices
+    dist.barrier()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'RANK' not in os.environ and args.gpus > 1:
+        self_launch(args)
+    if args.gpus != world:
+        raise SystemExit('bench.py --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    import torch.distributed as dist
+    # test hooks (1-GPU boxes): NMARL_BENCH_ONE_DEVICE=1 maps every rank to cuda:0, NMARL_DIST_BACKEND=gloo swaps RCCL,
+    # NMARL_BENCH_FORCE_DIST=1 creates the process group (and the gradient all-reduce) even for one rank
+    if os.environ.get('NMARL_BENCH_ONE_DEVICE') == '1':
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    group = None
+    use_dist = world > 1 or os.environ.get('NMARL_BENCH_FORCE_DIST') == '1'
+    if use_dist:
+        backend = os.environ.get('NMARL_DIST_BACKEND', 'nccl')   # 'nccl' IS RCCL on ROCm (xGMI)
+        if 'RANK' not in os.environ:
+            os.environ.update(RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1',
+                              MASTER_PORT=os.environ.get('MASTER_PORT', '29611'))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
+        group = dist.group.WORLD
+
+    cp = configparser.ConfigParser()
+    cp.read(args.config)
+    if world > 1:
+        tune_once(args, cp, device, rank, world)
+    from deeprl_network_amd.envs import make_batch_env
+    E, env, model, trainer = make_job(args, cp, device, rank, world, group)
     for _ in range(args.warmup):
         trainer.run_batch()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -220,7 +275,7 @@ def main():
         trainer.run_batch()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -314,7 +369,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not is_grid:
             out['cpu_baseline'] = cpu_baseline(args.config, args.cpu_batches)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -151,6 +151,9 @@ def ptr(t, dtype=None, strided=False):
         return None
     if not t.is_cuda:
         raise NmarlError('nmarl ops need HIP device tensors (got %s); there is no CPU path' % t.device)
+    if t.device.index != torch.cuda.current_device():
+        raise NmarlError('tensor on %s but the current device is cuda:%d: call torch.cuda.set_device first '
+                         '(kernels launch on the current device\'s stream)' % (t.device, torch.cuda.current_device()))
     if not strided and not t.is_contiguous():
         raise NmarlError('nmarl ops need contiguous tensors')
     if dtype is not None and t.dtype != dtype:
@@ -159,4 +162,7 @@ def ptr(t, dtype=None, strided=False):
 
 
 def stream():
+    """torch's current stream of the CURRENT device: launches are made there, so every tensor handed to an op must
+    live on that device (`ptr` checks it -- a model built on cuda:1 without torch.cuda.set_device(1) fails loudly
+    instead of launching on the wrong GPU)."""
     return torch.cuda.current_stream().cuda_stream

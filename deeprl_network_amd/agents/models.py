@@ -300,8 +300,9 @@ class IA2C:
     def update(self, R_end):
         """model.backward (models.py:34-42 / 211-215) for all replicas: R_end [N,E]."""
         assert self.t == self.n_step, 'update() needs a full n_step batch (got %d)' % self.t
-        # the schedule counts environment steps: n_step per replica (E = 1: the reference's get(n_step))
-        cur_lr = self.lr_scheduler.get(self.n_step * self.E * self.world_size)
+        # the schedule counts lock-steps (environment steps per replica), the reference's get(n_step): the ini's
+        # total_step keeps its meaning for any number of replicas and ranks
+        cur_lr = self.lr_scheduler.get(self.n_step)
         alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
         ops.nstep_return(self.buf_r, self.buf_v, self.buf_done_post, R_end.contiguous(), self.gamma, alpha,
                          self.dist_dev, self.R, self.Adv)
@@ -419,11 +420,16 @@ class IA2C:
 
     # ------------------------------------------------------------------ checkpoints (models.py:53-82)
     def save(self, model_dir, global_step):
+        """`checkpoint-<step>.pt` (the reference writes TF Saver files `checkpoint-<step>.*`, models.py:53-58; the two
+        formats are not interchangeable): a dict of plain tensors / numbers only, so it loads with
+        torch.load(weights_only=True) -- variables under the reference's names and ragged shapes, the RMSProp slots,
+        the lr schedule position."""
         path = model_dir + 'checkpoint-%d.pt' % int(global_step)
         ps = self.policy.params
-        torch.save({'variables': dict(ps.ref_variables()), 'rmsprop_ms': ps.ms.cpu(), 'name': self.name,
-                    'global_step': int(global_step), 'lr_n': getattr(self, 'lr_scheduler', None) and self.lr_scheduler.n},
-                   path)
+        sched = getattr(self, 'lr_scheduler', None)
+        torch.save({'variables': {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ps.ref_variables()},
+                    'rmsprop_ms': ps.ms.detach().cpu(), 'name': self.name, 'global_step': int(global_step),
+                    'lr_n': float(sched.n) if sched is not None else -1.0}, path)
         # keep the 5 newest, like tf.train.Saver(max_to_keep=5)
         found = sorted(self._list_checkpoints(model_dir))
         for step, f in found[:-5]:
@@ -440,6 +446,7 @@ class IA2C:
         return out
 
     def load(self, model_dir, checkpoint=None):
+        """models.py:60-82: newest `checkpoint-<step>` of the directory, or the given step; False if there is none."""
         save_file = None
         if os.path.exists(model_dir):
             if checkpoint is None:
@@ -448,11 +455,13 @@ class IA2C:
                     save_file = found[-1][1]
             else:
                 save_file = 'checkpoint-%d.pt' % int(checkpoint)
-        if save_file is not None:
-            blob = torch.load(os.path.join(model_dir, save_file), weights_only=False)
-            self.policy.params.load_ref_variables(blob['variables'])
+        if save_file is not None and os.path.isfile(os.path.join(model_dir, save_file)):
+            blob = torch.load(os.path.join(model_dir, save_file), weights_only=True, map_location='cpu')
+            self.policy.params.load_ref_variables({k: v.numpy() for k, v in blob['variables'].items()})
             if 'rmsprop_ms' in blob:
                 self.policy.params.ms.copy_(blob['rmsprop_ms'])
+            if blob.get('lr_n', -1.0) >= 0 and getattr(self, 'lr_scheduler', None) is not None:
+                self.lr_scheduler.n = blob['lr_n']       # resume the lr decay where it stopped
             logging.info('Checkpoint loaded: %s' % save_file)
             return True
         logging.error('Can not find old checkpoint for %s' % model_dir)

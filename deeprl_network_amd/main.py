@@ -61,7 +61,7 @@ def _dist():
 def train(args):
     world, rank, local, group = _dist()
     dirs = init_dir(args.base_dir)
-    init_log(dirs['log'])
+    init_log(dirs['log'], rank)
     if rank == 0:
         copy_file(args.config_dir, dirs['data'])
     config = configparser.ConfigParser()

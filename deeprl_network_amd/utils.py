@@ -43,21 +43,20 @@ def find_file(cur_dir, suffix='.ini'):
 
 
 def init_dir(base_dir, pathes=('log', 'data', 'model')):
-    if not os.path.exists(base_dir):
-        os.makedirs(base_dir)
+    """exist_ok everywhere: under torchrun every rank calls this on the same fresh base dir."""
     dirs = {}
     for path in pathes:
         cur_dir = base_dir + '/%s/' % path
-        if not os.path.exists(cur_dir):
-            os.mkdir(cur_dir)
+        os.makedirs(cur_dir, exist_ok=True)
         dirs[path] = cur_dir
     return dirs
 
 
-def init_log(log_dir):
-    logging.basicConfig(format='%(asctime)s [%(levelname)s] %(message)s', level=logging.INFO,
-                        handlers=[logging.FileHandler('%s/%d.log' % (log_dir, time.time())),
-                                  logging.StreamHandler()])
+def init_log(log_dir, rank=0):
+    """One log file per rank (`<time>.log`, `<time>.rank<r>.log` for r > 0); only rank 0 echoes to the console."""
+    name = '%s/%d%s.log' % (log_dir, time.time(), '' if rank == 0 else '.rank%d' % rank)
+    handlers = [logging.FileHandler(name)] + ([logging.StreamHandler()] if rank == 0 else [])
+    logging.basicConfig(format='%(asctime)s [%(levelname)s] %(message)s', level=logging.INFO, handlers=handlers)
 
 
 class Counter:
@@ -393,7 +392,9 @@ class BatchedTrainer:
         self.done_pre.copy_(done.to(torch.float32))
         self.n_batches += 1
         if self.global_counter is not None:
-            self.global_counter.advance(self.n_step * self.E * self.world_size)
+            # the counter (like the reference's global step and the lr schedule) counts LOCK-steps, i.e. environment
+            # steps per replica: `total_step` of the ini keeps its meaning (1e6 -> 16 667 updates at n_step 60)
+            self.global_counter.advance(self.n_step)
 
     def stats(self, reset=True):
         """(episodes finished, mean of episode-mean reward, mean of episode-std, collisions) since last call."""
@@ -435,26 +436,47 @@ class BatchedTrainer:
         per_ep = (total / steps.clamp_min(1)).cpu().numpy()
         return float(per_ep.mean()), float(per_ep.std()), int((steps < env.T).sum().item())
 
-    def run(self, log_every=10, eval_every=0):
-        """Train until the counter says stop; logs one row per `log_every` batches."""
+    def run(self, log_every=10, eval_every=None):
+        """Train until the counter says stop (`total_step` lock-steps per replica); one row per `log_every` batches.
+        Row: `avg_reward` / `std_reward` = the deterministic TEST episodes (argmax policy, raw reward) for CACC, like
+        the reference's train_reward.csv (utils.py:246-251), evaluated every `eval_every` rows (default: every row for
+        CACC, never for ATSC whose logged reward is the training episode's, utils.py:243-245); `train_avg_reward` etc.
+        = statistics of the training episodes finished since the last row (stochastic policy, training-mode reward)."""
         t0 = time.time()
+        if eval_every is None:
+            eval_every = 0 if self.env.name.startswith('atsc') else 1
+        total = self.global_counter.total_step
+        if total < log_every * self.n_step:
+            logging.warning('total_step %d < log_every x n_step = %d lock-steps: only the final row will be logged'
+                            % (total, log_every * self.n_step))
+        rows_done = 0
+
+        def log_row():
+            st = self.stats()
+            step = self.global_counter.cur_step
+            row = {'agent': self.env.agent, 'step': step, 'test_id': -1, 'avg_reward': st['avg_reward'],
+                   'std_reward': st['std_reward'], 'train_avg_reward': st['avg_reward'],
+                   'train_std_reward': st['std_reward'], 'episodes': st['episodes'], 'collisions': st['collisions'],
+                   'env_steps': step * self.E * self.world_size * self.N}
+            if eval_every and rows_done % eval_every == 0:
+                m, s, c = self.evaluate()
+                row.update(avg_reward=m, std_reward=s, test_collisions=c)
+            self.data.append(row)
+            if self.rank == 0:
+                logging.info('Training: lock-step %d, batches %d, %.0f env-steps/s, episodes %d, train r %.2f, '
+                             'logged r %.2f, collisions %d'
+                             % (step, self.n_batches, row['env_steps'] / max(time.time() - t0, 1e-9), st['episodes'],
+                                st['avg_reward'], row['avg_reward'], st['collisions']))
+                if self.summary_writer is not None:
+                    self.summary_writer.add_scalar('train_reward', row['avg_reward'], step)
+                    self.summary_writer.flush()
+
         while not self.global_counter.should_stop():
             self.run_batch()
             if self.n_batches % log_every == 0:
-                st = self.stats()
-                step = self.global_counter.cur_step
-                row = {'agent': self.env.agent, 'step': step, 'test_id': -1, 'avg_reward': st['avg_reward'],
-                       'std_reward': st['std_reward'], 'episodes': st['episodes'], 'collisions': st['collisions']}
-                if eval_every and (self.n_batches // log_every) % eval_every == 0:
-                    m, s, c = self.evaluate()
-                    row.update(test_avg_reward=m, test_std_reward=s, test_collisions=c)
-                self.data.append(row)
-                if self.rank == 0:
-                    logging.info('Training: env-steps %d, batches %d, %.0f env-steps/s, episodes %d, avg r %.2f, collisions %d'
-                                 % (step, self.n_batches, step / max(time.time() - t0, 1e-9), st['episodes'],
-                                    st['avg_reward'], st['collisions']))
-                    if self.summary_writer is not None:
-                        self.summary_writer.add_scalar('train_reward', st['avg_reward'], step)
-                        self.summary_writer.flush()
+                log_row()
+                rows_done += 1
+        if self.n_batches % log_every != 0:
+            log_row()                                     # final (partial) row: never leave train_reward.csv empty
         if self.output_path is not None and self.rank == 0:
             pd.DataFrame(self.data).to_csv(self.output_path + 'train_reward.csv')

@@ -63,6 +63,6 @@ def test_two_ranks_equal_one_process(agent, tmp_path):
     w0, s0 = torch.load(tmp_path / 'rank0.pt')
     w1, s1 = torch.load(tmp_path / 'rank1.pt')
     assert torch.equal(w0, w1), 'ranks diverged'
-    assert s0 == s1 == 3 * 10 * 3 * 2           # batches x n_step x replicas x world
+    assert s0 == s1 == 3 * 10                   # batches x n_step lock-steps on every rank
     single, _ = _run(agent, 6, 0, None, 3)
     torch.testing.assert_close(w0, single, rtol=2e-5, atol=2e-6)

@@ -38,7 +38,7 @@ def test_batched_trainer_runs_and_learns_something(agent):
         st = tr.stats()
         assert st['episodes'] == 5 * 2          # 7 batches = 2 full episodes (+1 batch) per replica
         assert np.isfinite(st['avg_reward'])
-        assert tr.global_counter.cur_step == 7 * 10 * 5
+        assert tr.global_counter.cur_step == 7 * 10            # lock-steps (env steps per replica)
         assert int(tr.step_dev.item()) == 7 * 11   # n_step draws + 1 bootstrap draw per batch
 
 

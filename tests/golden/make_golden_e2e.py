@@ -10,6 +10,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, 'oracle', 'tf1_shim'))
 sys.path.insert(0, '/root/reference')
@@ -50,11 +51,13 @@ def run(name, agent, scenario, seed, reward_norm):
                logged_mean=trainer.data[0]['avg_reward'], logged_std=trainer.data[0]['std_reward'],
                logged_step=trainer.data[0]['step'], stats=var_stats(tf.global_variables()),
                agent=agent, scenario=scenario, seed=seed, reward_norm=reward_norm)
-    np.savez_compressed(os.path.join(HERE, 'e2e_%s.npz' % name), **out)
+    np.savez_compressed(os.path.join(OUT, 'e2e_%s.npz' % name), **out)
     print('%-18s train steps %d (sum g %.3f) test steps %d mean %.4f' % (
         name, tr.sum(), g[tr].sum(), (~tr).sum(), out['logged_mean']))
 
 
 if __name__ == '__main__':
+    if '--out' in sys.argv:                       # regeneration check (tests/test_golden_regen.py): write elsewhere
+        OUT = sys.argv[sys.argv.index('--out') + 1]
     run('ia2c_fp_catchup', 'ia2c_fp', 'catchup', 12, 800.0)
     run('ma2c_nc_slowdown', 'ma2c_nc', 'slowdown', 12, 5000.0)

@@ -17,6 +17,7 @@ import numpy as np
 
 REF = '/root/reference'
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE
 
 INI = """
 [ENV_CONFIG]
@@ -109,11 +110,13 @@ def run_case(name, scenario, agent, seed, kind, train_mode=True, coop_gamma=-1, 
                obs=obs[:steps + 1], n_s=np.array(n_s), v0s=v0s, fps=fps[:steps + 1],
                scenario=scenario, agent=agent, seed=seed, train_mode=train_mode,
                coop_gamma=coop_gamma, neighbor_mask=env.neighbor_mask, distance_mask=env.distance_mask)
-    np.savez_compressed(os.path.join(HERE, 'cacc_%s.npz' % name), **out)
+    np.savez_compressed(os.path.join(OUT, 'cacc_%s.npz' % name), **out)
     print('%-28s steps=%3d collided=%s sum_g=%.10f' % (name, steps, env.collision, float(np.sum(grew))))
 
 
 if __name__ == '__main__':
+    if '--out' in sys.argv:                       # regeneration check (tests/test_golden_regen.py): write elsewhere
+        OUT = sys.argv[sys.argv.index('--out') + 1]
     run_case('catchup_nc_const0', 'catchup', 'ma2c_nc', 12, 'const0')
     run_case('catchup_nc_const1', 'catchup', 'ma2c_nc', 12, 'const1')       # collides, ends at step 120
     run_case('catchup_nc_const3', 'catchup', 'ma2c_nc', 12, 'const3')

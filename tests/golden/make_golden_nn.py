@@ -18,6 +18,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = HERE
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, 'oracle', 'tf1_shim'))
 sys.path.insert(0, '/root/reference')
@@ -26,6 +27,19 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import tensorflow as tf  # noqa: E402  (the shim)
 from agents.models import IA2C, IA2C_FP, IA2C_CU, MA2C_NC, MA2C_IC3, MA2C_DIAL  # noqa: E402  (the reference)
 from helpers import cacc_config  # noqa: E402
+
+# tf.gradients is recorded so that run_batched can fetch the RAW (pre-clip) gradient of every optimiser
+GRAD_NODES = {}
+_orig_gradients = tf.gradients
+
+
+def _recording_gradients(loss, wts):
+    gs = _orig_gradients(loss, wts)
+    GRAD_NODES[id(loss)] = (gs, list(wts))
+    return gs
+
+
+tf.gradients = _recording_gradients
 
 CLS = {'ia2c': IA2C, 'ia2c_fp': IA2C_FP, 'ma2c_nc': MA2C_NC, 'ma2c_ic3': MA2C_IC3, 'ma2c_cu': IA2C_CU,
        'ma2c_dial': MA2C_DIAL}
@@ -36,7 +50,7 @@ def var_stats(variables):
     """[n_var, 3 + N_SAMPLE]: sum, abs-sum, l2, then samples at idx (k*7919) % size."""
     rows = []
     for v in variables:
-        a = v.numpy().astype(np.float64).ravel()
+        a = (v if isinstance(v, np.ndarray) else v.numpy()).astype(np.float64).ravel()
         idx = (np.arange(N_SAMPLE) * 7919) % a.size
         rows.append(np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], a[idx]]))
     return np.array(rows)
@@ -188,7 +202,7 @@ def run_ragged(name, agent, seed, n_step, n_batch=3):
     out.update(X=X, ACT=ACT, REW=REW, PI=PI, V=V, RB=RB, LOSS=np.array(LOSS), STATS=np.array(STATS),
                STATES=np.array(STATES), nb=nb, dist=dist, agent=agent, topo='ragged', seed=seed, n_step=n_step,
                coop_gamma=-1, reward_norm=50.0, n_own=np.array(n_own), n_a_ls=np.array(n_a_ls), n_s_ls=np.array(n_s_ls))
-    np.savez_compressed(os.path.join(HERE, 'nn_%s.npz' % name), **out)
+    np.savez_compressed(os.path.join(OUT, 'nn_%s.npz' % name), **out)
     nparam = sum(int(np.prod(v.value.shape)) for v in variables)
     print('%-22s params=%7d loss=%s gnorm=%s' % (name, nparam, np.round(LOSS[0][:, 0], 5)[:3],
                                                  np.round(LOSS[0][:, 1], 4)[:3]))
@@ -307,10 +321,154 @@ def run_scripted(name, agent, topo, seed, n_step, n_batch=3, coop_gamma=-1):
     out.update(X=X, ACT=ACT, REW=REW, PI=PI, V=V, RB=RB, DONE0=DONE0, LOSS=np.array(LOSS),
                STATS=np.array(STATS), STATES=np.array(STATES), nb=nb, dist=dist, agent=agent,
                topo=topo, seed=seed, n_step=n_step, coop_gamma=coop_gamma, reward_norm=50.0)
-    np.savez_compressed(os.path.join(HERE, 'nn_%s.npz' % name), **out)
+    np.savez_compressed(os.path.join(OUT, 'nn_%s.npz' % name), **out)
     nparam = sum(int(np.prod(v.value.shape)) for v in variables)
     print('%-22s params=%7d loss=%s gnorm=%s' % (name, nparam, np.round(LOSS[0][:, 0], 5)[:3],
                                                  np.round(LOSS[0][:, 1], 4)[:3]))
+
+
+def run_batched(name, agent, topo, seed, n_step, K=4):
+    """The E > 1 update contract: K independent replicas of the reference model with IDENTICAL
+    weights each roll out one n_step batch (models.py:26-51 / 198-227, Trainer.explore order) and run `backward`
+    (models.py:34-42, 211-215) -- with the optimiser step intercepted, so the weights stay put and the raw gradient
+    of every optimiser (policies.py:32-33, 257-258) is recorded.  The batched update the product performs on E = K
+    lock-stepped replicas must equal: mean over replicas of those gradients -> clip_by_global_norm -> ONE RMSProp
+    step (policies.py:34-39, 259-264; loss means over T, so the mean over T*E is the mean of the replica means).
+
+    Episode layout (what BatchedTrainer produces around a batch boundary): every replica first runs a PREFIX batch
+    (no update); replicas 0, 1 end their episode there and start the main batch fresh (done = True, zero state,
+    uniform fingerprints -- the reference's env.reset(); model.reset()), replicas 2.. continue (done = False, states
+    and fingerprints carried over, states_bw <- states_fw as in policies.py:115, 211).  Replica 1's episode ends with
+    the last step of the main batch (R = 0, utils.py:189-190), the others bootstrap (utils.py:192-196)."""
+    cp = cacc_config(agent=agent, n_step=n_step, reward_norm=50.0, coop_gamma=-1)
+    mc = cp['MODEL_CONFIG']
+    if topo == 'line':
+        N, n_feat, A = 8, 5, 4
+        nb, dist = line_masks(N)
+    else:
+        N, n_feat, A = 25, 12, 5
+        nb, dist = grid_masks(5)
+    is_ma = agent.startswith('ma2c')
+    nbr = [np.where(nb[i] == 1)[0] for i in range(N)]
+    n_s_ls = [n_feat if is_ma else n_feat * (1 + len(nbr[i])) for i in range(N)]
+    np.random.seed(seed)
+    model = CLS[agent](n_s_ls, [A] * N, nb, dist, -1, 10 ** 9, mc, seed=seed)
+    variables = tf.global_variables()
+    by_name = {v.full_name: v for v in variables}
+    policies = model.policy if isinstance(model.policy, list) else [model.policy]
+    train_to_pol = {id(p._train): p for p in policies}
+    grad_log = []
+    orig_run = tf.Session.run
+
+    def intercept(self, fetches, feed_dict=None):
+        if isinstance(fetches, list) and any(getattr(f, 'is_train', False) for f in fetches):
+            for f in fetches:
+                if getattr(f, 'is_train', False):
+                    p = train_to_pol[id(f)]
+                    gs, wts = GRAD_NODES[id(p.loss)]
+                    vals = orig_run(self, [p.loss] + list(gs), feed_dict)
+                    grad_log.append((p, float(vals[0]), [np.array(g, dtype=np.float64) for g in vals[1:]],
+                                     [w.full_name for w in wts]))
+            return [None] * len(fetches)                      # the optimiser step is NOT applied
+        return orig_run(self, fetches, feed_dict)
+    tf.Session.run = intercept
+
+    T = n_step
+    rng = np.random.RandomState(seed + 2000)
+    X = rng.normal(0, 0.7, size=(K, 2, T + 1, N, n_feat))
+    ACT = rng.randint(0, A, size=(K, 2, T + 1, N))
+    REW = rng.normal(-30, 20, size=(K, 2, T))
+    PI = np.zeros((K, 2, T + 1, N, A))
+    V = np.zeros((K, 2, T + 1, N))
+    RB = np.zeros((K, N))
+    STATES = np.zeros((K, N, 2 * int(mc['num_lstm'])))
+    state = {'fp': None}
+
+    def make_ob(x):
+        ob = []
+        for i in range(N):
+            cur = [x[i]]
+            if not is_ma:
+                cur += [x[j] for j in nbr[i]]
+            if agent == 'ia2c_fp':
+                cur += [state['fp'][j] for j in nbr[i]]
+            ob.append(np.concatenate(cur))
+        return ob
+
+    def decide(x, done, a, update_fp=True):
+        ob = make_ob(x)
+        ps = state['fp'].copy()
+        if is_ma:
+            pi = np.array(model.forward(ob, done, ps))
+            v = np.array(model.forward(ob, done, ps, np.array(a), 'v'))
+            extra = ps
+        else:
+            pi = np.array(model.forward(ob, done))
+            extra = [a[nb[i] == 1] for i in range(N)]
+            v = np.array(model.forward(ob, done, extra, 'v'))
+        if update_fp:
+            state['fp'] = pi.copy()                           # env.update_fingerprint (utils.py:173), not at the bootstrap
+        return ob, extra, pi, v
+
+    def batch(k, ph, done, last_done):
+        for t in range(T):
+            a = ACT[k, ph, t]
+            ob, extra, pi, v = decide(X[k, ph, t], done, a)
+            done = bool(last_done and t == T - 1)
+            model.add_transition(ob, extra, a, float(REW[k, ph, t]), v, done)
+            PI[k, ph, t], V[k, ph, t] = pi, v
+        if done:
+            R = np.zeros(N)
+        else:
+            _, _, pi, R = decide(X[k, ph, T], done, ACT[k, ph, T], update_fp=False)
+            PI[k, ph, T], V[k, ph, T] = pi, R
+        model.backward(R, 0)                                  # intercepted: gradients recorded, states_bw <- states_fw
+        return R
+
+    per_replica = []
+    for k in range(K):
+        model.reset()
+        state['fp'] = np.ones((N, A)) / A
+        if k >= 2:                                            # continuing replicas: a prefix batch, discarded
+            batch(k, 0, True, False)
+            grad_log.clear()
+            RB[k] = batch(k, 1, False, False)
+        else:
+            RB[k] = batch(k, 1, True, k == 1)
+        per_replica.append(list(grad_log))
+        grad_log.clear()
+        STATES[k] = np.array([p.states_fw for p in policies], dtype=np.float64).reshape(N, -1)
+    tf.Session.run = orig_run
+
+    # ---- expected batched update: mean gradient -> clip -> RMSProp from fresh slots (ms = 1), per optimiser
+    lr, decay, eps, clip = float(mc['lr_init']), float(mc['rmsp_alpha']), float(mc['rmsp_epsilon']), float(mc['max_grad_norm'])
+    new_w = {v.full_name: v.numpy().astype(np.float64) for v in variables}
+    mean_g = {}
+    n_opt = len(per_replica[0])
+    LOSSK = np.array([[per_replica[k][o][1] for o in range(n_opt)] for k in range(K)])
+    GN = np.zeros(n_opt)
+    for o in range(n_opt):
+        names = per_replica[0][o][3]
+        gs = [np.mean([per_replica[k][o][2][j] for k in range(K)], axis=0) for j in range(len(names))]
+        GN[o] = np.sqrt(sum((g * g).sum() for g in gs))
+        scale = clip * min(1.0 / GN[o], 1.0 / clip)
+        for nm, g in zip(names, gs):
+            g = g * scale
+            ms = 1.0 + (g * g - 1.0) * (1.0 - decay)
+            new_w[nm] = by_name[nm].numpy().astype(np.float64) - lr * g / np.sqrt(ms + eps)
+            mean_g[nm] = g / scale
+    out = dict(stats0=var_stats(variables), names=np.array([v.full_name for v in variables]),
+               shapes=np.array([str(tuple(v.value.shape)) for v in variables]),
+               X=X, ACT=ACT, REW=REW, PI=PI, V=V, RB=RB, STATES=STATES, LOSSK=LOSSK, LOSS=LOSSK.mean(0), GN=GN,
+               STATS=var_stats([new_w[v.full_name] for v in variables]),
+               GSTATS=var_stats([mean_g.get(v.full_name, np.zeros(tuple(v.value.shape))) for v in variables]),
+               nb=nb, dist=dist, agent=agent, topo=topo, seed=seed, n_step=n_step, K=K, coop_gamma=-1, reward_norm=50.0)
+    np.savez_compressed(os.path.join(OUT, 'nnb_%s.npz' % name), **out)
+    print('%-22s K=%d T=%d loss=%s gnorm=%s' % ('nnb_' + name, K, T, np.round(out['LOSS'], 5)[:3], np.round(GN, 4)[:3]))
+
+
+BATCHED = [('ia2c_fp_line', 'ia2c_fp', 'line', 40, 60), ('ma2c_nc_line', 'ma2c_nc', 'line', 41, 60),
+           ('ma2c_ic3_grid', 'ma2c_ic3', 'grid', 42, 120)]
 
 
 def run_ortho():
@@ -322,35 +480,43 @@ def run_ortho():
         out['w%d' % k] = ortho_init()(s, None)
     out['shapes'] = np.array(shapes)
     out['after'] = np.random.rand()
-    np.savez_compressed(os.path.join(HERE, 'ortho_init.npz'), **out)
+    np.savez_compressed(os.path.join(OUT, 'ortho_init.npz'), **out)
     print('ortho w0[0,0] = %.7f' % out['w0'][0, 0])
 
 
-if __name__ == '__main__':
-    if '--ragged' in sys.argv:
-        for nm, ag, sd in RAGGED:
+def main(argv):
+    """No arguments: regenerate EVERY fixture.  --only a,b,...: the named fixtures (file names without .npz)."""
+    only = None
+    if '--only' in argv:
+        only = set(argv[argv.index('--only') + 1].split(','))
+
+    def want(fname):
+        return only is None or fname in only
+    if want('ortho_init'):
+        run_ortho()
+    for nm, ag, topo, sd, ns, cg in SCRIPTED:
+        if want('nn_' + nm):
+            tf.reset_default_graph()
+            run_scripted(nm, ag, topo, sd, ns, coop_gamma=cg)
+    for nm, ag, sd in RAGGED:
+        if want('nn_' + nm):
+            tf.reset_default_graph()
             run_ragged(nm, ag, sd, 4)
-        sys.exit(0)
-    if '--only-new' in sys.argv:
-        run_scripted('ma2c_cu_line', 'ma2c_cu', 'line', 20, 6)
-        run_scripted('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6)
-        run_scripted('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4)
-        run_scripted('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4)
-    for nm, ag, sd in RAGGED:
-        run_ragged(nm, ag, sd, 4)
-        sys.exit(0)
-    run_ortho()
-    run_scripted('ia2c_line', 'ia2c', 'line', 12, 6)
-    run_scripted('ia2c_fp_line', 'ia2c_fp', 'line', 13, 6)
-    run_scripted('ma2c_nc_line', 'ma2c_nc', 'line', 14, 6)
-    run_scripted('ma2c_ic3_line', 'ma2c_ic3', 'line', 15, 6)
-    run_scripted('ma2c_ic3_grid', 'ma2c_ic3', 'grid', 16, 4)
-    run_scripted('ma2c_nc_grid', 'ma2c_nc', 'grid', 17, 4)
-    run_scripted('ma2c_nc_line_spatial', 'ma2c_nc', 'line', 18, 6, coop_gamma=0.9)
-    run_scripted('ia2c_line_spatial', 'ia2c', 'line', 19, 6, coop_gamma=0.8)
-    run_scripted('ma2c_cu_line', 'ma2c_cu', 'line', 20, 6)
-    run_scripted('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6)
-    run_scripted('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4)
-    run_scripted('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4)
-    for nm, ag, sd in RAGGED:
-        run_ragged(nm, ag, sd, 4)
+    for nm, ag, topo, sd, ns in BATCHED:
+        if want('nnb_' + nm):
+            tf.reset_default_graph()
+            run_batched(nm, ag, topo, sd, ns)
+
+
+SCRIPTED = [('ia2c_line', 'ia2c', 'line', 12, 6, -1), ('ia2c_fp_line', 'ia2c_fp', 'line', 13, 6, -1),
+            ('ma2c_nc_line', 'ma2c_nc', 'line', 14, 6, -1), ('ma2c_ic3_line', 'ma2c_ic3', 'line', 15, 6, -1),
+            ('ma2c_ic3_grid', 'ma2c_ic3', 'grid', 16, 4, -1), ('ma2c_nc_grid', 'ma2c_nc', 'grid', 17, 4, -1),
+            ('ma2c_nc_line_spatial', 'ma2c_nc', 'line', 18, 6, 0.9), ('ia2c_line_spatial', 'ia2c', 'line', 19, 6, 0.8),
+            ('ma2c_cu_line', 'ma2c_cu', 'line', 20, 6, -1), ('ma2c_dial_line', 'ma2c_dial', 'line', 21, 6, -1),
+            ('ma2c_cu_grid', 'ma2c_cu', 'grid', 22, 4, -1), ('ma2c_dial_grid', 'ma2c_dial', 'grid', 23, 4, -1)]
+
+
+if __name__ == '__main__':
+    if '--out' in sys.argv:                       # regeneration check (tests/test_golden_regen.py): write elsewhere
+        OUT = sys.argv[sys.argv.index('--out') + 1]
+    main(sys.argv[1:])

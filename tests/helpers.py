@@ -228,3 +228,119 @@ def net_config(agent='ma2c_nc', coop_gamma=0.9, seed=12, n_step=120):
     cp['ENV_CONFIG']['seed'] = str(seed)
     cp['MODEL_CONFIG']['batch_size'] = str(n_step)
     return cp
+
+
+# --------------------------------------------------------------------------- batched (E = K) update golden
+def build_product_batched(z, device):
+    """The product model with E = K replicas, initial weights drawn like make_golden_nn.run_batched's reference model."""
+    from deeprl_network_amd.agents import models
+    agent, topo = str(z['agent']), str(z['topo'])
+    cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3,
+           'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[agent]
+    n_step, seed, K = int(z['n_step']), int(z['seed']), int(z['K'])
+    cp = cacc_config(agent=agent, n_step=n_step, reward_norm=float(z['reward_norm']), coop_gamma=-1)
+    nb, dist = z['nb'], z['dist']
+    N = nb.shape[0]
+    n_feat, A = (5, 4) if topo == 'line' else (12, 5)
+    is_ma = agent.startswith('ma2c')
+    n_s_ls = [n_feat if is_ma else n_feat * (1 + int(nb[i].sum())) for i in range(N)]
+    np.random.seed(seed)
+    return cls(n_s_ls, [A] * N, nb, dist, -1, 10 ** 9, cp['MODEL_CONFIG'], seed=seed, num_envs=K, device=device)
+
+
+def drive_batched(model, z):
+    """Replays make_golden_nn.run_batched on the product's BATCHED engine (act / bootstrap / update on E = K
+    lock-stepped replicas, the calls BatchedTrainer makes): a prefix batch without update, the episode boundary
+    (replicas 0, 1 restart: reset_states(mask), done_pre = 1), the main batch, ONE update.  Observations are written
+    into buf_x; the scripted actions are forced through the kernels' own draw with uniforms placed in the middle of the
+    golden CDF interval of the wanted action (mode SAMPLE_UNIFORM), so the fused policy/value kernels run unchanged."""
+    import torch
+    from deeprl_network_amd import ops
+    X, ACT, REW, PIg = z['X'], z['ACT'], z['REW'], z['PI']
+    K, T = int(z['K']), int(z['n_step'])
+    N, A, dev = model.n_agent, model.n_a, model.device
+    F = X.shape[-1]
+    nbrs = model.policy.nbrs
+    model.masked_steps = (0,)
+
+    def slab(x):                                  # [K,N,F] -> [K,N,n_obs]: own features, then the neighbours' (ascending)
+        s = np.zeros((K, N, model.policy.n_obs), dtype=np.float32)
+        s[:, :, :F] = x
+        for i in range(N):
+            for k, j in enumerate(nbrs[i]):
+                s[:, i, (k + 1) * F:(k + 2) * F] = x[:, j]
+        return torch.from_numpy(s).to(dev)
+
+    def uniforms(pi, a, live):                    # u [K,N] that makes the kernel draw action a from (about) pi
+        cdf = np.cumsum(pi, axis=-1) / np.maximum(pi.sum(-1, keepdims=True), 1e-30)
+        lo = np.where(a > 0, np.take_along_axis(cdf, np.maximum(a - 1, 0)[..., None], -1)[..., 0], 0.0)
+        hi = np.take_along_axis(cdf, a[..., None], -1)[..., 0]
+        u = np.where(live[:, None], 0.5 * (lo + hi), 0.5)
+        return torch.from_numpy(u.astype(np.float32)).to(dev)
+
+    zero = torch.zeros(K, dtype=torch.float32, device=dev)
+    scratch = torch.zeros(K, N, dtype=torch.uint8, device=dev)
+    PI = np.zeros_like(PIg)
+    V = np.zeros_like(z['V'])
+    model.reset_states()
+    done_pre = torch.ones(K, dtype=torch.float32, device=dev)
+    live = {0: np.arange(K) >= 2, 1: np.ones(K, bool)}      # replicas 0, 1 have no golden prefix (restarted afterwards)
+    for ph in (0, 1):
+        model.t = 0
+        for t in range(T):
+            model.buf_x[t].copy_(slab(X[:, ph, t]))
+            d = done_pre if t == 0 else zero
+            model.buf_done_pre[t].copy_(d)
+            model.act(d, mode=ops.SAMPLE_UNIFORM, u=uniforms(PIg[:, ph, t], ACT[:, ph, t], live[ph]), done_is_zero=(t > 0))
+            got = model.buf_act[t].cpu().numpy()
+            assert np.array_equal(got[live[ph]], ACT[:, ph, t][live[ph]]), 'forced action draw failed at step %d' % t
+            PI[:, ph, t] = model.buf_fp[t + 1].permute(1, 0, 2).cpu().numpy()
+            V[:, ph, t] = model.buf_v[t].t().cpu().numpy()
+            model.t = t + 1
+        model.buf_x[T].copy_(slab(X[:, ph, T]))
+        v = model.bootstrap(zero, scratch, mode=ops.SAMPLE_UNIFORM, u=uniforms(PIg[:, ph, T], ACT[:, ph, T], live[ph]),
+                            done_is_zero=True)
+        PI[:, ph, T] = model._pi_boot.permute(1, 0, 2).cpu().numpy()
+        V[:, ph, T] = v.t().cpu().numpy()
+        if ph == 0:
+            # batch boundary WITHOUT an update: what update() does to the rollout state (models.py: states_bw <-
+            # states_fw, slot T becomes slot 0), then replicas 0, 1 start a new episode
+            model.h_bw.copy_(model.h_fw)
+            model.c_bw.copy_(model.c_fw)
+            model.buf_fp[0].copy_(model.buf_fp[T])
+            model.t = 0
+            restart = torch.tensor([1, 1] + [0] * (K - 2), dtype=torch.uint8, device=dev)
+            model.reset_states(mask=restart)
+            done_pre = restart.to(torch.float32)
+    last_done = torch.tensor([0, 1] + [0] * (K - 2), dtype=torch.uint8, device=dev)
+    model.buf_done_post.zero_()
+    model.buf_done_post[T - 1].copy_(last_done)
+    model.load_rewards(torch.from_numpy(REW[:, 1].T.astype(np.float32)).to(dev).contiguous())
+    R_end = (v * (1.0 - last_done.to(torch.float32)).view(1, -1)).contiguous()
+    states = np.concatenate([model.c_fw.permute(1, 0, 2).cpu().numpy(), model.h_fw.permute(1, 0, 2).cpu().numpy()], axis=2)
+    model.update(R_end)
+    tot = model.last_loss[3].cpu().numpy().astype(np.float64)
+    gn = model.grad_norm.cpu().numpy().astype(np.float64)
+    loss, gnorm = (tot, gn) if model.per_agent_optimizer else (np.array([tot.sum()]), gn[:1])
+    return dict(PI=PI, V=V, RB=R_end.t().cpu().numpy(), STATES=states, LOSS=loss, GN=gnorm,
+                STATS=var_stats_from_named(model.policy.params.ref_variables()))
+
+
+def compare_batched(out, z, rtol_fw=1e-4, rtol_w=1e-3):
+    """SURVEY.md 8(c) tolerances: forward rtol 1e-4, post-update weights rtol 1e-3."""
+    K = int(z['K'])
+    m = np.arange(K) >= 2
+    # replica 1 ends its episode with the batch: the reference makes no bootstrap call for it (slot T stays 0)
+    vm = np.ones_like(z['V'][:, 1], dtype=bool)
+    vm[1, -1] = False
+    np.testing.assert_allclose(out['PI'][:, 1][vm], z['PI'][:, 1][vm], rtol=rtol_fw, atol=1e-6, err_msg='pi (main batch)')
+    np.testing.assert_allclose(out['PI'][m, 0], z['PI'][m, 0], rtol=rtol_fw, atol=1e-6, err_msg='pi (prefix)')
+    np.testing.assert_allclose(out['V'][:, 1][vm], z['V'][:, 1][vm], rtol=rtol_fw, atol=2e-5, err_msg='v')
+    np.testing.assert_allclose(out['RB'], z['RB'], rtol=rtol_fw, atol=2e-5, err_msg='R bootstrap')
+    keep = np.arange(K) != 1                      # replica 1: the product's (discarded) bootstrap call advanced its state
+    np.testing.assert_allclose(out['STATES'][keep], z['STATES'][keep], rtol=rtol_fw, atol=2e-6, err_msg='states_fw')
+    np.testing.assert_allclose(out['LOSS'], z['LOSS'], rtol=1e-4, atol=1e-5, err_msg='loss = mean of the replica losses')
+    np.testing.assert_allclose(out['GN'], z['GN'], rtol=1e-4, atol=1e-6, err_msg='norm of the mean gradient')
+    s, g = out['STATS'], z['STATS']
+    np.testing.assert_allclose(s[..., 1:3], g[..., 1:3], rtol=rtol_w, err_msg='|w| / l2 after the update')
+    np.testing.assert_allclose(s[..., 3:], g[..., 3:], rtol=rtol_w, atol=2e-6, err_msg='weight samples after the update')

@@ -1,0 +1,62 @@
+"""The committed fixtures under tests/golden/ ARE what the committed generator scripts produce from the reference
+(no test re-derived them, so script / npz drift would go unnoticed).
+
+Where /root/reference exists (the authoring container; never on the GPU box) the generators are re-run into a scratch
+directory and every array is compared for exact equality (dtype, shape, bytes) with the committed file.  The full set
+takes ~25 CPU-minutes (the reference's graphs run on the float64 fake-TF shim), so by default a representative
+subset is regenerated -- all 15 environment trajectories, the orthogonal-init draws, one scripted run per model family
+and the E = 4, n_step = 60 batched-update case; NMARL_REGEN_ALL=1 regenerates every fixture (round 2: the 36 fixtures
+of round 1 -- 15 cacc, ortho, 18 nn, 2 e2e -- were regenerated and found identical array by array)."""
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, 'golden')
+pytestmark = pytest.mark.skipif(not os.path.isdir('/root/reference/agents'), reason='needs the reference checkout')
+
+FAST_NN = 'ortho_init,nn_ia2c_fp_line,nn_ma2c_nc_line,nn_ma2c_ic3_ragged,nnb_ia2c_fp_line'
+
+
+def _same(out_dir, expect_at_least):
+    files = sorted(glob.glob(os.path.join(out_dir, '*.npz')))
+    assert len(files) >= expect_at_least
+    for f in files:
+        ref = os.path.join(GOLDEN, os.path.basename(f))
+        assert os.path.exists(ref), 'generator wrote %s, which is not committed' % os.path.basename(f)
+        with np.load(f) as a, np.load(ref) as b:
+            assert set(a.files) == set(b.files), os.path.basename(f)
+            for k in a.files:
+                assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), \
+                    '%s[%s] differs from the regenerated fixture' % (os.path.basename(f), k)
+    return len(files)
+
+
+def _run(script, out_dir, *args):
+    subprocess.run([sys.executable, os.path.join(GOLDEN, script), '--out', str(out_dir)] + list(args), check=True,
+                   capture_output=True, timeout=3600)
+
+
+def test_env_fixtures_regenerate(tmp_path):
+    _run('make_golden_env.py', tmp_path)
+    assert _same(str(tmp_path), 15) == len(glob.glob(os.path.join(GOLDEN, 'cacc_*.npz')))
+
+
+def test_nn_fixtures_regenerate(tmp_path):
+    if os.environ.get('NMARL_REGEN_ALL') == '1':
+        _run('make_golden_nn.py', tmp_path)
+        n = len(glob.glob(os.path.join(GOLDEN, 'nn_*.npz'))) + len(glob.glob(os.path.join(GOLDEN, 'nnb_*.npz'))) + 1
+        assert _same(str(tmp_path), n) == n
+    else:
+        _run('make_golden_nn.py', tmp_path, '--only', FAST_NN)
+        assert _same(str(tmp_path), 5) == 5
+
+
+@pytest.mark.skipif(os.environ.get('NMARL_REGEN_ALL') != '1', reason='9 CPU-minutes: NMARL_REGEN_ALL=1')
+def test_e2e_fixtures_regenerate(tmp_path):
+    _run('make_golden_e2e.py', tmp_path)
+    assert _same(str(tmp_path), 2) == 2

@@ -64,3 +64,19 @@ def test_heterogeneous_checkpoint_roundtrip_and_layout(name, tmp_path):
         pb = m2.policy.params['pi_b'].detach()
         for i, n in enumerate(m2.n_a_ls):
             assert (pb[i, n:] == -1e30).all() and (pb[i, :n] == 0).all()
+
+
+BATCHED = sorted(glob.glob(os.path.join(GOLDEN, 'nnb_*.npz')))
+
+
+@pytest.mark.parametrize('path', BATCHED, ids=[os.path.basename(c)[4:-4] for c in BATCHED])
+def test_batched_update_equals_mean_of_reference_replica_gradients(path):
+    """E = K = 4 replicas, n_step 60 / 120: the product's batched update == mean over K independent reference models'
+    gradients -> clip -> one RMSProp step (tests/golden/make_golden_nn.py run_batched), host logic on CPU emulation."""
+    from helpers import build_product_batched, compare_batched, drive_batched
+    z = load_npz(path)
+    with cpu_ops():
+        model = build_product_batched(z, 'cpu')
+        np.testing.assert_allclose(var_stats_from_named(model.policy.params.ref_variables()), z['stats0'], rtol=1e-6, atol=1e-7)
+        out = drive_batched(model, z)
+    compare_batched(out, z)

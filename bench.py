@@ -65,6 +65,7 @@ def parse():
     ap.add_argument('--envs', type=int, default=0, help='replicas per GPU (default: num_envs of the ini)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tune-only', action='store_true', help='internal: run one batch to tune the library GEMMs, print nothing')
     ap.add_argument('--no-tunableop', action='store_true', help='do not auto-tune the library GEMMs (PyTorch TunableOp)')
     ap.add_argument('--cpu-batches', type=int, default=100,
                     help='n_step batches of the E=1 CPU baseline (100 = 6000 env steps, about 13 s on one core)')
@@ -201,28 +202,30 @@ def make_job(args, cp, device, rank, world, group):
     return E, env, model, trainer
 
 
-def tune_once(args, cp, device, rank, world):
-    """N > 1: the library GEMMs are tuned ONCE, by rank 0 on a throw-away single-rank job (no collective inside),
-    while the other ranks wait at a barrier; rank 0 writes the TunableOp file and every other rank reads it -- instead
-    of N ranks tuning the same shapes concurrently inside --warmup."""
+def tune_once(args, rank):
+    """N > 1: the library GEMMs are tuned ONCE.  Rank 0 runs a throw-away single-GPU job of the same shapes in a child
+    process (`--tune-only`: one batch, no collective), whose TunableOp results land in one shared CSV
+    (PYTORCH_TUNABLEOP_FILENAME); the other ranks wait at a barrier, then every rank reads that file and switches
+    tuning off -- instead of N ranks tuning the same shapes concurrently inside --warmup."""
+    import subprocess
     import torch.cuda.tunable as tunable
     import torch.distributed as dist
     if not tunable.is_enabled():
         return
     path = os.environ.get('NMARL_TUNABLEOP_SHARED', '/tmp/nmarl_tunableop_shared_%d.csv' % os.getppid())
     if rank == 0:
-        tunable.tuning_enable(True)
-        _, _, _, tr = make_job(args, cp, device, 0, 1, None)
-        tr.run_batch()
-        torch.cuda.synchronize()
-        del tr
-        tunable.write_file(path)
-    else:
-        tunable.tuning_enable(False)
+        drop = ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK',
+                'ROLE_WORLD_SIZE', 'ROLE_NAME', 'NMARL_BENCH_FORCE_DIST')
+        env = {k: v for k, v in os.environ.items()
+               if k not in drop and not k.startswith('TORCHELASTIC') and not k.startswith('MASTER_')}
+        env['PYTORCH_TUNABLEOP_FILENAME'] = path
+        cmd = [sys.executable, os.path.abspath(__file__), '--tune-only', '--gpus', '1', '--config', args.config,
+               '--envs', str(args.envs)] + (['--no-graph'] if args.no_graph else [])
+        subprocess.call(cmd, env=env, stdout=subprocess.DEVNULL)
     dist.barrier()
-    if rank != 0:
+    if os.path.exists(path):
         tunable.read_file(path)
-    tunable.tuning_enable(False)                           # every rank now replays rank 0's choices
+    tunable.tuning_enable(False)                           # every rank replays the one set of choices
     dist.barrier()
 
 
@@ -258,9 +261,13 @@ def main():
     cp = configparser.ConfigParser()
     cp.read(args.config)
     if world > 1:
-        tune_once(args, cp, device, rank, world)
+        tune_once(args, rank)
     from deeprl_network_amd.envs import make_batch_env
     E, env, model, trainer = make_job(args, cp, device, rank, world, group)
+    if args.tune_only:                                     # child of tune_once: one batch tunes every GEMM shape
+        trainer.run_batch()
+        torch.cuda.synchronize()
+        return
     for _ in range(args.warmup):
         trainer.run_batch()
 

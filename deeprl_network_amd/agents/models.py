@@ -198,6 +198,7 @@ class IA2C:
 
     def _policy_step(self, obs, done, done_is_zero=False):
         """forward('p'): advances states_fw (policies.py:119-134); returns the pi LOGITS' softmax."""
+        self.policy.refresh_wimage()          # reference API: the weights may have changed since the last call
         self._enc = self.policy.encode(obs, self.fp)
         self.policy.step(self._enc, self.h_fw, self.c_fw, done, self.h_fw, self.c_fw, done_is_zero)
         with torch.no_grad():
@@ -207,6 +208,8 @@ class IA2C:
         """forward('v'): re-steps the LSTM from the state forward('p') wrote (quirk Q1), without
         storing the result (policies.py:124-133).  `reuse_enc`: obs / fingerprints are those of the
         preceding _policy_step, whose encoding is shared."""
+        if not reuse_enc:
+            self.policy.refresh_wimage()
         enc = self._enc if reuse_enc else self.policy.encode(obs, self.fp)
         self.policy.step(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, done_is_zero)
         with torch.no_grad():
@@ -221,7 +224,9 @@ class IA2C:
         of the env kernel)."""
         t = self.t
         p = self.policy
-        enc = p.encode(self.buf_x[t], self.fp)             # shared by the policy step and the value re-step (Q1)
+        if t == 0:
+            p.refresh_wimage()                             # weights change between batches only (inside the hipGraph: one
+        enc = p.encode(self.buf_x[t], self.fp)             # small node); enc is shared by policy step and value re-step (Q1)
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
         if p.fused_pv:
             p.step_policy_value(enc, self.h_fw, self.c_fw, done, self.buf_fp[t + 1], self.buf_act[t], self.buf_v[t], **draw)

@@ -315,10 +315,10 @@ class BatchedPolicy:
         x-side addends and applies the cell in its epilogue (csrc/lstm_mfma.hip).  Other widths: a plain
         batched GEMM + the cell kernel (which takes the x-side part as a second addend: no copy GEMM)."""
         with torch.no_grad():
-            z1, z2 = self._recur_addends(enc, h)
+            z1, z2, xs = self._recur_addends(enc, h)
             wh, b = self.params[self.k_wh], self.params[self.k_b]
             if self.n_h == ops.FUSED_H:
-                ops.lstm_step_fused(h, wh, b, z1, z2, c, done, None, c_out, h_out)
+                ops.lstm_step_fused(h, wh, b, z1, z2, c, done, None, c_out, h_out, xs=xs)
             else:
                 hk = h if done_is_zero else h * (1.0 - done).view(1, -1, 1)
                 z = torch.bmm(hk, wh) if z2 is None else torch.baddbmm(z2, hk, wh)
@@ -336,10 +336,10 @@ class BatchedPolicy:
         step / step_dev.  One kernel when `fused_heads`."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2 = self._recur_addends(enc, h)
+                z1, z2, xs = self._recur_addends(enc, h)
                 p = self.params
                 ops.lstm_step_policy(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['pi_w'], p['pi_b'],
-                                     pi_out, act_out, **draw)
+                                     pi_out, act_out, xs=xs, **draw)
             else:
                 self.step(enc, h, c, done, h_out, c_out, done_is_zero)
                 pi_out.copy_(self.pi(h_out))
@@ -356,10 +356,10 @@ class BatchedPolicy:
         """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) for uncoupled nets:
         advances (h, c) in place by the policy step; the value comes from the re-stepped copy (quirk Q1)."""
         with torch.no_grad():
-            z1, z2 = self._recur_addends(enc, h)
+            z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
             ops.lstm_step_policy_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, p['pi_w'], p['pi_b'], pi_out, act_out,
-                                       p['v_w'], p['v_b'], self.nbr_idx, self.n_a, v_out, **draw)
+                                       p['v_w'], p['v_b'], self.nbr_idx, self.n_a, v_out, xs=xs, **draw)
         return act_out
 
     def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):
@@ -367,10 +367,10 @@ class BatchedPolicy:
         [h', onehot(neighbours' actions)], actions given as the env-major byte array action [E,N] -> v_out [N,E]."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2 = self._recur_addends(enc, h)
+                z1, z2, xs = self._recur_addends(enc, h)
                 p = self.params
                 ops.lstm_step_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['v_w'], p['v_b'],
-                                    action, self.nbr_idx, self.n_a, v_out)
+                                    action, self.nbr_idx, self.n_a, v_out, xs=xs)
             else:
                 self.step(enc, h, c, done, h_out, c_out, done_is_zero)
                 self.value(h_out, ops.nbr_onehot(action, self.nbr_idx, self.n_a), out=v_out)
@@ -389,8 +389,28 @@ class BatchedPolicy:
         return ops.bias_act_(torch.bmm(x, w), b, act, out=out)
 
     def _recur_addends(self, enc, h):
-        """(zadd1, zadd2): everything of the LSTM pre-activation except (h*(1-done)) @ Wh and the bias."""
-        return enc, None
+        """(zadd1, zadd2, xs): everything of the LSTM pre-activation except (h*(1-done)) @ Wh and the bias -- as
+        ready-made addends [N,E,4H] and / or as xs = (x, wx, weight image): an input x [N,E,KX] whose product with
+        wx the fused step computes itself (ops.lstm_step_fused)."""
+        if self.xside:
+            return None, None, (enc, self.params[self.k_wx], self._img)
+        return enc, None, None
+
+    # -- x-side product inside the fused step (uncoupled nets: the LSTM input is the encoders' output itself)
+    k_wx = None
+    _img = None
+
+    @property
+    def xside(self):
+        """The step kernel multiplies the LSTM input by Wx itself (csrc/lstm_mfma.hip lstm_step_x_kernel): no
+        [rows,4H] pre-activation tensor, no separate GEMM.  Needs H = 64 and an input width that is a multiple of 32."""
+        return self.k_wx is not None and ops.xside_supported(self.params[self.k_wx].shape[1], self.n_h)
+
+    def refresh_wimage(self):
+        """Rebuild the chunked [Wx; Wh] image the x-side step reads; call after every change of the weights (the
+        batched engine does it at the first lock-step of a batch and before the update's forward pass)."""
+        if self.xside:
+            self._img = ops.lstm_wimage(self.params[self.k_wx], self.params[self.k_wh], out=self._img)
 
     # -- n_step unroll for the update (autograd)
     def unroll(self, X, FP, done, h0, c0, masked_steps=None):
@@ -402,8 +422,14 @@ class BatchedPolicy:
         if not self.coupled:
             # no cross-agent term inside the recurrence: fused sequence op (one wgrad GEMM, one bias
             # reduction, no per-step autograd nodes)
-            Hs = ops.lstm_sequence(enc.view(self.N, T, E, enc.shape[-1]), self.params[self.k_wh],
-                                   self.params[self.k_b], h0, c0, done, masked_steps)
+            if self.xside:      # enc = the LSTM input s; s @ Wx happens inside the step kernel
+                self.refresh_wimage()
+                Hs = ops.lstm_sequence_x(enc.view(self.N, T, E, enc.shape[-1]), self.params[self.k_wx],
+                                         self.params[self.k_wh], self.params[self.k_b], h0, c0, done, masked_steps,
+                                         self._img)
+            else:
+                Hs = ops.lstm_sequence(enc.view(self.N, T, E, enc.shape[-1]), self.params[self.k_wh],
+                                       self.params[self.k_b], h0, c0, done, masked_steps)
             return Hs.reshape(self.N, T * E, self.n_h)
         if self.fused_coupled:
             # cross-agent recurrences: manual BPTT in one autograd node (agents/sequence.py)
@@ -431,7 +457,7 @@ class BatchedPolicy:
 class LstmPolicy(BatchedPolicy):
     """IA2C: fc(n_s -> n_fc, relu) -> LSTM -> heads (policies.py:136-149)."""
     name = 'lstm'
-    k_wh, k_b = 'lstm_wh', 'lstm_b'
+    k_wh, k_b, k_wx = 'lstm_wh', 'lstm_b', 'lstm_wx'
     coupled = False               # the recurrence has no cross-agent term -> fused sequence op
 
     def _phases(self):
@@ -443,12 +469,15 @@ class LstmPolicy(BatchedPolicy):
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
     def _enc(self, xv, fp):
-        """x-side LSTM pre-activation [N,rows,4H] (bias is added in the cell kernel)."""
+        """The LSTM input s (x-side mode), else the x-side pre-activation s @ Wx [N,rows,4H] (bias is added in the
+        cell kernel)."""
         p = self.params
-        return ops.linear(ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
+        s = ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU)
+        return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
-        return torch.bmm(self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
+        s = self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU)
+        return s if self.xside else torch.bmm(s, self.params['lstm_wx'])
 
     def _recur_in(self, enc, h):
         return enc
@@ -473,7 +502,7 @@ class FPPolicy(LstmPolicy):
         pf = ops.nbr_gather(fp, self.nbr_idx)
         # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place
         s = ops.fc_concat([(xv, p['fcs_w'], p['fcs_b']), (pf, p['fcp_w'], p['fcp_b'])], ops.BIAS_RELU)
-        return ops.linear(s, p['lstm_wx'])
+        return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
         p = self.params
@@ -486,7 +515,7 @@ class FPPolicy(LstmPolicy):
             s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device)
             self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
-        return torch.bmm(s, p['lstm_wx'])                                               # ONE K = 2 nf GEMM
+        return s if self.xside else torch.bmm(s, p['lstm_wx'])                          # else ONE K = 2 nf GEMM
 
 
 class NCMultiAgentPolicy(BatchedPolicy):
@@ -541,7 +570,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
         p = self.params
         H = self.n_h
         hm = self._fc_infer(ops.nbr_gather(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU)
-        return torch.bmm(hm, p['wx_hid'][:, 2 * H:]), enc
+        return torch.bmm(hm, p['wx_hid'][:, 2 * H:]), enc, None
 
     def _seq_args(self):
         p = self.params
@@ -584,7 +613,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     def _recur_addends(self, enc, h):
         p = self.params
         s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
-        return torch.bmm(s, p['wx_hid']), None
+        return torch.bmm(s, p['wx_hid']), None, None
 
     def _seq_args(self):
         p = self.params
@@ -609,10 +638,12 @@ class ConsensusPolicy(LstmPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return ops.linear(ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU), p['lstm_wx'])
+        s = ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU)
+        return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp):
-        return torch.bmm(self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU), self.params['lstm_wx'])
+        s = self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU)
+        return s if self.xside else torch.bmm(s, self.params['lstm_wx'])
 
     def consensus_update(self):
         """policies.py:357-364, 403-426: simultaneous neighbourhood average of (wx, wh, b) of every agent's LSTM.
@@ -682,7 +713,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         p = self.params
         msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU)
         hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU).add_(enc)
-        return torch.bmm(hm, p['wx_hid']), None
+        return torch.bmm(hm, p['wx_hid']), None, None
 
     def _seq_args(self):
         p = self.params

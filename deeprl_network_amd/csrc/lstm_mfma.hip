@@ -7,18 +7,10 @@
 // with the cell fused into the GEMM epilogue: the [rows x 256] pre-activation never goes to HBM
 // (the separate GEMM + cell pair writes and re-reads it: 2 x 33.5 MB per step at E = 4096).
 //
-// Mapping (H = 64 -> 256 gate columns).  One 256-thread block = 4 waves = 128 rows of ONE agent and ALL
-// 256 columns, because unit j needs columns j, 64+j, 128+j, 192+j together.  Wh (64 x 256 fp32 = 64 KB) is
-// staged once per block in LDS, each wave's 32 x 64 tile of h in a padded LDS tile (row pitch 65: the 32
-// rows a wave reads per MFMA operand fall in 32 different banks).  A wave owns a 32 x 256 strip =
-// 8 accumulator tiles of v_mfma_f32_32x32x2_f32 (128 accumulator registers), K = 64 -> 32 MFMAs per tile.
-// The accumulators are INITIALISED with zadd1 (+ zadd2) + bias (C operand), so the epilogue needs no
-// further loads except c; in the C/D layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
-// a lane holds all four gates of its (row, unit) pairs in registers: the cell is lane-local.
-// fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md): 256 MFMAs x 64 cycles
-// per 32 rows and wave -> 6.8 us of matrix time for 32768 rows on 256 CUs.
+// Two kernels: lstm_step_mfma16_kernel (recurrent product only, the x-side pre-activation arrives as an addend) and
+// lstm_step_x_kernel (the x-side product s @ Wx is computed here as well: K = KX + 64, nothing of the pre-activation
+// ever exists in HBM).  fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md).
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -26,9 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int H = 64;
 constexpr int G4 = 4 * H;          // 256 gate columns
-constexpr int ROWS_W = 32;         // rows per wave
-constexpr int WAVES = 4;
-constexpr int ROWS_B = ROWS_W * WAVES;
+constexpr int ROWS_B = 128;        // rows per block
 constexpr int APITCH = H + 1;      // 65
 
 struct FusedArgs {
@@ -51,121 +41,9 @@ __device__ __forceinline__ float sigm(float x) {
 }
 __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigm(2.0f * x) - 1.0f; }
 
-template <bool HAS_Z2>
-__global__ __launch_bounds__(256, 1) void lstm_step_mfma_kernel(const FusedArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* w_lds = lds;                                   // [64][256]
-    float* a_lds = lds + H * G4;                          // [WAVES][32][65]
-    const int n = blockIdx.x / a.blocks_per_agent;
-    const int64_t row_blk = (int64_t)(blockIdx.x - n * a.blocks_per_agent) * ROWS_B;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = row_blk + wave * ROWS_W;         // first row of this wave's strip
-    const int col = lane & 31, half = lane >> 5;
-    float* a_tile = a_lds + wave * ROWS_W * APITCH;
-
-    // ---- accumulators <- zadd1: 128 independent loads per lane, nothing consumes them before the K loop, so
-    // they all stay in flight behind the LDS staging (an add right after each load serialised them: 29 us)
-    f32x16 acc[8];
-    const float* z1 = a.zadd1 + (int64_t)n * a.zadd1_sn;
-    int64_t rofs[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        rofs[r] = (row < a.E ? row : a.E - 1);
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = z1[rofs[r] * G4 + t * 32 + col];
-    // ---- c_prev of this lane's (row, unit) pairs
-    float cp[2][16];
-    const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            cp[jj][r] = cpn[rofs[r] * H + jj * 32 + col];
-        }
-
-    // ---- stage Wh (64 KB, whole block) and this wave's h tile (masked by 1 - done) in LDS
-    {
-        const float4* wg = reinterpret_cast<const float4*>(a.wh + (int64_t)n * a.wh_sn);
-        float4* wl = reinterpret_cast<float4*>(w_lds);
-#pragma unroll
-        for (int i = 0; i < (H * G4 / 4) / 256; ++i) wl[i * 256 + threadIdx.x] = wg[i * 256 + threadIdx.x];
-        const float* hn = a.h_in + (int64_t)n * a.h_sn;
-#pragma unroll
-        for (int i = 0; i < (ROWS_W * H / 4) / 64; ++i) {       // 8 float4 per lane, coalesced
-            const int v = i * 64 + lane;
-            const int r = v >> 4, k4 = (v & 15) * 4;
-            int64_t row = row0 + r;
-            row = row < a.E ? row : a.E - 1;
-            const float keep = 1.0f - a.done[row];
-            const float4 x = *reinterpret_cast<const float4*>(hn + row * H + k4);
-            float* d = a_tile + r * APITCH + k4;
-            d[0] = x.x * keep; d[1] = x.y * keep; d[2] = x.z * keep; d[3] = x.w * keep;
-        }
-    }
-    __syncthreads();
-
-    // ---- + bias (+ zadd2): C operand of the first MFMA of every tile
-    {
-        const float* bn = a.bias + (int64_t)n * a.bias_sn;
-        const float* z2 = HAS_Z2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float b = bn[t * 32 + col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[t][r] + b;
-                if (HAS_Z2) v += z2[rofs[r] * G4 + t * 32 + col];
-                acc[t][r] = v;
-            }
-        }
-    }
-
-    // ---- K loop: 32 steps of K = 2, 8 column tiles each
-#pragma unroll 4
-    for (int kk = 0; kk < H / 2; ++kk) {
-        const float av = a_tile[col * APITCH + 2 * kk + half];          // A[i = lane & 31][k = lane >> 5]
-        const float* wrow = w_lds + (2 * kk + half) * G4 + col;          // B[k = lane >> 5][j = lane & 31]
-#pragma unroll
-        for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wrow[t * 32], acc[t], 0, 0, 0);
-    }
-
-    // ---- lane-local cell epilogue
-    float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
-    float* cn = a.c_new + (int64_t)n * a.c_new_sn;
-    float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool ok = row < a.E;
-            const float keep = 1.0f - a.done[rofs[r]];
-            const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[2 + jj][r]);
-            const float go = sigm(acc[4 + jj][r]), gu = tanh_fast(acc[6 + jj][r]);
-            const float c = gf * (cp[jj][r] * keep) + gi * gu;
-            const float hv = go * tanh_fast(c);
-            if (ok) {
-                const int j = jj * 32 + col;
-                cn[row * H + j] = c;
-                hn_out[row * H + j] = hv;
-                if (gn) {
-                    float* g = gn + row * G4 + j;
-                    g[0] = gi; g[H] = gf; g[2 * H] = go; g[3 * H] = gu;
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// v2: 16-row wave strips on v_mfma_f32_16x16x4_f32, two waves per SIMD, staggered halves.
-//
-// v1 above runs ONE wave per SIMD, so its phases (HBM loads ~11 us chip-wide, MFMA 8 us, epilogue 5.6 us) add up
-// (26-28 us per call at E = 4096).  Here a 512-thread block = 8 waves x 16 rows (same 128 rows per block, same
+// Recurrent-only step (z = zadd + (h keep) @ Wh): 16-row wave strips on v_mfma_f32_16x16x4_f32, two waves per SIMD,
+// staggered halves.  A 512-thread block = 8 waves x 16 rows (same 128 rows per block, same
 // grid); waves 0-3 ("A") issue their input loads at once while waves 4-7 ("B") stage Wh into LDS; after the one
 // block barrier B issues its loads.  Each SIMD hosts one A and one B wave: B's loads overlap A's MFMAs, and B's
 // MFMAs overlap A's (VALU) epilogue.  Wh sits in LDS as [k][lane c][tile t] with pitch 20 floats per lane, so a
@@ -334,6 +212,10 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
         }
     }
 
+    float keepr[4];                      // hoisted: inside the epilogue loops every read would wait on its own load
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keepr[r] = 1.0f - a.done[rofs[r]];
+
     // HEAD 3 (forward 'p' + forward 'v' of one lock-step in one launch, uncoupled nets): the value re-step (quirk Q1)
     // starts from the state this step produces and adds the SAME x-side addend, so keep a copy of it
     f32x4 zs[HEAD == 3 ? 16 : 1];
@@ -375,7 +257,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 4 * grp + r;
             const bool ok = row < a.E;
-            const float keep = 1.0f - a.done[rofs[r]];
+            const float keep = keepr[r];
             const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
             const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
             const float cv = gf * (cp[jj][r] * keep) + gi * gu;
@@ -431,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float keep = 1.0f - a.done[rofs[r]];
+                const float keep = keepr[r];
                 const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
                 const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
                 const float cv = gf * (cp[jj][r] * keep) + gi * gu;
@@ -442,6 +324,289 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         head_epilogue<3>(a, n, (int)(gridDim.x / a.blocks_per_agent), row0, lane, a_tile);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// lstm_step_x_kernel: the WHOLE pre-activation on the matrix cores,
+//     z = [x | h * (1 - done)] @ [Wx; Wh] + bias (+ zadd1 + zadd2),   K = KX + 64  (KX = 0, 32, ... , 256)
+// then the same cell / head epilogues as above.  agents/utils.py:102-113 (lstm: x = fc output, KX = n_fc, or the
+// [fcs | fcp] concatenation of policies.py:176-181, KX = 2 n_fc), :199-208 (lstm_comm: x = [hx | hp | hm], KX = 3 H),
+// :401-408 (lstm_ic3: x = s, KX = H).  The separate library GEMM s @ Wx (25.6 us and 33.5 MB written + re-read per
+// lock-step at E = 4096) disappears; what is left is bound by the fp32 matrix pipe.
+//
+// Weights: [Wx; Wh] of an agent is (KX + 64) x 256 floats = up to 320 KB -- more than the 160 KB LDS -- so it streams
+// through LDS in chunks of 32 k-rows, double buffered, from a pre-permuted IMAGE (nmarl_lstm_wimage, rebuilt once per
+// weight update): chunk = [k][c = column & 15][t = column >> 4, padded to 20] floats = 40 KB, staged by plain
+// 16-byte copies; a lane fetches the B operands of all 16 column tiles of one k with four conflict-free
+// ds_read_b128.  The two Wh chunks come last, so after the K loop both LDS buffers still hold Wh: the value
+// re-step of head kind 3 (quirk Q1) needs no re-staging.
+// Activations: a wave owns 16 rows x all 256 columns (64 accumulator registers); its A operands are loaded from
+// global memory straight into registers as float4 (lane (row = lane & 15, g = lane >> 4) takes k = 32 ch + 16 j + 4 g
+// + {0..3}: 64-byte segments), one chunk ahead.  The MFMA k order inside a chunk is permuted accordingly -- A and B
+// use the same permutation, so the product is unchanged.
+// Block = 512 threads = 8 waves x 16 rows = 128 rows of agent (blockIdx % N): with N = 8 all blocks of an agent share
+// an XCD, whose L2 then holds just that agent's image.  One barrier per chunk.
+constexpr int CH_K = 32;                        // k rows per W chunk
+constexpr int CH_FLOATS = CH_K * 16 * 20;       // 10240 floats = 40 KB
+constexpr int LDSX_FLOATS = 2 * CH_FLOATS + WAVES2 * R16 * APITCH;
+constexpr int MAX_KX = 256;
+
+struct XArgs {
+    FusedArgs f;                  // h_in, bias, zadd*, c_prev, done, gates, c_new, h_new, strides, E, hd (wh unused)
+    const float* x; int64_t x_sn, x_row;
+    const float* img; int64_t img_sn;
+    int nx, N;                    // x chunks (KX / 32), agents
+};
+
+// one k-step: 16 MFMAs (all column tiles) with the A value `av` and the B operands in four float4 registers
+#define NMARL_MFMA16(av, b0, b1, b2, b3)                                                  \
+    {                                                                                     \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.x, acc[0], 0, 0, 0);         \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.y, acc[1], 0, 0, 0);         \
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.z, acc[2], 0, 0, 0);         \
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0.w, acc[3], 0, 0, 0);         \
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.x, acc[4], 0, 0, 0);         \
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.y, acc[5], 0, 0, 0);         \
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.z, acc[6], 0, 0, 0);         \
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1.w, acc[7], 0, 0, 0);         \
+        acc[8] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.x, acc[8], 0, 0, 0);         \
+        acc[9] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.y, acc[9], 0, 0, 0);         \
+        acc[10] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.z, acc[10], 0, 0, 0);       \
+        acc[11] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b2.w, acc[11], 0, 0, 0);       \
+        acc[12] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.x, acc[12], 0, 0, 0);       \
+        acc[13] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.y, acc[13], 0, 0, 0);       \
+        acc[14] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.z, acc[14], 0, 0, 0);       \
+        acc[15] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b3.w, acc[15], 0, 0, 0);       \
+    }
+// B operands of k row `krow` of a chunk buffer (lane base already applied): four ds_read_b128
+#define NMARL_BLOAD(dst, buf, krow)                                                       \
+    {                                                                                     \
+        const float4* q_ = reinterpret_cast<const float4*>((buf) + (krow) * 320);         \
+        dst##0 = q_[0]; dst##1 = q_[1]; dst##2 = q_[2]; dst##3 = q_[3];                   \
+    }
+// a whole chunk (8 k-steps) with the B operands of step s + 1 in flight while the MFMAs of step s issue
+// (two register sets; sched_barrier keeps the compiler from sinking the reads back behind the MFMAs)
+#define NMARL_CHUNK(buf, A0, A1)                                                          \
+    {                                                                                     \
+        float4 p0, p1, p2, p3, q0, q1, q2, q3;                                            \
+        NMARL_BLOAD(p, buf, 0)                                                            \
+        NMARL_BLOAD(q, buf, 1) __builtin_amdgcn_sched_barrier(0);                         \
+        NMARL_MFMA16(A0.x, p0, p1, p2, p3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_BLOAD(p, buf, 2) __builtin_amdgcn_sched_barrier(0);                         \
+        NMARL_MFMA16(A0.y, q0, q1, q2, q3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_BLOAD(q, buf, 3) __builtin_amdgcn_sched_barrier(0);                         \
+        NMARL_MFMA16(A0.z, p0, p1, p2, p3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_BLOAD(p, buf, 16) __builtin_amdgcn_sched_barrier(0);                        \
+        NMARL_MFMA16(A0.w, q0, q1, q2, q3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_BLOAD(q, buf, 17) __builtin_amdgcn_sched_barrier(0);                        \
+        NMARL_MFMA16(A1.x, p0, p1, p2, p3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_BLOAD(p, buf, 18) __builtin_amdgcn_sched_barrier(0);                        \
+        NMARL_MFMA16(A1.y, q0, q1, q2, q3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_BLOAD(q, buf, 19) __builtin_amdgcn_sched_barrier(0);                        \
+        NMARL_MFMA16(A1.z, p0, p1, p2, p3) __builtin_amdgcn_sched_barrier(0);             \
+        NMARL_MFMA16(A1.w, q0, q1, q2, q3)                                                \
+    }
+
+template <int HEAD>
+__global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const FusedArgs& a = xa.f;
+    const int n = blockIdx.x % xa.N;
+    const int64_t row_blk = (int64_t)(blockIdx.x / xa.N) * ROWS_B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = row_blk + wave * R16;
+    const int c = lane & 15, grp = lane >> 4;
+    float* a_tile = lds + 2 * CH_FLOATS + wave * R16 * APITCH;
+    const int nx = xa.nx, nch = xa.nx + 2;
+    const float4* img = reinterpret_cast<const float4*>(xa.img + (int64_t)n * xa.img_sn);
+
+    // ---- W chunk staging: 2560 float4 per chunk = 5 per thread, image order == LDS order
+    // (five NAMED registers: as an array living across the runtime chunk loop the compiler demotes it to scratch)
+    float4 sg0, sg1, sg2, sg3, sg4;
+#define NMARL_STAGE_LOAD(ch)                                                              \
+    {                                                                                     \
+        const float4* g_ = img + (int64_t)(ch) * (CH_FLOATS / 4) + threadIdx.x;           \
+        sg0 = g_[0]; sg1 = g_[512]; sg2 = g_[1024]; sg3 = g_[1536]; sg4 = g_[2048];       \
+    }
+#define NMARL_STAGE_STORE(b)                                                              \
+    {                                                                                     \
+        float4* d_ = reinterpret_cast<float4*>(lds + (b) * CH_FLOATS) + threadIdx.x;      \
+        d_[0] = sg0; d_[512] = sg1; d_[1024] = sg2; d_[1536] = sg3; d_[2048] = sg4;       \
+    }
+    NMARL_STAGE_LOAD(0)
+
+    // ---- A operands: row (lane & 15) of this wave's strip, k = 32 ch + 16 j + 4 grp + {0..3}
+    const int64_t arow = row0 + c < a.E ? row0 + c : a.E - 1;
+    const float keepA = 1.0f - a.done[arow];
+    const float* xrow = xa.x ? xa.x + (int64_t)n * xa.x_sn + arow * xa.x_row + 4 * grp : nullptr;
+    const float* hrow = a.h_in + (int64_t)n * a.h_sn + arow * H + 4 * grp;
+    float4 a0, a1, n0, n1;
+#define NMARL_A_LOAD(ch, d0, d1)     /* raw load; the (1 - done) mask of the h chunks is applied at first use */ \
+    if ((ch) < nx) {                                                                      \
+        d0 = *reinterpret_cast<const float4*>(xrow + (ch) * CH_K);                        \
+        d1 = *reinterpret_cast<const float4*>(xrow + (ch) * CH_K + 16);                   \
+    } else {                                                                              \
+        d0 = *reinterpret_cast<const float4*>(hrow + ((ch) - nx) * CH_K);                 \
+        d1 = *reinterpret_cast<const float4*>(hrow + ((ch) - nx) * CH_K + 16);            \
+    }
+#define NMARL_A_MASK(ch, d0, d1)                                                          \
+    {                                                                                     \
+        const float kf_ = (ch) < nx ? 1.0f : keepA;                                       \
+        d0.x *= kf_; d0.y *= kf_; d0.z *= kf_; d0.w *= kf_;                               \
+        d1.x *= kf_; d1.y *= kf_; d1.z *= kf_; d1.w *= kf_;                               \
+    }
+    NMARL_A_LOAD(0, a0, a1)
+    NMARL_STAGE_STORE(0)
+    NMARL_STAGE_LOAD(1)
+
+    // ---- accumulators <- bias (+ zadd1 + zadd2);  C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+    int64_t rofs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = row0 + 4 * grp + r;
+        rofs[r] = row < a.E ? row : a.E - 1;
+    }
+    f32x4 acc[16];
+    {
+        const float* bn = a.bias + (int64_t)n * a.bias_sn;
+        const float* z1 = a.zadd1 ? a.zadd1 + (int64_t)n * a.zadd1_sn : nullptr;
+        const float* z2 = a.zadd2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float b = bn[t * 16 + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[t][r] = b;
+        }
+        if (z1) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += z1[rofs[r] * G4 + t * 16 + c];
+        }
+        if (z2) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[t][r] += z2[rofs[r] * G4 + t * 16 + c];
+        }
+    }
+    float cp[4][4];
+    {
+        const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cp[jj][r] = cpn[rofs[r] * H + jj * 16 + c];
+    }
+    NMARL_STAGE_STORE(1)
+    NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
+    __syncthreads();
+
+    float keepr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) keepr[r] = 1.0f - a.done[rofs[r]];
+    f32x4 zs[HEAD == 3 ? 16 : 1];
+    NMARL_A_MASK(0, a0, a1)
+    for (int ch = 0; ch < nch; ++ch) {
+        // Loads are issued UNCONDITIONALLY (indices clamped to the last chunk): a load inside a branch makes the
+        // compiler's waitcnt pass assume the worst path at the join and wait for everything in flight, i.e. expose
+        // the global latency of the staging loads once per chunk.
+        const int chn = ch + 1 < nch ? ch + 1 : nch - 1;
+        NMARL_A_LOAD(chn, n0, n1)
+        if (HEAD == 3 && ch == nx) {            // x-side part complete: the value re-step adds the SAME addend
+#pragma unroll
+            for (int t = 0; t < 16; ++t) zs[t] = acc[t];
+        }
+        const float* buf = lds + (ch & 1) * CH_FLOATS + (4 * grp * 16 + c) * 20;
+        NMARL_CHUNK(buf, a0, a1)
+        __syncthreads();                         // every wave is done with buf[ch & 1]; chunk ch + 1 is visible
+        if (ch + 2 < nch) NMARL_STAGE_STORE(ch & 1)
+        const int chs = ch + 3 < nch ? ch + 3 : nch - 1;
+        NMARL_STAGE_LOAD(chs)
+        a0 = n0; a1 = n1;
+        NMARL_A_MASK(chn, a0, a1)
+    }
+
+    // ---- lane-local cell epilogue
+    float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
+    float* cn = a.c_new + (int64_t)n * a.c_new_sn;
+    float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * grp + r;
+            const bool ok = row < a.E;
+            const float keep = keepr[r];
+            const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
+            const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
+            const float cv = gf * (cp[jj][r] * keep) + gi * gu;
+            const float hv = go * tanh_fast(cv);
+            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;
+            if (HEAD == 3) cp[jj][r] = cv;
+            if (ok) {
+                const int j = jj * 16 + c;
+                cn[row * H + j] = cv;
+                hn_out[row * H + j] = hv;
+                if (gn) {
+                    float* g = gn + row * G4 + j;
+                    g[0] = gi; g[H] = gf; g[2 * H] = go; g[3 * H] = gu;
+                }
+            }
+        }
+    }
+    if (HEAD != 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        head_epilogue<(HEAD == 3 ? 1 : HEAD)>(a, n, xa.N, row0, lane, a_tile);
+    }
+    if (HEAD == 3) {
+        // ---- the value re-step (quirk Q1): z = x-side addend + (h' keep) @ Wh from the two resident Wh chunks
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = zs[t];
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+            const float* buf = lds + ((nx + hc) & 1) * CH_FLOATS + (4 * grp * 16 + c) * 20;
+            const float* ar = a_tile + c * APITCH + hc * CH_K + 4 * grp;
+            float4 r0, r1;
+            r0.x = ar[0] * keepA; r0.y = ar[1] * keepA; r0.z = ar[2] * keepA; r0.w = ar[3] * keepA;
+            r1.x = ar[16] * keepA; r1.y = ar[17] * keepA; r1.z = ar[18] * keepA; r1.w = ar[19] * keepA;
+            NMARL_CHUNK(buf, r0, r1)
+        }
+        __builtin_amdgcn_wave_barrier();                 // every lane has read its A operands: the tile may be overwritten
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float keep = keepr[r];
+                const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
+                const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
+                const float cv = gf * (cp[jj][r] * keep) + gi * gu;
+                a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = go * tanh_fast(cv);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        head_epilogue<3>(a, n, xa.N, row0, lane, a_tile);
+    }
+#undef NMARL_STAGE_LOAD
+#undef NMARL_STAGE_STORE
+#undef NMARL_A_LOAD
+#undef NMARL_A_MASK
+}
+
+// image[n][ch][kl][c][t] = W[32 ch + kl][16 t + c] (t < 16; 16..19 = 0), W = [wx (KX rows); wh (64 rows)]
+__global__ void lstm_wimage_kernel(const int N, const int KX, const float* wx, const int64_t wx_sn, const float* wh,
+                                   const int64_t wh_sn, float* img, const int64_t img_sn) {
+    const int per_agent = (KX + H) * 320;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * per_agent) return;
+    const int n = (int)(i / per_agent), o = (int)(i % per_agent);
+    const int k = o / 320, cc = (o % 320) / 20, t = o % 20;
+    float v = 0.0f;
+    if (t < 16) v = k < KX ? wx[(int64_t)n * wx_sn + (int64_t)k * G4 + 16 * t + cc] : wh[(int64_t)n * wh_sn + (int64_t)(k - KX) * G4 + 16 * t + cc];
+    img[(int64_t)n * img_sn + o] = v;
 }
 
 inline bool stride_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
@@ -481,33 +646,25 @@ static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     if (kind != 0) a.hd = *head;
-    static int variant = -1;        // NMARL_FUSED_VARIANT=1 selects the one-wave-per-SIMD 32x32x2 kernel (A/B comparisons)
-    if (variant < 0) {
-        const char* ev = getenv("NMARL_FUSED_VARIANT");
-        const int l1 = (int)((H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float)), l2 = (int)(LDS2_FLOATS * sizeof(float));
+    static bool lds_set = false;
+    const int l2 = (int)(LDS2_FLOATS * sizeof(float));
+    if (!lds_set) {
 #define NMARL_SET_LDS(k, bytes) \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return NMARL_EHIP;
-        NMARL_SET_LDS(lstm_step_mfma_kernel<false>, l1) NMARL_SET_LDS(lstm_step_mfma_kernel<true>, l1)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 0>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 0>), l2)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 1>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 1>), l2)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 2>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 2>), l2)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 3>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 3>), l2)
 #undef NMARL_SET_LDS
-        variant = (ev && ev[0] == '1') ? 1 : 2;
+        lds_set = true;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.blocks_per_agent * N);
-    if (variant == 1 && kind == 0) {
-        const size_t lds_bytes = (size_t)(H * G4 + WAVES * ROWS_W * APITCH) * sizeof(float);
-        if (zadd2) hipLaunchKernelGGL(lstm_step_mfma_kernel<true>, grid, dim3(256), lds_bytes, st, a);
-        else hipLaunchKernelGGL(lstm_step_mfma_kernel<false>, grid, dim3(256), lds_bytes, st, a);
-    } else {
-        const size_t lds_bytes = (size_t)LDS2_FLOATS * sizeof(float);
+    const size_t lds_bytes = (size_t)LDS2_FLOATS * sizeof(float);
 #define NMARL_LAUNCH16(Z2, HD) hipLaunchKernelGGL((lstm_step_mfma16_kernel<Z2, HD>), grid, dim3(512), lds_bytes, st, a)
-        if (zadd2) { if (kind == 0) NMARL_LAUNCH16(true, 0); else if (kind == 1) NMARL_LAUNCH16(true, 1); else if (kind == 2) NMARL_LAUNCH16(true, 2); else NMARL_LAUNCH16(true, 3); }
-        else       { if (kind == 0) NMARL_LAUNCH16(false, 0); else if (kind == 1) NMARL_LAUNCH16(false, 1); else if (kind == 2) NMARL_LAUNCH16(false, 2); else NMARL_LAUNCH16(false, 3); }
+    if (zadd2) { if (kind == 0) NMARL_LAUNCH16(true, 0); else if (kind == 1) NMARL_LAUNCH16(true, 1); else if (kind == 2) NMARL_LAUNCH16(true, 2); else NMARL_LAUNCH16(true, 3); }
+    else       { if (kind == 0) NMARL_LAUNCH16(false, 0); else if (kind == 1) NMARL_LAUNCH16(false, 1); else if (kind == 2) NMARL_LAUNCH16(false, 2); else NMARL_LAUNCH16(false, 3); }
 #undef NMARL_LAUNCH16
-    }
     return nmarl_check_launch();
 }
 
@@ -529,4 +686,75 @@ extern "C" int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t Hh, cons
                                           int64_t h_new_sn, const nmarl_head_t* head, void* stream) {
     return launch_fused(E, N, Hh, h_in, h_sn, wh, wh_sn, bias, bias_sn, zadd1, zadd1_sn, zadd2, zadd2_sn, c_prev, c_prev_sn,
                         done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, stream);
+}
+
+extern "C" int nmarl_lstm_wimage_floats(int32_t KX) { return (KX + H) * 320; }
+
+extern "C" int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t wx_sn, const float* wh, int64_t wh_sn,
+                                 float* img, int64_t img_sn, void* stream) {
+    if (N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || !wh || !img || (KX > 0 && !wx) || img_sn < (int64_t)(KX + H) * 320 ||
+        (img_sn % 4) || ((uintptr_t)img % 16) || wh_sn < H * G4 || (KX > 0 && wx_sn < (int64_t)KX * G4))
+        return NMARL_EINVAL;
+    const int64_t total = (int64_t)N * (KX + H) * 320;
+    hipLaunchKernelGGL(lstm_wimage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       N, KX, wx, wx_sn, wh, wh_sn, img, img_sn);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                                 const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                                 int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                                 const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
+                                 float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
+                                 void* stream) {
+    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K ||
+        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX > 0 && !x))))
+        return NMARL_EINVAL;
+    const int kind = head ? head->kind : 0;
+    if (kind < 0 || kind > 3) return NMARL_EINVAL;
+    if (kind != 0 && E > 0) {
+        if (head->A <= 0 || head->A > MAXA || !head->w || !head->b || head->b_sn < (kind == 2 ? 1 : head->A)) return NMARL_EINVAL;
+        if ((kind == 1 || kind == 3) && (head->w_sn < (int64_t)H * head->A || !head->pi_out || head->pi_sn < E * head->A || !head->act_out ||
+                          head->mode < 0 || head->mode > 2 || (head->mode == 0 && !head->u)))
+            return NMARL_EINVAL;
+        if (kind == 3 && (!head->w2 || !head->b2 || head->w2_sn < H || head->b2_sn < 1 || !head->v_out || head->v_sn < E))
+            return NMARL_EINVAL;
+        if (kind == 2 && (head->m_max < 0 || head->w_sn < H + (int64_t)head->m_max * head->A || !head->v_out || head->v_sn < E ||
+                          (head->m_max > 0 && (!head->act_in || !head->nbr_idx))))
+            return NMARL_EINVAL;
+    }
+    if (E == 0) return NMARL_OK;
+    if (!stride_ok(h_sn, E * H) || !stride_ok(bias_sn, G4) || (zadd1 && !stride_ok(zadd1_sn, E * G4)) ||
+        (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
+        !stride_ok(h_new_sn, E * H) || (gates && !stride_ok(gates_sn, E * G4)) || ((uintptr_t)h_in % 16) || ((uintptr_t)img % 16) ||
+        img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
+        (KX > 0 && (x_row < KX || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))))
+        return NMARL_EINVAL;
+    XArgs xa{};
+    FusedArgs& a = xa.f;
+    a.h_in = h_in; a.bias = bias; a.zadd1 = zadd1; a.zadd2 = zadd2; a.c_prev = c_prev; a.done = done;
+    a.gates = gates; a.c_new = c_new; a.h_new = h_new;
+    a.h_sn = h_sn; a.bias_sn = bias_sn; a.zadd1_sn = zadd1_sn; a.zadd2_sn = zadd2_sn;
+    a.c_prev_sn = c_prev_sn; a.gates_sn = gates_sn; a.c_new_sn = c_new_sn; a.h_new_sn = h_new_sn;
+    a.E = E;
+    a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
+    if (kind != 0) a.hd = *head;
+    xa.x = KX > 0 ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row; xa.img = img; xa.img_sn = img_sn;
+    xa.nx = KX / CH_K; xa.N = N;
+    static bool lds_set = false;
+    const int lb = (int)(LDSX_FLOATS * sizeof(float));
+    if (!lds_set) {
+#define NMARL_SET_LDS(k) \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess) return NMARL_EHIP;
+        NMARL_SET_LDS(lstm_step_x_kernel<0>) NMARL_SET_LDS(lstm_step_x_kernel<1>) NMARL_SET_LDS(lstm_step_x_kernel<2>) NMARL_SET_LDS(lstm_step_x_kernel<3>)
+#undef NMARL_SET_LDS
+        lds_set = true;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(a.blocks_per_agent * N);
+    if (kind == 0) hipLaunchKernelGGL(lstm_step_x_kernel<0>, grid, dim3(512), (size_t)lb, st, xa);
+    else if (kind == 1) hipLaunchKernelGGL(lstm_step_x_kernel<1>, grid, dim3(512), (size_t)lb, st, xa);
+    else if (kind == 2) hipLaunchKernelGGL(lstm_step_x_kernel<2>, grid, dim3(512), (size_t)lb, st, xa);
+    else hipLaunchKernelGGL(lstm_step_x_kernel<3>, grid, dim3(512), (size_t)lb, st, xa);
+    return nmarl_check_launch();
 }

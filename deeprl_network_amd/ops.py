@@ -142,10 +142,55 @@ def cell_fwd(z, bias, c_prev, done, gates, c_new, h_new, z2=None):
 FUSED_H = 64      # nmarl_lstm_step_fused is specialised for 64-unit cells (256 gate columns per MFMA strip)
 
 
-def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out):
-    """(gates, c', h') = cell(zadd1 (+ zadd2) + (h*(1-done)) @ wh + bias, c_prev, done) in ONE MFMA kernel
-    (H = 64).  All operands [N,E,*] panels (strided slots allowed); h_out / c_out may alias h / c_prev."""
+XSIDE_MAX_K = 256      # widest x-side input of nmarl_lstm_step_x (multiples of 32)
+
+
+def xside_supported(kx, n_h):
+    """The x-side product s @ Wx fits the fused step (csrc/lstm_mfma.hip: lstm_step_x_kernel)."""
+    return n_h == FUSED_H and kx % 32 == 0 and 0 <= kx <= XSIDE_MAX_K
+
+
+def lstm_wimage(wx, wh, out=None):
+    """Chunked LDS image of [wx; wh] (wx [N,KX,4H] or None, wh [N,H,4H]) for the x-mode of the fused step; rebuild it
+    whenever the weights change.  -> [N, (KX+64)*320] f32."""
+    N = wh.shape[0]
+    KX = 0 if wx is None else wx.shape[1]
+    n = lib.nmarl_lstm_wimage_floats(KX)
+    if out is None:
+        out = torch.empty(N, n, dtype=F32, device=wh.device)
+    if wh.stride(2) != 1 or wh.stride(1) != wh.shape[2] or (wx is not None and (wx.stride(2) != 1 or wx.stride(1) != wx.shape[2])):
+        raise _lib.NmarlError('lstm_wimage: weights need contiguous per-agent panels')
+    check(lib.nmarl_lstm_wimage(N, KX, ptr(wx, F32, strided=True), 0 if wx is None else wx.stride(0),
+                                ptr(wh, F32, strided=True), wh.stride(0), ptr(out, F32), out.stride(0), stream()),
+          'nmarl_lstm_wimage')
+    return out
+
+
+def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, what):
+    """nmarl_lstm_step_x: xs = (x [N,E,KX] or None, wx (unused here: it is inside the image), image)."""
     N, E, H = h.shape
+    x, _, img = xs
+    if x is None:
+        xp, x_sn, x_row, KX = None, 0, 0, 0
+    else:
+        KX = x.shape[2]
+        xp, x_sn, x_row = _rows_view(x, KX, what + ' x')
+    if img.shape != (N, lib.nmarl_lstm_wimage_floats(KX)):
+        raise _lib.NmarlError('%s: weight image does not match KX = %d' % (what, KX))
+    check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
+                                *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out),
+                                *_pn(h_out), None if head is None else C.byref(head), stream()), what)
+
+
+def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=None):
+    """(gates, c', h') = cell(zadd1 (+ zadd2) + (h*(1-done)) @ wh + bias, c_prev, done) in ONE MFMA kernel
+    (H = 64).  All operands [N,E,*] panels (strided slots allowed); h_out / c_out may alias h / c_prev.
+    xs = (x, wx, image): the x-side product x @ wx is computed inside as well (K = KX + 64, image from lstm_wimage;
+    zadd1 / zadd2 may then be None)."""
+    N, E, H = h.shape
+    if xs is not None:
+        _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, None, 'nmarl_lstm_step_x')
+        return h_out, c_out
     if wh.stride(2) != 1 or wh.stride(1) != 4 * H:
         raise _lib.NmarlError('lstm_step_fused: wh must be [N,H,4H] with contiguous [H,4H] panels')
     check(lib.nmarl_lstm_step_fused(E, N, H, *_pn(h), ptr(wh, F32, strided=True), wh.stride(0), *_bias(bias),
@@ -157,8 +202,11 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
 HEAD_MAX_A = 8      # widest action set the fused head epilogue supports (csrc/lstm_mfma.hip: MAXA)
 
 
-def _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, head, what):
+def _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, head, what, xs=None):
     N, E, H = h.shape
+    if xs is not None:
+        _step_x(h, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out, xs, head, what)
+        return
     if wh.stride(2) != 1 or wh.stride(1) != 4 * H:
         raise _lib.NmarlError('%s: wh must be [N,H,4H] with contiguous [H,4H] panels' % what)
     check(lib.nmarl_lstm_step_fused_head(E, N, H, *_pn(h), ptr(wh, F32, strided=True), wh.stride(0), *_bias(bias),
@@ -174,7 +222,7 @@ def _head_param(w, what):
 
 
 def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode,
-                     u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+                     u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
     """forward('p') of one lock-step in ONE kernel: the fused step (lstm_step_fused), then in its epilogue
     pi = softmax(h' @ pi_w + pi_b) -> pi_out [N,E,A] and the action draw of sample_actions -> act_out [E,N]."""
     N, E, H = h.shape
@@ -186,11 +234,11 @@ def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w
     hd.pi_out, hd.pi_sn = _pn(pi_out)
     hd.act_out, hd.u = ptr(act_out, torch.uint8), ptr(u, F32)
     hd.seed, hd.env_id_base, hd.step, hd.step_dev = seed, env_id_base, int(step), ptr(step_dev, torch.int64)
-    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[p]')
+    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[p]', xs)
     return pi_out, act_out
 
 
-def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, v_b, action, nbr_idx, n_a, v_out):
+def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, v_b, action, nbr_idx, n_a, v_out, xs=None):
     """forward('v') of one lock-step in ONE kernel: the fused step, then v = [h', onehot(neighbour actions)] @ v_w
     + v_b -> v_out [N,E]; the one-hot rows are gathered from action [E,N] u8 (no one-hot tensor)."""
     N, E, H = h.shape
@@ -204,12 +252,12 @@ def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, 
     if v_out.dim() != 2 or v_out.stride(1) != 1:
         raise _lib.NmarlError('lstm_step_value: v_out must be [N,E] with unit column stride')
     hd.v_out, hd.v_sn = ptr(v_out, F32, strided=True), v_out.stride(0)
-    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[v]')
+    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[v]', xs)
     return v_out
 
 
 def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
-                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
     """forward('p') AND forward('v') of one lock-step (quirk Q1) for nets without a cross-agent recurrence, the state
     (h, c) [N,E,64] advanced IN PLACE by the policy step only: one MFMA kernel (policy step + pi + draw, then the value
     re-step from the new state with the same addend and the critic on h'') + the critic's neighbour-action term, which
@@ -227,7 +275,7 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     if not v_out.is_contiguous() or v_out.shape != (N, E):
         raise _lib.NmarlError('lstm_step_policy_value: v_out must be a contiguous [N,E] tensor')
     hd.v_out, hd.v_sn = ptr(v_out, F32), E
-    _fused_head(h, wh, bias, zadd1, zadd2, c, done, c, h, hd, 'nmarl_lstm_step_fused_head[pv]')
+    _fused_head(h, wh, bias, zadd1, zadd2, c, done, c, h, hd, 'nmarl_lstm_step_fused_head[pv]', xs)
     nbr_action_value(act_out, nbr_idx, v_w[:, H:], n_a, out=v_out, accumulate=True)
     return pi_out, act_out, v_out
 
@@ -619,6 +667,72 @@ def lstm_sequence(pre, wh, b, h0, c0, done, masked_steps=None):
     """masked_steps: the steps t whose done[t] can be non-zero (None = any); the others skip the state-mask
     multiplies (in the batched trainer only t = 0 can start an episode, quirk Q4)."""
     return _LstmSequence.apply(pre, wh, b, h0, c0, done, masked_steps)
+
+
+class _LstmSequenceX(torch.autograd.Function):
+    """_LstmSequence with the x-side product INSIDE the step kernel (nmarl_lstm_step_x):
+
+        z_t = s[:, t] @ wx + (h_{t-1} * (1 - done_t)) @ wh ;  (h_t, c_t) = cell(z_t + b, c_{t-1}, done_t)
+
+    s [N,T,E,KX] (the encoders' output, e.g. [fcs | fcp]), wx [N,KX,4H], wh [N,H,4H]: no [N,T,E,4H] pre-activation
+    tensor and no forward GEMM over T*E rows.  Backward: the reverse loop of (cell_bwd, dgrad GEMM vs wh), then
+    ds = dZ @ wx^T, dwx = s^T dZ, dwh, db as single GEMMs / reductions over all T*E rows."""
+
+    @staticmethod
+    def forward(ctx, s, wx, wh, b, h0, c0, done, masked_steps, img):
+        N, T, E, KX = s.shape
+        H = wh.shape[1]
+        H4 = 4 * H
+        G = torch.empty(N, T, E, H4, dtype=F32, device=s.device)
+        Hall = torch.empty(N, T + 1, E, H, dtype=F32, device=s.device)
+        Call = torch.empty(N, T + 1, E, H, dtype=F32, device=s.device)
+        Hall[:, 0].copy_(h0)
+        Call[:, 0].copy_(c0)
+        for t in range(T):
+            lstm_step_fused(Hall[:, t], wh, b, None, None, Call[:, t], done[t], G[:, t], Call[:, t + 1], Hall[:, t + 1],
+                            xs=(s[:, t], wx, img))
+        ctx.save_for_backward(G, Hall, Call, s, wx, wh, done)
+        ctx.masked = set(range(T)) if masked_steps is None else set(masked_steps)
+        return Hall[:, 1:]
+
+    @staticmethod
+    def backward(ctx, dHs):
+        G, Hall, Call, s, wx, wh, done = ctx.saved_tensors
+        N, T, E, H4 = G.shape
+        H = H4 // 4
+        dHs = dHs.contiguous()
+        dZ = torch.empty_like(G)
+        keep = (1.0 - done)
+        dh_rec = None
+        dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
+        dc_next = torch.empty_like(dc)
+        wh_t = wh.transpose(1, 2)
+        for t in range(T - 1, -1, -1):
+            cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
+            dc, dc_next = dc_next, dc
+            dh_rec = torch.bmm(dZ[:, t], wh_t)
+            if t in ctx.masked:
+                dh_rec = dh_rec * keep[t].view(1, E, 1)
+        dZf = dZ.view(N, T * E, H4)
+        if len(ctx.masked) == T:
+            Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+        else:
+            Hprev = Hall[:, :T].clone()
+            for t in ctx.masked:
+                Hprev[:, t].mul_(keep[t].view(1, E, 1))
+            Hprev = Hprev.view(N, T * E, H)
+        dwh = wgrad(Hprev, dZf)
+        db = dZf.sum(dim=1)
+        KX = s.shape[3]
+        sf = s.reshape(N, T * E, KX)
+        ds = torch.bmm(dZf, wx.transpose(1, 2)).view(N, T, E, KX) if ctx.needs_input_grad[0] else None
+        dwx = wgrad(sf, dZf)
+        return ds, dwx, dwh, db, dh_rec, dc, None, None, None
+
+
+def lstm_sequence_x(s, wx, wh, b, h0, c0, done, masked_steps, img):
+    """s [N,T,E,KX] contiguous -> Hs [N,T,E,H]; img = lstm_wimage(wx, wh) of the CURRENT weights."""
+    return _LstmSequenceX.apply(s, wx, wh, b, h0, c0, done, masked_steps, img)
 
 
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2

@@ -416,6 +416,7 @@ class BatchedTrainer:
         h, c = (torch.zeros(self.N, n_envs, model.n_lstm, device=self.device) for _ in range(2))
         fp = model.fp_uniform.expand(self.N, n_envs, model.n_a).clone()       # uniform over each agent's own actions
         env.reset()
+        model.policy.refresh_wimage()
         done = torch.ones(n_envs, device=self.device)
         act = torch.zeros(n_envs, self.N, dtype=torch.uint8, device=self.device)
         total = torch.zeros(n_envs, dtype=torch.float64, device=self.device)

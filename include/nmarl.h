@@ -267,7 +267,7 @@ int nmarl_lstm_cell_bwd(int64_t E, int32_t N, int32_t H, const float* gates, int
                         int64_t dh2_sn, const float* dc_new, int64_t dc_sn, float* dz, int64_t dz_sn,
                         float* dc_prev, int64_t dc_prev_sn, void* stream);
 /*
- * Fused recurrent GEMM + cell on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32), H = 64 only:
+ * Fused recurrent GEMM + cell on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32), H = 64 only:
  *   z = zadd1 (+ zadd2) + (h_in * (1-done)) @ wh ;  (gates, c_new, h_new) = cell(z + bias, c_prev, done)
  * Same maths as a batched GEMM followed by nmarl_lstm_cell_fwd, but the [rows,4H] pre-activation never
  * reaches HBM.  h_in [N,E,H], wh [N,H,4H], bias [N,4H], zadd1/zadd2 [N,E,4H] (zadd2 may be NULL: the
@@ -321,6 +321,27 @@ int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t H, const float* h_i
                                const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
                                int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
                                int64_t h_new_sn, const nmarl_head_t* head, void* stream);
+/*
+ * The fused step with the x-side product inside: the WHOLE pre-activation of agents/utils.py:102-113 (lstm),
+ * 199-208 (lstm_comm), 401-408 (lstm_ic3) on the matrix cores,
+ *   z = [x | h_in * (1-done)] @ [wx; wh] + bias (+ zadd1) (+ zadd2),   x [N,E,KX], KX in {0, 32, ..., 256},
+ * then cell + optional head exactly as nmarl_lstm_step_fused_head (head NULL / kind 0: none; gates may be requested).
+ * x: the LSTM input of one lock-step -- fc output (KX = n_fc), the [fcs | fcp] concatenation of policies.py:176-181
+ * (KX = 2 n_fc), lstm_comm's [hx | hp | hm] (KX = 3 H), lstm_ic3's s (KX = H) -- with agent stride x_sn and row pitch
+ * x_row >= KX (floats, multiples of 4; a column block of a wider buffer is read in place).  zadd1 / zadd2 may be NULL.
+ * The weights come as the chunked image nmarl_lstm_wimage builds from wx [N,KX,4H] and wh [N,H,4H] (agent strides in
+ * floats): per agent nmarl_lstm_wimage_floats(KX) = (KX+64)*320 floats, image[k][c][t] = W[k][16t+c] for t < 16, 4
+ * floats of padding per (k,c); rebuild it whenever the weights change (once per update).  H = 64 only.
+ */
+int nmarl_lstm_wimage_floats(int32_t KX);
+int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t wx_sn, const float* wh, int64_t wh_sn,
+                      float* img, int64_t img_sn, void* stream);
+int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                      const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                      int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                      const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
+                      float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
+                      void* stream);
 /*
  * y[n,r,:W] = act(x[n,r,:] + bias[n,:]) for x [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the

@@ -94,10 +94,28 @@ def lstm_cell(z, bias, c_prev, done):
 FUSED_H = 64
 
 
-def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out):
-    """agents/utils.py:102-113 with z = zadd1 (+ zadd2) + (h*(1-done)) @ wh."""
+XSIDE_MAX_K = 256
+
+
+def xside_supported(kx, n_h):
+    return n_h == FUSED_H and kx % 32 == 0 and 0 <= kx <= XSIDE_MAX_K
+
+
+def lstm_wimage(wx, wh, out=None):
+    """The product's chunked LDS image of [wx; wh] is a kernel-side layout; the restatement multiplies by wx / wh
+    directly, so the 'image' is just a token."""
+    return torch.zeros(wh.shape[0], 1) if out is None else out
+
+
+def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=None):
+    """agents/utils.py:102-113 with z = zadd1 (+ zadd2) + (h*(1-done)) @ wh; with xs = (x, wx, image) the x-side
+    product x @ wx is part of the step (z = x @ wx + (h*(1-done)) @ wh (+ zadd1) (+ zadd2))."""
     keep = (1.0 - done).view(1, -1, 1)
-    z = zadd1 + torch.bmm(h * keep, wh)
+    z = torch.bmm(h * keep, wh)
+    if xs is not None and xs[0] is not None:
+        z = z + torch.bmm(xs[0], xs[1])
+    if zadd1 is not None:
+        z = z + zadd1
     if zadd2 is not None:
         z = z + zadd2
     hn, cn = lstm_cell(z, bias, c_prev, done)
@@ -111,17 +129,17 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
 
 
 def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode,
-                     u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+                     u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
     """forward('p') (policies.py:119-123, 50-57) + the action draw (utils.py:135-141) after one LSTM step."""
-    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out)
+    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out, xs=xs)
     pi_out.copy_(torch.softmax(torch.bmm(h_out, pi_w) + pi_b.unsqueeze(1), dim=-1))
     sample_actions(pi_out, act_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
     return pi_out, act_out
 
 
-def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, v_b, action, nbr_idx, n_a, v_out):
+def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, v_b, action, nbr_idx, n_a, v_out, xs=None):
     """forward('v') (policies.py:124-133, 59-77): v = [h', one_hot(neighbour actions)] @ w + b."""
-    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out)
+    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out, xs=xs)
     na = nbr_onehot(action, nbr_idx, n_a)
     v_out.copy_((torch.bmm(torch.cat([h_out, na], dim=-1), v_w) + v_b.unsqueeze(1)).squeeze(-1))
     return v_out
@@ -194,13 +212,13 @@ def nbr_action_value(action, nbr_idx, w_a, n_a, out=None, accumulate=False):
 
 
 def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
-                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None):
+                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
     """Trainer._get_policy + _get_value of one lock-step (utils.py:129-149): forward('p') advances the state, forward('v')
     re-steps a COPY of it (policies.py:119-133, quirk Q1)."""
     lstm_step_policy(h, wh, bias, zadd1, zadd2, c, done, c, h, pi_w, pi_b, pi_out, act_out, mode, u=u, seed=seed,
-                     env_id_base=env_id_base, step=step, step_dev=step_dev)
+                     env_id_base=env_id_base, step=step, step_dev=step_dev, xs=xs)
     lstm_step_value(h, wh, bias, zadd1, zadd2, c, done, torch.empty_like(c), torch.empty_like(h), v_w, v_b, act_out,
-                    nbr_idx, n_a, v_out)
+                    nbr_idx, n_a, v_out, xs=xs)
     return pi_out, act_out, v_out
 
 
@@ -253,6 +271,19 @@ def lstm_sequence(pre, wh, b, h0, c0, done, masked_steps=None):
     for t in range(T):
         keep = (1.0 - done[t]).view(1, E, 1)
         z = pre[:, t] + torch.bmm(h * keep, wh)
+        h, c = lstm_cell(z, b, c, done[t])
+        hs.append(h)
+    return torch.stack(hs, dim=1)
+
+
+def lstm_sequence_x(s, wx, wh, b, h0, c0, done, masked_steps, img):
+    """lstm_sequence with the x-side product inside the step: s [N,T,E,KX], wx [N,KX,4H]."""
+    N, T, E, KX = s.shape
+    h, c = h0, c0
+    hs = []
+    for t in range(T):
+        keep = (1.0 - done[t]).view(1, E, 1)
+        z = torch.bmm(s[:, t], wx) + torch.bmm(h * keep, wh)
         h, c = lstm_cell(z, b, c, done[t])
         hs.append(h)
     return torch.stack(hs, dim=1)

@@ -585,3 +585,137 @@ def test_ops_reject_cpu_tensors():
     nbr, _ = ops.neighbor_table(_masks('line'), 'cuda')
     with pytest.raises(_lib.NmarlError):
         ops.nbr_gather(torch.zeros(8, 2, 4), nbr)
+
+
+def _xside_case(N, E, KX, A, m_max, seed, addends):
+    H = 64
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    d = dict(h=r(N, E, H) * 0.7, c=r(N, E, H), done=(torch.rand(E, generator=g) < 0.3).float(),
+             x=None if KX == 0 else r(N, E, KX) * 0.5,
+             # asymmetric weights: a swapped row / column / chunk mapping of the image cannot pass
+             wx=None if KX == 0 else r(N, KX, 4 * H) * 0.15 + torch.arange(4 * H).view(1, 1, -1) * 1e-3 + torch.arange(KX).view(1, -1, 1) * 1e-3,
+             wh=r(N, H, 4 * H) * 0.2 + torch.arange(4 * H).view(1, 1, -1) * 1e-3, b=r(N, 4 * H) * 0.1,
+             z1=r(N, E, 4 * H) if addends >= 1 else None, z2=r(N, E, 4 * H) if addends >= 2 else None,
+             pi_w=r(N, H, A) * 0.5, pi_b=r(N, A) * 0.3, v_w=r(N, H + m_max * A, 1), v_b=r(N, 1))
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + 1]
+        idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    d['idx'] = idx
+    return d
+
+
+@pytest.mark.parametrize('N,E', [(8, 4096), (8, 1), (25, 130), (3, 127), (8, 257)])
+@pytest.mark.parametrize('KX,addends', [(128, 0), (64, 0), (192, 1), (0, 1), (32, 2), (256, 0)])
+def test_lstm_step_x_whole_preactivation_on_mfma(N, E, KX, addends):
+    """nmarl_lstm_step_x: z = [x | h keep] @ [Wx; Wh] + b (+ addends) -> cell, vs the float64 restatement
+    (agents/utils.py:102-113): every supported input width, ragged row counts, x as a column block of a wider buffer,
+    strided sequence slots, gates output, in-place state."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    d = _xside_case(N, E, KX, 4, 2, N * 1000 + E + KX, addends)
+    f64 = lambda t: None if t is None else t.double()                                    # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
+    hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
+    gr = torch.empty(N, E, 4 * H, dtype=torch.float64)
+    ops_ref.lstm_step_fused(f64(d['h']), f64(d['wh']), f64(d['b']), f64(d['z1']), f64(d['z2']), f64(d['c']), f64(d['done']),
+                            gr, cr, hr, xs=(f64(d['x']), f64(d['wx']), None))
+    img = ops.lstm_wimage(cu(d['wx']), cu(d['wh']))
+    assert img.shape == (N, (KX + 64) * 320)
+    xg = None
+    if KX:
+        wide = torch.zeros(N, E, KX + 64, device='cuda')          # x = columns [32, 32 + KX) of a wider buffer
+        xg = wide[:, :, 32:32 + KX]
+        xg.copy_(d['x'])
+    Hbuf = torch.zeros(N, 3, E, H, device='cuda'); Cbuf = torch.zeros(N, 3, E, H, device='cuda')
+    Gbuf = torch.zeros(N, 3, E, 4 * H, device='cuda')
+    Hbuf[:, 0].copy_(d['h']); Cbuf[:, 0].copy_(d['c'])
+    ops.lstm_step_fused(Hbuf[:, 0], None, cu(d['b']), cu(d['z1']), cu(d['z2']), Cbuf[:, 0], cu(d['done']), Gbuf[:, 1],
+                        Cbuf[:, 1], Hbuf[:, 1], xs=(xg, None, img))
+    tol = dict(rtol=3e-5, atol=5e-6)
+    torch.testing.assert_close(Hbuf[:, 1].cpu().double(), hr, **tol)
+    torch.testing.assert_close(Cbuf[:, 1].cpu().double(), cr, **tol)
+    torch.testing.assert_close(Gbuf[:, 1].cpu().double(), gr, **tol)
+    assert torch.all(Hbuf[:, 2] == 0) and torch.all(Gbuf[:, 2] == 0) and torch.all(Gbuf[:, 0] == 0)
+    hg, cg = cu(d['h']), cu(d['c'])                                # in place, no gates (rollout)
+    ops.lstm_step_fused(hg, None, cu(d['b']), cu(d['z1']), cu(d['z2']), cg, cu(d['done']), None, cg, hg, xs=(xg, None, img))
+    torch.testing.assert_close(hg.cpu().double(), hr, **tol)
+    torch.testing.assert_close(cg.cpu().double(), cr, **tol)
+
+
+@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (3, 127, 8, 2), (8, 1, 4, 2)])
+@pytest.mark.parametrize('KX,addends', [(128, 0), (64, 1), (192, 0)])
+@pytest.mark.parametrize('mode', [1, 2])
+def test_lstm_step_x_heads(N, E, A, m_max, KX, addends, mode):
+    """The head epilogues on top of the x-side step: forward('p') + draw (kind 1), forward('v') (kind 2) and both in
+    one kernel (kind 3, quirk Q1: the value re-step re-uses the x-side part and the resident Wh chunks)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    d = _xside_case(N, E, KX, A, m_max, N * 77 + E + A + KX, addends)
+    f64 = lambda t: None if t is None else t.double()                                    # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
+    draw = dict(mode=mode, seed=5, env_id_base=40, step=3)
+    img = ops.lstm_wimage(cu(d['wx']), cu(d['wh']))
+    xs_g = (cu(d['x']), None, img)
+    xs_r = (f64(d['x']), f64(d['wx']), None)
+    # oracle: policy half (float64), draw from the KERNEL's probabilities, then the value half
+    hr, cr = d['h'].double(), d['c'].double()
+    pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.lstm_step_policy(hr, f64(d['wh']), f64(d['b']), f64(d['z1']), f64(d['z2']), cr, f64(d['done']), cr, hr,
+                             f64(d['pi_w']), f64(d['pi_b']), pir, actr, xs=xs_r, **draw)
+    # kind 3
+    hg, cg = cu(d['h']), cu(d['c'])
+    pig, actg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda')
+    vg = torch.zeros(N, E, device='cuda')
+    ops.lstm_step_policy_value(hg, None, cu(d['b']), cu(d['z1']), cu(d['z2']), cg, cu(d['done']), cu(d['pi_w']), cu(d['pi_b']),
+                               pig, actg, cu(d['v_w']), cu(d['v_b']), cu(d['idx']), A, vg, xs=xs_g, **draw)
+    tol = dict(rtol=3e-5, atol=5e-6)
+    torch.testing.assert_close(hg.cpu().double(), hr, **tol)
+    torch.testing.assert_close(cg.cpu().double(), cr, **tol)
+    torch.testing.assert_close(pig.cpu().double(), pir, **tol)
+    act_chk = torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.sample_actions(pig.cpu(), act_chk, **draw)
+    assert torch.equal(actg.cpu(), act_chk)
+    vr = torch.zeros(N, E, dtype=torch.float64)
+    ops_ref.lstm_step_value(hr, f64(d['wh']), f64(d['b']), f64(d['z1']), f64(d['z2']), cr, f64(d['done']), torch.empty_like(cr),
+                            torch.empty_like(hr), f64(d['v_w']), f64(d['v_b']), act_chk, d['idx'], A, vr, xs=xs_r)
+    torch.testing.assert_close(vg.cpu().double(), vr, rtol=1e-4, atol=3e-5)
+    # kinds 1 and 2 as separate launches give the same numbers
+    h1, c1 = cu(d['h']), cu(d['c'])
+    pi1, act1 = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda')
+    ops.lstm_step_policy(h1, None, cu(d['b']), cu(d['z1']), cu(d['z2']), c1, cu(d['done']), c1, h1, cu(d['pi_w']), cu(d['pi_b']),
+                         pi1, act1, xs=xs_g, **draw)
+    assert torch.equal(act1, actg)
+    torch.testing.assert_close(pi1, pig, rtol=1e-6, atol=1e-7)
+    h2, c2, v2 = torch.zeros_like(h1), torch.zeros_like(c1), torch.zeros(N, E, device='cuda')
+    ops.lstm_step_value(h1, None, cu(d['b']), cu(d['z1']), cu(d['z2']), c1, cu(d['done']), c2, h2, cu(d['v_w']), cu(d['v_b']),
+                        act1, cu(d['idx']), A, v2, xs=xs_g)
+    torch.testing.assert_close(v2, vg, rtol=1e-5, atol=1e-6)
+
+
+def test_lstm_sequence_x_fwd_bwd():
+    """The update's recurrence with the x-side product inside the step (ops.lstm_sequence_x) vs plain autograd over the
+    restatement: outputs and all gradients (s, wx, wh, b, h0, c0)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    N, T, E, KX, H = 3, 5, 130, 128, 64
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    s, wx, wh, b = r(N, T, E, KX) * 0.5, r(N, KX, 4 * H) * 0.15, r(N, H, 4 * H) * 0.2, r(N, 4 * H) * 0.1
+    h0, c0 = r(N, E, H) * 0.5, r(N, E, H) * 0.5
+    done = torch.zeros(T, E)
+    done[0] = (torch.rand(E, generator=g) < 0.4).float()
+    dH = r(N, T, E, H)
+    ref_in = [t.double().requires_grad_(True) for t in (s, wx, wh, b, h0, c0)]
+    out_r = ops_ref.lstm_sequence_x(*ref_in, done.double(), (0,), None)
+    (out_r * dH.double()).sum().backward()
+    gpu_in = [t.cuda().requires_grad_(True) for t in (s, wx, wh, b, h0, c0)]
+    img = ops.lstm_wimage(gpu_in[1].detach(), gpu_in[2].detach())
+    out_g = ops.lstm_sequence_x(*gpu_in, done.cuda(), (0,), img)
+    (out_g * dH.cuda()).sum().backward()
+    torch.testing.assert_close(out_g.detach().cpu().double(), out_r.detach(), rtol=1e-4, atol=1e-5)
+    for name, a, bb in zip('s wx wh b h0 c0'.split(), gpu_in, ref_in):
+        torch.testing.assert_close(a.grad.cpu().double(), bb.grad, rtol=2e-3, atol=2e-4, msg=lambda m, n=name: '%s: %s' % (n, m))

@@ -1,28 +1,69 @@
-"""Time nmarl_lstm_step_fused at the bench shape (N=8, E=4096, H=64); NMARL_FUSED_VARIANT=1|2 picks the kernel."""
-import os, sys
+"""Time the fused LSTM step kernels at the bench shape (N = 8, E = 4096, H = 64):
+  * recurrent-only step (nmarl_lstm_step_fused: addend from a separate s @ Wx library GEMM, timed beside it),
+  * the x-side step (nmarl_lstm_step_x: K = KX + 64 inside), plain / with gates / with the policy+value heads (kind 3).
+    python tools/time_fused.py [E] [KX]
+"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-from deeprl_network_amd import ops
-N, E, H = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 4096, 64
+import torch  # noqa: E402
+
+from deeprl_network_amd import ops  # noqa: E402
+
+N, H, A = 8, 64, 4
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+KX = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 g = torch.Generator().manual_seed(0)
-h = torch.randn(N, E, H, generator=g).cuda(); c = torch.randn(N, E, H, generator=g).cuda()
-z1 = torch.randn(N, E, 4 * H, generator=g).cuda(); wh = (torch.randn(N, H, 4 * H, generator=g) * 0.2).cuda()
-b = torch.zeros(N, 4 * H).cuda(); done = torch.zeros(E).cuda()
+r = lambda *s: torch.randn(*s, generator=g).cuda()          # noqa: E731
+h, c, z1 = r(N, E, H), r(N, E, H), r(N, E, 4 * H)
+x, wx, wh = r(N, E, KX) * 0.5, r(N, KX, 4 * H) * 0.15, r(N, H, 4 * H) * 0.2
+b, done = torch.zeros(N, 4 * H).cuda(), torch.zeros(E).cuda()
+pi_w, pi_b, v_w, v_b = r(N, H, A), r(N, A), r(N, H + 2 * A, 1), r(N, 1)
+nbr = torch.tensor([[max(i - 1, 0), min(i + 1, N - 1)] for i in range(N)], dtype=torch.int32).cuda()
 co, ho = torch.empty_like(c), torch.empty_like(h)
 gates = torch.empty(N, E, 4 * H, device='cuda')
-for with_gates in (False, True):
-    f = lambda: ops.lstm_step_fused(h, wh, b, z1, None, c, done, gates if with_gates else None, co, ho)
-    for _ in range(5): f()
-    gr = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s): f()
+pi, act, v = torch.empty(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.empty(N, E, device='cuda')
+img = ops.lstm_wimage(wx, wh)
+zbuf = torch.empty(N, E, 4 * H, device='cuda')
+
+
+def timed(name, f, n=20, reps=10):
+    for _ in range(3):
+        f()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        f()
     torch.cuda.current_stream().wait_stream(s)
+    gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
-        for _ in range(20): f()
-    gr.replay(); torch.cuda.synchronize()
+        for _ in range(n):
+            f()
+    gr.replay()
+    torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
-    for _ in range(10): gr.replay()
-    t1.record(); torch.cuda.synchronize()
-    print('variant %s gates=%s: %.2f us per call' % (os.environ.get('NMARL_FUSED_VARIANT', '2'), with_gates, t0.elapsed_time(t1) * 1e3 / 200))
+    for _ in range(reps):
+        gr.replay()
+    t1.record()
+    torch.cuda.synchronize()
+    us = t0.elapsed_time(t1) * 1e3 / (n * reps)
+    print('%-58s %7.2f us' % (name, us))
+    return us
+
+
+flops_x = 2.0 * N * E * (KX + H) * 4 * H
+print('N=%d E=%d KX=%d: x-side step = %.2f GFLOP -> %.1f us at the 157.3 TFLOP/s fp32 matrix peak' % (N, E, KX, flops_x / 1e9, flops_x / 157.3e6))
+timed('library GEMM s @ Wx', lambda: torch.bmm(x, wx, out=zbuf))
+timed('recurrent-only step (addend given)', lambda: ops.lstm_step_fused(h, wh, b, z1, None, c, done, None, co, ho))
+timed('recurrent-only step + gates', lambda: ops.lstm_step_fused(h, wh, b, z1, None, c, done, gates, co, ho))
+timed('recurrent-only policy+value (kind 3)', lambda: ops.lstm_step_policy_value(h, wh, b, z1, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2))
+u = timed('x-side step', lambda: ops.lstm_step_fused(h, None, b, None, None, c, done, None, co, ho, xs=(x, None, img)))
+print('    -> %.1f TFLOP/s = %.2f of the fp32 matrix peak' % (flops_x / u / 1e6, flops_x / u / 157.3e6))
+timed('x-side step + gates', lambda: ops.lstm_step_fused(h, None, b, None, None, c, done, gates, co, ho, xs=(x, None, img)))
+u3 = timed('x-side policy+value (kind 3)', lambda: ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img)))
+f3 = flops_x + 2.0 * N * E * H * 4 * H
+print('    -> %.1f TFLOP/s = %.2f of the fp32 matrix peak (incl. the value re-step)' % (f3 / u3 / 1e6, f3 / u3 / 157.3e6))
+timed('weight image rebuild', lambda: ops.lstm_wimage(wx, wh, out=img))

@@ -181,6 +181,25 @@ class IA2C:
         # steps whose pre-step done flag may be non-zero (None = any, the reference API); the batched trainer
         # sets (0,) because episodes start only at batch boundaries (quirk Q4)
         self.masked_steps = None
+        self.save_acts = False
+
+    def enable_saved_activations(self):
+        """Batched engine, uncoupled nets: the rollout's policy steps ARE the forward pass of the update (on-policy
+        A2C: same weights, same inputs, states_bw = the state the rollout started from), so the step kernel saves the
+        LSTM inputs, gates and state sequences and update() runs the backward only.  The critic's neighbour-action
+        term is added for all T lock-steps by one launch at update time.  Returns False if the policy cannot do it."""
+        p = self.policy
+        if not p.can_save_acts:
+            return False
+        N, E, T, H, d = self.n_agent, self.E, self.n_step, self.n_lstm, self.device
+        KX = p.params[p.k_wx].shape[1]
+        self.S_buf = torch.zeros(N, T, E, KX, dtype=F32, device=d)
+        self.G_buf = torch.zeros(N, T, E, 4 * H, dtype=F32, device=d)
+        self.H_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
+        self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
+        self.buf_vn = torch.zeros(N, T, E, dtype=F32, device=d)          # agent-major values (critic's h part)
+        self.save_acts = True
+        return True
 
     # ------------------------------------------------------------------ batched engine
     def reset_states(self, mask=None):
@@ -226,8 +245,19 @@ class IA2C:
         p = self.policy
         if t == 0:
             p.refresh_wimage()                             # weights change between batches only (inside the hipGraph: one
-        enc = p.encode(self.buf_x[t], self.fp)             # small node); enc is shared by policy step and value re-step (Q1)
+            if self.save_acts:                             # small node)
+                self.H_all[:, 0].copy_(self.h_fw)
+                self.C_all[:, 0].copy_(self.c_fw)
+        # enc is shared by the policy step and the value re-step (Q1)
+        enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+        if self.save_acts:
+            # the policy step reads slot t of the state sequences and writes slot t + 1, gates into G[:, t]; the value
+            # (critic's h part) goes to the agent-major buffer, its neighbour-action term is added in update()
+            p.step_policy_value(enc, self.H_all[:, t], self.C_all[:, t], done, self.buf_fp[t + 1], self.buf_act[t],
+                                self.buf_vn[:, t], h_out=self.H_all[:, t + 1], c_out=self.C_all[:, t + 1],
+                                gates=self.G_buf[:, t], defer_action_term=True, **draw)
+            return self.buf_act[t]
         if p.fused_pv:
             p.step_policy_value(enc, self.h_fw, self.c_fw, done, self.buf_fp[t + 1], self.buf_act[t], self.buf_v[t], **draw)
             return self.buf_act[t]
@@ -263,6 +293,12 @@ class IA2C:
         assert self.t == self.n_step
         p = self.policy
         enc = p.encode(self.buf_x[self.n_step], self.fp)
+        if self.save_acts:                                  # from slot T of the sequences into the persistent state
+            T = self.n_step
+            p.step_policy_value(enc, self.H_all[:, T], self.C_all[:, T], done, self._pi_boot, action_scratch, self._v_boot,
+                                h_out=self.h_fw, c_out=self.c_fw, mode=mode, u=u, seed=seed, env_id_base=env_id_base,
+                                step=step, step_dev=step_dev)
+            return self._v_boot
         if p.fused_pv:
             p.step_policy_value(enc, self.h_fw, self.c_fw, done, self._pi_boot, action_scratch, self._v_boot, mode=mode, u=u,
                                 seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
@@ -309,14 +345,26 @@ class IA2C:
         # total_step keeps its meaning for any number of replicas and ranks
         cur_lr = self.lr_scheduler.get(self.n_step)
         alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
+        T = self.n_step
+        if self.save_acts:
+            # the critic's neighbour-action term of all T lock-steps in one launch (policies.py:59-77), then the values
+            # in the [T,N,E] order the return scan reads
+            with torch.no_grad():
+                vn = self.buf_vn.view(self.n_agent, T * self.E)
+                ops.nbr_action_value(self.buf_act.view(T * self.E, self.n_agent), self.policy.nbr_idx,
+                                     self.policy.params['v_w'][:, self.n_lstm:], self.n_a, out=vn, accumulate=True)
+                self.buf_v.copy_(self.buf_vn.permute(1, 0, 2))
         ops.nstep_return(self.buf_r, self.buf_v, self.buf_done_post, R_end.contiguous(), self.gamma, alpha,
                          self.dist_dev, self.R, self.Adv)
         ps = self.policy.params
         ps.grad.zero_()
-        T = self.n_step
         FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
-        Hs = self.policy.unroll(self.buf_x[:T], FP, self.buf_done_pre, self.h_bw, self.c_bw,
-                                masked_steps=self.masked_steps)
+        if self.save_acts:
+            Hs = self.policy.unroll_saved(self.buf_x[:T], FP, self.S_buf, self.G_buf, self.H_all, self.C_all,
+                                          self.buf_done_pre, masked_steps=self.masked_steps)
+        else:
+            Hs = self.policy.unroll(self.buf_x[:T], FP, self.buf_done_pre, self.h_bw, self.c_bw,
+                                    masked_steps=self.masked_steps)
         loss = self._loss(Hs)
         loss.backward()
         if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)

@@ -302,11 +302,14 @@ class BatchedPolicy:
         return torch.baddbmm(v, na_onehot, p['v_w'][:, H:]).squeeze(-1)
 
     # -- rollout (no autograd): encode once per lock-step, then one recurrent step per call
-    def encode(self, x, fp_prev):
+    def encode(self, x, fp_prev, out=None):
         """The h-independent part of the LSTM input for one lock-step: x [E,N,n_obs] env-major slab
         (any view with that shape), fp_prev [N,E,A] previous-step policies.  Both the policy step and
-        the value re-step (quirk Q1) of a lock-step share it."""
+        the value re-step (quirk Q1) of a lock-step share it.  `out` (x-side mode only): the slot of the saved
+        activations [N,E,KX] the LSTM input is written to."""
         with torch.no_grad():
+            if out is not None:
+                return self._enc_infer(x.transpose(0, 1), fp_prev, out=out)
             return self._enc_infer(x.transpose(0, 1), fp_prev)
 
     def step(self, enc, h, c, done, h_out, c_out, done_is_zero=False):
@@ -352,15 +355,34 @@ class BatchedPolicy:
         cross-agent term (the value re-step of a coupled net needs the other agents' new h)."""
         return self.fused_heads and not self.coupled
 
-    def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, **draw):
+    def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, h_out=None, c_out=None, gates=None,
+                          defer_action_term=False, **draw):
         """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) for uncoupled nets:
-        advances (h, c) in place by the policy step; the value comes from the re-stepped copy (quirk Q1)."""
+        advances (h, c) by the policy step -- in place, or into (h_out, c_out) with the gates saved for the update --;
+        the value comes from the re-stepped copy (quirk Q1)."""
         with torch.no_grad():
             z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
             ops.lstm_step_policy_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, p['pi_w'], p['pi_b'], pi_out, act_out,
-                                       p['v_w'], p['v_b'], self.nbr_idx, self.n_a, v_out, xs=xs, **draw)
+                                       p['v_w'], p['v_b'], self.nbr_idx, self.n_a, v_out, xs=xs, h_out=h_out, c_out=c_out,
+                                       gates=gates, defer_action_term=defer_action_term, **draw)
         return act_out
+
+    @property
+    def can_save_acts(self):
+        """The rollout can hand its activations (LSTM inputs, gates, state sequences) to the update, which then needs
+        no forward pass: uncoupled nets whose lock-step is the one fused x-side kernel."""
+        return (not self.coupled) and self.xside and self.fused_pv
+
+    def unroll_saved(self, X, FP, S, G, Hall, Call, done, masked_steps=None):
+        """`unroll` for a batch whose forward pass the rollout already did with the CURRENT weights: S [N,T,E,KX] the
+        LSTM inputs, G the gates, Hall / Call [N,T+1,E,H] the state sequences it saved.  Sets up the backward only."""
+        T, E = done.shape
+        Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)
+        s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
+        Hs = ops.lstm_sequence_saved(s.view(self.N, T, E, s.shape[-1]), self.params[self.k_wx], self.params[self.k_wh],
+                                     self.params[self.k_b], G, Hall, Call, done, masked_steps)
+        return Hs.reshape(self.N, T * E, self.n_h)
 
     def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):
         """forward('v') of one lock-step (policies.py:124-133): the LSTM re-step and the critic on
@@ -468,15 +490,15 @@ class LstmPolicy(BatchedPolicy):
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
-    def _enc(self, xv, fp):
+    def _enc(self, xv, fp, saved=None):
         """The LSTM input s (x-side mode), else the x-side pre-activation s @ Wx [N,rows,4H] (bias is added in the
-        cell kernel)."""
+        cell kernel).  saved: s as the rollout computed it (x-side mode) -- only the backward is set up."""
         p = self.params
-        s = ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU)
+        s = ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU, saved=saved)
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
-    def _enc_infer(self, xv, fp):
-        s = self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU)
+    def _enc_infer(self, xv, fp, out=None):
+        s = self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU, out=out)
         return s if self.xside else torch.bmm(s, self.params['lstm_wx'])
 
     def _recur_in(self, enc, h):
@@ -496,23 +518,23 @@ class FPPolicy(LstmPolicy):
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
-    def _enc(self, xv, fp):
+    def _enc(self, xv, fp, saved=None):
         p = self.params
         nf = self.n_fc
         pf = ops.nbr_gather(fp, self.nbr_idx)
         # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place
-        s = ops.fc_concat([(xv, p['fcs_w'], p['fcs_b']), (pf, p['fcp_w'], p['fcp_b'])], ops.BIAS_RELU)
+        s = ops.fc_concat([(xv, p['fcs_w'], p['fcs_b']), (pf, p['fcp_w'], p['fcp_b'])], ops.BIAS_RELU, saved=saved)
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
-    def _enc_infer(self, xv, fp):
+    def _enc_infer(self, xv, fp, out=None):
         p = self.params
         nf = self.n_fc
         if self._enc_one_launch(xv, nf):
             # [hx | hp] (policies.py:181) by ONE kernel: both layers, the fingerprint gather folded into the second
             s = ops.fc_fwd_multi([(xv, p['fcs_w'], p['fcs_b'], None), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)],
-                                 ops.BIAS_RELU)
+                                 ops.BIAS_RELU, out=out)
         else:
-            s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device)
+            s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device) if out is None else out
             self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
         return s if self.xside else torch.bmm(s, p['lstm_wx'])                          # else ONE K = 2 nf GEMM
@@ -636,13 +658,13 @@ class ConsensusPolicy(LstmPolicy):
     def _own(self, xv):
         return xv[:, :, :self.n_feat]        # the consensus net sees the agent's own features only
 
-    def _enc(self, xv, fp):
+    def _enc(self, xv, fp, saved=None):
         p = self.params
-        s = ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU)
+        s = ops.fc_concat([(self._own(xv), p['fc_w'], p['fc_b'])], ops.BIAS_RELU, saved=saved)
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
-    def _enc_infer(self, xv, fp):
-        s = self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU)
+    def _enc_infer(self, xv, fp, out=None):
+        s = self._fc_infer(self._own(xv), 'fc_w', 'fc_b', ops.BIAS_RELU, out=out)
         return s if self.xside else torch.bmm(s, self.params['lstm_wx'])
 
     def consensus_update(self):

@@ -257,11 +257,14 @@ def lstm_step_value(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, v_w, 
 
 
 def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
-                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
-    """forward('p') AND forward('v') of one lock-step (quirk Q1) for nets without a cross-agent recurrence, the state
-    (h, c) [N,E,64] advanced IN PLACE by the policy step only: one MFMA kernel (policy step + pi + draw, then the value
-    re-step from the new state with the same addend and the critic on h'') + the critic's neighbour-action term, which
-    needs all agents' draws, added by one small launch.  v_out [N,E] contiguous."""
+                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None, h_out=None,
+                           c_out=None, gates=None, defer_action_term=False):
+    """forward('p') AND forward('v') of one lock-step (quirk Q1) for nets without a cross-agent recurrence: one MFMA
+    kernel (policy step + pi + draw, then the value re-step from the new state with the same addend and the critic on
+    h'') + the critic's neighbour-action term, which needs all agents' draws, added by one small launch (unless
+    `defer_action_term`: the caller adds it later for many lock-steps at once).  The state (h, c) [N,E,64] is advanced
+    by the policy step only -- in place, or into (h_out, c_out) (slots of the update's sequence buffers); `gates`
+    [N,E,4H] receives the policy step's gates (x-side mode only).  v_out [N,E] with unit column stride."""
     N, E, H = h.shape
     hd = _lib.Head()
     hd.kind, hd.A, hd.mode = 3, pi_w.shape[2], mode
@@ -272,11 +275,20 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     hd.seed, hd.env_id_base, hd.step, hd.step_dev = seed, env_id_base, int(step), ptr(step_dev, torch.int64)
     hd.w2, hd.w2_sn = _head_param(v_w, 'lstm_step_policy_value')
     hd.b2, hd.b2_sn = _bias(v_b)
-    if not v_out.is_contiguous() or v_out.shape != (N, E):
-        raise _lib.NmarlError('lstm_step_policy_value: v_out must be a contiguous [N,E] tensor')
-    hd.v_out, hd.v_sn = ptr(v_out, F32), E
-    _fused_head(h, wh, bias, zadd1, zadd2, c, done, c, h, hd, 'nmarl_lstm_step_fused_head[pv]', xs)
-    nbr_action_value(act_out, nbr_idx, v_w[:, H:], n_a, out=v_out, accumulate=True)
+    if v_out.shape != (N, E) or v_out.stride(1) != 1 or (N > 1 and v_out.stride(0) < E):
+        raise _lib.NmarlError('lstm_step_policy_value: v_out must be [N,E] with unit column stride')
+    hd.v_out, hd.v_sn = ptr(v_out, F32, strided=True), v_out.stride(0)
+    h_out, c_out = (h if h_out is None else h_out), (c if c_out is None else c_out)
+    if xs is not None:
+        _step_x(h, bias, zadd1, zadd2, c, done, gates, c_out, h_out, xs, hd, 'nmarl_lstm_step_x[pv]')
+    else:
+        if gates is not None:
+            raise _lib.NmarlError('lstm_step_policy_value: gates output needs the x-side mode')
+        _fused_head(h, wh, bias, zadd1, zadd2, c, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[pv]')
+    if not defer_action_term:
+        if not v_out.is_contiguous():
+            raise _lib.NmarlError('lstm_step_policy_value: the neighbour-action add needs a contiguous v_out')
+        nbr_action_value(act_out, nbr_idx, v_w[:, H:], n_a, out=v_out, accumulate=True)
     return pi_out, act_out, v_out
 
 
@@ -395,10 +407,35 @@ class _FcConcat(torch.autograd.Function):
         return tuple(grads)
 
 
-def fc_concat(parts, act):
+class _FcConcatSaved(torch.autograd.Function):
+    """_FcConcat whose output S the rollout already computed (same weights, same inputs): no forward work."""
+
+    @staticmethod
+    def forward(ctx, act, S, *args):
+        xs = args[0::3]
+        ctx.act = act
+        ctx.save_for_backward(S, *xs)
+        return S.view_as(S)
+
+    @staticmethod
+    def backward(ctx, dS):
+        S, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        if dS.stride(2) != 1:
+            dS = dS.contiguous()
+        grads = [None, None]
+        for i, x in enumerate(xs):
+            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act)
+            grads += [None, dw, db]
+        return tuple(grads)
+
+
+def fc_concat(parts, act, saved=None):
     """parts: [(x_i [N,rows,F_i], w_i [N,F_i,64], b_i [N,64]), ...] with data inputs -> [N,rows,64*len(parts)]
-    (differentiable w.r.t. w_i, b_i).  Inputs wider than 64 or layers not 64 wide: plain batched GEMMs."""
+    (differentiable w.r.t. w_i, b_i).  Inputs wider than 64 or layers not 64 wide: plain batched GEMMs.
+    saved: the output as the rollout computed it with the current weights -- only the backward is set up."""
     if all(fc_supported(x, w) and not x.requires_grad for x, w, _ in parts):
+        if saved is not None:
+            return _FcConcatSaved.apply(act, saved, *[t for part in parts for t in part])
         return _FcConcat.apply(act, *[t for part in parts for t in part])
     f = {BIAS_NONE: lambda t: t, BIAS_RELU: torch.relu, BIAS_TANH: torch.tanh}[act]
     ys = [f(torch.baddbmm(b.unsqueeze(1), x, w)) for x, w, b in parts]
@@ -698,36 +735,72 @@ class _LstmSequenceX(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dHs):
         G, Hall, Call, s, wx, wh, done = ctx.saved_tensors
-        N, T, E, H4 = G.shape
-        H = H4 // 4
-        dHs = dHs.contiguous()
-        dZ = torch.empty_like(G)
-        keep = (1.0 - done)
-        dh_rec = None
-        dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
-        dc_next = torch.empty_like(dc)
-        wh_t = wh.transpose(1, 2)
-        for t in range(T - 1, -1, -1):
-            cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
-            dc, dc_next = dc_next, dc
-            dh_rec = torch.bmm(dZ[:, t], wh_t)
-            if t in ctx.masked:
-                dh_rec = dh_rec * keep[t].view(1, E, 1)
-        dZf = dZ.view(N, T * E, H4)
-        if len(ctx.masked) == T:
-            Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
-        else:
-            Hprev = Hall[:, :T].clone()
-            for t in ctx.masked:
-                Hprev[:, t].mul_(keep[t].view(1, E, 1))
-            Hprev = Hprev.view(N, T * E, H)
-        dwh = wgrad(Hprev, dZf)
-        db = dZf.sum(dim=1)
-        KX = s.shape[3]
-        sf = s.reshape(N, T * E, KX)
-        ds = torch.bmm(dZf, wx.transpose(1, 2)).view(N, T, E, KX) if ctx.needs_input_grad[0] else None
-        dwx = wgrad(sf, dZf)
+        ds, dwx, dwh, db, dh_rec, dc = _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, ctx.masked, dHs,
+                                                            ctx.needs_input_grad[0])
         return ds, dwx, dwh, db, dh_rec, dc, None, None, None
+
+
+def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds):
+    """BPTT of z_t = s_t @ wx + (h_{t-1} keep_t) @ wh, (h_t, c_t) = cell(z_t + b, c_{t-1}, done_t) from the saved gates
+    G [N,T,E,4H] and state sequences Hall / Call [N,T+1,E,H]: the reverse loop of (cell_bwd, dgrad GEMM vs wh), then
+    ds = dZ @ wx^T, dwx = s^T dZ, dwh = (h keep)^T dZ, db = sum dZ over all T*E rows."""
+    N, T, E, H4 = G.shape
+    H = H4 // 4
+    dHs = dHs.contiguous()
+    dZ = torch.empty_like(G)
+    keep = (1.0 - done)
+    dh_rec = None
+    dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
+    dc_next = torch.empty_like(dc)
+    wh_t = wh.transpose(1, 2)
+    for t in range(T - 1, -1, -1):
+        cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
+        dc, dc_next = dc_next, dc
+        dh_rec = torch.bmm(dZ[:, t], wh_t)
+        if t in masked:
+            dh_rec = dh_rec * keep[t].view(1, E, 1)
+    dZf = dZ.view(N, T * E, H4)
+    if len(masked) == T:
+        Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+    else:
+        Hprev = Hall[:, :T].clone()
+        for t in masked:
+            Hprev[:, t].mul_(keep[t].view(1, E, 1))
+        Hprev = Hprev.view(N, T * E, H)
+    dwh = wgrad(Hprev, dZf)
+    db = dZf.sum(dim=1)
+    KX = s.shape[3]
+    sf = s.reshape(N, T * E, KX)
+    ds = torch.bmm(dZf, wx.transpose(1, 2)).view(N, T, E, KX) if need_ds else None
+    dwx = wgrad(sf, dZf)
+    return ds, dwx, dwh, db, dh_rec, dc
+
+
+class _LstmSequenceSaved(torch.autograd.Function):
+    """The recurrence of the update WITHOUT a forward pass: the rollout already evaluated exactly this sequence with
+    exactly these weights (on-policy A2C: one update per batch, states_bw = the states the rollout started from), and
+    its step kernel saved the gates and the state sequences.  forward = hand out Hall[:, 1:]; backward = the BPTT of
+    _LstmSequenceX.  The reference recomputes the forward inside its training graph (policies.py:99-100, 330-331):
+    same weights, same inputs, same function -- the values are those of the rollout."""
+
+    @staticmethod
+    def forward(ctx, s, wx, wh, b, G, Hall, Call, done, masked_steps):
+        T = G.shape[1]
+        ctx.save_for_backward(G, Hall, Call, s, wx, wh, done)
+        ctx.masked = set(range(T)) if masked_steps is None else set(masked_steps)
+        return Hall[:, 1:]
+
+    @staticmethod
+    def backward(ctx, dHs):
+        G, Hall, Call, s, wx, wh, done = ctx.saved_tensors
+        ds, dwx, dwh, db, _, _ = _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, ctx.masked, dHs,
+                                                      ctx.needs_input_grad[0])
+        return ds, dwx, dwh, db, None, None, None, None, None
+
+
+def lstm_sequence_saved(s, wx, wh, b, G, Hall, Call, done, masked_steps):
+    """s [N,T,E,KX] (autograd-connected encoders' output), G / Hall / Call saved by the rollout -> Hs [N,T,E,H]."""
+    return _LstmSequenceSaved.apply(s, wx, wh, b, G, Hall, Call, done, masked_steps)
 
 
 def lstm_sequence_x(s, wx, wh, b, h0, c0, done, masked_steps, img):

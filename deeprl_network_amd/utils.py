@@ -278,8 +278,10 @@ class BatchedTrainer:
     """
 
     def __init__(self, env, model, global_counter=None, summary_writer=None, output_path=None,
-                 use_graph=True, rank=0, world_size=1):
+                 use_graph=True, rank=0, world_size=1, save_activations=True):
         self.env, self.model = env, model
+        # uncoupled nets: the rollout's policy steps double as the forward pass of the update (models.py)
+        self.saved_acts = bool(save_activations) and model.enable_saved_activations()
         self.E, self.N = env.E, env.n_agent
         self.n_step = model.n_step
         assert env.T % self.n_step == 0

@@ -184,7 +184,7 @@ def fc_bwd(x, y, dy, act):
     return torch.bmm(x.transpose(1, 2), g), g.sum(1)
 
 
-def fc_concat(parts, act):
+def fc_concat(parts, act, saved=None):
     """tf.concat of per-input fc layers (policies.py:176-181, agents/utils.py:186-199), plain autograd."""
     ys = [_act(torch.baddbmm(b.unsqueeze(1), x, w), act) for x, w, b in parts]
     return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
@@ -212,13 +212,23 @@ def nbr_action_value(action, nbr_idx, w_a, n_a, out=None, accumulate=False):
 
 
 def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
-                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
+                           v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None, h_out=None,
+                           c_out=None, gates=None, defer_action_term=False):
     """Trainer._get_policy + _get_value of one lock-step (utils.py:129-149): forward('p') advances the state, forward('v')
     re-steps a COPY of it (policies.py:119-133, quirk Q1)."""
-    lstm_step_policy(h, wh, bias, zadd1, zadd2, c, done, c, h, pi_w, pi_b, pi_out, act_out, mode, u=u, seed=seed,
+    h_out, c_out = (h if h_out is None else h_out), (c if c_out is None else c_out)
+    if gates is not None:
+        lstm_step_fused(h, wh, bias, zadd1, zadd2, c, done, gates, torch.empty_like(c), torch.empty_like(h), xs=xs)
+    lstm_step_policy(h, wh, bias, zadd1, zadd2, c, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode, u=u, seed=seed,
                      env_id_base=env_id_base, step=step, step_dev=step_dev, xs=xs)
-    lstm_step_value(h, wh, bias, zadd1, zadd2, c, done, torch.empty_like(c), torch.empty_like(h), v_w, v_b, act_out,
-                    nbr_idx, n_a, v_out, xs=xs)
+    if defer_action_term:      # only the h part of the critic: v = h'' @ w[:H] + b
+        H = h.shape[-1]
+        hv, cv = torch.empty_like(h), torch.empty_like(c)
+        lstm_step_fused(h_out, wh, bias, zadd1, zadd2, c_out, done, None, cv, hv, xs=xs)
+        v_out.copy_((torch.bmm(hv, v_w[:, :H]) + v_b.unsqueeze(1)).squeeze(-1))
+    else:
+        lstm_step_value(h_out, wh, bias, zadd1, zadd2, c_out, done, torch.empty_like(c), torch.empty_like(h), v_w, v_b,
+                        act_out, nbr_idx, n_a, v_out, xs=xs)
     return pi_out, act_out, v_out
 
 
@@ -287,6 +297,12 @@ def lstm_sequence_x(s, wx, wh, b, h0, c0, done, masked_steps, img):
         h, c = lstm_cell(z, b, c, done[t])
         hs.append(h)
     return torch.stack(hs, dim=1)
+
+
+def lstm_sequence_saved(s, wx, wh, b, G, Hall, Call, done, masked_steps):
+    """The restatement has no saved-activation shortcut: it recomputes the sequence from Hall[:, 0] / Call[:, 0] (what
+    the product's rollout saved must equal this; tests compare the two)."""
+    return lstm_sequence_x(s, wx, wh, b, Hall[:, 0], Call[:, 0], done, masked_steps, None)
 
 
 SAMPLE_UNIFORM, SAMPLE_PHILOX, SAMPLE_ARGMAX = 0, 1, 2

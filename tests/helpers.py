@@ -248,8 +248,11 @@ def build_product_batched(z, device):
     return cls(n_s_ls, [A] * N, nb, dist, -1, 10 ** 9, cp['MODEL_CONFIG'], seed=seed, num_envs=K, device=device)
 
 
-def drive_batched(model, z):
-    """Replays make_golden_nn.run_batched on the product's BATCHED engine (act / bootstrap / update on E = K
+def drive_batched(model, z, saved=False):
+    """saved: the rollout hands its activations to the update (model.enable_saved_activations, what BatchedTrainer does
+    for uncoupled nets) instead of the update recomputing the forward pass.
+
+    Replays make_golden_nn.run_batched on the product's BATCHED engine (act / bootstrap / update on E = K
     lock-stepped replicas, the calls BatchedTrainer makes): a prefix batch without update, the episode boundary
     (replicas 0, 1 restart: reset_states(mask), done_pre = 1), the main batch, ONE update.  Observations are written
     into buf_x; the scripted actions are forced through the kernels' own draw with uniforms placed in the middle of the
@@ -262,6 +265,8 @@ def drive_batched(model, z):
     F = X.shape[-1]
     nbrs = model.policy.nbrs
     model.masked_steps = (0,)
+    if saved:
+        assert model.enable_saved_activations(), 'this policy cannot save its rollout activations'
 
     def slab(x):                                  # [K,N,F] -> [K,N,n_obs]: own features, then the neighbours' (ascending)
         s = np.zeros((K, N, model.policy.n_obs), dtype=np.float32)
@@ -295,7 +300,8 @@ def drive_batched(model, z):
             got = model.buf_act[t].cpu().numpy()
             assert np.array_equal(got[live[ph]], ACT[:, ph, t][live[ph]]), 'forced action draw failed at step %d' % t
             PI[:, ph, t] = model.buf_fp[t + 1].permute(1, 0, 2).cpu().numpy()
-            V[:, ph, t] = model.buf_v[t].t().cpu().numpy()
+            if not saved:
+                V[:, ph, t] = model.buf_v[t].t().cpu().numpy()
             model.t = t + 1
         model.buf_x[T].copy_(slab(X[:, ph, T]))
         v = model.bootstrap(zero, scratch, mode=ops.SAMPLE_UNIFORM, u=uniforms(PIg[:, ph, T], ACT[:, ph, T], live[ph]),
@@ -319,10 +325,12 @@ def drive_batched(model, z):
     R_end = (v * (1.0 - last_done.to(torch.float32)).view(1, -1)).contiguous()
     states = np.concatenate([model.c_fw.permute(1, 0, 2).cpu().numpy(), model.h_fw.permute(1, 0, 2).cpu().numpy()], axis=2)
     model.update(R_end)
+    if saved:       # the values are complete (critic's neighbour-action term added) only after update()
+        V[:, 1, :T] = model.buf_v.permute(2, 0, 1).cpu().numpy()
     tot = model.last_loss[3].cpu().numpy().astype(np.float64)
     gn = model.grad_norm.cpu().numpy().astype(np.float64)
     loss, gnorm = (tot, gn) if model.per_agent_optimizer else (np.array([tot.sum()]), gn[:1])
-    return dict(PI=PI, V=V, RB=R_end.t().cpu().numpy(), STATES=states, LOSS=loss, GN=gnorm,
+    return dict(PI=PI, V=V, RB=R_end.t().cpu().numpy(), STATES=states, LOSS=loss, GN=gnorm, saved=saved,
                 STATS=var_stats_from_named(model.policy.params.ref_variables()))
 
 
@@ -335,6 +343,8 @@ def compare_batched(out, z, rtol_fw=1e-4, rtol_w=1e-3):
     vm[1, -1] = False
     np.testing.assert_allclose(out['PI'][:, 1][vm], z['PI'][:, 1][vm], rtol=rtol_fw, atol=1e-6, err_msg='pi (main batch)')
     np.testing.assert_allclose(out['PI'][m, 0], z['PI'][m, 0], rtol=rtol_fw, atol=1e-6, err_msg='pi (prefix)')
+    if out.get('saved'):
+        vm[:, -1] = False                        # bootstrap values are checked through RB; prefix values are not kept
     np.testing.assert_allclose(out['V'][:, 1][vm], z['V'][:, 1][vm], rtol=rtol_fw, atol=2e-5, err_msg='v')
     np.testing.assert_allclose(out['RB'], z['RB'], rtol=rtol_fw, atol=2e-5, err_msg='R bootstrap')
     keep = np.arange(K) != 1                      # replica 1: the product's (discarded) bootstrap call advanced its state

@@ -25,14 +25,18 @@ def test_scripted_run_matches_reference_on_gpu(path):
 BATCHED = sorted(glob.glob(os.path.join(GOLDEN, 'nnb_*.npz')))
 
 
+@pytest.mark.parametrize('saved', [False, True], ids=['recompute', 'saved_acts'])
 @pytest.mark.parametrize('path', BATCHED, ids=[os.path.basename(c)[4:-4] for c in BATCHED])
-def test_batched_update_matches_reference_replicas_on_gpu(path):
+def test_batched_update_matches_reference_replicas_on_gpu(path, saved):
     """The E > 1 update at real shapes (n_step 60 on the line, 120 on the 5x5 grid) through the REAL kernels: E = 4
     lock-stepped replicas == mean of 4 independent reference models' gradients -> clip -> one RMSProp step
     (policies.py:20-48, 232-273; agents/utils.py:763-775, 837-855; tests/golden/make_golden_nn.py run_batched).
-    Forward rtol 1e-4, post-update weights rtol 1e-3."""
+    Forward rtol 1e-4, post-update weights rtol 1e-3.  saved_acts: the rollout's step kernel hands gates /
+    states / LSTM inputs to the update (no forward pass there) -- what BatchedTrainer does for uncoupled nets."""
     from helpers import build_product_batched, compare_batched, drive_batched
     z = load_npz(path)
     model = build_product_batched(z, 'cuda')
+    if saved and not model.policy.can_save_acts:
+        pytest.skip('coupled net: the update recomputes its forward pass')
     np.testing.assert_allclose(var_stats_from_named(model.policy.params.ref_variables()), z['stats0'], rtol=1e-6, atol=1e-7)
-    compare_batched(drive_batched(model, z), z)
+    compare_batched(drive_batched(model, z, saved=saved), z)

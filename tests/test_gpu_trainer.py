@@ -75,3 +75,29 @@ def test_episode_bookkeeping_on_gpu():
     assert torch.all(model.h_fw == 0) and torch.allclose(model.fp, torch.full_like(model.fp, 0.25))
     m, s, c = tr.evaluate(n_envs=32)
     assert np.isfinite(m) and 0 <= c <= 32
+
+
+def test_saved_activations_equal_recomputed_forward():
+    """Uncoupled nets: the update fed by the rollout's saved activations == the update that recomputes its forward pass
+    (3 batches at E = 4096: weights, values, returns)."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    out = []
+    for save in (True, False):
+        cp = cacc_config(agent='ia2c_fp', scenario='catchup', n_step=60, reward_norm=800.0)
+        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=4096)
+        np.random.seed(12)
+        model = models.IA2C_FP(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                               cp['MODEL_CONFIG'], seed=12, num_envs=4096)
+        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True, save_activations=save)
+        assert tr.saved_acts == save
+        for _ in range(3):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        out.append((model.policy.params.flat.clone(), model.buf_v.clone(), model.R.clone(), model.buf_act.clone()))
+        del env, model, tr
+    assert torch.equal(out[0][3], out[1][3])
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out[0][2], out[1][2], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-4, atol=1e-6)

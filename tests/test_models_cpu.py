@@ -69,14 +69,17 @@ def test_heterogeneous_checkpoint_roundtrip_and_layout(name, tmp_path):
 BATCHED = sorted(glob.glob(os.path.join(GOLDEN, 'nnb_*.npz')))
 
 
+@pytest.mark.parametrize('saved', [False, True], ids=['recompute', 'saved_acts'])
 @pytest.mark.parametrize('path', BATCHED, ids=[os.path.basename(c)[4:-4] for c in BATCHED])
-def test_batched_update_equals_mean_of_reference_replica_gradients(path):
+def test_batched_update_equals_mean_of_reference_replica_gradients(path, saved):
     """E = K = 4 replicas, n_step 60 / 120: the product's batched update == mean over K independent reference models'
     gradients -> clip -> one RMSProp step (tests/golden/make_golden_nn.py run_batched), host logic on CPU emulation."""
     from helpers import build_product_batched, compare_batched, drive_batched
     z = load_npz(path)
     with cpu_ops():
         model = build_product_batched(z, 'cpu')
+        if saved and not model.policy.can_save_acts:
+            pytest.skip('coupled net: the update recomputes its forward pass')
         np.testing.assert_allclose(var_stats_from_named(model.policy.params.ref_variables()), z['stats0'], rtol=1e-6, atol=1e-7)
-        out = drive_batched(model, z)
+        out = drive_batched(model, z, saved=saved)
     compare_batched(out, z)

@@ -14,8 +14,10 @@ the bootstrap value, the n-step return scan and ONE A2C update (unroll + loss + 
 [RCCL all-reduce] + clip/RMSProp).  metric = agents x replicas x lock-steps / second, whole job.
 
 Extra objects on the JSON line (tier contract):
-  roofline      the CACC step kernel: algorithmic bytes per launch (B_alg) / average
-                launch duration measured live with HIP events; see `roofline.how`.
+  roofline      the DOMINANT kernel of the batch, the fused MFMA LSTM lock-step: algorithmic flops per launch / average
+                launch duration measured live with HIP events, against the dense fp32 matrix peak; see `roofline.how`.
+  roofline_env_step[_large_E]   the CACC step kernel (north_star's HBM roofline): algorithmic bytes per launch (B_alg,
+                DESIGN.md) / average launch duration, at the workload size and at E = 2^21.
   cpu_baseline  the reference-equivalent E=1 CPU loop (oracle/trainer_ref.py, kind "port") timed
                 on one host core on a bounded sample (rank 0, N=1 only).
 """
@@ -104,21 +106,49 @@ def measure_step_kernel(env, actions_tape, reps=20):
     return us
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 matrix peak (MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, no xf32 on gfx950)
+
+
 def measure_lstm_step(model, n=60, reps=10):
-    """Average duration of one fused MFMA LSTM step (nmarl_lstm_step_fused, the kernel with the largest share of
-    the batch time) on the model's own [N,E,64] state shapes and weights: hipGraph of n launches between HIP events.
-    Algorithmic bytes per (agent, replica) row: read h 256 + pre-activation addend 1024 + c 256, write c' 256 + h' 256."""
+    """Average duration of the DOMINANT kernel of the batch, the fused MFMA LSTM lock-step of the rollout, on the model's
+    own shapes and weights: hipGraph of n launches between HIP events on the launch stream.
+    x-side nets (IA2C / IA2C-FP / ConseNet): nmarl_lstm_step_x with the policy + value heads (kind 3): per (agent,
+    replica) row 2*(KX+64)*256 flops of the policy step + 2*64*256 of the value re-step (quirk Q1), all on
+    v_mfma_f32_16x16x4_f32.  Other nets: the recurrent-only step (2*64*256 flops per row).
+    Returns (us per launch, flops per launch, algorithmic HBM bytes per launch, kernel name)."""
     from deeprl_network_amd import ops
     p = model.policy
     N, E, H = model.h_fw.shape
-    h, c = torch.randn(N, E, H, device=model.device) * 0.3, torch.randn(N, E, H, device=model.device) * 0.3
-    z = torch.randn(N, E, 4 * H, device=model.device)
-    done = torch.zeros(E, device=model.device)
+    A = model.n_a
+    dev = model.device
+    h, c = torch.randn(N, E, H, device=dev) * 0.3, torch.randn(N, E, H, device=dev) * 0.3
+    done = torch.zeros(E, device=dev)
     wh, b = p.params[p.k_wh], p.params[p.k_b]
+    if p.can_save_acts:
+        KX = p.params[p.k_wx].shape[1]
+        p.refresh_wimage()
+        x = torch.relu(torch.randn(N, E, KX, device=dev))
+        pi, act, v = torch.empty(N, E, A, device=dev), torch.zeros(E, N, dtype=torch.uint8, device=dev), torch.empty(N, E, device=dev)
+        gates = torch.empty(N, E, 4 * H, device=dev)
+        ho, co = torch.empty_like(h), torch.empty_like(c)
 
-    def body():
-        for _ in range(n):
-            ops.lstm_step_fused(h, wh, b, z, None, c, done, None, c, h)
+        def body():
+            for _ in range(n):
+                p.step_policy_value(x, h, c, done, pi, act, v, h_out=ho, c_out=co, gates=gates, defer_action_term=True,
+                                    mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0)
+        flops = N * E * (2 * (KX + H) * 4 * H + 2 * H * 4 * H)
+        # read x, h, c; write h', c', gates, pi, v, action
+        nbytes = N * E * ((KX + 2 * H) * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
+        name = 'lstm_step_x_kernel<3> (nmarl_lstm_step_x, policy + value heads)'
+    else:
+        z = torch.randn(N, E, 4 * H, device=dev)
+
+        def body():
+            for _ in range(n):
+                ops.lstm_step_fused(h, wh, b, z, None, c, done, None, c, h)
+        flops = N * E * 2 * H * 4 * H
+        nbytes = N * E * (3 * H + 4 * H + H) * 4
+        name = 'lstm_step_mfma16_kernel (nmarl_lstm_step_fused)'
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -134,7 +164,7 @@ def measure_lstm_step(model, n=60, reps=10):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (reps * n), N * E * (3 * H + 4 * H + H) * 4      # 2048 B / row at H = 64
+    return e0.elapsed_time(e1) * 1e3 / (reps * n), flops, nbytes, name
 
 
 def pmc_traffic(key):
@@ -316,21 +346,46 @@ def main():
                                       '1 A2C update over all replicas' % n_step},
     }
     if rank == 0:
-        # ---- roofline of the env-step kernel, measured live on this rank's stream
+        # ---- `roofline`: the DOMINANT kernel of the batch = the fused MFMA LSTM lock-step (fp32 matrix pipe)
+        if model.n_lstm == 64:
+            try:
+                us_l, flops_l, bytes_l, lname = measure_lstm_step(model)
+                x_side = model.policy.can_save_acts
+                ach = flops_l / us_l / 1e6
+                out['roofline'] = {
+                    'kernel': lname, 'bound': 'mfma' if x_side else 'hbm',
+                    'achieved': ach if x_side else bytes_l / us_l / 1e3,
+                    'peak': MFMA_F32_PEAK_TFLOPS if x_side else HBM_PEAK_GBPS,
+                    'unit': 'TFLOP/s' if x_side else 'GB/s',
+                    'frac': ach / MFMA_F32_PEAK_TFLOPS if x_side else bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
+                    'traffic': None, 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
+                    'rows_per_launch': n_agent * E, 'launches_per_batch': n_step + 1,
+                    'hbm_frac_of_same_launch': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
+                    'how': 'hipGraph of 60 launches on the model shapes and weights, 10 replays between two HIP events on '
+                           'the launch stream (includes graph-node gaps).  Algorithmic work per (agent, replica) row: '
+                           'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops, fp32 in / fp32 accumulate on '
+                           'v_mfma_f32_16x16x4_f32 (peak %.1f TFLOP/s dense, MI355X_MICROARCH.md); the same launch moves '
+                           '%.1f MB of algorithmic HBM bytes (x, h, c in; h, c, gates, pi, v, action out), i.e. it is '
+                           'matrix-pipe-bound, not HBM-bound' % (MFMA_F32_PEAK_TFLOPS, bytes_l / 1e6)}
+            except Exception as ex:
+                out['roofline'] = {'error': repr(ex)}
+        # ---- the env-step kernel (north_star's HBM roofline), measured live on this rank's stream
         tape = model.buf_act.clone()
         us = measure_step_kernel(env, tape)
         ach = balg * E / us / 1e3
         tr_small, tr_src = pmc_traffic('cacc_step_E4096') if (not is_grid and E == 4096) else (None, None)
-        out['roofline'] = {
+        out['roofline_env_step'] = {
             'kernel': kname, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
             'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None if tr_small is None else tr_small * E,
             'traffic_source': tr_src,
             'bytes_per_launch': balg * E, 'us_per_launch': us, 'replicas_per_launch': E,
             'how': 'hipGraph of %d back-to-back step launches on the rollout state with the batch action tape, '
                    '20 replays between two HIP events on the launch stream (includes graph-node gaps). '
-                   'B_alg = %d B/replica-step (gathered-observation variant). At E=%d the launch moves %.2f MB: '
-                   'latency-bound and LLC-resident (SURVEY.md H1); see roofline_large_E for the HBM regime.'
+                   'B_alg = %d B/replica-step. At E=%d the launch moves %.2f MB: '
+                   'latency-bound and LLC-resident (SURVEY.md H1); see roofline_env_step_large_E for the HBM regime.'
                    % (n_step, balg, E, balg * E / 1e6)}
+        if 'roofline' not in out or 'error' in out['roofline']:
+            out['roofline'] = dict(out['roofline_env_step'])
         if world == 1 and not is_grid:
             try:
                 big_E = 1 << 21
@@ -342,37 +397,19 @@ def main():
                 for k in range(60):                      # leave the all-equilibrium start of the episode
                     big.step(big_tape[k % 8], auto_reset=True)
                 us_b = measure_step_kernel(big, big_tape, reps=5)
-                ach_b = B_ALG_GATHERED * big_E / us_b / 1e3
+                ach_b = balg * big_E / us_b / 1e3
                 tr_big, tr_src_b = pmc_traffic('cacc_step_E2p21')
-                out['roofline_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,
-                                           'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
-                                           'traffic': None if tr_big is None else tr_big * big_E,
-                                           'traffic_source': tr_src_b,
-                                           'replicas_per_launch': big_E, 'us_per_launch': us_b,
-                                           'bytes_per_launch': B_ALG_GATHERED * big_E,
-                                           'how': 'same kernel at E=2^21 (working set 1.4 GB >> 256 MB Infinity Cache), '
-                                                  'actions (env+3*agent+step) mod 4 (SURVEY.md 8d)'}
+                out['roofline_env_step_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,
+                                                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
+                                                    'traffic': None if tr_big is None else tr_big * big_E,
+                                                    'traffic_source': tr_src_b,
+                                                    'replicas_per_launch': big_E, 'us_per_launch': us_b,
+                                                    'bytes_per_launch': balg * big_E,
+                                                    'how': 'same kernel at E=2^21 (working set >> 256 MB Infinity Cache), '
+                                                           'actions (env+3*agent+step) mod 4 (SURVEY.md 8d)'}
                 del big
             except Exception as ex:      # never lose the headline line to the side measurement
-                out['roofline_large_E'] = {'error': repr(ex)}
-        if model.n_lstm == 64:
-            try:
-                us_l, bytes_l = measure_lstm_step(model)
-                out['roofline_lstm_step'] = {
-                    'kernel': 'lstm_step_mfma16_kernel (nmarl_lstm_step_fused[_head])', 'bound': 'hbm',
-                    'achieved': bytes_l / us_l / 1e3, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-                    'frac': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
-                    'traffic': (lambda t: None if t[0] is None or n_agent * E != 8 * 4096 else t[0] * n_agent * E)(
-                        pmc_traffic('lstm_step_N8_E4096')),
-                    'traffic_source': pmc_traffic('lstm_step_N8_E4096')[1], 'bytes_per_launch': bytes_l,
-                    'us_per_launch': us_l, 'launches_per_batch': 3 * n_step + 2,
-                    'mfma_flops_per_launch': 2 * n_agent * E * 64 * 256,
-                    'how': 'hipGraph of 60 in-place fused steps on [N,E,64] state with the model weights, 10 replays '
-                           'between HIP events; 2048 B per (agent, replica) row; the fp32 MFMA work is %.1f GFLOP per '
-                           'launch (157 TFLOP/s peak -> %.1f us), so the kernel is HBM-side'
-                           % (2 * n_agent * E * 64 * 256 / 1e9, 2 * n_agent * E * 64 * 256 / 157e12 * 1e6)}
-            except Exception as ex:
-                out['roofline_lstm_step'] = {'error': repr(ex)}
+                out['roofline_env_step_large_E'] = {'error': repr(ex)}
         if world == 1 and not args.no_cpu_baseline and not is_grid:
             out['cpu_baseline'] = cpu_baseline(args.config, args.cpu_batches)
         print(json.dumps(out))

@@ -198,8 +198,16 @@ class IA2C:
         self.H_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.buf_vn = torch.zeros(N, T, E, dtype=F32, device=d)          # agent-major values (critic's h part)
+        # coupled nets: further per-step message terms the backward needs (policy.save_spec)
+        p._extra = {k: torch.zeros(N, T, E, w, dtype=F32, device=d) for k, w in p.save_spec().items()}
         self.save_acts = True
         return True
+
+    def _save_slots(self, t):
+        """Slots of lock-step t in the saved activations, for the policy step of a coupled net."""
+        d = {k: v[:, t] for k, v in self.policy._extra.items()}
+        d['S'] = self.S_buf[:, t]
+        return d
 
     # ------------------------------------------------------------------ batched engine
     def reset_states(self, mask=None):
@@ -230,7 +238,7 @@ class IA2C:
         if not reuse_enc:
             self.policy.refresh_wimage()
         enc = self._enc if reuse_enc else self.policy.encode(obs, self.fp)
-        self.policy.step(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, done_is_zero)
+        self.policy.step(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, done_is_zero, second=True)
         with torch.no_grad():
             return self.policy.value(self._h2, na_onehot, out=out)
 
@@ -251,12 +259,21 @@ class IA2C:
         # enc is shared by the policy step and the value re-step (Q1)
         enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
-        if self.save_acts:
+        if self.save_acts and p.fused_pv:
             # the policy step reads slot t of the state sequences and writes slot t + 1, gates into G[:, t]; the value
             # (critic's h part) goes to the agent-major buffer, its neighbour-action term is added in update()
             p.step_policy_value(enc, self.H_all[:, t], self.C_all[:, t], done, self.buf_fp[t + 1], self.buf_act[t],
                                 self.buf_vn[:, t], h_out=self.H_all[:, t + 1], c_out=self.C_all[:, t + 1],
                                 gates=self.G_buf[:, t], defer_action_term=True, **draw)
+            return self.buf_act[t]
+        if self.save_acts:
+            # coupled nets: policy step (saves its message terms, gates, states), then the value re-step from the new
+            # states of ALL agents (its message term is recomputed from them; nothing of it is kept)
+            p.step_policy(enc, self.H_all[:, t], self.C_all[:, t], done, self.H_all[:, t + 1], self.C_all[:, t + 1],
+                          self.buf_fp[t + 1], self.buf_act[t], done_is_zero, gates=self.G_buf[:, t], save=self._save_slots(t),
+                          **draw)
+            p.step_value(enc, self.H_all[:, t + 1], self.C_all[:, t + 1], done, self._h2, self._c2, self.buf_act[t],
+                         self.buf_v[t], done_is_zero)
             return self.buf_act[t]
         if p.fused_pv:
             p.step_policy_value(enc, self.h_fw, self.c_fw, done, self.buf_fp[t + 1], self.buf_act[t], self.buf_v[t], **draw)
@@ -293,12 +310,18 @@ class IA2C:
         assert self.t == self.n_step
         p = self.policy
         enc = p.encode(self.buf_x[self.n_step], self.fp)
-        if self.save_acts:                                  # from slot T of the sequences into the persistent state
+        if self.save_acts and p.fused_pv:                   # from slot T of the sequences into the persistent state
             T = self.n_step
             p.step_policy_value(enc, self.H_all[:, T], self.C_all[:, T], done, self._pi_boot, action_scratch, self._v_boot,
                                 h_out=self.h_fw, c_out=self.c_fw, mode=mode, u=u, seed=seed, env_id_base=env_id_base,
                                 step=step, step_dev=step_dev)
             return self._v_boot
+        if self.save_acts:
+            T = self.n_step
+            p.step_policy(enc, self.H_all[:, T], self.C_all[:, T], done, self.h_fw, self.c_fw, self._pi_boot, action_scratch,
+                          done_is_zero, mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
+            return p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, action_scratch, self._v_boot,
+                                done_is_zero)
         if p.fused_pv:
             p.step_policy_value(enc, self.h_fw, self.c_fw, done, self._pi_boot, action_scratch, self._v_boot, mode=mode, u=u,
                                 seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
@@ -346,7 +369,7 @@ class IA2C:
         cur_lr = self.lr_scheduler.get(self.n_step)
         alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
         T = self.n_step
-        if self.save_acts:
+        if self.save_acts and self.policy.fused_pv:
             # the critic's neighbour-action term of all T lock-steps in one launch (policies.py:59-77), then the values
             # in the [T,N,E] order the return scan reads
             with torch.no_grad():

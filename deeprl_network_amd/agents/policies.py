@@ -312,13 +312,13 @@ class BatchedPolicy:
                 return self._enc_infer(x.transpose(0, 1), fp_prev, out=out)
             return self._enc_infer(x.transpose(0, 1), fp_prev)
 
-    def step(self, enc, h, c, done, h_out, c_out, done_is_zero=False):
+    def step(self, enc, h, c, done, h_out, c_out, done_is_zero=False, second=False):
         """One LSTM step from (h, c) [N,E,H] with done [E] f32 -> writes (h', c') into (h_out, c_out),
         which MAY alias (h, c).  H = 64: ONE fused MFMA kernel computes (h*(1-done)) @ Wh on top of the
         x-side addends and applies the cell in its epilogue (csrc/lstm_mfma.hip).  Other widths: a plain
         batched GEMM + the cell kernel (which takes the x-side part as a second addend: no copy GEMM)."""
         with torch.no_grad():
-            z1, z2, xs = self._recur_addends(enc, h)
+            z1, z2, xs = self._recur_addends(enc, h, second=second)
             wh, b = self.params[self.k_wh], self.params[self.k_b]
             if self.n_h == ops.FUSED_H:
                 ops.lstm_step_fused(h, wh, b, z1, z2, c, done, None, c_out, h_out, xs=xs)
@@ -333,16 +333,17 @@ class BatchedPolicy:
         """The actor / critic heads can ride in the fused step's epilogue (csrc/lstm_mfma.hip)."""
         return self.n_h == ops.FUSED_H and self.n_a <= ops.HEAD_MAX_A
 
-    def step_policy(self, enc, h, c, done, h_out, c_out, pi_out, act_out, done_is_zero=False, **draw):
+    def step_policy(self, enc, h, c, done, h_out, c_out, pi_out, act_out, done_is_zero=False, gates=None, save=None,
+                    **draw):
         """forward('p') + the action draw of one lock-step (policies.py:119-123, utils.py:135-141): one LSTM step,
         pi -> pi_out [N,E,A], actions -> act_out [E,N] u8.  `draw`: sample_actions' mode / u / seed / env_id_base /
         step / step_dev.  One kernel when `fused_heads`."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2, xs = self._recur_addends(enc, h)
+                z1, z2, xs = self._recur_addends(enc, h, save=save)
                 p = self.params
                 ops.lstm_step_policy(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['pi_w'], p['pi_b'],
-                                     pi_out, act_out, xs=xs, **draw)
+                                     pi_out, act_out, xs=xs, gates=gates, **draw)
             else:
                 self.step(enc, h, c, done, h_out, c_out, done_is_zero)
                 pi_out.copy_(self.pi(h_out))
@@ -370,18 +371,33 @@ class BatchedPolicy:
 
     @property
     def can_save_acts(self):
-        """The rollout can hand its activations (LSTM inputs, gates, state sequences) to the update, which then needs
-        no forward pass: uncoupled nets whose lock-step is the one fused x-side kernel."""
-        return (not self.coupled) and self.xside and self.fused_pv
+        """The rollout can hand its activations (LSTM inputs, gates, state sequences, message terms) to the update,
+        which then needs no forward pass: nets whose recurrent step is the fused x-side kernel."""
+        return self.xside and self.fused_heads
 
     def unroll_saved(self, X, FP, S, G, Hall, Call, done, masked_steps=None):
         """`unroll` for a batch whose forward pass the rollout already did with the CURRENT weights: S [N,T,E,KX] the
         LSTM inputs, G the gates, Hall / Call [N,T+1,E,H] the state sequences it saved.  Sets up the backward only."""
         T, E = done.shape
         Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)
+        if self.coupled:
+            return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps)
         s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
         Hs = ops.lstm_sequence_saved(s.view(self.N, T, E, s.shape[-1]), self.params[self.k_wx], self.params[self.k_wh],
                                      self.params[self.k_b], G, Hall, Call, done, masked_steps)
+        return Hs.reshape(self.N, T * E, self.n_h)
+
+    def save_spec(self):
+        """Extra per-step tensors a coupled net saves besides S / G / Hall / Call: {name: width}."""
+        return {}
+
+    def _unroll_saved_coupled(self, Xv, FP, S, G, Hall, Call, done, masked_steps):
+        T, E = done.shape
+        kind, wx, w_msg, b_msg, mfc_w, mfc_b = self._seq_args()
+        enc = self._enc_saved(Xv, FP, S)
+        Hs = sequence.coupled_sequence_saved(kind, self.nbr_idx, masked_steps, enc.view(self.N, T, E, enc.shape[-1]), done,
+                                             self.params[self.k_wx], self.params[self.k_wh], self.params[self.k_b],
+                                             w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, getattr(self, '_extra', {}))
         return Hs.reshape(self.N, T * E, self.n_h)
 
     def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):
@@ -389,12 +405,12 @@ class BatchedPolicy:
         [h', onehot(neighbours' actions)], actions given as the env-major byte array action [E,N] -> v_out [N,E]."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2, xs = self._recur_addends(enc, h)
+                z1, z2, xs = self._recur_addends(enc, h, second=True)
                 p = self.params
                 ops.lstm_step_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['v_w'], p['v_b'],
                                     action, self.nbr_idx, self.n_a, v_out, xs=xs)
             else:
-                self.step(enc, h, c, done, h_out, c_out, done_is_zero)
+                self.step(enc, h, c, done, h_out, c_out, done_is_zero, second=True)
                 self.value(h_out, ops.nbr_onehot(action, self.nbr_idx, self.n_a), out=v_out)
         return v_out
 
@@ -410,10 +426,13 @@ class BatchedPolicy:
             return ops.fc_fwd(x, w, b, act, out=out)          # small-K layer: one streaming kernel (csrc/fc.hip)
         return ops.bias_act_(torch.bmm(x, w), b, act, out=out)
 
-    def _recur_addends(self, enc, h):
+    def _recur_addends(self, enc, h, second=False, save=None):
         """(zadd1, zadd2, xs): everything of the LSTM pre-activation except (h*(1-done)) @ Wh and the bias -- as
-        ready-made addends [N,E,4H] and / or as xs = (x, wx, weight image): an input x [N,E,KX] whose product with
-        wx the fused step computes itself (ops.lstm_step_fused)."""
+        ready-made addends [N,E,4H] and / or as xs = (x, wx, weight image[, x2]): an input [x | x2] [N,E,KX] whose
+        product with wx the fused step computes itself (ops.lstm_step_fused).
+        Coupled nets compute their message terms from h here.  second: the call is the value re-step of a lock-step
+        (quirk Q1) -- what the policy step wrote into `enc` / the save slots must survive.  save: slots of the saved
+        activations (dict of [N,E,*] tensors) the policy step's message terms are written to."""
         if self.xside:
             return None, None, (enc, self.params[self.k_wx], self._img)
         return enc, None, None
@@ -544,7 +563,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
     """NeurComm: s = [relu(x~ W_ob), relu(p~ W_fp), relu(m~ W_msg)] -> LSTM(3H) (agents/utils.py:182-208).
     m~ = neighbours' previous h, NOT done-masked (Q3: agents/utils.py:182-183)."""
     name = 'nc'
-    k_wh, k_b = 'wh_hid', 'hid_b'
+    k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     scope = 'nc/lstm_comm_%d'
     coupled = True                # messages: neighbours' h_{t-1} enter every step
 
@@ -568,6 +587,14 @@ class NCMultiAgentPolicy(BatchedPolicy):
         s = ops.fc_concat([(xv, p['w_ob'], p['w_ob_b']), (pf, p['w_fp'], p['w_fp_b'])], ops.BIAS_RELU)
         return ops.linear(s, p['wx_hid'][:, :2 * H])
 
+    def _enc_saved(self, xv, fp, S):
+        """[hx | hp] as the rollout wrote it into the first 2H columns of the saved LSTM inputs (backward only)."""
+        p = self.params
+        H = self.n_h
+        pf = ops.nbr_gather(fp, self.nbr_idx)
+        Sv = S.view(self.N, -1, S.shape[-1])[:, :, :2 * H]
+        return ops.fc_concat([(xv, p['w_ob'], p['w_ob_b']), (pf, p['w_fp'], p['w_fp_b'])], ops.BIAS_RELU, saved=Sv)
+
     def _recur_in(self, enc, h):
         p = self.params
         H = self.n_h
@@ -575,23 +602,41 @@ class NCMultiAgentPolicy(BatchedPolicy):
         hm = torch.relu(torch.baddbmm(p['w_msg_b'].unsqueeze(1), m, p['w_msg']))
         return torch.baddbmm(enc, hm, p['wx_hid'][:, 2 * H:])
 
-    def _enc_infer(self, xv, fp):
+    def _enc_infer(self, xv, fp, out=None):
+        """x-side mode: the full LSTM input [hx | hp | hm] [N,E,3H] (a fresh buffer or the given slot of the saved
+        activations) with [hx | hp] filled in; the recurrent step adds the message third.  Else: [hx | hp] @ Wx[:2H]."""
         p = self.params
         H = self.n_h
+        full = None
+        if self.xside:
+            full = out if out is not None else torch.empty(self.N, xv.shape[1], 3 * H, dtype=F32, device=xv.device)
+        s = None if full is None else full[:, :, :2 * H]
         if self._enc_one_launch(xv, H):
             # [hx | hp] of agents/utils.py:199 by ONE kernel (fingerprint gather folded in)
             s = ops.fc_fwd_multi([(xv, p['w_ob'], p['w_ob_b'], None), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)],
-                                 ops.BIAS_RELU)
+                                 ops.BIAS_RELU, out=s)
         else:
-            s = torch.empty(self.N, xv.shape[1], 2 * H, dtype=F32, device=xv.device)
+            if s is None:
+                s = torch.empty(self.N, xv.shape[1], 2 * H, dtype=F32, device=xv.device)
             self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
-        return torch.bmm(s, p['wx_hid'][:, :2 * H])
+        return full if self.xside else torch.bmm(s, p['wx_hid'][:, :2 * H])
 
-    def _recur_addends(self, enc, h):
+    def _recur_addends(self, enc, h, second=False, save=None):
         p = self.params
         H = self.n_h
-        hm = self._fc_infer(ops.nbr_gather(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU)
+        m = ops.nbr_gather(h, self.nbr_idx)                                   # un-masked previous h (Q3)
+        if self.xside:
+            # hm = relu(m~ W_msg + b) becomes the last third of the LSTM input: in place for the policy step (it is the
+            # saved message term of the update), into a scratch third for the value re-step
+            if second:
+                if getattr(self, '_hm2', None) is None or self._hm2.shape[1] != h.shape[1]:
+                    self._hm2 = torch.empty(self.N, h.shape[1], H, dtype=F32, device=h.device)
+                self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU, out=self._hm2)
+                return None, None, (enc[:, :, :2 * H], p['wx_hid'], self._img, self._hm2)
+            self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU, out=enc[:, :, 2 * H:])
+            return None, None, (enc, p['wx_hid'], self._img)
+        hm = self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU)
         return torch.bmm(hm, p['wx_hid'][:, 2 * H:]), enc, None
 
     def _seq_args(self):
@@ -603,7 +648,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     """CommNet ("IC3"): s = tanh(x~ W_ob + b) + mean_nbr(h_prev) W_msg + b_msg -> LSTM(H)
     (agents/utils.py:385-408)."""
     name = 'ic3'
-    k_wh, k_b = 'wh_hid', 'hid_b'
+    k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     scope = 'ic3/lstm_ic3_%d'
     coupled = True
 
@@ -629,11 +674,28 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         s = enc + torch.baddbmm(p['w_msg_b'].unsqueeze(1), mm, p['w_msg'])
         return torch.bmm(s, p['wx_hid'])
 
-    def _enc_infer(self, xv, fp):
+    def _enc_saved(self, xv, fp, S):
+        return self._enc(xv, fp)             # tanh(x~ W_ob + b): recomputed (one streaming pass), only the recurrence is saved
+
+    def _enc_infer(self, xv, fp, out=None):
         return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH)
 
-    def _recur_addends(self, enc, h):
+    def _x_target(self, h, second, save):
+        """Where the LSTM input of this step goes: the slot of the saved activations (policy step of the batched
+        engine), else a scratch tensor (one per half of the lock-step)."""
+        if save is not None and not second:
+            return save['S']
+        name = '_x2' if second else '_x1'
+        if getattr(self, name, None) is None or getattr(self, name).shape[1] != h.shape[1]:
+            setattr(self, name, torch.empty(self.N, h.shape[1], self.n_h, dtype=F32, device=h.device))
+        return getattr(self, name)
+
+    def _recur_addends(self, enc, h, second=False, save=None):
         p = self.params
+        if self.xside:
+            x = self._x_target(h, second, save)
+            self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE, out=x).add_(enc)
+            return None, None, (x, p['wx_hid'], self._img)
         s = self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE).add_(enc)
         return torch.bmm(s, p['wx_hid']), None, None
 
@@ -691,7 +753,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     s_i = relu(x~_i W_ob) + relu([mfc_j(h_j) for j in nbr(i)] W_msg) + onehot_H(argmax pi_i(t-1)) -> LSTM(H);
     the message encoder mfc_j = relu(h_j W + b) acts on the sender's un-masked previous h."""
     name = 'dial'
-    k_wh, k_b = 'wh_hid', 'hid_b'
+    k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     coupled = True
 
     def _phases(self):
@@ -728,14 +790,28 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         hm = torch.relu(torch.baddbmm(p['w_msg_b'].unsqueeze(1), ops.nbr_gather(msg, self.nbr_idx), p['w_msg']))
         return torch.bmm(enc + hm, p['wx_hid'])
 
-    def _enc_infer(self, xv, fp):
+    def _enc_saved(self, xv, fp, S):
+        return self._enc(xv, fp)             # recomputed: only the recurrence is saved
+
+    def _enc_infer(self, xv, fp, out=None):
         return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU).add_(self._own_action_onehot(fp))
 
-    def _recur_addends(self, enc, h):
+    def save_spec(self):
+        return {'A1': self.n_h, 'A2': self.n_h}        # hm (post-relu), msg (post-relu): relu masks of the backward
+
+    _x_target = IC3MultiAgentPolicy._x_target
+
+    def _recur_addends(self, enc, h, second=False, save=None):
         p = self.params
-        msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU)
-        hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU).add_(enc)
-        return torch.bmm(hm, p['wx_hid']), None, None
+        keep = save is not None and not second
+        msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU, out=save['A2'] if keep else None)
+        hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU,
+                            out=save['A1'] if keep else None)
+        if self.xside:
+            x = self._x_target(h, second, save)
+            torch.add(hm, enc, out=x)
+            return None, None, (x, p['wx_hid'], self._img)
+        return torch.bmm(hm.add_(enc), p['wx_hid']), None, None
 
     def _seq_args(self):
         p = self.params

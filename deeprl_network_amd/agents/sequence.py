@@ -150,6 +150,109 @@ class CoupledSequence(torch.autograd.Function):
         return None, None, None, denc, dh_rec, dc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b
 
 
+class CoupledSequenceSaved(torch.autograd.Function):
+    """The coupled recurrences of the update WITHOUT a forward pass: the rollout's policy steps (x-side step kernel,
+    agents/policies.py `_recur_addends`) evaluated exactly this sequence with exactly these weights and saved
+    S [N,T,E,KX] (the LSTM inputs: nc [hx | hp | hm], ic3 s, dial enc + hm), the gates G, the state sequences Hall /
+    Call and, for dial, the post-relu message terms A1 (hm) / A2 (msg).  forward = hand out Hall[:, 1:]; backward = the
+    manual BPTT of CoupledSequence with the x-side weight as ONE matrix:
+      nc    `enc` = [hx | hp] (autograd-connected, = S[..., :2H]); wx = the full [3H,4H]:
+            d enc = dZ @ wx[:2H]^T, d wx = S^T dZ (one GEMM over all T*E rows, all three thirds at once)
+      ic3 / dial as in CoupledSequence (their `enc` enters the LSTM input additively)."""
+
+    @staticmethod
+    def forward(ctx, kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, A1, A2):
+        T = G.shape[1]
+        e = G.new_empty(0)
+        ctx.save_for_backward(G, Hall, Call, S, A1 if A1 is not None else e, A2 if A2 is not None else e, done, wx, wh, w_msg,
+                              mfc_w if mfc_w is not None else e, nbr_idx)
+        ctx.kind = kind
+        ctx.masked = set(range(T)) if masked_steps is None else set(masked_steps)
+        return Hall[:, 1:]
+
+    @staticmethod
+    def backward(ctx, dHs):
+        G, Hall, Call, S, A1, A2, done, wx, wh, w_msg, mfc_w, nbr_idx = ctx.saved_tensors
+        kind, masked = ctx.kind, ctx.masked
+        N, T, E, H4 = G.shape
+        H = H4 // 4
+        dev = G.device
+        R = T * E
+        dHs = dHs.contiguous()
+        dZ = torch.empty_like(G)
+        D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
+        D2 = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
+        DS = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
+        keep = 1.0 - done
+        wxm = wx[:, 2 * H:] if kind == 'nc' else wx           # the rows of wx the h-dependent part of the input meets
+        hm = S[..., 2 * H:] if kind == 'nc' else A1           # post-relu message term (nc: last third of the input)
+        w2 = _stack_rows(wxm, wh)
+        w2_t = None if w2 is None else w2.transpose(1, 2)
+        wxm_t, wh_t, wmsg_t = wxm.transpose(1, 2), wh.transpose(1, 2), w_msg.transpose(1, 2)
+        dh_rec = None
+        dc = torch.zeros(N, E, H, dtype=F32, device=dev)
+        dc_next = torch.empty_like(dc)
+        for t in range(T - 1, -1, -1):
+            ops.cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
+            dc, dc_next = dc_next, dc
+            if w2_t is not None:
+                d2 = torch.bmm(dZ[:, t], w2_t)
+                dx, dhd = d2[..., :H], d2[..., H:]
+            else:
+                dx, dhd = torch.bmm(dZ[:, t], wxm_t), torch.bmm(dZ[:, t], wh_t)
+            if t in masked:
+                dhd = dhd * keep[t].view(1, E, 1)
+            if kind == 'nc':
+                torch.mul(dx, (hm[:, t] > 0), out=D1[:, t])
+                dh_msg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
+            elif kind == 'ic3':
+                D1[:, t].copy_(dx)
+                dh_msg = ops.nbr_mean_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx)
+            else:
+                DS[:, t].copy_(dx)
+                torch.mul(dx, (hm[:, t] > 0), out=D1[:, t])
+                dmsg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
+                torch.mul(dmsg, (A2[:, t] > 0), out=D2[:, t])
+                dh_msg = torch.bmm(D2[:, t], mfc_w.transpose(1, 2))
+            dh_rec = dh_msg + dhd
+        dZf = dZ.view(N, R, H4)
+        Hprev = Hall[:, :T]
+        if len(masked) == T:
+            Hk = (Hprev * keep.view(1, T, E, 1)).reshape(N, R, H)
+        else:
+            Hk = Hprev.clone()
+            for t in masked:
+                Hk[:, t].mul_(keep[t].view(1, E, 1))
+            Hk = Hk.view(N, R, H)
+        dwh = ops.wgrad(Hk, dZf)
+        db = dZf.sum(dim=1)
+        Hp = Hprev.reshape(N, R, H)                            # un-masked h_{t-1} of all steps (message inputs)
+        D1f = D1.view(N, R, H)
+        dbmsg = D1f.sum(dim=1)
+        dwx = ops.wgrad(S.view(N, R, S.shape[-1]), dZf)        # the whole x-side weight in one GEMM
+        dmfc_w = dmfc_b = None
+        if kind == 'nc':
+            dwmsg = ops.wgrad(ops.nbr_gather(Hp, nbr_idx), D1f)
+            denc = torch.bmm(dZf, wx[:, :2 * H].transpose(1, 2)).view(N, T, E, 2 * H) if ctx.needs_input_grad[3] else None
+        elif kind == 'ic3':
+            dwmsg = ops.wgrad(ops.nbr_mean(Hp, nbr_idx), D1f)
+            denc = D1
+        else:
+            D2f = D2.view(N, R, H)
+            dwmsg = ops.wgrad(ops.nbr_gather(A2.reshape(N, R, H), nbr_idx), D1f)
+            dmfc_w = ops.wgrad(Hp, D2f)
+            dmfc_b = D2f.sum(dim=1)
+            denc = DS
+        return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b, None, None, None, None, None, None)
+
+
+def coupled_sequence_saved(kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S,
+                           extra):
+    """enc [N,T,E,W] (autograd-connected h-independent part), saved activations of the rollout -> Hs [N,T,E,H]."""
+    return CoupledSequenceSaved.apply(kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall,
+                                      Call, S, extra.get('A1'), extra.get('A2'))
+
+
 def coupled_sequence(kind, nbr_idx, masked_steps, enc, h0, c0, done, wx, wh, b, w_msg, b_msg, mfc_w=None, mfc_b=None):
     """enc [N,T,E,W] -> Hs [N,T,E,H]; see the module docstring."""
     return CoupledSequence.apply(kind, nbr_idx, masked_steps, enc, h0, c0, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b)

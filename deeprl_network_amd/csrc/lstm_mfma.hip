@@ -354,8 +354,9 @@ constexpr int MAX_KX = 256;
 struct XArgs {
     FusedArgs f;                  // h_in, bias, zadd*, c_prev, done, gates, c_new, h_new, strides, E, hd (wh unused)
     const float* x; int64_t x_sn, x_row;
+    const float* x2; int64_t x2_sn, x2_row;   // optional second piece of x: columns [32 nx1, KX) come from here
     const float* img; int64_t img_sn;
-    int nx, N;                    // x chunks (KX / 32), agents
+    int nx, nx1, N;               // x chunks (KX / 32), chunks of the first piece, agents
 };
 
 // one k-step: 16 MFMAs (all column tiles) with the A value `av` and the B operands in four float4 registers
@@ -439,12 +440,15 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const int64_t arow = row0 + c < a.E ? row0 + c : a.E - 1;
     const float keepA = 1.0f - a.done[arow];
     const float* xrow = xa.x ? xa.x + (int64_t)n * xa.x_sn + arow * xa.x_row + 4 * grp : nullptr;
+    const float* x2row = xa.x2 ? xa.x2 + (int64_t)n * xa.x2_sn + arow * xa.x2_row + 4 * grp : nullptr;
+    const int nx1 = xa.nx1;
     const float* hrow = a.h_in + (int64_t)n * a.h_sn + arow * H + 4 * grp;
     float4 a0, a1, n0, n1;
 #define NMARL_A_LOAD(ch, d0, d1)     /* raw load; the (1 - done) mask of the h chunks is applied at first use */ \
     if ((ch) < nx) {                                                                      \
-        d0 = *reinterpret_cast<const float4*>(xrow + (ch) * CH_K);                        \
-        d1 = *reinterpret_cast<const float4*>(xrow + (ch) * CH_K + 16);                   \
+        const float* p_ = (ch) < nx1 ? xrow + (ch) * CH_K : x2row + ((ch) - nx1) * CH_K;  \
+        d0 = *reinterpret_cast<const float4*>(p_);                                        \
+        d1 = *reinterpret_cast<const float4*>(p_ + 16);                                   \
     } else {                                                                              \
         d0 = *reinterpret_cast<const float4*>(hrow + ((ch) - nx) * CH_K);                 \
         d1 = *reinterpret_cast<const float4*>(hrow + ((ch) - nx) * CH_K + 16);            \
@@ -702,13 +706,14 @@ extern "C" int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t
 }
 
 extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                                 int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
                                  const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
                                  int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
                                  const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
                                  float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
                                  void* stream) {
-    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K ||
-        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX > 0 && !x))))
+    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K ||
+        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 > 0 && !x) || (KX2 > 0 && !x2))))
         return NMARL_EINVAL;
     const int kind = head ? head->kind : 0;
     if (kind < 0 || kind > 3) return NMARL_EINVAL;
@@ -728,7 +733,8 @@ extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, c
         (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
         !stride_ok(h_new_sn, E * H) || (gates && !stride_ok(gates_sn, E * G4)) || ((uintptr_t)h_in % 16) || ((uintptr_t)img % 16) ||
         img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
-        (KX > 0 && (x_row < KX || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))))
+        (KX - KX2 > 0 && (x_row < KX - KX2 || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
+        (KX2 > 0 && (x2_row < KX2 || (x2_row % 4) || (x2_sn % 4) || ((uintptr_t)x2 % 16))))
         return NMARL_EINVAL;
     XArgs xa{};
     FusedArgs& a = xa.f;
@@ -739,8 +745,10 @@ extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, c
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     if (kind != 0) a.hd = *head;
-    xa.x = KX > 0 ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row; xa.img = img; xa.img_sn = img_sn;
-    xa.nx = KX / CH_K; xa.N = N;
+    xa.x = KX - KX2 > 0 ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
+    xa.x2 = KX2 > 0 ? x2 : nullptr; xa.x2_sn = x2_sn; xa.x2_row = x2_row;
+    xa.img = img; xa.img_sn = img_sn;
+    xa.nx = KX / CH_K; xa.nx1 = (KX - KX2) / CH_K; xa.N = N;
     static bool lds_set = false;
     const int lb = (int)(LDSX_FLOATS * sizeof(float));
     if (!lds_set) {

@@ -167,19 +167,19 @@ def lstm_wimage(wx, wh, out=None):
 
 
 def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, what):
-    """nmarl_lstm_step_x: xs = (x [N,E,KX] or None, wx (unused here: it is inside the image), image)."""
+    """nmarl_lstm_step_x: xs = (x [N,E,KX1] or None, wx (unused here: it is inside the image), image[, x2 [N,E,KX2]]):
+    the LSTM input is [x | x2] (x2 optional)."""
     N, E, H = h.shape
-    x, _, img = xs
-    if x is None:
-        xp, x_sn, x_row, KX = None, 0, 0, 0
-    else:
-        KX = x.shape[2]
-        xp, x_sn, x_row = _rows_view(x, KX, what + ' x')
+    x, _, img = xs[:3]
+    x2 = xs[3] if len(xs) > 3 else None
+    xp, x_sn, x_row, K1 = (None, 0, 0, 0) if x is None else (*_rows_view(x, x.shape[2], what + ' x'), x.shape[2])
+    x2p, x2_sn, x2_row, K2 = (None, 0, 0, 0) if x2 is None else (*_rows_view(x2, x2.shape[2], what + ' x2'), x2.shape[2])
+    KX = K1 + K2
     if img.shape != (N, lib.nmarl_lstm_wimage_floats(KX)):
         raise _lib.NmarlError('%s: weight image does not match KX = %d' % (what, KX))
-    check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
-                                *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out),
-                                *_pn(h_out), None if head is None else C.byref(head), stream()), what)
+    check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, K2, x2p, x2_sn, x2_row, *_pn(h), ptr(img, F32), img.stride(0),
+                                *_bias(bias), *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
+                                *_pn(c_out), *_pn(h_out), None if head is None else C.byref(head), stream()), what)
 
 
 def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=None):
@@ -202,11 +202,13 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
 HEAD_MAX_A = 8      # widest action set the fused head epilogue supports (csrc/lstm_mfma.hip: MAXA)
 
 
-def _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, head, what, xs=None):
+def _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, head, what, xs=None, gates=None):
     N, E, H = h.shape
     if xs is not None:
-        _step_x(h, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out, xs, head, what)
+        _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, what)
         return
+    if gates is not None:
+        raise _lib.NmarlError('%s: gates output needs the x-side mode' % what)
     if wh.stride(2) != 1 or wh.stride(1) != 4 * H:
         raise _lib.NmarlError('%s: wh must be [N,H,4H] with contiguous [H,4H] panels' % what)
     check(lib.nmarl_lstm_step_fused_head(E, N, H, *_pn(h), ptr(wh, F32, strided=True), wh.stride(0), *_bias(bias),
@@ -222,7 +224,7 @@ def _head_param(w, what):
 
 
 def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode,
-                     u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
+                     u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None, gates=None):
     """forward('p') of one lock-step in ONE kernel: the fused step (lstm_step_fused), then in its epilogue
     pi = softmax(h' @ pi_w + pi_b) -> pi_out [N,E,A] and the action draw of sample_actions -> act_out [E,N]."""
     N, E, H = h.shape
@@ -234,7 +236,7 @@ def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w
     hd.pi_out, hd.pi_sn = _pn(pi_out)
     hd.act_out, hd.u = ptr(act_out, torch.uint8), ptr(u, F32)
     hd.seed, hd.env_id_base, hd.step, hd.step_dev = seed, env_id_base, int(step), ptr(step_dev, torch.int64)
-    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[p]', xs)
+    _fused_head(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, hd, 'nmarl_lstm_step_fused_head[p]', xs, gates)
     return pi_out, act_out
 
 

@@ -329,6 +329,8 @@ int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t H, const float* h_i
  * x: the LSTM input of one lock-step -- fc output (KX = n_fc), the [fcs | fcp] concatenation of policies.py:176-181
  * (KX = 2 n_fc), lstm_comm's [hx | hp | hm] (KX = 3 H), lstm_ic3's s (KX = H) -- with agent stride x_sn and row pitch
  * x_row >= KX (floats, multiples of 4; a column block of a wider buffer is read in place).  zadd1 / zadd2 may be NULL.
+ * KX2 > 0: the LAST KX2 columns of x come from a second tensor x2 [N,E,KX2] (x then holds the first KX - KX2): the
+ * value re-step of a coupled net re-uses the observation / fingerprint encodings and swaps in the re-computed message.
  * The weights come as the chunked image nmarl_lstm_wimage builds from wx [N,KX,4H] and wh [N,H,4H] (agent strides in
  * floats): per agent nmarl_lstm_wimage_floats(KX) = (KX+64)*320 floats, image[k][c][t] = W[k][16t+c] for t < 16, 4
  * floats of padding per (k,c); rebuild it whenever the weights change (once per update).  H = 64 only.
@@ -337,6 +339,7 @@ int nmarl_lstm_wimage_floats(int32_t KX);
 int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t wx_sn, const float* wh, int64_t wh_sn,
                       float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                      int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
                       const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
                       int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
                       const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,

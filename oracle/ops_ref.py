@@ -112,8 +112,12 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
     product x @ wx is part of the step (z = x @ wx + (h*(1-done)) @ wh (+ zadd1) (+ zadd2))."""
     keep = (1.0 - done).view(1, -1, 1)
     z = torch.bmm(h * keep, wh)
-    if xs is not None and xs[0] is not None:
-        z = z + torch.bmm(xs[0], xs[1])
+    if xs is not None:
+        x = xs[0]
+        if len(xs) > 3 and xs[3] is not None:          # [x | x2]: the last columns of the LSTM input from a second tensor
+            x = xs[3] if x is None else torch.cat([x, xs[3]], dim=-1)
+        if x is not None:
+            z = z + torch.bmm(x, xs[1])
     if zadd1 is not None:
         z = z + zadd1
     if zadd2 is not None:
@@ -129,9 +133,9 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
 
 
 def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode,
-                     u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None):
+                     u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None, gates=None):
     """forward('p') (policies.py:119-123, 50-57) + the action draw (utils.py:135-141) after one LSTM step."""
-    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, None, c_out, h_out, xs=xs)
+    lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=xs)
     pi_out.copy_(torch.softmax(torch.bmm(h_out, pi_w) + pi_b.unsqueeze(1), dim=-1))
     sample_actions(pi_out, act_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
     return pi_out, act_out

@@ -192,25 +192,40 @@ class CoupledSequenceSaved(torch.autograd.Function):
         dh_rec = None
         dc = torch.zeros(N, E, H, dtype=F32, device=dev)
         dc_next = torch.empty_like(dc)
+        fused = ops.bptt_supported(H) and wxm.stride(2) == 1 and wxm.stride(1) == H4 and wh.stride(2) == 1 and wh.stride(1) == H4
+        if fused:     # cell backward + [dx | dh] = dz @ [wxm; wh]^T (+ relu mask, + done mask) in one MFMA kernel per step
+            ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
+            dhd_buf = torch.empty(N, E, H, dtype=F32, device=dev)
         for t in range(T - 1, -1, -1):
-            ops.cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
-            dc, dc_next = dc_next, dc
-            if w2_t is not None:
-                d2 = torch.bmm(dZ[:, t], w2_t)
-                dx, dhd = d2[..., :H], d2[..., H:]
+            if fused:
+                ops.bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next,
+                              dhd_buf, t in masked, dx=DS[:, t] if kind == 'dial' else D1[:, t],
+                              mask=hm[:, t] if kind == 'nc' else None)
+                dc, dc_next = dc_next, dc
+                dhd = dhd_buf
+                if kind == 'dial':
+                    torch.mul(DS[:, t], (hm[:, t] > 0), out=D1[:, t])
             else:
-                dx, dhd = torch.bmm(dZ[:, t], wxm_t), torch.bmm(dZ[:, t], wh_t)
-            if t in masked:
-                dhd = dhd * keep[t].view(1, E, 1)
+                ops.cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
+                dc, dc_next = dc_next, dc
+                if w2_t is not None:
+                    d2 = torch.bmm(dZ[:, t], w2_t)
+                    dx, dhd = d2[..., :H], d2[..., H:]
+                else:
+                    dx, dhd = torch.bmm(dZ[:, t], wxm_t), torch.bmm(dZ[:, t], wh_t)
+                if t in masked:
+                    dhd = dhd * keep[t].view(1, E, 1)
+                if kind == 'ic3':
+                    D1[:, t].copy_(dx)
+                else:
+                    if kind == 'dial':
+                        DS[:, t].copy_(dx)
+                    torch.mul(dx, (hm[:, t] > 0), out=D1[:, t])
             if kind == 'nc':
-                torch.mul(dx, (hm[:, t] > 0), out=D1[:, t])
                 dh_msg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
             elif kind == 'ic3':
-                D1[:, t].copy_(dx)
                 dh_msg = ops.nbr_mean_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx)
             else:
-                DS[:, t].copy_(dx)
-                torch.mul(dx, (hm[:, t] > 0), out=D1[:, t])
                 dmsg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
                 torch.mul(dmsg, (A2[:, t] > 0), out=D2[:, t])
                 dh_msg = torch.bmm(D2[:, t], mfc_w.transpose(1, 2))

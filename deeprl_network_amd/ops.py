@@ -598,6 +598,39 @@ def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
                                   *_pn(dh2), *_pn(dc), *_pn(dz), *_pn(dc_prev), stream()), 'nmarl_lstm_cell_bwd')
 
 
+def bptt_supported(H):
+    return H == FUSED_H
+
+
+def lstm_bptt_wimage(wxm, wh, out=None):
+    """LDS image of [wxm; wh]^T for bptt_step: wxm [N,64,4H] (rows of the x-side weight that meet the h-dependent input
+    part) or None, wh [N,H,4H]; rebuild when the weights change."""
+    N = wh.shape[0]
+    KM = 0 if wxm is None else wxm.shape[1]
+    n = lib.nmarl_lstm_bptt_wimage_floats(KM)
+    if out is None:
+        out = torch.empty(N, n, dtype=F32, device=wh.device)
+    if wh.stride(2) != 1 or wh.stride(1) != wh.shape[2] or (wxm is not None and (wxm.stride(2) != 1 or wxm.stride(1) != wxm.shape[2])):
+        raise _lib.NmarlError('lstm_bptt_wimage: weights need contiguous per-agent panels')
+    check(lib.nmarl_lstm_bptt_wimage(N, KM, ptr(wxm, F32, strided=True), 0 if wxm is None else wxm.stride(0),
+                                     ptr(wh, F32, strided=True), wh.stride(0), ptr(out, F32), out.stride(0), stream()),
+          'nmarl_lstm_bptt_wimage')
+    return out
+
+
+def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None):
+    """cell_bwd + the dgrad product of one reverse step in ONE MFMA kernel (nmarl_lstm_bptt_step):
+    dz, dc_prev as cell_bwd; dhd [N,E,H] = (dz @ wh^T) (* (1-done) if apply_keep); dx [N,E,64] = dz @ wxm^T, zeroed where
+    mask <= 0.  ws = (wxm or None, wh, image from lstm_bptt_wimage)."""
+    N, E, H4 = gates.shape
+    wxm, _, img = ws
+    KM = 0 if wxm is None else wxm.shape[1]
+    mp, m_sn, m_row = (None, 0, 0) if mask is None else _rows_view(mask, mask.shape[2], 'bptt_step mask')
+    check(lib.nmarl_lstm_bptt_step(E, N, H4 // 4, KM, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh), *_pn(dh2),
+                                   *_pn(dc), ptr(img, F32), img.stride(0), *_pn(dz), *_pn(dc_prev), *_pn(dx), mp, m_sn, m_row,
+                                   *_pn(dhd), 1 if apply_keep else 0, stream()), 'nmarl_lstm_bptt_step')
+
+
 class _LstmCell(torch.autograd.Function):
     """(z [N,E,4H], bias [N,4H], c_prev [N,E,H], done [E]) -> (h_new, c_new)."""
 
@@ -755,12 +788,22 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds):
     dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
     dc_next = torch.empty_like(dc)
     wh_t = wh.transpose(1, 2)
-    for t in range(T - 1, -1, -1):
-        cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
-        dc, dc_next = dc_next, dc
-        dh_rec = torch.bmm(dZ[:, t], wh_t)
-        if t in masked:
-            dh_rec = dh_rec * keep[t].view(1, E, 1)
+    if bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4:
+        # fused reverse step: cell backward + dz @ wh^T in one MFMA kernel, dh_rec ping-pongs between two buffers
+        ws = (None, wh, lstm_bptt_wimage(None, wh))
+        dh_a, dh_b = torch.empty_like(dc), torch.empty_like(dc)
+        for t in range(T - 1, -1, -1):
+            bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next, dh_a,
+                      t in masked)
+            dc, dc_next = dc_next, dc
+            dh_rec, dh_a, dh_b = dh_a, dh_b, dh_a
+    else:
+        for t in range(T - 1, -1, -1):
+            cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
+            dc, dc_next = dc_next, dc
+            dh_rec = torch.bmm(dZ[:, t], wh_t)
+            if t in masked:
+                dh_rec = dh_rec * keep[t].view(1, E, 1)
     dZf = dZ.view(N, T * E, H4)
     if len(masked) == T:
         Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)

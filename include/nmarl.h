@@ -346,6 +346,28 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
                       float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
                       void* stream);
 /*
+ * One reverse step of the unrolled LSTM training graph (agents/utils.py:102-113, 199-208, 401-408, 585-593), the cell
+ * backward and the dgrad product fused on the matrix cores (H = 64):
+ *   dz = d cell/d z from gates / c_prev / c_new / done and dL/dh' = dh + dh2, dL/dc' = dc_in   (as nmarl_lstm_cell_bwd)
+ *   [dx | dhd] = dz @ [wxm; wh]^T;   dhd *= (1 - done) if apply_keep;   dx = 0 where mask <= 0 (mask optional)
+ * KM = 0: only dhd [N,E,64] (uncoupled nets: the recurrent part of dL/dh_{t-1}); KM = 64: also dx [N,E,64], the
+ * gradient of the h-dependent part of the LSTM input (lstm_comm's message third hm with mask = hm for its relu;
+ * lstm_ic3's / lstm_dial's s with mask = NULL resp. hm).  dz [N,E,4H] and dc_prev [N,E,H] are written as by
+ * nmarl_lstm_cell_bwd.  The weights come as the image nmarl_lstm_bptt_wimage builds from wxm [N,KM,4H] (the rows of the
+ * x-side weight that meet that input part; NULL for KM = 0) and wh [N,H,4H]: nmarl_lstm_bptt_wimage_floats(KM) =
+ * 256*(KM+64) floats per agent; rebuild it whenever the weights change.  mask: row pitch mask_row >= 64.
+ */
+int nmarl_lstm_bptt_wimage_floats(int32_t KM);
+int nmarl_lstm_bptt_wimage(int32_t N, int32_t KM, const float* wxm, int64_t wxm_sn, const float* wh, int64_t wh_sn,
+                           float* img, int64_t img_sn, void* stream);
+int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t H, int32_t KM, const float* gates, int64_t gates_sn,
+                         const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
+                         const float* done, const float* dh, int64_t dh_sn, const float* dh2, int64_t dh2_sn,
+                         const float* dc_in, int64_t dc_sn, const float* img, int64_t img_sn, float* dz,
+                         int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn, float* dx, int64_t dx_sn,
+                         const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
+                         int32_t apply_keep, void* stream);
+/*
  * y[n,r,:W] = act(x[n,r,:] + bias[n,:]) for x [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the
  * lstm_comm / lstm_ic3 encoders (agents/utils.py:196-198, 400) after a plain batched GEMM.

@@ -65,6 +65,29 @@ def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):
     dc_prev.copy_(g_c * gf * keep)
 
 
+def bptt_supported(H):
+    return H == 64
+
+
+def lstm_bptt_wimage(wxm, wh, out=None):
+    return torch.zeros(wh.shape[0], 1) if out is None else out     # kernel-side layout; the restatement uses wxm / wh
+
+
+def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None):
+    """One reverse step of the unrolled LSTM graph: cell backward, then [dx | dhd] = dz @ [wxm; wh]^T."""
+    cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=dh2)
+    wxm, wh, _ = ws
+    r = torch.bmm(dz, wh.transpose(1, 2))
+    if apply_keep:
+        r = r * (1.0 - done).view(1, -1, 1)
+    dhd.copy_(r)
+    if wxm is not None:
+        v = torch.bmm(dz, wxm.transpose(1, 2))
+        if mask is not None:
+            v = v * (mask > 0)
+        dx.copy_(v)
+
+
 def nbr_onehot(action, nbr_idx, n_a, out=None):
     """one_hot(boolean_mask(action, mask_i)) -> [N,E,m_max*A] (policies.py:66-68, 305)."""
     E, N = action.shape

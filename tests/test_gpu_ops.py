@@ -719,3 +719,46 @@ def test_lstm_sequence_x_fwd_bwd():
     torch.testing.assert_close(out_g.detach().cpu().double(), out_r.detach(), rtol=1e-4, atol=1e-5)
     for name, a, bb in zip('s wx wh b h0 c0'.split(), gpu_in, ref_in):
         torch.testing.assert_close(a.grad.cpu().double(), bb.grad, rtol=2e-3, atol=2e-4, msg=lambda m, n=name: '%s: %s' % (n, m))
+
+
+@pytest.mark.parametrize('N,E', [(8, 4096), (8, 1), (25, 130), (3, 127)])
+@pytest.mark.parametrize('KM,masked,with_rec', [(0, True, True), (0, False, False), (64, True, True), (64, False, True)])
+def test_lstm_bptt_step_fused(N, E, KM, masked, with_rec):
+    """nmarl_lstm_bptt_step (cell backward + [dx | dh] = dz @ [wxm; wh]^T on MFMA, relu / done masks) vs the float64
+    restatement: strided sequence slots, ragged rows, absent recurrent / cell gradients."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 31 + E + KM)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    gates = torch.cat([torch.sigmoid(r(N, E, 3 * H)), torch.tanh(r(N, E, H))], dim=-1)
+    c_prev, c_new = r(N, E, H), r(N, E, H) * 0.8
+    done = (torch.rand(E, generator=g) < 0.3).float()
+    dh, dh2, dc = r(N, E, H), (r(N, E, H) if with_rec else None), (r(N, E, H) if with_rec else None)
+    wh = r(N, H, 4 * H) * 0.2 + torch.arange(4 * H).view(1, 1, -1) * 1e-3 + torch.arange(H).view(1, -1, 1) * 2e-3
+    wxm = None if KM == 0 else r(N, KM, 4 * H) * 0.2 + torch.arange(4 * H).view(1, 1, -1) * 1e-3
+    hm = torch.relu(r(N, E, 3 * H))                       # the mask: last third of a [N,E,3H] LSTM input (row pitch 192)
+    f64 = lambda t: None if t is None else t.double()                                    # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
+    dz_r, dcp_r, dhd_r = torch.empty(N, E, 4 * H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
+    dx_r = torch.empty(N, E, H, dtype=torch.float64) if KM else None
+    mask_r = f64(hm[:, :, 2 * H:]) if (KM and masked) else None
+    ops_ref.bptt_step(f64(gates), f64(c_prev), f64(c_new), f64(done), f64(dh), f64(dh2), f64(dc), (f64(wxm), f64(wh), None), dz_r,
+                      dcp_r, dhd_r, masked, dx=dx_r, mask=mask_r)
+    ws = (cu(wxm), cu(wh), ops.lstm_bptt_wimage(cu(wxm), cu(wh)))
+    G = torch.zeros(N, 3, E, 4 * H, device='cuda'); G[:, 1].copy_(gates)
+    C = torch.zeros(N, 3, E, H, device='cuda'); C[:, 1].copy_(c_prev); C[:, 2].copy_(c_new)
+    dZ = torch.zeros(N, 3, E, 4 * H, device='cuda')
+    dcp, dhd = torch.zeros(N, E, H, device='cuda'), torch.zeros(N, E, H, device='cuda')
+    dxg = torch.zeros(N, 2, E, H, device='cuda') if KM else None
+    hmg = cu(hm)
+    ops.bptt_step(G[:, 1], C[:, 1], C[:, 2], cu(done), cu(dh), cu(dh2), cu(dc), ws, dZ[:, 1], dcp, dhd, masked,
+                  dx=None if dxg is None else dxg[:, 1], mask=hmg[:, :, 2 * H:] if (KM and masked) else None)
+    tol = dict(rtol=2e-5, atol=3e-6)
+    torch.testing.assert_close(dZ[:, 1].cpu().double(), dz_r, **tol)
+    torch.testing.assert_close(dcp.cpu().double(), dcp_r, **tol)
+    torch.testing.assert_close(dhd.cpu().double(), dhd_r, rtol=1e-4, atol=2e-5)
+    assert torch.all(dZ[:, 0] == 0) and torch.all(dZ[:, 2] == 0)
+    if KM:
+        torch.testing.assert_close(dxg[:, 1].cpu().double(), dx_r, rtol=1e-4, atol=2e-5)
+        assert torch.all(dxg[:, 0] == 0)

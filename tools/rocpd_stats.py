@@ -52,8 +52,17 @@ def main():
             else:
                 cnt[short(r[0])] += 1
                 tt[short(r[0])] += d
-        for k, v in cnt.most_common(12):
+        for k, v in cnt.most_common(16):
             print('   %4d x %8.1f us total  %s' % (v, tt[k], k))
+        # the rollout part: per kernel totals (the hipGraph of n_step lock-steps + bootstrap)
+        cnt, tt = Counter(), Counter()
+        for r in seg[end:]:
+            cnt[short(r[0])] += 1
+            tt[short(r[0])] += (r[2] - r[1]) / 1e3
+        print('rollout: %d kernels, span %.2f ms, busy %.2f ms' % (len(seg) - end, (seg[-1][2] - seg[end][1]) / 1e6,
+                                                                  sum(tt.values()) / 1e3))
+        for k, v in sorted(tt.items(), key=lambda kv: -kv[1])[:14]:
+            print('   %4d x %8.1f us total (avg %6.1f)  %s' % (cnt[k], v, v / cnt[k], k))
 
 
 if __name__ == '__main__':

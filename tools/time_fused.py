@@ -67,3 +67,18 @@ u3 = timed('x-side policy+value (kind 3)', lambda: ops.lstm_step_policy_value(h,
 f3 = flops_x + 2.0 * N * E * H * 4 * H
 print('    -> %.1f TFLOP/s = %.2f of the fp32 matrix peak (incl. the value re-step)' % (f3 / u3 / 1e6, f3 / u3 / 157.3e6))
 timed('weight image rebuild', lambda: ops.lstm_wimage(wx, wh, out=img))
+
+# ---- the reverse step: cell_bwd + dgrad GEMM vs the fused BPTT step
+G = torch.cat([torch.sigmoid(r(N, E, 3 * H)), torch.tanh(r(N, E, H))], dim=-1)
+cp, cn, dh, dh2, dc = r(N, E, H), r(N, E, H), r(N, E, H), r(N, E, H), r(N, E, H)
+dz, dcp, dhd, dx = torch.empty(N, E, 4 * H, device='cuda'), torch.empty(N, E, H, device='cuda'), torch.empty(N, E, H, device='cuda'), torch.empty(N, E, H, device='cuda')
+wxm = r(N, H, 4 * H) * 0.2
+wh_t = wh.transpose(1, 2)
+timed('cell_bwd', lambda: ops.cell_bwd(G, cp, cn, done, dh, dc, dz, dcp, dh2=dh2))
+timed('dgrad GEMM dz @ wh^T', lambda: torch.bmm(dz, wh_t, out=dhd))
+ws0 = (None, wh, ops.lstm_bptt_wimage(None, wh))
+ws1 = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
+ub = timed('fused BPTT step (dh only)', lambda: ops.bptt_step(G, cp, cn, done, dh, dh2, dc, ws0, dz, dcp, dhd, True))
+nb = N * E * (4 * H + 5 * H + 4 * H + 2 * H) * 4
+print('    -> %.1f MB algorithmic -> %.2f TB/s' % (nb / 1e6, nb / ub / 1e6))
+timed('fused BPTT step ([dx | dh], relu mask)', lambda: ops.bptt_step(G, cp, cn, done, dh, dh2, dc, ws1, dz, dcp, dhd, True, dx=dx, mask=cp))

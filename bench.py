@@ -56,6 +56,7 @@ def b_alg(obs_floats):
 # the product writes the 'ia2c' pre-gathered observation, sum n_s = 110 floats = 440 B
 # (declared variant of SURVEY.md 8d; the 2 zero pad slots of the edge vehicles are NOT counted).
 B_ALG_GATHERED = b_alg(110)
+B_ALG_COMPACT = b_alg(40)       # 351 B: what the batched engine's env kernel moves (p.compact_obs)
 
 
 def parse():
@@ -321,7 +322,8 @@ def main():
     is_grid = env.name.startswith('atsc')
     n_agent = env.n_agent
     # algorithmic bytes per replica-step of the env kernel
-    balg = 7548 if is_grid else B_ALG_GATHERED
+    balg = 7548 if is_grid else (B_ALG_COMPACT if trainer.compact_obs else B_ALG_GATHERED)
+    obs_variant = 'compact [E,8,5] observation' if trainer.compact_obs else 'gathered [E,8,15] observation'
     kname = 'grid_step_kernel (nmarl_grid_step)' if is_grid else 'cacc_step_kernel (nmarl_cacc_step)'
     if env.name.endswith('real_net'):
         # q, transit in and out (4 B x 2 x 2 x 264 links) + action / prev bytes + scalars + the padded neighbour slab
@@ -358,7 +360,9 @@ def main():
                     'peak': MFMA_F32_PEAK_TFLOPS if x_side else HBM_PEAK_GBPS,
                     'unit': 'TFLOP/s' if x_side else 'GB/s',
                     'frac': ach / MFMA_F32_PEAK_TFLOPS if x_side else bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
-                    'traffic': None, 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
+                    'traffic': (lambda t: None if (t[0] is None or not x_side or n_agent * E != 8 * 4096) else t[0] * n_agent * E)(
+                        pmc_traffic('lstm_step_x_N8_E4096')),
+                    'traffic_source': pmc_traffic('lstm_step_x_N8_E4096')[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
                     'rows_per_launch': n_agent * E, 'launches_per_batch': n_step + 1,
                     'hbm_frac_of_same_launch': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
                     'how': 'hipGraph of 60 launches on the model shapes and weights, 10 replays between two HIP events on '
@@ -373,7 +377,8 @@ def main():
         tape = model.buf_act.clone()
         us = measure_step_kernel(env, tape)
         ach = balg * E / us / 1e3
-        tr_small, tr_src = pmc_traffic('cacc_step_E4096') if (not is_grid and E == 4096) else (None, None)
+        pk = 'cacc_step_compact' if trainer.compact_obs else 'cacc_step'
+        tr_small, tr_src = pmc_traffic(pk + '_E4096') if (not is_grid and E == 4096) else (None, None)
         out['roofline_env_step'] = {
             'kernel': kname, 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
             'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': None if tr_small is None else tr_small * E,
@@ -381,15 +386,17 @@ def main():
             'bytes_per_launch': balg * E, 'us_per_launch': us, 'replicas_per_launch': E,
             'how': 'hipGraph of %d back-to-back step launches on the rollout state with the batch action tape, '
                    '20 replays between two HIP events on the launch stream (includes graph-node gaps). '
-                   'B_alg = %d B/replica-step. At E=%d the launch moves %.2f MB: '
+                   'B_alg = %d B/replica-step (%s). At E=%d the launch moves %.2f MB: '
                    'latency-bound and LLC-resident (SURVEY.md H1); see roofline_env_step_large_E for the HBM regime.'
-                   % (n_step, balg, E, balg * E / 1e6)}
+                   % (n_step, balg, obs_variant, E, balg * E / 1e6)}
         if 'roofline' not in out or 'error' in out['roofline']:
             out['roofline'] = dict(out['roofline_env_step'])
         if world == 1 and not is_grid:
             try:
                 big_E = 1 << 21
                 big = make_batch_env(cp['ENV_CONFIG'], num_envs=big_E, device=device, env_id_base=10 ** 7)
+                if trainer.compact_obs:
+                    big.set_compact_obs(True)
                 big.reset()
                 e = torch.arange(big_E, device=device)[:, None]
                 a = torch.arange(N_AGENT, device=device)[None, :]
@@ -398,14 +405,14 @@ def main():
                     big.step(big_tape[k % 8], auto_reset=True)
                 us_b = measure_step_kernel(big, big_tape, reps=5)
                 ach_b = balg * big_E / us_b / 1e3
-                tr_big, tr_src_b = pmc_traffic('cacc_step_E2p21')
+                tr_big, tr_src_b = pmc_traffic(pk + '_E2p21')
                 out['roofline_env_step_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,
                                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
                                                     'traffic': None if tr_big is None else tr_big * big_E,
                                                     'traffic_source': tr_src_b,
                                                     'replicas_per_launch': big_E, 'us_per_launch': us_b,
                                                     'bytes_per_launch': balg * big_E,
-                                                    'how': 'same kernel at E=2^21 (working set >> 256 MB Infinity Cache), '
+                                                    'how': 'same kernel (' + obs_variant + ') at E=2^21 (working set >> 256 MB Infinity Cache), '
                                                            'actions (env+3*agent+step) mod 4 (SURVEY.md 8d)'}
                 del big
             except Exception as ex:      # never lose the headline line to the side measurement

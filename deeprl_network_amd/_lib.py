@@ -35,7 +35,7 @@ class CaccParams(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ('dt', 'h_min', 'h_star', 'h_s', 'h_g', 'v_max', 'v_star', 'u_min', 'u_max',
                  'reward_a', 'reward_b', 'G')] + \
-               [(n, C.c_int32) for n in ('T', 'batch_size', 'scenario', 'train_mode', 'per_agent_reward')]
+               [(n, C.c_int32) for n in ('T', 'batch_size', 'scenario', 'train_mode', 'per_agent_reward', 'compact_obs')]
 
 
 class Head(C.Structure):

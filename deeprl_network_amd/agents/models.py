@@ -203,6 +203,19 @@ class IA2C:
         self.save_acts = True
         return True
 
+    def enable_compact_obs(self):
+        """Batched engine: the env writes compact observations [E,N,n_feat] (own features only); the rollout's encoder
+        gathers the neighbours inside its kernel and update() expands the batch once (policy.expand_obs)."""
+        p = self.policy
+        if p.hetero or p.n_obs == p.n_feat:
+            return False
+        T, E, N = self.n_step, self.E, self.n_agent
+        self.buf_x = torch.zeros(T + 1, E, N, p.n_feat, dtype=F32, device=self.device)
+        self.compact_obs = True
+        return True
+
+    compact_obs = False
+
     def _save_slots(self, t):
         """Slots of lock-step t in the saved activations, for the policy step of a coupled net."""
         d = {k: v[:, t] for k, v in self.policy._extra.items()}
@@ -382,12 +395,12 @@ class IA2C:
         ps = self.policy.params
         ps.grad.zero_()
         FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
+        X = self.policy.expand_obs(self.buf_x[:T]) if self.compact_obs else self.buf_x[:T]
         if self.save_acts:
-            Hs = self.policy.unroll_saved(self.buf_x[:T], FP, self.S_buf, self.G_buf, self.H_all, self.C_all,
+            Hs = self.policy.unroll_saved(X, FP, self.S_buf, self.G_buf, self.H_all, self.C_all,
                                           self.buf_done_pre, masked_steps=self.masked_steps)
         else:
-            Hs = self.policy.unroll(self.buf_x[:T], FP, self.buf_done_pre, self.h_bw, self.c_bw,
-                                    masked_steps=self.masked_steps)
+            Hs = self.policy.unroll(X, FP, self.buf_done_pre, self.h_bw, self.c_bw, masked_steps=self.masked_steps)
         loss = self._loss(Hs)
         loss.backward()
         if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)

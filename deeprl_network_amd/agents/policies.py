@@ -215,6 +215,8 @@ class BatchedPolicy:
             raise ValueError('heterogeneous agents: n_feat / n_a must be the maxima of n_feat_ls / n_a_ls')
         tab = self.nbr_idx.cpu().numpy()
         self.nbrs = [[int(j) for j in tab[i] if j >= 0] for i in range(self.N)]
+        # [own | neighbours] gather table for compact observations: slot 0 = the agent itself
+        self.nbr_self = torch.cat([torch.arange(self.N, dtype=torch.int32, device=self.device).view(-1, 1), self.nbr_idx], dim=1)
         self.n_obs = n_feat * (1 + self.m_max)          # gathered observation slab width
         self.n_na = n_a * self.m_max                    # neighbour one-hot width
         self.params = ParamStore(self.N, self._phases(), self.device)
@@ -416,7 +418,30 @@ class BatchedPolicy:
 
     def _enc_one_launch(self, xv, width):
         """Observation and fingerprint encoders fit the multi-layer fc kernel (inputs <= 64 wide, 64 outputs)."""
-        return width == ops.FC_J and xv.shape[2] <= ops.FC_MAX_F and self.n_na <= ops.FC_MAX_F
+        return width == ops.FC_J and self.n_obs <= ops.FC_MAX_F and self.n_na <= ops.FC_MAX_F
+
+    def _compact(self, xv):
+        """xv holds each agent's OWN features only ([N,rows,n_feat], the env's compact observation): the observation
+        encoder gathers [own | neighbours] through `nbr_self` inside the fc kernel."""
+        return xv.shape[2] == self.n_feat and self.n_obs != self.n_feat
+
+    def _ob_part(self, xv, w_key, b_key):
+        p = self.params
+        return (xv, p[w_key], p[b_key], self.nbr_self if self._compact(xv) else None)
+
+    def _fc_ob_infer(self, xv, w_key, b_key, act, out=None):
+        """The observation encoder layer act([x_i, x_nbr] W + b) (policies.py:145, 177; agents/utils.py:186-197, 395-399)
+        on the gathered slab or on the compact observation."""
+        if self._compact(xv):
+            return ops.fc_fwd_multi([self._ob_part(xv, w_key, b_key)], act, out=out)
+        return self._fc_infer(xv, w_key, b_key, act, out=out)
+
+    def expand_obs(self, X):
+        """Compact observations [..., N, n_feat] -> the gathered slab [..., N, n_obs] ([own | neighbours ascending],
+        zero padded): what the update's encoders read (one gather pass over the batch)."""
+        idx = self.nbr_self.long()
+        g = X[..., idx.clamp(min=0), :] * (idx >= 0).to(X.dtype).unsqueeze(-1)       # [..., N, 1+m, n_feat]
+        return g.reshape(*X.shape[:-1], self.n_obs)
 
     def _fc_infer(self, x, w_key, b_key, act, out=None):
         """act(x @ W + b) with the bias/activation fused in one pass (no autograd); `out` may be a column
@@ -517,7 +542,7 @@ class LstmPolicy(BatchedPolicy):
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp, out=None):
-        s = self._fc_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU, out=out)
+        s = self._fc_ob_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU, out=out)
         return s if self.xside else torch.bmm(s, self.params['lstm_wx'])
 
     def _recur_in(self, enc, h):
@@ -550,11 +575,11 @@ class FPPolicy(LstmPolicy):
         nf = self.n_fc
         if self._enc_one_launch(xv, nf):
             # [hx | hp] (policies.py:181) by ONE kernel: both layers, the fingerprint gather folded into the second
-            s = ops.fc_fwd_multi([(xv, p['fcs_w'], p['fcs_b'], None), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)],
+            s = ops.fc_fwd_multi([self._ob_part(xv, 'fcs_w', 'fcs_b'), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)],
                                  ops.BIAS_RELU, out=out)
         else:
             s = torch.empty(self.N, xv.shape[1], 2 * nf, dtype=F32, device=xv.device) if out is None else out
-            self._fc_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
+            self._fc_ob_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
         return s if self.xside else torch.bmm(s, p['lstm_wx'])                          # else ONE K = 2 nf GEMM
 
@@ -613,12 +638,12 @@ class NCMultiAgentPolicy(BatchedPolicy):
         s = None if full is None else full[:, :, :2 * H]
         if self._enc_one_launch(xv, H):
             # [hx | hp] of agents/utils.py:199 by ONE kernel (fingerprint gather folded in)
-            s = ops.fc_fwd_multi([(xv, p['w_ob'], p['w_ob_b'], None), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)],
+            s = ops.fc_fwd_multi([self._ob_part(xv, 'w_ob', 'w_ob_b'), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)],
                                  ops.BIAS_RELU, out=s)
         else:
             if s is None:
                 s = torch.empty(self.N, xv.shape[1], 2 * H, dtype=F32, device=xv.device)
-            self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
+            self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
         return full if self.xside else torch.bmm(s, p['wx_hid'][:, :2 * H])
 
@@ -678,7 +703,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         return self._enc(xv, fp)             # tanh(x~ W_ob + b): recomputed (one streaming pass), only the recurrence is saved
 
     def _enc_infer(self, xv, fp, out=None):
-        return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH)
+        return self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH)
 
     def _x_target(self, h, second, save):
         """Where the LSTM input of this step goes: the slot of the saved activations (policy step of the batched
@@ -718,7 +743,7 @@ class ConsensusPolicy(LstmPolicy):
                  ('lstm_b', 'cu/lstm_%da/b', (4 * H,), None)] + self._head_phase('cu/pi_%da' if self.hetero else 'cu/pi_%d', 'cu/v_%da')]   # policies.py:381-390: the identical branch names the actor head pi_<i>, the hetero one pi_<i>a
 
     def _own(self, xv):
-        return xv[:, :, :self.n_feat]        # the consensus net sees the agent's own features only
+        return xv[:, :, :self.n_feat]        # the consensus net sees the agent's own features only (compact obs: all of xv)
 
     def _enc(self, xv, fp, saved=None):
         p = self.params
@@ -794,7 +819,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         return self._enc(xv, fp)             # recomputed: only the recurrence is saved
 
     def _enc_infer(self, xv, fp, out=None):
-        return self._fc_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU).add_(self._own_action_onehot(fp))
+        return self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU).add_(self._own_action_onehot(fp))
 
     def save_spec(self):
         return {'A1': self.n_h, 'A2': self.n_h}        # hm (post-relu), msg (post-relu): relu masks of the backward

@@ -100,10 +100,14 @@ __device__ __noinline__ double cos_0_pi(double t) {
 
 // _get_veh_state (cacc_env.py:54-65) for this lane's vehicle, then the
 // neighbour gather and the LDS-staged coalesced store of the wave's slab.
-template <int NT>
+// COMPACT: only the vehicle's own 5 features are written ([E,8,5]: SURVEY.md 8d's 41 N + 19 B layout); the policy's
+// encoder gathers the neighbours' features itself (nmarl_fc_fwd_multi with a neighbour table whose slot 0 is the
+// agent).  Otherwise the 'ia2c' pre-gathered observation [E,8,15] of cacc_env.py:70-73.
+template <int NT, bool COMPACT>
 __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, float v, float u,
                                          float v_lead, int a, bool valid, int lane, float* lds_wave,
                                          float* __restrict__ obs_wave, int n_valid_lanes) {
+    constexpr int W = COMPACT ? NF : NOBS;
     float x[NF];
     x[0] = (v - p.v_star) / p.v_star;
     x[1] = clampf((v_lead - v) / 5.0f, -2.0f, 2.0f);
@@ -125,25 +129,27 @@ __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, 
     }
     x[3] = (h + (v_lead - v) * p.dt - p.h_star) / p.h_star;
     x[4] = u / p.u_max;
-    float* row = lds_wave + lane * NOBS;
+    float* row = lds_wave + lane * W;
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        const float lo = __shfl_up(x[k], 1, N);     // vehicle a-1
-        const float hi = __shfl_down(x[k], 1, N);   // vehicle a+1
-        // slots hold the neighbours in ascending index, left-packed (cacc_env.py:72)
-        const float s1 = a == 0 ? hi : lo;
-        const float s2 = (a == 0 || a == N - 1) ? 0.0f : hi;
         row[k] = x[k];
-        row[NF + k] = s1;
-        row[2 * NF + k] = s2;
+        if (!COMPACT) {
+            const float lo = __shfl_up(x[k], 1, N);     // vehicle a-1
+            const float hi = __shfl_down(x[k], 1, N);   // vehicle a+1
+            // slots hold the neighbours in ascending index, left-packed (cacc_env.py:72)
+            const float s1 = a == 0 ? hi : lo;
+            const float s2 = (a == 0 || a == N - 1) ? 0.0f : hi;
+            row[NF + k] = s1;
+            row[2 * NF + k] = s2;
+        }
     }
     __builtin_amdgcn_wave_barrier();
-    // 64 lanes x 15 floats = 240 float4, contiguous in HBM
+    // 64 lanes x W floats = 240 (80) float4, contiguous in HBM
     const float4* src = reinterpret_cast<const float4*>(lds_wave);
     float4* dst = reinterpret_cast<float4*>(obs_wave);
-    const int n_vec = n_valid_lanes * NOBS / 4;  // n_valid_lanes is a multiple of 8 -> exact
+    const int n_vec = n_valid_lanes * W / 4;     // n_valid_lanes is a multiple of 8 -> exact
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (COMPACT ? 2 : 4); ++i) {
         const int idx = i * NMARL_WAVE + lane;
 #if NMARL_CACC_NOOBS
         (void)dst;
@@ -180,7 +186,7 @@ __device__ __forceinline__ float reset_uniform(uint64_t seed, int64_t env_id, in
     return u01_from_bits(r.x);
 }
 
-template <int BLOCK, int NT>
+template <int BLOCK, int NT, bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
     const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ action,
     float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
@@ -188,26 +194,49 @@ __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
     float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
     float* __restrict__ greward, const int auto_reset, const uint64_t seed,
     const int64_t env_id_base, int32_t* __restrict__ episode) {
-    __shared__ __attribute__((aligned(16))) float lds[BLOCK * NOBS];
+    constexpr int W = COMPACT ? NF : NOBS;
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * W];
     const int lane = threadIdx.x & (NMARL_WAVE - 1);
     const int wave = threadIdx.x / NMARL_WAVE;
-    float* lds_wave = lds + wave * NMARL_WAVE * NOBS;
+    float* lds_wave = lds + wave * NMARL_WAVE * W;
     const int64_t n_lanes = E * N;
     const int64_t waves_total = (n_lanes + NMARL_WAVE - 1) / NMARL_WAVE;
     const int64_t wave_stride = (int64_t)gridDim.x * (BLOCK / NMARL_WAVE);
 
-    for (int64_t w = (int64_t)blockIdx.x * (BLOCK / NMARL_WAVE) + wave; w < waves_total; w += wave_stride) {
+    // The inputs of the NEXT tile of this wave are loaded before the current one is computed (one tile = 64 lanes = 8
+    // replicas): the step is a dependent load -> compute -> store chain, and at large E its HBM rate is set by the
+    // bytes in flight.  The prefetch index is clamped, so the loads stay unconditional.
+    int64_t w = (int64_t)blockIdx.x * (BLOCK / NMARL_WAVE) + wave;
+    float h_n = 0.f, v_n = 0.f, v0i_n = 0.f, h_m = 0.f, v_m = 0.f, v0i_m = 0.f;
+    int act_n = 0, t_n = 0, coll_n = 0, act_m = 0, t_m = 0, coll_m = 0;
+#define NMARL_CACC_LOAD(wt, S)                                                             \
+    {                                                                                      \
+        const int64_t wc_ = (wt) < waves_total ? (wt) : waves_total - 1;                   \
+        const int64_t gid_ = wc_ * NMARL_WAVE + lane;                                      \
+        const int64_t g_ = gid_ < n_lanes ? gid_ : n_lanes - 1;                            \
+        h_##S = hs[g_]; v_##S = vs[g_]; act_##S = action[g_];                              \
+        t_##S = ts[g_ >> 3]; coll_##S = coll[g_ >> 3]; v0i_##S = v0_init[g_ >> 3];         \
+    }
+    // two tiles ahead: (n) = tile w, (m) = tile w + stride; a clamped index re-reads the wave's last tile, whose
+    // values are then never used
+    if (w < waves_total) {
+        NMARL_CACC_LOAD(w, n)
+        NMARL_CACC_LOAD(w + wave_stride, m)
+    }
+    for (; w < waves_total; w += wave_stride) {
         const int64_t gid = w * NMARL_WAVE + lane;      // = e*8 + a
         const bool valid = gid < n_lanes;
         const int64_t g = valid ? gid : n_lanes - 1;    // clamp: tail lanes mirror the last vehicle
         const int64_t e = g >> 3;
         const int a = (int)(g & 7);
 
-        float h = hs[g], v = vs[g];
-        const int act = action[g];
-        int t = ts[e];
-        bool collided = coll[e] != 0;
-        float v0i = v0_init[e];
+        float h = h_n, v = v_n;
+        const int act = act_n;
+        int t = t_n;
+        bool collided = coll_n != 0;
+        float v0i = v0i_n;
+        h_n = h_m; v_n = v_m; act_n = act_m; t_n = t_m; coll_n = coll_m; v0i_n = v0i_m;
+        NMARL_CACC_LOAD(w + 2 * wave_stride, m)
         const bool frozen = collided;                                   // :193
 
         const float alpha = (act & 1) ? 0.5f : 0.0f;                    // a_map, :275
@@ -290,23 +319,24 @@ __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
         const int64_t lanes_here = n_lanes - w * NMARL_WAVE;
         const int n_valid = lanes_here >= NMARL_WAVE ? NMARL_WAVE : (int)lanes_here;
         __builtin_amdgcn_wave_barrier();
-        emit_obs<NT>(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
-                     obs + w * NMARL_WAVE * NOBS, n_valid);
+        emit_obs<NT, COMPACT>(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
+                              obs + w * NMARL_WAVE * W, n_valid);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-template <int BLOCK>
+template <int BLOCK, bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void cacc_reset_kernel(
     const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ mask,
     const float* __restrict__ u0, const uint64_t seed, const int64_t env_id_base,
     int32_t* __restrict__ episode, float* __restrict__ hs, float* __restrict__ vs,
     float* __restrict__ us, int32_t* __restrict__ ts, uint8_t* __restrict__ coll,
     float* __restrict__ v0_init, float* __restrict__ obs, float* __restrict__ fp, const int A) {
-    __shared__ __attribute__((aligned(16))) float lds[BLOCK * NOBS];
+    constexpr int W = COMPACT ? NF : NOBS;
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * W];
     const int lane = threadIdx.x & (NMARL_WAVE - 1);
     const int wave = threadIdx.x / NMARL_WAVE;
-    float* lds_wave = lds + wave * NMARL_WAVE * NOBS;
+    float* lds_wave = lds + wave * NMARL_WAVE * W;
     const int64_t n_lanes = E * N;
     const int64_t waves_total = (n_lanes + NMARL_WAVE - 1) / NMARL_WAVE;
     const int64_t wave_stride = (int64_t)gridDim.x * (BLOCK / NMARL_WAVE);
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void cacc_reset_kernel(
         // the slab of a wave is rewritten as a whole; unselected replicas re-emit
         // their current observation (same values), so no read-modify-write is needed
         __builtin_amdgcn_wave_barrier();
-        emit_obs<0>(p, h, v, u, v_lead, a, valid, lane, lds_wave, obs + w * NMARL_WAVE * NOBS, n_valid);
+        emit_obs<0, COMPACT>(p, h, v, u, v_lead, a, valid, lane, lds_wave, obs + w * NMARL_WAVE * W, n_valid);
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -362,6 +392,7 @@ inline int pick_grid(int64_t E, int block) {
 
 bool params_ok(const nmarl_cacc_params_t* p) {
     return p != nullptr && p->T > 0 && p->batch_size > 0 && (p->scenario == 0 || p->scenario == 1) &&
+           (p->compact_obs == 0 || p->compact_obs == 1) &&
            p->dt > 0.f && p->h_g > p->h_s && p->u_max != 0.f && p->v_star != 0.f && p->h_star != 0.f;
 }
 
@@ -388,17 +419,17 @@ extern "C" int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     // small E is latency bound and cache resident: 1-wave blocks spread the replicas over more CUs and
     // plain stores keep the state in L2 for the next step; large E streams (non-temporal stores)
+#define NMARL_CACC_LAUNCH(BLK, NTV, CMP)                                                                              \
+    hipLaunchKernelGGL((cacc_step_kernel<BLK, NTV, CMP>), dim3(pick_grid(E, BLK)), dim3(BLK), 0, s, *p, E, action, h, v, u, t, \
+                       collided, v0_init, obs, reward, done, global_reward, auto_reset, seed, env_id_base, episode)
     if (E * N <= 256 * 4 * NMARL_WAVE) {
-        hipLaunchKernelGGL((cacc_step_kernel<NMARL_CACC_BLOCK_SMALL, NMARL_CACC_NT_SMALL>), dim3(pick_grid(E, NMARL_CACC_BLOCK_SMALL)),
-                           dim3(NMARL_CACC_BLOCK_SMALL), 0, s, *p, E, action, h, v, u,
-                           t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
-                           env_id_base, episode);
+        if (p->compact_obs) NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_SMALL, NMARL_CACC_NT_SMALL, true);
+        else NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_SMALL, NMARL_CACC_NT_SMALL, false);
     } else {
-        hipLaunchKernelGGL((cacc_step_kernel<NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE>), dim3(pick_grid(E, NMARL_CACC_BLOCK_LARGE)),
-                           dim3(NMARL_CACC_BLOCK_LARGE), 0, s, *p, E, action, h, v,
-                           u, t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
-                           env_id_base, episode);
+        if (p->compact_obs) NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE, true);
+        else NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE, false);
     }
+#undef NMARL_CACC_LAUNCH
     return nmarl_check_launch();
 }
 
@@ -412,7 +443,11 @@ extern "C" int nmarl_cacc_reset(const nmarl_cacc_params_t* p, int64_t E, const u
     if (fp && A <= 0) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(cacc_reset_kernel<256>, dim3(pick_grid(E, 256)), dim3(256), 0, s, *p, E, mask, u0, seed,
-                       env_id_base, episode, h, v, u, t, collided, v0_init, obs, fp, A);
+    if (p->compact_obs)
+        hipLaunchKernelGGL((cacc_reset_kernel<256, true>), dim3(pick_grid(E, 256)), dim3(256), 0, s, *p, E, mask, u0, seed,
+                           env_id_base, episode, h, v, u, t, collided, v0_init, obs, fp, A);
+    else
+        hipLaunchKernelGGL((cacc_reset_kernel<256, false>), dim3(pick_grid(E, 256)), dim3(256), 0, s, *p, E, mask, u0, seed,
+                           env_id_base, episode, h, v, u, t, collided, v0_init, obs, fp, A);
     return nmarl_check_launch();
 }

@@ -106,6 +106,17 @@ class CACCBatchEnv:
         """Everything a step mutates (snapshot / restore around hipGraph capture)."""
         return [self.h, self.v, self.u, self.t, self.collided, self.v0_init, self.obs, self.episode, self.done]
 
+    compact_obs = False
+
+    def set_compact_obs(self, flag=True):
+        """Compact observation [E,8,5] (each vehicle's own features, SURVEY.md 8d's 347-B layout) instead of the
+        pre-gathered [E,8,15]: the consumer gathers the neighbours (agents/policies.py `_ob_part`).  Batched engine only
+        (the E = 1 reference duck-type keeps the reference's concatenated observations)."""
+        self.compact_obs = bool(flag)
+        self.params.compact_obs = 1 if flag else 0
+        self.obs = torch.zeros(self.E, self.n_agent, N_FEAT if flag else N_OBS, dtype=torch.float32, device=self.device)
+        return True
+
     @property
     def train_mode(self):
         return self._train_mode

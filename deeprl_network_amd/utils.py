@@ -278,10 +278,13 @@ class BatchedTrainer:
     """
 
     def __init__(self, env, model, global_counter=None, summary_writer=None, output_path=None,
-                 use_graph=True, rank=0, world_size=1, save_activations=True):
+                 use_graph=True, rank=0, world_size=1, save_activations=True, compact_obs=True):
         self.env, self.model = env, model
         # uncoupled nets: the rollout's policy steps double as the forward pass of the update (models.py)
         self.saved_acts = bool(save_activations) and model.enable_saved_activations()
+        # CACC: compact observations (own features only; the encoder gathers the neighbours) -- SURVEY.md 8d's layout
+        self.compact_obs = bool(compact_obs) and hasattr(env, 'set_compact_obs') and model.enable_compact_obs() and \
+            env.set_compact_obs(True)
         self.E, self.N = env.E, env.n_agent
         self.n_step = model.n_step
         assert env.T % self.n_step == 0

@@ -66,6 +66,9 @@ typedef struct nmarl_cacc_params {
     int32_t train_mode;  /* 1: add the soft-collision term (:48-49)               */
     int32_t per_agent_reward; /* coop_gamma >= 0: reward is [E,N]; else the global
                             scalar is broadcast, reward is [E] (:236-237)         */
+    int32_t compact_obs; /* 1: obs is [E,8,5], each vehicle's OWN features only (_get_veh_state,
+                            :54-65; the 'ma2c' observation) and the consumer gathers the
+                            neighbours; 0: the 'ia2c' pre-gathered [E,8,15] (:70-73)       */
 } nmarl_cacc_params_t;
 
 /*
@@ -81,7 +84,7 @@ typedef struct nmarl_cacc_params {
  *   h,v,u     [E,8] f32 headway / speed / constrained acceleration
  *   t         [E] i32 step in episode; collided [E] u8; v0_init [E] f32 (speed
  *             of the leading vehicle at t=0; its profile v0s[t] is analytic)
- *   obs       [E,8,15] f32 gathered observation (see nmarl_cacc_step)
+ *   obs       [E,8,15] f32 gathered observation (see nmarl_cacc_step); [E,8,5] with p->compact_obs
  *   fp        [E,8,A] f32 fingerprints, set to 1/A (:184) -- may be NULL
  */
 int nmarl_cacc_reset(const nmarl_cacc_params_t* p, int64_t E,
@@ -96,7 +99,8 @@ int nmarl_cacc_reset(const nmarl_cacc_params_t* p, int64_t E,
  * _get_reward (:40-52) and _get_state/_get_veh_state (:54-79) for E replicas.
  *
  *   action    [E,8] u8 in 0..3 -> (alpha,beta) = a_map[action] (:275)
- *   obs       [E,8,15] f32: slot 0 = own 5 features, slots 1..2 = the
+ *   obs       [E,8,5] f32 own features (p->compact_obs), or
+ *             [E,8,15] f32: slot 0 = own 5 features, slots 1..2 = the
  *             neighbours' 5 features in ascending vehicle index, zero padded
  *             (the 'ia2c' concatenation of :70-73 and lstm_comm's xi,
  *             agents/utils.py:192-193; the 'ma2c' 5-vector is columns 0..4)

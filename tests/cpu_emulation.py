@@ -52,11 +52,19 @@ class CpuCaccBatchEnv:
         self.global_reward = torch.zeros(num_envs)
 
     train_mode = property(lambda self: self.ref.train_mode, lambda self, f: setattr(self.ref, 'train_mode', bool(f)))
+    compact_obs = False
+
+    def set_compact_obs(self, flag=True):
+        import torch
+        self.compact_obs = bool(flag)
+        self.obs = torch.zeros(self.E, self.n_agent, 5 if flag else 15)
+        return True
 
     def _emit(self):
         import torch
         from oracle.cacc_ref import gather_line
-        self.obs.copy_(torch.from_numpy(gather_line(self.ref.veh_state())))
+        vs = self.ref.veh_state()
+        self.obs.copy_(torch.from_numpy(np_f32(vs) if self.compact_obs else gather_line(vs)))
         return self.obs
 
     def reset(self, mask=None, u0=None):

@@ -186,3 +186,23 @@ def test_full_size_properties(E):
         assert torch.all(env.t[~dn] == k + 1 - 60 * ((env.episode[~dn] - 1) > 0).int() * 0) or True
     assert (env.episode > ep_before).any()   # random actions do collide -> some replicas restarted
     assert torch.isfinite(env.obs).all()
+
+
+@pytest.mark.parametrize('E', [1, 13, 4096])
+def test_compact_observation_is_the_own_feature_block(E):
+    """p.compact_obs: obs [E,8,5] == columns 0..4 of the gathered [E,8,15] slab, identical state / reward / done
+    (reset, steps, auto-reset)."""
+    import torch
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    cp = cacc_config(agent='ia2c', scenario='slowdown')
+    cp['ENV_CONFIG']['episode_length_sec'] = '1'                     # T = 10: the auto-reset path is hit
+    a = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+    b = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+    assert b.set_compact_obs(True) and b.obs.shape == (E, 8, 5)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa[:, :, :5], ob)
+    g = torch.Generator().manual_seed(E)
+    for k in range(25):
+        act = torch.randint(0, 4, (E, 8), generator=g, dtype=torch.uint8).cuda()
+        (oa, ra, da, ga), (ob, rb, db, gb) = a.step(act, auto_reset=True), b.step(act, auto_reset=True)
+        assert torch.equal(oa[:, :, :5], ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(a.h, b.h)

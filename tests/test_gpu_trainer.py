@@ -101,3 +101,31 @@ def test_saved_activations_equal_recomputed_forward():
     torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(out[0][2], out[1][2], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ma2c_ic3'])
+def test_compact_observation_equals_gathered_slab(agent):
+    """CACC: the env writing each vehicle's own 5 features ([E,8,5], the encoder gathers the neighbours inside its
+    kernel, update() expands the batch once) == the env writing the pre-gathered [E,8,15] slab: same actions, values,
+    weights after 3 batches."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    out = []
+    for compact in (True, False):
+        cp = cacc_config(agent=agent, scenario='slowdown', n_step=60, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
+        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=1024)
+        np.random.seed(12)
+        cls = {'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3}[agent]
+        model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                    cp['MODEL_CONFIG'], seed=12, num_envs=1024)
+        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True, compact_obs=compact)
+        assert tr.compact_obs == compact and model.buf_x.shape[-1] == (5 if compact else 15)
+        for _ in range(3):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        out.append((model.policy.params.flat.clone(), model.buf_v.clone(), model.buf_act.clone(), env.h.clone()))
+        del env, model, tr
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)

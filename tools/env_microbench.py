@@ -8,10 +8,11 @@ import torch
 from helpers import cacc_config
 from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
 
-B_ALG = 41 * 8 + 19
+B_ALG = 41 * 8 + 19 + 4        # compact observation + the [E] reward vector = 351 B (bench.py B_ALG_COMPACT)
 
-for E in [4096, 32768, 1 << 18, 1 << 20, 1 << 22]:
+for E in [4096, 32768, 1 << 18, 1 << 20, 1 << 21, 1 << 22]:
     env = CACCBatchEnv(cacc_config()['ENV_CONFIG'], num_envs=E)
+    env.set_compact_obs(True)
     env.reset()
     e = torch.arange(E, device='cuda')[:, None]
     a = torch.arange(8, device='cuda')[None, :]

@@ -24,7 +24,10 @@ for _ in range(3):
     y[:n].copy_(x[1:n + 1])                    # misaligned source: scalar 4 B / lane loads
 torch.cuda.synchronize()
 E = int(os.environ.get('PMC_E', 1 << 21))
+COMPACT = os.environ.get('PMC_COMPACT', '1') == '1'          # the batched engine's variant: obs [E,8,5]
 env = CACCBatchEnv(cacc_config()['ENV_CONFIG'], num_envs=E)
+if COMPACT:
+    env.set_compact_obs(True)
 env.reset()
 e = torch.arange(E, device='cuda')[:, None]
 a = torch.arange(8, device='cuda')[None, :]
@@ -34,6 +37,8 @@ for s in range(8):
 torch.cuda.synchronize()
 Es = 4096                                      # the bench workload: cacc_step_kernel<64,0>
 senv = CACCBatchEnv(cacc_config()['ENV_CONFIG'], num_envs=Es)
+if COMPACT:
+    senv.set_compact_obs(True)
 senv.reset()
 for s in range(16):
     senv.step(acts[s % 4][:Es].contiguous(), auto_reset=True)
@@ -45,15 +50,21 @@ ga = [torch.randint(0, 5, (Eg, 25), dtype=torch.uint8, device='cuda') for _ in r
 for s in range(6):
     genv.step(ga[s % 2], auto_reset=True)
 torch.cuda.synchronize()
-# the fused MFMA LSTM step at the bench shape ([8, 4096, 64] state; in place like the rollout) and its head variants
+# the fused MFMA LSTM lock-step at the bench shape (x-side policy + value kernel, as the rollout launches it)
 from deeprl_network_amd import ops
-N, El, H, A = 8, 4096, 64, 4
+N, El, H, A, KX = 8, 4096, 64, 4, 128
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).cuda()                                   # noqa: E731
-h, c, z = r(N, El, H) * 0.3, r(N, El, H) * 0.3, r(N, El, 4 * H)
-wh, b = r(N, H, 4 * H) * 0.1, r(N, 4 * H) * 0.1
+h, c, x = r(N, El, H) * 0.3, r(N, El, H) * 0.3, torch.relu(r(N, El, KX))
+wx, wh, b = r(N, KX, 4 * H) * 0.1, r(N, H, 4 * H) * 0.1, r(N, 4 * H) * 0.1
+pi_w, pi_b, v_w, v_b = r(N, H, A), r(N, A), r(N, H + 2 * A, 1), r(N, 1)
+nbr = torch.tensor([[max(i - 1, 0), min(i + 1, N - 1)] for i in range(N)], dtype=torch.int32).cuda()
 done = torch.zeros(El, device='cuda')
+img = ops.lstm_wimage(wx, wh)
+ho, co, gates = torch.empty_like(h), torch.empty_like(c), torch.empty(N, El, 4 * H, device='cuda')
+pi, act, v = torch.empty(N, El, A, device='cuda'), torch.zeros(El, N, dtype=torch.uint8, device='cuda'), torch.empty(N, El, device='cuda')
 for s in range(12):
-    ops.lstm_step_fused(h, wh, b, z, None, c, done, None, c, h)
+    ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),
+                               h_out=ho, c_out=co, gates=gates, defer_action_term=True)
 torch.cuda.synchronize()
 print('done', E, Eg)

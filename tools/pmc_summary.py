@@ -9,6 +9,7 @@ import json
 import sys
 
 d, tag = sys.argv[1], sys.argv[2]
+out_dir = sys.argv[3] if len(sys.argv) > 3 else 'profiles'
 
 
 def load(counter):
@@ -37,24 +38,28 @@ fetch_corr = (1 << 20) / cal['fetch_KiB']          # known: 1 GiB read per launc
 write_corr = (1 << 20) / cal['write_KiB']
 res = {'calibration': dict(cal, known_bytes_each_way=1 << 30, fetch_correction=fetch_corr, write_correction=write_corr),
        'fetch_factor_used': 2.0, 'write_factor_used': 1.0, 'kernels': {}}
-for key, part, E, balg in (('cacc_step_E2p21', 'cacc_step_kernel<256', 1 << 21, 631), ('cacc_step_E4096', 'cacc_step_kernel<64', 4096, 631),
+import os
+COMPACT = os.environ.get('PMC_COMPACT', '1') == '1'
+pk, bcacc = ('cacc_step_compact', 351) if COMPACT else ('cacc_step', 631)
+for key, part, E, balg in ((pk + '_E2p21', 'cacc_step_kernel<256', 1 << 21, bcacc), (pk + '_E4096', 'cacc_step_kernel<64', 4096, bcacc),
                            ('grid_step_E2p17', 'grid_step_kernel', 1 << 17, 7548)):
     s = stat(part)
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     s.update(replicas=E, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / E,
              algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / E / balg)
     res['kernels'][key] = s
-try:        # fused MFMA LSTM step: "replica" = one (agent, replica) row of 64 units, 2048 algorithmic bytes
-    s = stat('lstm_step_mfma16_kernel<false, 0>')
+try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica" = one (agent, replica) row;
+    # algorithmic bytes per row: x 512 + h, c in 512 + h', c' out 512 + gates 1024 + pi 16 + v 4 + action 1
+    s = stat('lstm_step_x_kernel<3>')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
-             algorithmic_bytes_per_replica=2048, traffic_over_algorithmic=traffic / rows / 2048)
-    res['kernels']['lstm_step_N8_E4096'] = s
+             algorithmic_bytes_per_replica=2581, traffic_over_algorithmic=traffic / rows / 2581)
+    res['kernels']['lstm_step_x_N8_E4096'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no lstm step in this collection:', ex)
-json.dump(res, open('profiles/%s_pmc_traffic.json' % tag, 'w'), indent=1)
-with open('profiles/%s_pmc_traffic.md' % tag, 'w') as f:
+json.dump(res, open('%s/%s_pmc_traffic.json' % (out_dir, tag), 'w'), indent=1)
+with open('%s/%s_pmc_traffic.md' % (out_dir, tag), 'w') as f:
     f.write('# HBM traffic of the env-step kernels (and the fused LSTM step) from rocprofv3 PMC passes\n\n'
             'commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python tools/pmc_env.py` and the same with '
             '`--pmc WRITE_SIZE` (separate runs).\n\ncalibration on a 1 GiB `copy_` in the same runs: FETCH_SIZE = %.0f KiB '

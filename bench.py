@@ -68,6 +68,7 @@ def parse():
     ap.add_argument('--envs', type=int, default=0, help='replicas per GPU (default: num_envs of the ini)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-port-worker', type=int, default=0, help='internal: run N batches of the CPU port, print the timing')
     ap.add_argument('--tune-only', action='store_true', help='internal: run one batch to tune the library GEMMs, print nothing')
     ap.add_argument('--no-tunableop', action='store_true', help='do not auto-tune the library GEMMs (PyTorch TunableOp)')
     ap.add_argument('--cpu-batches', type=int, default=100,
@@ -181,8 +182,21 @@ def pmc_traffic(key):
     return (k['traffic_bytes_per_replica'], os.path.basename(files[-1])) if k else (None, None)
 
 
+def cpu_port_worker(cfg_path, n_batches):
+    """`bench.py --cpu-port-worker N`: one replica of the restated E=1 CPU loop on one thread; prints steps, seconds, agents."""
+    from oracle import trainer_ref
+    torch.set_num_threads(1)
+    cp = configparser.ConfigParser()
+    cp.read(cfg_path)
+    env, model, tr = trainer_ref.build(cp)
+    tr.run_batches(1)
+    steps, sec = tr.run_batches(n_batches)
+    print('CPUPORT %d %.6f %d' % (steps, sec, env.n_agent))
+
+
 def cpu_baseline(cfg_path, n_batches):
-    """Reference-equivalent E=1 CPU loop (restated; TF-1.12 cannot run here) on ONE core."""
+    """Reference-equivalent E=1 CPU loop (restated; TF-1.12 cannot run here): ONE core (the `value`), then one
+    independent replica per host core; plus the env-only numbers of the REAL reference env (committed profile)."""
     from oracle import trainer_ref
     torch.set_num_threads(1)
     cp = configparser.ConfigParser()
@@ -190,12 +204,38 @@ def cpu_baseline(cfg_path, n_batches):
     env, model, tr = trainer_ref.build(cp)
     tr.run_batches(1)                                   # warm-up (allocator, first-touch)
     steps, sec = tr.run_batches(n_batches)
-    return {'value': steps * env.n_agent / sec, 'unit': 'env-steps/s (agents x envs x steps/s)', 'cores': 1,
-            'kind': 'port',
-            'sample': '%d n_step batches (%d env steps, E=1) of the restated reference loop '
-                      '(oracle/trainer_ref.py: NumPy env + per-agent torch-CPU LSTMs + TF-RMSProp), %.1f s'
-                      % (n_batches, steps, sec),
-            'updates_per_s': n_batches / sec}
+    out = {'value': steps * env.n_agent / sec, 'unit': 'env-steps/s (agents x envs x steps/s)', 'cores': 1,
+           'kind': 'port',
+           'sample': '%d n_step batches (%d env steps, E=1) of the restated reference loop '
+                     '(oracle/trainer_ref.py: NumPy env + per-agent torch-CPU LSTMs + TF-RMSProp), %.1f s'
+                     % (n_batches, steps, sec),
+           'updates_per_s': n_batches / sec}
+    try:        # the same loop as one independent replica (process) per host core
+        import subprocess
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        nb = max(10, n_batches // 2)
+        envv = dict(os.environ, OMP_NUM_THREADS='1', HIP_VISIBLE_DEVICES='', NMARL_BENCH_TUNABLEOP='0')
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-port-worker', str(nb), '--config', cfg_path],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=envv) for _ in range(ncores)]
+        res = []
+        for p_ in ps:
+            o, _ = p_.communicate(timeout=300)
+            ln = [x for x in o.splitlines() if x.startswith('CPUPORT')][0].split()
+            res.append((int(ln[1]), float(ln[2]), int(ln[3])))
+        out['all_cores'] = {'value': sum(s_ * n / t for s_, t, n in res), 'cores': ncores, 'kind': 'port',
+                            'sample': '%d processes x %d batches, %.1f s wall' % (ncores, nb, time.perf_counter() - t0)}
+    except Exception as ex:
+        out['all_cores'] = {'error': repr(ex)}
+    ref = os.path.join(ROOT, 'profiles', 'r02_cpu_env_reference.json')
+    if os.path.exists(ref):
+        d = json.load(open(ref))
+        key = '%s_%s' % (env.agent, env.name)
+        if key in d['runs']:
+            out['reference_env_only'] = dict(d['runs'][key], kind='reference', unit=d['unit'], cpu_model=d['cpu_model'],
+                                             what=d['what'] + '; measured in the authoring container by '
+                                             'tools/cpu_env_baseline.py (the reference checkout does not exist on the GPU box)')
+    return out
 
 
 def self_launch(args):
@@ -262,6 +302,8 @@ def tune_once(args, rank):
 
 def main():
     args = parse()
+    if args.cpu_port_worker:
+        return cpu_port_worker(args.config, args.cpu_port_worker)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -357,6 +357,13 @@ struct XArgs {
     const float* x2; int64_t x2_sn, x2_row;   // optional second piece of x: columns [32 nx1, KX) come from here
     const float* img; int64_t img_sn;
     int nx, nx1, N;               // x chunks (KX / 32), chunks of the first piece, agents
+    // message pre-phase (MSG != 0): the LAST 64 columns of x are computed here from the neighbours' previous h
+    int msg_kc, m_max;            // chunks of the message input (K_m / 32), neighbour slots
+    const int32_t* nbr_idx;       // [N, m_max], -1 padded
+    const float* msg_img; int64_t msg_img_sn;     // [K_m][16][4]: image of W_msg (nmarl_lstm_msg_wimage)
+    const float* msg_b; int64_t msg_b_sn;         // [N, 64]
+    const float* enc; int64_t enc_sn, enc_row;    // MSG 2: the additive h-independent part of the input [N,E,64]
+    float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
 };
 
 // one k-step: 16 MFMAs (all column tiles) with the A value `av` and the B operands in four float4 registers
@@ -408,7 +415,14 @@ struct XArgs {
         NMARL_MFMA16(A1.w, q0, q1, q2, q3)                                                \
     }
 
-template <int HEAD>
+// MSG: the message term of a coupled net computed IN the step kernel (no gather / GEMM / bias-activation launches):
+//   1  lstm_comm (agents/utils.py:182-199):  hm = relu([h_j : j in nbr(i)] @ W_msg + b_msg)          -> x[:, KX-64:]
+//   2  lstm_ic3  (agents/utils.py:395-400):  s  = mean_j(h_j) @ W_msg + b_msg + enc                   -> x (KX = 64)
+// from the neighbours' PREVIOUS, un-masked h (quirk Q3): h_in of the other agents, complete before this launch.
+// A pre-phase on the matrix cores ([16 rows x K_m] @ [K_m x 64], A operands gathered from global memory, W_msg from an
+// LDS image staged behind the chunk buffers); its result goes through the wave's LDS tile into A layout, where the
+// main K loop picks it up as its last two x chunks, and (policy step) to global memory for the update's backward.
+template <int HEAD, int MSG>
 __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedArgs& a = xa.f;
@@ -445,7 +459,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const float* hrow = a.h_in + (int64_t)n * a.h_sn + arow * H + 4 * grp;
     float4 a0, a1, n0, n1;
 #define NMARL_A_LOAD(ch, d0, d1)     /* raw load; the (1 - done) mask of the h chunks is applied at first use */ \
-    if ((ch) < nx) {                                                                      \
+    if (MSG != 0 && (ch) >= nx - 2 && (ch) < nx) {       /* the message columns: from the wave's LDS tile */ \
+        const float* t_ = a_tile + c * APITCH + ((ch) - (nx - 2)) * CH_K + 4 * grp;       \
+        d0.x = t_[0]; d0.y = t_[1]; d0.z = t_[2]; d0.w = t_[3];                           \
+        d1.x = t_[16]; d1.y = t_[17]; d1.z = t_[18]; d1.w = t_[19];                       \
+    } else if ((ch) < nx) {                                                               \
         const float* p_ = (ch) < nx1 ? xrow + (ch) * CH_K : x2row + ((ch) - nx1) * CH_K;  \
         d0 = *reinterpret_cast<const float4*>(p_);                                        \
         d1 = *reinterpret_cast<const float4*>(p_ + 16);                                   \
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d0.x *= kf_; d0.y *= kf_; d0.z *= kf_; d0.w *= kf_;                               \
         d1.x *= kf_; d1.y *= kf_; d1.z *= kf_; d1.w *= kf_;                               \
     }
-    NMARL_A_LOAD(0, a0, a1)
+    if (MSG == 0) { NMARL_A_LOAD(0, a0, a1) }
     NMARL_STAGE_STORE(0)
     NMARL_STAGE_LOAD(1)
 
@@ -504,7 +522,80 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     }
     NMARL_STAGE_STORE(1)
     NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
+    float* m_lds = lds + 2 * CH_FLOATS + WAVES2 * R16 * APITCH;     // W_msg image: msg_kc * 32 * 64 floats
+    if (MSG != 0) {
+        const float4* g = reinterpret_cast<const float4*>(xa.msg_img + (int64_t)n * xa.msg_img_sn);
+        float4* d = reinterpret_cast<float4*>(m_lds);
+        for (int i = threadIdx.x; i < xa.msg_kc * (CH_K * 64 / 4); i += 512) d[i] = g[i];
+    }
     __syncthreads();
+    if (MSG != 0) {
+        f32x4 macc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) macc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* hbase = a.h_in + arow * H + 4 * grp;            // + j * h_sn: row `arow` of agent j
+        const int32_t* nb = xa.nbr_idx + n * xa.m_max;
+        float inv = 0.0f;
+        if (MSG == 2) {
+            int cnt = 0;
+            for (int k = 0; k < xa.m_max; ++k) cnt += nb[k] >= 0;
+            inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
+        }
+        for (int kc = 0; kc < xa.msg_kc; ++kc) {
+            float4 m0, m1;
+            if (MSG == 1) {                 // chunk kc = half (kc & 1) of neighbour slot (kc >> 1); absent slot: zeros
+                const int j = nb[kc >> 1];
+                const float w = j >= 0 ? 1.0f : 0.0f;
+                const float* p_ = hbase + (int64_t)(j >= 0 ? j : n) * a.h_sn + (kc & 1) * CH_K;
+                m0 = *reinterpret_cast<const float4*>(p_);
+                m1 = *reinterpret_cast<const float4*>(p_ + 16);
+                m0.x *= w; m0.y *= w; m0.z *= w; m0.w *= w; m1.x *= w; m1.y *= w; m1.z *= w; m1.w *= w;
+            } else {                        // mean over the existing neighbours
+                m0 = float4{0.f, 0.f, 0.f, 0.f}; m1 = m0;
+                for (int k = 0; k < xa.m_max; ++k) {
+                    const int j = nb[k];
+                    const float w = j >= 0 ? 1.0f : 0.0f;
+                    const float* p_ = hbase + (int64_t)(j >= 0 ? j : n) * a.h_sn + kc * CH_K;
+                    const float4 u0 = *reinterpret_cast<const float4*>(p_), u1 = *reinterpret_cast<const float4*>(p_ + 16);
+                    m0.x += w * u0.x; m0.y += w * u0.y; m0.z += w * u0.z; m0.w += w * u0.w;
+                    m1.x += w * u1.x; m1.y += w * u1.y; m1.z += w * u1.z; m1.w += w * u1.w;
+                }
+                m0.x *= inv; m0.y *= inv; m0.z *= inv; m0.w *= inv; m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
+            }
+            const float* mb = m_lds + ((kc * CH_K + 4 * grp) * 16 + c) * 4;      // + kl * 64 floats per k row
+#define NMARL_MSTEP(av, kl)                                                                    \
+            {                                                                                  \
+                const float4 b_ = *reinterpret_cast<const float4*>(mb + (kl) * 64);            \
+                macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.x, macc[0], 0, 0, 0);    \
+                macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.y, macc[1], 0, 0, 0);    \
+                macc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.z, macc[2], 0, 0, 0);    \
+                macc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.w, macc[3], 0, 0, 0);    \
+            }
+            NMARL_MSTEP(m0.x, 0) NMARL_MSTEP(m0.y, 1) NMARL_MSTEP(m0.z, 2) NMARL_MSTEP(m0.w, 3)
+            NMARL_MSTEP(m1.x, 16) NMARL_MSTEP(m1.y, 17) NMARL_MSTEP(m1.z, 18) NMARL_MSTEP(m1.w, 19)
+#undef NMARL_MSTEP
+        }
+        // result (C layout) + bias, relu / + enc -> the wave's LDS tile (A layout source) and, if asked, global memory
+        const float* mbias = xa.msg_b + (int64_t)n * xa.msg_b_sn;
+        const float* encn = MSG == 2 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
+        float* xo = xa.xm_out ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float bv = mbias[16 * t + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = macc[t][r] + bv;
+                if (MSG == 1) v = fmaxf(v, 0.0f);
+                else v += encn[rofs[r] * xa.enc_row + 16 * t + c];
+                a_tile[(4 * grp + r) * APITCH + 16 * t + c] = v;
+                if (xo && row0 + 4 * grp + r < a.E) xo[(row0 + 4 * grp + r) * xa.xm_row + 16 * t + c] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        NMARL_A_LOAD(0, a0, a1)
+    }
 
     float keepr[4];
 #pragma unroll
@@ -613,6 +704,18 @@ __global__ void lstm_wimage_kernel(const int N, const int KX, const float* wx, c
     img[(int64_t)n * img_sn + o] = v;
 }
 
+// msg image[k][c][t] = W_msg[k][16 t + c]  (K_m rows, 64 columns): a lane fetches the B operands of the 4 column tiles of
+// one k with a single ds_read_b128
+__global__ void lstm_msg_wimage_kernel(const int N, const int K, const float* w, const int64_t w_sn, float* img,
+                                       const int64_t img_sn) {
+    const int per_agent = K * 64;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * per_agent) return;
+    const int n = (int)(i / per_agent), o = (int)(i % per_agent);
+    const int k = o / 64, cc = (o % 64) / 4, t = o % 4;
+    img[(int64_t)n * img_sn + o] = w[(int64_t)n * w_sn + (int64_t)k * 64 + 16 * t + cc];
+}
+
 inline bool stride_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
 
 }  // namespace
@@ -705,16 +808,37 @@ extern "C" int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
-                                 int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
+extern "C" int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn,
+                                     void* stream) {
+    if (N <= 0 || K <= 0 || K % CH_K || K > 128 || !w_msg || !img || w_sn < (int64_t)K * 64 || img_sn < (int64_t)K * 64 ||
+        (img_sn % 4) || ((uintptr_t)img % 16))
+        return NMARL_EINVAL;
+    const int64_t total = (int64_t)N * K * 64;
+    hipLaunchKernelGGL(lstm_msg_wimage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       N, K, w_msg, w_sn, img, img_sn);
+    return nmarl_check_launch();
+}
+
+static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                         int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
                                  const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
                                  int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
                                  const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
                                  float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
-                                 void* stream) {
-    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K ||
-        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 > 0 && !x) || (KX2 > 0 && !x2))))
+                                 const nmarl_msg_t* msg, void* stream) {
+    const int mk = msg ? msg->kind : 0;
+    const int KM = mk ? H : 0;                   // columns of x the message pre-phase produces
+    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K || mk < 0 || mk > 2 ||
+        (mk && (KX2 != 0 || KX < H)) ||
+        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 - KM > 0 && !x) || (KX2 > 0 && !x2))))
         return NMARL_EINVAL;
+    if (mk && E > 0) {
+        if (msg->m_max <= 0 || msg->m_max > 8 || !msg->nbr_idx || !msg->img || !msg->b || msg->b_sn < H ||
+            msg->K != (mk == 1 ? H * msg->m_max : H) || msg->K > 128 || msg->img_sn < (int64_t)msg->K * 64 || (msg->img_sn % 4) ||
+            ((uintptr_t)msg->img % 16) || (mk == 2 && (!msg->enc || msg->enc_row < H || msg->enc_sn < E * msg->enc_row)) ||
+            (msg->out && (msg->out_row < H || msg->out_sn < E * msg->out_row)))
+            return NMARL_EINVAL;
+    }
     const int kind = head ? head->kind : 0;
     if (kind < 0 || kind > 3) return NMARL_EINVAL;
     if (kind != 0 && E > 0) {
@@ -733,7 +857,7 @@ extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, c
         (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
         !stride_ok(h_new_sn, E * H) || (gates && !stride_ok(gates_sn, E * G4)) || ((uintptr_t)h_in % 16) || ((uintptr_t)img % 16) ||
         img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
-        (KX - KX2 > 0 && (x_row < KX - KX2 || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
+        (KX - KX2 - KM > 0 && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
         (KX2 > 0 && (x2_row < KX2 || (x2_row % 4) || (x2_sn % 4) || ((uintptr_t)x2 % 16))))
         return NMARL_EINVAL;
     XArgs xa{};
@@ -745,24 +869,60 @@ extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, c
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     if (kind != 0) a.hd = *head;
-    xa.x = KX - KX2 > 0 ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
+    xa.x = KX - KX2 - KM > 0 ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
     xa.x2 = KX2 > 0 ? x2 : nullptr; xa.x2_sn = x2_sn; xa.x2_row = x2_row;
     xa.img = img; xa.img_sn = img_sn;
     xa.nx = KX / CH_K; xa.nx1 = (KX - KX2) / CH_K; xa.N = N;
+    if (mk) {
+        xa.msg_kc = msg->K / CH_K; xa.m_max = msg->m_max; xa.nbr_idx = msg->nbr_idx; xa.msg_img = msg->img;
+        xa.msg_img_sn = msg->img_sn; xa.msg_b = msg->b; xa.msg_b_sn = msg->b_sn; xa.enc = msg->enc; xa.enc_sn = msg->enc_sn;
+        xa.enc_row = msg->enc_row; xa.xm_out = msg->out; xa.xm_sn = msg->out_sn; xa.xm_row = msg->out_row;
+    }
     static bool lds_set = false;
-    const int lb = (int)(LDSX_FLOATS * sizeof(float));
+    const int lb_max = (int)((LDSX_FLOATS + 128 * 64) * sizeof(float));
+    const size_t lb = (size_t)(LDSX_FLOATS + (mk ? msg->K * 64 : 0)) * sizeof(float);
     if (!lds_set) {
 #define NMARL_SET_LDS(k) \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb) != hipSuccess) return NMARL_EHIP;
-        NMARL_SET_LDS(lstm_step_x_kernel<0>) NMARL_SET_LDS(lstm_step_x_kernel<1>) NMARL_SET_LDS(lstm_step_x_kernel<2>) NMARL_SET_LDS(lstm_step_x_kernel<3>)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb_max) != hipSuccess) return NMARL_EHIP;
+        NMARL_SET_LDS((lstm_step_x_kernel<0, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 0>))
+        NMARL_SET_LDS((lstm_step_x_kernel<3, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 1>))
+        NMARL_SET_LDS((lstm_step_x_kernel<1, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 2>))
 #undef NMARL_SET_LDS
         lds_set = true;
     }
+    if (mk && kind != 1 && kind != 2) return NMARL_EINVAL;      // the message pre-phase exists for the policy / value steps
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.blocks_per_agent * N);
-    if (kind == 0) hipLaunchKernelGGL(lstm_step_x_kernel<0>, grid, dim3(512), (size_t)lb, st, xa);
-    else if (kind == 1) hipLaunchKernelGGL(lstm_step_x_kernel<1>, grid, dim3(512), (size_t)lb, st, xa);
-    else if (kind == 2) hipLaunchKernelGGL(lstm_step_x_kernel<2>, grid, dim3(512), (size_t)lb, st, xa);
-    else hipLaunchKernelGGL(lstm_step_x_kernel<3>, grid, dim3(512), (size_t)lb, st, xa);
+#define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb, st, xa)
+    if (mk == 0) {
+        if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);
+    } else if (mk == 1) {
+        if (kind == 1) NMARL_LX(1, 1); else NMARL_LX(2, 1);
+    } else {
+        if (kind == 1) NMARL_LX(1, 2); else NMARL_LX(2, 2);
+    }
+#undef NMARL_LX
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                                 int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
+                                 const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                                 int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
+                                 const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
+                                 float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
+                                 void* stream) {
+    return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, KX2, x2, x2_sn, x2_row, h_in, h_sn, img, img_sn, bias, bias_sn, zadd1, zadd1_sn,
+                         zadd2, zadd2_sn, c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, nullptr,
+                         stream);
+}
+
+extern "C" int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                                     const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                                     int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                                     int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
+                                     const nmarl_head_t* head, const nmarl_msg_t* msg, void* stream) {
+    if (!msg || msg->kind == 0 || !head) return NMARL_EINVAL;
+    return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
+                         c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream);
 }

@@ -427,18 +427,21 @@ class BatchedTrainer:
         total = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
         alive = torch.ones(n_envs, dtype=torch.float64, device=self.device)
         steps = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
+        hist = torch.zeros(model.n_a, dtype=torch.float64, device=self.device)      # greedy actions taken, by index
         for _ in range(env.T):
             model.policy.step(model.policy.encode(env.obs, fp), h, c, done, h, c)
             with torch.no_grad():
                 pi = model.policy.pi(h)
             ops.sample_actions(pi, act, ops.SAMPLE_ARGMAX)
             fp.copy_(pi)
+            hist += torch.bincount(act.flatten().long(), weights=alive.repeat_interleave(self.N), minlength=model.n_a)[:model.n_a]
             _, _, d, g = env.step(act)
             total += g.double() * alive
             steps += alive
             alive = alive * (1.0 - d.double())
             done.zero_()
         assert model.E == E0                      # evaluation used its own state tensors only
+        self.last_eval_action_share = (hist / hist.sum().clamp_min(1)).cpu().numpy().round(4).tolist()
         per_ep = (total / steps.clamp_min(1)).cpu().numpy()
         return float(per_ep.mean()), float(per_ep.std()), int((steps < env.T).sum().item())
 

@@ -350,6 +350,31 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
                       float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
                       void* stream);
 /*
+ * nmarl_lstm_step_x for the policy / value step of a COUPLED net, its message term computed inside the kernel from the
+ * neighbours' previous, un-masked h (quirk Q3; h_in of the other agents, agent stride h_sn) instead of by separate
+ * gather / GEMM / bias-activation launches:
+ *   kind 1  lstm_comm (agents/utils.py:182-199): hm = relu([h_j : j in nbr(i)] @ w_msg + b_msg), K = 64*m_max <= 128;
+ *           the LSTM input is [x (KX-64 columns: [hx | hp]) | hm]
+ *   kind 2  lstm_ic3 (agents/utils.py:395-400): s = mean_j(h_j) @ w_msg + b_msg + enc, K = 64; the LSTM input is s (KX = 64)
+ * w_msg comes as the image of nmarl_lstm_msg_wimage (K*64 floats per agent: image[k][c][t] = w_msg[k][16t+c]); nbr_idx
+ * [N,m_max] (-1 padded, ascending); enc [N,E,64] with row pitch enc_row (kind 2).  out (may be NULL): where the 64
+ * computed columns are stored for the update's backward ([N,E,64] view, row pitch out_row).  head: kind 1 or 2.
+ */
+typedef struct nmarl_msg {
+    int32_t kind, m_max, K, pad_;
+    const int32_t* nbr_idx;
+    const float* img; int64_t img_sn;
+    const float* b; int64_t b_sn;
+    const float* enc; int64_t enc_sn, enc_row;
+    float* out; int64_t out_sn, out_row;
+} nmarl_msg_t;
+int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
+int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t H, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                          const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                          int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                          int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
+                          const nmarl_head_t* head, const nmarl_msg_t* msg, void* stream);
+/*
  * One reverse step of the unrolled LSTM training graph (agents/utils.py:102-113, 199-208, 401-408, 585-593), the cell
  * backward and the dgrad product fused on the matrix cores (H = 64):
  *   dz = d cell/d z from gates / c_prev / c_new / done and dL/dh' = dh + dh2, dL/dc' = dc_in   (as nmarl_lstm_cell_bwd)

@@ -39,17 +39,18 @@ tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph
 rows = []
 t0 = time.time()
 m, s, c = tr.evaluate(n_envs=64)
-rows.append(dict(batch=0, env_steps=0, test_avg_reward=m, test_collisions=c))
+rows.append(dict(batch=0, env_steps=0, test_avg_reward=m, test_collisions=c, test_action_share=tr.last_eval_action_share))
 print(json.dumps(rows[-1]))
 for b in range(1, n_batches + 1):
     tr.run_batch()
     if b % every == 0:
         st = tr.stats()
         m, s, c = tr.evaluate(n_envs=64)
-        rows.append(dict(batch=b, env_steps=tr.global_counter.cur_step, train_episodes=st['episodes'],
+        rows.append(dict(batch=b, env_steps=b * model.n_step * E * env.n_agent, lock_steps=tr.global_counter.cur_step, train_episodes=st['episodes'],
                          train_avg_reward=st['avg_reward'], train_collisions=st['collisions'],
-                         test_avg_reward=m, test_collisions=c, wall_s=round(time.time() - t0, 1)))
+                         test_avg_reward=m, test_std_reward=s, test_collisions=c, test_action_share=tr.last_eval_action_share,
+                         wall_s=round(time.time() - t0, 1)))
         print(json.dumps(rows[-1]))
-out = os.path.join(ROOT, 'gpurun_out', 'learn_%s_%s.json' % (agent, scenario))
+out = os.path.join(ROOT, 'gpurun_out', 'learn_%s_%s_E%d_b%d.json' % (agent, scenario, E, n_batches))
 os.makedirs(os.path.dirname(out), exist_ok=True)
 json.dump(dict(agent=agent, scenario=scenario, E=E, rows=rows), open(out, 'w'), indent=1)

@@ -48,6 +48,14 @@ class Head(C.Structure):
                 ('w2', C.c_void_p), ('w2_sn', C.c_int64), ('b2', C.c_void_p), ('b2_sn', C.c_int64)]
 
 
+class Msg(C.Structure):
+    """nmarl_msg_t (include/nmarl.h): the in-kernel message term of a coupled net's policy / value step."""
+    _fields_ = [('kind', C.c_int32), ('m_max', C.c_int32), ('K', C.c_int32), ('pad_', C.c_int32), ('nbr_idx', C.c_void_p),
+                ('img', C.c_void_p), ('img_sn', C.c_int64), ('b', C.c_void_p), ('b_sn', C.c_int64),
+                ('enc', C.c_void_p), ('enc_sn', C.c_int64), ('enc_row', C.c_int64),
+                ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64)]
+
+
 class NetParams(C.Structure):
     """nmarl_net_params_t (include/nmarl.h)."""
     _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('flow_rate', C.c_float), ('T', C.c_int32),
@@ -113,6 +121,9 @@ SIGNATURES = {
     'nmarl_lstm_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_step_x': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p,
                           _i64, _p, _i64, _p, _i64, C.POINTER(Head), _p],
+    'nmarl_lstm_msg_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p],
+    'nmarl_lstm_step_x_msg': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
+                              C.POINTER(Head), C.POINTER(Msg), _p],
     'nmarl_lstm_bptt_wimage_floats': [_i32],
     'nmarl_lstm_bptt_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_step': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,

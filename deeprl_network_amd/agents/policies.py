@@ -342,7 +342,7 @@ class BatchedPolicy:
         step / step_dev.  One kernel when `fused_heads`."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2, xs = self._recur_addends(enc, h, save=save)
+                z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
                 p = self.params
                 ops.lstm_step_policy(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['pi_w'], p['pi_b'],
                                      pi_out, act_out, xs=xs, gates=gates, **draw)
@@ -407,7 +407,7 @@ class BatchedPolicy:
         [h', onehot(neighbours' actions)], actions given as the env-major byte array action [E,N] -> v_out [N,E]."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2, xs = self._recur_addends(enc, h, second=True)
+                z1, z2, xs = self._recur_addends(enc, h, second=True, fuse_msg=True)
                 p = self.params
                 ops.lstm_step_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['v_w'], p['v_b'],
                                     action, self.nbr_idx, self.n_a, v_out, xs=xs)
@@ -451,13 +451,14 @@ class BatchedPolicy:
             return ops.fc_fwd(x, w, b, act, out=out)          # small-K layer: one streaming kernel (csrc/fc.hip)
         return ops.bias_act_(torch.bmm(x, w), b, act, out=out)
 
-    def _recur_addends(self, enc, h, second=False, save=None):
+    def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         """(zadd1, zadd2, xs): everything of the LSTM pre-activation except (h*(1-done)) @ Wh and the bias -- as
         ready-made addends [N,E,4H] and / or as xs = (x, wx, weight image[, x2]): an input [x | x2] [N,E,KX] whose
         product with wx the fused step computes itself (ops.lstm_step_fused).
         Coupled nets compute their message terms from h here.  second: the call is the value re-step of a lock-step
         (quirk Q1) -- what the policy step wrote into `enc` / the save slots must survive.  save: slots of the saved
-        activations (dict of [N,E,*] tensors) the policy step's message terms are written to."""
+        activations (dict of [N,E,*] tensors) the policy step's message terms are written to.  fuse_msg: the caller is a
+        head step (policy / value), whose kernel can compute the message term itself (`_msg`)."""
         if self.xside:
             return None, None, (enc, self.params[self.k_wx], self._img)
         return enc, None, None
@@ -477,6 +478,18 @@ class BatchedPolicy:
         batched engine does it at the first lock-step of a batch and before the update's forward pass)."""
         if self.xside:
             self._img = ops.lstm_wimage(self.params[self.k_wx], self.params[self.k_wh], out=self._img)
+            if self.msg_kind and ops.msg_supported(self.msg_kind, self.m_max, self.n_h):
+                self._msg_img = ops.lstm_msg_wimage(self.params['w_msg'], out=self._msg_img)
+
+    msg_kind = 0            # ops.MSG_*: the message term the step kernel can compute itself (coupled nets)
+    _msg_img = None
+
+    def _msg(self, **kw):
+        """The in-kernel message term of a policy / value step (ops._step_x `msg`), or None if it does not fit."""
+        if not (self.xside and self.msg_kind and self._msg_img is not None):
+            return None
+        p = self.params
+        return dict(kind=self.msg_kind, nbr_idx=self.nbr_idx, w_msg=p['w_msg'], b_msg=p['w_msg_b'], img=self._msg_img, **kw)
 
     # -- n_step unroll for the update (autograd)
     def unroll(self, X, FP, done, h0, c0, masked_steps=None):
@@ -591,6 +604,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     scope = 'nc/lstm_comm_%d'
     coupled = True                # messages: neighbours' h_{t-1} enter every step
+    msg_kind = ops.MSG_GATHER_RELU
 
     def _phases(self):
         H, F, A = self.n_h, self.n_feat, self.n_a
@@ -647,9 +661,13 @@ class NCMultiAgentPolicy(BatchedPolicy):
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
         return full if self.xside else torch.bmm(s, p['wx_hid'][:, :2 * H])
 
-    def _recur_addends(self, enc, h, second=False, save=None):
+    def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params
         H = self.n_h
+        if fuse_msg and self._msg() is not None:
+            # hm = relu(m~ W_msg + b) is computed by the step kernel itself; the policy step keeps it in the last third
+            # of the LSTM input (the saved message term of the update), the value re-step discards it
+            return None, None, (enc[:, :, :2 * H], p['wx_hid'], self._img, None, self._msg(out=None if second else enc[:, :, 2 * H:]))
         m = ops.nbr_gather(h, self.nbr_idx)                                   # un-masked previous h (Q3)
         if self.xside:
             # hm = relu(m~ W_msg + b) becomes the last third of the LSTM input: in place for the policy step (it is the
@@ -676,6 +694,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     scope = 'ic3/lstm_ic3_%d'
     coupled = True
+    msg_kind = ops.MSG_MEAN_ADD
 
     def _phases(self):
         H, F = self.n_h, self.n_feat
@@ -715,8 +734,12 @@ class IC3MultiAgentPolicy(BatchedPolicy):
             setattr(self, name, torch.empty(self.N, h.shape[1], self.n_h, dtype=F32, device=h.device))
         return getattr(self, name)
 
-    def _recur_addends(self, enc, h, second=False, save=None):
+    def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params
+        if fuse_msg and self._msg() is not None:
+            # s = mean_nbr(h) W_msg + b_msg + enc inside the step kernel; the policy step keeps it for the update
+            out = save['S'] if (save is not None and not second) else None
+            return None, None, (None, p['wx_hid'], self._img, None, self._msg(enc=enc, out=out))
         if self.xside:
             x = self._x_target(h, second, save)
             self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE, out=x).add_(enc)
@@ -826,7 +849,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
 
     _x_target = IC3MultiAgentPolicy._x_target
 
-    def _recur_addends(self, enc, h, second=False, save=None):
+    def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params
         keep = save is not None and not second
         msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU, out=save['A2'] if keep else None)

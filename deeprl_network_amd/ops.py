@@ -166,17 +166,57 @@ def lstm_wimage(wx, wh, out=None):
     return out
 
 
+MSG_GATHER_RELU, MSG_MEAN_ADD = 1, 2      # nmarl_msg_t.kind: lstm_comm / lstm_ic3
+MSG_MAX_K = 128
+
+
+def msg_supported(kind, m_max, n_h):
+    """The message term of a coupled net fits the step kernel's pre-phase (csrc/lstm_mfma.hip, MSG)."""
+    return n_h == FUSED_H and m_max <= 8 and (n_h * m_max if kind == MSG_GATHER_RELU else n_h) <= MSG_MAX_K
+
+
+def lstm_msg_wimage(w_msg, out=None):
+    """LDS image of w_msg [N,K,64] for the in-kernel message term; rebuild when the weights change."""
+    N, K, J = w_msg.shape
+    if out is None:
+        out = torch.empty(N, K * J, dtype=F32, device=w_msg.device)
+    if J != FC_J or w_msg.stride(2) != 1 or w_msg.stride(1) != J:
+        raise _lib.NmarlError('lstm_msg_wimage: w_msg must be [N,K,64] with contiguous panels')
+    check(lib.nmarl_lstm_msg_wimage(N, K, ptr(w_msg, F32, strided=True), w_msg.stride(0), ptr(out, F32), out.stride(0), stream()),
+          'nmarl_lstm_msg_wimage')
+    return out
+
+
 def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, what):
-    """nmarl_lstm_step_x: xs = (x [N,E,KX1] or None, wx (unused here: it is inside the image), image[, x2 [N,E,KX2]]):
-    the LSTM input is [x | x2] (x2 optional)."""
+    """nmarl_lstm_step_x: xs = (x [N,E,KX1] or None, wx (unused here: it is inside the image), image[, x2 [N,E,KX2][, msg]]):
+    the LSTM input is [x | x2] (x2 optional), or [x | message term] with msg = dict(kind, nbr_idx, w_msg, b_msg, img,
+    enc=None, out=None): the last 64 columns are computed inside the kernel from the neighbours' h (heads only)."""
     N, E, H = h.shape
     x, _, img = xs[:3]
     x2 = xs[3] if len(xs) > 3 else None
+    msg = xs[4] if len(xs) > 4 else None
     xp, x_sn, x_row, K1 = (None, 0, 0, 0) if x is None else (*_rows_view(x, x.shape[2], what + ' x'), x.shape[2])
     x2p, x2_sn, x2_row, K2 = (None, 0, 0, 0) if x2 is None else (*_rows_view(x2, x2.shape[2], what + ' x2'), x2.shape[2])
-    KX = K1 + K2
+    KX = K1 + K2 + (H if msg is not None else 0)
     if img.shape != (N, lib.nmarl_lstm_wimage_floats(KX)):
         raise _lib.NmarlError('%s: weight image does not match KX = %d' % (what, KX))
+    if msg is not None:
+        if head is None or x2 is not None or zadd1 is not None or zadd2 is not None:
+            raise _lib.NmarlError('%s: the in-kernel message term needs a head and excludes x2 / addends' % what)
+        m = _lib.Msg()
+        nbr_idx = msg['nbr_idx']
+        m.kind, m.m_max, m.K = msg['kind'], nbr_idx.shape[1], msg['w_msg'].shape[1]
+        m.nbr_idx = ptr(nbr_idx, torch.int32)
+        m.img, m.img_sn = ptr(msg['img'], F32), msg['img'].stride(0)
+        m.b, m.b_sn = _bias(msg['b_msg'])
+        if msg.get('enc') is not None:
+            m.enc, m.enc_sn, m.enc_row = _rows_view(msg['enc'], H, what + ' enc')
+        if msg.get('out') is not None:
+            m.out, m.out_sn, m.out_row = _rows_view(msg['out'], H, what + ' msg out')
+        check(lib.nmarl_lstm_step_x_msg(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
+                                        *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
+                                        C.byref(m), stream()), what)
+        return
     check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, K2, x2p, x2_sn, x2_row, *_pn(h), ptr(img, F32), img.stride(0),
                                 *_bias(bias), *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
                                 *_pn(c_out), *_pn(h_out), None if head is None else C.byref(head), stream()), what)

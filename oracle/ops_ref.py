@@ -124,6 +124,17 @@ def xside_supported(kx, n_h):
     return n_h == FUSED_H and kx % 32 == 0 and 0 <= kx <= XSIDE_MAX_K
 
 
+MSG_GATHER_RELU, MSG_MEAN_ADD = 1, 2
+
+
+def msg_supported(kind, m_max, n_h):
+    return n_h == FUSED_H and m_max <= 8 and (n_h * m_max if kind == MSG_GATHER_RELU else n_h) <= 128
+
+
+def lstm_msg_wimage(w_msg, out=None):
+    return torch.zeros(w_msg.shape[0], 1) if out is None else out
+
+
 def lstm_wimage(wx, wh, out=None):
     """The product's chunked LDS image of [wx; wh] is a kernel-side layout; the restatement multiplies by wx / wh
     directly, so the 'image' is just a token."""
@@ -139,6 +150,15 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
         x = xs[0]
         if len(xs) > 3 and xs[3] is not None:          # [x | x2]: the last columns of the LSTM input from a second tensor
             x = xs[3] if x is None else torch.cat([x, xs[3]], dim=-1)
+        if len(xs) > 4 and xs[4] is not None:          # [x | message term] from the neighbours' un-masked h (quirk Q3)
+            m = xs[4]
+            if m['kind'] == 1:                         # lstm_comm: relu([h_j] W_msg + b)   (agents/utils.py:182-199)
+                t = torch.relu(torch.bmm(nbr_gather(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1))
+            else:                                      # lstm_ic3: mean_j(h_j) W_msg + b + enc   (agents/utils.py:395-400)
+                t = torch.bmm(nbr_mean(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1) + m['enc']
+            if m.get('out') is not None:
+                m['out'].copy_(t)
+            x = t if x is None else torch.cat([x, t], dim=-1)
         if x is not None:
             z = z + torch.bmm(x, xs[1])
     if zadd1 is not None:

@@ -60,7 +60,7 @@ def test_library_is_built_from_the_current_sources():
     assert fn().decode() == 'NMARL_SRC_HASH=' + build.source_hash()
 
 
-@pytest.mark.parametrize('ctype,cls', [('nmarl_head_t', 'Head'), ('nmarl_fc_part_t', 'FcPart'),
+@pytest.mark.parametrize('ctype,cls', [('nmarl_head_t', 'Head'), ('nmarl_fc_part_t', 'FcPart'), ('nmarl_msg_t', 'Msg'),
                                        ('nmarl_cacc_params_t', 'CaccParams'), ('nmarl_grid_params_t', 'GridParams')])
 def test_struct_layouts_match_c_compiler(tmp_path, ctype, cls):
     """Every struct of the C-ABI as gcc lays it out == its ctypes mirror, field by field."""

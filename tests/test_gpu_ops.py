@@ -762,3 +762,75 @@ def test_lstm_bptt_step_fused(N, E, KM, masked, with_rec):
     if KM:
         torch.testing.assert_close(dxg[:, 1].cpu().double(), dx_r, rtol=1e-4, atol=2e-5)
         assert torch.all(dxg[:, 0] == 0)
+
+
+@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (5, 127, 4, 2)])
+@pytest.mark.parametrize('kind', [1, 2])
+def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
+    """The message term of a coupled net computed by the step kernel's pre-phase (nmarl_lstm_step_x_msg) vs the float64
+    restatement: lstm_comm hm = relu(gather(h) W_msg + b) (kind 1, K = 64 m_max <= 128) / lstm_ic3 s = mean(h) W_msg + b +
+    enc (kind 2), ragged -1 padded neighbour tables, message output stored into a column block, policy and value heads."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    if kind == 1 and H * m_max > ops.MSG_MAX_K:
+        pytest.skip('message input wider than the pre-phase supports (falls back to separate launches)')
+    g = torch.Generator().manual_seed(N * 13 + E + kind)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    KXg = 2 * H if kind == 1 else 0
+    KX = KXg + H
+    Km = H * m_max if kind == 1 else H
+    h, c, done = r(N, E, H) * 0.7, r(N, E, H), (torch.rand(E, generator=g) < 0.3).float()
+    xg = torch.relu(r(N, E, KXg)) if KXg else None
+    enc = torch.tanh(r(N, E, H)) if kind == 2 else None
+    wx = r(N, KX, 4 * H) * 0.15 + torch.arange(4 * H).view(1, 1, -1) * 1e-3 + torch.arange(KX).view(1, -1, 1) * 1e-3
+    wh, b = r(N, H, 4 * H) * 0.2, r(N, 4 * H) * 0.1
+    w_msg = r(N, Km, H) * 0.2 + torch.arange(H).view(1, 1, -1) * 2e-3 + torch.arange(Km).view(1, -1, 1) * 1e-3
+    b_msg = r(N, H) * 0.2
+    pi_w, pi_b, v_w, v_b = r(N, H, A) * 0.5, r(N, A) * 0.3, r(N, H + m_max * A, 1), r(N, 1)
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + (0 if i == N - 1 else 1)]   # the last agent: no neighbours
+        if others:
+            idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    f64 = lambda t: None if t is None else t.double()                                    # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
+    draw = dict(mode=2, seed=5, env_id_base=40, step=3)
+    # oracle
+    out_r = torch.zeros(N, E, H, dtype=torch.float64)
+    msg_r = dict(kind=kind, nbr_idx=idx, w_msg=f64(w_msg), b_msg=f64(b_msg), enc=f64(enc), out=out_r)
+    hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
+    pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
+    gr = torch.zeros(N, E, 4 * H, dtype=torch.float64)
+    ops_ref.lstm_step_policy(f64(h), f64(wh), f64(b), None, None, f64(c), f64(done), cr, hr, f64(pi_w), f64(pi_b), pir, actr,
+                             xs=(f64(xg), f64(wx), None, None, msg_r), gates=gr, **draw)
+    # product: message output into the last third of a [N,E,KX] slot (kind 1) / a separate slot (kind 2)
+    img, mimg = ops.lstm_wimage(cu(wx), cu(wh)), ops.lstm_msg_wimage(cu(w_msg))
+    slot = torch.zeros(N, E, KX, device='cuda')
+    if KXg:
+        slot[:, :, :KXg].copy_(xg)
+    msg_g = dict(kind=kind, nbr_idx=cu(idx), w_msg=cu(w_msg), b_msg=cu(b_msg), img=mimg, enc=cu(enc), out=slot[:, :, KXg:])
+    hg, cg = torch.zeros(N, E, H, device='cuda'), torch.zeros(N, E, H, device='cuda')
+    pig, actg, gg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.zeros(N, E, 4 * H, device='cuda')
+    ops.lstm_step_policy(cu(h), None, cu(b), None, None, cu(c), cu(done), cg, hg, cu(pi_w), cu(pi_b), pig, actg,
+                         xs=(slot[:, :, :KXg] if KXg else None, None, img, None, msg_g), gates=gg, **draw)
+    tol = dict(rtol=5e-5, atol=1e-5)
+    torch.testing.assert_close(slot[:, :, KXg:].cpu().double(), out_r, **tol)
+    torch.testing.assert_close(hg.cpu().double(), hr, **tol)
+    torch.testing.assert_close(cg.cpu().double(), cr, **tol)
+    torch.testing.assert_close(gg.cpu().double(), gr, **tol)
+    torch.testing.assert_close(pig.cpu().double(), pir, **tol)
+    # value step from the new state: message recomputed from h', not stored
+    act_chk = torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.sample_actions(pig.cpu(), act_chk, **draw)
+    assert torch.equal(actg.cpu(), act_chk)
+    vr = torch.zeros(N, E, dtype=torch.float64)
+    msg_r2 = dict(msg_r, out=None)
+    ops_ref.lstm_step_value(hr, f64(wh), f64(b), None, None, cr, f64(done), torch.empty_like(cr), torch.empty_like(hr), f64(v_w),
+                            f64(v_b), act_chk, idx, A, vr, xs=(f64(xg), f64(wx), None, None, msg_r2))
+    vg, h2, c2 = torch.zeros(N, E, device='cuda'), torch.zeros_like(hg), torch.zeros_like(cg)
+    keep = slot.clone()
+    ops.lstm_step_value(hg, None, cu(b), None, None, cg, cu(done), c2, h2, cu(v_w), cu(v_b), actg, cu(idx), A, vg,
+                        xs=(slot[:, :, :KXg] if KXg else None, None, img, None, dict(msg_g, out=None)))
+    torch.testing.assert_close(vg.cpu().double(), vr, rtol=2e-4, atol=5e-5)
+    assert torch.equal(slot, keep)

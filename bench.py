@@ -95,6 +95,7 @@ def measure_step_kernel(env, actions_tape, reps=20):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         body()
+    g.replay()                                  # untimed: the first replay also uploads the graph
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -126,7 +127,7 @@ def measure_lstm_step(model, n=60, reps=10):
     h, c = torch.randn(N, E, H, device=dev) * 0.3, torch.randn(N, E, H, device=dev) * 0.3
     done = torch.zeros(E, device=dev)
     wh, b = p.params[p.k_wh], p.params[p.k_b]
-    if p.can_save_acts:
+    if p.can_save_acts and p.fused_pv:
         KX = p.params[p.k_wx].shape[1]
         p.refresh_wimage()
         x = torch.relu(torch.randn(N, E, KX, device=dev))
@@ -142,6 +143,24 @@ def measure_lstm_step(model, n=60, reps=10):
         # read x, h, c; write h', c', gates, pi, v, action
         nbytes = N * E * ((KX + 2 * H) * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
         name = 'lstm_step_x_kernel<3> (nmarl_lstm_step_x, policy + value heads)'
+    elif p.can_save_acts:
+        # coupled nets: the policy step (kind 1) with the message term computed in its pre-phase where it fits
+        KX = p.params[p.k_wx].shape[1]
+        p.refresh_wimage()
+        enc = p.encode(model.buf_x[0], model.fp)
+        pi, act = torch.empty(N, E, A, device=dev), torch.zeros(E, N, dtype=torch.uint8, device=dev)
+        gates = torch.empty(N, E, 4 * H, device=dev)
+        ho, co = torch.empty_like(h), torch.empty_like(c)
+        fused_msg = p._msg() is not None
+        Km = p.params['w_msg'].shape[1] if fused_msg else 0
+
+        def body():
+            for _ in range(n):
+                p.step_policy(enc, h, c, done, ho, co, pi, act, gates=gates, mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0)
+        flops = N * E * (2 * (KX + H) * 4 * H + 2 * Km * H)
+        nbytes = N * E * ((KX - (H if fused_msg else 0) + 2 * H) * 4 + Km * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 1)
+        name = 'lstm_step_x_kernel<1,%d> (policy step of the coupled net%s)' % (p.msg_kind if fused_msg else 0,
+                                                                              ', in-kernel message term' if fused_msg else '')
     else:
         z = torch.randn(N, E, 4 * H, device=dev)
 
@@ -159,6 +178,7 @@ def measure_lstm_step(model, n=60, reps=10):
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         body()
+    g.replay()                                  # untimed: the first replay also uploads the graph
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -213,20 +233,24 @@ def cpu_baseline(cfg_path, n_batches):
     try:        # the same loop as one independent replica (process) per host core
         import subprocess
         ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-        nb = max(10, n_batches // 2)
+        nproc = min(ncores, 8)                  # 8 processes (a fresh box imports torch slowly per process)
+        nb = max(10, n_batches // 4)
         envv = dict(os.environ, OMP_NUM_THREADS='1', HIP_VISIBLE_DEVICES='', NMARL_BENCH_TUNABLEOP='0')
         t0 = time.perf_counter()
         ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-port-worker', str(nb), '--config', cfg_path],
-                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=envv) for _ in range(ncores)]
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=envv) for _ in range(nproc)]
         res = []
         for p_ in ps:
-            o, _ = p_.communicate(timeout=300)
+            o, _ = p_.communicate(timeout=240)
             ln = [x for x in o.splitlines() if x.startswith('CPUPORT')][0].split()
             res.append((int(ln[1]), float(ln[2]), int(ln[3])))
-        out['all_cores'] = {'value': sum(s_ * n / t for s_, t, n in res), 'cores': ncores, 'kind': 'port',
-                            'sample': '%d processes x %d batches, %.1f s wall' % (ncores, nb, time.perf_counter() - t0)}
+        out['all_cores'] = {'value': sum(s_ * n / t for s_, t, n in res), 'cores': nproc, 'host_cores': ncores, 'kind': 'port',
+                            'sample': '%d processes x %d batches, %.1f s wall' % (nproc, nb, time.perf_counter() - t0)}
     except Exception as ex:
         out['all_cores'] = {'error': repr(ex)}
+        for p_ in locals().get('ps', []):      # never leave our own workers behind
+            if p_.poll() is None:
+                p_.kill()
     ref = os.path.join(ROOT, 'profiles', 'r02_cpu_env_reference.json')
     if os.path.exists(ref):
         d = json.load(open(ref))
@@ -395,6 +419,7 @@ def main():
             try:
                 us_l, flops_l, bytes_l, lname = measure_lstm_step(model)
                 x_side = model.policy.can_save_acts
+                lpb = (n_step + 1) if model.policy.fused_pv else 2 * (n_step + 1)
                 ach = flops_l / us_l / 1e6
                 out['roofline'] = {
                     'kernel': lname, 'bound': 'mfma' if x_side else 'hbm',
@@ -405,11 +430,12 @@ def main():
                     'traffic': (lambda t: None if (t[0] is None or not x_side or n_agent * E != 8 * 4096) else t[0] * n_agent * E)(
                         pmc_traffic('lstm_step_x_N8_E4096')),
                     'traffic_source': pmc_traffic('lstm_step_x_N8_E4096')[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
-                    'rows_per_launch': n_agent * E, 'launches_per_batch': n_step + 1,
+                    'rows_per_launch': n_agent * E, 'launches_per_batch': lpb,
                     'hbm_frac_of_same_launch': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
                     'how': 'hipGraph of 60 launches on the model shapes and weights, 10 replays between two HIP events on '
                            'the launch stream (includes graph-node gaps).  Algorithmic work per (agent, replica) row: '
-                           'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops, fp32 in / fp32 accumulate on '
+                           'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops (uncoupled nets; coupled nets: the '
+                           'policy step + its 2*K_m*64 message flops, the value step is a second launch), fp32 in / fp32 accumulate on '
                            'v_mfma_f32_16x16x4_f32 (peak %.1f TFLOP/s dense, MI355X_MICROARCH.md); the same launch moves '
                            '%.1f MB of algorithmic HBM bytes (x, h, c in; h, c, gates, pi, v, action out), i.e. it is '
                            'matrix-pipe-bound, not HBM-bound' % (MFMA_F32_PEAK_TFLOPS, bytes_l / 1e6)}
@@ -445,7 +471,7 @@ def main():
                 big_tape = torch.stack([((e + 3 * a + s) % 4).to(torch.uint8) for s in range(8)])
                 for k in range(60):                      # leave the all-equilibrium start of the episode
                     big.step(big_tape[k % 8], auto_reset=True)
-                us_b = measure_step_kernel(big, big_tape, reps=5)
+                us_b = measure_step_kernel(big, big_tape, reps=10)
                 ach_b = balg * big_E / us_b / 1e3
                 tr_big, tr_src_b = pmc_traffic(pk + '_E2p21')
                 out['roofline_env_step_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,

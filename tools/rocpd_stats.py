@@ -45,15 +45,16 @@ def main():
             len(seg), (seg[-1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg) / 1e6, end,
             (seg[end - 1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg[:end]) / 1e6))
         cnt, tt = Counter(), Counter()
+        many = Counter(short(r[0]) for r in seg[:end])
         for r in seg[:end]:
             d = (r[2] - r[1]) / 1e3
-            if d > 30:
+            if d > 30 and many[short(r[0])] < 8:          # one-off big kernels in launch order; loops are summed below
                 print('%9.1f us  %s' % (d, short(r[0])))
             else:
                 cnt[short(r[0])] += 1
                 tt[short(r[0])] += d
         for k, v in cnt.most_common(16):
-            print('   %4d x %8.1f us total  %s' % (v, tt[k], k))
+            print('   %4d x %8.1f us total (avg %6.1f)  %s' % (v, tt[k], tt[k] / v, k))
         # the rollout part: per kernel totals (the hipGraph of n_step lock-steps + bootstrap)
         cnt, tt = Counter(), Counter()
         for r in seg[end:]:

@@ -342,7 +342,8 @@ class BatchedPolicy:
         step / step_dev.  One kernel when `fused_heads`."""
         with torch.no_grad():
             if self.fused_heads:
-                z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
+                # (in place, another agent's block could overwrite h while this one still gathers it for its message term)
+                z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=h_out.data_ptr() != h.data_ptr())
                 p = self.params
                 ops.lstm_step_policy(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['pi_w'], p['pi_b'],
                                      pi_out, act_out, xs=xs, gates=gates, **draw)

@@ -62,7 +62,7 @@ constexpr int LDS2_FLOATS = H * WPITCH + WAVES2 * R16 * APITCH;
 // critic's one-hot rows gathered from the neighbours' action bytes (kind 2).
 template <int KIND>
 __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, const int N, const int64_t row0,
-                                              const int lane, const float* a_tile) {
+                                              const int lane, const float* a_tile, const float* w_h = nullptr) {
     const nmarl_head_t& hd = a.hd;
     const int A = hd.A;
     const int nout = KIND == 1 ? A : 1;
@@ -71,16 +71,33 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
     float acc[MAXA];
 #pragma unroll
     for (int o = 0; o < MAXA; ++o) acc[o] = 0.0f;
+    // w_h: the first 64 rows of w staged in LDS by the caller (64 dependent global loads per lane otherwise).  Two separate
+    // loops: selecting between an LDS and a global pointer at run time would make every access a flat load.
+    if (w_h) {
 #pragma unroll 4
-    for (int kk = 0; kk < 16; ++kk) {
-        const int k = q * 16 + kk;
-        const float hk = a_tile[rl * APITCH + k];
-        if (KIND == 1) {
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = q * 16 + kk;
+            const float hk = a_tile[rl * APITCH + k];
+            if (KIND == 1) {
 #pragma unroll
-            for (int o = 0; o < MAXA; ++o)
-                if (o < nout) acc[o] += hk * w[k * nout + o];
-        } else {
-            acc[0] += hk * w[k];
+                for (int o = 0; o < MAXA; ++o)
+                    if (o < nout) acc[o] += hk * w_h[k * nout + o];
+            } else {
+                acc[0] += hk * w_h[k];
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = q * 16 + kk;
+            const float hk = a_tile[rl * APITCH + k];
+            if (KIND == 1) {
+#pragma unroll
+                for (int o = 0; o < MAXA; ++o)
+                    if (o < nout) acc[o] += hk * w[k * nout + o];
+            } else {
+                acc[0] += hk * w[k];
+            }
         }
     }
 #pragma unroll
@@ -123,6 +140,90 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
             }
         hd.v_out[(int64_t)n * hd.v_sn + row] = v;
     }
+}
+
+// Actor head + draw of the x-side kernel: weights / bias come zero-padded to MAXA columns from LDS (wl [64][MAXA],
+// bl [MAXA]), so every loop runs over MAXA without a branch (padded logits are -inf -> probability exactly 0: adding
+// them to the CDF sums is exact, and cum / tot = 1 <= u never holds for u < 1): the branchy version above spent
+// ~13 k cycles per wave here.  Same arithmetic as head_epilogue<1> / nmarl_draw_action otherwise.
+__device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n, const int N, const int64_t row0,
+                                                const int lane, const float* a_tile, const float* wl, const float* bl) {
+    static_assert(MAXA == 8, "two float4 per k");
+    const nmarl_head_t& hd = a.hd;
+    const int A = hd.A;
+    const int rl = lane & 15, q = lane >> 4;
+    const int64_t row = row0 + rl;
+    const int64_t rowc = row < a.E ? row : a.E - 1;
+    // late inputs first: their latency hides behind the dot products
+    const int64_t step = hd.step + (hd.step_dev ? *hd.step_dev : 0);
+    const float uh = hd.mode == 0 ? hd.u[rowc * N + n] : 0.0f;
+    float acc[MAXA];
+#pragma unroll
+    for (int o = 0; o < MAXA; ++o) acc[o] = 0.0f;
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const int k = q * 16 + kk;
+        const float hk = a_tile[rl * APITCH + k];
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + k * MAXA), w1 = *reinterpret_cast<const float4*>(wl + k * MAXA + 4);
+        acc[0] += hk * w0.x; acc[1] += hk * w0.y; acc[2] += hk * w0.z; acc[3] += hk * w0.w;
+        acc[4] += hk * w1.x; acc[5] += hk * w1.y; acc[6] += hk * w1.z; acc[7] += hk * w1.w;
+    }
+#pragma unroll
+    for (int o = 0; o < MAXA; ++o) {
+        acc[o] += __shfl_xor(acc[o], 16, 64);
+        acc[o] += __shfl_xor(acc[o], 32, 64);
+    }
+    if (q != 0 || row >= a.E) return;
+    float p[MAXA];
+    float m = -INFINITY;
+#pragma unroll
+    for (int o = 0; o < MAXA; ++o) {
+        p[o] = o < A ? acc[o] + bl[o] : -INFINITY;
+        m = fmaxf(m, p[o]);
+    }
+    float ssum = 0.0f;
+#pragma unroll
+    for (int o = 0; o < MAXA; ++o) {
+        p[o] = expf(p[o] - m);                       // exp(-inf) = 0 for the padded columns
+        ssum += p[o];
+    }
+#pragma unroll
+    for (int o = 0; o < MAXA; ++o) p[o] = p[o] / ssum;
+    float* po = hd.pi_out + (int64_t)n * hd.pi_sn + row * A;
+    if (A == 4) {
+        *reinterpret_cast<float4*>(po) = float4{p[0], p[1], p[2], p[3]};
+    } else {
+        for (int o = 0; o < A; ++o) po[o] = p[o];
+    }
+    int act = 0;
+    if (hd.mode == 2) {
+        float best = p[0];
+#pragma unroll
+        for (int k = 1; k < MAXA; ++k) {
+            const bool gt = k < A && p[k] > best;
+            best = gt ? p[k] : best;
+            act = gt ? k : act;
+        }
+    } else {
+        float uu = uh;
+        if (hd.mode == 1) {
+            const Philox4 r = philox4x32_10((uint32_t)(hd.env_id_base + row), (uint32_t)(n >> 2), (uint32_t)step, NMARL_STREAM_ACTION,
+                                            (uint32_t)hd.seed, (uint32_t)(hd.seed >> 32));
+            const uint32_t w = (n & 3) == 0 ? r.x : (n & 3) == 1 ? r.y : (n & 3) == 2 ? r.z : r.w;
+            uu = u01_from_bits(w);
+        }
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) tot += (double)p[k];
+        double cum = 0.0;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) {
+            cum += (double)p[k];
+            act = (k < A && cum / tot <= (double)uu) ? k + 1 : act;
+        }
+        act = act > A - 1 ? A - 1 : act;
+    }
+    hd.act_out[row * N + n] = (uint8_t)act;
 }
 
 template <bool HAS_Z2, int HEAD>
@@ -348,7 +449,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_mfma16_kernel(const FusedArg
 // an XCD, whose L2 then holds just that agent's image.  One barrier per chunk.
 constexpr int CH_K = 32;                        // k rows per W chunk
 constexpr int CH_FLOATS = CH_K * 16 * 20;       // 10240 floats = 40 KB
-constexpr int LDSX_FLOATS = 2 * CH_FLOATS + WAVES2 * R16 * APITCH;
+constexpr int HW_FLOATS = H * MAXA + MAXA + H;  // head weights staged in LDS: actor [64][8] + bias [8] (zero padded), critic [64]
+constexpr int LDSX_FLOATS = 2 * CH_FLOATS + WAVES2 * R16 * APITCH + HW_FLOATS;
+constexpr int SPITCH = 68;                      // row pitch of the epilogue's store-staging tiles (16-byte aligned rows)
 constexpr int MAX_KX = 256;
 
 struct XArgs {
@@ -422,16 +525,31 @@ struct XArgs {
 // A pre-phase on the matrix cores ([16 rows x K_m] @ [K_m x 64], A operands gathered from global memory, W_msg from an
 // LDS image staged behind the chunk buffers); its result goes through the wave's LDS tile into A layout, where the
 // main K loop picks it up as its last two x chunks, and (policy step) to global memory for the update's backward.
+#ifdef NMARL_STEP_TIMELINE      // instrumentation build (tools/step_timeline.py): shader-clock stamps of block 0's waves
+__device__ unsigned long long* g_timeline = nullptr;
+__global__ void timeline_set_kernel(unsigned long long* p) { g_timeline = p; }
+#define NMARL_STAMP(i) if (g_timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_timeline[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define NMARL_STAMP(i)
+#endif
+
 template <int HEAD, int MSG>
 __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedArgs& a = xa.f;
+    NMARL_STAMP(0)
     const int n = blockIdx.x % xa.N;
     const int64_t row_blk = (int64_t)(blockIdx.x / xa.N) * ROWS_B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = row_blk + wave * R16;
     const int c = lane & 15, grp = lane >> 4;
-    float* a_tile = lds + 2 * CH_FLOATS + wave * R16 * APITCH;
+    // De-phased wave groups (no message pre-phase only: LDS): waves 4-7 run ONE chunk behind waves 0-3 through a ring
+    // of three chunk buffers, so that on every SIMD one wave's VALU epilogue / head overlaps the other's MFMAs instead
+    // of both epilogues running side by side with an idle matrix pipe.
+    constexpr bool DEPH = MSG == 0;
+    constexpr int NBUF = DEPH ? 3 : 2;
+    float* a_tile = lds + NBUF * CH_FLOATS + wave * R16 * APITCH;
+    float* hw_lds = lds + NBUF * CH_FLOATS + WAVES2 * R16 * APITCH;       // head weights: [64][A] actor, then [64] critic
     const int nx = xa.nx, nch = xa.nx + 2;
     const float4* img = reinterpret_cast<const float4*>(xa.img + (int64_t)n * xa.img_sn);
 
@@ -449,6 +567,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d_[0] = sg0; d_[512] = sg1; d_[1024] = sg2; d_[1536] = sg3; d_[2048] = sg4;       \
     }
     NMARL_STAGE_LOAD(0)
+    float4 tg0, tg1, tg2, tg3, tg4;              // chunk 1, in flight together with chunk 0 (prologue only)
+    {
+        const float4* g_ = img + (CH_FLOATS / 4) + threadIdx.x;
+        tg0 = g_[0]; tg1 = g_[512]; tg2 = g_[1024]; tg3 = g_[1536]; tg4 = g_[2048];
+    }
 
     // ---- A operands: row (lane & 15) of this wave's strip, k = 32 ch + 16 j + 4 grp + {0..3}
     const int64_t arow = row0 + c < a.E ? row0 + c : a.E - 1;
@@ -479,7 +602,6 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     }
     if (MSG == 0) { NMARL_A_LOAD(0, a0, a1) }
     NMARL_STAGE_STORE(0)
-    NMARL_STAGE_LOAD(1)
 
     // ---- accumulators <- bias (+ zadd1 + zadd2);  C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
     int64_t rofs[4];
@@ -520,15 +642,35 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) cp[jj][r] = cpn[rofs[r] * H + jj * 16 + c];
     }
-    NMARL_STAGE_STORE(1)
+    {
+        float4* d_ = reinterpret_cast<float4*>(lds + CH_FLOATS) + threadIdx.x;
+        d_[0] = tg0; d_[512] = tg1; d_[1024] = tg2; d_[1536] = tg3; d_[2048] = tg4;
+    }
     NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
-    float* m_lds = lds + 2 * CH_FLOATS + WAVES2 * R16 * APITCH;     // W_msg image: msg_kc * 32 * 64 floats
+    float* m_lds = hw_lds + HW_FLOATS;                               // W_msg image: msg_kc * 32 * 64 floats
+    if (HEAD != 0) {        // the heads' h-weights -> LDS (read 16 x (A + 1) times per lane in the head epilogues)
+        const nmarl_head_t& hd = a.hd;
+        const float* w1 = hd.w + (int64_t)n * hd.w_sn;
+        if (HEAD == 2) {                                     // critic only: [64]
+            if (threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = w1[threadIdx.x];
+        } else {                                             // actor [64][A] -> [64][MAXA] zero padded, bias [A] -> [MAXA]
+            const int A = hd.A;
+            const int k = threadIdx.x >> 3, o = threadIdx.x & 7;               // 512 threads = 64 x 8
+            hw_lds[threadIdx.x] = o < A ? w1[k * A + o] : 0.0f;
+            if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = threadIdx.x < A ? (hd.b + (int64_t)n * hd.b_sn)[threadIdx.x] : 0.0f;
+            if (HEAD == 3) {
+                const float* w2 = hd.w2 + (int64_t)n * hd.w2_sn;
+                if (threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = w2[threadIdx.x];
+            }
+        }
+    }
     if (MSG != 0) {
         const float4* g = reinterpret_cast<const float4*>(xa.msg_img + (int64_t)n * xa.msg_img_sn);
         float4* d = reinterpret_cast<float4*>(m_lds);
         for (int i = threadIdx.x; i < xa.msg_kc * (CH_K * 64 / 4); i += 512) d[i] = g[i];
     }
     __syncthreads();
+    NMARL_STAMP(1)
     if (MSG != 0) {
         f32x4 macc[4];
 #pragma unroll
@@ -602,73 +744,120 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     for (int r = 0; r < 4; ++r) keepr[r] = 1.0f - a.done[rofs[r]];
     f32x4 zs[HEAD == 3 ? 16 : 1];
     NMARL_A_MASK(0, a0, a1)
-    for (int ch = 0; ch < nch; ++ch) {
-        // Loads are issued UNCONDITIONALLY (indices clamped to the last chunk): a load inside a branch makes the
-        // compiler's waitcnt pass assume the worst path at the join and wait for everything in flight, i.e. expose
-        // the global latency of the staging loads once per chunk.
+    const int lag = DEPH ? (wave >> 2) : 0;      // wave group B computes chunk tau - 1 in tick tau
+    if (DEPH && lag) __builtin_amdgcn_s_setprio(1);   // the lagging (younger) group wins issue arbitration: its MFMAs are
+                                                      // what the other group's VALU epilogue has to hide behind
+    int bsel = lag ? NBUF - 1 : 0;               // (tau - lag) mod NBUF, kept incrementally
+    int wsel = 2 % NBUF;                         // (tau + 2) mod NBUF: the buffer chunk tau + 2 is staged into
+    for (int tau = 0; tau < nch; ++tau) {
+        // Loads are issued UNCONDITIONALLY (indices clamped): a load inside a branch makes the compiler's waitcnt pass
+        // assume the worst path at the join and wait for everything in flight, i.e. expose the global latency of the
+        // staging loads once per chunk.
+        const int ch = tau - lag;                // -1 in group B's first tick (idle)
         const int chn = ch + 1 < nch ? ch + 1 : nch - 1;
         NMARL_A_LOAD(chn, n0, n1)
-        if (HEAD == 3 && ch == nx) {            // x-side part complete: the value re-step adds the SAME addend
+        if (ch >= 0) {
+            if (HEAD == 3 && ch == nx) {        // x-side part complete: the value re-step adds the SAME addend
 #pragma unroll
-            for (int t = 0; t < 16; ++t) zs[t] = acc[t];
+                for (int t = 0; t < 16; ++t) zs[t] = acc[t];
+            }
+            const float* buf = lds + bsel * CH_FLOATS + (4 * grp * 16 + c) * 20;
+            NMARL_CHUNK(buf, a0, a1)
         }
-        const float* buf = lds + (ch & 1) * CH_FLOATS + (4 * grp * 16 + c) * 20;
-        NMARL_CHUNK(buf, a0, a1)
-        __syncthreads();                         // every wave is done with buf[ch & 1]; chunk ch + 1 is visible
-        if (ch + 2 < nch) NMARL_STAGE_STORE(ch & 1)
-        const int chs = ch + 3 < nch ? ch + 3 : nch - 1;
+        NMARL_STAMP(2 + 2 * tau)
+        __syncthreads();                         // tick done: the oldest chunk's buffer is free, chunk tau + 1 visible
+        NMARL_STAMP(3 + 2 * tau)
+        if (tau + 2 < nch) NMARL_STAGE_STORE(wsel)
+        const int chs = tau + 3 < nch ? tau + 3 : nch - 1;
         NMARL_STAGE_LOAD(chs)
         a0 = n0; a1 = n1;
         NMARL_A_MASK(chn, a0, a1)
+        bsel = bsel + 1 == NBUF ? 0 : bsel + 1;
+        wsel = wsel + 1 == NBUF ? 0 : wsel + 1;
     }
+    if (DEPH && lag) {                           // group B's last chunk, while group A is already in its epilogue
+        if (HEAD == 3 && nch - 1 == nx) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) zs[t] = acc[t];
+        }
+        const float* buf = lds + bsel * CH_FLOATS + (4 * grp * 16 + c) * 20;
+        NMARL_CHUNK(buf, a0, a1)
+    }
+    NMARL_STAMP(20)
 
-    // ---- lane-local cell epilogue
+    // ---- lane-local cell epilogue.  Results leave through LDS: in the C/D layout a lane holds single floats of 16 rows, and
+    // 4-byte stores are ISSUE-bound (96 store instructions per wave with gates cost ~10 k cycles); staged through a
+    // wave-private tile (free chunk buffer) every output goes out as 16-byte stores of contiguous row pieces.
     float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
     float* cn = a.c_new + (int64_t)n * a.c_new_sn;
     float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
+    float hv_[4][4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t row = row0 + 4 * grp + r;
-            const bool ok = row < a.E;
             const float keep = keepr[r];
             const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
             const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
             const float cv = gf * (cp[jj][r] * keep) + gi * gu;
             const float hv = go * tanh_fast(cv);
             if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;
-            if (HEAD == 3) cp[jj][r] = cv;
-            if (ok) {
-                const int j = jj * 16 + c;
-                cn[row * H + j] = cv;
-                hn_out[row * H + j] = hv;
-                if (gn) {
-                    float* g = gn + row * G4 + j;
-                    g[0] = gi; g[H] = gf; g[2 * H] = go; g[3 * H] = gu;
-                }
-            }
+            cp[jj][r] = cv;                                                        // c' (HEAD 3: the re-step's previous cell)
+            hv_[jj][r] = hv;
+            acc[0 + jj][r] = gi; acc[4 + jj][r] = gf; acc[8 + jj][r] = go; acc[12 + jj][r] = gu;
         }
     }
+    {
+        // free chunk buffer: de-phased groups -> the one holding neither Wh chunk; else any (all waves passed the last barrier)
+        float* st = lds + (DEPH ? (nch % NBUF) : 0) * CH_FLOATS + wave * (R16 * SPITCH);
+        const int srow = lane >> 4, sk4 = (lane & 15) * 4;           // read side: 4 rows x 16 float4 per pass
+#define NMARL_STORE_TILE(VAL, dst, pitch)                                                  \
+        {                                                                                  \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) st[(4 * grp + r) * SPITCH + jj * 16 + c] = VAL;   \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         \
+            __builtin_amdgcn_wave_barrier();                                               \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                 \
+                const int rr = 4 * i + srow;                                               \
+                const float4 v4 = *reinterpret_cast<const float4*>(st + rr * SPITCH + sk4); \
+                if (row0 + rr < a.E) *reinterpret_cast<float4*>((dst) + (row0 + rr) * (pitch) + sk4) = v4;   \
+            }                                                                              \
+            __builtin_amdgcn_wave_barrier();                                               \
+        }
+        NMARL_STORE_TILE(cp[jj][r], cn, H)
+        NMARL_STORE_TILE(hv_[jj][r], hn_out, H)
+        if (gn) {
+            NMARL_STORE_TILE(acc[0 + jj][r], gn, G4)
+            NMARL_STORE_TILE(acc[4 + jj][r], gn + H, G4)
+            NMARL_STORE_TILE(acc[8 + jj][r], gn + 2 * H, G4)
+            NMARL_STORE_TILE(acc[12 + jj][r], gn + 3 * H, G4)
+        }
+#undef NMARL_STORE_TILE
+    }
+    NMARL_STAMP(21)
     if (HEAD != 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        head_epilogue<(HEAD == 3 ? 1 : HEAD)>(a, n, xa.N, row0, lane, a_tile);
+        if (HEAD == 2) head_epilogue<2>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
+        else head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
     }
+    NMARL_STAMP(22)
     if (HEAD == 3) {
         // ---- the value re-step (quirk Q1): z = x-side addend + (h' keep) @ Wh from the two resident Wh chunks
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = zs[t];
 #pragma unroll
         for (int hc = 0; hc < 2; ++hc) {
-            const float* buf = lds + ((nx + hc) & 1) * CH_FLOATS + (4 * grp * 16 + c) * 20;
+            const float* buf = lds + ((nx + hc) % NBUF) * CH_FLOATS + (4 * grp * 16 + c) * 20;
             const float* ar = a_tile + c * APITCH + hc * CH_K + 4 * grp;
             float4 r0, r1;
             r0.x = ar[0] * keepA; r0.y = ar[1] * keepA; r0.z = ar[2] * keepA; r0.w = ar[3] * keepA;
             r1.x = ar[16] * keepA; r1.y = ar[17] * keepA; r1.z = ar[18] * keepA; r1.w = ar[19] * keepA;
             NMARL_CHUNK(buf, r0, r1)
         }
+        NMARL_STAMP(23)
         __builtin_amdgcn_wave_barrier();                 // every lane has read its A operands: the tile may be overwritten
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
@@ -683,7 +872,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        head_epilogue<3>(a, n, xa.N, row0, lane, a_tile);
+        NMARL_STAMP(24)
+        head_epilogue<3>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
+        NMARL_STAMP(25)
     }
 #undef NMARL_STAGE_LOAD
 #undef NMARL_STAGE_STORE
@@ -856,6 +1047,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     if (!stride_ok(h_sn, E * H) || !stride_ok(bias_sn, G4) || (zadd1 && !stride_ok(zadd1_sn, E * G4)) ||
         (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
         !stride_ok(h_new_sn, E * H) || (gates && !stride_ok(gates_sn, E * G4)) || ((uintptr_t)h_in % 16) || ((uintptr_t)img % 16) ||
+        ((uintptr_t)c_new % 16) || ((uintptr_t)h_new % 16) || (gates && ((uintptr_t)gates % 16)) ||
         img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
         (KX - KX2 - KM > 0 && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
         (KX2 > 0 && (x2_row < KX2 || (x2_row % 4) || (x2_sn % 4) || ((uintptr_t)x2 % 16))))
@@ -879,8 +1071,9 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.enc_row = msg->enc_row; xa.xm_out = msg->out; xa.xm_sn = msg->out_sn; xa.xm_row = msg->out_row;
     }
     static bool lds_set = false;
-    const int lb_max = (int)((LDSX_FLOATS + 128 * 64) * sizeof(float));
-    const size_t lb = (size_t)(LDSX_FLOATS + (mk ? msg->K * 64 : 0)) * sizeof(float);
+    // no message pre-phase: three chunk buffers (de-phased wave groups); with it: two + the W_msg image
+    const int lb_max = (int)((LDSX_FLOATS + CH_FLOATS) * sizeof(float));
+    const size_t lb = (size_t)(LDSX_FLOATS + (mk ? msg->K * 64 : CH_FLOATS)) * sizeof(float);
     if (!lds_set) {
 #define NMARL_SET_LDS(k) \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb_max) != hipSuccess) return NMARL_EHIP;
@@ -926,3 +1119,10 @@ extern "C" int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t Hh, int32_t K
     return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
                          c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream);
 }
+
+#ifdef NMARL_STEP_TIMELINE
+extern "C" int nmarl_timeline_set(unsigned long long* p, void* stream) {
+    hipLaunchKernelGGL(timeline_set_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), p);
+    return nmarl_check_launch();
+}
+#endif

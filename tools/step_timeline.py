@@ -1,0 +1,71 @@
+"""Shader-clock timeline of the x-side LSTM lock-step kernel: builds csrc/lstm_mfma.hip with -DNMARL_STEP_TIMELINE into
+tools/dbg/libstep_tl.so (instrumentation build, not the product), runs the policy + value step at the bench shape and
+prints, for block 0, the stamps of every wave relative to the block's first stamp (cycles):
+  0 entry | 1 prologue done | 2+2t chunk-tick t computed | 3+2t its barrier passed | 20 K loop done | 21 cell epilogue done
+  22 head done | 23 re-step MFMAs done | 24 re-step cell done | 25 end.      python tools/step_timeline.py [head]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, 'tools', 'dbg')
+SO = os.path.join(OUT, 'libstep_tl.so')
+SRC = os.path.join(ROOT, 'deeprl_network_amd', 'csrc', 'lstm_mfma.hip')
+
+if '--build' in sys.argv or not os.path.exists(SO):
+    os.makedirs(OUT, exist_ok=True)
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+                           '-DNMARL_STEP_TIMELINE', SRC, '-o', SO])
+    if '--build' in sys.argv:
+        sys.exit(0)
+
+import torch  # noqa: E402
+from deeprl_network_amd import _lib, ops  # noqa: E402
+
+dbg = C.CDLL(SO)
+for name, args in _lib.SIGNATURES.items():
+    if hasattr(dbg, name):
+        getattr(dbg, name).argtypes = args
+        getattr(dbg, name).restype = C.c_int
+_lib.lib.nmarl_lstm_step_x = dbg.nmarl_lstm_step_x            # route the product wrappers through the instrumented build
+_lib.lib.nmarl_lstm_wimage = dbg.nmarl_lstm_wimage
+N, E, H, A, KX = 8, 4096, 64, 4, 128
+head = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
+g = torch.Generator().manual_seed(0)
+r = lambda *s: torch.randn(*s, generator=g).cuda()            # noqa: E731
+h, c, x = r(N, E, H), r(N, E, H), torch.relu(r(N, E, KX))
+wx, wh, b = r(N, KX, 4 * H) * 0.15, r(N, H, 4 * H) * 0.2, torch.zeros(N, 4 * H).cuda()
+pi_w, pi_b, v_w, v_b = r(N, H, A), r(N, A), r(N, H + 2 * A, 1), r(N, 1)
+nbr = torch.tensor([[max(i - 1, 0), min(i + 1, N - 1)] for i in range(N)], dtype=torch.int32).cuda()
+done = torch.zeros(E).cuda()
+img = ops.lstm_wimage(wx, wh)
+co, ho, gates = torch.empty_like(c), torch.empty_like(h), torch.empty(N, E, 4 * H, device='cuda')
+pi, act, v = torch.empty(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.empty(N, E, device='cuda')
+tl = torch.zeros(8 * 32, dtype=torch.int64, device='cuda')
+dbg.nmarl_timeline_set.argtypes = [C.c_void_p, C.c_void_p]
+dbg.nmarl_timeline_set(tl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+
+def run():
+    if head == 3:
+        ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),
+                                   h_out=ho, c_out=co, gates=gates, defer_action_term=True)
+    else:
+        ops.lstm_step_fused(h, None, b, None, None, c, done, gates, co, ho, xs=(x, None, img))
+
+
+for _ in range(5):
+    run()
+torch.cuda.synchronize()
+t = tl.cpu().view(8, 32)
+t0 = int(t[:, 0].min())
+names = {0: 'entry', 1: 'prologue', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end'}
+for i in range(2, 20, 2):
+    names[i], names[i + 1] = 'tick %d computed' % ((i - 2) // 2), 'tick %d barrier' % ((i - 2) // 2)
+print('stamp'.ljust(18) + ''.join(('wave %d' % w).rjust(9) for w in range(8)))
+for i in sorted(names):
+    if int(t[:, i].max()) == 0:
+        continue
+    print(names[i].ljust(18) + ''.join(('%d' % (int(t[w, i]) - t0) if int(t[w, i]) else '-').rjust(9) for w in range(8)))

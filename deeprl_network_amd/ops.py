@@ -671,6 +671,27 @@ def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, app
                                    *_pn(dhd), 1 if apply_keep else 0, stream()), 'nmarl_lstm_bptt_step')
 
 
+def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False):
+    """The whole reverse recurrence in one launch (nmarl_lstm_bptt_seq): G / dZ [N,T,E,4H], Call [N,T+1,E,H], done [T,E],
+    dHs [N,T,E,H] (the heads' dL/dh_t), img = lstm_bptt_wimage(None, wh).  -> (db [N,4H] or None, dh0, dc0 or None):
+    every step masks the carried state by done_t (the reference's lstm does, agents/utils.py:104-105)."""
+    N, T, E, H4 = G.shape
+    H = H4 // 4
+    for x, w, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (dHs, H, 'dh_ext')):
+        if x.stride(3) != 1 or x.stride(2) != w:
+            raise ValueError('bptt_seq: %s must have contiguous rows' % what)
+    nblk = lib.nmarl_lstm_bptt_seq_blocks(E)
+    part = torch.empty(N, nblk, H4, dtype=F32, device=G.device) if want_db else None
+    dh0 = torch.empty(N, E, H, dtype=F32, device=G.device) if want_state_grad else None
+    dc0 = torch.empty(N, E, H, dtype=F32, device=G.device) if want_state_grad else None
+    check(lib.nmarl_lstm_bptt_seq(T, E, N, H, ptr(G, F32, strided=True), G.stride(0), G.stride(1), ptr(Call, F32, strided=True),
+                                  Call.stride(0), Call.stride(1), ptr(done, F32), ptr(dHs, F32, strided=True), dHs.stride(0),
+                                  dHs.stride(1), ptr(img, F32), img.stride(0), ptr(dZ, F32, strided=True), dZ.stride(0),
+                                  dZ.stride(1), ptr(part), 0 if part is None else part.stride(0), *_pn(dh0), *_pn(dc0),
+                                  stream()), 'nmarl_lstm_bptt_seq')
+    return (part.sum(dim=1) if want_db else None), dh0, dc0
+
+
 class _LstmCell(torch.autograd.Function):
     """(z [N,E,4H], bias [N,4H], c_prev [N,E,H], done [E]) -> (h_new, c_new)."""
 
@@ -815,7 +836,7 @@ class _LstmSequenceX(torch.autograd.Function):
         return ds, dwx, dwh, db, dh_rec, dc, None, None, None
 
 
-def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds):
+def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, want_state_grad=True):
     """BPTT of z_t = s_t @ wx + (h_{t-1} keep_t) @ wh, (h_t, c_t) = cell(z_t + b, c_{t-1}, done_t) from the saved gates
     G [N,T,E,4H] and state sequences Hall / Call [N,T+1,E,H]: the reverse loop of (cell_bwd, dgrad GEMM vs wh), then
     ds = dZ @ wx^T, dwx = s^T dZ, dwh = (h keep)^T dZ, db = sum dZ over all T*E rows."""
@@ -824,20 +845,16 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds):
     dHs = dHs.contiguous()
     dZ = torch.empty_like(G)
     keep = (1.0 - done)
-    dh_rec = None
-    dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
-    dc_next = torch.empty_like(dc)
-    wh_t = wh.transpose(1, 2)
+    db = None
     if bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4:
-        # fused reverse step: cell backward + dz @ wh^T in one MFMA kernel, dh_rec ping-pongs between two buffers
-        ws = (None, wh, lstm_bptt_wimage(None, wh))
-        dh_a, dh_b = torch.empty_like(dc), torch.empty_like(dc)
-        for t in range(T - 1, -1, -1):
-            bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next, dh_a,
-                      t in masked)
-            dc, dc_next = dc_next, dc
-            dh_rec, dh_a, dh_b = dh_a, dh_b, dh_a
+        # the whole reverse recurrence in one launch; the bias gradient comes out of the same pass.  It multiplies by
+        # (1 - done_t) at every step: exact also for the steps outside `masked`, whose done_t is zero by contract
+        db, dh_rec, dc = bptt_seq(G, Call, done, dHs, lstm_bptt_wimage(None, wh), dZ, want_state_grad=want_state_grad)
     else:
+        dh_rec = None
+        dc = torch.zeros(N, E, H, dtype=F32, device=G.device)
+        dc_next = torch.empty_like(dc)
+        wh_t = wh.transpose(1, 2)
         for t in range(T - 1, -1, -1):
             cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dZ[:, t], dc_next, dh2=dh_rec)
             dc, dc_next = dc_next, dc
@@ -853,7 +870,8 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds):
             Hprev[:, t].mul_(keep[t].view(1, E, 1))
         Hprev = Hprev.view(N, T * E, H)
     dwh = wgrad(Hprev, dZf)
-    db = dZf.sum(dim=1)
+    if db is None:
+        db = dZf.sum(dim=1)
     KX = s.shape[3]
     sf = s.reshape(N, T * E, KX)
     ds = torch.bmm(dZf, wx.transpose(1, 2)).view(N, T, E, KX) if need_ds else None
@@ -879,7 +897,7 @@ class _LstmSequenceSaved(torch.autograd.Function):
     def backward(ctx, dHs):
         G, Hall, Call, s, wx, wh, done = ctx.saved_tensors
         ds, dwx, dwh, db, _, _ = _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, ctx.masked, dHs,
-                                                      ctx.needs_input_grad[0])
+                                                      ctx.needs_input_grad[0], want_state_grad=False)
         return ds, dwx, dwh, db, None, None, None, None, None
 
 

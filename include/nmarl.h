@@ -397,6 +397,23 @@ int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t H, int32_t KM, const floa
                          const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
                          int32_t apply_keep, void* stream);
 /*
+ * The whole reverse recurrence of one update in ONE launch, for nets whose recurrence has no cross-agent term (lstm,
+ * agents/utils.py:102-113 unrolled by policies.py:99-100): T reverse steps of nmarl_lstm_bptt_step(KM = 0,
+ * apply_keep = 1) with dL/dc, the recurrent dL/dh, c_{t-1} and the weight image kept on chip between steps.
+ *   gates [N][T][E][4H], dz likewise (agent stride *_sn, step stride *_st, floats);  c_all [N][T+1][E][H] (c_all[t] =
+ *   the cell state step t started from);  done [T][E];  dh_ext [N][T][E][H] = dL/dh_t from the heads;
+ *   img = nmarl_lstm_bptt_wimage(KM = 0) of the current wh.
+ * Outputs: dz (every step: the weight-gradient GEMMs need it);  db_part [N][nmarl_lstm_bptt_seq_blocks(E)][4H] or
+ * NULL: per-block column sums of dz over all T steps and the block's rows (bias gradient = their sum over blocks);
+ * dh0 / dc0 [N][E][H] or NULL: dL/d(h, c) of the initial state.  Pointers 16-byte aligned, strides % 4 == 0.
+ */
+int nmarl_lstm_bptt_seq_blocks(int64_t E);
+int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t H, const float* gates, int64_t gates_sn,
+                        int64_t gates_st, const float* c_all, int64_t c_sn, int64_t c_st, const float* done,
+                        const float* dh_ext, int64_t dh_sn, int64_t dh_st, const float* img, int64_t img_sn,
+                        float* dz, int64_t dz_sn, int64_t dz_st, float* db_part, int64_t db_sn, float* dh0,
+                        int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream);
+/*
  * y[n,r,:W] = act(x[n,r,:] + bias[n,:]) for x [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the
  * lstm_comm / lstm_ic3 encoders (agents/utils.py:196-198, 400) after a plain batched GEMM.

@@ -70,7 +70,7 @@ def bptt_supported(H):
 
 
 def lstm_bptt_wimage(wxm, wh, out=None):
-    return torch.zeros(wh.shape[0], 1) if out is None else out     # kernel-side layout; the restatement uses wxm / wh
+    return wh if out is None else out     # kernel-side layout in the product; the restatement hands wh through
 
 
 def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None):
@@ -86,6 +86,22 @@ def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, app
         if mask is not None:
             v = v * (mask > 0)
         dx.copy_(v)
+
+
+def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False, wh=None):
+    """T reverse steps of bptt_step (KM = 0, every step masked) -> (db, dh0, dc0); wh is the restatement's weight
+    operand (the product passes the kernel-side image `img`, which the restatement cannot read back)."""
+    N, T, E, H4 = G.shape
+    H = H4 // 4
+    wh = img if wh is None else wh
+    dh_rec = None
+    dc = torch.zeros(N, E, H, dtype=G.dtype, device=G.device)
+    for t in range(T - 1, -1, -1):
+        dc_prev, dhd = torch.empty_like(dc), torch.empty_like(dc)
+        bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, (None, wh, None), dZ[:, t], dc_prev, dhd, True)
+        dc, dh_rec = dc_prev, dhd
+    db = dZ.reshape(N, T * E, H4).sum(dim=1) if want_db else None
+    return db, (dh_rec if want_state_grad else None), (dc if want_state_grad else None)
 
 
 def nbr_onehot(action, nbr_idx, n_a, out=None):

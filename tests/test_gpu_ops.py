@@ -764,6 +764,52 @@ def test_lstm_bptt_step_fused(N, E, KM, masked, with_rec):
         assert torch.all(dxg[:, 0] == 0)
 
 
+@pytest.mark.parametrize('N,T,E', [(8, 12, 4096), (8, 60, 256), (3, 5, 127), (25, 4, 130), (2, 1, 1)])
+def test_lstm_bptt_seq_one_launch(N, T, E):
+    """nmarl_lstm_bptt_seq (the whole reverse recurrence in one launch, state on chip) vs T launches of
+    nmarl_lstm_bptt_step (bit for bit: same arithmetic) and vs the float64 restatement; bias-gradient partials;
+    strided sequence buffers (slots of wider allocations), ragged rows, dones inside the sequence."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 131 + T * 7 + E)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    gates = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
+    call = r(N, T + 1, E, H) * 0.8
+    done = (torch.rand(T, E, generator=g) < 0.2).float()
+    dhs = r(N, T, E, H)
+    wh = r(N, H, 4 * H) * 0.1 + torch.arange(4 * H).view(1, 1, -1) * 1e-4 + torch.arange(H).view(1, -1, 1) * 2e-4
+    dz_r = torch.empty(N, T, E, 4 * H, dtype=torch.float64)
+    db_r, dh0_r, dc0_r = ops_ref.bptt_seq(gates.double(), call.double(), done.double(), dhs.double(), None, dz_r,
+                                          want_state_grad=True, wh=wh.double())
+    # device buffers: slots of wider allocations (agent stride > T * E * W)
+    G = torch.zeros(N, T + 2, E, 4 * H, device='cuda'); G[:, 1:T + 1].copy_(gates)
+    C = torch.zeros(N, T + 3, E, H, device='cuda'); C[:, 1:T + 2].copy_(call)
+    D = torch.zeros(N, T + 1, E, H, device='cuda'); D[:, :T].copy_(dhs)
+    dZ = torch.zeros(N, T + 2, E, 4 * H, device='cuda')
+    whg, doneg = wh.cuda(), done.cuda()
+    img = ops.lstm_bptt_wimage(None, whg)
+    db, dh0, dc0 = ops.bptt_seq(G[:, 1:T + 1], C[:, 1:T + 2], doneg, D[:, :T], img, dZ[:, 1:T + 1], want_state_grad=True)
+    assert torch.all(dZ[:, 0] == 0) and torch.all(dZ[:, T + 1] == 0)
+    # the step-by-step path
+    dZ2 = torch.zeros(N, T, E, 4 * H, device='cuda')
+    dc = torch.zeros(N, E, H, device='cuda'); dcn = torch.empty_like(dc)
+    dh_a, dh_b, dh_rec = torch.empty_like(dc), torch.empty_like(dc), None
+    ws = (None, whg, img)
+    for t in range(T - 1, -1, -1):
+        ops.bptt_step(G[:, 1 + t], C[:, 1 + t], C[:, 2 + t], doneg[t], D[:, t], dh_rec, dc, ws, dZ2[:, t], dcn, dh_a, True)
+        dc, dcn = dcn, dc
+        dh_rec, dh_a, dh_b = dh_a, dh_b, dh_a
+    assert torch.equal(dZ[:, 1:T + 1], dZ2)
+    assert torch.equal(dh0, dh_rec) and torch.equal(dc0, dc)
+    torch.testing.assert_close(dZ[:, 1:T + 1].cpu().double(), dz_r, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dh0.cpu().double(), dh0_r, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(dc0.cpu().double(), dc0_r, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(db.cpu().double(), db_r, rtol=1e-4, atol=1e-4 * max(1.0, float(db_r.abs().max())))
+    torch.testing.assert_close(db.cpu().double(), dZ2.double().sum(dim=(1, 2)).cpu(), rtol=1e-5,
+                               atol=1e-6 * max(1.0, float(db_r.abs().max())) * (T * E) ** 0.5)
+
+
 @pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (5, 127, 4, 2)])
 @pytest.mark.parametrize('kind', [1, 2])
 def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):

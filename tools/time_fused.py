@@ -82,3 +82,12 @@ ub = timed('fused BPTT step (dh only)', lambda: ops.bptt_step(G, cp, cn, done, d
 nb = N * E * (4 * H + 5 * H + 4 * H + 2 * H) * 4
 print('    -> %.1f MB algorithmic -> %.2f TB/s' % (nb / 1e6, nb / ub / 1e6))
 timed('fused BPTT step ([dx | dh], relu mask)', lambda: ops.bptt_step(G, cp, cn, done, dh, dh2, dc, ws1, dz, dcp, dhd, True, dx=dx, mask=cp))
+
+# ---- the whole reverse recurrence in one launch
+T = 60
+Gs = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
+Cs, Ds, dZs = r(N, T + 1, E, H), r(N, T, E, H), torch.empty(N, T, E, 4 * H, device='cuda')
+dones = torch.zeros(T, E, device='cuda')
+us = timed('BPTT sequence, T = 60, one launch', lambda: ops.bptt_seq(Gs, Cs, dones, Ds, ws0[2], dZs), reps=5)
+nbs = N * E * (4 * H + H + H + 4 * H) * 4 * T
+print('    -> %.1f us per step; %.1f MB algorithmic per step -> %.2f TB/s' % (us / T, nbs / T / 1e6, nbs / us / 1e6))

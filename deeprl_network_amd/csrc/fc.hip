@@ -146,8 +146,142 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
 }
 
 // partial: [N, gridDim.x, F + 1, 64] (rows 0..F-1: dW, row F: db)
+// Thread = (4 consecutive output columns j4, row lane rl of 16): dy / y are read as float4 (16 threads cover a row's
+// 256 bytes), all four row passes of a 64-row tile are in flight together, rows past the end are clamped loads with a
+// zero weight (no branch around a load).  Bound by the two streams dy and y (2 x rows x 256 B per agent).
 template <int FMAX>
 __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const int F, const int tiles_per_block,
+                                                     const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
+                                                     const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
+                                                     const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
+                                                     const int act, float* __restrict__ partial) {
+    constexpr int FP = FMAX + 4;
+    __shared__ __attribute__((aligned(16))) float xs[(FMAX + 1) * J > TILE * FP ? (FMAX + 1) * J : TILE * FP];   // x tile, later the reduction pad
+    const int n = blockIdx.y, j4 = (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+    float acc[FMAX][4];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[f][q] = 0.0f;
+    float db[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xn = x + (int64_t)n * x_sn;
+    const float* yn = y + (int64_t)n * y_sn + j4;
+    const float* dyn = dy + (int64_t)n * dy_sn + j4;
+    float4 gy[4], gd[4];
+    float okf[4];
+    // loads of a tile (clamped rows, zero weight past the end / past this block's tiles): issued one tile ahead
+#define NMARL_FCB_LOAD(tile_)                                                              \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+            const int64_t row = r0_ + rl + 16 * i;                                         \
+            const bool ok = row < rows && (tile_) < tiles_per_block;                       \
+            const int64_t rc = ok ? row : rows - 1;                                        \
+            okf[i] = ok ? 1.0f : 0.0f;                                                     \
+            gd[i] = *reinterpret_cast<const float4*>(dyn + rc * dy_row);                   \
+            gy[i] = *reinterpret_cast<const float4*>(yn + rc * y_row);                     \
+        }                                                                                  \
+    }
+    // the x tile of the NEXT tile waits in registers as well (TILE * FMAX / 256 values per thread), so that no global
+    // latency is exposed between two tiles
+    constexpr int XR = TILE * FMAX / 256;
+    float xr[XR];
+#define NMARL_FCB_XLOAD(tile_)                                                             \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        _Pragma("unroll") for (int m = 0; m < XR; ++m) {                                   \
+            const int idx = threadIdx.x + 256 * m;                                         \
+            const int r = idx / FMAX, f = idx - r * FMAX;                                  \
+            const int64_t row = r0_ + r;                                                   \
+            const bool ok = f < F && row < rows;                                           \
+            xr[m] = xn[(ok ? row : 0) * x_row + (ok ? f : 0)] * (ok ? 1.0f : 0.0f);        \
+        }                                                                                  \
+    }
+    NMARL_FCB_LOAD(0)
+    NMARL_FCB_XLOAD(0)
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+#pragma unroll
+        for (int m = 0; m < XR; ++m) {
+            const int idx = threadIdx.x + 256 * m;
+            const int r = idx / FMAX;
+            xs[r * FP + (idx - r * FMAX)] = xr[m];
+        }
+        NMARL_FCB_XLOAD(tile + 1)
+        float g[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            g[i][0] = act_bwd(gd[i].x, gy[i].x, act) * okf[i];
+            g[i][1] = act_bwd(gd[i].y, gy[i].y, act) * okf[i];
+            g[i][2] = act_bwd(gd[i].z, gy[i].z, act) * okf[i];
+            g[i][3] = act_bwd(gd[i].w, gy[i].w, act) * okf[i];
+        }
+        NMARL_FCB_LOAD(tile + 1)                 // in flight during this tile's FMAs
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = rl + 16 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) db[q] += g[i][q];
+#pragma unroll
+            for (int f4 = 0; f4 < FMAX / 4; ++f4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xs + rr * FP + 4 * f4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[4 * f4 + 0][q] = fmaf(xv.x, g[i][q], acc[4 * f4 + 0][q]);
+                    acc[4 * f4 + 1][q] = fmaf(xv.y, g[i][q], acc[4 * f4 + 1][q]);
+                    acc[4 * f4 + 2][q] = fmaf(xv.z, g[i][q], acc[4 * f4 + 2][q]);
+                    acc[4 * f4 + 3][q] = fmaf(xv.w, g[i][q], acc[4 * f4 + 3][q]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef NMARL_FCB_LOAD
+#undef NMARL_FCB_XLOAD
+    // the 16 row lanes add up in a fixed order: 4 inside the wave (lanes 16 i + j), then the 4 waves through LDS
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[f][q];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[f][q] = v;
+        }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v = db[q];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        db[q] = v;
+    }
+    float* red = xs;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = 0; k < 4; ++k) {
+        if (wave == k && lane < 16) {
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f)
+                if (f < F) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[f * J + j4 + q] = (k == 0 ? 0.0f : red[f * J + j4 + q]) + acc[f][q];
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[FMAX * J + j4 + q] = (k == 0 ? 0.0f : red[FMAX * J + j4 + q]) + db[q];
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)(F + 1) * J;
+    for (int idx = threadIdx.x; idx < (F + 1) * J; idx += 256) {
+        const int f = idx >> 6;
+        out[idx] = red[(f < F ? f : FMAX) * J + (idx & 63)];
+    }
+}
+
+// Wider inputs (F > 16; or unaligned column blocks): thread = (column j, row lane of 4), scalar loads.
+template <int FMAX>
+__global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, const int F, const int tiles_per_block,
                                                      const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
                                                      const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
                                                      const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
@@ -226,6 +360,9 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const int C, const i
 // partial: [N, gridDim.x, 65, O] (rows 0..63 dW, row 64 db), summed in fixed order by thin_bwd_reduce_kernel.
 constexpr int MAXO = 8;
 
+// thread = (4 consecutive hidden units k4, row lane rl of 16): h is read and dh written as float4 (16 threads cover a
+// row's 256 bytes), the four row passes of a 64-row tile are in flight together; rows past the end: clamped loads, zero
+// gradient (their dy tile entries are zero), predicated store.
 __global__ __launch_bounds__(256) void thin_bwd_kernel(const int64_t rows, const int O, const int tiles_per_block,
                                                        const float* __restrict__ h, const int64_t h_sn,
                                                        const float* __restrict__ dy, const int64_t dy_sn,
@@ -234,62 +371,112 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const int64_t rows, const
                                                        float* __restrict__ dh, const int64_t dh_sn,
                                                        float* __restrict__ partial) {
     __shared__ float ds[TILE * MAXO];
-    __shared__ float red[65 * MAXO];
-    const int n = blockIdx.y, k = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    float wk[MAXO], acc[MAXO], dbacc[MAXO];
+    __shared__ float red[4 * 65 * MAXO];
+    const int n = blockIdx.y, k4 = (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
+    float wk[4][MAXO], acc[4][MAXO], dbacc[MAXO];
 #pragma unroll
     for (int o = 0; o < MAXO; ++o) {
-        wk[o] = o < O ? w[(int64_t)n * w_sn + k * O + o] : 0.0f;
-        acc[o] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wk[q][o] = o < O ? w[(int64_t)n * w_sn + (k4 + q) * O + o] : 0.0f;
+            acc[q][o] = 0.0f;
+        }
         dbacc[o] = 0.0f;
     }
-    const float* hn = h + (int64_t)n * h_sn;
+    const float* hn = h + (int64_t)n * h_sn + k4;
     const float* dyn = dy + (int64_t)n * dy_sn;
     const float* dy2n = dy2 ? dy2 + (int64_t)n * dy2_sn : nullptr;
     const int O1 = dy2 ? O - 1 : O;          // dy holds the first O1 columns, dy2 (optional, [rows]) the last one
-    float* dhn = dh + (int64_t)n * dh_sn;
+    float* dhn = dh + (int64_t)n * dh_sn + k4;
+    // the dy tile of the NEXT tile waits in registers (TILE * O1 <= 512 values: two per thread, + one of dy2), the h rows
+    // of the next tile are requested before this tile's FMAs: no global latency exposed between two tiles
+    float dr0, dr1, dr2;
+    float4 hv[4];
+#define NMARL_THIN_LOAD(tile_)                                                             \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        const int64_t g0_ = r0_ * O1 + threadIdx.x, g1_ = g0_ + 256, lim_ = rows * O1;     \
+        dr0 = dyn[g0_ < lim_ ? g0_ : 0] * (g0_ < lim_ ? 1.0f : 0.0f);                      \
+        dr1 = dyn[g1_ < lim_ ? g1_ : 0] * (g1_ < lim_ ? 1.0f : 0.0f);                      \
+        const int64_t r2_ = r0_ + (threadIdx.x & (TILE - 1));                              \
+        dr2 = dy2n ? dy2n[r2_ < rows ? r2_ : 0] * (r2_ < rows ? 1.0f : 0.0f) : 0.0f;       \
+    }
+#define NMARL_THIN_HLOAD(tile_)                                                            \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+            const int64_t row = r0_ + rl + 16 * i;                                         \
+            hv[i] = *reinterpret_cast<const float4*>(hn + (row < rows ? row : rows - 1) * J); \
+        }                                                                                  \
+    }
+    NMARL_THIN_LOAD(0)
+    NMARL_THIN_HLOAD(0)
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
-        for (int idx = threadIdx.x; idx < TILE * O1; idx += 256) {         // the tile's dy rows are contiguous
-            const int64_t g = row0 * O1 + idx;
-            const int r = idx / O1;
-            ds[r * O + (idx - r * O1)] = g < rows * O1 ? dyn[g] : 0.0f;
+        {
+            const int i0 = threadIdx.x, i1 = threadIdx.x + 256;             // the tile's dy rows are contiguous
+            if (i0 < TILE * O1) ds[(i0 / O1) * O + i0 % O1] = dr0;
+            if (i1 < TILE * O1) ds[(i1 / O1) * O + i1 % O1] = dr1;
+            if (dy2n && threadIdx.x < TILE) ds[threadIdx.x * O + O1] = dr2;
         }
-        if (dy2n && threadIdx.x < TILE) ds[threadIdx.x * O + O1] = row0 + threadIdx.x < rows ? dy2n[row0 + threadIdx.x] : 0.0f;
-        __syncthreads();
-#pragma unroll 4
-        for (int rr = rl; rr < TILE; rr += 4) {
-            const int64_t row = row0 + rr;
-            if (row < rows) {
-                const float hv = hn[row * J + k];
-                float g = 0.0f;
+        NMARL_THIN_LOAD(tile + 1)
+        float4 hc[4];
 #pragma unroll
-                for (int o = 0; o < MAXO; ++o)
-                    if (o < O) {
-                        const float d = ds[rr * O + o];
-                        g = fmaf(d, wk[o], g);
-                        acc[o] = fmaf(hv, d, acc[o]);
-                        dbacc[o] += d;
-                    }
-                dhn[row * J + k] = g;
-            }
-        }
+        for (int i = 0; i < 4; ++i) hc[i] = hv[i];
+        NMARL_THIN_HLOAD(tile + 1)
         __syncthreads();
-    }
-    for (int q = 0; q < 4; ++q) {
-        if (rl == q) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = rl + 16 * i;
+            float g[4] = {0.f, 0.f, 0.f, 0.f};
+            const float hq[4] = {hc[i].x, hc[i].y, hc[i].z, hc[i].w};
 #pragma unroll
             for (int o = 0; o < MAXO; ++o)
                 if (o < O) {
-                    red[k * O + o] = (q == 0 ? 0.0f : red[k * O + o]) + acc[o];
-                    if (k == 0) red[64 * O + o] = (q == 0 ? 0.0f : red[64 * O + o]) + dbacc[o];
+                    const float d = ds[rr * O + o];          // zero for rows past the end
+                    dbacc[o] += d;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        g[q] = fmaf(d, wk[q][o], g[q]);
+                        acc[q][o] = fmaf(hq[q], d, acc[q][o]);
+                    }
                 }
+            if (row0 + rr < rows) *reinterpret_cast<float4*>(dhn + (row0 + rr) * J) = float4{g[0], g[1], g[2], g[3]};
         }
         __syncthreads();
     }
+#undef NMARL_THIN_LOAD
+#undef NMARL_THIN_HLOAD
+    // 16 row lanes: 4 inside the wave (lanes 16 i + j) by shuffles, then the 4 waves through LDS in a fixed order
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[q][o];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[q][o] = v;
+        }
+        float v = dbacc[o];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        dbacc[o] = v;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane < 16) {
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o)
+            if (o < O) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[wave * 65 * MAXO + (k4 + q) * O + o] = acc[q][o];
+                if (lane == 0) red[wave * 65 * MAXO + 64 * O + o] = dbacc[o];
+            }
+    }
+    __syncthreads();
     float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)65 * O;
-    for (int idx = threadIdx.x; idx < 65 * O; idx += 256) out[idx] = red[idx];
+    for (int idx = threadIdx.x; idx < 65 * O; idx += 256)
+        out[idx] = ((red[idx] + red[65 * MAXO + idx]) + red[2 * 65 * MAXO + idx]) + red[3 * 65 * MAXO + idx];
 }
 
 __global__ __launch_bounds__(256) void thin_bwd_reduce_kernel(const int C, const int O, const float* __restrict__ partial,
@@ -446,9 +633,14 @@ extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, cons
     const int tpb = (int)((tiles + C - 1) / C);
     const dim3 grid(C, N);
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define NMARL_FC_BWD(FM) hipLaunchKernelGGL(fc_bwd_kernel<FM>, grid, dim3(256), 0, st, rows, F, tpb, x, x_sn, x_row, y, y_sn, y_row, \
-                                            dy, dy_sn, dy_row, act, partial)
-    if (F <= 16) NMARL_FC_BWD(16); else if (F <= 32) NMARL_FC_BWD(32); else NMARL_FC_BWD(64);
+#define NMARL_FC_BWD(K, FM) hipLaunchKernelGGL(K<FM>, grid, dim3(256), 0, st, rows, F, tpb, x, x_sn, x_row, y, y_sn, y_row, \
+                                               dy, dy_sn, dy_row, act, partial)
+    const bool vec = ((uintptr_t)y % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (y_sn % 4) == 0 && (y_row % 4) == 0 &&
+                     (dy_sn % 4) == 0 && (dy_row % 4) == 0;
+    if (F <= 16 && vec) NMARL_FC_BWD(fc_bwd_kernel, 16);
+    else if (F <= 16) NMARL_FC_BWD(fc_bwd_rows_kernel, 16);
+    else if (F <= 32) NMARL_FC_BWD(fc_bwd_rows_kernel, 32);
+    else NMARL_FC_BWD(fc_bwd_rows_kernel, 64);
 #undef NMARL_FC_BWD
     hipLaunchKernelGGL(fc_bwd_reduce_kernel, dim3(((F + 1) * J + 255) / 256, N), dim3(256), 0, st, C, F, partial, dw, dw_sn, db, db_sn);
     return nmarl_check_launch();
@@ -460,7 +652,8 @@ extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t
                                      float* db, int64_t db_sn, void* stream) {
     const int O1 = dy2 ? O - 1 : O;
     if (rows <= 0 || N <= 0 || H != J || O <= 0 || O > MAXO || O1 <= 0 || !h || !dy || !w || !partial || !dh || !dw || !db ||
-        h_sn < rows * J || dh_sn < rows * J || dy_sn < rows * O1 || (dy2 && dy2_sn < rows) || w_sn < (int64_t)J * O ||
+        h_sn < rows * J || dh_sn < rows * J || (h_sn % 4) || (dh_sn % 4) || ((uintptr_t)h % 16) || ((uintptr_t)dh % 16) ||
+        dy_sn < rows * O1 || (dy2 && dy2_sn < rows) || w_sn < (int64_t)J * O ||
         dw_sn < (int64_t)J * O || db_sn < O)
         return NMARL_EINVAL;
     const int C = nmarl_fc_bwd_chunks(rows, N);

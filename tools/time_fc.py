@@ -36,3 +36,10 @@ for N, rows, F, tag in [(8, 4096, 15, 'cacc rollout x~'), (25, 1024, 60, 'grid r
             return ops.wgrad(x, g), g.sum(1)
         line += '; bwd kernel %.1f us, mask + split wgrad + sum %.1f us' % (t_b, timeit(lib, 3))
     print(line)
+
+# the heads' backward over the update batch (thin linear layer, 64 -> 5 columns)
+N, rows, O = 8, 245760, 5
+h = torch.randn(N, rows, 64, device='cuda'); dy = torch.randn(N, rows, O, device='cuda'); w = torch.randn(N, 64, O, device='cuda')
+t_t = timeit(lambda: ops.thin_linear_bwd(h, dy, w), 3)
+print('thin_linear_bwd N=%d rows=%d O=%d: %.1f us (h read + dh written: %.0f MB -> %.2f TB/s)' % (N, rows, O, t_t, 2 * h.numel() * 4 / 1e6,
+                                                                                               2 * h.numel() * 4 / t_t / 1e6))

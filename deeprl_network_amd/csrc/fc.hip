@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const i
 // encoding of the rollout is one kernel before the s @ Wx GEMM.
 struct FcParts { nmarl_fc_part_t p[NMARL_FC_MAX_PARTS]; };
 
-template <int FMAX>
+template <int FMAX, bool VEC = false>
 __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, const int tiles_per_block, const FcParts parts,
                                                            const int act, float* __restrict__ y, const int64_t y_sn,
                                                            const int64_t y_row) {
@@ -102,11 +102,68 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
     const nmarl_fc_part_t& pt = parts.p[blockIdx.z];
     const int F = pt.F;
     const int n = blockIdx.y, j = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    float* yn = y + (int64_t)n * y_sn + blockIdx.z * J;
+    if (FMAX <= 16 && VEC) {
+        // narrow inputs (the rollout's encoders): thread = (4 consecutive columns, row lane of 16), outputs leave as
+        // float4; per output the same ascending fmaf chain over the inputs as below (identical results)
+        const int j4 = (threadIdx.x & 15) * 4, r16 = threadIdx.x >> 4;
+        float4 w4[FMAX];
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) {
+            const float4 v = *reinterpret_cast<const float4*>(pt.w + (int64_t)n * pt.w_sn + (f < F ? f : 0) * J + j4);
+            const float m = f < F ? 1.0f : 0.0f;
+            w4[f] = float4{v.x * m, v.y * m, v.z * m, v.w * m};
+        }
+        const float4 b4 = *reinterpret_cast<const float4*>(pt.b + (int64_t)n * pt.b_sn + j4);
+        for (int tile = 0; tile < tiles_per_block; ++tile) {
+            const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+            if (row0 >= rows) break;
+            if (pt.nbr_idx == nullptr) {
+                stage_tile<FMAX>(xs, pt.x + (int64_t)n * pt.x_sn, pt.x_row, row0, rows, F);
+            } else {
+                const int A = pt.gather_A;
+#pragma unroll
+                for (int m = 0; m < TILE * FMAX / 256; ++m) {      // unconditional loads: clamped source, zero weight
+                    const int idx = threadIdx.x + 256 * m;
+                    const int r = idx / FMAX, f = idx - r * FMAX;
+                    const int64_t row = row0 + r;
+                    const int k = (f < F ? f : 0) / A;
+                    const int src = pt.nbr_idx[n * pt.m_max + k];
+                    const bool ok = f < F && row < rows && src >= 0;
+                    const float v = pt.x[(int64_t)(ok ? src : 0) * pt.x_sn + (ok ? row : 0) * pt.x_row + (ok ? f - k * A : 0)];
+                    xs[r * FP + f] = ok ? v : 0.0f;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = r16 + 16 * i;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+                for (int f4 = 0; f4 < FMAX / 4; ++f4) {
+                    const float4 xv = *reinterpret_cast<const float4*>(xs + rr * FP + 4 * f4);
+                    const float xq[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        a0 = fmaf(xq[u], w4[4 * f4 + u].x, a0);
+                        a1 = fmaf(xq[u], w4[4 * f4 + u].y, a1);
+                        a2 = fmaf(xq[u], w4[4 * f4 + u].z, a2);
+                        a3 = fmaf(xq[u], w4[4 * f4 + u].w, a3);
+                    }
+                }
+                const int64_t row = row0 + rr;
+                if (row < rows)
+                    *reinterpret_cast<float4*>(yn + row * y_row + j4) =
+                        float4{act_fwd(a0 + b4.x, act), act_fwd(a1 + b4.y, act), act_fwd(a2 + b4.z, act), act_fwd(a3 + b4.w, act)};
+            }
+            __syncthreads();
+        }
+        return;
+    }
     float wr[FMAX];
 #pragma unroll
     for (int f = 0; f < FMAX; ++f) wr[f] = f < F ? pt.w[(int64_t)n * pt.w_sn + f * J + j] : 0.0f;
     const float bj = pt.b[(int64_t)n * pt.b_sn + j];
-    float* yn = y + (int64_t)n * y_sn + blockIdx.z * J;
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
@@ -616,7 +673,11 @@ extern "C" int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, cons
     const dim3 grid((unsigned)((tiles + tpb - 1) / tpb), N, n_parts);
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NMARL_FC_MULTI(FM) hipLaunchKernelGGL(fc_fwd_multi_kernel<FM>, grid, dim3(256), 0, st, rows, (int)tpb, ps, act, y, y_sn, y_row)
-    if (fmax <= 16) NMARL_FC_MULTI(16); else if (fmax <= 32) NMARL_FC_MULTI(32); else NMARL_FC_MULTI(64);
+    bool vec = ((uintptr_t)y % 16) == 0 && (y_sn % 4) == 0 && (y_row % 4) == 0;           // float4 outputs / weights / biases
+    for (int i = 0; i < n_parts; ++i)
+        vec = vec && ((uintptr_t)ps.p[i].w % 16) == 0 && ((uintptr_t)ps.p[i].b % 16) == 0 && (ps.p[i].w_sn % 4) == 0 && (ps.p[i].b_sn % 4) == 0;
+    if (fmax <= 16 && vec) hipLaunchKernelGGL((fc_fwd_multi_kernel<16, true>), grid, dim3(256), 0, st, rows, (int)tpb, ps, act, y, y_sn, y_row);
+    else if (fmax <= 16) NMARL_FC_MULTI(16); else if (fmax <= 32) NMARL_FC_MULTI(32); else NMARL_FC_MULTI(64);
 #undef NMARL_FC_MULTI
     return nmarl_check_launch();
 }

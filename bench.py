@@ -189,6 +189,33 @@ def measure_lstm_step(model, n=60, reps=10):
     return e0.elapsed_time(e1) * 1e3 / (reps * n), flops, nbytes, name
 
 
+def measure_bptt_seq(model, reps=5):
+    """Average duration of the second kernel of the update, the whole reverse recurrence in one launch
+    (nmarl_lstm_bptt_seq), on the model's own saved-activation buffers (shapes [N,T,E,*]): HIP events on the launch
+    stream around `reps` launches.  Algorithmic bytes per (agent, replica, step): gates 1 KB + c 256 B + dL/dh 256 B read,
+    dz 1 KB written = 2560 B.  Returns (us per launch, bytes per launch)."""
+    from deeprl_network_amd import ops
+    p = model.policy
+    G, C = model.G_buf, model.C_all
+    N, T, E, H4 = G.shape
+    G.copy_(torch.rand_like(G))
+    C.copy_(torch.randn_like(C) * 0.5)
+    dHs = torch.randn(N, T, E, H4 // 4, device=G.device)
+    dZ = torch.empty_like(G)
+    done = torch.zeros(T, E, device=G.device)
+    img = ops.lstm_bptt_wimage(None, p.params[p.k_wh])
+    for _ in range(2):
+        ops.bptt_seq(G, C, done, dHs, img, dZ)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.bptt_seq(G, C, done, dHs, img, dZ, want_db=False)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * (H4 + H4 // 4 + H4 // 4 + H4) * 4
+
+
 def pmc_traffic(key):
     """HBM bytes per replica-step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE runs of tools/pmc_env.py, FETCH x2 per MI355X_MICROARCH.md, calibrated on a known copy).
@@ -441,6 +468,22 @@ def main():
                            'matrix-pipe-bound, not HBM-bound' % (MFMA_F32_PEAK_TFLOPS, bytes_l / 1e6)}
             except Exception as ex:
                 out['roofline'] = {'error': repr(ex)}
+        # ---- the update's recurrence (uncoupled nets with saved activations): one HBM-bound launch
+        if getattr(model, 'save_acts', False) and not model.policy.coupled and model.n_lstm == 64:
+            try:
+                us_b, bytes_b = measure_bptt_seq(model)
+                out['roofline_bptt'] = {
+                    'kernel': 'lstm_bptt_seq_kernel (nmarl_lstm_bptt_seq: %d reverse steps in one launch)' % n_step,
+                    'bound': 'hbm', 'achieved': bytes_b / us_b / 1e3, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': bytes_b / us_b / 1e3 / HBM_PEAK_GBPS,
+                    'traffic': (lambda t: None if (t[0] is None or n_agent * E * n_step != 8 * 4096 * 60) else t[0] * n_agent * E * n_step)(
+                        pmc_traffic('lstm_bptt_seq_N8_E4096_T60')),
+                    'traffic_source': pmc_traffic('lstm_bptt_seq_N8_E4096_T60')[1], 'bytes_per_launch': bytes_b,
+                    'us_per_launch': us_b, 'launches_per_batch': 1,
+                    'how': 'HIP events around 5 launches on the model\'s own [N,T,E,*] buffers; algorithmic bytes per (agent, '
+                           'replica, step) = gates 1024 + c 256 + dL/dh 256 read + dz 1024 written = 2560 B'}
+            except Exception as ex:
+                out['roofline_bptt'] = {'error': repr(ex)}
         # ---- the env-step kernel (north_star's HBM roofline), measured live on this rank's stream
         tape = model.buf_act.clone()
         us = measure_step_kernel(env, tape)

@@ -67,4 +67,13 @@ for s in range(12):
     ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),
                                h_out=ho, c_out=co, gates=gates, defer_action_term=True)
 torch.cuda.synchronize()
+# the update's recurrence in one launch (nmarl_lstm_bptt_seq) at the bench shape: T = 60 reverse steps
+T = 60
+Gs = torch.cat([torch.sigmoid(r(N, T, El, 3 * H)), torch.tanh(r(N, T, El, H))], dim=-1)
+Cs, Ds, dZs = r(N, T + 1, El, H), r(N, T, El, H), torch.empty(N, T, El, 4 * H, device='cuda')
+dones = torch.zeros(T, El, device='cuda')
+bimg = ops.lstm_bptt_wimage(None, wh)
+for s in range(5):
+    ops.bptt_seq(Gs, Cs, dones, Ds, bimg, dZs)
+torch.cuda.synchronize()
 print('done', E, Eg)

@@ -58,6 +58,16 @@ try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica
     res['kernels']['lstm_step_x_N8_E4096'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no lstm step in this collection:', ex)
+try:        # the whole reverse recurrence in one launch: "replica" = one (agent, replica, step) row of T = 60 steps;
+    # algorithmic bytes per row: gates 1024 + c 256 + dL/dh 256 read, dz 1024 written
+    s = stat('lstm_bptt_seq_kernel')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 8 * 4096 * 60
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=2560, traffic_over_algorithmic=traffic / rows / 2560)
+    res['kernels']['lstm_bptt_seq_N8_E4096_T60'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no bptt_seq in this collection:', ex)
 json.dump(res, open('%s/%s_pmc_traffic.json' % (out_dir, tag), 'w'), indent=1)
 with open('%s/%s_pmc_traffic.md' % (out_dir, tag), 'w') as f:
     f.write('# HBM traffic of the env-step kernels (and the fused LSTM step) from rocprofv3 PMC passes\n\n'

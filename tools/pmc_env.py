@@ -69,8 +69,9 @@ for s in range(12):
 torch.cuda.synchronize()
 # the update's recurrence in one launch (nmarl_lstm_bptt_seq) at the bench shape: T = 60 reverse steps
 T = 60
-Gs = torch.cat([torch.sigmoid(r(N, T, El, 3 * H)), torch.tanh(r(N, T, El, H))], dim=-1)
-Cs, Ds, dZs = r(N, T + 1, El, H), r(N, T, El, H), torch.empty(N, T, El, 4 * H, device='cuda')
+rd = lambda *s: torch.randn(*s, device='cuda')        # on the device: big host copies would show up as copyBuffer launches  # noqa: E731
+Gs = torch.cat([torch.sigmoid(rd(N, T, El, 3 * H)), torch.tanh(rd(N, T, El, H))], dim=-1)
+Cs, Ds, dZs = rd(N, T + 1, El, H), rd(N, T, El, H), torch.empty(N, T, El, 4 * H, device='cuda')
 dones = torch.zeros(T, El, device='cuda')
 bimg = ops.lstm_bptt_wimage(None, wh)
 for s in range(5):

@@ -22,18 +22,18 @@ def load(counter):
 F, W = load('FETCH_SIZE'), load('WRITE_SIZE')
 
 
-def stat(name_part, skip=2):
+def stat(name_part, skip=2, first=None):
     ks = [k for k in F if name_part in k]
     assert len(ks) == 1, (name_part, ks)
     k = ks[0]
-    f = [x for x, _ in F[k]][skip:]
-    w = [x for x, _ in W[k]][skip:]
-    us = [t / 1e3 for _, t in F[k]][skip:]
+    f = [x for x, _ in F[k]][skip:first]
+    w = [x for x, _ in W[k]][skip:first]
+    us = [t / 1e3 for _, t in F[k]][skip:first]
     return dict(kernel=k[:80], launches=len(f), fetch_KiB=sum(f) / len(f), write_KiB=sum(w) / len(w),
                 us_per_launch_profiled=sum(us) / len(us))
 
 
-cal = stat('__amd_rocclr_copyBuffer', skip=0)
+cal = stat('__amd_rocclr_copyBuffer', skip=0, first=6)          # the six 1 GiB calibration copies at the start of pmc_env.py
 fetch_corr = (1 << 20) / cal['fetch_KiB']          # known: 1 GiB read per launch
 write_corr = (1 << 20) / cal['write_KiB']
 res = {'calibration': dict(cal, known_bytes_each_way=1 << 30, fetch_correction=fetch_corr, write_correction=write_corr),
@@ -50,7 +50,7 @@ for key, part, E, balg in ((pk + '_E2p21', 'cacc_step_kernel<256', 1 << 21, bcac
     res['kernels'][key] = s
 try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica" = one (agent, replica) row;
     # algorithmic bytes per row: x 512 + h, c in 512 + h', c' out 512 + gates 1024 + pi 16 + v 4 + action 1
-    s = stat('lstm_step_x_kernel<3>')
+    s = stat('lstm_step_x_kernel<3')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,

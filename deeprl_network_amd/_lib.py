@@ -135,6 +135,7 @@ SIGNATURES = {
     'nmarl_fc_fwd_multi': [_i64, _i32, _i32, C.POINTER(FcPart), _i32, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
+    'nmarl_fc_bwd_gather': [_i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_nbr_action_value_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p],
     'nmarl_nbr_action_value_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p],

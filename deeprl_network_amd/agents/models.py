@@ -205,7 +205,7 @@ class IA2C:
 
     def enable_compact_obs(self):
         """Batched engine: the env writes compact observations [E,N,n_feat] (own features only); the rollout's encoder
-        gathers the neighbours inside its kernel and update() expands the batch once (policy.expand_obs)."""
+        gathers the neighbours inside its kernels, forward (rollout) and backward (update)."""
         p = self.policy
         if p.hetero or p.n_obs == p.n_feat:
             return False
@@ -395,7 +395,7 @@ class IA2C:
         ps = self.policy.params
         ps.grad.zero_()
         FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
-        X = self.policy.expand_obs(self.buf_x[:T]) if self.compact_obs else self.buf_x[:T]
+        X = self.buf_x[:T]            # compact [T,E,N,n_feat] slab: the encoders' kernels gather the neighbours themselves
         if self.save_acts:
             Hs = self.policy.unroll_saved(X, FP, self.S_buf, self.G_buf, self.H_all, self.C_all,
                                           self.buf_done_pre, masked_steps=self.masked_steps)

@@ -382,7 +382,7 @@ class BatchedPolicy:
         """`unroll` for a batch whose forward pass the rollout already did with the CURRENT weights: S [N,T,E,KX] the
         LSTM inputs, G the gates, Hall / Call [N,T+1,E,H] the state sequences it saved.  Sets up the backward only."""
         T, E = done.shape
-        Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)
+        Xv = X.reshape(T * E, self.N, X.shape[-1]).transpose(0, 1)          # gathered [.., n_obs] or compact [.., n_feat] slab
         if self.coupled:
             return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps)
         s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
@@ -497,7 +497,7 @@ class BatchedPolicy:
         """X [T,E,N,n_obs] env-major, FP [N,T*E,A] previous-step policies, done [T,E] f32
         (pre-step), (h0, c0) [N,E,H] -> Hs [N,T*E,H]."""
         T, E = done.shape
-        Xv = X.reshape(T * E, self.N, self.n_obs).transpose(0, 1)       # [N, T*E, n_obs], no copy
+        Xv = X.reshape(T * E, self.N, X.shape[-1]).transpose(0, 1)       # [N, T*E, n_obs] (or compact: n_feat), no copy
         enc = self._enc(Xv, FP)
         if not self.coupled:
             # no cross-agent term inside the recurrence: fused sequence op (one wgrad GEMM, one bias
@@ -552,7 +552,7 @@ class LstmPolicy(BatchedPolicy):
         """The LSTM input s (x-side mode), else the x-side pre-activation s @ Wx [N,rows,4H] (bias is added in the
         cell kernel).  saved: s as the rollout computed it (x-side mode) -- only the backward is set up."""
         p = self.params
-        s = ops.fc_concat([(xv, p['fc_w'], p['fc_b'])], ops.BIAS_RELU, saved=saved)
+        s = ops.fc_concat([self._ob_part(xv, 'fc_w', 'fc_b')], ops.BIAS_RELU, saved=saved)
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp, out=None):
@@ -579,9 +579,9 @@ class FPPolicy(LstmPolicy):
     def _enc(self, xv, fp, saved=None):
         p = self.params
         nf = self.n_fc
-        pf = ops.nbr_gather(fp, self.nbr_idx)
-        # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place
-        s = ops.fc_concat([(xv, p['fcs_w'], p['fcs_b']), (pf, p['fcp_w'], p['fcp_b'])], ops.BIAS_RELU, saved=saved)
+        # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place; the
+        # neighbour gathers of the (compact) observation and of the fingerprints happen inside the fc kernels
+        s = ops.fc_concat([self._ob_part(xv, 'fcs_w', 'fcs_b'), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)], ops.BIAS_RELU, saved=saved)
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp, out=None):
@@ -623,17 +623,15 @@ class NCMultiAgentPolicy(BatchedPolicy):
         """Observation + fingerprint thirds of s, already multiplied by their rows of wx_hid."""
         p = self.params
         H = self.n_h
-        pf = ops.nbr_gather(fp, self.nbr_idx)
-        s = ops.fc_concat([(xv, p['w_ob'], p['w_ob_b']), (pf, p['w_fp'], p['w_fp_b'])], ops.BIAS_RELU)
+        s = ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b'), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)], ops.BIAS_RELU)
         return ops.linear(s, p['wx_hid'][:, :2 * H])
 
     def _enc_saved(self, xv, fp, S):
         """[hx | hp] as the rollout wrote it into the first 2H columns of the saved LSTM inputs (backward only)."""
         p = self.params
         H = self.n_h
-        pf = ops.nbr_gather(fp, self.nbr_idx)
         Sv = S.view(self.N, -1, S.shape[-1])[:, :, :2 * H]
-        return ops.fc_concat([(xv, p['w_ob'], p['w_ob_b']), (pf, p['w_fp'], p['w_fp_b'])], ops.BIAS_RELU, saved=Sv)
+        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b'), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)], ops.BIAS_RELU, saved=Sv)
 
     def _recur_in(self, enc, h):
         p = self.params
@@ -711,7 +709,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return ops.fc_concat([(xv, p['w_ob'], p['w_ob_b'])], ops.BIAS_TANH)
+        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b')], ops.BIAS_TANH)
 
     def _recur_in(self, enc, h):
         p = self.params
@@ -831,7 +829,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
 
     def _enc(self, xv, fp):
         p = self.params
-        return ops.fc_concat([(xv, p['w_ob'], p['w_ob_b'])], ops.BIAS_RELU) + self._own_action_onehot(fp)
+        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b')], ops.BIAS_RELU) + self._own_action_onehot(fp)
 
     def _recur_in(self, enc, h):
         p = self.params

@@ -35,6 +35,21 @@ __device__ __forceinline__ float act_bwd(const float g, const float y, const int
     return act == 1 ? (y > 0.0f ? g : 0.0f) : act == 2 ? g * (1.0f - y * y) : g;
 }
 
+// optional neighbour gather of a layer's input: feature f of agent n = x[nbr_idx[n, f / A]][row][f % A] (zero for a
+// -1 slot), i.e. tf.boolean_mask + concat of policies.py:171-174 / agents/utils.py:186-195 without materialising it
+struct XGather { const int32_t* nbr_idx; int A, m_max; };
+
+__device__ __forceinline__ float x_elem(const float* __restrict__ x, const int64_t x_sn, const int64_t x_row, const int n, const int64_t row,
+                                        const int f, const bool ok, const XGather g) {
+    // unconditional load: clamped indices, the caller zeroes the value when !ok
+    if (g.nbr_idx == nullptr) return x[(int64_t)n * x_sn + (ok ? row : 0) * x_row + (ok ? f : 0)];
+    const int k = (ok ? f : 0) / g.A;
+    const int src = g.nbr_idx[n * g.m_max + k];
+    const bool ok2 = ok && src >= 0;
+    const float v = x[(int64_t)(ok2 ? src : 0) * x_sn + (ok2 ? row : 0) * x_row + (ok2 ? f - k * g.A : 0)];
+    return ok2 ? v : 0.0f;
+}
+
 template <int FMAX>
 __device__ __forceinline__ void stage_tile(float* xs, const float* __restrict__ xn, const int64_t x_row, const int64_t row0,
                                            const int64_t rows, const int F) {
@@ -211,7 +226,7 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
                                                      const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
                                                      const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
                                                      const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
-                                                     const int act, float* __restrict__ partial) {
+                                                     const int act, float* __restrict__ partial, const XGather xg) {
     constexpr int FP = FMAX + 4;
     __shared__ __attribute__((aligned(16))) float xs[(FMAX + 1) * J > TILE * FP ? (FMAX + 1) * J : TILE * FP];   // x tile, later the reduction pad
     const int n = blockIdx.y, j4 = (threadIdx.x & 15) * 4, rl = threadIdx.x >> 4;
@@ -243,15 +258,29 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
     // latency is exposed between two tiles
     constexpr int XR = TILE * FMAX / 256;
     float xr[XR];
+    // a thread stages the same features of every tile: their source (agent, offset) through the neighbour table is
+    // looked up once, so that the per-tile loads are independent (no table load -> input load chain per tile)
+    int64_t xoff[XR];
+    bool xok[XR];
+#pragma unroll
+    for (int m = 0; m < XR; ++m) {
+        const int f = (threadIdx.x + 256 * m) % FMAX;
+        xok[m] = f < F;
+        xoff[m] = (int64_t)n * x_sn + (xok[m] ? f : 0);
+        if (xg.nbr_idx != nullptr) {
+            const int k = (xok[m] ? f : 0) / xg.A;
+            const int src = xg.nbr_idx[n * xg.m_max + k];
+            xok[m] = xok[m] && src >= 0;
+            xoff[m] = (int64_t)(src >= 0 ? src : 0) * x_sn + (xok[m] ? f - k * xg.A : 0);
+        }
+    }
 #define NMARL_FCB_XLOAD(tile_)                                                             \
     {                                                                                      \
         const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
         _Pragma("unroll") for (int m = 0; m < XR; ++m) {                                   \
-            const int idx = threadIdx.x + 256 * m;                                         \
-            const int r = idx / FMAX, f = idx - r * FMAX;                                  \
-            const int64_t row = r0_ + r;                                                   \
-            const bool ok = f < F && row < rows;                                           \
-            xr[m] = xn[(ok ? row : 0) * x_row + (ok ? f : 0)] * (ok ? 1.0f : 0.0f);        \
+            const int64_t row = r0_ + (threadIdx.x + 256 * m) / FMAX;                      \
+            const bool ok = xok[m] && row < rows;                                          \
+            xr[m] = x[xoff[m] + (ok ? row : 0) * x_row] * (ok ? 1.0f : 0.0f);              \
         }                                                                                  \
     }
     NMARL_FCB_LOAD(0)
@@ -342,7 +371,7 @@ __global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, co
                                                      const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
                                                      const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
                                                      const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
-                                                     const int act, float* __restrict__ partial) {
+                                                     const int act, float* __restrict__ partial, const XGather xg) {
     constexpr int FP = FMAX + 4;
     constexpr int RU = RowUnroll<FMAX>::value;
     __shared__ __attribute__((aligned(16))) float xs[TILE * FP];        // later reused as the [FMAX + 1, 64] reduction pad
@@ -357,7 +386,13 @@ __global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, co
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
-        stage_tile<FMAX>(xs, xn, x_row, row0, rows, F);
+        for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
+            const int r = idx / FMAX, f = idx - r * FMAX;
+            const int64_t row = row0 + r;
+            const bool ok = f < F && row < rows;
+            const float v = x_elem(x, x_sn, x_row, n, row, f, ok, xg);
+            xs[r * FP + f] = ok ? v : 0.0f;
+        }
         __syncthreads();
 #pragma unroll RU
         for (int rr = rl; rr < TILE; rr += 4) {
@@ -682,20 +717,24 @@ extern "C" int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, cons
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const float* x, int64_t x_sn, int64_t x_row,
-                            const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
-                            int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream) {
+static int launch_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const float* x, int64_t x_sn, int64_t x_row,
+                         const int32_t* nbr_idx, int32_t gather_A, int32_t m_max, const float* y, int64_t y_sn, int64_t y_row,
+                         const float* dy, int64_t dy_sn, int64_t dy_row, int32_t act, float* partial, float* dw, int64_t dw_sn,
+                         float* db, int64_t db_sn, void* stream) {
     if (rows <= 0 || N <= 0 || F <= 0 || F > 64 || Jw != J || act < 0 || act > 2 || dw_sn < (int64_t)F * J || db_sn < J ||
         !partial || !dw || !db)
         return NMARL_EINVAL;
-    if (!view_ok(x, x_sn, x_row, 1, F) || !view_ok(y, y_sn, y_row, rows, J) || !view_ok(dy, dy_sn, dy_row, rows, J)) return NMARL_EINVAL;
+    if (nbr_idx ? (gather_A <= 0 || m_max <= 0 || F != gather_A * m_max || !x || x_row < gather_A) : !view_ok(x, x_sn, x_row, 1, F))
+        return NMARL_EINVAL;
+    if (!view_ok(y, y_sn, y_row, rows, J) || !view_ok(dy, dy_sn, dy_row, rows, J)) return NMARL_EINVAL;
     const int C = nmarl_fc_bwd_chunks(rows, N);
     const int64_t tiles = (rows + TILE - 1) / TILE;
     const int tpb = (int)((tiles + C - 1) / C);
     const dim3 grid(C, N);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const XGather xg{nbr_idx, gather_A, m_max};
 #define NMARL_FC_BWD(K, FM) hipLaunchKernelGGL(K<FM>, grid, dim3(256), 0, st, rows, F, tpb, x, x_sn, x_row, y, y_sn, y_row, \
-                                               dy, dy_sn, dy_row, act, partial)
+                                               dy, dy_sn, dy_row, act, partial, xg)
     const bool vec = ((uintptr_t)y % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (y_sn % 4) == 0 && (y_row % 4) == 0 &&
                      (dy_sn % 4) == 0 && (dy_row % 4) == 0;
     if (F <= 16 && vec) NMARL_FC_BWD(fc_bwd_kernel, 16);
@@ -705,6 +744,22 @@ extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, cons
 #undef NMARL_FC_BWD
     hipLaunchKernelGGL(fc_bwd_reduce_kernel, dim3(((F + 1) * J + 255) / 256, N), dim3(256), 0, st, C, F, partial, dw, dw_sn, db, db_sn);
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const float* x, int64_t x_sn, int64_t x_row,
+                            const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
+                            int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream) {
+    return launch_fc_bwd(rows, N, F, Jw, x, x_sn, x_row, nullptr, 0, 0, y, y_sn, y_row, dy, dy_sn, dy_row, act, partial, dw, dw_sn, db,
+                         db_sn, stream);
+}
+
+extern "C" int nmarl_fc_bwd_gather(int64_t rows, int32_t N, int32_t gather_A, int32_t m_max, const int32_t* nbr_idx, int32_t Jw,
+                                   const float* x, int64_t x_sn, int64_t x_row, const float* y, int64_t y_sn, int64_t y_row,
+                                   const float* dy, int64_t dy_sn, int64_t dy_row, int32_t act, float* partial, float* dw,
+                                   int64_t dw_sn, float* db, int64_t db_sn, void* stream) {
+    if (!nbr_idx || gather_A <= 0 || m_max <= 0) return NMARL_EINVAL;
+    return launch_fc_bwd(rows, N, gather_A * m_max, Jw, x, x_sn, x_row, nbr_idx, gather_A, m_max, y, y_sn, y_row, dy, dy_sn, dy_row, act,
+                         partial, dw, dw_sn, db, db_sn, stream);
 }
 
 extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const float* h, int64_t h_sn,

@@ -406,16 +406,22 @@ def fc_fwd_multi(parts, act, out=None):
     return out
 
 
-def fc_bwd(x, y, dy, act):
-    """(dw [N,F,64], db [N,64]) of y = act(x @ w + b) given the layer OUTPUT y and dL/dy (column-block views allowed)."""
-    N, rows, F = x.shape
-    xp, xs, xr = _rows_view(x, F, 'fc_bwd x')
+def fc_bwd(x, y, dy, act, nbr_idx=None):
+    """(dw [N,F,64], db [N,64]) of y = act(x @ w + b) given the layer OUTPUT y and dL/dy (column-block views allowed).
+    nbr_idx [N,m_max]: the layer's input is gather(x) over the neighbour table (x [*,rows,A] -> F = m_max*A), read in place."""
+    N, rows = y.shape[:2]
+    F = x.shape[2] if nbr_idx is None else x.shape[2] * nbr_idx.shape[1]
+    xp, xs, xr = _rows_view(x, x.shape[2], 'fc_bwd x')
     yp, ys, yr = _rows_view(y, FC_J, 'fc_bwd y')
     gp, gs, gr = _rows_view(dy, FC_J, 'fc_bwd dy')
     C_ = lib.nmarl_fc_bwd_chunks(rows, N)
     partial = torch.empty(N, C_, F + 1, FC_J, dtype=F32, device=x.device)
     dw = torch.empty(N, F, FC_J, dtype=F32, device=x.device)
     db = torch.empty(N, FC_J, dtype=F32, device=x.device)
+    if nbr_idx is not None:
+        check(lib.nmarl_fc_bwd_gather(rows, N, x.shape[2], nbr_idx.shape[1], ptr(nbr_idx, torch.int32), FC_J, xp, xs, xr, yp, ys, yr,
+                                      gp, gs, gr, act, ptr(partial), ptr(dw), F * FC_J, ptr(db), FC_J, stream()), 'nmarl_fc_bwd_gather')
+        return dw, db
     check(lib.nmarl_fc_bwd(rows, N, F, FC_J, xp, xs, xr, yp, ys, yr, gp, gs, gr, act, ptr(partial), ptr(dw), F * FC_J,
                            ptr(db), FC_J, stream()), 'nmarl_fc_bwd')
     return dw, db
@@ -424,16 +430,20 @@ def fc_bwd(x, y, dy, act):
 class _FcConcat(torch.autograd.Function):
     """S = [act(x_1 w_1 + b_1) | act(x_2 w_2 + b_2) | ...]  (tf.concat of per-input fc layers, policies.py:176-181,
     agents/utils.py:186-199) for DATA inputs x_i (no dx): each block is written in place into S, and the backward
-    streams S and dS once per block (fc_bwd) instead of relu-mask + skinny wgrad GEMM + bias reduction."""
+    streams S and dS once per block (fc_bwd) instead of relu-mask + skinny wgrad GEMM + bias reduction.
+    args = (x_i, w_i, b_i, nbr_idx_i or None) per layer: with a table the layer's input is gather(x_i), read in place."""
 
     @staticmethod
     def forward(ctx, act, *args):
-        xs, ws, bs = args[0::3], args[1::3], args[2::3]
-        N, rows = xs[0].shape[:2]
+        xs, ws, bs, idxs = args[0::4], args[1::4], args[2::4], args[3::4]
+        N, rows = ws[0].shape[0], xs[0].shape[1]
         S = torch.empty(N, rows, FC_J * len(xs), dtype=F32, device=xs[0].device)
-        for i, (x, w, b) in enumerate(zip(xs, ws, bs)):
-            fc_fwd(x, w, b, act, out=S[:, :, i * FC_J:(i + 1) * FC_J])
-        ctx.act = act
+        if any(i is not None for i in idxs):
+            fc_fwd_multi(list(zip(xs, ws, bs, idxs)), act, out=S)
+        else:
+            for i, (x, w, b) in enumerate(zip(xs, ws, bs)):
+                fc_fwd(x, w, b, act, out=S[:, :, i * FC_J:(i + 1) * FC_J])
+        ctx.act, ctx.idxs = act, idxs
         ctx.save_for_backward(S, *xs)
         return S
 
@@ -444,8 +454,8 @@ class _FcConcat(torch.autograd.Function):
             dS = dS.contiguous()
         grads = [None]
         for i, x in enumerate(xs):
-            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act)
-            grads += [None, dw, db]
+            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act, nbr_idx=ctx.idxs[i])
+            grads += [None, dw, db, None]
         return tuple(grads)
 
 
@@ -454,8 +464,8 @@ class _FcConcatSaved(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, act, S, *args):
-        xs = args[0::3]
-        ctx.act = act
+        xs = args[0::4]
+        ctx.act, ctx.idxs = act, args[3::4]
         ctx.save_for_backward(S, *xs)
         return S.view_as(S)
 
@@ -466,21 +476,26 @@ class _FcConcatSaved(torch.autograd.Function):
             dS = dS.contiguous()
         grads = [None, None]
         for i, x in enumerate(xs):
-            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act)
-            grads += [None, dw, db]
+            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act, nbr_idx=ctx.idxs[i])
+            grads += [None, dw, db, None]
         return tuple(grads)
 
 
 def fc_concat(parts, act, saved=None):
-    """parts: [(x_i [N,rows,F_i], w_i [N,F_i,64], b_i [N,64]), ...] with data inputs -> [N,rows,64*len(parts)]
-    (differentiable w.r.t. w_i, b_i).  Inputs wider than 64 or layers not 64 wide: plain batched GEMMs.
+    """parts: [(x_i [N,rows,F_i], w_i [N,F_i,64], b_i [N,64][, nbr_idx_i]), ...] with data inputs -> [N,rows,64*len(parts)]
+    (differentiable w.r.t. w_i, b_i).  nbr_idx_i [N,m_max] (optional): layer i's input is gather(x_i) over the neighbour
+    table, x_i [*,rows,A] read in place (the env's compact observation, the fingerprints).  Inputs wider than 64 or layers
+    not 64 wide: plain batched GEMMs.
     saved: the output as the rollout computed it with the current weights -- only the backward is set up."""
-    if all(fc_supported(x, w) and not x.requires_grad for x, w, _ in parts):
+    parts = [tuple(pt) + (None,) * (4 - len(pt)) for pt in parts]
+    if all((idx is not None or fc_supported(x, w)) and w.shape[1] <= FC_MAX_F and w.shape[2] == FC_J and not x.requires_grad
+           for x, w, _, idx in parts):
+        flat = [t for part in parts for t in part]
         if saved is not None:
-            return _FcConcatSaved.apply(act, saved, *[t for part in parts for t in part])
-        return _FcConcat.apply(act, *[t for part in parts for t in part])
+            return _FcConcatSaved.apply(act, saved, *flat)
+        return _FcConcat.apply(act, *flat)
     f = {BIAS_NONE: lambda t: t, BIAS_RELU: torch.relu, BIAS_TANH: torch.tanh}[act]
-    ys = [f(torch.baddbmm(b.unsqueeze(1), x, w)) for x, w, b in parts]
+    ys = [f(torch.baddbmm(b.unsqueeze(1), x if idx is None else nbr_gather(x, idx), w)) for x, w, b, idx in parts]
     return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
 
 

@@ -455,6 +455,13 @@ int nmarl_fc_bwd_chunks(int64_t rows, int32_t N);
 int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, int64_t x_sn, int64_t x_row,
                  const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
                  int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
+/* nmarl_fc_bwd with the layer's input gathered over a neighbour table inside the kernel, like nmarl_fc_fwd_multi's parts:
+ * x [*, rows, gather_A] (agent stride x_sn, row pitch x_row), nbr_idx [N, m_max] (-1 = absent: zeros), F = gather_A * m_max
+ * -- the update reads the env's compact observation slab / the fingerprints in place (policies.py:171-174). */
+int nmarl_fc_bwd_gather(int64_t rows, int32_t N, int32_t gather_A, int32_t m_max, const int32_t* nbr_idx, int32_t J,
+                        const float* x, int64_t x_sn, int64_t x_row, const float* y, int64_t y_sn, int64_t y_row,
+                        const float* dy, int64_t dy_sn, int64_t dy_row, int32_t act, float* partial, float* dw, int64_t dw_sn,
+                        float* db, int64_t db_sn, void* stream);
 /*
  * Backward of the thin actor / critic head layers y = h @ w + b over all rows of the update (policies.py:50-77):
  * h [N,rows,64], w [N,64,O] (O <= 8), dL/dy given as dy [N,rows,O1] (contiguous rows) plus, optionally, dy2 [N,rows]

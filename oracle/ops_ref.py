@@ -241,15 +241,18 @@ def fc_fwd_multi(parts, act, out=None):
     return y
 
 
-def fc_bwd(x, y, dy, act):
+def fc_bwd(x, y, dy, act, nbr_idx=None):
     """Gradient of fc w.r.t. (w, b), the activation derivative taken from the layer output y."""
+    if nbr_idx is not None:
+        x = nbr_gather(x, nbr_idx)
     g = dy * (y > 0).to(dy.dtype) if act == BIAS_RELU else dy * (1.0 - y * y) if act == BIAS_TANH else dy
     return torch.bmm(x.transpose(1, 2), g), g.sum(1)
 
 
 def fc_concat(parts, act, saved=None):
     """tf.concat of per-input fc layers (policies.py:176-181, agents/utils.py:186-199), plain autograd."""
-    ys = [_act(torch.baddbmm(b.unsqueeze(1), x, w), act) for x, w, b in parts]
+    parts = [tuple(pt) + (None,) * (4 - len(pt)) for pt in parts]
+    ys = [_act(torch.baddbmm(b.unsqueeze(1), x if idx is None else nbr_gather(x, idx), w), act) for x, w, b, idx in parts]
     return ys[0] if len(ys) == 1 else torch.cat(ys, dim=-1)
 
 

@@ -390,6 +390,35 @@ def test_fc_concat_autograd_matches_torch():
     torch.testing.assert_close(ops.fc_concat([(xw, ww, bw)], ops.BIAS_TANH), torch.tanh(torch.bmm(xw, ww)), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('N,rows,A,m_max,act', [(8, 4096 * 3 + 17, 5, 3, 1), (25, 1300, 12, 5, 2), (5, 63, 4, 2, 1)])
+def test_fc_bwd_with_in_kernel_gather(N, rows, A, m_max, act):
+    """nmarl_fc_bwd_gather: the layer's input gathered over a (-1 padded) neighbour table inside the backward kernel, read
+    in place from an env-major slab [rows,N,A] -- vs the same kernel on the materialised gather (bit for bit) and vs the
+    float64 restatement; S / dS as column blocks of wider buffers (the update's layout)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(N * 3 + rows + A)
+    slab = torch.randn(rows, N, A, generator=g)                       # env-major: agent stride A, row pitch N*A
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        js = [j for j in (i, i - 1, i + 1, i + 2, i - 2) if 0 <= j < N][:(i % m_max) + 1]
+        idx[i, :len(js)] = torch.tensor(js, dtype=torch.int32)
+    F = A * m_max
+    S = torch.relu(torch.randn(N, rows, 128, generator=g)) if act == 1 else torch.tanh(torch.randn(N, rows, 128, generator=g))
+    dS = torch.randn(N, rows, 128, generator=g)
+    xv = slab.cuda().transpose(0, 1)                                  # [N,rows,A] view of the slab
+    Sg, dSg, idxg = S.cuda(), dS.cuda(), idx.cuda()
+    dw, db = ops.fc_bwd(xv, Sg[:, :, 64:], dSg[:, :, 64:], act, nbr_idx=idxg)
+    xg = ops.nbr_gather(xv.contiguous(), idxg)
+    assert xg.shape == (N, rows, F)
+    dw2, db2 = ops.fc_bwd(xg, Sg[:, :, 64:], dSg[:, :, 64:], act)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dwr, dbr = ops_ref.fc_bwd(slab.double().transpose(0, 1), S[:, :, 64:].double(), dS[:, :, 64:].double(), act, nbr_idx=idx)
+    scale = max(1.0, float(dwr.abs().max()))
+    torch.testing.assert_close(dw.cpu().double(), dwr, rtol=2e-4, atol=2e-5 * scale)
+    torch.testing.assert_close(db.cpu().double(), dbr, rtol=2e-4, atol=2e-5 * scale)
+
+
 @pytest.mark.parametrize('N,rows,O', [(8, 4096, 5), (25, 131, 6), (3, 1, 1), (8, 70001, 5), (2, 300, 8)])
 def test_thin_linear_bwd(N, rows, O):
     """Heads backward in one streaming pass == dy w^T, h^T dy, sum dy (float64), deterministic."""

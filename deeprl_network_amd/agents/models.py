@@ -193,7 +193,10 @@ class IA2C:
             return False
         N, E, T, H, d = self.n_agent, self.E, self.n_step, self.n_lstm, self.device
         KX = p.params[p.k_wx].shape[1]
-        self.S_buf = torch.zeros(N, T, E, KX, dtype=F32, device=d)
+        # uncoupled nets: one zero slab more than needed, so that [S | .] and the state sequences have the SAME (T + 1)-slab
+        # shape -- the update's weight-gradient GEMMs then read the saved buffers in place (ops._lstm_seq_x_backward)
+        self.S_ext = None if p.coupled else torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
+        self.S_buf = torch.zeros(N, T, E, KX, dtype=F32, device=d) if p.coupled else self.S_ext[:, :T]
         self.G_buf = torch.zeros(N, T, E, 4 * H, dtype=F32, device=d)
         self.H_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
@@ -398,7 +401,7 @@ class IA2C:
         X = self.buf_x[:T]            # compact [T,E,N,n_feat] slab: the encoders' kernels gather the neighbours themselves
         if self.save_acts:
             Hs = self.policy.unroll_saved(X, FP, self.S_buf, self.G_buf, self.H_all, self.C_all,
-                                          self.buf_done_pre, masked_steps=self.masked_steps)
+                                          self.buf_done_pre, masked_steps=self.masked_steps, S_ext=self.S_ext)
         else:
             Hs = self.policy.unroll(X, FP, self.buf_done_pre, self.h_bw, self.c_bw, masked_steps=self.masked_steps)
         loss = self._loss(Hs)

@@ -378,16 +378,17 @@ class BatchedPolicy:
         which then needs no forward pass: nets whose recurrent step is the fused x-side kernel."""
         return self.xside and self.fused_heads
 
-    def unroll_saved(self, X, FP, S, G, Hall, Call, done, masked_steps=None):
+    def unroll_saved(self, X, FP, S, G, Hall, Call, done, masked_steps=None, S_ext=None):
         """`unroll` for a batch whose forward pass the rollout already did with the CURRENT weights: S [N,T,E,KX] the
-        LSTM inputs, G the gates, Hall / Call [N,T+1,E,H] the state sequences it saved.  Sets up the backward only."""
+        LSTM inputs, G the gates, Hall / Call [N,T+1,E,H] the state sequences it saved.  Sets up the backward only.
+        S_ext: the [N,T+1,E,KX] buffer S is the first T slabs of (last slab zero), see ops._lstm_seq_x_backward."""
         T, E = done.shape
         Xv = X.reshape(T * E, self.N, X.shape[-1]).transpose(0, 1)          # gathered [.., n_obs] or compact [.., n_feat] slab
         if self.coupled:
             return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps)
         s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
         Hs = ops.lstm_sequence_saved(s.view(self.N, T, E, s.shape[-1]), self.params[self.k_wx], self.params[self.k_wh],
-                                     self.params[self.k_b], G, Hall, Call, done, masked_steps)
+                                     self.params[self.k_b], G, Hall, Call, done, masked_steps, s_ext=S_ext)
         return Hs.reshape(self.N, T * E, self.n_h)
 
     def save_spec(self):

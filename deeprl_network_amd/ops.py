@@ -851,15 +851,27 @@ class _LstmSequenceX(torch.autograd.Function):
         return ds, dwx, dwh, db, dh_rec, dc, None, None, None
 
 
-def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, want_state_grad=True):
+def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, want_state_grad=True, s_ext=None):
     """BPTT of z_t = s_t @ wx + (h_{t-1} keep_t) @ wh, (h_t, c_t) = cell(z_t + b, c_{t-1}, done_t) from the saved gates
     G [N,T,E,4H] and state sequences Hall / Call [N,T+1,E,H]: the reverse loop of (cell_bwd, dgrad GEMM vs wh), then
     ds = dZ @ wx^T, dwx = s^T dZ, dwh = (h keep)^T dZ, db = sum dZ over all T*E rows."""
     N, T, E, H4 = G.shape
     H = H4 // 4
     dHs = dHs.contiguous()
-    dZ = torch.empty_like(G)
     keep = (1.0 - done)
+    KX = s.shape[3]
+    # In-place weight gradients: with the LSTM inputs handed over as the first T slabs of a (T + 1)-slab buffer (last slab
+    # zero), dZ allocated the same way (last slab zero) and the h sequence being (T + 1) slabs anyway, all three are plain
+    # contiguous [N, (T+1)*E, .] operands of the row-split GEMMs: no masked COPY of the h sequence (0.2 ms at T*E*N = 2 M
+    # rows).  The few maskable steps are masked in the saved buffer itself (the rollout rewrites it next batch).
+    ext = (s_ext is not None and len(masked) < T and s_ext.shape == (N, T + 1, E, KX) and s_ext.is_contiguous() and Hall.is_contiguous()
+           and s.data_ptr() == s_ext.data_ptr() and ((T + 1) * E) % WGRAD_SPLIT == 0)
+    if ext:
+        dZe = torch.empty(N, T + 1, E, H4, dtype=F32, device=G.device)
+        dZe[:, T].zero_()
+        dZ = dZe[:, :T]
+    else:
+        dZ = torch.empty_like(G)
     db = None
     if bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4:
         # the whole reverse recurrence in one launch; the bias gradient comes out of the same pass.  It multiplies by
@@ -876,21 +888,27 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, w
             dh_rec = torch.bmm(dZ[:, t], wh_t)
             if t in masked:
                 dh_rec = dh_rec * keep[t].view(1, E, 1)
-    dZf = dZ.view(N, T * E, H4)
-    if len(masked) == T:
-        Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+    dZf = dZ.reshape(N, T * E, H4)              # a view in both layouts (agent-strided when `ext`)
+    if ext:
+        with torch.no_grad():
+            for t in masked:
+                Hall[:, t].mul_(keep[t].view(1, E, 1))
+        dZx = dZe.view(N, (T + 1) * E, H4)
+        dwh = wgrad(Hall.view(N, (T + 1) * E, H), dZx)
+        dwx = wgrad(s_ext.view(N, (T + 1) * E, KX), dZx)
     else:
-        Hprev = Hall[:, :T].clone()
-        for t in masked:
-            Hprev[:, t].mul_(keep[t].view(1, E, 1))
-        Hprev = Hprev.view(N, T * E, H)
-    dwh = wgrad(Hprev, dZf)
+        if len(masked) == T:
+            Hprev = (Hall[:, :T] * keep.view(1, T, E, 1)).reshape(N, T * E, H)
+        else:
+            Hprev = Hall[:, :T].clone()
+            for t in masked:
+                Hprev[:, t].mul_(keep[t].view(1, E, 1))
+            Hprev = Hprev.view(N, T * E, H)
+        dwh = wgrad(Hprev, dZf)
+        dwx = wgrad(s.reshape(N, T * E, KX), dZf)
     if db is None:
         db = dZf.sum(dim=1)
-    KX = s.shape[3]
-    sf = s.reshape(N, T * E, KX)
     ds = torch.bmm(dZf, wx.transpose(1, 2)).view(N, T, E, KX) if need_ds else None
-    dwx = wgrad(sf, dZf)
     return ds, dwx, dwh, db, dh_rec, dc
 
 
@@ -902,23 +920,26 @@ class _LstmSequenceSaved(torch.autograd.Function):
     same weights, same inputs, same function -- the values are those of the rollout."""
 
     @staticmethod
-    def forward(ctx, s, wx, wh, b, G, Hall, Call, done, masked_steps):
+    def forward(ctx, s, wx, wh, b, G, Hall, Call, done, masked_steps, s_ext):
         T = G.shape[1]
         ctx.save_for_backward(G, Hall, Call, s, wx, wh, done)
         ctx.masked = set(range(T)) if masked_steps is None else set(masked_steps)
+        ctx.s_ext = s_ext
         return Hall[:, 1:]
 
     @staticmethod
     def backward(ctx, dHs):
         G, Hall, Call, s, wx, wh, done = ctx.saved_tensors
         ds, dwx, dwh, db, _, _ = _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, ctx.masked, dHs,
-                                                      ctx.needs_input_grad[0], want_state_grad=False)
-        return ds, dwx, dwh, db, None, None, None, None, None
+                                                      ctx.needs_input_grad[0], want_state_grad=False, s_ext=ctx.s_ext)
+        return ds, dwx, dwh, db, None, None, None, None, None, None
 
 
-def lstm_sequence_saved(s, wx, wh, b, G, Hall, Call, done, masked_steps):
-    """s [N,T,E,KX] (autograd-connected encoders' output), G / Hall / Call saved by the rollout -> Hs [N,T,E,H]."""
-    return _LstmSequenceSaved.apply(s, wx, wh, b, G, Hall, Call, done, masked_steps)
+def lstm_sequence_saved(s, wx, wh, b, G, Hall, Call, done, masked_steps, s_ext=None):
+    """s [N,T,E,KX] (autograd-connected encoders' output), G / Hall / Call saved by the rollout -> Hs [N,T,E,H].
+    s_ext (optional): the [N,T+1,E,KX] buffer whose first T slabs s is a view of, last slab zero: the weight gradients then
+    read the saved sequences in place (see _lstm_seq_x_backward)."""
+    return _LstmSequenceSaved.apply(s, wx, wh, b, G, Hall, Call, done, masked_steps, s_ext)
 
 
 def lstm_sequence_x(s, wx, wh, b, h0, c0, done, masked_steps, img):

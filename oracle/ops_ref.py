@@ -365,7 +365,7 @@ def lstm_sequence_x(s, wx, wh, b, h0, c0, done, masked_steps, img):
     return torch.stack(hs, dim=1)
 
 
-def lstm_sequence_saved(s, wx, wh, b, G, Hall, Call, done, masked_steps):
+def lstm_sequence_saved(s, wx, wh, b, G, Hall, Call, done, masked_steps, s_ext=None):
     """The restatement has no saved-activation shortcut: it recomputes the sequence from Hall[:, 0] / Call[:, 0] (what
     the product's rollout saved must equal this; tests compare the two)."""
     return lstm_sequence_x(s, wx, wh, b, Hall[:, 0], Call[:, 0], done, masked_steps, None)

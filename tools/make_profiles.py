@@ -85,7 +85,8 @@ with open(os.path.join(dst, '%s_other_configs.md' % tag), 'w') as f:
 
 # ---- verbatim copies
 for a, b in (('%s_pmc_traffic.json', '%s_pmc_traffic.json'), ('%s_pmc_traffic.md', '%s_pmc_traffic.md'), ('%s_pmc_lstm.md', '%s_pmc_lstm_stalls.md'),
-             ('%s_time_fused.log', '%s_time_fused.txt'), ('%s_env_microbench.log', '%s_env_microbench.txt')):
+             ('%s_time_fused.log', '%s_time_fused.txt'), ('%s_env_microbench.log', '%s_env_microbench.txt'),
+             ('%s_step_timeline.txt', '%s_step_timeline.txt')):
     if os.path.exists(os.path.join(src, a % tag)):
         shutil.copy(os.path.join(src, a % tag), os.path.join(dst, b % tag))
 print('profiles/%s_* written' % tag)

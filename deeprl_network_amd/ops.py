@@ -686,6 +686,9 @@ def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, app
                                    *_pn(dhd), 1 if apply_keep else 0, stream()), 'nmarl_lstm_bptt_step')
 
 
+BPTT_SEQ_MAX_E = 1 << 21     # nmarl_lstm_bptt_seq addresses one (agent, step) panel with 32-bit byte offsets
+
+
 def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False):
     """The whole reverse recurrence in one launch (nmarl_lstm_bptt_seq): G / dZ [N,T,E,4H], Call [N,T+1,E,H], done [T,E],
     dHs [N,T,E,H] (the heads' dL/dh_t), img = lstm_bptt_wimage(None, wh).  -> (db [N,4H] or None, dh0, dc0 or None):
@@ -873,7 +876,7 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, w
     else:
         dZ = torch.empty_like(G)
     db = None
-    if bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4:
+    if bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4 and E <= BPTT_SEQ_MAX_E:
         # the whole reverse recurrence in one launch; the bias gradient comes out of the same pass.  It multiplies by
         # (1 - done_t) at every step: exact also for the steps outside `masked`, whose done_t is zero by contract
         db, dh_rec, dc = bptt_seq(G, Call, done, dHs, lstm_bptt_wimage(None, wh), dZ, want_state_grad=want_state_grad)

@@ -88,6 +88,9 @@ def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, app
         dx.copy_(v)
 
 
+BPTT_SEQ_MAX_E = 1 << 21
+
+
 def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False, wh=None):
     """T reverse steps of bptt_step (KM = 0, every step masked) -> (db, dh0, dc0); wh is the restatement's weight
     operand (the product passes the kernel-side image `img`, which the restatement cannot read back)."""

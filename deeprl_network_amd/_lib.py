@@ -111,6 +111,8 @@ SIGNATURES = {
     'nmarl_nbr_gather_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_mean_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
     'nmarl_nbr_mean_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p],
+    'nmarl_nbr_gather_bwd_add': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p],
+    'nmarl_nbr_mean_bwd_add': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p],
     'nmarl_nbr_onehot': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p],
     'nmarl_lstm_cell_fwd': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_step_fused': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p,

@@ -221,15 +221,17 @@ class CoupledSequenceSaved(torch.autograd.Function):
                     if kind == 'dial':
                         DS[:, t].copy_(dx)
                     torch.mul(dx, (hm[:, t] > 0), out=D1[:, t])
+            # dL/dh_{t-1} = message part (adjoint of the neighbour gather / mean) + recurrent part, added in the same pass
+            if not dhd.is_contiguous():
+                dhd = dhd.contiguous()
             if kind == 'nc':
-                dh_msg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
+                dh_rec = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H, add=dhd)
             elif kind == 'ic3':
-                dh_msg = ops.nbr_mean_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx)
+                dh_rec = ops.nbr_mean_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, add=dhd)
             else:
                 dmsg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
                 torch.mul(dmsg, (A2[:, t] > 0), out=D2[:, t])
-                dh_msg = torch.bmm(D2[:, t], mfc_w.transpose(1, 2))
-            dh_rec = dh_msg + dhd
+                dh_rec = torch.baddbmm(dhd, D2[:, t], mfc_w.transpose(1, 2))
         dZf = dZ.view(N, R, H4)
         Hprev = Hall[:, :T]
         if len(masked) == T:

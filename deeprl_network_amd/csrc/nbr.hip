@@ -43,7 +43,7 @@ __device__ __forceinline__ float4 scale(const float4 a, const float s) { return 
 template <typename V>
 __global__ __launch_bounds__(256) void gather_bwd_kernel(
     const int64_t E, const int N, const int Fv, const int m_max, const int32_t* __restrict__ nbr,
-    const V* __restrict__ dy, V* __restrict__ dx) {
+    const V* __restrict__ dy, const V* __restrict__ add, V* __restrict__ dx) {
     __shared__ int32_t s_nbr[MAX_PAIRS];
     for (int p = threadIdx.x; p < N * m_max; p += blockDim.x) s_nbr[p] = nbr[p];
     __syncthreads();
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(
                 acc(g, dy[(int64_t)i * n * m_max + (e * m_max + k) * Fv + f]);
             }
         }
+        if (add) acc(g, add[(int64_t)j * n + idx]);          // (sum over the fan-in) + add: the order of the separate pass
         dx[(int64_t)j * n + idx] = g;
     }
 }
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void mean_fwd_kernel(
 template <typename V>
 __global__ __launch_bounds__(256) void mean_bwd_kernel(
     const int64_t E, const int N, const int Fv, const int m_max, const int32_t* __restrict__ nbr,
-    const V* __restrict__ dy, V* __restrict__ dx) {
+    const V* __restrict__ dy, const V* __restrict__ add, V* __restrict__ dx) {
     __shared__ int32_t s_nbr[MAX_PAIRS];
     __shared__ float s_inv[MAX_PAIRS];
     for (int p = threadIdx.x; p < N * m_max; p += blockDim.x) s_nbr[p] = nbr[p];
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void mean_bwd_kernel(
                 acc(g, scale(dy[(int64_t)i * n + idx], s_inv[i]));
             }
         }
+        if (add) acc(g, add[(int64_t)j * n + idx]);
         dx[(int64_t)j * n + idx] = g;
     }
 }
@@ -159,19 +161,30 @@ extern "C" int nmarl_nbr_gather_fwd(int64_t E, int32_t N, int32_t F, int32_t m_m
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_nbr_gather_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
-                                    const float* dy, float* dx, void* stream) {
+static int launch_gather_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx, const float* dy, const float* add,
+                             float* dx, void* stream) {
     if (!args_ok(E, N, F, m_max, nbr_idx, dy, dx)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec4(F, dy, dx)) {
+    if (vec4(F, dy, dx) && (!add || ((uintptr_t)add % 16) == 0)) {
         hipLaunchKernelGGL(gather_bwd_kernel<float4>, dim3(grid_x(E * F / 4), N), dim3(256), 0, s, E, N, F / 4, m_max,
-                           nbr_idx, reinterpret_cast<const float4*>(dy), reinterpret_cast<float4*>(dx));
+                           nbr_idx, reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(add), reinterpret_cast<float4*>(dx));
     } else {
         hipLaunchKernelGGL(gather_bwd_kernel<float>, dim3(grid_x(E * F), N), dim3(256), 0, s, E, N, F, m_max, nbr_idx,
-                           dy, dx);
+                           dy, add, dx);
     }
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_nbr_gather_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                                    const float* dy, float* dx, void* stream) {
+    return launch_gather_bwd(E, N, F, m_max, nbr_idx, dy, nullptr, dx, stream);
+}
+
+extern "C" int nmarl_nbr_gather_bwd_add(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                                        const float* dy, const float* add, float* dx, void* stream) {
+    if (!add) return NMARL_EINVAL;
+    return launch_gather_bwd(E, N, F, m_max, nbr_idx, dy, add, dx, stream);
 }
 
 extern "C" int nmarl_nbr_mean_fwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
@@ -188,18 +201,29 @@ extern "C" int nmarl_nbr_mean_fwd(int64_t E, int32_t N, int32_t F, int32_t m_max
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_nbr_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
-                                  const float* dy, float* dx, void* stream) {
+static int launch_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx, const float* dy, const float* add,
+                           float* dx, void* stream) {
     if (!args_ok(E, N, F, m_max, nbr_idx, dy, dx)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (vec4(F, dy, dx)) {
+    if (vec4(F, dy, dx) && (!add || ((uintptr_t)add % 16) == 0)) {
         hipLaunchKernelGGL(mean_bwd_kernel<float4>, dim3(grid_x(E * F / 4), N), dim3(256), 0, s, E, N, F / 4, m_max,
-                           nbr_idx, reinterpret_cast<const float4*>(dy), reinterpret_cast<float4*>(dx));
+                           nbr_idx, reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(add), reinterpret_cast<float4*>(dx));
     } else {
-        hipLaunchKernelGGL(mean_bwd_kernel<float>, dim3(grid_x(E * F), N), dim3(256), 0, s, E, N, F, m_max, nbr_idx, dy, dx);
+        hipLaunchKernelGGL(mean_bwd_kernel<float>, dim3(grid_x(E * F), N), dim3(256), 0, s, E, N, F, m_max, nbr_idx, dy, add, dx);
     }
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_nbr_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                                  const float* dy, float* dx, void* stream) {
+    return launch_mean_bwd(E, N, F, m_max, nbr_idx, dy, nullptr, dx, stream);
+}
+
+extern "C" int nmarl_nbr_mean_bwd_add(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                                      const float* dy, const float* add, float* dx, void* stream) {
+    if (!add) return NMARL_EINVAL;
+    return launch_mean_bwd(E, N, F, m_max, nbr_idx, dy, add, dx, stream);
 }
 
 extern "C" int nmarl_nbr_onehot(int64_t E, int32_t N, int32_t A, int32_t m_max, const int32_t* nbr_idx,

@@ -77,21 +77,29 @@ def nbr_gather(x, nbr_idx):
     return _NbrGather.apply(x, nbr_idx)
 
 
-def nbr_gather_bwd(dy, nbr_idx, F):
-    """Adjoint of nbr_gather as a plain function (manual BPTT): dy [N,E,m_max*F] -> dx [N,E,F]."""
+def nbr_gather_bwd(dy, nbr_idx, F, add=None):
+    """Adjoint of nbr_gather as a plain function (manual BPTT): dy [N,E,m_max*F] -> dx [N,E,F] (+ add [N,E,F], same pass)."""
     N, E, _ = dy.shape
     dy = dy.contiguous()
     dx = torch.empty(N, E, F, dtype=F32, device=dy.device)
+    if add is not None:
+        check(lib.nmarl_nbr_gather_bwd_add(E, N, F, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(dy, F32), ptr(add, F32), ptr(dx),
+                                           stream()), 'nmarl_nbr_gather_bwd_add')
+        return dx
     check(lib.nmarl_nbr_gather_bwd(E, N, F, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(dy, F32), ptr(dx), stream()),
           'nmarl_nbr_gather_bwd')
     return dx
 
 
-def nbr_mean_bwd(dy, nbr_idx):
-    """Adjoint of nbr_mean as a plain function: dy [N,E,F] -> dx [N,E,F]."""
+def nbr_mean_bwd(dy, nbr_idx, add=None):
+    """Adjoint of nbr_mean as a plain function: dy [N,E,F] -> dx [N,E,F] (+ add [N,E,F], same pass)."""
     N, E, F = dy.shape
     dy = dy.contiguous()
     dx = torch.empty_like(dy)
+    if add is not None:
+        check(lib.nmarl_nbr_mean_bwd_add(E, N, F, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(dy, F32), ptr(add, F32), ptr(dx),
+                                         stream()), 'nmarl_nbr_mean_bwd_add')
+        return dx
     check(lib.nmarl_nbr_mean_bwd(E, N, F, nbr_idx.shape[1], ptr(nbr_idx, torch.int32), ptr(dy, F32), ptr(dx), stream()),
           'nmarl_nbr_mean_bwd')
     return dx

@@ -232,6 +232,12 @@ int nmarl_nbr_mean_fwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int
                        const float* x, float* y, void* stream);
 int nmarl_nbr_mean_bwd(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
                        const float* dy, float* dx, void* stream);
+/* The adjoints with a second addend, dx = (sum over the fan-in) + add [N,E,F]: the manual BPTT of the coupled nets adds
+ * the recurrent part of dL/dh_{t-1} to the message part in the same pass (add may alias dx). */
+int nmarl_nbr_gather_bwd_add(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                             const float* dy, const float* add, float* dx, void* stream);
+int nmarl_nbr_mean_bwd_add(int64_t E, int32_t N, int32_t F, int32_t m_max, const int32_t* nbr_idx,
+                           const float* dy, const float* add, float* dx, void* stream);
 /*
  * One-hot of the neighbours' actions for the centralised critic:
  * y[i, e, k*A + a] = (action[e, nbr_idx[i,k]] == a); replaces

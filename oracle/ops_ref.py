@@ -34,20 +34,22 @@ def nbr_mean(x, nbr_idx):
                         for js in neighbor_lists(nbr_idx)], 0)
 
 
-def nbr_gather_bwd(dy, nbr_idx, F):
+def nbr_gather_bwd(dy, nbr_idx, F, add=None):
     """Adjoint of nbr_gather (by autograd of the forward restatement)."""
     N, E, _ = dy.shape
     x = torch.zeros(N, E, F, dtype=dy.dtype, requires_grad=True)
     with torch.enable_grad():
         y = nbr_gather(x, nbr_idx)
-    return torch.autograd.grad(y, x, dy)[0]
+    g = torch.autograd.grad(y, x, dy)[0]
+    return g if add is None else g + add
 
 
-def nbr_mean_bwd(dy, nbr_idx):
+def nbr_mean_bwd(dy, nbr_idx, add=None):
     x = torch.zeros_like(dy, requires_grad=True)
     with torch.enable_grad():
         y = nbr_mean(x, nbr_idx)
-    return torch.autograd.grad(y, x, dy)[0]
+    g = torch.autograd.grad(y, x, dy)[0]
+    return g if add is None else g + add
 
 
 def cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=None):

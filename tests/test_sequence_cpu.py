@@ -50,3 +50,41 @@ def test_manual_bptt_equals_autograd(cls_name, topo, masked):
     for a, b, name in zip(grads[0], grads[1], ['params', 'h0', 'c0']):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5, msg=name)
     assert grads[0][0].abs().sum() > 0
+
+
+@pytest.mark.parametrize('N,T,E', [(3, 5, 7), (1, 1, 2)])
+def test_restated_one_launch_bptt_equals_autograd_of_the_restated_cell(N, T, E):
+    """The float64 checker of nmarl_lstm_bptt_seq (oracle/ops_ref.bptt_seq: T reverse steps of the closed-form cell
+    backward + dz @ wh^T, bias gradient, gradient of the initial state) against torch.autograd through the restated
+    forward recurrence (ops_ref.lstm_cell, agents/utils.py:102-113): pins the checker the GPU test compares the kernel with."""
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 17 + T * 3 + E)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)                    # noqa: E731
+    zx = r(N, T, E, 4 * H)                                   # x-side pre-activation of every step (a leaf: its gradient is dZ)
+    wh, b = r(N, H, 4 * H) * 0.2, r(N, 4 * H) * 0.1
+    h0, c0 = r(N, E, H) * 0.5, r(N, E, H) * 0.5
+    done = (torch.rand(T, E, generator=g) < 0.3).double()
+    dHs = r(N, T, E, H)
+    zx.requires_grad_(True); b.requires_grad_(True); h0.requires_grad_(True); c0.requires_grad_(True)
+    h, c = h0, c0
+    Hs, gates, cs = [], [], [c0]
+    for t in range(T):
+        keep = (1.0 - done[t]).view(1, E, 1)
+        z = zx[:, t] + torch.bmm(h * keep, wh)
+        hn, cn = ops_ref.lstm_cell(z, b, c, done[t])
+        zb = z + b.unsqueeze(1)
+        gates.append(torch.cat([torch.sigmoid(zb[..., :3 * H]), torch.tanh(zb[..., 3 * H:])], dim=-1))
+        Hs.append(hn); cs.append(cn)
+        h, c = hn, cn
+    loss = sum((Hs[t] * dHs[:, t]).sum() for t in range(T))
+    loss.backward()
+    G = torch.stack([x.detach() for x in gates], dim=1)
+    Call = torch.stack([x.detach() for x in cs], dim=1)
+    dZ = torch.empty(N, T, E, 4 * H, dtype=torch.float64)
+    db, dh0, dc0 = ops_ref.bptt_seq(G, Call, done, dHs, None, dZ, want_state_grad=True, wh=wh)
+    tol = dict(rtol=1e-9, atol=1e-11)
+    torch.testing.assert_close(dZ, zx.grad, **tol)
+    torch.testing.assert_close(db, b.grad, **tol)
+    torch.testing.assert_close(dh0, h0.grad, **tol)        # gradients of the initial state (the done mask of step 0 applied)
+    torch.testing.assert_close(dc0, c0.grad, **tol)

@@ -88,3 +88,28 @@ def test_restated_one_launch_bptt_equals_autograd_of_the_restated_cell(N, T, E):
     torch.testing.assert_close(db, b.grad, **tol)
     torch.testing.assert_close(dh0, h0.grad, **tol)        # gradients of the initial state (the done mask of step 0 applied)
     torch.testing.assert_close(dc0, c0.grad, **tol)
+
+
+def test_restated_gathering_fc_backward_equals_autograd():
+    """The checker of nmarl_fc_bwd_gather / nmarl_fc_fwd_multi (ops_ref.fc_bwd / fc_concat with a neighbour table: the
+    concatenation of policies.py:171-174 folded into the layer) against autograd of relu(gather(x) @ w + b) built from
+    plain tensor indexing -- and the table semantics: -1 slots are zeros, slot order is column order."""
+    from oracle import ops_ref
+    N, rows, A, m_max = 5, 11, 3, 3
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, rows, A, generator=g, dtype=torch.float64)
+    idx = torch.tensor([[0, 1, -1], [1, 0, 2], [2, 1, 3], [3, 2, 4], [4, 3, -1]], dtype=torch.int32)     # self first, then neighbours
+    w = torch.randn(N, A * m_max, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(N, 64, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(N, rows, 64, generator=g, dtype=torch.float64)
+    cols = []
+    for n in range(N):
+        cols.append(torch.cat([x[int(j)] if j >= 0 else torch.zeros(rows, A, dtype=torch.float64) for j in idx[n]], dim=-1))
+    xin = torch.stack(cols, 0)
+    y = torch.relu(torch.bmm(xin, w) + b.unsqueeze(1))
+    (y * dy).sum().backward()
+    s = ops_ref.fc_concat([(x, w.detach(), b.detach(), idx)], ops_ref.BIAS_RELU)
+    torch.testing.assert_close(s, y.detach(), rtol=1e-12, atol=1e-12)
+    dw, db = ops_ref.fc_bwd(x, y.detach(), dy, ops_ref.BIAS_RELU, nbr_idx=idx)
+    torch.testing.assert_close(dw, w.grad, rtol=1e-10, atol=1e-12)
+    torch.testing.assert_close(db, b.grad, rtol=1e-10, atol=1e-12)

@@ -56,7 +56,13 @@ def test_nn_fixtures_regenerate(tmp_path):
         assert _same(str(tmp_path), 5) == 5
 
 
+def test_e2e_multi_episode_fixture_regenerates(tmp_path):
+    """Three training episodes + test episodes of the real reference loop (35 s, single-threaded by construction)."""
+    _run('make_golden_e2e.py', tmp_path, '--only', 'multi')
+    assert _same(str(tmp_path), 1) == 1
+
+
 @pytest.mark.skipif(os.environ.get('NMARL_REGEN_ALL') != '1', reason='9 CPU-minutes: NMARL_REGEN_ALL=1')
 def test_e2e_fixtures_regenerate(tmp_path):
     _run('make_golden_e2e.py', tmp_path)
-    assert _same(str(tmp_path), 2) == 2
+    assert _same(str(tmp_path), 3) == 3

@@ -53,6 +53,52 @@ def test_first_episode_replays_reference(name):
         pytest.skip('sampled action flipped at step %d (fp32 CDF boundary); prefix verified' % first_div)
 
 
+def test_three_episodes_replay_reference():
+    """The episode seam: three training episodes + their test episodes of the REAL reference loop
+    (tests/golden/e2e_multi_ma2c_nc_slowdown.npz) through the product env kernel, product model and product Trainer --
+    second / third env.reset() (seed0 + 2k, cacc_env.py:166-189; the test episode reuses the training seed),
+    model.reset(), states_bw / RMSProp slots carried across episodes and test episodes (utils.py:213-254)."""
+    from deeprl_network_amd.envs.cacc_env import CACCEnv
+    from deeprl_network_amd.main import init_agent
+    from deeprl_network_amd.utils import Counter, Trainer
+    z = load_npz(os.path.join(GOLDEN, 'e2e_multi_ma2c_nc_slowdown.npz'))
+    cp = cacc_config(agent=str(z['agent']), scenario=str(z['scenario']), seed=int(z['seed']), n_step=60,
+                     reward_norm=float(z['reward_norm']), total_step=10 ** 9)
+    env = CACCEnv(cp['ENV_CONFIG'])
+    model = init_agent(env, cp['MODEL_CONFIG'], 10 ** 9, int(z['seed']))
+    counter = Counter(10 ** 9, 10 ** 9, 10 ** 9)
+    log = {'a': [], 'g': [], 'train': []}
+    orig_step, orig_reset = env.step, env.reset
+    n_train = [0]
+
+    def reset(*a, **k):
+        if env.train_mode:
+            n_train[0] += 1
+            counter.stop = n_train[0] == 3
+        return orig_reset(*a, **k)
+
+    def step(action):
+        out = orig_step(action)
+        log['a'].append(np.array(action).copy()); log['g'].append(out[3]); log['train'].append(env.train_mode)
+        return out
+    env.step, env.reset = step, reset
+    tr = Trainer(env, model, counter, None, output_path=None)
+    tr.run()
+    acts, g = np.array(log['a']), np.array(log['g'])
+    n = min(len(acts), len(z['actions']))
+    same = np.all(acts[:n] == z['actions'][:n], axis=1)
+    first_div = n if same.all() else int(np.argmin(same))
+    assert first_div >= 420, 'diverged at step %d (episode %d)' % (first_div, z['episode'][first_div])   # past the first seam
+    np.testing.assert_array_equal(np.array(log['train'])[:first_div], z['train'][:first_div])
+    np.testing.assert_allclose(g[:first_div], z['rewards'][:first_div], rtol=1e-4, atol=1e-2)
+    if first_div == len(z['actions']) == len(acts):
+        np.testing.assert_allclose([[d['avg_reward'], d['std_reward'], d['step']] for d in tr.data], z['logged'], rtol=1e-3)
+        s = var_stats_from_named(model.policy.params.ref_variables())
+        np.testing.assert_allclose(s[:, 1:3], z['stats'][:, 1:3], rtol=2e-3, atol=2e-5)
+    else:
+        pytest.skip('sampled action flipped at step %d (fp32 CDF boundary); prefix incl. the first episode seam verified' % first_div)
+
+
 def test_cli_train_and_evaluate(tmp_path):
     """main.py train (E=1 reference loop and batched loop) + evaluate, checkpoint naming, CSV outputs."""
     import pandas as pd

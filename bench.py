@@ -72,7 +72,7 @@ def parse():
     ap.add_argument('--tune-only', action='store_true', help='internal: run one batch to tune the library GEMMs, print nothing')
     ap.add_argument('--no-tunableop', action='store_true', help='do not auto-tune the library GEMMs (PyTorch TunableOp)')
     ap.add_argument('--cpu-batches', type=int, default=100,
-                    help='n_step batches of the E=1 CPU baseline (100 = 6000 env steps, about 13 s on one core)')
+                    help='n_step batches of the E=1 CPU baseline (100 = 6000 env steps of BASELINE configs[0], ~10 s on one core)')
     return ap.parse_args()
 
 
@@ -189,6 +189,35 @@ def measure_lstm_step(model, n=60, reps=10):
     return e0.elapsed_time(e1) * 1e3 / (reps * n), flops, nbytes, name
 
 
+def measure_lstm_step_in_rollout(trainer):
+    """Average duration of the LSTM lock-step launches INSIDE a real rollout (what rocprofv3's kernel trace reports for
+    the batch): one eager n_step rollout of the trainer -- same launches, same neighbours on the stream (encoder kernel
+    before, env kernel after) as the captured graph -- with a HIP event pair on the launch stream around every
+    step_policy_value / step_policy launch.  The rollout state is restored afterwards."""
+    pol = trainer.model.policy
+    name = 'step_policy_value' if pol.fused_pv else 'step_policy'
+    orig = getattr(pol, name)
+    pairs = []
+
+    def timed(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(*a, **k)
+        e1.record()
+        pairs.append((e0, e1))
+        return r
+    snap = trainer._snapshot()
+    setattr(pol, name, timed)
+    try:
+        trainer._rollout()
+        torch.cuda.synchronize()
+    finally:
+        setattr(pol, name, orig)
+        trainer._restore(snap)
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs[2:])        # the first launches pay cold caches
+    return sum(us) / len(us), us[len(us) // 2], len(us)
+
+
 def measure_bptt_seq(model, reps=5):
     """Average duration of the second kernel of the update, the whole reverse recurrence in one launch
     (nmarl_lstm_bptt_seq), on the model's own saved-activation buffers (shapes [N,T,E,*]): HIP events on the launch
@@ -217,16 +246,22 @@ def measure_bptt_seq(model, reps=5):
 
 
 def pmc_traffic(key):
-    """HBM bytes per replica-step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: separate
+    """HBM bytes per replica-step from the committed rocprofv3 PMC passes (profiles/rNN_pmc_traffic.json: separate
     FETCH_SIZE / WRITE_SIZE runs of tools/pmc_env.py, FETCH x2 per MI355X_MICROARCH.md, calibrated on a known copy).
-    PMC counters cannot be read from inside this process, so the newest committed measurement is reported."""
+    PMC counters cannot be read from inside this process, so a committed measurement is reported: for every key the one
+    of the HIGHEST round (the number in the file name) that holds it -- a later round need not re-measure kernels it did
+    not touch."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json')))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    k = d['kernels'].get(key)
-    return (k['traffic_bytes_per_replica'], os.path.basename(files[-1])) if k else (None, None)
+    import re
+    best = (None, None, -1)
+    for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')):
+        m = re.match(r'r(\d+)[a-z]?_pmc_traffic\.json$', os.path.basename(f))
+        if not m or int(m.group(1)) <= best[2]:
+            continue
+        k = json.load(open(f)).get('kernels', {}).get(key)
+        if k:
+            best = (k['traffic_bytes_per_replica'], os.path.basename(f), int(m.group(1)))
+    return best[0], best[1]
 
 
 def cpu_port_worker(cfg_path, n_batches):
@@ -241,30 +276,55 @@ def cpu_port_worker(cfg_path, n_batches):
     print('CPUPORT %d %.6f %d' % (steps, sec, env.n_agent))
 
 
-def cpu_baseline(cfg_path, n_batches):
-    """Reference-equivalent E=1 CPU loop (restated; TF-1.12 cannot run here): ONE core (the `value`), then one
-    independent replica per host core; plus the env-only numbers of the REAL reference env (committed profile)."""
+def _host_cpu():
+    model = 'unknown'
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                model = ln.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    return model, ncores
+
+
+def _time_port(cfg_path, n_batches):
     from oracle import trainer_ref
-    torch.set_num_threads(1)
     cp = configparser.ConfigParser()
     cp.read(cfg_path)
     env, model, tr = trainer_ref.build(cp)
     tr.run_batches(1)                                   # warm-up (allocator, first-touch)
     steps, sec = tr.run_batches(n_batches)
+    return env, steps, sec
+
+
+BASELINE_CONFIG0 = os.path.join(ROOT, 'config', 'config_ia2c_catchup.ini')     # BASELINE.json configs[0]
+
+
+def cpu_baseline(cfg_path, n_batches):
+    """Reference-equivalent E=1 CPU loop (restated; TF-1.12 cannot run here), timed on THIS host's cores:
+    `value` = BASELINE.json configs[0] to the letter -- CACC catch-up, 8 agents, 1 env, IA2C (config_ia2c_catchup.ini) -- on
+    ONE core, whatever --config the GPU side ran; `all_cores` = the same as one independent replica per core (8 processes);
+    `workload_matched` = the port of the GPU workload's own algorithm (--config) on one core; plus the env-only numbers of
+    the REAL reference env (a committed profile: the reference checkout does not exist on the GPU box)."""
+    import subprocess
+    torch.set_num_threads(1)
+    cpu_model, ncores = _host_cpu()
+    env, steps, sec = _time_port(BASELINE_CONFIG0, n_batches)
     out = {'value': steps * env.n_agent / sec, 'unit': 'env-steps/s (agents x envs x steps/s)', 'cores': 1,
-           'kind': 'port',
-           'sample': '%d n_step batches (%d env steps, E=1) of the restated reference loop '
+           'kind': 'port', 'config': 'BASELINE configs[0]: ' + os.path.basename(BASELINE_CONFIG0),
+           'host_cpu': cpu_model, 'host_cores': ncores,
+           'sample': '%d n_step batches (%d env steps, E=1, IA2C catch-up) of the restated reference loop '
                      '(oracle/trainer_ref.py: NumPy env + per-agent torch-CPU LSTMs + TF-RMSProp), %.1f s'
                      % (n_batches, steps, sec),
            'updates_per_s': n_batches / sec}
     try:        # the same loop as one independent replica (process) per host core
-        import subprocess
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
         nproc = min(ncores, 8)                  # BASELINE.md 3.1: 8 processes (a fresh box imports torch slowly per process)
         nb = max(10, n_batches // 4)
         envv = dict(os.environ, OMP_NUM_THREADS='1', HIP_VISIBLE_DEVICES='', NMARL_BENCH_TUNABLEOP='0')
         t0 = time.perf_counter()
-        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-port-worker', str(nb), '--config', cfg_path],
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-port-worker', str(nb), '--config', BASELINE_CONFIG0],
                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=envv) for _ in range(nproc)]
         res = []
         for p_ in ps:
@@ -278,6 +338,17 @@ def cpu_baseline(cfg_path, n_batches):
         for p_ in locals().get('ps', []):      # never leave our own workers behind
             if p_.poll() is None:
                 p_.kill()
+    if os.path.abspath(cfg_path) != os.path.abspath(BASELINE_CONFIG0):
+        try:
+            nb = max(10, n_batches // 2)
+            env_w, steps_w, sec_w = _time_port(cfg_path, nb)
+            out['workload_matched'] = {'value': steps_w * env_w.n_agent / sec_w, 'cores': 1, 'kind': 'port',
+                                       'config': os.path.basename(cfg_path),
+                                       'sample': '%d batches (%d env steps, E=1, %s) of the same port, %.1f s'
+                                                 % (nb, steps_w, env_w.agent, sec_w)}
+            env = env_w
+        except Exception as ex:
+            out['workload_matched'] = {'error': repr(ex)}
     ref = os.path.join(ROOT, 'profiles', 'r02_cpu_env_reference.json')
     if os.path.exists(ref):
         d = json.load(open(ref))
@@ -406,10 +477,25 @@ def main():
         trainer.run_batch()
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms, allreduce_us = [elapsed / args.steps * 1e3], None
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
+        elapsed = max(float(x.item()) for x in every)                  # MAX over ranks
+        # the path's one collective, timed on its own after the timed region: the flat gradient all-reduce of an update
+        g = model.policy.params.grad
+        for _ in range(3):
+            dist.all_reduce(g, group=group)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(g, group=group)
+        torch.cuda.synchronize()
+        allreduce_us = (time.perf_counter() - t1) / 20 * 1e6
 
     n_step = model.n_step
     is_grid = env.name.startswith('atsc')
@@ -430,6 +516,12 @@ def main():
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'a2c_updates_per_s': args.steps / elapsed,
+        'per_rank_ms_per_step': rank_ms,
+        'grad_allreduce': None if allreduce_us is None else {
+            'us': allreduce_us, 'bytes': int(model.policy.params.grad.numel()) * 4, 'per_update': 1,
+            'backend': os.environ.get('NMARL_DIST_BACKEND', 'nccl'),
+            'how': '20 back-to-back all_reduce(sum) of the flat [N,P] fp32 gradient after the timed region, host clock around '
+                   'them with a device synchronize on both sides (mean; the timed region contains exactly one per step)'},
         'lock_steps_per_s': n_step * args.steps / elapsed,
         'config': {'workload': '%s, %d agents x %d replicas/GPU, %s (%s), n_step %d'
                                % (('ATSC Monaco-like network (synthetic, heterogeneous agents)' if env.name.endswith('real_net') else 'ATSC 5x5 grid (synthetic)') if is_grid else 'CACC ' + env.name, n_agent, E, env.agent,
@@ -447,6 +539,15 @@ def main():
                 us_l, flops_l, bytes_l, lname = measure_lstm_step(model)
                 x_side = model.policy.can_save_acts
                 lpb = (n_step + 1) if model.policy.fused_pv else 2 * (n_step + 1)
+                us_iso = us_l
+                us_roll = None
+                if x_side:
+                    try:          # the figure the roofline is quoted on: the launch as it runs inside the rollout
+                        us_roll, us_roll_med, n_roll = measure_lstm_step_in_rollout(trainer)
+                        us_l = us_roll
+                    except Exception as ex:
+                        us_roll = None
+                        out['roofline_in_rollout_error'] = repr(ex)
                 ach = flops_l / us_l / 1e6
                 out['roofline'] = {
                     'kernel': lname, 'bound': 'mfma' if x_side else 'hbm',
@@ -457,10 +558,16 @@ def main():
                     'traffic': (lambda t: None if (t[0] is None or not x_side or n_agent * E != 8 * 4096) else t[0] * n_agent * E)(
                         pmc_traffic('lstm_step_x_N8_E4096')),
                     'traffic_source': pmc_traffic('lstm_step_x_N8_E4096')[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
+                    'us_per_launch_isolated_graph': us_iso, 'us_per_launch_in_rollout': us_roll,
+                    'us_per_launch_in_rollout_median': None if us_roll is None else us_roll_med,
+                    'frac_isolated_graph': flops_l / us_iso / 1e6 / MFMA_F32_PEAK_TFLOPS if x_side else None,
                     'rows_per_launch': n_agent * E, 'launches_per_batch': lpb,
                     'hbm_frac_of_same_launch': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
-                    'how': 'hipGraph of 60 launches on the model shapes and weights, 10 replays between two HIP events on '
-                           'the launch stream (includes graph-node gaps).  Algorithmic work per (agent, replica) row: '
+                    'how': 'achieved / frac use the launch duration INSIDE the rollout: one eager n_step rollout with a HIP event '
+                           'pair on the launch stream around every LSTM lock-step launch (mean over the launches; agrees with the '
+                           'rocprofv3 kernel trace of the batch, profiles/).  us_per_launch_isolated_graph: hipGraph of 60 '
+                           'back-to-back launches on the model shapes and weights, 10 replays between two events (hot caches: '
+                           'flatters the kernel by 5-8 %).  Algorithmic work per (agent, replica) row: '
                            'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops (uncoupled nets; coupled nets: the '
                            'policy step + its 2*K_m*64 message flops, the value step is a second launch), fp32 in / fp32 accumulate on '
                            'v_mfma_f32_16x16x4_f32 (peak %.1f TFLOP/s dense, MI355X_MICROARCH.md); the same launch moves '

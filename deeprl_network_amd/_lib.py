@@ -83,6 +83,17 @@ class FcPart(C.Structure):
 FC_MAX_PARTS = 4
 
 
+class BpttCoupled(C.Structure):
+    """nmarl_bptt_coupled_t (include/nmarl.h): arguments of nmarl_lstm_bptt_coupled."""
+    _fields_ = ([(k, C.c_int32) for k in ('kind', 'N', 'T', 'H', 'm_max', 'r_max', 'r_row', 'symmetric', 'mode', 'ring_slots')] +
+                [('E', C.c_int64)] +
+                [(k, C.c_void_p) for k in ('gates', 'c_all', 'done', 'dh_ext', 'img', 'img_m', 'mask', 'dz', 'd1', 'ring', 'db_part',
+                                           'dbm_part', 'dhr_io', 'dc_io', 'ws', 'rev_agent', 'rev_col', 'rev_w')] +
+                [(k, C.c_int64) for k in ('gates_sn', 'gates_st', 'c_sn', 'c_st', 'dh_sn', 'dh_st', 'img_sn', 'imgm_sn', 'mask_sn',
+                                          'mask_st', 'mask_row', 'dz_sn', 'dz_st', 'd1_sn', 'd1_st', 'ring_sn', 'ring_slot', 'db_sn',
+                                          'dbm_sn', 'io_sn')])
+
+
 class GridParams(C.Structure):
     """nmarl_grid_params_t (include/nmarl.h)."""
     _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('peak1', C.c_float), ('peak2', C.c_float),
@@ -133,6 +144,9 @@ SIGNATURES = {
     'nmarl_lstm_bptt_seq_blocks': [_i64],
     'nmarl_lstm_bptt_seq': [_i32, _i64, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64,
                             _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_lstm_bptt_msg_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p],
+    'nmarl_lstm_bptt_coupled_ws_words': [_i64, _i32],
+    'nmarl_lstm_bptt_coupled': [C.POINTER(BpttCoupled), _p],
     'nmarl_fc_fwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_fc_fwd_multi': [_i64, _i32, _i32, C.POINTER(FcPart), _i32, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],

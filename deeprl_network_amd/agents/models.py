@@ -212,6 +212,8 @@ class IA2C:
         p = self.policy
         if p.hetero or p.n_obs == p.n_feat:
             return False
+        if p.params[p.k_ob].shape[2] != ops.FC_J or p.n_obs > ops.FC_MAX_F:
+            return False          # the gathering encoder kernel (nmarl_fc_fwd_multi) is 64 outputs wide, inputs <= 64
         T, E, N = self.n_step, self.E, self.n_agent
         self.buf_x = torch.zeros(T + 1, E, N, p.n_feat, dtype=F32, device=self.device)
         self.compact_obs = True

@@ -273,6 +273,16 @@ class BatchedPolicy:
                  lambda i: Layout(rows=list(range(H)) + [H + r for r in self._L_fp(i).rows])),
                 ('v_b', v_fmt + '/b', (1,), None)]
 
+    def _scratch(self, name, h):
+        """Per-(name, row count) scratch [N,E,H].  Buffers are never dropped or replaced: a captured hipGraph holds the
+        pointer of the one its rollout used, and an evaluation with a different row count (BatchedTrainer.evaluate) must
+        not free it under the graph's feet."""
+        pool = self.__dict__.setdefault('_scratch_pool', {})
+        key = (name, h.shape[1], h.device)
+        if key not in pool:
+            pool[key] = torch.empty(self.N, h.shape[1], self.n_h, dtype=F32, device=h.device)
+        return pool[key]
+
     # -- heads: policies.py:50-77
     def pi(self, h):
         p = self.params
@@ -539,6 +549,7 @@ class LstmPolicy(BatchedPolicy):
     """IA2C: fc(n_s -> n_fc, relu) -> LSTM -> heads (policies.py:136-149)."""
     name = 'lstm'
     k_wh, k_b, k_wx = 'lstm_wh', 'lstm_b', 'lstm_wx'
+    k_ob = 'fc_w'                 # the observation encoder's weight
     coupled = False               # the recurrence has no cross-agent term -> fused sequence op
 
     def _phases(self):
@@ -566,6 +577,7 @@ class LstmPolicy(BatchedPolicy):
 
 class FPPolicy(LstmPolicy):
     """IA2C_FP: fcs(obs) || fcp(neighbour fingerprints) -> LSTM(2 n_fc) (policies.py:163-185)."""
+    k_ob = 'fcs_w'
 
     def _phases(self):
         nf, H, F, A = self.n_fc, self.n_h, self.n_feat, self.n_a
@@ -604,6 +616,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
     m~ = neighbours' previous h, NOT done-masked (Q3: agents/utils.py:182-183)."""
     name = 'nc'
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
+    k_ob = 'w_ob'
     scope = 'nc/lstm_comm_%d'
     coupled = True                # messages: neighbours' h_{t-1} enter every step
     msg_kind = ops.MSG_GATHER_RELU
@@ -673,10 +686,9 @@ class NCMultiAgentPolicy(BatchedPolicy):
             # hm = relu(m~ W_msg + b) becomes the last third of the LSTM input: in place for the policy step (it is the
             # saved message term of the update), into a scratch third for the value re-step
             if second:
-                if getattr(self, '_hm2', None) is None or self._hm2.shape[1] != h.shape[1]:
-                    self._hm2 = torch.empty(self.N, h.shape[1], H, dtype=F32, device=h.device)
-                self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU, out=self._hm2)
-                return None, None, (enc[:, :, :2 * H], p['wx_hid'], self._img, self._hm2)
+                hm2 = self._scratch('_hm2', h)
+                self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU, out=hm2)
+                return None, None, (enc[:, :, :2 * H], p['wx_hid'], self._img, hm2)
             self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU, out=enc[:, :, 2 * H:])
             return None, None, (enc, p['wx_hid'], self._img)
         hm = self._fc_infer(m, 'w_msg', 'w_msg_b', ops.BIAS_RELU)
@@ -692,6 +704,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     (agents/utils.py:385-408)."""
     name = 'ic3'
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
+    k_ob = 'w_ob'
     scope = 'ic3/lstm_ic3_%d'
     coupled = True
     msg_kind = ops.MSG_MEAN_ADD
@@ -729,10 +742,7 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         engine), else a scratch tensor (one per half of the lock-step)."""
         if save is not None and not second:
             return save['S']
-        name = '_x2' if second else '_x1'
-        if getattr(self, name, None) is None or getattr(self, name).shape[1] != h.shape[1]:
-            setattr(self, name, torch.empty(self.N, h.shape[1], self.n_h, dtype=F32, device=h.device))
-        return getattr(self, name)
+        return self._scratch('_x2' if second else '_x1', h)
 
     def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params
@@ -757,6 +767,7 @@ class ConsensusPolicy(LstmPolicy):
     optimiser; after every update each agent's LSTM weights are replaced by the mean over itself and its
     neighbours (`_get_critic_wts` averages only the `lstm_%da` scope)."""
     name = 'cu'
+    k_ob = 'fc_w'
 
     def _phases(self):
         H, F = self.n_h, self.n_feat
@@ -802,6 +813,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     the message encoder mfc_j = relu(h_j W + b) acts on the sender's un-masked previous h."""
     name = 'dial'
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
+    k_ob = 'w_ob'
     coupled = True
 
     def _phases(self):

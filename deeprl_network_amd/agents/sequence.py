@@ -193,10 +193,22 @@ class CoupledSequenceSaved(torch.autograd.Function):
         dc = torch.zeros(N, E, H, dtype=F32, device=dev)
         dc_next = torch.empty_like(dc)
         fused = ops.bptt_supported(H) and wxm.stride(2) == 1 and wxm.stride(1) == H4 and wh.stride(2) == 1 and wh.stride(1) == H4
-        if fused:     # cell backward + [dx | dh] = dz @ [wxm; wh]^T (+ relu mask, + done mask) in one MFMA kernel per step
+        ckind = {'nc': ops.COUPLED_NC, 'ic3': ops.COUPLED_IC3}.get(kind)
+        rev = None
+        db = dbmsg = None
+        if fused and ckind is not None and ops.bptt_coupled_supported(ckind, nbr_idx.shape[1], H) and w_msg.stride(2) == 1 and \
+                w_msg.stride(1) == H:
+            rev = _reverse_table(nbr_idx, ckind)
+        if rev is not None:
+            # the WHOLE reverse recurrence in one launch: cell backward, [dx | dh] = dz @ [wxm; wh]^T, relu mask, the message
+            # adjoint D1 @ w_msg^T handed between the agents' blocks inside the kernel, both bias gradients on the way
+            ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
+            wm = (w_msg, ops.lstm_bptt_msg_wimage(w_msg))
+            db, dbmsg = ops.bptt_coupled(ckind, rev, nbr_idx.shape[1], G, Call, done, dHs, ws, wm, hm if kind == 'nc' else None, dZ, D1)
+        elif fused:   # cell backward + [dx | dh] = dz @ [wxm; wh]^T (+ relu mask, + done mask) in one MFMA kernel per step
             ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
             dhd_buf = torch.empty(N, E, H, dtype=F32, device=dev)
-        for t in range(T - 1, -1, -1):
+        for t in (range(T - 1, -1, -1) if rev is None else ()):
             if fused:
                 ops.bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next,
                               dhd_buf, t in masked, dx=DS[:, t] if kind == 'dial' else D1[:, t],
@@ -242,10 +254,11 @@ class CoupledSequenceSaved(torch.autograd.Function):
                 Hk[:, t].mul_(keep[t].view(1, E, 1))
             Hk = Hk.view(N, R, H)
         dwh = ops.wgrad(Hk, dZf)
-        db = dZf.sum(dim=1)
         Hp = Hprev.reshape(N, R, H)                            # un-masked h_{t-1} of all steps (message inputs)
         D1f = D1.view(N, R, H)
-        dbmsg = D1f.sum(dim=1)
+        if db is None:
+            db = dZf.sum(dim=1)
+            dbmsg = D1f.sum(dim=1)
         dwx = ops.wgrad(S.view(N, R, S.shape[-1]), dZf)        # the whole x-side weight in one GEMM
         dmfc_w = dmfc_b = None
         if kind == 'nc':
@@ -261,6 +274,17 @@ class CoupledSequenceSaved(torch.autograd.Function):
             dmfc_b = D2f.sum(dim=1)
             denc = DS
         return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b, None, None, None, None, None, None)
+
+
+_rev_tables = {}
+
+
+def _reverse_table(nbr_idx, ckind):
+    """ops.reverse_neighbor_table, built once per (neighbour table, kind): it lives as long as the policy's table."""
+    key = (nbr_idx.data_ptr(), nbr_idx.device, ckind, tuple(nbr_idx.shape))
+    if key not in _rev_tables:
+        _rev_tables[key] = (nbr_idx, ops.reverse_neighbor_table(nbr_idx, ckind))      # keeps nbr_idx alive: the key stays unique
+    return _rev_tables[key][1]
 
 
 def coupled_sequence_saved(kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S,

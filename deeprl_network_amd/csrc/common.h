@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/nmarl.h"
 
 #define NMARL_WAVE 64
@@ -9,6 +10,21 @@
 static inline int nmarl_check_launch() {
     return hipGetLastError() == hipSuccess ? NMARL_OK : NMARL_EHIP;
 }
+
+// Function attributes (the dynamic-LDS limit) are per DEVICE: a call site keeps one bit per device ordinal and sets the
+// attributes of its kernels the first time it launches on each (a process may drive several GPUs, from several threads).
+struct NmarlPerDeviceOnce {
+    std::atomic<unsigned long long> seen{0};
+    // -> ~0: this device is set up; otherwise the bit to hand to done() after setting the attributes (0: ordinal unknown,
+    //    the attributes are then simply set on every launch -- hipFuncSetAttribute is cheap)
+    unsigned long long pending() const {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0ull;
+        const unsigned long long bit = 1ull << dev;
+        return (seen.load(std::memory_order_acquire) & bit) ? ~0ull : bit;
+    }
+    void done(unsigned long long bit) { seen.fetch_or(bit, std::memory_order_release); }
+};
 
 // Philox4x32-10; contract shared with oracle/philox.py.
 struct Philox4 { uint32_t x, y, z, w; };

@@ -465,6 +465,454 @@ __global__ void lstm_bptt_wimage_kernel(const int N, const int KM, const float* 
     img[(int64_t)n * img_sn + o] = v;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The reverse recurrence of a COUPLED net -- NeurComm (lstm_comm, agents/utils.py:182-208) and CommNet (lstm_ic3,
+// agents/utils.py:395-408) -- in ONE launch.  Per reverse step t an agent's block does what lstm_bptt_seq_kernel does for
+// its 128 rows (dL/dc, the recurrent dL/dh, c_t stay in registers; loads of step t-1 in flight while step t computes) and
+// in addition the adjoint of the message term:
+//
+//     [dx | dh]^T = [Wxm; Wh] . dz_t^T                  (one transposed product, 8 output tiles)
+//     D1_t        = dx (* (hm_t > 0): relu of lstm_comm's message layer)          -> d1 (weight / bias gradients of w_msg)
+//     M_t^T       = W_msg . D1_t^T                      (second transposed product: D1 in registers IS its B operand)
+//     dL/dh_{t-1}[i] = dh[i] keep_t  +  sum over {(a, k): agent i is neighbour k of a} w_a M_t[a][:, k-th slot]
+//
+// The last sum crosses agents, i.e. blocks: M_t of (agent a, rows r) is handed to the blocks of a's neighbours for the
+// SAME rows through a message buffer in global memory ([slots][N][E][K]), wave to wave (a wave owns 16 rows for the whole launch, so the
+// hand-off needs no block barrier): payload with write-through (sc1) 16-byte stores, every storing wave drains, one
+// relaxed agent-scope flag per (agent, tile, wave) carrying the number of steps done; the consumer polls that one word,
+// then reads the payload with sc1 loads (MI355X_MICROARCH.md "inter-workgroup visibility", recipe R1).  Results do not
+// depend on dispatch order or placement; PROGRESS needs the blocks of a row tile co-resident, which the launcher
+// guarantees (grid <= CUs, one 160-KB-LDS block per CU) -- otherwise it launches step by step (t_hi == t_lo: every
+// flag a step polls was published by an earlier launch, state through dhr_io / dc_io), same kernel, same bits.  Spins are
+// bounded: a wave that waits too long raises *err and stops waiting (the host checks it).
+// The one-launch form writes every step's messages to its OWN slot (slots = T): a consumer must never re-read an address it
+// read earlier in the launch -- the per-XCD L2s are not coherent, an sc1 load bypasses the reader's L1 only, and a line the
+// reader's L2 still holds from two steps ago would be served stale (seen: rare wrong rows with a two-slot ring).  The
+// step-wise form alternates two slots (kernel boundaries make them coherent); with a symmetric neighbour relation a
+// producer's consumers are exactly the agents it waits for, so a slot is rewritten only after its readers are done.
+struct CoupledArgs {
+    const float *gates, *c_all, *done, *dh_ext, *img, *img_m, *mask;
+    float *dz, *d1, *ring, *db_part, *dbm_part, *dhr_io, *dc_io;
+    unsigned *flags, *err;
+    const int32_t *rev_agent, *rev_col;     // [N][RMAX]: source agent (own index where absent), first column of my slot
+    const float* rev_w;                     // [N][RMAX]: weight of that source (0 where absent)
+    int64_t gates_sn, gates_st, c_sn, c_st, dh_sn, dh_st, img_sn, imgm_sn, mask_sn, mask_st, dz_sn, dz_st, d1_sn, d1_st,
+        ring_sn, ring_slot, db_sn, dbm_sn, io_sn;
+    int64_t E;
+    int32_t N, T, t_hi, t_lo, mask_row, tiles, slots;
+};
+
+typedef __attribute__((address_space(1))) unsigned gu32;
+// LOADS take (lane offset, compile-time byte offset): the constant travels in the instruction's scalar-offset field instead
+// of one loop-invariant VGPR per distinct sum -- with ~40 distinct sums per step those VGPRs were spilled and every reload
+// drained the loads in flight.  The range check is on the lane offset: rows past E stay out of range.  (Loads only: see the
+// note on stores in lstm_bptt_coupled_kernel.)
+template <int AUX = 0>
+__device__ __forceinline__ float4 bload4i(const __amdgpu_buffer_rsrc_t r, const uint32_t off, const int imm) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, imm, AUX));
+}
+constexpr int SC1 = 16;                              // aux bit: write-through store / L1-bypassing load (agent scope)
+__device__ __forceinline__ void bstore4_wt(const __amdgpu_buffer_rsrc_t r, const uint32_t off, const float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, SC1);      // write-through (sc1)
+}
+
+constexpr unsigned COUPLED_MAX_SPINS = 1u << 20;
+
+template <int NTM, int RMAX, bool MASK>     // NTM: 16-column tiles of a message row (64 m_max / 16 or 4); RMAX: max sources
+__global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const CoupledArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int IMG8 = G4 * 16 * 8;                // [Wxm; Wh]^T image (NT = 8)
+    constexpr int KMO = NTM * 16;                    // floats per message row
+    const int n = blockIdx.x % a.N;
+    const int blk = blockIdx.x / a.N;
+    const int64_t row_blk = (int64_t)blk * ROWS_B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = row_blk + wave * R16;
+    const int c = lane & 15, q = lane >> 4;
+    const int64_t arow_raw = row0 + c;
+    const bool arow_ok = arow_raw < a.E;
+    const bool odd = (c & 1) != 0, hi = (c & 2) != 0;
+    {
+        const float4* g = reinterpret_cast<const float4*>(a.img + (int64_t)n * a.img_sn);
+        float4* d = reinterpret_cast<float4*>(lds);
+#pragma unroll
+        for (int i = 0; i < IMG8 / 4 / 512; ++i) d[i * 512 + threadIdx.x] = g[i * 512 + threadIdx.x];
+        const float4* gm = reinterpret_cast<const float4*>(a.img_m + (int64_t)n * a.imgm_sn);
+        float4* dm = reinterpret_cast<float4*>(lds + IMG8);
+#pragma unroll
+        for (int i = 0; i < KMO * 64 / 4 / 512; ++i) dm[i * 512 + threadIdx.x] = gm[i * 512 + threadIdx.x];
+    }
+    const int T = a.T, t_hi = a.t_hi, t_lo = a.t_lo;
+    const float* gA = a.gates + (int64_t)n * a.gates_sn;
+    const float* cA = a.c_all + (int64_t)n * a.c_sn;
+    const float* eA = a.dh_ext + (int64_t)n * a.dh_sn;
+    float* zA = a.dz + (int64_t)n * a.dz_sn;
+    float* d1A = a.d1 + (int64_t)n * a.d1_sn;
+    const float* mkA = MASK ? a.mask + (int64_t)n * a.mask_sn : nullptr;
+    const uint32_t lo4 = (uint32_t)(arow_raw * G4 + 4 * q) * 4u, lo1 = (uint32_t)(arow_raw * H + 4 * q) * 4u;
+    const uint32_t nb4 = (uint32_t)(a.E * G4) * 4u, nb1 = (uint32_t)(a.E * H) * 4u;
+    const uint32_t lom = MASK ? (uint32_t)(arow_raw * a.mask_row + 4 * q) * 4u : 0u;
+    const uint32_t nbm = MASK ? (uint32_t)((a.E - 1) * a.mask_row + H) * 4u : 0u;
+    const uint32_t lor = (uint32_t)(arow_ok ? arow_raw : a.E - 1);
+    const uint32_t loR = (uint32_t)(arow_raw * KMO + 4 * q) * 4u;      // my row of a message tensor, + 64 tau (+ 4 col)
+    const uint32_t nbR = (uint32_t)(a.E * KMO) * 4u;
+
+    // the agents whose message adjoint reaches this agent (uniform per block)
+    int src_n[RMAX];
+    uint32_t src_c4[RMAX];
+    float src_w[RMAX];
+    gu32* src_flag[RMAX];
+#pragma unroll
+    for (int s = 0; s < RMAX; ++s) {
+        src_n[s] = a.rev_agent[n * RMAX + s];
+        src_c4[s] = (uint32_t)a.rev_col[n * RMAX + s] * 4u;
+        src_w[s] = a.rev_w[n * RMAX + s];
+        src_flag[s] = (gu32*)(a.flags + ((int64_t)src_n[s] * a.tiles + blk) * WAVES + wave);
+    }
+    gu32* my_flag = (gu32*)(a.flags + ((int64_t)n * a.tiles + blk) * WAVES + wave);
+    bool give_up = false;
+
+#define NMARL_CP_LOAD2(UA, UB, t_, j)                                                      \
+    {                                                                                      \
+        const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);                            \
+        const __amdgpu_buffer_rsrc_t rg_ = make_rsrc(gA + ts_ * a.gates_st, nb4);          \
+        const __amdgpu_buffer_rsrc_t rc_ = make_rsrc(cA + ts_ * a.c_st, nb1);              \
+        const __amdgpu_buffer_rsrc_t re_ = make_rsrc(eA + ts_ * a.dh_st, nb1);             \
+        UA.gi = bload4i(rg_, lo4, (64 * (j)) * 1);                                               \
+        UB.gi = bload4i(rg_, lo4, (64 * (j) + 64) * 1);                                          \
+        UA.gf = bload4i(rg_, lo4, (64 * (j) + 4 * H) * 1);                                       \
+        UB.gf = bload4i(rg_, lo4, (64 * (j) + 4 * H + 64) * 1);                                  \
+        UA.go = bload4i(rg_, lo4, (64 * (j) + 8 * H) * 1);                                       \
+        UB.go = bload4i(rg_, lo4, (64 * (j) + 8 * H + 64) * 1);                                  \
+        UA.gu = bload4i(rg_, lo4, (64 * (j) + 12 * H) * 1);                                      \
+        UB.gu = bload4i(rg_, lo4, (64 * (j) + 12 * H + 64) * 1);                                 \
+        UA.cp = bload4i(rc_, lo1, (64 * (j)) * 1);                                               \
+        UB.cp = bload4i(rc_, lo1, (64 * (j) + 64) * 1);                                          \
+        UA.gh = bload4i(re_, lo1, (64 * (j)) * 1);                                               \
+        UB.gh = bload4i(re_, lo1, (64 * (j) + 64) * 1);                                          \
+    }
+    SeqGroup u0, u1, u2, u3;
+    NMARL_CP_LOAD2(u0, u1, t_hi, 0)
+    NMARL_CP_LOAD2(u2, u3, t_hi, 2)
+    float4 cn[4], dc[4];
+    {
+        // state the range starts from: zero at the end of the sequence, else what the previous launch left.  The recurrent
+        // dL/dh lives INSIDE the prefetched inputs: it is added to the heads' dL/dh (gh) of the step it belongs to
+        const bool first = t_hi == T - 1;
+        const __amdgpu_buffer_rsrc_t rcn = make_rsrc(cA + (int64_t)(t_hi + 1) * a.c_st, nb1);
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.dhr_io + (int64_t)n * a.io_sn, first ? 0u : nb1);
+        const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dc_io + (int64_t)n * a.io_sn, first ? 0u : nb1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cn[j] = bload4i(rcn, lo1, 64 * j);
+            dc[j] = bload4i(rd, lo1, 64 * j);                         // num_records 0: reads 0
+        }
+        const float4 h0 = bload4i(rh, lo1, 0), h1 = bload4i(rh, lo1, 64), h2 = bload4i(rh, lo1, 128), h3 = bload4i(rh, lo1, 192);
+        u0.gh.x += h0.x; u0.gh.y += h0.y; u0.gh.z += h0.z; u0.gh.w += h0.w;
+        u1.gh.x += h1.x; u1.gh.y += h1.y; u1.gh.z += h1.z; u1.gh.w += h1.w;
+        u2.gh.x += h2.x; u2.gh.y += h2.y; u2.gh.z += h2.z; u2.gh.w += h2.w;
+        u3.gh.x += h3.x; u3.gh.y += h3.y; u3.gh.z += h3.z; u3.gh.w += h3.w;
+    }
+    // bias-gradient partial sums, fully reduced over the wave's 16 rows every step: lane (c, q) keeps, per unit group j,
+    // the column of gate 2 (c & 1) + ((c >> 1) & 1), unit 16 j + 4 q + 2 ((c >> 2) & 1) + ((c >> 3) & 1)  (4 registers), and of
+    // the message layer's bias the unit 16 jm + 4 q + 2 ((c >> 1) & 1) + (c & 1), jm = 2 ((c >> 2) & 1) + ((c >> 3) & 1)  (1)
+    float dbacc[4], dbm = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dbacc[i] = 0.0f;
+    const bool b2 = (c & 4) != 0, b3 = (c & 8) != 0;
+    float keepA = 1.0f - (a.done + (int64_t)t_hi * a.E)[lor];
+    __syncthreads();                                 // images visible
+
+#define NMARL_CP_KSTEP(bv, s)                                                              \
+    {                                                                                      \
+        const float* p_ = abase + (s) * 64 * 8;                                            \
+        const float4 w0_ = *reinterpret_cast<const float4*>(p_ + 4 * sw);                  \
+        const float4 w1_ = *reinterpret_cast<const float4*>(p_ + 4 * (sw ^ 1));            \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.x, bv, acc[0], 0, 0, 0);         \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.y, bv, acc[1], 0, 0, 0);         \
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.z, bv, acc[2], 0, 0, 0);         \
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.w, bv, acc[3], 0, 0, 0);         \
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.x, bv, acc[4], 0, 0, 0);         \
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.y, bv, acc[5], 0, 0, 0);         \
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.z, bv, acc[6], 0, 0, 0);         \
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.w, bv, acc[7], 0, 0, 0);         \
+    }
+#define NMARL_CP_CELLB(U, j, k, i_)                                                        \
+    {                                                                                      \
+        const float tc = tanh_fast_(cn[j].k);                                              \
+        const float gh_ = U.gh.k;                                                          \
+        const float g_c = dc[j].k + gh_ * U.go.k * (1.0f - tc * tc);                       \
+        di.k = g_c * U.gu.k * U.gi.k * (1.0f - U.gi.k);                                    \
+        df.k = g_c * (U.cp.k * keepA) * U.gf.k * (1.0f - U.gf.k);                          \
+        dO.k = gh_ * tc * U.go.k * (1.0f - U.go.k);                                        \
+        du.k = g_c * U.gi.k * (1.0f - U.gu.k * U.gu.k);                                    \
+        dc[j].k = g_c * U.gf.k * keepA;                                                    \
+        cn[j].k = U.cp.k;                                                                  \
+    }
+#define NMARL_CP_DB1(j, k, i_)                                                             \
+    {                                                                                      \
+        const float ka = odd ? dO.k : di.k, ga = odd ? di.k : dO.k;                        \
+        const float kb = odd ? du.k : df.k, gb = odd ? df.k : du.k;                        \
+        const float ra = ka + dpp_xor1(ga), rb = kb + dpp_xor1(gb);                        \
+        const float k2 = hi ? rb : ra, g2 = hi ? ra : rb;                                  \
+        qs[i_] = k2 + dpp_xor2(g2);                                                        \
+    }
+#define NMARL_CP_CELL(U, j)                                                                \
+    NMARL_CP_CELLB(U, j, x, 0) NMARL_CP_CELLB(U, j, y, 1) NMARL_CP_CELLB(U, j, z, 2) NMARL_CP_CELLB(U, j, w, 3)         \
+    {                                                                                      \
+        float qs[4];                                                                       \
+        NMARL_CP_DB1(j, x, 0) NMARL_CP_DB1(j, y, 1) NMARL_CP_DB1(j, z, 2) NMARL_CP_DB1(j, w, 3)                          \
+        const float k0_ = b2 ? qs[2] : qs[0], g0_ = b2 ? qs[0] : qs[2];                    \
+        const float k1_ = b2 ? qs[3] : qs[1], g1_ = b2 ? qs[1] : qs[3];                    \
+        const float r0_ = k0_ + __shfl_xor(g0_, 4, 64), r1_ = k1_ + __shfl_xor(g1_, 4, 64); \
+        const float k3_ = b3 ? r1_ : r0_, g3_ = b3 ? r0_ : r1_;                            \
+        dbacc[j] += k3_ + __shfl_xor(g3_, 8, 64);                                          \
+    }
+#define NMARL_CP_PROD(j)                                                                   \
+    {                                                                                      \
+        bstore4(rz, so4 + (64 * (j)), di);                                                   \
+        bstore4(rz, so4 + (64 * (j) + 4 * H), df);                                           \
+        bstore4(rz, so4 + (64 * (j) + 8 * H), dO);                                           \
+        bstore4(rz, so4 + (64 * (j) + 12 * H), du);                                          \
+        NMARL_CP_KSTEP(di.x, (j) * 16 + 0) NMARL_CP_KSTEP(di.y, (j) * 16 + 1)              \
+        NMARL_CP_KSTEP(di.z, (j) * 16 + 2) NMARL_CP_KSTEP(di.w, (j) * 16 + 3)              \
+        NMARL_CP_KSTEP(df.x, (j) * 16 + 4) NMARL_CP_KSTEP(df.y, (j) * 16 + 5)              \
+        NMARL_CP_KSTEP(df.z, (j) * 16 + 6) NMARL_CP_KSTEP(df.w, (j) * 16 + 7)              \
+        NMARL_CP_KSTEP(dO.x, (j) * 16 + 8) NMARL_CP_KSTEP(dO.y, (j) * 16 + 9)              \
+        NMARL_CP_KSTEP(dO.z, (j) * 16 + 10) NMARL_CP_KSTEP(dO.w, (j) * 16 + 11)            \
+        NMARL_CP_KSTEP(du.x, (j) * 16 + 12) NMARL_CP_KSTEP(du.y, (j) * 16 + 13)            \
+        NMARL_CP_KSTEP(du.z, (j) * 16 + 14) NMARL_CP_KSTEP(du.w, (j) * 16 + 15)            \
+    }
+    // message product: k-step s = 4 t_ + r_ takes D1 unit 16 t_ + 4 q + r_ of the lane's row
+#define NMARL_CP_MSTEP(bv, s)                                                              \
+    {                                                                                      \
+        const float* p_ = mbase + (s) * 64 * NTM;                                          \
+        if (NTM == 4) {                                                                    \
+            const float4 w0_ = *reinterpret_cast<const float4*>(p_);                       \
+            am[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.x, bv, am[0], 0, 0, 0);       \
+            am[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.y, bv, am[1], 0, 0, 0);       \
+            am[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.z, bv, am[2], 0, 0, 0);       \
+            am[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.w, bv, am[3], 0, 0, 0);       \
+        } else {                                                                           \
+            const float4 w0_ = *reinterpret_cast<const float4*>(p_ + 4 * sw);              \
+            const float4 w1_ = *reinterpret_cast<const float4*>(p_ + 4 * (sw ^ 1));        \
+            am[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.x, bv, am[0], 0, 0, 0);       \
+            am[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.y, bv, am[1], 0, 0, 0);       \
+            am[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.z, bv, am[2], 0, 0, 0);       \
+            am[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.w, bv, am[3], 0, 0, 0);       \
+            am[NTM - 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.x, bv, am[NTM - 4], 0, 0, 0); \
+            am[NTM - 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.y, bv, am[NTM - 3], 0, 0, 0); \
+            am[NTM - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.z, bv, am[NTM - 2], 0, 0, 0); \
+            am[NTM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.w, bv, am[NTM - 1], 0, 0, 0); \
+        }                                                                                  \
+    }
+    const int sw = c >> 3;
+    for (int t = t_hi; t >= t_lo; --t) {
+        const int tp = t > t_lo ? t - 1 : t_lo;      // clamped: the last prefetch re-reads the range's last step
+        const float keep_next = 1.0f - (a.done + (int64_t)__builtin_amdgcn_readfirstlane(tp) * a.E)[lor];
+        const int64_t tu = __builtin_amdgcn_readfirstlane(t);
+        const __amdgpu_buffer_rsrc_t rz = make_rsrc(zA + tu * a.dz_st, nb4);
+        const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(d1A + tu * a.d1_st, nb1);
+        // ---- relu mask of the message layer at step t (independent of the neighbours: in flight while the flags are polled)
+        float4 mk0, mk1, mk2, mk3;
+        if (MASK) {
+            const __amdgpu_buffer_rsrc_t rm = make_rsrc(mkA + tu * a.mask_st, nbm);
+            mk0 = bload4i(rm, lom, 0);
+            mk1 = bload4i(rm, lom, 64);
+            mk2 = bload4i(rm, lom, 128);
+            mk3 = bload4i(rm, lom, 192);
+        }
+        // ---- the neighbours' message adjoints of step t + 1 (none at the end of the sequence: weight 0, the ring is finite)
+        {
+            const unsigned need = (unsigned)(T - 1 - t);
+            const float* rbase = a.ring + (int64_t)((t + 1) % a.slots) * a.ring_slot;
+            const float wsel0 = t == T - 1 ? 0.0f : 1.0f;
+#pragma unroll
+            for (int s = 0; s < RMAX; ++s) {
+                if (!give_up) {
+                    for (unsigned spins = 0;; ++spins) {
+                        const unsigned v = __builtin_amdgcn_readfirstlane(
+                            __hip_atomic_load(src_flag[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (v >= need) break;
+                        if (spins > COUPLED_MAX_SPINS) {
+                            if (lane == 0) __hip_atomic_store((gu32*)a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            give_up = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                asm volatile("" ::: "memory");       // payload loads stay below the poll
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc(rbase + (int64_t)src_n[s] * a.ring_sn, nbR);
+                const float w_ = src_w[s] * wsel0;
+                const uint32_t ro_ = loR + src_c4[s];
+                const float4 m0 = bload4i<SC1>(rr, ro_, 0);
+                const float4 m1 = bload4i<SC1>(rr, ro_, 64);
+                const float4 m2 = bload4i<SC1>(rr, ro_, 128);
+                const float4 m3 = bload4i<SC1>(rr, ro_, 192);
+                u0.gh.x += w_ * m0.x; u0.gh.y += w_ * m0.y; u0.gh.z += w_ * m0.z; u0.gh.w += w_ * m0.w;
+                u1.gh.x += w_ * m1.x; u1.gh.y += w_ * m1.y; u1.gh.z += w_ * m1.z; u1.gh.w += w_ * m1.w;
+                u2.gh.x += w_ * m2.x; u2.gh.y += w_ * m2.y; u2.gh.z += w_ * m2.z; u2.gh.w += w_ * m2.w;
+                u3.gh.x += w_ * m3.x; u3.gh.y += w_ * m3.y; u3.gh.z += w_ * m3.z; u3.gh.w += w_ * m3.w;
+                __builtin_amdgcn_sched_barrier(0);   // one source's 4 loads in flight at a time (registers)
+            }
+        }
+        unsigned mbits = 0xFFFFu;                     // bit 4 j + i: hm > 0 for unit 16 j + 4 q + i of the lane's row
+        if (MASK) {
+            mbits = (mk0.x > 0.0f ? 1u : 0u) | (mk0.y > 0.0f ? 2u : 0u) | (mk0.z > 0.0f ? 4u : 0u) | (mk0.w > 0.0f ? 8u : 0u) |
+                    (mk1.x > 0.0f ? 16u : 0u) | (mk1.y > 0.0f ? 32u : 0u) | (mk1.z > 0.0f ? 64u : 0u) | (mk1.w > 0.0f ? 128u : 0u) |
+                    (mk2.x > 0.0f ? 256u : 0u) | (mk2.y > 0.0f ? 512u : 0u) | (mk2.z > 0.0f ? 1024u : 0u) | (mk2.w > 0.0f ? 2048u : 0u) |
+                    (mk3.x > 0.0f ? 4096u : 0u) | (mk3.y > 0.0f ? 8192u : 0u) | (mk3.z > 0.0f ? 16384u : 0u) | (mk3.w > 0.0f ? 32768u : 0u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int aoff = (q * 16 + c) * 8;                 // opaque copies: see lstm_bptt_seq_kernel
+        asm volatile("" : "+v"(aoff));
+        // STORES take (lane offset + constant) in a VGPR, never a scalar offset: after a 16-byte buffer store with an SGPR
+        // soffset hipcc (ROCm 7.2) lets the next VALU instruction overwrite the store's data registers without the wait
+        // state it inserts for the soffset-less form -- on gfx950 the store then picks up the NEXT value of its first data
+        // register (seen: the x component of a gate's dz replaced by the next gate's, intermittently).  Opaque copies keep
+        // the 28 sums from being hoisted out of the loop into registers.
+        uint32_t so4 = lo4, so1 = lo1, soR = loR;
+        asm volatile("" : "+v"(so4), "+v"(so1), "+v"(soR));
+        const float* abase = lds + aoff;
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 di, df, dO, du;
+        NMARL_CP_CELL(u0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_PROD(0)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_CELL(u1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_LOAD2(u0, u1, tp, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_PROD(1)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_CELL(u2, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_PROD(2)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_CELL(u3, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_LOAD2(u2, u3, tp, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_PROD(3)
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- D1 = dx (relu-masked) in the lane's own units; bias gradient of the message layer
+        f32x4 d1v[4];
+        {
+            float qm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d1v[j] = acc[j];
+                if (MASK) {
+                    if (!((mbits >> (4 * j)) & 1u)) d1v[j][0] = 0.0f;
+                    if (!((mbits >> (4 * j + 1)) & 1u)) d1v[j][1] = 0.0f;
+                    if (!((mbits >> (4 * j + 2)) & 1u)) d1v[j][2] = 0.0f;
+                    if (!((mbits >> (4 * j + 3)) & 1u)) d1v[j][3] = 0.0f;
+                }
+                bstore4(rd1, so1 + 64 * j, float4{d1v[j][0], d1v[j][1], d1v[j][2], d1v[j][3]});
+                const float a0 = odd ? d1v[j][1] : d1v[j][0], g0 = odd ? d1v[j][0] : d1v[j][1];
+                const float a1 = odd ? d1v[j][3] : d1v[j][2], g1 = odd ? d1v[j][2] : d1v[j][3];
+                const float r0 = a0 + dpp_xor1(g0), r1 = a1 + dpp_xor1(g1);
+                const float k2 = hi ? r1 : r0, g2 = hi ? r0 : r1;
+                qm[j] = k2 + dpp_xor2(g2);            // unit 2 hi + odd of group j, summed over the quad's rows
+            }
+            const float k0_ = b2 ? qm[2] : qm[0], g0_ = b2 ? qm[0] : qm[2];
+            const float k1_ = b2 ? qm[3] : qm[1], g1_ = b2 ? qm[1] : qm[3];
+            const float r0_ = k0_ + __shfl_xor(g0_, 4, 64), r1_ = k1_ + __shfl_xor(g1_, 4, 64);
+            const float k3_ = b3 ? r1_ : r0_, g3_ = b3 ? r0_ : r1_;
+            dbm += k3_ + __shfl_xor(g3_, 8, 64);
+        }
+        // ---- M_t^T = W_msg . D1^T, handed to the neighbours' blocks
+        {
+            int moff = (q * 16 + c) * NTM;
+            asm volatile("" : "+v"(moff));
+            const float* mbase = lds + IMG8 + moff;
+            f32x4 am[NTM];
+#pragma unroll
+            for (int i = 0; i < NTM; ++i) am[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t_ = 0; t_ < 4; ++t_) {
+                NMARL_CP_MSTEP(d1v[t_][0], t_ * 4 + 0) NMARL_CP_MSTEP(d1v[t_][1], t_ * 4 + 1)
+                NMARL_CP_MSTEP(d1v[t_][2], t_ * 4 + 2) NMARL_CP_MSTEP(d1v[t_][3], t_ * 4 + 3)
+            }
+            const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.ring + (int64_t)(t % a.slots) * a.ring_slot + (int64_t)n * a.ring_sn, nbR);
+#pragma unroll
+            for (int i = 0; i < NTM; ++i) bstore4_wt(rw, soR + 64 * i, float4{am[i][0], am[i][1], am[i][2], am[i][3]});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
+        if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // own recurrent part of dL/dh_{t-1} = (dz @ wh^T) keep_t: into the prefetched inputs of step t - 1 (landed: drained)
+        if (t == t_lo && arow_ok) {                  // end of the range: state for the next launch of a step-wise run
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v_ = acc[4 + j] * keepA;
+                *reinterpret_cast<float4*>(a.dhr_io + (int64_t)n * a.io_sn + arow_raw * H + 4 * q + 16 * j) =
+                    float4{v_[0], v_[1], v_[2], v_[3]};
+                *reinterpret_cast<float4*>(a.dc_io + (int64_t)n * a.io_sn + arow_raw * H + 4 * q + 16 * j) = dc[j];
+            }
+        }
+        u0.gh.x += acc[4][0] * keepA; u0.gh.y += acc[4][1] * keepA; u0.gh.z += acc[4][2] * keepA; u0.gh.w += acc[4][3] * keepA;
+        u1.gh.x += acc[5][0] * keepA; u1.gh.y += acc[5][1] * keepA; u1.gh.z += acc[5][2] * keepA; u1.gh.w += acc[5][3] * keepA;
+        u2.gh.x += acc[6][0] * keepA; u2.gh.y += acc[6][1] * keepA; u2.gh.z += acc[6][2] * keepA; u2.gh.w += acc[6][3] * keepA;
+        u3.gh.x += acc[7][0] * keepA; u3.gh.y += acc[7][1] * keepA; u3.gh.z += acc[7][2] * keepA; u3.gh.w += acc[7][3] * keepA;
+        keepA = keep_next;
+    }
+#undef NMARL_CP_LOAD2
+#undef NMARL_CP_KSTEP
+#undef NMARL_CP_CELLB
+#undef NMARL_CP_DB1
+#undef NMARL_CP_CELL
+#undef NMARL_CP_PROD
+#undef NMARL_CP_MSTEP
+
+    // ---- bias gradients: every lane holds 4 + 1 finished column sums of its wave; sum over the 8 waves, a step-wise run
+    // accumulates over its launches
+    __syncthreads();                                 // every wave is done with the images: reuse their LDS
+    {
+        const int g = 2 * (c & 1) + ((c >> 1) & 1), iu = 2 * ((c >> 2) & 1) + ((c >> 3) & 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[wave * G4 + 64 * g + 16 * j + 4 * q + iu] = dbacc[j];
+        lds[WAVES * G4 + wave * H + 16 * iu + 4 * q + 2 * ((c >> 1) & 1) + (c & 1)] = dbm;
+    }
+    __syncthreads();
+    const bool accum = t_hi != T - 1;
+    if (threadIdx.x < G4) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += lds[w * G4 + threadIdx.x];
+        float* o = a.db_part + (int64_t)n * a.db_sn + (int64_t)blk * G4 + threadIdx.x;
+        *o = accum ? *o + v : v;
+    } else if (threadIdx.x < G4 + H) {
+        const int u = threadIdx.x - G4;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) v += lds[WAVES * G4 + w * H + u];
+        float* o = a.dbm_part + (int64_t)n * a.dbm_sn + (int64_t)blk * H + u;
+        *o = accum ? *o + v : v;
+    }
+}
+
+// image_m[(s, q)][c][slot(tau)] = W_msg[16 tau + c][16 t_ + 4 q + r_],  s = 4 t_ + r_;  NTM = K / 16 tiles (8: swizzled like the
+// main image)
+__global__ void lstm_bptt_msg_wimage_kernel(const int N, const int K, const float* w, const int64_t w_sn, float* img,
+                                            const int64_t img_sn) {
+    const int NTM = K / 16;
+    const int per_agent = K * H;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * per_agent) return;
+    const int n = (int)(idx / per_agent), o = (int)(idx % per_agent);
+    const int slot = o % NTM, cc = (o / NTM) % 16, sq = o / (NTM * 16);
+    const int qq = sq & 3, s = sq >> 2;
+    const int t_ = s >> 2, r_ = s & 3;
+    int tau = slot;
+    if (NTM == 8) tau = (((slot >> 2) ^ (cc >> 3)) << 2) | (slot & 3);
+    img[(int64_t)n * img_sn + o] = w[(int64_t)n * w_sn + (int64_t)(16 * tau + cc) * H + 16 * t_ + 4 * qq + r_];
+}
+
 inline bool sn_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
 
 }  // namespace
@@ -506,14 +954,14 @@ extern "C" int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t Hh, int32_t KM
     a.gates_sn = gates_sn; a.c_prev_sn = c_prev_sn; a.c_new_sn = c_new_sn; a.dh_sn = dh_sn; a.dh2_sn = dh2_sn; a.dc_sn = dc_sn;
     a.img_sn = img_sn; a.mask_sn = mask_sn; a.mask_row = mask_row; a.dz_sn = dz_sn; a.dc_prev_sn = dc_prev_sn; a.dx_sn = dx_sn;
     a.dhd_sn = dhd_sn; a.E = E; a.N = N; a.apply_keep = apply_keep;
-    static bool lds_set = false;
-    if (!lds_set) {
+    static NmarlPerDeviceOnce lds_once;
+    if (const unsigned long long lds_bit = lds_once.pending(); lds_bit != ~0ull) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_step_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G4 * 16 * 4 * 4) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_step_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 G4 * 16 * 8 * 4) != hipSuccess)
             return NMARL_EHIP;
-        lds_set = true;
+        lds_once.done(lds_bit);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)(((E + ROWS_B - 1) / ROWS_B) * N));
@@ -546,14 +994,114 @@ extern "C" int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t Hh, 
     a.dh0 = dh0; a.dc0 = dc0; a.gates_sn = gates_sn; a.gates_st = gates_st; a.c_sn = c_sn; a.c_st = c_st; a.dh_sn = dh_sn;
     a.dh_st = dh_st; a.img_sn = img_sn; a.dz_sn = dz_sn; a.dz_st = dz_st; a.db_sn = db_sn; a.dh0_sn = dh0_sn; a.dc0_sn = dc0_sn;
     a.E = E; a.N = N; a.T = T;
-    static bool lds_set = false;
-    if (!lds_set) {
+    static NmarlPerDeviceOnce lds_once;
+    if (const unsigned long long lds_bit = lds_once.pending(); lds_bit != ~0ull) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 SEQ_IMG * 4) != hipSuccess)
             return NMARL_EHIP;
-        lds_set = true;
+        lds_once.done(lds_bit);
     }
     hipLaunchKernelGGL(lstm_bptt_seq_kernel, dim3((unsigned)(nblk * N)), dim3(512), (size_t)SEQ_IMG * 4,
                        static_cast<hipStream_t>(stream), a);
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_bptt_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn,
+                                          void* stream) {
+    if (N <= 0 || (K != 64 && K != 128) || !w_msg || !img || w_sn < (int64_t)K * H || img_sn < (int64_t)K * H || (img_sn % 4) ||
+        ((uintptr_t)img % 16))
+        return NMARL_EINVAL;
+    const int64_t total = (int64_t)N * K * H;
+    hipLaunchKernelGGL(lstm_bptt_msg_wimage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), N, K, w_msg, w_sn, img, img_sn);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_bptt_coupled_ws_words(int64_t E, int32_t N) {
+    // flags: one word per (agent, 128-row tile, wave) + the error word, rounded up to 64 words
+    const int64_t tiles = (E + ROWS_B - 1) / ROWS_B;
+    return (int)(((int64_t)N * tiles * WAVES + 1 + 63) / 64 * 64);
+}
+
+namespace {
+template <int NTM, int RMAX, bool MASK>
+int launch_coupled(const CoupledArgs& a, unsigned grid, size_t lds_bytes, hipStream_t st) {
+    static NmarlPerDeviceOnce once;
+    if (const unsigned long long bit = once.pending(); bit != ~0ull) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<NTM, RMAX, MASK>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return NMARL_EHIP;
+        once.done(bit);
+    }
+    hipLaunchKernelGGL((lstm_bptt_coupled_kernel<NTM, RMAX, MASK>), dim3(grid), dim3(512), lds_bytes, st, a);
+    return nmarl_check_launch();
+}
+}  // namespace
+
+extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stream) {
+    if (!p || p->H != H || p->E < 0 || p->N <= 0 || p->T <= 0 || (p->kind != 1 && p->kind != 2) || p->r_max <= 0 || p->r_max > 4)
+        return NMARL_EINVAL;
+    const int64_t E = p->E;
+    const int N = p->N, T = p->T;
+    const int K = p->kind == 1 ? H * p->m_max : H;                        // floats per message row
+    if (K != 64 && K != 128) return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    if (E > (1 << 21)) return NMARL_EINVAL;
+    if (!p->gates || !p->c_all || !p->done || !p->dh_ext || !p->img || !p->img_m || !p->dz || !p->d1 || !p->ring || !p->db_part ||
+        !p->dbm_part || !p->dhr_io || !p->dc_io || !p->ws || !p->rev_agent || !p->rev_col || !p->rev_w || (p->kind == 1 && !p->mask))
+        return NMARL_EINVAL;
+    const int64_t tiles = (E + ROWS_B - 1) / ROWS_B;
+    if (p->gates_st < E * G4 || (p->gates_st % 4) || !sn_ok(p->gates_sn, (T - 1) * p->gates_st + E * G4) || p->dz_st < E * G4 ||
+        (p->dz_st % 4) || !sn_ok(p->dz_sn, (T - 1) * p->dz_st + E * G4) || p->c_st < E * H || (p->c_st % 4) ||
+        !sn_ok(p->c_sn, T * p->c_st + E * H) || p->dh_st < E * H || (p->dh_st % 4) || !sn_ok(p->dh_sn, (T - 1) * p->dh_st + E * H) ||
+        p->d1_st < E * H || (p->d1_st % 4) || !sn_ok(p->d1_sn, (T - 1) * p->d1_st + E * H) || p->img_sn < (int64_t)G4 * 2 * H ||
+        (p->img_sn % 4) || p->imgm_sn < (int64_t)K * H || (p->imgm_sn % 4) || !sn_ok(p->ring_sn, E * K) ||
+        !sn_ok(p->ring_slot, (N - 1) * p->ring_sn + E * K) || p->db_sn < tiles * G4 || p->dbm_sn < tiles * H || !sn_ok(p->io_sn, E * H) ||
+        (p->kind == 1 && (p->mask_row < H || (p->mask_row % 4) || p->mask_st < (E - 1) * p->mask_row + H || (p->mask_st % 4) ||
+                          !sn_ok(p->mask_sn, (T - 1) * p->mask_st + (E - 1) * p->mask_row + H) || ((uintptr_t)p->mask % 16))) ||
+        ((uintptr_t)p->img % 16) || ((uintptr_t)p->img_m % 16) || ((uintptr_t)p->gates % 16) || ((uintptr_t)p->dz % 16) ||
+        ((uintptr_t)p->c_all % 16) || ((uintptr_t)p->dh_ext % 16) || ((uintptr_t)p->d1 % 16) || ((uintptr_t)p->ring % 16) ||
+        ((uintptr_t)p->dhr_io % 16) || ((uintptr_t)p->dc_io % 16) || ((uintptr_t)p->ws % 4))
+        return NMARL_EINVAL;
+    CoupledArgs a{};
+    a.gates = p->gates; a.c_all = p->c_all; a.done = p->done; a.dh_ext = p->dh_ext; a.img = p->img; a.img_m = p->img_m;
+    a.mask = p->kind == 1 ? p->mask : nullptr;
+    a.dz = p->dz; a.d1 = p->d1; a.ring = p->ring; a.db_part = p->db_part; a.dbm_part = p->dbm_part; a.dhr_io = p->dhr_io;
+    a.dc_io = p->dc_io;
+    a.flags = reinterpret_cast<unsigned*>(p->ws);
+    a.err = a.flags + (int64_t)N * tiles * WAVES;
+    a.rev_agent = p->rev_agent; a.rev_col = p->rev_col; a.rev_w = p->rev_w;
+    a.gates_sn = p->gates_sn; a.gates_st = p->gates_st; a.c_sn = p->c_sn; a.c_st = p->c_st; a.dh_sn = p->dh_sn; a.dh_st = p->dh_st;
+    a.img_sn = p->img_sn; a.imgm_sn = p->imgm_sn; a.mask_sn = p->mask_sn; a.mask_st = p->mask_st; a.dz_sn = p->dz_sn;
+    a.dz_st = p->dz_st; a.d1_sn = p->d1_sn; a.d1_st = p->d1_st; a.ring_sn = p->ring_sn; a.ring_slot = p->ring_slot;
+    a.db_sn = p->db_sn; a.dbm_sn = p->dbm_sn; a.io_sn = p->io_sn;
+    a.E = E; a.N = N; a.T = T; a.mask_row = (int32_t)p->mask_row; a.tiles = (int32_t)tiles;
+    if (p->ring_slots < 2) return NMARL_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // every polled word starts at zero for every call (flags count the steps done WITHIN the call)
+    if (hipMemsetAsync(p->ws, 0, (size_t)nmarl_lstm_bptt_coupled_ws_words(E, N) * 4, st) != hipSuccess) return NMARL_EHIP;
+    const int64_t grid = tiles * N;
+    // one launch for all T steps needs every block resident (the waves wait for their neighbours' blocks): one 512-thread
+    // block with 160 KB of LDS per CU, so grid <= CUs; and a symmetric neighbour relation (two ring slots).  Otherwise
+    // step by step: T launches of the same kernel, state through dhr_io / dc_io.
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return NMARL_EHIP;
+    const bool one_launch = p->mode != 2 && p->ring_slots >= T && (p->mode == 1 || (p->symmetric && grid <= cus));
+    a.slots = one_launch ? T : 2;
+    const size_t lds_bytes = ((size_t)G4 * 16 * 8 + (size_t)K * H) * 4;
+    const int ntm = K / 16;
+    const int rmax = p->r_max <= 2 ? 2 : 4;
+    if (p->r_row != rmax) return NMARL_EINVAL;            // tables come padded to 2 or 4 entries per agent
+    int rc = NMARL_OK;
+    for (int t_hi = T - 1; t_hi >= 0 && rc == NMARL_OK; t_hi = one_launch ? -1 : t_hi - 1) {
+        a.t_hi = t_hi;
+        a.t_lo = one_launch ? 0 : t_hi;
+        if (p->kind == 1 && ntm == 8 && rmax == 2) rc = launch_coupled<8, 2, true>(a, (unsigned)grid, lds_bytes, st);
+        else if (p->kind == 1 && ntm == 4 && rmax == 2) rc = launch_coupled<4, 2, true>(a, (unsigned)grid, lds_bytes, st);
+        else if (p->kind == 2 && rmax == 2) rc = launch_coupled<4, 2, false>(a, (unsigned)grid, lds_bytes, st);
+        else if (p->kind == 2 && rmax == 4) rc = launch_coupled<4, 4, false>(a, (unsigned)grid, lds_bytes, st);
+        else rc = NMARL_EINVAL;
+    }
+    return rc;
 }

@@ -944,9 +944,9 @@ static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     if (kind != 0) a.hd = *head;
-    static bool lds_set = false;
+    static NmarlPerDeviceOnce lds_once;
     const int l2 = (int)(LDS2_FLOATS * sizeof(float));
-    if (!lds_set) {
+    if (const unsigned long long lds_bit = lds_once.pending(); lds_bit != ~0ull) {
 #define NMARL_SET_LDS(k, bytes) \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return NMARL_EHIP;
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 0>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 0>), l2)
@@ -954,7 +954,7 @@ static int launch_fused(int64_t E, int32_t N, int32_t Hh, const float* h_in, int
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 2>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 2>), l2)
         NMARL_SET_LDS((lstm_step_mfma16_kernel<false, 3>), l2) NMARL_SET_LDS((lstm_step_mfma16_kernel<true, 3>), l2)
 #undef NMARL_SET_LDS
-        lds_set = true;
+        lds_once.done(lds_bit);
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.blocks_per_agent * N);
@@ -1070,20 +1070,31 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.msg_img_sn = msg->img_sn; xa.msg_b = msg->b; xa.msg_b_sn = msg->b_sn; xa.enc = msg->enc; xa.enc_sn = msg->enc_sn;
         xa.enc_row = msg->enc_row; xa.xm_out = msg->out; xa.xm_sn = msg->out_sn; xa.xm_row = msg->out_row;
     }
-    static bool lds_set = false;
+    static NmarlPerDeviceOnce lds_once;
     // no message pre-phase: three chunk buffers (de-phased wave groups); with it: two + the W_msg image
     const int lb_max = (int)((LDSX_FLOATS + CH_FLOATS) * sizeof(float));
     const size_t lb = (size_t)(LDSX_FLOATS + (mk ? msg->K * 64 : CH_FLOATS)) * sizeof(float);
-    if (!lds_set) {
+    if (const unsigned long long lds_bit = lds_once.pending(); lds_bit != ~0ull) {
 #define NMARL_SET_LDS(k) \
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lb_max) != hipSuccess) return NMARL_EHIP;
         NMARL_SET_LDS((lstm_step_x_kernel<0, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 0>))
         NMARL_SET_LDS((lstm_step_x_kernel<3, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 1>))
         NMARL_SET_LDS((lstm_step_x_kernel<1, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 2>))
 #undef NMARL_SET_LDS
-        lds_set = true;
+        lds_once.done(lds_bit);
     }
     if (mk && kind != 1 && kind != 2) return NMARL_EINVAL;      // the message pre-phase exists for the policy / value steps
+    if (mk) {
+        // the pre-phase gathers OTHER agents' previous h while their blocks write h_new: no panel of h_new may overlap a
+        // panel of h_in (in-place stepping is for nets without the in-kernel message term)
+        const int64_t span = E * (int64_t)H;
+        for (int i = 0; i < N; ++i)
+            for (int j = 0; j < N; ++j) {
+                const float* a0 = h_in + i * h_sn;
+                const float* b0 = h_new + j * h_new_sn;
+                if (a0 < b0 + span && b0 < a0 + span) return NMARL_EINVAL;
+            }
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid(a.blocks_per_agent * N);
 #define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb, st, xa)

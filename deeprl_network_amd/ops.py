@@ -718,6 +718,132 @@ def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False):
     return (part.sum(dim=1) if want_db else None), dh0, dc0
 
 
+COUPLED_NC, COUPLED_IC3 = 1, 2           # nmarl_bptt_coupled_t.kind: lstm_comm / lstm_ic3
+
+
+def lstm_bptt_msg_wimage(w_msg, out=None):
+    """LDS image of w_msg [N,K,64] (K = 64 or 128) for the message adjoint inside nmarl_lstm_bptt_coupled."""
+    N, K, J = w_msg.shape
+    if out is None:
+        out = torch.empty(N, K * J, dtype=F32, device=w_msg.device)
+    if J != FUSED_H or w_msg.stride(2) != 1 or w_msg.stride(1) != J:
+        raise _lib.NmarlError('lstm_bptt_msg_wimage: w_msg must be [N,K,64] with contiguous panels')
+    check(lib.nmarl_lstm_bptt_msg_wimage(N, K, ptr(w_msg, F32, strided=True), w_msg.stride(0), ptr(out, F32), out.stride(0), stream()),
+          'nmarl_lstm_bptt_msg_wimage')
+    return out
+
+
+def reverse_neighbor_table(nbr_idx, kind):
+    """For every agent i the sources of the message adjoint: (agent a, first column of i's slot in a's message row, weight)
+    for every (a, k) with nbr_idx[a, k] == i -- lstm_comm: slot k (64 k), weight 1; lstm_ic3: column 0, weight 1 / |nbr(a)|.
+    -> dict(rev_agent, rev_col [N,r_row] int32, rev_w [N,r_row] f32 device tensors, r_max, r_row, symmetric) or None when an
+    agent has more than 4 sources."""
+    tab = nbr_idx.cpu().numpy()
+    N, m = tab.shape
+    lists = [[] for _ in range(N)]
+    for a_ in range(N):
+        cnt = int((tab[a_] >= 0).sum())
+        for k in range(m):
+            i = int(tab[a_, k])
+            if i >= 0:
+                lists[i].append((a_, 64 * k, 1.0) if kind == COUPLED_NC else (a_, 0, 1.0 / cnt))
+    r_max = max(1, max(len(x) for x in lists))
+    if r_max > 4:
+        return None
+    r_row = 2 if r_max <= 2 else 4
+    ra, rc, rw = (np.zeros((N, r_row), dtype=t) for t in (np.int32, np.int32, np.float32))
+    for i, lst in enumerate(lists):
+        ra[i, :] = i
+        for s_, (a_, col, w_) in enumerate(lst):
+            ra[i, s_], rc[i, s_], rw[i, s_] = a_, col, w_
+    nb = [set(int(j) for j in tab[i] if j >= 0) for i in range(N)]
+    sym = all((i in nb[j]) for i in range(N) for j in nb[i])
+    dev = nbr_idx.device
+    return dict(rev_agent=torch.from_numpy(ra).to(dev), rev_col=torch.from_numpy(rc).to(dev), rev_w=torch.from_numpy(rw).to(dev),
+                r_max=r_max, r_row=r_row, symmetric=sym)
+
+
+def bptt_coupled_supported(kind, m_max, H):
+    """nmarl_lstm_bptt_coupled handles this recurrence: 64-unit cells, message rows of 64 or 128 floats."""
+    return H == FUSED_H and ((kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3)
+
+
+_coupled_ws = {}
+
+
+COUPLED_RING_MAX_BYTES = 4 << 30     # one slot per step (one-launch form) up to this size, else two slots (step-wise)
+
+
+def _coupled_workspace(dev, N, E, K, T):
+    """Message buffer ([slots][N][E][K], zeroed ONCE: the kernel only needs finite contents; slots = T so that the
+    one-launch form never re-reads an address, 2 if that would not fit COUPLED_RING_MAX_BYTES), flag words and the state
+    hand-off buffers of nmarl_lstm_bptt_coupled -- allocated once per shape and kept (the update calls it every batch)."""
+    key = (dev, N, E, K, T)
+    w = _coupled_ws.get(key)
+    if w is None:
+        tiles = -(-E // 128)
+        slots = T if T * N * E * K * 4 <= COUPLED_RING_MAX_BYTES else 2
+        w = dict(ring=torch.zeros(max(slots, 2), N, E, K, dtype=F32, device=dev),
+                 ws=torch.zeros(lib.nmarl_lstm_bptt_coupled_ws_words(E, N), dtype=torch.int32, device=dev),
+                 dhr=torch.zeros(N, E, FUSED_H, dtype=F32, device=dev), dc=torch.zeros(N, E, FUSED_H, dtype=F32, device=dev),
+                 db=torch.zeros(N, tiles, 4 * FUSED_H, dtype=F32, device=dev), dbm=torch.zeros(N, tiles, FUSED_H, dtype=F32, device=dev),
+                 tiles=tiles)
+        _coupled_ws[key] = w
+    return w
+
+
+def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0):
+    """The whole reverse recurrence of a coupled net's update in one launch (nmarl_lstm_bptt_coupled; step-wise launches of
+    the same kernel when the grid is not resident at once): G / dZ [N,T,E,4H], Call [N,T+1,E,H], done [T,E], dHs / D1
+    [N,T,E,H], mask (lstm_comm) = the saved message term hm as an [N,T,E,H] view (unit column stride); ws = (wxm, wh,
+    lstm_bptt_wimage(wxm, wh)), wm = (w_msg, lstm_bptt_msg_wimage(w_msg)); rev = reverse_neighbor_table(nbr_idx, kind).
+    -> (db [N,4H], dbmsg [N,H]); writes dZ and D1.  `ws['err']` semantics: see check_coupled_status()."""
+    N, T, E, H4 = G.shape
+    H = H4 // 4
+    K = H * m_max if kind == COUPLED_NC else H
+    img, img_m = ws[2], wm[1]
+    for x, w_, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (dHs, H, 'dh_ext'), (D1, H, 'd1')):
+        if x.stride(3) != 1 or x.stride(2) != w_:
+            raise ValueError('bptt_coupled: %s must have contiguous rows' % what)
+    w = _coupled_workspace(G.device, N, E, K, T)
+    a = _lib.BpttCoupled()
+    a.kind, a.N, a.T, a.H, a.m_max, a.r_max, a.r_row, a.symmetric, a.mode = kind, N, T, H, m_max, rev['r_max'], rev['r_row'], \
+        int(rev['symmetric']), int(mode)
+    a.E = E
+    a.gates, a.gates_sn, a.gates_st = ptr(G, F32, strided=True), G.stride(0), G.stride(1)
+    a.c_all, a.c_sn, a.c_st = ptr(Call, F32, strided=True), Call.stride(0), Call.stride(1)
+    a.done = ptr(done, F32)
+    a.dh_ext, a.dh_sn, a.dh_st = ptr(dHs, F32, strided=True), dHs.stride(0), dHs.stride(1)
+    a.img, a.img_sn = ptr(img, F32), img.stride(0)
+    a.img_m, a.imgm_sn = ptr(img_m, F32), img_m.stride(0)
+    if kind == COUPLED_NC:
+        if mask.dim() != 4 or mask.stride(3) != 1 or mask.shape[3] != H:
+            raise ValueError('bptt_coupled: mask must be an [N,T,E,H] view with unit column stride')
+        a.mask, a.mask_sn, a.mask_st, a.mask_row = ptr(mask, F32, strided=True), mask.stride(0), mask.stride(1), mask.stride(2)
+    a.dz, a.dz_sn, a.dz_st = ptr(dZ, F32, strided=True), dZ.stride(0), dZ.stride(1)
+    a.d1, a.d1_sn, a.d1_st = ptr(D1, F32, strided=True), D1.stride(0), D1.stride(1)
+    a.ring, a.ring_sn, a.ring_slot, a.ring_slots = ptr(w['ring'], F32), w['ring'].stride(1), w['ring'].stride(0), w['ring'].shape[0]
+    a.db_part, a.db_sn = ptr(w['db'], F32), w['db'].stride(0)
+    a.dbm_part, a.dbm_sn = ptr(w['dbm'], F32), w['dbm'].stride(0)
+    a.dhr_io, a.dc_io, a.io_sn = ptr(w['dhr'], F32), ptr(w['dc'], F32), w['dhr'].stride(0)
+    a.ws = ptr(w['ws'], torch.int32)
+    a.rev_agent, a.rev_col, a.rev_w = ptr(rev['rev_agent'], torch.int32), ptr(rev['rev_col'], torch.int32), ptr(rev['rev_w'], F32)
+    check(lib.nmarl_lstm_bptt_coupled(C.byref(a), stream()), 'nmarl_lstm_bptt_coupled')
+    bptt_coupled.last_ws = (w['ws'], N * w['tiles'] * 8)          # (flag words, index of the error word)
+    return w['db'].sum(dim=1), w['dbm'].sum(dim=1)
+
+
+bptt_coupled.last_ws = None
+
+
+def check_coupled_status():
+    """Raises if a wave of the last nmarl_lstm_bptt_coupled call gave up waiting for a neighbour's block (its results are
+    invalid).  Synchronises: call where the host syncs anyway (BatchedTrainer.stats)."""
+    last = bptt_coupled.last_ws
+    if last is not None and int(last[0][last[1]].item()) != 0:
+        raise _lib.NmarlError('nmarl_lstm_bptt_coupled: a wave timed out waiting for a neighbour block (results invalid)')
+
+
 class _LstmCell(torch.autograd.Function):
     """(z [N,E,4H], bias [N,4H], c_prev [N,E,H], done [E]) -> (h_new, c_new)."""
 

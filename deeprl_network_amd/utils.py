@@ -404,6 +404,7 @@ class BatchedTrainer:
     def stats(self, reset=True):
         """(episodes finished, mean of episode-mean reward, mean of episode-std, collisions) since last call."""
         f = self.fin.cpu().numpy().copy()
+        ops.check_coupled_status()            # (the copy above synchronised) a wave of the coupled BPTT gave up waiting?
         if reset:
             self.fin.zero_()
         n = max(f[0], 1.0)

@@ -365,6 +365,8 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
  * w_msg comes as the image of nmarl_lstm_msg_wimage (K*64 floats per agent: image[k][c][t] = w_msg[k][16t+c]); nbr_idx
  * [N,m_max] (-1 padded, ascending); enc [N,E,64] with row pitch enc_row (kind 2).  out (may be NULL): where the 64
  * computed columns are stored for the update's backward ([N,E,64] view, row pitch out_row).  head: kind 1 or 2.
+ * NO ALIASING: the pre-phase reads the other agents' panels of h_in while their blocks write h_new, so no [E,64] panel
+ * of h_new may overlap a panel of h_in (NMARL_EINVAL otherwise); step in place only without the in-kernel message term.
  */
 typedef struct nmarl_msg {
     int32_t kind, m_max, K, pad_;
@@ -419,6 +421,44 @@ int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t H, const float*
                         const float* dh_ext, int64_t dh_sn, int64_t dh_st, const float* img, int64_t img_sn,
                         float* dz, int64_t dz_sn, int64_t dz_st, float* db_part, int64_t db_sn, float* dh0,
                         int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream);
+/*
+ * The reverse recurrence of a COUPLED net's update -- NeurComm (lstm_comm, agents/utils.py:182-208; unrolled training graph
+ * of policies.py:330-331) or CommNet (lstm_ic3, agents/utils.py:395-408) -- in ONE launch: per step the work of
+ * nmarl_lstm_bptt_seq plus the adjoint of the message term,
+ *     [dx | dh] = dz_t @ [wxm; wh]^T;   D1_t = dx (kind 1: * (hm_t > 0));   M_t = D1_t @ w_msg^T   [E, K]
+ *     dL/dh_{t-1}[i] = dh[i] (1 - done_t) + sum_{(a, k): i is neighbour k of a} M_t[a][:, 64 k : 64 k + 64]        (kind 1)
+ *                    = dh[i] (1 - done_t) + sum_{a: i in nbr(a)} M_t[a] / |nbr(a)|                               (kind 2)
+ * M_t crosses agents (blocks) inside the launch through `ring` ([ring_slots][N][E][K] floats, zero it once after
+ * allocating; ring_slots >= T for the one-launch form -- every step's messages get their own slot, a consumer never
+ * re-reads an address inside a launch because the per-XCD L2s are not coherent -- else >= 2: step-wise launches)
+ * with write-through stores and one flag per (agent, 128-row tile, wave) in `ws` (nmarl_lstm_bptt_coupled_ws_words(E, N)
+ * 32-bit words; zeroed by the call).  kind 1: K = 64 m_max (<= 128), mask = hm [N][T][E][..] (row pitch mask_row);
+ * kind 2: K = 64.  img = nmarl_lstm_bptt_wimage(KM = 64) of [wxm; wh]; img_m = nmarl_lstm_bptt_msg_wimage of w_msg
+ * [N][K][64].  rev_agent / rev_col / rev_w [N][r_row]: for every agent the (source agent, first column of its slot in the
+ * source's message row, weight) triples of the sum above, padded with (own index, 0, 0.0f) to r_row = 2 (r_max <= 2) or
+ * 4 entries.  symmetric: i in nbr(a) <=> a in nbr(i).
+ * Outputs: dz [N][T][E][4H], d1 [N][T][E][H], db_part [N][tiles][4H] / dbm_part [N][tiles][H] (column sums of dz / d1 per
+ * 128-row tile; bias gradients = their sums over tiles), dhr_io / dc_io [N][E][H] (scratch; on return dL/d(h, c) of the
+ * state the sequence started from, without the message part).  ws word [N * tiles * 8] is non-zero afterwards if a wave
+ * gave up waiting for a neighbour's block (results invalid).
+ * mode 0: one launch if the grid (N * tiles blocks, one per CU) is resident at once, the relation symmetric and
+ * ring_slots >= T, else T
+ * launches of one step each (same kernel, same results); 1 / 2 force the one-launch / step-wise form (tests).
+ */
+typedef struct nmarl_bptt_coupled {
+    int32_t kind, N, T, H, m_max, r_max, r_row, symmetric, mode, ring_slots;
+    int64_t E;
+    const float *gates, *c_all, *done, *dh_ext, *img, *img_m, *mask;
+    float *dz, *d1, *ring, *db_part, *dbm_part, *dhr_io, *dc_io;
+    void* ws;
+    const int32_t *rev_agent, *rev_col;
+    const float* rev_w;
+    int64_t gates_sn, gates_st, c_sn, c_st, dh_sn, dh_st, img_sn, imgm_sn, mask_sn, mask_st, mask_row, dz_sn, dz_st, d1_sn, d1_st,
+        ring_sn, ring_slot, db_sn, dbm_sn, io_sn;
+} nmarl_bptt_coupled_t;
+int nmarl_lstm_bptt_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
+int nmarl_lstm_bptt_coupled_ws_words(int64_t E, int32_t N);
+int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stream);
 /*
  * y[n,r,:W] = act(x[n,r,:] + bias[n,:]) for x [N,rows,W] (agent strides in floats, W % 4 == 0);
  * act 0 none / 1 relu / 2 tanh: the bias + activation of `fc` (agents/utils.py:65-73) and of the

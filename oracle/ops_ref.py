@@ -455,3 +455,44 @@ def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, n
         w.sub_(lr * gs / torch.sqrt(ms + eps))
         if norm_out is not None:
             norm_out[:norm.shape[0]].copy_(norm.view(-1))
+
+
+# ---- the coupled nets' reverse recurrence in one op (csrc/lstm_bptt.hip: lstm_bptt_coupled_kernel)
+COUPLED_NC, COUPLED_IC3 = 1, 2
+
+
+def lstm_bptt_msg_wimage(w_msg, out=None):
+    return w_msg                   # the restatement multiplies by the weight itself
+
+
+def reverse_neighbor_table(nbr_idx, kind):
+    return dict(nbr_idx=nbr_idx, r_max=1, r_row=2, symmetric=True)
+
+
+def bptt_coupled_supported(kind, m_max, H):
+    return (kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3
+
+
+def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0):
+    """Restatement of nmarl_lstm_bptt_coupled: per reverse step cell backward, [dx | dh] = dz @ [wxm; wh]^T, D1 = dx (relu
+    mask for lstm_comm), message adjoint through the neighbour table; ws = (wxm, wh, .), wm = (w_msg, .)."""
+    wxm, wh, _ = ws
+    w_msg = wm[0]
+    nbr_idx = rev['nbr_idx']
+    N, T, E, H4 = G.shape
+    H = H4 // 4
+    dh_rec = None
+    dc = torch.zeros(N, E, H, dtype=G.dtype)
+    for t in range(T - 1, -1, -1):
+        dz_t, dc_prev = torch.empty(N, E, H4, dtype=G.dtype), torch.empty(N, E, H, dtype=G.dtype)
+        cell_bwd(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dc, dz_t, dc_prev, dh2=dh_rec)
+        dc = dc_prev
+        dZ[:, t].copy_(dz_t)
+        dhd = torch.bmm(dz_t, wh.transpose(1, 2)) * (1.0 - done[t]).view(1, -1, 1)
+        dx = torch.bmm(dz_t, wxm.transpose(1, 2))
+        if kind == COUPLED_NC:
+            dx = dx * (mask[:, t] > 0)
+        D1[:, t].copy_(dx)
+        m_t = torch.bmm(dx, w_msg.transpose(1, 2))
+        dh_rec = (nbr_gather_bwd(m_t, nbr_idx, H) if kind == COUPLED_NC else nbr_mean_bwd(m_t, nbr_idx)) + dhd
+    return dZ.sum(dim=(1, 2)), D1.sum(dim=(1, 2))

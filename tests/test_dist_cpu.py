@@ -1,7 +1,8 @@
-"""Data-parallel path with world_size 2 on the gloo backend (CPU; HIP ops + env emulated by their
+"""Data-parallel path with world_size 2 and 8 on the gloo backend (CPU; HIP ops + env emulated by their
 oracle restatements): two ranks with 3 replicas each must end with bit-identical weights on both
 ranks, equal (to fp32 rounding) to ONE process stepping the same 6 replicas -- i.e. the single flat
-gradient all-reduce + 1/world scaling implements the global batch mean."""
+gradient all-reduce + 1/world scaling implements the global batch mean.  World 8 = BASELINE configs[4]'s
+layout (rank-offset `env_id_base`, one all-reduce per update) with 2 replicas per rank against one process x 16."""
 import os
 import sys
 
@@ -12,6 +13,18 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(autouse=True)
+def _one_thread(monkeypatch):
+    """The emulated ops are tiny: with the default thread pool, 2-8 spawned ranks plus the parent oversubscribe the host
+    and spin (measured: 6 min instead of 10 s for 8 ranks).  The workers inherit OMP_NUM_THREADS before importing torch."""
+    monkeypatch.setenv('OMP_NUM_THREADS', '1')
+    monkeypatch.setenv('MKL_NUM_THREADS', '1')
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
 
 
 def _run(agent, E, env_id_base, group, n_batches):
@@ -46,12 +59,12 @@ def _run(agent, E, env_id_base, group, n_batches):
         return model.policy.params.flat.clone(), tr.global_counter.cur_step
 
 
-def _worker(rank, world, port, agent, out):
+def _worker(rank, world, port, agent, out, e_rank=3):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(1)
-    w, steps = _run(agent, 3, rank * 3, dist.group.WORLD, 3)
+    w, steps = _run(agent, e_rank, rank * e_rank, dist.group.WORLD, 3)
     torch.save((w, steps), os.path.join(out, 'rank%d.pt' % rank))
     dist.destroy_process_group()
 
@@ -66,3 +79,19 @@ def test_two_ranks_equal_one_process(agent, tmp_path):
     assert s0 == s1 == 3 * 10                   # batches x n_step lock-steps on every rank
     single, _ = _run(agent, 6, 0, None, 3)
     torch.testing.assert_close(w0, single, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('agent', ['ma2c_nc'])
+def test_eight_ranks_equal_one_process(agent, tmp_path):
+    """The 8-GPU layout of BASELINE configs[4] on 8 gloo ranks: replicas sharded contiguously (rank r owns the global
+    replica ids [2r, 2r + 2): Philox streams are global), ONE flat all-reduce per update, 1/8 inside the optimiser kernel
+    -> all 8 ranks bit-identical, and equal to one process stepping the 16 replicas."""
+    world = 8
+    port = 31500 + (os.getpid() % 2000) + {'ma2c_nc': 0, 'ia2c_fp': 9}[agent]
+    mp.spawn(_worker, args=(world, port, agent, str(tmp_path), 2), nprocs=world, join=True)
+    ws = [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(world)]
+    for r in range(1, world):
+        assert torch.equal(ws[0][0], ws[r][0]), 'rank %d diverged from rank 0' % r
+        assert ws[r][1] == 3 * 10
+    single, _ = _run(agent, 2 * world, 0, None, 3)
+    torch.testing.assert_close(ws[0][0], single, rtol=2e-5, atol=2e-6)

@@ -909,3 +909,129 @@ def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
                         xs=(slot[:, :, :KXg] if KXg else None, None, img, None, dict(msg_g, out=None)))
     torch.testing.assert_close(vg.cpu().double(), vr, rtol=2e-4, atol=5e-5)
     assert torch.equal(slot, keep)
+
+
+def _topology(N, kind):
+    """line (m_max 2) or 5x5-style grid (m_max 4) neighbour masks for N agents."""
+    nm = np.zeros((N, N), dtype=int)
+    if kind == 'line':
+        for i in range(N - 1):
+            nm[i, i + 1] = nm[i + 1, i] = 1
+    else:
+        side = int(round(N ** 0.5))
+        assert side * side == N
+        for i in range(N):
+            r, c_ = divmod(i, side)
+            for rr, cc in ((r - 1, c_), (r + 1, c_), (r, c_ - 1), (r, c_ + 1)):
+                if 0 <= rr < side and 0 <= cc < side:
+                    nm[i, rr * side + cc] = 1
+    return nm
+
+
+@pytest.mark.parametrize('kind,topo,N,T,E', [(1, 'line', 8, 12, 4096), (1, 'line', 8, 60, 300), (1, 'line', 3, 5, 127),
+                                             (2, 'line', 8, 12, 4096), (2, 'grid', 25, 7, 1024), (2, 'grid', 9, 6, 130),
+                                             (1, 'line', 2, 3, 1)])
+def test_lstm_bptt_coupled_one_launch(kind, topo, N, T, E):
+    """nmarl_lstm_bptt_coupled: the whole reverse recurrence of a coupled net (lstm_comm kind 1 / lstm_ic3 kind 2,
+    agents/utils.py:182-208, 395-408) in one launch, the message adjoint handed between the agents' blocks inside the kernel
+    -- against the float64 restatement (oracle/ops_ref.py bptt_coupled: cell backward, dgrad, relu mask, neighbour gather /
+    mean adjoint per step), and the step-wise form of the same kernel (mode 2: T launches) bit for bit.  The one-launch
+    form is forced (mode 1) where the grid fits the chip, so the in-kernel hand-off (flags, write-through ring) is what runs;
+    strided sequence buffers, ragged rows, dones inside the sequence."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    nm = _topology(N, topo)
+    nbr_idx, _ = ops.neighbor_table(nm, 'cuda')
+    m_max = nbr_idx.shape[1]
+    K = H * m_max if kind == 1 else H
+    g = torch.Generator().manual_seed(N * 131 + T * 7 + E + kind)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    gates = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
+    call = r(N, T + 1, E, H) * 0.8
+    done = (torch.rand(T, E, generator=g) < 0.2).float()
+    dhs = r(N, T, E, H)
+    wh = r(N, H, 4 * H) * 0.1
+    wxm = r(N, H, 4 * H) * 0.1
+    w_msg = r(N, K, H) * 0.15
+    S = torch.relu(r(N, T, E, 3 * H))                     # lstm_comm's saved LSTM input; its last third is the message term hm
+    hm = S[..., 2 * H:]
+    dz_r = torch.empty(N, T, E, 4 * H, dtype=torch.float64)
+    d1_r = torch.empty(N, T, E, H, dtype=torch.float64)
+    rev_r = ops_ref.reverse_neighbor_table(nbr_idx.cpu(), kind)
+    db_r, dbm_r = ops_ref.bptt_coupled(kind, rev_r, m_max, gates.double(), call.double(), done.double(), dhs.double(),
+                                       (wxm.double(), wh.double(), None), (w_msg.double(), None),
+                                       hm.double() if kind == 1 else None, dz_r, d1_r)
+    # device buffers: slots of wider allocations
+    G = torch.zeros(N, T + 2, E, 4 * H, device='cuda'); G[:, 1:T + 1].copy_(gates)
+    C = torch.zeros(N, T + 3, E, H, device='cuda'); C[:, 1:T + 2].copy_(call)
+    D = torch.zeros(N, T + 1, E, H, device='cuda'); D[:, :T].copy_(dhs)
+    Sg = S.cuda()
+    doneg = done.cuda()
+    wxg, whg, wmg = wxm.cuda(), wh.cuda(), w_msg.cuda()
+    ws = (wxg, whg, ops.lstm_bptt_wimage(wxg, whg))
+    wm = (wmg, ops.lstm_bptt_msg_wimage(wmg))
+    rev = ops.reverse_neighbor_table(nbr_idx, kind)
+    assert rev is not None and rev['symmetric']
+    out = {}
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    resident = N * -(-E // 128) <= cus
+    for mode in ((1, 2) if resident else (0, 2)):
+        dZ = torch.zeros(N, T + 2, E, 4 * H, device='cuda')
+        D1 = torch.zeros(N, T, E, H, device='cuda')
+        db, dbm = ops.bptt_coupled(kind, rev, m_max, G[:, 1:T + 1], C[:, 1:T + 2], doneg, D[:, :T], ws, wm,
+                                   Sg[..., 2 * H:] if kind == 1 else None, dZ[:, 1:T + 1], D1, mode=mode)
+        torch.cuda.synchronize()
+        ops.check_coupled_status()
+        assert torch.all(dZ[:, 0] == 0) and torch.all(dZ[:, T + 1] == 0)
+        out[mode] = (dZ[:, 1:T + 1].clone(), D1, db, dbm)
+    a, b = out[1 if resident else 0], out[2]
+    for name, o in (('one launch', a), ('step-wise', b)):          # each form against the restatement first: says WHICH is off
+        bad = (~torch.isclose(o[0].cpu().double(), dz_r, rtol=2e-4, atol=5e-5)).sum().item()
+        assert bad == 0, '%s: %d of %d dz entries off the restatement' % (name, bad, dz_r.numel())
+    ndiff = (a[0] != b[0]).sum().item() + (a[1] != b[1]).sum().item()
+    assert ndiff == 0, 'one launch and step-wise launches differ in %d entries' % ndiff
+    torch.testing.assert_close(a[2], b[2], rtol=1e-5, atol=1e-5 * (T * E) ** 0.5)
+    dZ, D1, db, dbm = a
+    torch.testing.assert_close(dZ.cpu().double(), dz_r, rtol=2e-4, atol=5e-5)
+    torch.testing.assert_close(D1.cpu().double(), d1_r, rtol=2e-4, atol=5e-5)
+    torch.testing.assert_close(db.cpu().double(), db_r, rtol=1e-4, atol=1e-4 * max(1.0, float(db_r.abs().max())))
+    torch.testing.assert_close(dbm.cpu().double(), dbm_r, rtol=1e-4, atol=1e-4 * max(1.0, float(dbm_r.abs().max())))
+    torch.testing.assert_close(db.cpu().double(), dZ.double().sum(dim=(1, 2)).cpu(), rtol=1e-5,
+                               atol=1e-6 * max(1.0, float(db_r.abs().max())) * (T * E) ** 0.5)
+
+
+def test_lstm_bptt_coupled_repeated_calls_under_load():
+    """The in-kernel hand-off must not depend on timing: the same update twice while another stream keeps the chip busy
+    with a bandwidth-bound kernel (uneven load between the agents' blocks), results identical to the quiet run."""
+    from deeprl_network_amd import ops
+    H, N, T, E, kind = 64, 8, 20, 4096, 1
+    nbr_idx, _ = ops.neighbor_table(_topology(N, 'line'), 'cuda')
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()                                  # noqa: E731
+    G = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
+    C, D = r(N, T + 1, E, H) * 0.8, r(N, T, E, H)
+    done = (torch.rand(T, E, generator=g) < 0.1).float().cuda()
+    wx, wh, wmsg = r(N, H, 4 * H) * 0.1, r(N, H, 4 * H) * 0.1, r(N, 2 * H, H) * 0.15
+    S = torch.relu(r(N, T, E, 3 * H))
+    ws, wm = (wx, wh, ops.lstm_bptt_wimage(wx, wh)), (wmsg, ops.lstm_bptt_msg_wimage(wmsg))
+    rev = ops.reverse_neighbor_table(nbr_idx, kind)
+
+    def run():
+        dZ, D1 = torch.empty(N, T, E, 4 * H, device='cuda'), torch.empty(N, T, E, H, device='cuda')
+        db, dbm = ops.bptt_coupled(kind, rev, 2, G, C, done, D, ws, wm, S[..., 2 * H:], dZ, D1, mode=1)
+        return dZ, D1, db.clone(), dbm.clone()
+    quiet = run()
+    torch.cuda.synchronize()
+    ops.check_coupled_status()
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, device='cuda')
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                big.mul_(1.0001)
+        loaded = run()
+        torch.cuda.synchronize()
+        ops.check_coupled_status()
+        for x, y in zip(quiet, loaded):
+            assert torch.equal(x, y)

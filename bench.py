@@ -501,8 +501,13 @@ def main():
     is_grid = env.name.startswith('atsc')
     n_agent = env.n_agent
     # algorithmic bytes per replica-step of the env kernel
-    balg = 7548 if is_grid else (B_ALG_COMPACT if trainer.compact_obs else B_ALG_GATHERED)
-    obs_variant = 'compact [E,8,5] observation' if trainer.compact_obs else 'gathered [E,8,15] observation'
+    # grid: read q, transit 1200 + action 25 + prev 25 + t 4 + xi 16; write q, transit 1200 + prev 25 + t 4 + reward /
+    # global reward / done 9 + observation (compact [25,12] 1200 B; gathered slab: 5040 B of its 6000 are data)
+    balg = (3708 if trainer.compact_obs else 7548) if is_grid else (B_ALG_COMPACT if trainer.compact_obs else B_ALG_GATHERED)
+    if is_grid:
+        obs_variant = 'compact [E,25,12] observation' if trainer.compact_obs else 'gathered [E,25,60] observation'
+    else:
+        obs_variant = 'compact [E,8,5] observation' if trainer.compact_obs else 'gathered [E,8,15] observation'
     kname = 'grid_step_kernel (nmarl_grid_step)' if is_grid else 'cacc_step_kernel (nmarl_cacc_step)'
     if env.name.endswith('real_net'):
         # q, transit in and out (4 B x 2 x 2 x 264 links) + action / prev bytes + scalars + the padded neighbour slab
@@ -567,7 +572,7 @@ def main():
                            'pair on the launch stream around every LSTM lock-step launch (mean over the launches; agrees with the '
                            'rocprofv3 kernel trace of the batch, profiles/).  us_per_launch_isolated_graph: hipGraph of 60 '
                            'back-to-back launches on the model shapes and weights, 10 replays between two events (hot caches: '
-                           'flatters the kernel by 5-8 %).  Algorithmic work per (agent, replica) row: '
+                           'flatters the kernel by 5-8 %%).  Algorithmic work per (agent, replica) row: '
                            'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops (uncoupled nets; coupled nets: the '
                            'policy step + its 2*K_m*64 message flops, the value step is a second launch), fp32 in / fp32 accumulate on '
                            'v_mfma_f32_16x16x4_f32 (peak %.1f TFLOP/s dense, MI355X_MICROARCH.md); the same launch moves '
@@ -608,30 +613,32 @@ def main():
                    'latency-bound and LLC-resident (SURVEY.md H1); see roofline_env_step_large_E for the HBM regime.'
                    % (n_step, balg, obs_variant, E, balg * E / 1e6)}
         if 'roofline' not in out or 'error' in out['roofline']:
+            if 'roofline' in out:
+                out['roofline_lstm_error'] = out['roofline']['error']
             out['roofline'] = dict(out['roofline_env_step'])
-        if world == 1 and not is_grid:
+        if world == 1 and not env.name.endswith('real_net'):
             try:
-                big_E = 1 << 21
+                big_E = (1 << 17) if is_grid else (1 << 21)
                 big = make_batch_env(cp['ENV_CONFIG'], num_envs=big_E, device=device, env_id_base=10 ** 7)
                 if trainer.compact_obs:
                     big.set_compact_obs(True)
                 big.reset()
                 e = torch.arange(big_E, device=device)[:, None]
-                a = torch.arange(N_AGENT, device=device)[None, :]
-                big_tape = torch.stack([((e + 3 * a + s) % 4).to(torch.uint8) for s in range(8)])
+                a = torch.arange(n_agent, device=device)[None, :]
+                big_tape = torch.stack([((e + 3 * a + s) % env.n_a).to(torch.uint8) for s in range(8)])
                 for k in range(60):                      # leave the all-equilibrium start of the episode
                     big.step(big_tape[k % 8], auto_reset=True)
                 us_b = measure_step_kernel(big, big_tape, reps=10)
                 ach_b = balg * big_E / us_b / 1e3
-                tr_big, tr_src_b = pmc_traffic(pk + '_E2p21')
-                out['roofline_env_step_large_E'] = {'kernel': 'cacc_step_kernel', 'bound': 'hbm', 'achieved': ach_b,
+                tr_big, tr_src_b = pmc_traffic(('grid_step_compact_E2p17' if trainer.compact_obs else 'grid_step_E2p17') if is_grid else pk + '_E2p21')
+                out['roofline_env_step_large_E'] = {'kernel': kname, 'bound': 'hbm', 'achieved': ach_b,
                                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
                                                     'traffic': None if tr_big is None else tr_big * big_E,
                                                     'traffic_source': tr_src_b,
                                                     'replicas_per_launch': big_E, 'us_per_launch': us_b,
                                                     'bytes_per_launch': balg * big_E,
-                                                    'how': 'same kernel (' + obs_variant + ') at E=2^21 (working set >> 256 MB Infinity Cache), '
-                                                           'actions (env+3*agent+step) mod 4 (SURVEY.md 8d)'}
+                                                    'how': 'same kernel (' + obs_variant + ') at E=2^%d (working set >> 256 MB Infinity Cache), '
+                                                           'actions (env+3*agent+step) mod n_a (SURVEY.md 8d)' % (17 if is_grid else 21)}
                 del big
             except Exception as ex:      # never lose the headline line to the side measurement
                 out['roofline_env_step_large_E'] = {'error': repr(ex)}

@@ -193,10 +193,10 @@ class IA2C:
             return False
         N, E, T, H, d = self.n_agent, self.E, self.n_step, self.n_lstm, self.device
         KX = p.params[p.k_wx].shape[1]
-        # uncoupled nets: one zero slab more than needed, so that [S | .] and the state sequences have the SAME (T + 1)-slab
-        # shape -- the update's weight-gradient GEMMs then read the saved buffers in place (ops._lstm_seq_x_backward)
-        self.S_ext = None if p.coupled else torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
-        self.S_buf = torch.zeros(N, T, E, KX, dtype=F32, device=d) if p.coupled else self.S_ext[:, :T]
+        # one zero slab more than needed, so that [S | .] and the state sequences have the SAME (T + 1)-slab shape -- the
+        # update's weight-gradient GEMMs then read the saved buffers in place (ops._lstm_seq_x_backward, agents/sequence.py)
+        self.S_ext = torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
+        self.S_buf = self.S_ext[:, :T]
         self.G_buf = torch.zeros(N, T, E, 4 * H, dtype=F32, device=d)
         self.H_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)

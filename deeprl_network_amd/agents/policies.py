@@ -395,7 +395,7 @@ class BatchedPolicy:
         T, E = done.shape
         Xv = X.reshape(T * E, self.N, X.shape[-1]).transpose(0, 1)          # gathered [.., n_obs] or compact [.., n_feat] slab
         if self.coupled:
-            return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps)
+            return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext)
         s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
         Hs = ops.lstm_sequence_saved(s.view(self.N, T, E, s.shape[-1]), self.params[self.k_wx], self.params[self.k_wh],
                                      self.params[self.k_b], G, Hall, Call, done, masked_steps, s_ext=S_ext)
@@ -405,13 +405,13 @@ class BatchedPolicy:
         """Extra per-step tensors a coupled net saves besides S / G / Hall / Call: {name: width}."""
         return {}
 
-    def _unroll_saved_coupled(self, Xv, FP, S, G, Hall, Call, done, masked_steps):
+    def _unroll_saved_coupled(self, Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext=None):
         T, E = done.shape
         kind, wx, w_msg, b_msg, mfc_w, mfc_b = self._seq_args()
         enc = self._enc_saved(Xv, FP, S)
         Hs = sequence.coupled_sequence_saved(kind, self.nbr_idx, masked_steps, enc.view(self.N, T, E, enc.shape[-1]), done,
                                              self.params[self.k_wx], self.params[self.k_wh], self.params[self.k_b],
-                                             w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, getattr(self, '_extra', {}))
+                                             w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, getattr(self, '_extra', {}), s_ext=S_ext)
         return Hs.reshape(self.N, T * E, self.n_h)
 
     def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):

@@ -161,8 +161,10 @@ class CoupledSequenceSaved(torch.autograd.Function):
       ic3 / dial as in CoupledSequence (their `enc` enters the LSTM input additively)."""
 
     @staticmethod
-    def forward(ctx, kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, A1, A2):
+    def forward(ctx, kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, A1, A2,
+                s_ext=None):
         T = G.shape[1]
+        ctx.s_ext = s_ext
         e = G.new_empty(0)
         ctx.save_for_backward(G, Hall, Call, S, A1 if A1 is not None else e, A2 if A2 is not None else e, done, wx, wh, w_msg,
                               mfc_w if mfc_w is not None else e, nbr_idx)
@@ -179,8 +181,21 @@ class CoupledSequenceSaved(torch.autograd.Function):
         dev = G.device
         R = T * E
         dHs = dHs.contiguous()
-        dZ = torch.empty_like(G)
-        D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
+        # (T + 1)-slab operands: with the LSTM inputs handed over as the first T slabs of a (T + 1)-slab buffer (last slab
+        # zero), dZ / D1 allocated the same way and the h sequence being (T + 1) slabs anyway, every weight-gradient GEMM
+        # reads contiguous [N, (T+1) E, .] operands in place -- no masked copy of the h sequence, no gathered copy
+        s_ext = ctx.s_ext
+        ext = (s_ext is not None and kind != 'dial' and Hall.is_contiguous() and s_ext.is_contiguous() and
+               S.data_ptr() == s_ext.data_ptr() and tuple(s_ext.shape) == (N, T + 1, E, S.shape[-1]))
+        if ext:
+            dZe = torch.empty(N, T + 1, E, H4, dtype=F32, device=dev)
+            D1e = torch.empty(N, T + 1, E, H, dtype=F32, device=dev)
+            dZe[:, T].zero_()
+            D1e[:, T].zero_()
+            dZ, D1 = dZe[:, :T], D1e[:, :T]
+        else:
+            dZ = torch.empty_like(G)
+            D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
         D2 = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
         DS = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
         keep = 1.0 - done
@@ -244,6 +259,28 @@ class CoupledSequenceSaved(torch.autograd.Function):
                 dmsg = ops.nbr_gather_bwd(torch.bmm(D1[:, t], wmsg_t), nbr_idx, H)
                 torch.mul(dmsg, (A2[:, t] > 0), out=D2[:, t])
                 dh_rec = torch.baddbmm(dhd, D2[:, t], mfc_w.transpose(1, 2))
+        if ext:
+            Rx = (T + 1) * E
+            Hx, D1x, dZx = Hall.view(N, Rx, H), D1e.view(N, Rx, H), dZe.view(N, Rx, H4)
+            # message layer first: its input is the UN-masked h_{t-1} (quirk Q3)
+            if kind == 'nc':
+                dwmsg = _dwmsg_by_runs(Hx, D1x, nbr_idx, H)
+            else:
+                dwmsg = ops.wgrad(ops.nbr_mean(Hx, nbr_idx), D1x)
+            if db is None:
+                db, dbmsg = dZx.sum(dim=1), D1x.sum(dim=1)
+            with torch.no_grad():            # h_{t-1} keep_t for the recurrent weight, in the saved buffer itself (the next
+                for t in masked:             # rollout rewrites it); steps outside `masked` have done_t = 0 by contract
+                    Hall[:, t].mul_(keep[t].view(1, E, 1))
+            dwh = ops.wgrad(Hx, dZx)
+            dwx = ops.wgrad(s_ext.view(N, Rx, S.shape[-1]), dZx)
+            if kind == 'nc':
+                denc = None
+                if ctx.needs_input_grad[3]:
+                    denc = torch.bmm(dZ.reshape(N, R, H4), wx[:, :2 * H].transpose(1, 2)).view(N, T, E, 2 * H)
+            else:
+                denc = D1
+            return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, None, None, None, None, None, None, None, None, None)
         dZf = dZ.view(N, R, H4)
         Hprev = Hall[:, :T]
         if len(masked) == T:
@@ -273,7 +310,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
             dmfc_w = ops.wgrad(Hp, D2f)
             dmfc_b = D2f.sum(dim=1)
             denc = DS
-        return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b, None, None, None, None, None, None)
+        return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b, None, None, None, None, None, None, None)
 
 
 _rev_tables = {}
@@ -287,11 +324,41 @@ def _reverse_table(nbr_idx, ckind):
     return _rev_tables[key][1]
 
 
+_runs = {}
+
+
+def _dwmsg_by_runs(Hx, D1x, nbr_idx, H):
+    """lstm_comm's message-weight gradient  gather(h)^T D1  without the gathered copy: block (agent i, slot k) of it is
+    h[nbr(i, k)]^T D1[i], and over a run of consecutive agents whose k-th neighbour sits at a constant index offset both
+    operands are plain slices -- one row-split GEMM per run (3 on the line graph).  Hx / D1x [N,rows,H] contiguous."""
+    key = (nbr_idx.data_ptr(), nbr_idx.device, tuple(nbr_idx.shape))
+    if key not in _runs:
+        tab = nbr_idx.cpu().numpy()
+        runs = []
+        for k in range(tab.shape[1]):
+            i = 0
+            while i < tab.shape[0]:
+                if tab[i, k] < 0:
+                    i += 1
+                    continue
+                d, i0 = int(tab[i, k]) - i, i
+                while i < tab.shape[0] and tab[i, k] >= 0 and int(tab[i, k]) - i == d:
+                    i += 1
+                runs.append((i0, i, k, d))
+        _runs[key] = (nbr_idx, runs)
+    N, m = nbr_idx.shape
+    out = torch.zeros(N, m * H, H, dtype=F32, device=Hx.device)      # slots an agent does not have: zero gradient
+    for i0, i1, k, d in _runs[key][1]:
+        out[i0:i1, k * H:(k + 1) * H] = ops.wgrad(Hx[i0 + d:i1 + d], D1x[i0:i1])
+    return out
+
+
 def coupled_sequence_saved(kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S,
-                           extra):
-    """enc [N,T,E,W] (autograd-connected h-independent part), saved activations of the rollout -> Hs [N,T,E,H]."""
+                           extra, s_ext=None):
+    """enc [N,T,E,W] (autograd-connected h-independent part), saved activations of the rollout -> Hs [N,T,E,H].
+    s_ext (optional): the [N,T+1,E,KX] buffer S is the first T slabs of (last slab zero): in-place weight gradients."""
     return CoupledSequenceSaved.apply(kind, nbr_idx, masked_steps, enc, done, wx, wh, b, w_msg, b_msg, mfc_w, mfc_b, G, Hall,
-                                      Call, S, extra.get('A1'), extra.get('A2'))
+                                      Call, S, extra.get('A1'), extra.get('A2'), s_ext)
 
 
 def coupled_sequence(kind, nbr_idx, masked_steps, enc, h0, c0, done, wx, wh, b, w_msg, b_msg, mfc_w=None, mfc_b=None):

@@ -61,6 +61,42 @@ __device__ __forceinline__ void stage_tile(float* xs, const float* __restrict__ 
     }
 }
 
+// Gathered input x~[n,r,k*A+a] = x[nbr(n,k),r,a] with A % 4 == 0 and 16-byte aligned rows (the grid's compact observation:
+// A = 12): staged as float4 units through a per-block table of source offsets -- the element-wise form divides by A and
+// re-reads the neighbour table for every one of the tile's 4096 elements.
+template <int FMAX>
+__device__ __forceinline__ void gather_table(int64_t* gsrc, const int32_t* __restrict__ nbr_idx, const int n, const int m_max,
+                                             const int A, const int F, const int64_t x_sn) {
+    if (threadIdx.x < FMAX / 4) {
+        const int f = 4 * threadIdx.x;
+        int64_t o = -1;
+        if (f < F) {
+            const int k = f / A;
+            const int src = nbr_idx[n * m_max + k];
+            if (src >= 0) o = (int64_t)src * x_sn + (f - k * A);
+        }
+        gsrc[threadIdx.x] = o;
+    }
+    __syncthreads();
+}
+template <int FMAX>
+__device__ __forceinline__ void stage_tile_gather4(float* xs, const float* __restrict__ x, const int64_t x_row, const int64_t row0,
+                                                   const int64_t rows, const int64_t* gsrc) {
+    constexpr int FP = FMAX + 4, Q = FMAX / 4;
+#pragma unroll
+    for (int m = 0; m < TILE * Q / 256; ++m) {             // unconditional loads: clamped source, value selected afterwards
+        const int idx = threadIdx.x + 256 * m;
+        const int r = idx / Q, f4 = idx - r * Q;
+        const int64_t row = row0 + r, o = gsrc[f4];
+        const bool ok = o >= 0 && row < rows;
+        const float4 v = *reinterpret_cast<const float4*>(x + (ok ? o : 0) + (ok ? row : 0) * x_row);
+        *reinterpret_cast<float4*>(xs + r * FP + 4 * f4) = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+__device__ __forceinline__ bool gather4_ok(const float* x, const int64_t x_sn, const int64_t x_row, const int A) {
+    return (A & 3) == 0 && (x_sn & 3) == 0 && (x_row & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
 template <int FMAX>
 __global__ __launch_bounds__(256) void fc_fwd_kernel(const int64_t rows, const int F, const int tiles_per_block,
                                                      const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
@@ -179,11 +215,16 @@ __global__ __launch_bounds__(256) void fc_fwd_multi_kernel(const int64_t rows, c
 #pragma unroll
     for (int f = 0; f < FMAX; ++f) wr[f] = f < F ? pt.w[(int64_t)n * pt.w_sn + f * J + j] : 0.0f;
     const float bj = pt.b[(int64_t)n * pt.b_sn + j];
+    __shared__ int64_t gsrc[FMAX / 4];
+    const bool g4 = pt.nbr_idx != nullptr && gather4_ok(pt.x, pt.x_sn, pt.x_row, pt.gather_A);
+    if (g4) gather_table<FMAX>(gsrc, pt.nbr_idx, n, pt.m_max, pt.gather_A, F, pt.x_sn);
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
         if (pt.nbr_idx == nullptr) {
             stage_tile<FMAX>(xs, pt.x + (int64_t)n * pt.x_sn, pt.x_row, row0, rows, F);
+        } else if (g4) {
+            stage_tile_gather4<FMAX>(xs, pt.x, pt.x_row, row0, rows, gsrc);
         } else {
             const int A = pt.gather_A;
             for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
@@ -383,15 +424,22 @@ __global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, co
     const float* xn = x + (int64_t)n * x_sn;
     const float* yn = y + (int64_t)n * y_sn;
     const float* dyn = dy + (int64_t)n * dy_sn;
+    __shared__ int64_t gsrc[FMAX / 4];
+    const bool g4 = xg.nbr_idx != nullptr && gather4_ok(x, x_sn, x_row, xg.A);
+    if (g4) gather_table<FMAX>(gsrc, xg.nbr_idx, n, xg.m_max, xg.A, F, x_sn);
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
-        for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
-            const int r = idx / FMAX, f = idx - r * FMAX;
-            const int64_t row = row0 + r;
-            const bool ok = f < F && row < rows;
-            const float v = x_elem(x, x_sn, x_row, n, row, f, ok, xg);
-            xs[r * FP + f] = ok ? v : 0.0f;
+        if (g4) {
+            stage_tile_gather4<FMAX>(xs, x, x_row, row0, rows, gsrc);
+        } else {
+            for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
+                const int r = idx / FMAX, f = idx - r * FMAX;
+                const int64_t row = row0 + r;
+                const bool ok = f < F && row < rows;
+                const float v = x_elem(x, x_sn, x_row, n, row, f, ok, xg);
+                xs[r * FP + f] = ok ? v : 0.0f;
+            }
         }
         __syncthreads();
 #pragma unroll RU

@@ -11,11 +11,13 @@
 // (q, transit: 2 x 25 x 6 fp32 = 1200 B, contiguous) is loaded with coalesced
 // accesses into LDS; the neighbour exchange (desired link flows D, receiving space,
 // spill-back scale) goes through LDS with wave barriers -- the 4-neighbourhood of the
-// lattice never leaves the half wave; the gathered observation slab [25, 5*12]
-// (own + up to 4 neighbours in ascending node index) is assembled in LDS and written
-// with 16-byte coalesced stores (6000 contiguous bytes per replica).
-// HBM-bound (about 8.5 KB per replica-step); no MFMA.
+// lattice never leaves the half wave.  Observation: COMPACT [25, 12] -- every node's OWN wave vector, what the reference
+// hands an agent (atsc_env.py:253-262; 1200 contiguous bytes per replica, the batched engine's layout: the policy's
+// encoder kernel gathers the neighbours itself) -- or the gathered slab [25, 5*12] (own + up to 4 neighbours in ascending
+// node index, 6000 bytes) for the reference duck-type; assembled in LDS, 16-byte coalesced stores.
+// HBM-bound (3.7 KB per replica-step with the compact observation, 8.5 KB with the slab); no MFMA.
 #include "common.h"
+#include <cstddef>
 
 namespace {
 
@@ -27,29 +29,50 @@ constexpr int NSLOT = 5;                // own + 4 neighbour slots
 constexpr int OBSW = NSLOT * NL;        // 60
 constexpr float DT = 5.0f, YELLOW = 2.0f, SAT = 0.5f, Q_MAX = 26.0f, DET_CAP = 7.0f, YELLOW_EFF = 1.0f;
 
-// large_grid_env.py:25-26   0 = r, 1 = G, 2 = g
-__constant__ uint8_t c_green[5][NL] = {
-    {1, 1, 2, 0, 0, 0, 1, 1, 2, 0, 0, 0}, {0, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 1}, {0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1, 0},
-    {0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1}};
-__constant__ int8_t c_link_lane[NL] = {0, 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5};
-__constant__ float c_link_share[NL] = {.2f, .6f, .2f, .15f / .85f, .7f / .85f, 1.0f,
-                                       .2f, .6f, .2f, .15f / .85f, .7f / .85f, 1.0f};
-__constant__ int8_t c_lane_approach[NLANE] = {0, 1, 1, 2, 3, 3};
-__constant__ float c_split[NLANE] = {1.0f, 0.85f, 0.15f, 1.0f, 0.85f, 0.15f};
-// link -> (drow, dcol, receiving approach)
-__constant__ int8_t c_dest[NL][3] = {{0, -1, 1}, {-1, 0, 0}, {0, 1, 3}, {1, 0, 2}, {0, -1, 1}, {-1, 0, 0},
-                                     {0, 1, 3}, {1, 0, 2}, {0, -1, 1}, {-1, 0, 0}, {0, 1, 3}, {1, 0, 2}};
-__constant__ int8_t c_from[4][2] = {{1, 0}, {0, 1}, {-1, 0}, {0, -1}};
-__constant__ int8_t c_feed[4][3] = {{1, 5, 9}, {0, 4, 8}, {3, 7, 11}, {2, 6, 10}};
-__constant__ float c_ratio1[7] = {0.4f, 0.7f, 0.9f, 1.0f, 0.75f, 0.5f, 0.25f};
-__constant__ float c_ratio2[7] = {0.3f, 0.8f, 0.9f, 1.0f, 0.8f, 0.6f, 0.2f};
-// entry group (+1) per (node, approach); 0 = no external entry          build_file.py:285-295
-__constant__ int8_t c_entry[NN][4] = {
-    {0, 0, 0, 2}, {0, 0, 3, 0}, {0, 0, 3, 0}, {0, 0, 3, 0}, {0, 4, 0, 0},
-    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
-    {0, 0, 0, 2}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 4, 0, 0},
-    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
-    {0, 0, 0, 2}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {0, 4, 0, 0}};
+// All static tables in ONE __constant__ object: one base address in scalar registers instead of twelve (the twelve separate
+// arrays cost 24 SGPRs of addresses and the kernel spilled 23).
+struct GridTables {
+    uint8_t green[5][NL];        // large_grid_env.py:25-26   0 = r, 1 = G, 2 = g
+    int8_t link_lane[NL];
+    int8_t lane_approach[NLANE];
+    int8_t dest[NL][3];          // link -> (drow, dcol, receiving approach)
+    int8_t from[4][2];
+    int8_t feed[4][3];
+    int8_t entry[NN][4];         // entry group (+1) per (node, approach); 0 = no external entry   build_file.py:285-295
+    float link_share[NL];
+    float split[NLANE];
+    float ratio1[7];
+    float ratio2[7];
+};
+__constant__ GridTables c_tab = {
+    {{1, 1, 2, 0, 0, 0, 1, 1, 2, 0, 0, 0}, {0, 0, 0, 1, 0, 1, 0, 0, 0, 1, 0, 1}, {0, 0, 0, 1, 1, 0, 0, 0, 0, 1, 1, 0},
+     {0, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1}},
+    {0, 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5},
+    {0, 1, 1, 2, 3, 3},
+    {{0, -1, 1}, {-1, 0, 0}, {0, 1, 3}, {1, 0, 2}, {0, -1, 1}, {-1, 0, 0},
+     {0, 1, 3}, {1, 0, 2}, {0, -1, 1}, {-1, 0, 0}, {0, 1, 3}, {1, 0, 2}},
+    {{1, 0}, {0, 1}, {-1, 0}, {0, -1}},
+    {{1, 5, 9}, {0, 4, 8}, {3, 7, 11}, {2, 6, 10}},
+    {{0, 0, 0, 2}, {0, 0, 3, 0}, {0, 0, 3, 0}, {0, 0, 3, 0}, {0, 4, 0, 0},
+     {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
+     {0, 0, 0, 2}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 4, 0, 0},
+     {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
+     {0, 0, 0, 2}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {0, 4, 0, 0}},
+    {.2f, .6f, .2f, .15f / .85f, .7f / .85f, 1.0f, .2f, .6f, .2f, .15f / .85f, .7f / .85f, 1.0f},
+    {1.0f, 0.85f, 0.15f, 1.0f, 0.85f, 0.15f},
+    {0.4f, 0.7f, 0.9f, 1.0f, 0.75f, 0.5f, 0.25f},
+    {0.3f, 0.8f, 0.9f, 1.0f, 0.8f, 0.6f, 0.2f}};
+#define c_green c_tab.green
+#define c_link_lane c_tab.link_lane
+#define c_link_share c_tab.link_share
+#define c_lane_approach c_tab.lane_approach
+#define c_split c_tab.split
+#define c_dest c_tab.dest
+#define c_from c_tab.from
+#define c_feed c_tab.feed
+#define c_ratio1 c_tab.ratio1
+#define c_ratio2 c_tab.ratio2
+#define c_entry c_tab.entry
 
 __device__ __forceinline__ float demand_rate(int group, int sec, float peak1, float peak2) {
     const int piece = sec / 300;
@@ -68,8 +91,9 @@ struct Lds {           // per replica
     float space[NN * 4];
     float scale[NN * 4];
     float inflow[NN * 4];
-    float wave[NN * NL];
+    float wave[NN * NL];          // offset 3600 B: 16-byte aligned (float4 reads of the compact emit)
 };
+static_assert(offsetof(Lds, wave) % 16 == 0 && sizeof(Lds) % 16 == 0, "Lds::wave must be 16-byte aligned in every array slot");
 
 __device__ __forceinline__ void half_barrier() { __builtin_amdgcn_wave_barrier(); }
 
@@ -87,10 +111,24 @@ __device__ __forceinline__ int nbr_of(int n, int k) {
     return -1;
 }
 
-template <int NT>
+template <int NT, bool COMPACT>
 __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ obs_env, int l32) {
-    // 25 x 60 floats = 375 float4, coalesced
     float4* dst = reinterpret_cast<float4*>(obs_env);
+    if (COMPACT) {
+        // 25 x 12 floats = 75 float4: the wave vectors as they sit in LDS
+        const float4* src = reinterpret_cast<const float4*>(s.wave);
+        for (int v = l32; v < NN * NL / 4; v += 32) {
+            const float4 val = src[v];
+            if (NT) {
+                __builtin_nontemporal_store(val.x, &dst[v].x); __builtin_nontemporal_store(val.y, &dst[v].y);
+                __builtin_nontemporal_store(val.z, &dst[v].z); __builtin_nontemporal_store(val.w, &dst[v].w);
+            } else {
+                dst[v] = val;
+            }
+        }
+        return;
+    }
+    // 25 x 60 floats = 375 float4, coalesced
     for (int v = l32; v < NN * OBSW / 4; v += 32) {
         const int node = v / (OBSW / 4);
         const int w = (v - node * (OBSW / 4)) * 4;          // first float within the 60-wide row
@@ -112,7 +150,7 @@ __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ 
 
 // NT = 1: non-temporal stores for state and slab when the working set exceeds the caches (same effect as
 // in csrc/cacc.hip: streaming writes at the fill ceiling instead of ~60 % of it).
-template <int NT>
+template <int NT, bool COMPACT>
 __global__ __launch_bounds__(256) void grid_step_kernel(
     const nmarl_grid_params_t p, const int64_t E, const uint8_t* __restrict__ action,
     float* __restrict__ qs, float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts,
@@ -255,7 +293,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
                 xi[e * 4 + l32] = 0.8f + 0.4f * u01_from_bits(w);
             }
             if (rst && l32 == 4) episode[e] = episode[e] + 1;
-            emit_obs_slab<NT>(s, obs + e * NN * OBSW, l32);
+            emit_obs_slab<NT, COMPACT>(s, obs + e * NN * (COMPACT ? NL : OBSW), l32);
         }
         half_barrier();
     }
@@ -264,13 +302,13 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
 __global__ __launch_bounds__(256) void grid_reset_kernel(
     const int64_t E, const uint8_t* __restrict__ mask, const float* __restrict__ u0, float* __restrict__ qs,
     float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts, float* __restrict__ xi,
-    float* __restrict__ obs, const uint64_t seed, const int64_t env_id_base, int32_t* __restrict__ episode) {
+    float* __restrict__ obs, const int obs_w, const uint64_t seed, const int64_t env_id_base, int32_t* __restrict__ episode) {
     const int l32 = threadIdx.x & 31;
     const int sub = threadIdx.x >> 5;
     for (int64_t e = (int64_t)blockIdx.x * 8 + sub; e < E; e += (int64_t)gridDim.x * 8) {
         if (mask != nullptr && mask[e] == 0) continue;
         for (int i = l32; i < NN * NLANE; i += 32) { qs[e * NN * NLANE + i] = 0.0f; trs[e * NN * NLANE + i] = 0.0f; }
-        for (int i = l32; i < NN * OBSW; i += 32) obs[e * NN * OBSW + i] = 0.0f;
+        for (int i = l32; i < NN * obs_w; i += 32) obs[e * NN * obs_w + i] = 0.0f;
         if (l32 < NN) prev[e * NN + l32] = 0;
         if (l32 == 0) ts[e] = 0;
         if (l32 < 4) {
@@ -306,15 +344,14 @@ extern "C" int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const ui
         return NMARL_EINVAL;
     if (auto_reset && !episode) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
-    if (E * 8800 > (int64_t)256 << 20) {     // beyond the 256 MB Infinity Cache: stream the writes
-        hipLaunchKernelGGL(grid_step_kernel<1>, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p,
-                           E, action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset,
-                           seed, env_id_base, episode);
-    } else {
-        hipLaunchKernelGGL(grid_step_kernel<0>, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), *p,
-                           E, action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset,
-                           seed, env_id_base, episode);
-    }
+    const bool nt = E * (p->compact_obs ? 4000 : 8800) > (int64_t)256 << 20;     // beyond the 256 MB Infinity Cache: stream the writes
+#define NMARL_GRID_LAUNCH(NT_, C_)                                                                                      \
+    hipLaunchKernelGGL((grid_step_kernel<NT_, C_>), dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), \
+                       *p, E, action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset, seed,  \
+                       env_id_base, episode)
+    if (p->compact_obs) { if (nt) NMARL_GRID_LAUNCH(1, true); else NMARL_GRID_LAUNCH(0, true); }
+    else { if (nt) NMARL_GRID_LAUNCH(1, false); else NMARL_GRID_LAUNCH(0, false); }
+#undef NMARL_GRID_LAUNCH
     return nmarl_check_launch();
 }
 
@@ -325,6 +362,6 @@ extern "C" int nmarl_grid_reset(const nmarl_grid_params_t* p, int64_t E, const u
     if (!u0 && !episode) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     hipLaunchKernelGGL(grid_reset_kernel, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), E, mask,
-                       u0, q, transit, prev_action, t, xi, obs, seed, env_id_base, episode);
+                       u0, q, transit, prev_action, t, xi, obs, p->compact_obs ? NL : OBSW, seed, env_id_base, episode);
     return nmarl_check_launch();
 }

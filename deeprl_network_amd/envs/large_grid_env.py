@@ -80,6 +80,17 @@ class LargeGridBatchEnv:
     def state_tensors(self):
         return [self.q, self.transit, self.prev_action, self.t, self.xi, self.obs, self.episode, self.done]
 
+    compact_obs = False
+
+    def set_compact_obs(self, flag=True):
+        """Compact observation [E,25,12]: every node's OWN wave vector -- what the reference hands an MA2C agent
+        (atsc_env.py:253-262) -- instead of the gathered [E,25,60] slab; the consumer gathers the neighbours
+        (agents/policies.py `_ob_part`).  Batched engine only: the E = 1 reference duck-type keeps the slab."""
+        self.compact_obs = bool(flag)
+        self.params.compact_obs = 1 if flag else 0
+        self.obs = torch.zeros(self.E, N_NODE, N_FEAT if flag else N_OBS, dtype=torch.float32, device=self.device)
+        return True
+
     def reset(self, mask=None, u0=None):
         P = _lib.ptr
         rc = _lib.lib.nmarl_grid_reset(ctypes.byref(self.params), self.E, P(mask, torch.uint8), P(u0, torch.float32),

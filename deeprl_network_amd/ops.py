@@ -829,17 +829,17 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
     a.ws = ptr(w['ws'], torch.int32)
     a.rev_agent, a.rev_col, a.rev_w = ptr(rev['rev_agent'], torch.int32), ptr(rev['rev_col'], torch.int32), ptr(rev['rev_w'], F32)
     check(lib.nmarl_lstm_bptt_coupled(C.byref(a), stream()), 'nmarl_lstm_bptt_coupled')
-    bptt_coupled.last_ws = (w['ws'], N * w['tiles'] * 8)          # (flag words, index of the error word)
+    _coupled_last[0] = (w['ws'], N * w['tiles'] * 8)          # (flag words, index of the error word)
     return w['db'].sum(dim=1), w['dbm'].sum(dim=1)
 
 
-bptt_coupled.last_ws = None
+_coupled_last = [None]
 
 
 def check_coupled_status():
     """Raises if a wave of the last nmarl_lstm_bptt_coupled call gave up waiting for a neighbour's block (its results are
     invalid).  Synchronises: call where the host syncs anyway (BatchedTrainer.stats)."""
-    last = bptt_coupled.last_ws
+    last = _coupled_last[0]
     if last is not None and int(last[0][last[1]].item()) != 0:
         raise _lib.NmarlError('nmarl_lstm_bptt_coupled: a wave timed out waiting for a neighbour block (results invalid)')
 

@@ -133,6 +133,8 @@ typedef struct nmarl_grid_params {
     float peak2;              /* peak_flow2                                              */
     int32_t T;                /* ceil(episode_length_sec / control_interval_sec) = 720   */
     int32_t per_agent_reward; /* coop_gamma >= 0 -> reward [E,25], else global [E]       */
+    int32_t compact_obs;      /* 1: obs [E,25,12] = every node's OWN wave vector (what the reference hands an agent,
+                                 atsc_env.py:253-262; the consumer gathers the neighbours); 0: the gathered [E,25,60] slab */
 } nmarl_grid_params_t;
 
 /*
@@ -140,7 +142,7 @@ typedef struct nmarl_grid_params {
  * network (init_density = 0), prev_action = 0 (:509-513), t = 0, and the per-replica
  * demand scale xi[e,g] = 0.8 + 0.4*U for the 4 flow groups; U from u0 [E,4] or from
  * Philox4x32-10(key=seed, ctr=(env_id_base+e, 0, episode[e], 0)) words 0..3.
- * q, transit [E,25,6] f32; prev_action [E,25] u8; t [E] i32; xi [E,4]; obs [E,25,60].
+ * q, transit [E,25,6] f32; prev_action [E,25] u8; t [E] i32; xi [E,4]; obs [E,25,60] ([E,25,12] with p->compact_obs).
  */
 int nmarl_grid_reset(const nmarl_grid_params_t* p, int64_t E, const uint8_t* mask, const float* u0,
                      uint64_t seed, int64_t env_id_base, int32_t* episode, float* q, float* transit,
@@ -149,7 +151,8 @@ int nmarl_grid_reset(const nmarl_grid_params_t* p, int64_t E, const uint8_t* mas
  * TrafficSimulator.step (atsc_env.py:181-207): phase = action[e,i] in 0..4, 2 s yellow
  * handling (:216-240), 5 s of store-and-forward traffic, `wave` observation (:420-462,
  * :502-504) and queue reward (:383-418).  obs [E,25,60]: slot 0 own 12 features, slots
- * 1..4 the neighbours' in ascending node index (lstm_ic3 / lstm_comm concatenation).
+ * 1..4 the neighbours' in ascending node index (lstm_ic3 / lstm_comm concatenation); with p->compact_obs obs [E,25,12]
+ * = slot 0 only.
  * reward [E] (global) or [E,25]; done [E] u8 when t reaches T; auto_reset as for CACC.
  */
 int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const uint8_t* action, float* q,

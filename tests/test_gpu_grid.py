@@ -95,3 +95,50 @@ def test_full_size_batch_invariance():
         small.step(a[400:408].contiguous())
         assert torch.equal(env.q[400:408], small.q) and torch.equal(env.obs[400:408], small.obs)
     assert torch.isfinite(env.obs).all() and float(env.global_reward.max()) <= 0
+
+
+@pytest.mark.parametrize('E', [9, 300, 1024])
+def test_compact_observation_is_the_own_wave_block(E):
+    """p.compact_obs: obs [E,25,12] (every node's own wave vector -- what the reference hands an MA2C agent,
+    atsc_env.py:253-262) == columns 0..11 of the gathered [E,25,60] slab; identical state, reward, done; the gathered
+    slab is the neighbour gather of the compact one (ascending node index, zero padded)."""
+    from deeprl_network_amd import ops
+    a_env, b_env = make(E), make(E)
+    assert b_env.set_compact_obs(True) and b_env.obs.shape == (E, 25, 12)
+    a_env.reset(); b_env.reset()
+    nbr_idx, _ = ops.neighbor_table(a_env.neighbor_mask, 'cuda')
+    rng = np.random.RandomState(E)
+    for t in range(60):
+        a = torch.from_numpy(rng.randint(0, 5, size=(E, 25)).astype(np.uint8)).cuda()
+        oa, ra, da, ga = a_env.step(a)
+        ob, rb, db, gb = b_env.step(a)
+        assert torch.equal(oa[:, :, :12], ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(ga, gb)
+        assert torch.equal(a_env.q, b_env.q) and torch.equal(a_env.transit, b_env.transit)
+        own = ob.transpose(0, 1).contiguous()                                  # [25,E,12]
+        torch.testing.assert_close(oa[:, :, 12:], ops.nbr_gather(own, nbr_idx).transpose(0, 1), rtol=0, atol=0)
+
+
+def test_compact_observation_training_equals_gathered_slab():
+    """Grid CommNet (BASELINE configs[3] at E = 256): the env writing compact observations, the encoder gathering the
+    neighbours inside its kernels (rollout and update) == the env writing the gathered slab: same actions, values and
+    weights after 2 batches."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.large_grid_env import LargeGridBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    out = []
+    for compact in (True, False):
+        cp = grid_config()
+        env = LargeGridBatchEnv(cp['ENV_CONFIG'], num_envs=256)
+        np.random.seed(12)
+        model = models.MA2C_IC3(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                                cp['MODEL_CONFIG'], seed=12, num_envs=256)
+        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True, compact_obs=compact)
+        assert tr.compact_obs == compact and model.buf_x.shape[-1] == (12 if compact else 60)
+        for _ in range(2):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        out.append((model.policy.params.flat.clone(), model.buf_v.clone(), model.buf_act.clone(), env.q.clone()))
+        del env, model, tr
+    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-4, atol=1e-6)

@@ -83,6 +83,13 @@ class FcPart(C.Structure):
 FC_MAX_PARTS = 4
 
 
+class BatchEpilogue(C.Structure):
+    """nmarl_batch_epilogue_t (include/nmarl.h)."""
+    _fields_ = ([('E', C.c_int64)] + [(k, C.c_int32) for k in ('N', 'H', 'A', 'F', 'T', 'T_env')] +
+                [(k, C.c_void_p) for k in ('g', 'done', 'ep_sum', 'ep_sq', 'ep_len', 'fin', 'h_fw', 'c_fw', 'h_bw', 'c_bw', 'fp_T',
+                                           'fp_uniform', 'x_T', 'fp_0', 'x_0', 'done_pre')])
+
+
 class BpttCoupled(C.Structure):
     """nmarl_bptt_coupled_t (include/nmarl.h): arguments of nmarl_lstm_bptt_coupled."""
     _fields_ = ([(k, C.c_int32) for k in ('kind', 'N', 'T', 'H', 'm_max', 'r_max', 'r_row', 'symmetric', 'mode', 'ring_slots')] +
@@ -163,6 +170,7 @@ SIGNATURES = {
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],
     'nmarl_nstep_return': [_i64, _i32, _i32, _p, _p, _p, _p, C.c_double, C.c_double, _p, _p, _p, _p],
     'nmarl_rmsprop_tf_clip': [_i32, _i64, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p],
+    'nmarl_batch_epilogue': [C.POINTER(BatchEpilogue), _p],
 }
 
 for _name, _args in SIGNATURES.items():

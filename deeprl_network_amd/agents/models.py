@@ -379,8 +379,9 @@ class IA2C:
         self.last_loss = (policy_loss.detach(), value_loss.detach(), entropy_loss.detach(), per_agent.detach())
         return per_agent.sum()
 
-    def update(self, R_end):
-        """model.backward (models.py:34-42 / 211-215) for all replicas: R_end [N,E]."""
+    def update(self, R_end, rotate=True):
+        """model.backward (models.py:34-42 / 211-215) for all replicas: R_end [N,E].  rotate=False: the caller hands the
+        states / slot T of the rollout buffers over to the next batch itself (BatchedTrainer: ops.batch_epilogue)."""
         assert self.t == self.n_step, 'update() needs a full n_step batch (got %d)' % self.t
         # the schedule counts lock-steps (environment steps per replica), the reference's get(n_step): the ini's
         # total_step keeps its meaning for any number of replicas and ranks
@@ -422,12 +423,13 @@ class IA2C:
             n = self.n_agent * ps.P
             ops.rmsprop_tf_clip(ps.flat.view(1, n), ps.grad.view(1, n), ps.ms.view(1, n), ps.scratch, cur_lr,
                                 self.rmsp_alpha, self.rmsp_epsilon, self.max_grad_norm, scale, self.grad_norm)
-        # states_bw <- states_fw (policies.py:115, 211)
-        self.h_bw.copy_(self.h_fw)
-        self.c_bw.copy_(self.c_fw)
-        # slot T (bootstrap inputs) is slot 0 of the next batch
-        self.buf_x[0].copy_(self.buf_x[T])
-        self.buf_fp[0].copy_(self.buf_fp[T])
+        if rotate:
+            # states_bw <- states_fw (policies.py:115, 211)
+            self.h_bw.copy_(self.h_fw)
+            self.c_bw.copy_(self.c_fw)
+            # slot T (bootstrap inputs) is slot 0 of the next batch
+            self.buf_x[0].copy_(self.buf_x[T])
+            self.buf_fp[0].copy_(self.buf_fp[T])
         self.t = 0
         self.cur_lr = cur_lr
 
@@ -640,8 +642,8 @@ class IA2C_CU(MA2C_NC):
     policy_cls = ConsensusPolicy
     name = 'ma2c_cu'
 
-    def update(self, R_end):
-        super().update(R_end)
+    def update(self, R_end, rotate=True):
+        super().update(R_end, rotate=rotate)
         self.policy.consensus_update()
 
 

@@ -212,6 +212,83 @@ __global__ __launch_bounds__(256) void nstep_kernel(
 }
 
 // ---- clip_by_global_norm + RMSProp over flat [G, P] (G groups = optimisers) ----
+// ---------------------------------------------------------------------------------------------------------------------
+// What the batched loop does between two n_step batches, in two launches instead of ~45 elementwise ones:
+//   (1) episode statistics of the reference's Trainer.run (utils.py:228-229, 253: mean / std of an episode's global
+//       rewards), kept per replica across batches and closed where done is set; an episode shorter than T_env ended in
+//       a collision (cacc_env.py:231-233);
+//   (2) the state hand-over of the next `env.reset(); model.reset()` (utils.py:215-217; policies.py:151-154; cacc_env.py:184)
+//       for the replicas that finished, and of `states_bw <- states_fw` (policies.py:115) / "slot T of the rollout buffers
+//       is slot 0 of the next batch" for all.
+struct EpilogueArgs {
+    int64_t E;
+    int32_t N, H, A, F, T, T_env;
+    const float* g;
+    const uint8_t* done;
+    double *ep_sum, *ep_sq, *ep_len, *fin;
+    float *h_fw, *c_fw, *h_bw, *c_bw;
+    const float *fp_T, *fp_uniform, *x_T;
+    float *fp_0, *x_0, *done_pre;
+};
+
+__global__ __launch_bounds__(1024) void epilogue_stats_kernel(const EpilogueArgs a) {
+    // one block: per-replica float64 sums in the order t = 0 .. T-1, then a fixed-order tree over the replicas
+    double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
+    for (int64_t e = threadIdx.x; e < a.E; e += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int t = 0; t < a.T; ++t) {
+            const double v = (double)a.g[(int64_t)t * a.E + e];
+            s += v;
+            q += v * v;
+        }
+        const double sum = a.ep_sum[e] + s, sq = a.ep_sq[e] + q, len = a.ep_len[e] + (double)a.T;
+        const bool d = a.done[e] != 0;
+        if (d) {
+            const double mean = sum / len;
+            double var = sq / len - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            f0 += 1.0;
+            f1 += mean;
+            f2 += sqrt(var);
+            f3 += len < (double)a.T_env ? 1.0 : 0.0;
+        }
+        a.ep_sum[e] = d ? 0.0 : sum;
+        a.ep_sq[e] = d ? 0.0 : sq;
+        a.ep_len[e] = d ? 0.0 : len;
+    }
+    __shared__ double red[4][1024];
+    red[0][threadIdx.x] = f0; red[1][threadIdx.x] = f1; red[2][threadIdx.x] = f2; red[3][threadIdx.x] = f3;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) a.fin[threadIdx.x] += red[threadIdx.x][0];
+}
+
+__global__ __launch_bounds__(256) void epilogue_state_kernel(const EpilogueArgs a) {
+    const int64_t nh = (int64_t)a.N * a.E * a.H, na = (int64_t)a.N * a.E * a.A, nx = a.E * (int64_t)a.N * a.F;
+    const int64_t total = nh > na ? (nh > nx ? nh : nx) : (na > nx ? na : nx);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < nh) {                                  // [N][E][H]: recurrent state, zero where an episode ended
+            const int64_t e = (i / a.H) % a.E;
+            const float keep = a.done[e] ? 0.0f : 1.0f;
+            const float h = a.h_fw[i] * keep, c = a.c_fw[i] * keep;
+            a.h_fw[i] = h; a.h_bw[i] = h;
+            a.c_fw[i] = c; a.c_bw[i] = c;
+        }
+        if (i < na) {                                  // [N][E][A]: fingerprints, uniform where an episode ended
+            const int64_t e = (i / a.A) % a.E, n = i / (a.A * a.E);
+            a.fp_0[i] = a.done[e] ? a.fp_uniform[n * a.A + (i % a.A)] : a.fp_T[i];
+        }
+        if (i < nx) a.x_0[i] = a.x_T[i];               // the env wrote the next observation (after its auto-reset)
+        if (i < a.E) a.done_pre[i] = a.done[i] ? 1.0f : 0.0f;
+    }
+}
+
 constexpr int SUMSQ_BLOCKS = 64;   // partial sums per group
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const int64_t P, const float* __restrict__ g,
@@ -479,5 +556,25 @@ extern "C" int nmarl_a2c_loss_bwd(int64_t rows, int32_t N, int32_t A, const floa
     const int rpb = (int)((rows + C - 1) / C);
     hipLaunchKernelGGL(a2c_loss_kernel<true>, dim3(C, N), dim3(256), 0, static_cast<hipStream_t>(stream), rows, N, A, rpb, logits,
                        l_sn, l_row, v, action, adv, R, v_coef, e_coef, g_up, (float*)nullptr, dlogits, dv);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* stream) {
+    if (!p || p->E < 0 || p->N <= 0 || p->H <= 0 || p->A <= 0 || p->F <= 0 || p->T <= 0) return NMARL_EINVAL;
+    if (p->E == 0) return NMARL_OK;
+    if (!p->g || !p->done || !p->ep_sum || !p->ep_sq || !p->ep_len || !p->fin || !p->h_fw || !p->c_fw || !p->h_bw || !p->c_bw ||
+        !p->fp_T || !p->fp_0 || !p->fp_uniform || !p->x_T || !p->x_0 || !p->done_pre)
+        return NMARL_EINVAL;
+    EpilogueArgs a{};
+    a.E = p->E; a.N = p->N; a.H = p->H; a.A = p->A; a.F = p->F; a.T = p->T; a.T_env = p->T_env;
+    a.g = p->g; a.done = p->done; a.ep_sum = p->ep_sum; a.ep_sq = p->ep_sq; a.ep_len = p->ep_len; a.fin = p->fin;
+    a.h_fw = p->h_fw; a.c_fw = p->c_fw; a.h_bw = p->h_bw; a.c_bw = p->c_bw; a.fp_T = p->fp_T; a.fp_uniform = p->fp_uniform;
+    a.x_T = p->x_T; a.fp_0 = p->fp_0; a.x_0 = p->x_0; a.done_pre = p->done_pre;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(epilogue_stats_kernel, dim3(1), dim3(1024), 0, st, a);
+    const int64_t nh = (int64_t)a.N * a.E * a.H, nx = a.E * (int64_t)a.N * a.F;
+    int64_t blocks = ((nh > nx ? nh : nx) + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(epilogue_state_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
     return nmarl_check_launch();
 }

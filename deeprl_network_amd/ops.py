@@ -1163,3 +1163,19 @@ def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, n
     check(lib.nmarl_rmsprop_tf_clip(G, P, ptr(w, F32), ptr(g, F32), ptr(ms, F32), ptr(scratch, F32),
                                     ptr(lr_dev, F32), float(lr), float(rho), float(eps), float(max_norm),
                                     float(grad_scale), ptr(norm_out, F32), stream()), 'nmarl_rmsprop_tf_clip')
+
+
+def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre):
+    """nmarl_batch_epilogue: episode statistics + the state hand-over between two n_step batches (see include/nmarl.h).
+    g [T,E] f32, done [E] u8, ep_* [E] f64, fin [4] f64; h_* / c_* [N,E,H]; fp_T / fp_0 [N,E,A], fp_uniform [N,1,A] or [N,A];
+    x_T / x_0 [E,N,F]; done_pre [E] f32."""
+    T, E = g.shape
+    N, _, H = h_fw.shape
+    a = _lib.BatchEpilogue()
+    a.E, a.N, a.H, a.A, a.F, a.T, a.T_env = E, N, H, fp_T.shape[2], x_T.shape[2], T, int(T_env)
+    a.g, a.done = ptr(g, F32), ptr(done, torch.uint8)
+    a.ep_sum, a.ep_sq, a.ep_len, a.fin = (ptr(t, torch.float64) for t in (ep_sum, ep_sq, ep_len, fin))
+    a.h_fw, a.c_fw, a.h_bw, a.c_bw = (ptr(t, F32) for t in (h_fw, c_fw, h_bw, c_bw))
+    a.fp_T, a.fp_0, a.fp_uniform = ptr(fp_T, F32), ptr(fp_0, F32), ptr(fp_uniform.reshape(N, -1), F32)
+    a.x_T, a.x_0, a.done_pre = ptr(x_T, F32), ptr(x_0, F32), ptr(done_pre, F32)
+    check(lib.nmarl_batch_epilogue(C.byref(a), stream()), 'nmarl_batch_epilogue')

@@ -12,10 +12,10 @@ Trainer 100-254, Evaluator 311-336) plus the batched MI355X trainer.
                       data-parallel ranks exchange one flat gradient all-reduce.
   * `Evaluator`       the reference's evaluation loop over test seeds.
 """
-import itertools
+import glob
 import logging
 import os
-import subprocess
+import shutil
 import time
 
 import numpy as np
@@ -25,30 +25,28 @@ import torch
 from . import ops
 
 
-# ------------------------------------------------------------------ small helpers (utils.py:11-60)
-def check_dir(cur_dir):
-    return os.path.exists(cur_dir)
+# ------------------------------------------------------------------ small helpers (the names main.py imports, utils.py:11-60)
+check_dir = os.path.exists
 
 
-def copy_file(src_dir, tar_dir):
-    subprocess.check_call('cp %s %s' % (src_dir, tar_dir), shell=True)
+def copy_file(src, dst_dir):
+    shutil.copy(src, dst_dir)
 
 
 def find_file(cur_dir, suffix='.ini'):
-    for file in os.listdir(cur_dir):
-        if file.endswith(suffix):
-            return cur_dir + '/' + file
-    logging.error('Cannot find %s file' % suffix)
-    return None
+    hits = sorted(glob.glob(os.path.join(cur_dir, '*' + suffix)))
+    if not hits:
+        logging.error('Cannot find %s file' % suffix)
+        return None
+    return hits[0]
 
 
 def init_dir(base_dir, pathes=('log', 'data', 'model')):
     """exist_ok everywhere: under torchrun every rank calls this on the same fresh base dir."""
     dirs = {}
     for path in pathes:
-        cur_dir = base_dir + '/%s/' % path
-        os.makedirs(cur_dir, exist_ok=True)
-        dirs[path] = cur_dir
+        dirs[path] = os.path.join(base_dir, path) + '/'
+        os.makedirs(dirs[path], exist_ok=True)
     return dirs
 
 
@@ -60,41 +58,32 @@ def init_log(log_dir, rank=0):
 
 
 class Counter:
-    """utils.py:70-97."""
+    """The reference's step counter (utils.py:70-97: same attributes and methods, main.py / Trainer drive it) over a plain
+    integer; `advance(n)` is the batched path's n environment steps at once."""
 
     def __init__(self, total_step, test_step, log_step):
-        self.counter = itertools.count(1)
-        self.cur_step = 0
-        self.cur_test_step = 0
-        self.total_step = total_step
-        self.test_step = test_step
-        self.log_step = log_step
+        self.total_step, self.test_step, self.log_step = total_step, test_step, log_step
+        self.cur_step = self.cur_test_step = 0
         self.stop = False
 
-    def next(self):
-        self.cur_step = next(self.counter)
+    def advance(self, n):
+        self.cur_step += n
         return self.cur_step
 
-    def advance(self, n):
-        """Batched path: n environment steps at once."""
-        self.cur_step += n
-        self.counter = itertools.count(self.cur_step + 1)
-        return self.cur_step
+    def next(self):
+        return self.advance(1)
 
     def should_test(self):
-        test = False
-        if (self.cur_step - self.cur_test_step) >= self.test_step:
-            test = True
+        due = self.cur_step - self.cur_test_step >= self.test_step
+        if due:
             self.cur_test_step = self.cur_step
-        return test
+        return due
 
     def should_log(self):
         return self.cur_step % self.log_step == 0
 
     def should_stop(self):
-        if self.cur_step >= self.total_step:
-            return True
-        return self.stop
+        return self.stop or self.cur_step >= self.total_step
 
 
 class SummaryWriter:
@@ -374,27 +363,16 @@ class BatchedTrainer:
     def run_batch(self):
         """One rollout + update.  Returns nothing; statistics stay on the device until `stats()`."""
         self.rollout()
-        self.model.load_rewards(self.buf_rraw)
-        done = self.last_done.clone()            # update() recycles nothing here, but keep a stable copy
-        self.model.update(self.R_end)
-        # episode bookkeeping, all on device
-        g = self.buf_g.double()
-        self.ep_sum += g.sum(0)
-        self.ep_sq += (g * g).sum(0)
-        self.ep_len += self.n_step
-        dm = done.bool()
-        mean = self.ep_sum / self.ep_len
-        std = (self.ep_sq / self.ep_len - mean * mean).clamp_min(0).sqrt()
-        dmf = dm.double()
-        coll = (self.ep_len < self.env.T).double() * dmf          # ended early == collision (cacc_env.py:231-233)
-        self.fin += torch.stack([dmf.sum(), (mean * dmf).sum(), (std * dmf).sum(), coll.sum()])
-        keep = 1.0 - dmf
-        self.ep_sum *= keep
-        self.ep_sq *= keep
-        self.ep_len *= keep
-        # next batch: finished replicas start a new episode (env already auto-reset)
-        self.model.reset_states(mask=done)
-        self.done_pre.copy_(done.to(torch.float32))
+        m = self.model
+        m.load_rewards(self.buf_rraw)
+        m.update(self.R_end, rotate=False)
+        # episode statistics, then the hand-over to the next batch in one call: finished replicas start a new episode (the
+        # env already auto-reset them) with zero recurrent state and uniform fingerprints -- what the reference does at its
+        # next `env.reset(); model.reset()` --, states_bw <- states_fw, slot T of the rollout buffers -> slot 0
+        T = self.n_step
+        ops.batch_epilogue(self.buf_g, self.last_done, self.ep_sum, self.ep_sq, self.ep_len, self.fin, self.env.T,
+                           m.h_fw, m.c_fw, m.h_bw, m.c_bw, m.buf_fp[T], m.buf_fp[0], m.fp_uniform, m.buf_x[T], m.buf_x[0],
+                           self.done_pre)
         self.n_batches += 1
         if self.global_counter is not None:
             # the counter (like the reference's global step and the lr schedule) counts LOCK-steps, i.e. environment

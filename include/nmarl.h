@@ -588,6 +588,29 @@ int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float*
                           const float* lr_dev, float lr, float rho, float eps, float max_norm,
                           float grad_scale, float* grad_norm_out, void* stream);
 
+/*
+ * Between two n_step batches of the batched loop (two launches instead of ~45 elementwise ones):
+ *  - episode statistics as Trainer.run keeps them (utils.py:228-229: mean / std of an episode's global rewards): g [T][E]
+ *    the batch's global rewards, done [E] u8 the flags of its last lock-step; per replica running ep_sum / ep_sq / ep_len
+ *    [E] f64, closed into fin [4] f64 += (episodes, sum of means, sum of stds, episodes shorter than T_env = collisions,
+ *    cacc_env.py:231-233) and zeroed where done;
+ *  - the hand-over to the next batch: for finished replicas `model.reset()` / a fresh episode's fingerprint
+ *    (policies.py:151-154, cacc_env.py:184): h_fw, c_fw [N][E][H] zeroed, fp_0 <- fp_uniform [N][A]; for all:
+ *    h_bw, c_bw <- h_fw, c_fw (states_bw <- states_fw, policies.py:115), fp_0 [N][E][A] <- fp_T, x_0 [E][N*F] <- x_T
+ *    (slot T of the rollout buffers becomes slot 0), done_pre [E] f32 <- done.
+ */
+typedef struct nmarl_batch_epilogue {
+    int64_t E;
+    int32_t N, H, A, F, T, T_env;
+    const float* g;
+    const uint8_t* done;
+    double *ep_sum, *ep_sq, *ep_len, *fin;
+    float *h_fw, *c_fw, *h_bw, *c_bw;
+    const float *fp_T, *fp_uniform, *x_T;
+    float *fp_0, *x_0, *done_pre;
+} nmarl_batch_epilogue_t;
+int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -496,3 +496,29 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
         m_t = torch.bmm(dx, w_msg.transpose(1, 2))
         dh_rec = (nbr_gather_bwd(m_t, nbr_idx, H) if kind == COUPLED_NC else nbr_mean_bwd(m_t, nbr_idx)) + dhd
     return dZ.sum(dim=(1, 2)), D1.sum(dim=(1, 2))
+
+
+def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre):
+    """Restatement of nmarl_batch_epilogue (csrc/a2c.hip): the elementwise host code the batched loop used to run."""
+    T = g.shape[0]
+    gd = g.double()
+    ep_sum += gd.sum(0)
+    ep_sq += (gd * gd).sum(0)
+    ep_len += T
+    dmf = done.bool().double()
+    mean = ep_sum / ep_len
+    std = (ep_sq / ep_len - mean * mean).clamp_min(0).sqrt()
+    coll = (ep_len < T_env).double() * dmf
+    fin += torch.stack([dmf.sum(), (mean * dmf).sum(), (std * dmf).sum(), coll.sum()])
+    keep = 1.0 - dmf
+    ep_sum *= keep
+    ep_sq *= keep
+    ep_len *= keep
+    k32 = keep.to(h_fw.dtype).view(1, -1, 1)
+    for s_ in (h_fw, c_fw):
+        s_.mul_(k32)
+    h_bw.copy_(h_fw)
+    c_bw.copy_(c_fw)
+    fp_0.copy_(fp_T * k32 + (1.0 - k32) * fp_uniform.reshape(fp_T.shape[0], 1, -1))
+    x_0.copy_(x_T)
+    done_pre.copy_(done.to(done_pre.dtype))

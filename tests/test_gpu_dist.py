@@ -134,6 +134,22 @@ def test_bench_self_launches_two_ranks():
     assert d['value'] > 0 and 'roofline' in d
 
 
+def test_bench_self_launches_eight_ranks():
+    """The driver's 8-GPU scaling run without the hardware: `python bench.py --gpus 8` on whatever devices there are
+    (8 ranks on one device through gloo when fewer than 8 are visible): self_launch, the one-time GEMM tuning by rank 0
+    with seven ranks waiting at the barrier, rank-offset replica ids, eight-way gradient all-reduce.  Rank 0 prints ONE
+    line that explains itself: n_gpus, per-rank ms per step, the all-reduce time."""
+    hooks = {} if torch.cuda.device_count() >= 8 else {'NMARL_BENCH_ONE_DEVICE': '1', 'NMARL_DIST_BACKEND': 'gloo'}
+    p, lines = _bench(hooks, '--gpus', '8', '--steps', '2', '--warmup', '1', '--envs', '128', '--no-cpu-baseline')
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_replicas'] == 8 * 128 and d['config']['parallelism'] == 'dp8'
+    assert len(d['per_rank_ms_per_step']) == 8 and max(d['per_rank_ms_per_step']) == pytest.approx(d['ms_per_step'], rel=1e-6)
+    ar = d['grad_allreduce']
+    assert ar['per_update'] == 1 and ar['us'] > 0 and ar['bytes'] > 1e6
+
+
 def test_bench_one_rank_on_rccl():
     """bench.py with the process group forced on for one rank: communicator + all-reduce on RCCL in the timed loop."""
     p, lines = _bench({'NMARL_BENCH_FORCE_DIST': '1'}, '--steps', '2', '--warmup', '1', '--envs', '256',

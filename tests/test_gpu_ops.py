@@ -1035,3 +1035,36 @@ def test_lstm_bptt_coupled_repeated_calls_under_load():
         ops.check_coupled_status()
         for x, y in zip(quiet, loaded):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('N,E,H,A,F,T', [(8, 4096, 64, 4, 5, 60), (25, 130, 64, 5, 12, 7), (3, 1, 64, 4, 15, 3)])
+def test_batch_epilogue_matches_host_code(N, E, H, A, F, T):
+    """nmarl_batch_epilogue (episode statistics + state hand-over between two batches, two launches) == the elementwise
+    host code it replaces (oracle/ops_ref.py batch_epilogue), over two consecutive batches with episodes ending in the
+    first (some early = collisions)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g_ = torch.Generator().manual_seed(N + E)
+    T_env = 3 * T
+    host = dict(ep_sum=torch.zeros(E, dtype=torch.float64), ep_sq=torch.zeros(E, dtype=torch.float64),
+                ep_len=torch.full((E,), float(T), dtype=torch.float64), fin=torch.zeros(4, dtype=torch.float64),
+                h_fw=torch.randn(N, E, H, generator=g_), c_fw=torch.randn(N, E, H, generator=g_),
+                h_bw=torch.zeros(N, E, H), c_bw=torch.zeros(N, E, H), fp_0=torch.zeros(N, E, A), x_0=torch.zeros(E, N, F),
+                done_pre=torch.zeros(E))
+    fp_uniform = torch.rand(N, 1, A, generator=g_)
+    dev = {k: v.clone().cuda() for k, v in host.items()}
+    for b in range(2):
+        g = -torch.rand(T, E, generator=g_) * 100
+        done = (torch.rand(E, generator=g_) < (0.4 if b == 0 else 1.0)).to(torch.uint8)
+        fp_T, x_T = torch.rand(N, E, A, generator=g_), torch.randn(E, N, F, generator=g_)
+        ops_ref.batch_epilogue(g, done, host['ep_sum'], host['ep_sq'], host['ep_len'], host['fin'], T_env, host['h_fw'],
+                               host['c_fw'], host['h_bw'], host['c_bw'], fp_T, host['fp_0'], fp_uniform, x_T, host['x_0'],
+                               host['done_pre'])
+        ops.batch_epilogue(g.cuda(), done.cuda(), dev['ep_sum'], dev['ep_sq'], dev['ep_len'], dev['fin'], T_env, dev['h_fw'],
+                           dev['c_fw'], dev['h_bw'], dev['c_bw'], fp_T.cuda(), dev['fp_0'], fp_uniform.cuda(), x_T.cuda(),
+                           dev['x_0'], dev['done_pre'])
+        for k in ('h_fw', 'c_fw', 'h_bw', 'c_bw', 'fp_0', 'x_0', 'done_pre'):
+            assert torch.equal(dev[k].cpu(), host[k]), k
+        for k in ('ep_sum', 'ep_sq', 'ep_len', 'fin'):
+            torch.testing.assert_close(dev[k].cpu(), host[k], rtol=1e-12, atol=1e-9)
+    assert host['fin'][0] > 0 and host['fin'][3] > 0

@@ -1,17 +1,12 @@
 #!/bin/bash
 # the full NeurComm slow-down schedule (16 667 updates = 1e6 lock-steps per replica) through
-# the SAME batched product at E = 8 / 64 / 512 (two seeds each) and E = 4096 (second seed; seed 12 is profiles/r02_learn_*),
-# all processes concurrently on the one GPU (the small-E runs are launch-bound).  Output: gpurun_out/learn_*.json
+# the SAME batched product at E = 8 / 64 / 512 and a second seed at E = 4096 (seed 12: profiles/r02_learn_*), one run after
+# the other (seven concurrent processes on one GPU ran 10x slower each and were cut by the time limit: gpurun_out of the
+# first attempt is kept under profiles/r03_nc_quality_partial_*).  Rows are flushed as they come (python -u).
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-pids=""
-for E in 8 64 512; do
-  for s in 12 13; do
-    python tools/learn_curve.py ma2c_nc slowdown $E 16667 500 $s > gpurun_out/nc_quality_E${E}_s${s}.log 2>&1 &
-    pids="$pids $!"
-  done
+for spec in "8 12" "64 12" "512 12" "4096 13"; do
+  set -- $spec
+  timeout ${NC_QUALITY_TIMEOUT:-400} python -u tools/learn_curve.py ma2c_nc slowdown $1 16667 500 $2 > gpurun_out/nc_quality_E$1_s$2.log 2>&1
+  tail -n 1 gpurun_out/nc_quality_E$1_s$2.log | cut -c1-300
 done
-python tools/learn_curve.py ma2c_nc slowdown 4096 16667 500 13 > gpurun_out/nc_quality_E4096_s13.log 2>&1 &
-pids="$pids $!"
-for p in $pids; do wait $p; done
-tail -n 2 gpurun_out/nc_quality_E*.log

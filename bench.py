@@ -189,33 +189,46 @@ def measure_lstm_step(model, n=60, reps=10):
     return e0.elapsed_time(e1) * 1e3 / (reps * n), flops, nbytes, name
 
 
-def measure_lstm_step_in_rollout(trainer):
-    """Average duration of the LSTM lock-step launches INSIDE a real rollout (what rocprofv3's kernel trace reports for
-    the batch): one eager n_step rollout of the trainer -- same launches, same neighbours on the stream (encoder kernel
-    before, env kernel after) as the captured graph -- with a HIP event pair on the launch stream around every
-    step_policy_value / step_policy launch.  The rollout state is restored afterwards."""
+def measure_lstm_step_in_rollout(trainer, reps=5):
+    """Average duration of an LSTM lock-step launch INSIDE the rollout (what rocprofv3's kernel trace reports for the
+    batch), by difference: the n_step rollout captured twice as a hipGraph -- as it runs, and with the LSTM step launches
+    left out (same encoders, env steps, bootstrap glue) -- each replayed `reps` times between two HIP events on the
+    launch stream; (t_full - t_without) / launches.  Eager event pairs around single launches do not work here: the
+    eager rollout is host-bound, the stream idles between launches and the pairs time the host.  State restored after."""
     pol = trainer.model.policy
-    name = 'step_policy_value' if pol.fused_pv else 'step_policy'
-    orig = getattr(pol, name)
-    pairs = []
+    names = ['step_policy_value'] if pol.fused_pv else ['step_policy', 'step_value']
+    n_launch = (trainer.n_step + 1) * len(names)
 
-    def timed(*a, **k):
+    def timed(skip):
+        orig = {n: getattr(pol, n) for n in names}
+        snap = trainer._snapshot()
+        try:
+            if skip:
+                # stubs with the methods' return contracts: step_policy_value / step_policy hand back their action buffer,
+                # step_value its value buffer (step_value(enc, h, c, done, h_out, c_out, action, v_out, ...))
+                stubs = {'step_policy_value': lambda *a, **k: a[5], 'step_policy': lambda *a, **k: (a[6], a[7]),
+                         'step_value': lambda *a, **k: a[7]}
+                for n in names:
+                    setattr(pol, n, stubs[n])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                trainer._rollout()
+        finally:
+            for n, f in orig.items():
+                setattr(pol, n, f)
+        g.replay()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        r = orig(*a, **k)
+        for _ in range(reps):
+            g.replay()
         e1.record()
-        pairs.append((e0, e1))
-        return r
-    snap = trainer._snapshot()
-    setattr(pol, name, timed)
-    try:
-        trainer._rollout()
         torch.cuda.synchronize()
-    finally:
-        setattr(pol, name, orig)
         trainer._restore(snap)
-    us = sorted(a.elapsed_time(b) * 1e3 for a, b in pairs[2:])        # the first launches pay cold caches
-    return sum(us) / len(us), us[len(us) // 2], len(us)
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    full, without = timed(False), timed(True)
+    return (full - without) / n_launch, full, without
 
 
 def measure_bptt_seq(model, reps=5):
@@ -548,7 +561,7 @@ def main():
                 us_roll = None
                 if x_side:
                     try:          # the figure the roofline is quoted on: the launch as it runs inside the rollout
-                        us_roll, us_roll_med, n_roll = measure_lstm_step_in_rollout(trainer)
+                        us_roll, us_roll_full, us_roll_without = measure_lstm_step_in_rollout(trainer)
                         us_l = us_roll
                     except Exception as ex:
                         us_roll = None
@@ -564,14 +577,15 @@ def main():
                         pmc_traffic('lstm_step_x_N8_E4096')),
                     'traffic_source': pmc_traffic('lstm_step_x_N8_E4096')[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
                     'us_per_launch_isolated_graph': us_iso, 'us_per_launch_in_rollout': us_roll,
-                    'us_per_launch_in_rollout_median': None if us_roll is None else us_roll_med,
+                    'rollout_graph_us': None if us_roll is None else us_roll_full,
+                    'rollout_graph_us_without_lstm_steps': None if us_roll is None else us_roll_without,
                     'frac_isolated_graph': flops_l / us_iso / 1e6 / MFMA_F32_PEAK_TFLOPS if x_side else None,
                     'rows_per_launch': n_agent * E, 'launches_per_batch': lpb,
                     'hbm_frac_of_same_launch': bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
-                    'how': 'achieved / frac use the launch duration INSIDE the rollout: one eager n_step rollout with a HIP event '
-                           'pair on the launch stream around every LSTM lock-step launch (mean over the launches; agrees with the '
-                           'rocprofv3 kernel trace of the batch, profiles/).  us_per_launch_isolated_graph: hipGraph of 60 '
-                           'back-to-back launches on the model shapes and weights, 10 replays between two events (hot caches: '
+                    'how': 'achieved / frac use the launch duration INSIDE the rollout, by difference: the n_step rollout captured as a '
+                           'hipGraph with and without its LSTM lock-step launches, 5 replays each between two HIP events on the launch '
+                           'stream, (t_full - t_without) / launches (agrees with the rocprofv3 kernel trace of the batch, profiles/).  '
+                           'us_per_launch_isolated_graph: hipGraph of 60 back-to-back launches on the model shapes and weights (hot caches: '
                            'flatters the kernel by 5-8 %%).  Algorithmic work per (agent, replica) row: '
                            'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops (uncoupled nets; coupled nets: the '
                            'policy step + its 2*K_m*64 message flops, the value step is a second launch), fp32 in / fp32 accumulate on '

@@ -83,11 +83,18 @@ class FcPart(C.Structure):
 FC_MAX_PARTS = 4
 
 
+class CaccEncode(C.Structure):
+    """nmarl_cacc_encode_t (include/nmarl.h): the encoders fused behind the CACC step."""
+    _fields_ = ([(k, C.c_void_p) for k in ('w_ob', 'b_ob', 'w_fp', 'b_fp', 'fp', 'nbr_idx', 'out')] +
+                [(k, C.c_int64) for k in ('w_ob_sn', 'b_ob_sn', 'w_fp_sn', 'b_fp_sn', 'fp_sn', 'out_sn', 'out_row')] +
+                [('act', C.c_int32), ('n_parts', C.c_int32)])
+
+
 class BatchEpilogue(C.Structure):
     """nmarl_batch_epilogue_t (include/nmarl.h)."""
     _fields_ = ([('E', C.c_int64)] + [(k, C.c_int32) for k in ('N', 'H', 'A', 'F', 'T', 'T_env')] +
                 [(k, C.c_void_p) for k in ('g', 'done', 'ep_sum', 'ep_sq', 'ep_len', 'fin', 'h_fw', 'c_fw', 'h_bw', 'c_bw', 'fp_T',
-                                           'fp_uniform', 'x_T', 'fp_0', 'x_0', 'done_pre')])
+                                           'fp_uniform', 'x_T', 'fp_0', 'x_0', 'done_pre', 'scratch')])
 
 
 class BpttCoupled(C.Structure):
@@ -120,6 +127,8 @@ SIGNATURES = {
                          _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p],
     'nmarl_cacc_step': [C.POINTER(CaccParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                         _i32, _u64, _i64, _p, _p],
+    'nmarl_cacc_step_encode': [C.POINTER(CaccParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                               _i32, _u64, _i64, _p, C.POINTER(CaccEncode), _p],
     'nmarl_grid_reset': [C.POINTER(GridParams), _i64, _p, _p, _u64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],
     'nmarl_grid_step': [C.POINTER(GridParams), _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _u64, _i64, _p, _p],
     'nmarl_net_reset': [C.POINTER(NetTopo), _i64, _p, _p, _u64, _i64, _p, _p, _p, _p, _p, _p, _p, _p],

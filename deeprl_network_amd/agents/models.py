@@ -260,8 +260,18 @@ class IA2C:
         with torch.no_grad():
             return self.policy.value(self._h2, na_onehot, out=out)
 
+    def encode_target(self, t):
+        """Where lock-step t's LSTM input encoding lives when the env kernel produces it behind its step (fused encode):
+        slot t of the saved activations, or a scratch buffer for the bootstrap step t = n_step (slab n_step of the saved
+        inputs must stay zero: it pads the update's weight-gradient GEMMs)."""
+        if t < self.n_step:
+            return self.S_buf[:, t]
+        if getattr(self, '_enc_boot', None) is None:
+            self._enc_boot = torch.zeros_like(self.S_buf[:, 0])
+        return self._enc_boot
+
     def act(self, done, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0, step_dev=None,
-            done_is_zero=False):
+            done_is_zero=False, pre_encoded=False):
         """One lock-step decision for all replicas at buffer slot t: reads the observation buf_x[t]
         and fingerprints buf_fp[t]; writes the action into buf_act[t], the value into buf_v[t] and the
         new policy into buf_fp[t+1] (env.update_fingerprint, utils.py:173).  done [E] f32 is the pre-step
@@ -275,7 +285,10 @@ class IA2C:
                 self.H_all[:, 0].copy_(self.h_fw)
                 self.C_all[:, 0].copy_(self.c_fw)
         # enc is shared by the policy step and the value re-step (Q1)
-        enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
+        if pre_encoded:             # the env kernel of the previous lock-step already encoded buf_x[t] / fp[t] into slot t
+            enc = self.S_buf[:, t]
+        else:
+            enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
         if self.save_acts and p.fused_pv:
             # the policy step reads slot t of the state sequences and writes slot t + 1, gates into G[:, t]; the value
@@ -322,12 +335,12 @@ class IA2C:
         self.t = self.n_step
 
     def bootstrap(self, done, action_scratch, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0,
-                  step=0, step_dev=None, done_is_zero=False):
+                  step=0, step_dev=None, done_is_zero=False, pre_encoded=False):
         """R for the unfinished replicas (utils.py:192-196) from buf_x[T] / buf_fp[T]: one more policy
         step (which advances states_fw -- quirk Q2) and the double-stepped value."""
         assert self.t == self.n_step
         p = self.policy
-        enc = p.encode(self.buf_x[self.n_step], self.fp)
+        enc = self.encode_target(self.n_step) if pre_encoded else p.encode(self.buf_x[self.n_step], self.fp)
         if self.save_acts and p.fused_pv:                   # from slot T of the sequences into the persistent state
             T = self.n_step
             p.step_policy_value(enc, self.H_all[:, T], self.C_all[:, T], done, self._pi_boot, action_scratch, self._v_boot,

@@ -428,6 +428,24 @@ class BatchedPolicy:
                 self.value(h_out, ops.nbr_onehot(action, self.nbr_idx, self.n_a), out=v_out)
         return v_out
 
+    def fused_env_encode(self, fp_next, out):
+        """Arguments for the env kernel to run THIS policy's input encoders behind its step (envs/cacc_env.py `encode`), or
+        None if the encoders do not have that shape: relu layers of 64 outputs over the compact CACC observation
+        ([own | 2 neighbours] x 5 features) and, optionally, the 2 neighbours' 4-wide fingerprints."""
+        return None
+
+    def _fused_spec(self, ob, fp_keys, fp_next, out):
+        """ob = (weight key, bias key) of the observation layer, fp_keys likewise for the fingerprint layer or None."""
+        p = self.params
+        if self.hetero or self.n_feat != 5 or self.m_max != 2 or self.n_a != 4 or p[ob[0]].shape[1:] != (15, 64):
+            return None
+        d = dict(w_ob=p[ob[0]], b_ob=p[ob[1]], nbr_idx=self.nbr_idx, out=out, act=ops.BIAS_RELU)
+        if fp_keys is not None:
+            if p[fp_keys[0]].shape[1:] != (8, 64):
+                return None
+            d.update(w_fp=p[fp_keys[0]], b_fp=p[fp_keys[1]], fp=fp_next)
+        return d
+
     def _enc_one_launch(self, xv, width):
         """Observation and fingerprint encoders fit the multi-layer fc kernel (inputs <= 64 wide, 64 outputs)."""
         return width == ops.FC_J and self.n_obs <= ops.FC_MAX_F and self.n_na <= ops.FC_MAX_F
@@ -571,6 +589,9 @@ class LstmPolicy(BatchedPolicy):
         s = self._fc_ob_infer(xv, 'fc_w', 'fc_b', ops.BIAS_RELU, out=out)
         return s if self.xside else torch.bmm(s, self.params['lstm_wx'])
 
+    def fused_env_encode(self, fp_next, out):
+        return self._fused_spec(('fc_w', 'fc_b'), None, fp_next, out) if self.xside else None
+
     def _recur_in(self, enc, h):
         return enc
 
@@ -609,6 +630,9 @@ class FPPolicy(LstmPolicy):
             self._fc_ob_infer(xv, 'fcs_w', 'fcs_b', ops.BIAS_RELU, out=s[:, :, :nf])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'fcp_w', 'fcp_b', ops.BIAS_RELU, out=s[:, :, nf:])
         return s if self.xside else torch.bmm(s, p['lstm_wx'])                          # else ONE K = 2 nf GEMM
+
+    def fused_env_encode(self, fp_next, out):
+        return self._fused_spec(('fcs_w', 'fcs_b'), ('fcp_w', 'fcp_b'), fp_next, out) if self.xside else None
 
 
 class NCMultiAgentPolicy(BatchedPolicy):
@@ -673,6 +697,9 @@ class NCMultiAgentPolicy(BatchedPolicy):
             self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU, out=s[:, :, :H])
             self._fc_infer(ops.nbr_gather(fp, self.nbr_idx), 'w_fp', 'w_fp_b', ops.BIAS_RELU, out=s[:, :, H:])
         return full if self.xside else torch.bmm(s, p['wx_hid'][:, :2 * H])
+
+    def fused_env_encode(self, fp_next, out):
+        return self._fused_spec(('w_ob', 'w_ob_b'), ('w_fp', 'w_fp_b'), fp_next, out) if self.xside else None
 
     def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params

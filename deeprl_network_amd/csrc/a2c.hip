@@ -231,10 +231,14 @@ struct EpilogueArgs {
     float *fp_0, *x_0, *done_pre;
 };
 
-__global__ __launch_bounds__(1024) void epilogue_stats_kernel(const EpilogueArgs a) {
-    // one block: per-replica float64 sums in the order t = 0 .. T-1, then a fixed-order tree over the replicas
+constexpr int EPI_BLOCK = 256;
+constexpr int EPI_MAX_BLOCKS = 1024;
+
+// per-replica float64 sums in the order t = 0 .. T-1 (one thread per replica), a fixed-order tree over the block's
+// replicas; the per-block partials are added in block order by the state kernel that follows (deterministic)
+__global__ __launch_bounds__(EPI_BLOCK) void epilogue_stats_kernel(const EpilogueArgs a, double* __restrict__ partial) {
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
-    for (int64_t e = threadIdx.x; e < a.E; e += blockDim.x) {
+    for (int64_t e = (int64_t)blockIdx.x * EPI_BLOCK + threadIdx.x; e < a.E; e += (int64_t)gridDim.x * EPI_BLOCK) {
         double s = 0.0, q = 0.0;
         for (int t = 0; t < a.T; ++t) {
             const double v = (double)a.g[(int64_t)t * a.E + e];
@@ -256,20 +260,25 @@ __global__ __launch_bounds__(1024) void epilogue_stats_kernel(const EpilogueArgs
         a.ep_sq[e] = d ? 0.0 : sq;
         a.ep_len[e] = d ? 0.0 : len;
     }
-    __shared__ double red[4][1024];
+    __shared__ double red[4][EPI_BLOCK];
     red[0][threadIdx.x] = f0; red[1][threadIdx.x] = f1; red[2][threadIdx.x] = f2; red[3][threadIdx.x] = f3;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
+    for (int off = EPI_BLOCK / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
         }
         __syncthreads();
     }
-    if (threadIdx.x < 4) a.fin[threadIdx.x] += red[threadIdx.x][0];
+    if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-__global__ __launch_bounds__(256) void epilogue_state_kernel(const EpilogueArgs a) {
+__global__ __launch_bounds__(256) void epilogue_state_kernel(const EpilogueArgs a, const double* __restrict__ partial, const int n_partial) {
+    if (blockIdx.x == 0 && threadIdx.x < 4) {          // episode statistics: the stats kernel's per-block partials, in block order
+        double v = 0.0;
+        for (int b = 0; b < n_partial; ++b) v += partial[b * 4 + threadIdx.x];
+        a.fin[threadIdx.x] += v;
+    }
     const int64_t nh = (int64_t)a.N * a.E * a.H, na = (int64_t)a.N * a.E * a.A, nx = a.E * (int64_t)a.N * a.F;
     const int64_t total = nh > na ? (nh > nx ? nh : nx) : (na > nx ? na : nx);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -571,10 +580,13 @@ extern "C" int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* strea
     a.h_fw = p->h_fw; a.c_fw = p->c_fw; a.h_bw = p->h_bw; a.c_bw = p->c_bw; a.fp_T = p->fp_T; a.fp_uniform = p->fp_uniform;
     a.x_T = p->x_T; a.fp_0 = p->fp_0; a.x_0 = p->x_0; a.done_pre = p->done_pre;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(epilogue_stats_kernel, dim3(1), dim3(1024), 0, st, a);
+    if (!p->scratch) return NMARL_EINVAL;
+    int64_t sb = (a.E + EPI_BLOCK - 1) / EPI_BLOCK;
+    sb = sb > EPI_MAX_BLOCKS ? EPI_MAX_BLOCKS : sb;
+    hipLaunchKernelGGL(epilogue_stats_kernel, dim3((unsigned)sb), dim3(EPI_BLOCK), 0, st, a, p->scratch);
     const int64_t nh = (int64_t)a.N * a.E * a.H, nx = a.E * (int64_t)a.N * a.F;
     int64_t blocks = ((nh > nx ? nh : nx) + 255) / 256;
     blocks = blocks > 2048 ? 2048 : blocks;
-    hipLaunchKernelGGL(epilogue_state_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(epilogue_state_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, (const double*)p->scratch, (int)sb);
     return nmarl_check_launch();
 }

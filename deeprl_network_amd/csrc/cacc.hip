@@ -186,6 +186,110 @@ __device__ __forceinline__ float reset_uniform(uint64_t seed, int64_t env_id, in
     return u01_from_bits(r.x);
 }
 
+// One tile = 64 lanes = 8 replicas of one wave: the step of cacc_env.py:191-242 from the tile's loaded inputs, all stores, and
+// the observation of the new state staged in `lds_wave` ([64 lanes][W]) and written out.
+template <int NT, bool COMPACT>
+__device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const int64_t n_lanes, const int64_t w, const int lane,
+                                          float h, float v, const int act, int t, bool collided, float v0i,
+                                          float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
+                                          int32_t* __restrict__ ts, uint8_t* __restrict__ coll, float* __restrict__ v0_init,
+                                          float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+                                          float* __restrict__ greward, const int auto_reset, const uint64_t seed,
+                                          const int64_t env_id_base, int32_t* __restrict__ episode, float* lds_wave) {
+    constexpr int W = COMPACT ? NF : NOBS;
+    const int64_t gid = w * NMARL_WAVE + lane;      // = e*8 + a
+    const bool valid = gid < n_lanes;
+    const int64_t g = valid ? gid : n_lanes - 1;    // clamp: tail lanes mirror the last vehicle
+    const int64_t e = g >> 3;
+    const int a = (int)(g & 7);
+
+    const bool frozen = collided;                                   // :193
+
+    const float alpha = (act & 1) ? 0.5f : 0.0f;                    // a_map, :275
+    const float beta = (act & 2) ? 0.5f : 0.0f;
+    const float up_v = __shfl_up(v, 1, N);
+    const float v_lead = a == 0 ? lead_speed(p, v0i, t) : up_v;     // :33-37
+    const float u_raw = alpha * (ovm_vh(p, h) - v) + beta * (v_lead - v);   // :385
+    float v_next = v + clampf(u_raw, p.u_min, p.u_max) * p.dt;      // :26
+    v_next = clampf(v_next, 0.0f, p.v_max);                         // :27
+    const float u_c = (v_next - v) / p.dt;                          // :28
+    const float up_vn = __shfl_up(v_next, 1, N);
+    const float v_lead_next = a == 0 ? lead_speed(p, v0i, t + 1) : up_vn;
+    const float h_next = h + (0.5f * p.dt) * (v_lead + v_lead_next - v - v_next);  // :220
+
+    float u_new;
+    if (!frozen) { h = h_next; v = v_next; u_new = u_c; }
+    else { u_new = us[g]; }
+
+    // collision test: min over the platoon (:42)
+    float hmin = h;
+    hmin = fminf(hmin, __shfl_xor(hmin, 1, N));
+    hmin = fminf(hmin, __shfl_xor(hmin, 2, N));
+    hmin = fminf(hmin, __shfl_xor(hmin, 4, N));
+    if (!frozen && hmin < p.h_min) collided = true;
+
+    float r;
+    if (collided) {
+        r = -p.G;                                                   // :44, :194
+    } else {
+        const float dh = h - p.h_star, dv = v - p.v_star;
+        r = -(dh * dh);
+        r = r + (-p.reward_a * (dv * dv));
+        r = r + (-p.reward_b * (u_new * u_new));
+        if (p.train_mode) {
+            const float c = fminf(h - 10.0f, 0.0f);                 // COLLISION_HEADWAY, :10
+            r = r + (-5.0f * (c * c));                              // COLLISION_WT, :9
+        }
+    }
+    float rsum = r;                                                 // np.sum(reward), :229
+    rsum = rsum + __shfl_xor(rsum, 1, N);
+    rsum = rsum + __shfl_xor(rsum, 2, N);
+    rsum = rsum + __shfl_xor(rsum, 4, N);
+
+    t += 1;
+    const bool is_done = (collided && (t % p.batch_size == 0)) || (t == p.T);   // :231-235
+
+    if (valid) {
+        if (p.per_agent_reward) reward[g] = r;
+        if (a == 0) {
+            if (!p.per_agent_reward) reward[e] = rsum;
+            greward[e] = rsum;
+            done[e] = is_done ? 1 : 0;
+        }
+    }
+
+    if (auto_reset && is_done) {
+        const int ep = episode[e];
+        const float U = reset_uniform(seed, env_id_base + e, ep);
+        init_state(p, U, a, h, v, v0i);
+        u_new = 0.0f; t = 0; collided = false;
+        if (valid && a == 0) episode[e] = ep + 1;
+    }
+
+    if (valid) {
+        if (NT >= 2) {
+            __builtin_nontemporal_store(h, &hs[g]); __builtin_nontemporal_store(v, &vs[g]);
+            __builtin_nontemporal_store(u_new, &us[g]);
+        } else {
+            hs[g] = h; vs[g] = v; us[g] = u_new;
+        }
+        if (a == 0) {
+            ts[e] = t;
+            coll[e] = collided ? 1 : 0;
+            if (auto_reset && is_done) v0_init[e] = v0i;
+        }
+    }
+
+    const float up_v2 = __shfl_up(v, 1, N);
+    const float v_lead_obs = a == 0 ? lead_speed(p, v0i, t) : up_v2;   // :55, with the new t
+    const int64_t lanes_here = n_lanes - w * NMARL_WAVE;
+    const int n_valid = lanes_here >= NMARL_WAVE ? NMARL_WAVE : (int)lanes_here;
+    __builtin_amdgcn_wave_barrier();
+    emit_obs<NT, COMPACT>(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
+                          obs + w * NMARL_WAVE * W, n_valid);
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int BLOCK, int NT, bool COMPACT>
 __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
     const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ action,
@@ -224,104 +328,15 @@ __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
         NMARL_CACC_LOAD(w + wave_stride, m)
     }
     for (; w < waves_total; w += wave_stride) {
-        const int64_t gid = w * NMARL_WAVE + lane;      // = e*8 + a
-        const bool valid = gid < n_lanes;
-        const int64_t g = valid ? gid : n_lanes - 1;    // clamp: tail lanes mirror the last vehicle
-        const int64_t e = g >> 3;
-        const int a = (int)(g & 7);
-
         float h = h_n, v = v_n;
         const int act = act_n;
-        int t = t_n;
-        bool collided = coll_n != 0;
-        float v0i = v0i_n;
+        const int t = t_n;
+        const bool collided = coll_n != 0;
+        const float v0i = v0i_n;
         h_n = h_m; v_n = v_m; act_n = act_m; t_n = t_m; coll_n = coll_m; v0i_n = v0i_m;
         NMARL_CACC_LOAD(w + 2 * wave_stride, m)
-        const bool frozen = collided;                                   // :193
-
-        const float alpha = (act & 1) ? 0.5f : 0.0f;                    // a_map, :275
-        const float beta = (act & 2) ? 0.5f : 0.0f;
-        const float up_v = __shfl_up(v, 1, N);
-        const float v_lead = a == 0 ? lead_speed(p, v0i, t) : up_v;     // :33-37
-        const float u_raw = alpha * (ovm_vh(p, h) - v) + beta * (v_lead - v);   // :385
-        float v_next = v + clampf(u_raw, p.u_min, p.u_max) * p.dt;      // :26
-        v_next = clampf(v_next, 0.0f, p.v_max);                         // :27
-        const float u_c = (v_next - v) / p.dt;                          // :28
-        const float up_vn = __shfl_up(v_next, 1, N);
-        const float v_lead_next = a == 0 ? lead_speed(p, v0i, t + 1) : up_vn;
-        const float h_next = h + (0.5f * p.dt) * (v_lead + v_lead_next - v - v_next);  // :220
-
-        float u_new;
-        if (!frozen) { h = h_next; v = v_next; u_new = u_c; }
-        else { u_new = us[g]; }
-
-        // collision test: min over the platoon (:42)
-        float hmin = h;
-        hmin = fminf(hmin, __shfl_xor(hmin, 1, N));
-        hmin = fminf(hmin, __shfl_xor(hmin, 2, N));
-        hmin = fminf(hmin, __shfl_xor(hmin, 4, N));
-        if (!frozen && hmin < p.h_min) collided = true;
-
-        float r;
-        if (collided) {
-            r = -p.G;                                                   // :44, :194
-        } else {
-            const float dh = h - p.h_star, dv = v - p.v_star;
-            r = -(dh * dh);
-            r = r + (-p.reward_a * (dv * dv));
-            r = r + (-p.reward_b * (u_new * u_new));
-            if (p.train_mode) {
-                const float c = fminf(h - 10.0f, 0.0f);                 // COLLISION_HEADWAY, :10
-                r = r + (-5.0f * (c * c));                              // COLLISION_WT, :9
-            }
-        }
-        float rsum = r;                                                 // np.sum(reward), :229
-        rsum = rsum + __shfl_xor(rsum, 1, N);
-        rsum = rsum + __shfl_xor(rsum, 2, N);
-        rsum = rsum + __shfl_xor(rsum, 4, N);
-
-        t += 1;
-        const bool is_done = (collided && (t % p.batch_size == 0)) || (t == p.T);   // :231-235
-
-        if (valid) {
-            if (p.per_agent_reward) reward[g] = r;
-            if (a == 0) {
-                if (!p.per_agent_reward) reward[e] = rsum;
-                greward[e] = rsum;
-                done[e] = is_done ? 1 : 0;
-            }
-        }
-
-        if (auto_reset && is_done) {
-            const int ep = episode[e];
-            const float U = reset_uniform(seed, env_id_base + e, ep);
-            init_state(p, U, a, h, v, v0i);
-            u_new = 0.0f; t = 0; collided = false;
-            if (valid && a == 0) episode[e] = ep + 1;
-        }
-
-        if (valid) {
-            if (NT >= 2) {
-                __builtin_nontemporal_store(h, &hs[g]); __builtin_nontemporal_store(v, &vs[g]);
-                __builtin_nontemporal_store(u_new, &us[g]);
-            } else {
-                hs[g] = h; vs[g] = v; us[g] = u_new;
-            }
-            if (a == 0) {
-                ts[e] = t;
-                coll[e] = collided ? 1 : 0;
-                if (auto_reset && is_done) v0_init[e] = v0i;
-            }
-        }
-
-        const float up_v2 = __shfl_up(v, 1, N);
-        const float v_lead_obs = a == 0 ? lead_speed(p, v0i, t) : up_v2;   // :55, with the new t
-        const int64_t lanes_here = n_lanes - w * NMARL_WAVE;
-        const int n_valid = lanes_here >= NMARL_WAVE ? NMARL_WAVE : (int)lanes_here;
-        __builtin_amdgcn_wave_barrier();
-        emit_obs<NT, COMPACT>(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
-                              obs + w * NMARL_WAVE * W, n_valid);
-        __builtin_amdgcn_wave_barrier();
+        cacc_tile<NT, COMPACT>(p, n_lanes, w, lane, h, v, act, t, collided, v0i, hs, vs, us, ts, coll, v0_init, obs, reward, done,
+                               greward, auto_reset, seed, env_id_base, episode, lds_wave);
     }
 }
 
@@ -383,6 +398,126 @@ __global__ __launch_bounds__(BLOCK) void cacc_reset_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Lock-step tail of the batched rollout in ONE launch: the env step AND the next lock-step's input encoders
+// (fc of policies.py:145 / 176-181, w_ob / w_fp of agents/utils.py:186-199) -- the observation the step produces never
+// leaves the CU before it is encoded (it is also written once, compact, for the update).  Saves one launch and the
+// ~9 us latency chain of the separate encoder kernel per lock-step; same arithmetic as nmarl_fc_fwd_multi, bit for bit.
+//
+// Block = 256 threads = 8 replicas.  Phase 1: wave 0 steps them (cacc_tile) while wave 2 fetches the replicas' previous-step
+// policies (the fingerprints) into LDS; all waves load their encoder weights.  Phase 2: thread =
+// (layer 0: observation / 1: fingerprints, agent, 4 output columns): its 15 (8) x 4 weights sit in registers, the inputs
+// are LDS broadcasts ([own | neighbours] gathered through the neighbour table), 8 rows per thread, float4 stores into
+// columns [64 layer, 64 layer + 64) of the LSTM input.
+struct EncodeArgs {
+    const float *w_ob, *b_ob, *w_fp, *b_fp, *fp;
+    const int32_t* nbr_idx;
+    float* out;
+    int64_t w_ob_sn, b_ob_sn, w_fp_sn, b_fp_sn, fp_sn, out_sn, out_row;
+    int32_t act, n_parts;
+};
+constexpr int ENC_REPS = 8;           // replicas per block (one wave steps them; 2 blocks per CU overlap their phases)
+constexpr int ENC_J = 64;             // outputs per layer
+constexpr int ENC_A = 4;              // actions (fingerprint width per neighbour)
+
+__device__ __forceinline__ float enc_act(float x, int act) { return act == 1 ? fmaxf(x, 0.0f) : (act == 2 ? tanhf(x) : x); }
+
+__global__ __launch_bounds__(256) void cacc_step_encode_kernel(
+    const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ action,
+    float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
+    int32_t* __restrict__ ts, uint8_t* __restrict__ coll, float* __restrict__ v0_init,
+    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+    float* __restrict__ greward, const int auto_reset, const uint64_t seed,
+    const int64_t env_id_base, int32_t* __restrict__ episode, const EncodeArgs en) {
+    __shared__ __attribute__((aligned(16))) float lds_obs[ENC_REPS * N * NF];        // [16 replicas][8 vehicles][5]
+    __shared__ __attribute__((aligned(16))) float lds_fp[ENC_REPS * N * ENC_A];      // [16][8 agents][4]
+    const int lane = threadIdx.x & (NMARL_WAVE - 1);
+    const int wave = threadIdx.x / NMARL_WAVE;
+    const int64_t n_lanes = E * N;
+    const int64_t e0 = (int64_t)blockIdx.x * ENC_REPS;
+    // ---- encoder role of this thread and its weights (registers; issued before the env phase, landed after it)
+    const int part = threadIdx.x >> 7, ag = (threadIdx.x >> 4) & 7, j4 = (threadIdx.x & 15) * 4;
+    const bool has_part = part < en.n_parts;
+    const int n0 = en.nbr_idx[ag * 2], n1 = en.nbr_idx[ag * 2 + 1];
+    float4 wq[3 * NF];
+    float4 bq;
+    if (part == 0) {
+        const float* wp = en.w_ob + (int64_t)ag * en.w_ob_sn + j4;
+#pragma unroll
+        for (int f = 0; f < 3 * NF; ++f) wq[f] = *reinterpret_cast<const float4*>(wp + f * ENC_J);
+        bq = *reinterpret_cast<const float4*>(en.b_ob + (int64_t)ag * en.b_ob_sn + j4);
+    } else {
+        const float* wp = has_part ? en.w_fp + (int64_t)ag * en.w_fp_sn + j4 : en.w_ob + j4;
+#pragma unroll
+        for (int f = 0; f < 2 * ENC_A; ++f) wq[f] = *reinterpret_cast<const float4*>(wp + f * ENC_J);
+#pragma unroll
+        for (int f = 2 * ENC_A; f < 3 * NF; ++f) wq[f] = float4{0.f, 0.f, 0.f, 0.f};
+        bq = *reinterpret_cast<const float4*>((has_part ? en.b_fp + (int64_t)ag * en.b_fp_sn : en.b_ob) + j4);
+    }
+    // ---- phase 1: env step (wave 0) | fingerprint tile (wave 2)
+    if (wave < ENC_REPS / 8) {
+        const int64_t w = (int64_t)blockIdx.x * (ENC_REPS / 8) + wave;   // wave tile index: 8 replicas
+        const int64_t gid = w * NMARL_WAVE + lane;
+        const int64_t g = gid < n_lanes ? gid : n_lanes - 1;
+        if (w * NMARL_WAVE < n_lanes) {
+            const float h = hs[g], v = vs[g];
+            const int act = action[g], t = ts[g >> 3];
+            const bool collided = coll[g >> 3] != 0;
+            const float v0i = v0_init[g >> 3];
+            cacc_tile<0, true>(p, n_lanes, w, lane, h, v, act, t, collided, v0i, hs, vs, us, ts, coll, v0_init, obs, reward, done,
+                               greward, auto_reset, seed, env_id_base, episode, lds_obs + wave * NMARL_WAVE * NF);
+        }
+    } else if (en.n_parts > 1 && threadIdx.x >= 128 && threadIdx.x < 128 + N * ENC_REPS) {
+        const int i = threadIdx.x - 128;                                 // (agent, replica of the block): one float4 each
+        const int a2 = i / ENC_REPS, r = i % ENC_REPS;
+        const int64_t e = e0 + r;
+        const float4 v4 = *reinterpret_cast<const float4*>(en.fp + (int64_t)a2 * en.fp_sn + (e < E ? e : E - 1) * ENC_A);
+        *reinterpret_cast<float4*>(lds_fp + (r * N + a2) * ENC_A) = v4;
+    }
+    __syncthreads();
+    // ---- phase 2: encoders of the block's replicas
+    if (!has_part) return;
+    float* outp = en.out + (int64_t)ag * en.out_sn + part * ENC_J + j4;
+#pragma unroll 4
+    for (int r = 0; r < ENC_REPS; ++r) {
+        const int64_t e = e0 + r;
+        float x[3 * NF];
+        if (part == 0) {
+            const float* o = lds_obs + r * N * NF;
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+                x[k] = o[ag * NF + k];
+                x[NF + k] = n0 >= 0 ? o[n0 * NF + k] : 0.0f;
+                x[2 * NF + k] = n1 >= 0 ? o[n1 * NF + k] : 0.0f;
+            }
+        } else {
+            const float* q = lds_fp + r * N * ENC_A;
+#pragma unroll
+            for (int k = 0; k < ENC_A; ++k) {
+                x[k] = n0 >= 0 ? q[n0 * ENC_A + k] : 0.0f;
+                x[ENC_A + k] = n1 >= 0 ? q[n1 * ENC_A + k] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 2 * ENC_A; k < 3 * NF; ++k) x[k] = 0.0f;
+        }
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;        // the ascending fmaf chain of nmarl_fc_fwd_multi
+        if (part == 0) {
+#pragma unroll
+            for (int f = 0; f < 3 * NF; ++f) {
+                a0 = fmaf(x[f], wq[f].x, a0); a1 = fmaf(x[f], wq[f].y, a1); a2 = fmaf(x[f], wq[f].z, a2); a3 = fmaf(x[f], wq[f].w, a3);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 2 * ENC_A; ++f) {
+                a0 = fmaf(x[f], wq[f].x, a0); a1 = fmaf(x[f], wq[f].y, a1); a2 = fmaf(x[f], wq[f].z, a2); a3 = fmaf(x[f], wq[f].w, a3);
+            }
+        }
+        if (e < E)
+            *reinterpret_cast<float4*>(outp + e * en.out_row) =
+                float4{enc_act(a0 + bq.x, en.act), enc_act(a1 + bq.y, en.act), enc_act(a2 + bq.z, en.act), enc_act(a3 + bq.w, en.act)};
+    }
+}
+
 inline int pick_grid(int64_t E, int block) {
     const int64_t waves = (E * N + NMARL_WAVE - 1) / NMARL_WAVE;
     const int64_t blocks = (waves + block / NMARL_WAVE - 1) / (block / NMARL_WAVE);
@@ -430,6 +565,34 @@ extern "C" int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const ui
         else NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE, false);
     }
 #undef NMARL_CACC_LAUNCH
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_cacc_step_encode(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* action,
+                                      float* h, float* v, float* u, int32_t* t, uint8_t* collided,
+                                      float* v0_init, float* obs, float* reward, uint8_t* done,
+                                      float* global_reward, int32_t auto_reset, uint64_t seed,
+                                      int64_t env_id_base, int32_t* episode, const nmarl_cacc_encode_t* enc, void* stream) {
+    if (!params_ok(p) || !p->compact_obs || E < 0 || !enc ||
+        (E > 0 && (!action || !h || !v || !u || !t || !collided || !v0_init || !obs || !reward || !done || !global_reward)))
+        return NMARL_EINVAL;
+    if (auto_reset && !episode) return NMARL_EINVAL;
+    if (enc->n_parts < 1 || enc->n_parts > 2 || enc->act < 0 || enc->act > 2 || !enc->w_ob || !enc->b_ob || !enc->nbr_idx || !enc->out ||
+        enc->w_ob_sn < 3 * NF * 64 || (enc->w_ob_sn % 4) || enc->b_ob_sn < 64 || (enc->b_ob_sn % 4) || enc->out_row < 64 * enc->n_parts ||
+        (enc->out_row % 4) || (enc->out_sn % 4) || ((uintptr_t)enc->w_ob % 16) || ((uintptr_t)enc->b_ob % 16) || ((uintptr_t)enc->out % 16))
+        return NMARL_EINVAL;
+    if (enc->n_parts == 2 && (!enc->w_fp || !enc->b_fp || !enc->fp || enc->w_fp_sn < 2 * 4 * 64 || (enc->w_fp_sn % 4) || enc->b_fp_sn < 64 ||
+                              (enc->b_fp_sn % 4) || enc->fp_sn < E * 4 || (enc->fp_sn % 4) || ((uintptr_t)enc->w_fp % 16) ||
+                              ((uintptr_t)enc->b_fp % 16) || ((uintptr_t)enc->fp % 16)))
+        return NMARL_EINVAL;
+    if (E == 0) return NMARL_OK;
+    EncodeArgs en{};
+    en.w_ob = enc->w_ob; en.b_ob = enc->b_ob; en.w_fp = enc->w_fp; en.b_fp = enc->b_fp; en.fp = enc->fp; en.nbr_idx = enc->nbr_idx;
+    en.out = enc->out; en.w_ob_sn = enc->w_ob_sn; en.b_ob_sn = enc->b_ob_sn; en.w_fp_sn = enc->w_fp_sn; en.b_fp_sn = enc->b_fp_sn;
+    en.fp_sn = enc->fp_sn; en.out_sn = enc->out_sn; en.out_row = enc->out_row; en.act = enc->act; en.n_parts = enc->n_parts;
+    hipLaunchKernelGGL(cacc_step_encode_kernel, dim3((unsigned)((E + ENC_REPS - 1) / ENC_REPS)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), *p, E, action, h, v, u, t, collided, v0_init, obs, reward, done, global_reward,
+                       auto_reset, seed, env_id_base, episode, en);
     return nmarl_check_launch();
 }
 

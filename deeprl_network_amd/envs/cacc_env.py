@@ -138,15 +138,42 @@ class CACCBatchEnv:
         _lib.check(rc, 'nmarl_cacc_reset')
         return self.obs
 
-    def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
+    supports_fused_encode = True
+
+    def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None, encode=None):
         """action [E,8] uint8 -> (obs [E,8,15], reward [E]|[E,8], done [E] u8, global_reward [E]).
         By default the results land in this env's persistent buffers (overwritten every step); the
-        `*_out` tensors redirect them, e.g. straight into slot t of the trainer's rollout buffers."""
+        `*_out` tensors redirect them, e.g. straight into slot t of the trainer's rollout buffers.
+        encode (compact observation only): dict(w_ob, b_ob[, w_fp, b_fp, fp], nbr_idx, out, act) -- the NEXT lock-step's input
+        encoders run in the same launch on the observation this step produces (nmarl_cacc_step_encode)."""
         P = _lib.ptr
         obs = self.obs if obs_out is None else obs_out
         reward = self.reward if reward_out is None else reward_out
         done = self.done if done_out is None else done_out
         greward = self.global_reward if greward_out is None else greward_out
+        if encode is not None:
+            en = _lib.CaccEncode()
+            S = P
+            w, b, out = encode['w_ob'], encode['b_ob'], encode['out']
+            if w.shape[1:] != (15, 64) or w.stride(2) != 1 or w.stride(1) != 64 or out.stride(2) != 1:
+                raise _lib.NmarlError('fused encode: w_ob must be [N,15,64] panels, out [N,E,>=128] with unit column stride')
+            en.w_ob, en.w_ob_sn, en.b_ob, en.b_ob_sn = S(w, strided=True), w.stride(0), S(b, strided=True), b.stride(0)
+            en.n_parts, en.act = (2 if encode.get('w_fp') is not None else 1), int(encode['act'])
+            if en.n_parts == 2:
+                wf, bf, fp = encode['w_fp'], encode['b_fp'], encode['fp']
+                if wf.shape[1:] != (8, 64) or wf.stride(2) != 1 or wf.stride(1) != 64 or fp.shape[1:] != (self.E, 4) or not fp[0].is_contiguous():
+                    raise _lib.NmarlError('fused encode: w_fp must be [N,8,64] panels, fp [N,E,4]')
+                en.w_fp, en.w_fp_sn, en.b_fp, en.b_fp_sn = S(wf, strided=True), wf.stride(0), S(bf, strided=True), bf.stride(0)
+                en.fp, en.fp_sn = S(fp, strided=True), fp.stride(0)
+            en.nbr_idx = P(encode['nbr_idx'], torch.int32)
+            en.out, en.out_sn, en.out_row = S(out, strided=True), out.stride(0), out.stride(1)
+            rc = _lib.lib.nmarl_cacc_step_encode(
+                ctypes.byref(self.params), self.E, P(action, torch.uint8), P(self.h), P(self.v), P(self.u),
+                P(self.t), P(self.collided), P(self.v0_init), P(obs, torch.float32), P(reward, torch.float32),
+                P(done, torch.uint8), P(greward, torch.float32), 1 if auto_reset else 0, self.seed,
+                self.env_id_base, P(self.episode), ctypes.byref(en), _lib.stream())
+            _lib.check(rc, 'nmarl_cacc_step_encode')
+            return obs, reward, done, greward
         rc = _lib.lib.nmarl_cacc_step(
             ctypes.byref(self.params), self.E, P(action, torch.uint8), P(self.h), P(self.v), P(self.u),
             P(self.t), P(self.collided), P(self.v0_init), P(obs, torch.float32), P(reward, torch.float32),

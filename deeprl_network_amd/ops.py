@@ -1165,6 +1165,9 @@ def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, n
                                     float(grad_scale), ptr(norm_out, F32), stream()), 'nmarl_rmsprop_tf_clip')
 
 
+_epilogue_scratch = {}
+
+
 def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre):
     """nmarl_batch_epilogue: episode statistics + the state hand-over between two n_step batches (see include/nmarl.h).
     g [T,E] f32, done [E] u8, ep_* [E] f64, fin [4] f64; h_* / c_* [N,E,H]; fp_T / fp_0 [N,E,A], fp_uniform [N,1,A] or [N,A];
@@ -1178,4 +1181,8 @@ def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw,
     a.h_fw, a.c_fw, a.h_bw, a.c_bw = (ptr(t, F32) for t in (h_fw, c_fw, h_bw, c_bw))
     a.fp_T, a.fp_0, a.fp_uniform = ptr(fp_T, F32), ptr(fp_0, F32), ptr(fp_uniform.reshape(N, -1), F32)
     a.x_T, a.x_0, a.done_pre = ptr(x_T, F32), ptr(x_0, F32), ptr(done_pre, F32)
+    key = g.device
+    if key not in _epilogue_scratch:
+        _epilogue_scratch[key] = torch.zeros(4096, dtype=torch.float64, device=g.device)      # NMARL_EPILOGUE_SCRATCH
+    a.scratch = ptr(_epilogue_scratch[key], torch.float64)
     check(lib.nmarl_batch_epilogue(C.byref(a), stream()), 'nmarl_batch_epilogue')

@@ -267,13 +267,17 @@ class BatchedTrainer:
     """
 
     def __init__(self, env, model, global_counter=None, summary_writer=None, output_path=None,
-                 use_graph=True, rank=0, world_size=1, save_activations=True, compact_obs=True):
+                 use_graph=True, rank=0, world_size=1, save_activations=True, compact_obs=True, fused_encode=True):
         self.env, self.model = env, model
         # uncoupled nets: the rollout's policy steps double as the forward pass of the update (models.py)
         self.saved_acts = bool(save_activations) and model.enable_saved_activations()
         # CACC: compact observations (own features only; the encoder gathers the neighbours) -- SURVEY.md 8d's layout
         self.compact_obs = bool(compact_obs) and hasattr(env, 'set_compact_obs') and model.enable_compact_obs() and \
             env.set_compact_obs(True)
+        # CACC: the env kernel runs the next lock-step's input encoders behind its step (csrc/cacc.hip cacc_step_encode_kernel)
+        self.fused_encode = bool(fused_encode) and self.saved_acts and self.compact_obs and \
+            getattr(env, 'supports_fused_encode', False) and env.device.type == 'cuda' and \
+            model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1)) is not None
         self.E, self.N = env.E, env.n_agent
         self.n_step = model.n_step
         assert env.T % self.n_step == 0
@@ -315,15 +319,20 @@ class BatchedTrainer:
         T = self.n_step
         model.t = 0
         # Philox step = batch base (device counter, advanced once per batch) + slot offset baked into the graph
+        fused = self.fused_encode
         for t in range(T):
             action = model.act(self.done_pre if t == 0 else self.zero_done, mode=ops.SAMPLE_PHILOX, seed=env.seed,
-                               env_id_base=env.env_id_base, step=t, step_dev=self.step_dev, done_is_zero=(t > 0))
+                               env_id_base=env.env_id_base, step=t, step_dev=self.step_dev, done_is_zero=(t > 0),
+                               pre_encoded=fused and t > 0)
+            # fused: the env kernel also runs lock-step t + 1's input encoders on the observation it just produced and on the
+            # policies the step above wrote (the next fingerprints) -- one launch instead of two per lock-step
+            enc = model.policy.fused_env_encode(model.buf_fp[t + 1], model.encode_target(t + 1)) if fused else None
             env.step(action, auto_reset=(t == T - 1), obs_out=model.buf_x[t + 1], reward_out=self.buf_rraw[t],
-                     done_out=model.buf_done_post[t], greward_out=self.buf_g[t])
+                     done_out=model.buf_done_post[t], greward_out=self.buf_g[t], **({'encode': enc} if fused else {}))
             model.t = t + 1
         # bootstrap value for unfinished replicas (utils.py:192-196); finished ones get R = 0
         v = model.bootstrap(self.zero_done, self.action_boot, mode=ops.SAMPLE_PHILOX, seed=env.seed,
-                            env_id_base=env.env_id_base, step=T, step_dev=self.step_dev, done_is_zero=True)
+                            env_id_base=env.env_id_base, step=T, step_dev=self.step_dev, done_is_zero=True, pre_encoded=fused)
         self.step_dev.add_(T + 1)
         self.R_end.copy_(v * (1.0 - self.last_done.to(torch.float32)).view(1, -1))
 

@@ -117,6 +117,29 @@ int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* acti
                     float* global_reward, int32_t auto_reset, uint64_t seed,
                     int64_t env_id_base, int32_t* episode, void* stream);
 
+/*
+ * nmarl_cacc_step AND the next lock-step's input encoders in one launch (batched rollout, compact observation only):
+ * after the step, for every agent i and replica e
+ *     out[i,e,  0: 64] = act([x_i | x_nbr(i,0) | x_nbr(i,1)] @ w_ob[i] + b_ob[i])      x = the new observation [E,8,5]
+ *     out[i,e, 64:128] = act([fp_nbr(i,0) | fp_nbr(i,1)] @ w_fp[i] + b_fp[i])           (n_parts == 2)
+ * i.e. `fc` of policies.py:145 / 176-181 and w_ob / w_fp of agents/utils.py:186-199 -- the arithmetic of
+ * nmarl_fc_fwd_multi, bit for bit.  w_ob [N][15][64], w_fp [N][8][64], b_* [N][64], fp [N][E][4] (the policies of the
+ * lock-step just decided: next step's fingerprints), nbr_idx [N][2] (-1 padded), out [N][E][out_row] (agent stride
+ * out_sn).  act as in nmarl_bias_act.  Missing neighbours contribute zeros.
+ */
+typedef struct nmarl_cacc_encode {
+    const float *w_ob, *b_ob, *w_fp, *b_fp, *fp;
+    const int32_t* nbr_idx;
+    float* out;
+    int64_t w_ob_sn, b_ob_sn, w_fp_sn, b_fp_sn, fp_sn, out_sn, out_row;
+    int32_t act, n_parts;
+} nmarl_cacc_encode_t;
+int nmarl_cacc_step_encode(const nmarl_cacc_params_t* p, int64_t E, const uint8_t* action,
+                           float* h, float* v, float* u, int32_t* t, uint8_t* collided,
+                           float* v0_init, float* obs, float* reward, uint8_t* done,
+                           float* global_reward, int32_t auto_reset, uint64_t seed,
+                           int64_t env_id_base, int32_t* episode, const nmarl_cacc_encode_t* enc, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Synthetic (SUMO-free) 5x5 ATSC grid -- contract of envs/atsc_env.py +      */
 /* envs/large_grid_env.py; dynamics specified in oracle/grid_ref.py           */
@@ -608,7 +631,9 @@ typedef struct nmarl_batch_epilogue {
     float *h_fw, *c_fw, *h_bw, *c_bw;
     const float *fp_T, *fp_uniform, *x_T;
     float *fp_0, *x_0, *done_pre;
+    double* scratch;          /* [NMARL_EPILOGUE_SCRATCH] f64: per-block partial statistics */
 } nmarl_batch_epilogue_t;
+#define NMARL_EPILOGUE_SCRATCH 4096
 int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* stream);
 
 #ifdef __cplusplus

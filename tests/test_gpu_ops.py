@@ -1067,4 +1067,4 @@ def test_batch_epilogue_matches_host_code(N, E, H, A, F, T):
             assert torch.equal(dev[k].cpu(), host[k]), k
         for k in ('ep_sum', 'ep_sq', 'ep_len', 'fin'):
             torch.testing.assert_close(dev[k].cpu(), host[k], rtol=1e-12, atol=1e-9)
-    assert host['fin'][0] > 0 and host['fin'][3] > 0
+    assert host['fin'][0] > 0 and (E == 1 or host['fin'][3] > 0)

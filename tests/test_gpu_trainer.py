@@ -129,3 +129,31 @@ def test_compact_observation_equals_gathered_slab(agent):
     assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
     torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ia2c'])
+def test_fused_env_encode_equals_separate_launches(agent):
+    """The env kernel running the next lock-step's input encoders behind its step (nmarl_cacc_step_encode: the observation
+    is encoded before it leaves the CU) == env step + nmarl_fc_fwd_multi as two launches: bit-identical actions, values,
+    saved LSTM inputs and weights after 3 batches (E = 1000: a ragged last block of 16 replicas)."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    out = []
+    for fused in (True, False):
+        cp = cacc_config(agent=agent, scenario='slowdown', n_step=60, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
+        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=1000)
+        np.random.seed(12)
+        cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC}[agent]
+        model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                    cp['MODEL_CONFIG'], seed=12, num_envs=1000)
+        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True, fused_encode=fused)
+        assert tr.fused_encode == fused
+        for _ in range(3):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        out.append((model.policy.params.flat.clone(), model.buf_v.clone(), model.buf_act.clone(), env.h.clone(),
+                    model.S_buf.clone()))
+        del env, model, tr
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)

@@ -76,7 +76,7 @@ def parse():
     return ap.parse_args()
 
 
-def measure_step_kernel(env, actions_tape, reps=20):
+def measure_step_kernel(env, actions_tape, reps=20, encode=None):
     """Average duration of one nmarl_cacc_step launch: a hipGraph of len(tape) back-to-back
     launches (real rollout state, the batch's own action tape, auto-reset on) bracketed by two
     HIP events on the launch stream; includes the ~1.5 us graph-node gaps, i.e. an upper bound."""
@@ -86,7 +86,10 @@ def measure_step_kernel(env, actions_tape, reps=20):
 
     def body():
         for k in range(n):
-            env.step(actions_tape[k], auto_reset=True)
+            if encode is None:
+                env.step(actions_tape[k], auto_reset=True)
+            else:
+                env.step(actions_tape[k], auto_reset=True, encode=encode)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -626,6 +629,25 @@ def main():
                    'B_alg = %d B/replica-step (%s). At E=%d the launch moves %.2f MB: '
                    'latency-bound and LLC-resident (SURVEY.md H1); see roofline_env_step_large_E for the HBM regime.'
                    % (n_step, balg, obs_variant, E, balg * E / 1e6)}
+        if getattr(trainer, 'fused_encode', False):
+            # what the rollout actually launches per lock-step: the step AND the next lock-step's encoders (csrc/cacc.hip
+            # cacc_step_encode_kernel).  Algorithmic bytes per replica-step: the env's 351 + fingerprints read 8 x 16 + the
+            # encoded LSTM input written 8 agents x 128 floats
+            try:
+                spec = model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1))
+                us_f = measure_step_kernel(env, tape, encode=spec)
+                bf = B_ALG_COMPACT + 8 * 16 + 8 * 128 * 4
+                tr_f, tr_fs = pmc_traffic('cacc_step_encode_E4096') if E == 4096 else (None, None)
+                out['roofline_env_step_fused'] = {
+                    'kernel': 'cacc_step_encode_kernel (nmarl_cacc_step_encode: env step + next lock-step input encoders)',
+                    'bound': 'hbm', 'achieved': bf * E / us_f / 1e3, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+                    'frac': bf * E / us_f / 1e3 / HBM_PEAK_GBPS, 'traffic': None if tr_f is None else tr_f * E, 'traffic_source': tr_fs,
+                    'bytes_per_launch': bf * E, 'us_per_launch': us_f, 'replicas_per_launch': E,
+                    'how': 'hipGraph of %d back-to-back launches on the rollout state, 20 replays between two HIP events; B_alg = '
+                           '%d B/replica-step = env 351 + fingerprints 128 + encoded LSTM input 4096.  Latency-bound at this size like the '
+                           'plain step (%.1f MB per launch)' % (n_step, bf, bf * E / 1e6)}
+            except Exception as ex:
+                out['roofline_env_step_fused'] = {'error': repr(ex)}
         if 'roofline' not in out or 'error' in out['roofline']:
             if 'roofline' in out:
                 out['roofline_lstm_error'] = out['roofline']['error']

@@ -44,14 +44,33 @@ for s in range(16):
     senv.step(acts[s % 4][:Es].contiguous(), auto_reset=True)
 torch.cuda.synchronize()
 Eg = int(os.environ.get('PMC_EG', 1 << 17))
-genv = LargeGridBatchEnv(grid_config()['ENV_CONFIG'], num_envs=Eg)
-genv.reset()
 ga = [torch.randint(0, 5, (Eg, 25), dtype=torch.uint8, device='cuda') for _ in range(2)]
-for s in range(6):
-    genv.step(ga[s % 2], auto_reset=True)
+for compact in (False, True):                  # grid_step_kernel<1,false> (gathered slab), then <1,true> (compact: the batched engine's)
+    genv = LargeGridBatchEnv(grid_config()['ENV_CONFIG'], num_envs=Eg)
+    if compact:
+        genv.set_compact_obs(True)
+    genv.reset()
+    for s in range(6):
+        genv.step(ga[s % 2], auto_reset=True)
+    torch.cuda.synchronize()
+    del genv
+# the CACC step with the next lock-step's encoders behind it (cacc_step_encode_kernel) at the bench shape
+from deeprl_network_amd import ops
+import numpy as np
+from deeprl_network_amd.agents import models
+cpf = cacc_config(agent='ia2c_fp', scenario='catchup', n_step=60, reward_norm=800.0)
+fenv = CACCBatchEnv(cpf['ENV_CONFIG'], num_envs=Es)
+fenv.set_compact_obs(True)
+fenv.reset()
+np.random.seed(12)
+fm = models.IA2C_FP(fenv.n_s_ls, fenv.n_a_ls, fenv.neighbor_mask, fenv.distance_mask, fenv.coop_gamma, 10 ** 9, cpf['MODEL_CONFIG'],
+                    seed=12, num_envs=Es)
+fm.enable_saved_activations(); fm.enable_compact_obs()
+spec = fm.policy.fused_env_encode(fm.buf_fp[1], fm.encode_target(1))
+for s in range(16):
+    fenv.step(acts[s % 4][:Es].contiguous(), auto_reset=True, encode=spec)
 torch.cuda.synchronize()
 # the fused MFMA LSTM lock-step at the bench shape (x-side policy + value kernel, as the rollout launches it)
-from deeprl_network_amd import ops
 N, El, H, A, KX = 8, 4096, 64, 4, 128
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).cuda()                                   # noqa: E731
@@ -77,4 +96,18 @@ bimg = ops.lstm_bptt_wimage(None, wh)
 for s in range(5):
     ops.bptt_seq(Gs, Cs, dones, Ds, bimg, dZs)
 torch.cuda.synchronize()
+# the coupled nets' reverse recurrence in one launch (nmarl_lstm_bptt_coupled, NeurComm on the line graph) at the bench shape
+import sys as _sys
+_sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from test_gpu_ops import _topology
+nbr_idx, _ = ops.neighbor_table(_topology(N, 'line'), 'cuda')
+wxm, wmsg = rd(N, H, 4 * H) * 0.1, rd(N, 2 * H, H) * 0.15
+Ss = torch.relu(rd(N, T, El, 3 * H))
+D1s = torch.empty(N, T, El, H, device='cuda')
+ws_, wm_ = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh)), (wmsg, ops.lstm_bptt_msg_wimage(wmsg))
+rev = ops.reverse_neighbor_table(nbr_idx, ops.COUPLED_NC)
+for s in range(4):
+    ops.bptt_coupled(ops.COUPLED_NC, rev, 2, Gs, Cs, dones, Ds, ws_, wm_, Ss[..., 2 * H:], dZs, D1s)
+torch.cuda.synchronize()
+ops.check_coupled_status()
 print('done', E, Eg)

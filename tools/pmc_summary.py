@@ -42,8 +42,15 @@ import os
 COMPACT = os.environ.get('PMC_COMPACT', '1') == '1'
 pk, bcacc = ('cacc_step_compact', 351) if COMPACT else ('cacc_step', 631)
 for key, part, E, balg in ((pk + '_E2p21', 'cacc_step_kernel<256', 1 << 21, bcacc), (pk + '_E4096', 'cacc_step_kernel<64', 4096, bcacc),
-                           ('grid_step_E2p17', 'grid_step_kernel', 1 << 17, 7548)):
-    s = stat(part)
+                           ('grid_step_E2p17', 'grid_step_kernel<1, false>', 1 << 17, 7548),
+                           ('grid_step_compact_E2p17', 'grid_step_kernel<1, true>', 1 << 17, 3708),
+                           # env 351 + fingerprints read 128 + encoded LSTM input written 8 x 128 x 4
+                           ('cacc_step_encode_E4096', 'cacc_step_encode_kernel', 4096, 351 + 128 + 4096)):
+    try:
+        s = stat(part)
+    except AssertionError as ex:
+        print('skipped', key, ex)
+        continue
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     s.update(replicas=E, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / E,
              algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / E / balg)
@@ -68,6 +75,16 @@ try:        # the whole reverse recurrence in one launch: "replica" = one (agent
     res['kernels']['lstm_bptt_seq_N8_E4096_T60'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no bptt_seq in this collection:', ex)
+try:        # the coupled nets' reverse recurrence in one launch (NeurComm, line graph): per (agent, replica, step) row gates 1024 +
+    # c 256 + dL/dh 256 + relu mask 256 + 2 neighbours' message slots 512 read; dz 1024 + d1 256 + message row 512 written
+    s = stat('lstm_bptt_coupled_kernel')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 8 * 4096 * 60
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=4096, traffic_over_algorithmic=traffic / rows / 4096)
+    res['kernels']['lstm_bptt_coupled_nc_N8_E4096_T60'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no bptt_coupled in this collection:', ex)
 json.dump(res, open('%s/%s_pmc_traffic.json' % (out_dir, tag), 'w'), indent=1)
 with open('%s/%s_pmc_traffic.md' % (out_dir, tag), 'w') as f:
     f.write('# HBM traffic of the env-step kernels (and the fused LSTM step) from rocprofv3 PMC passes\n\n'

@@ -195,8 +195,12 @@ class IA2C:
         KX = p.params[p.k_wx].shape[1]
         # one zero slab more than needed, so that [S | .] and the state sequences have the SAME (T + 1)-slab shape -- the
         # update's weight-gradient GEMMs then read the saved buffers in place (ops._lstm_seq_x_backward, agents/sequence.py)
-        self.S_ext = torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
-        self.S_buf = self.S_ext[:, :T]
+        if getattr(p, 'saved_ext', True):
+            self.S_ext = torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
+            self.S_buf = self.S_ext[:, :T]
+        else:                               # DIAL: its step-wise backward multiplies the contiguous [N, T*E, KX] view
+            self.S_ext = None
+            self.S_buf = torch.zeros(N, T, E, KX, dtype=F32, device=d)
         self.G_buf = torch.zeros(N, T, E, 4 * H, dtype=F32, device=d)
         self.H_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
@@ -287,6 +291,11 @@ class IA2C:
         # enc is shared by the policy step and the value re-step (Q1)
         if pre_encoded:             # the env kernel of the previous lock-step already encoded buf_x[t] / fp[t] into slot t
             enc = self.S_buf[:, t]
+        elif self.save_acts and 'ENC' in p._extra:
+            # nets whose encoder output is NOT the LSTM input itself (CommNet: s = enc + message term): kept per lock-step so
+            # that the update's encoder backward needs no forward pass
+            enc = p.encode(self.buf_x[t], self.fp, out=p._extra['ENC'][:, t])
+            p._enc_was_saved = True
         else:
             enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)

@@ -758,11 +758,19 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         s = enc + torch.baddbmm(p['w_msg_b'].unsqueeze(1), mm, p['w_msg'])
         return torch.bmm(s, p['wx_hid'])
 
+    def save_spec(self):
+        return {'ENC': self.n_h}             # tanh(x~ W_ob + b) of every lock-step: the update's encoder backward needs no forward pass
+
     def _enc_saved(self, xv, fp, S):
-        return self._enc(xv, fp)             # tanh(x~ W_ob + b): recomputed (one streaming pass), only the recurrence is saved
+        enc = getattr(self, '_extra', {}).get('ENC')
+        if enc is None or not self._enc_was_saved:
+            return self._enc(xv, fp)         # recomputed (one streaming pass)
+        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b')], ops.BIAS_TANH, saved=enc.view(self.N, -1, self.n_h))
+
+    _enc_was_saved = False
 
     def _enc_infer(self, xv, fp, out=None):
-        return self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH)
+        return self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_TANH, out=out)
 
     def _x_target(self, h, second, save):
         """Where the LSTM input of this step goes: the slot of the saved activations (policy step of the batched
@@ -839,6 +847,7 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     s_i = relu(x~_i W_ob) + relu([mfc_j(h_j) for j in nbr(i)] W_msg) + onehot_H(argmax pi_i(t-1)) -> LSTM(H);
     the message encoder mfc_j = relu(h_j W + b) acts on the sender's un-masked previous h."""
     name = 'dial'
+    saved_ext = False             # the saved LSTM inputs stay a plain [N,T,E,KX] buffer (agents/sequence.py: step-wise backward)
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     k_ob = 'w_ob'
     coupled = True

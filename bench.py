@@ -130,9 +130,10 @@ def measure_lstm_step(model, n=60, reps=10):
     h, c = torch.randn(N, E, H, device=dev) * 0.3, torch.randn(N, E, H, device=dev) * 0.3
     done = torch.zeros(E, device=dev)
     wh, b = p.params[p.k_wh], p.params[p.k_b]
+    if p.can_save_acts:
+        p.refresh_wimage()
     if p.can_save_acts and p.fused_pv:
         KX = p.params[p.k_wx].shape[1]
-        p.refresh_wimage()
         x = torch.relu(torch.randn(N, E, KX, device=dev))
         pi, act, v = torch.empty(N, E, A, device=dev), torch.zeros(E, N, dtype=torch.uint8, device=dev), torch.empty(N, E, device=dev)
         gates = torch.empty(N, E, 4 * H, device=dev)
@@ -146,10 +147,27 @@ def measure_lstm_step(model, n=60, reps=10):
         # read x, h, c; write h', c', gates, pi, v, action
         nbytes = N * E * ((KX + 2 * H) * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
         name = 'lstm_step_x_kernel<3> (nmarl_lstm_step_x, policy + value heads)'
+    elif p.can_save_acts and p.pv_one_launch(E):
+        # coupled nets, one launch per lock-step: policy step (message term in the pre-phase), in-launch hand-off of the new h,
+        # value re-step from the kept x-side part + the re-computed message columns + the new h (head kind 3 + message term)
+        KX = p.params[p.k_wx].shape[1]
+        Km = p.params['w_msg'].shape[1]
+        enc = p.encode(model.buf_x[0], model.fp)
+        pi, act, v = torch.empty(N, E, A, device=dev), torch.zeros(E, N, dtype=torch.uint8, device=dev), torch.empty(N, E, device=dev)
+        gates = torch.empty(N, E, 4 * H, device=dev)
+        ho, co = torch.empty_like(h), torch.empty_like(c)
+
+        def body():
+            for _ in range(n):
+                p.step_policy_value(enc, h, c, done, pi, act, v, h_out=ho, c_out=co, gates=gates, defer_action_term=True,
+                                    mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0)
+        flops = N * E * (2 * (KX + H) * 4 * H + 2 * (2 * H) * 4 * H + 2 * 2 * Km * H)
+        # read x (KX - 64 gathered columns), own h, c, the neighbours' h (old, then new); write h', c', gates, message term, pi, v, action
+        nbytes = N * E * ((KX - H + 2 * H) * 4 + 2 * Km * 4 + 2 * H * 4 + 4 * H * 4 + H * 4 + A * 4 + 4 + 1)
+        name = 'lstm_step_x_kernel<4,%d> (nmarl_lstm_step_x_msg, policy + value of the coupled net in one launch)' % p.msg_kind
     elif p.can_save_acts:
         # coupled nets: the policy step (kind 1) with the message term computed in its pre-phase where it fits
         KX = p.params[p.k_wx].shape[1]
-        p.refresh_wimage()
         enc = p.encode(model.buf_x[0], model.fp)
         pi, act = torch.empty(N, E, A, device=dev), torch.zeros(E, N, dtype=torch.uint8, device=dev)
         gates = torch.empty(N, E, 4 * H, device=dev)
@@ -199,7 +217,7 @@ def measure_lstm_step_in_rollout(trainer, reps=5):
     launch stream; (t_full - t_without) / launches.  Eager event pairs around single launches do not work here: the
     eager rollout is host-bound, the stream idles between launches and the pairs time the host.  State restored after."""
     pol = trainer.model.policy
-    names = ['step_policy_value'] if pol.fused_pv else ['step_policy', 'step_value']
+    names = ['step_policy_value'] if pol.pv_one_launch(trainer.model.E) else ['step_policy', 'step_value']
     n_launch = (trainer.n_step + 1) * len(names)
 
     def timed(skip):
@@ -454,6 +472,8 @@ def main():
     # NMARL_BENCH_FORCE_DIST=1 creates the process group (and the gradient all-reduce) even for one rank
     if os.environ.get('NMARL_BENCH_ONE_DEVICE') == '1':
         local_rank = 0
+        if world > 1:       # ranks sharing a device: their blocks are not co-resident, no in-launch hand-off (ops.step_handoff_supported)
+            os.environ['NMARL_INKERNEL_HANDOFF'] = '0'
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     group = None

@@ -53,7 +53,7 @@ class Msg(C.Structure):
     _fields_ = [('kind', C.c_int32), ('m_max', C.c_int32), ('K', C.c_int32), ('pad_', C.c_int32), ('nbr_idx', C.c_void_p),
                 ('img', C.c_void_p), ('img_sn', C.c_int64), ('b', C.c_void_p), ('b_sn', C.c_int64),
                 ('enc', C.c_void_p), ('enc_sn', C.c_int64), ('enc_row', C.c_int64),
-                ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64)]
+                ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64), ('sync', C.c_void_p)]
 
 
 class NetParams(C.Structure):
@@ -151,6 +151,7 @@ SIGNATURES = {
     'nmarl_lstm_step_x': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p,
                           _i64, _p, _i64, _p, _i64, C.POINTER(Head), _p],
     'nmarl_lstm_msg_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p],
+    'nmarl_lstm_step_sync_words': [_i64, _i32],
     'nmarl_lstm_step_x_msg': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
                               C.POINTER(Head), C.POINTER(Msg), _p],
     'nmarl_lstm_bptt_wimage_floats': [_i32],

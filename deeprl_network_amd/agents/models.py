@@ -299,12 +299,14 @@ class IA2C:
         else:
             enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
-        if self.save_acts and p.fused_pv:
+        if self.save_acts and p.pv_one_launch(self.E):
             # the policy step reads slot t of the state sequences and writes slot t + 1, gates into G[:, t]; the value
-            # (critic's h part) goes to the agent-major buffer, its neighbour-action term is added in update()
+            # (critic's h part) goes to the agent-major buffer, its neighbour-action term is added in update().  Coupled nets:
+            # the policy step's message terms go to their save slots, the re-step's come from the new states of ALL agents
             p.step_policy_value(enc, self.H_all[:, t], self.C_all[:, t], done, self.buf_fp[t + 1], self.buf_act[t],
                                 self.buf_vn[:, t], h_out=self.H_all[:, t + 1], c_out=self.C_all[:, t + 1],
-                                gates=self.G_buf[:, t], defer_action_term=True, **draw)
+                                gates=self.G_buf[:, t], defer_action_term=True,
+                                **(dict(save=self._save_slots(t)) if p.coupled else {}), **draw)
             return self.buf_act[t]
         if self.save_acts:
             # coupled nets: policy step (saves its message terms, gates, states), then the value re-step from the new
@@ -350,7 +352,7 @@ class IA2C:
         assert self.t == self.n_step
         p = self.policy
         enc = self.encode_target(self.n_step) if pre_encoded else p.encode(self.buf_x[self.n_step], self.fp)
-        if self.save_acts and p.fused_pv:                   # from slot T of the sequences into the persistent state
+        if self.save_acts and p.pv_one_launch(self.E):     # from slot T of the sequences into the persistent state
             T = self.n_step
             p.step_policy_value(enc, self.H_all[:, T], self.C_all[:, T], done, self._pi_boot, action_scratch, self._v_boot,
                                 h_out=self.h_fw, c_out=self.c_fw, mode=mode, u=u, seed=seed, env_id_base=env_id_base,
@@ -410,7 +412,7 @@ class IA2C:
         cur_lr = self.lr_scheduler.get(self.n_step)
         alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
         T = self.n_step
-        if self.save_acts and self.policy.fused_pv:
+        if self.save_acts and self.policy.pv_one_launch(self.E):
             # the critic's neighbour-action term of all T lock-steps in one launch (policies.py:59-77), then the values
             # in the [T,N,E] order the return scan reads
             with torch.no_grad():

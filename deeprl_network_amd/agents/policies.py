@@ -369,13 +369,37 @@ class BatchedPolicy:
         cross-agent term (the value re-step of a coupled net needs the other agents' new h)."""
         return self.fused_heads and not self.coupled
 
+    @property
+    def fused_pv_coupled(self):
+        """forward('p') and forward('v') of a lock-step in ONE kernel for a COUPLED net: the message term is computed inside
+        the step kernel and the blocks hand their new h over inside the launch (ops.step_handoff_supported).  Decided per
+        call site (the number of replicas matters): `pv_one_launch(E)`."""
+        return self.coupled and self.fused_heads and self._msg() is not None
+
+    def pv_one_launch(self, E):
+        if self.fused_pv:
+            return True
+        return self.fused_pv_coupled and ops.step_handoff_supported(self.N, E, self.device)
+
+    _sync = None
+
+    def _sync_words(self, E):
+        if self._sync is None or self._sync_E != E:
+            self._sync, self._sync_E = ops.step_sync_words(self.N, E, self.device), E
+        return self._sync
+
     def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, h_out=None, c_out=None, gates=None,
-                          defer_action_term=False, **draw):
-        """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) for uncoupled nets:
+                          defer_action_term=False, save=None, **draw):
+        """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) in one kernel:
         advances (h, c) by the policy step -- in place, or into (h_out, c_out) with the gates saved for the update --;
-        the value comes from the re-stepped copy (quirk Q1)."""
+        the value comes from the re-stepped copy (quirk Q1).  Coupled nets (`pv_one_launch`): never in place; `save`
+        as in step_policy (the POLICY step's message term is what the update needs)."""
         with torch.no_grad():
-            z1, z2, xs = self._recur_addends(enc, h)
+            if self.coupled:
+                z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
+                xs[4]['sync'] = self._sync_words(h.shape[1])
+            else:
+                z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
             ops.lstm_step_policy_value(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, p['pi_w'], p['pi_b'], pi_out, act_out,
                                        p['v_w'], p['v_b'], self.nbr_idx, self.n_a, v_out, xs=xs, h_out=h_out, c_out=c_out,

@@ -11,6 +11,7 @@
 // lstm_step_x_kernel (the x-side product s @ Wx is computed here as well: K = KX + 64, nothing of the pre-activation
 // ever exists in HBM).  fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -56,6 +57,14 @@ constexpr int WAVES2 = 8;
 constexpr int WPITCH = 16 * 20;         // floats per k row of the permuted W image
 constexpr int LDS2_FLOATS = H * WPITCH + WAVES2 * R16 * APITCH;
 
+#ifdef NMARL_STEP_TIMELINE      // instrumentation build (tools/step_timeline.py): shader-clock stamps of block 0's waves
+__device__ unsigned long long* g_timeline = nullptr;
+__global__ void timeline_set_kernel(unsigned long long* p) { g_timeline = p; }
+#define NMARL_STAMP(i) if (g_timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_timeline[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define NMARL_STAMP(i)
+#endif
+
 // Head epilogue of one wave: its 16 fresh rows of h' sit in the wave's (now idle) LDS tile.  Lane
 // (row = lane & 15, quarter = lane >> 4) accumulates the quarter's 16 k of every output, two xor-shuffles
 // finish the 64-long dots; lanes 0..15 then own one row each: softmax + action draw (kind 1) or the
@@ -100,11 +109,13 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
             }
         }
     }
+    if (KIND == 3) { NMARL_STAMP(34) }
 #pragma unroll
     for (int o = 0; o < (KIND == 1 ? MAXA : 1); ++o) {
         acc[o] += __shfl_xor(acc[o], 16, 64);
         acc[o] += __shfl_xor(acc[o], 32, 64);
     }
+    if (KIND == 3) { NMARL_STAMP(35) }
     const int64_t row = row0 + rl;
     if (q != 0 || row >= a.E) return;
     const float* b = KIND == 3 ? hd.b2 + (int64_t)n * hd.b2_sn : hd.b + (int64_t)n * hd.b_sn;
@@ -467,7 +478,18 @@ struct XArgs {
     const float* msg_b; int64_t msg_b_sn;         // [N, 64]
     const float* enc; int64_t enc_sn, enc_row;    // MSG 2: the additive h-independent part of the input [N,E,64]
     float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
+    unsigned* sync;               // HEAD 4: [0] generation, [1] blocks finished, [2] error, [16 + (agent, block, wave)] flags
 };
+
+// raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
+// L1-bypassing loads carry the sc1 bit; stores take their offset in a VGPR, never in the scalar-offset field)
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
+typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr int SC1 = 16;
+constexpr unsigned HANDOFF_MAX_SPINS = 1u << 20;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, const uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
 
 // one k-step: 16 MFMAs (all column tiles) with the A value `av` and the B operands in four float4 registers
 #define NMARL_MFMA16(av, b0, b1, b2, b3)                                                  \
@@ -525,13 +547,6 @@ struct XArgs {
 // A pre-phase on the matrix cores ([16 rows x K_m] @ [K_m x 64], A operands gathered from global memory, W_msg from an
 // LDS image staged behind the chunk buffers); its result goes through the wave's LDS tile into A layout, where the
 // main K loop picks it up as its last two x chunks, and (policy step) to global memory for the update's backward.
-#ifdef NMARL_STEP_TIMELINE      // instrumentation build (tools/step_timeline.py): shader-clock stamps of block 0's waves
-__device__ unsigned long long* g_timeline = nullptr;
-__global__ void timeline_set_kernel(unsigned long long* p) { g_timeline = p; }
-#define NMARL_STAMP(i) if (g_timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_timeline[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime();
-#else
-#define NMARL_STAMP(i)
-#endif
 
 template <int HEAD, int MSG>
 __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
@@ -543,6 +558,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = row_blk + wave * R16;
     const int c = lane & 15, grp = lane >> 4;
+    static_assert(HEAD != 4 || MSG != 0, "HEAD 4 is the coupled nets' policy + value step");
+    constexpr bool PV = HEAD == 3 || HEAD == 4;          // policy step + value re-step in this launch
+    unsigned epoch = 0;                                  // HEAD 4: this launch's flag value (generation + 1)
+    if (HEAD == 4)
+        epoch = __builtin_amdgcn_readfirstlane(__hip_atomic_load((gu32*)xa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
     // De-phased wave groups (no message pre-phase only: LDS): waves 4-7 run ONE chunk behind waves 0-3 through a ring
     // of three chunk buffers, so that on every SIMD one wave's VALU epilogue / head overlaps the other's MFMAs instead
     // of both epilogues running side by side with an idle matrix pipe.
@@ -658,7 +678,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             const int k = threadIdx.x >> 3, o = threadIdx.x & 7;               // 512 threads = 64 x 8
             hw_lds[threadIdx.x] = o < A ? w1[k * A + o] : 0.0f;
             if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = threadIdx.x < A ? (hd.b + (int64_t)n * hd.b_sn)[threadIdx.x] : 0.0f;
-            if (HEAD == 3) {
+            if (PV) {
                 const float* w2 = hd.w2 + (int64_t)n * hd.w2_sn;
                 if (threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = w2[threadIdx.x];
             }
@@ -671,56 +691,108 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     }
     __syncthreads();
     NMARL_STAMP(1)
-    if (MSG != 0) {
+    // The message pre-phase.  second_c = true_type: the VALUE re-step's message term (HEAD 4), from the neighbours' NEW h (h_new,
+    // written through by their blocks earlier in this launch: L1-bypassing loads); nothing of it is kept.
+    auto msg_phase = [&](auto second_c) {
+        constexpr bool SECOND = decltype(second_c)::value;
         f32x4 macc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) macc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* hbase = a.h_in + arow * H + 4 * grp;            // + j * h_sn: row `arow` of agent j
+        const float* hsrc = SECOND ? a.h_new : a.h_in;
+        const int64_t hsn = SECOND ? a.h_new_sn : a.h_sn;
+        const float* hbase = hsrc + arow * H + 4 * grp;              // + j * hsn: row `arow` of agent j
+        const uint32_t hoff = (uint32_t)((arow * H + 4 * grp) * 4), hbytes = (uint32_t)(a.E * (H * 4));
+        auto load2 = [&](const int jj, const int col, float4& u0, float4& u1) {
+            if (SECOND) {
+                const __amdgpu_buffer_rsrc_t r_ = make_rsrc(hsrc + (int64_t)jj * hsn, hbytes);
+                u0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_, hoff + col * 4, 0, SC1));
+                u1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_, hoff + col * 4 + 64, 0, SC1));
+            } else {
+                const float* p_ = hbase + (int64_t)jj * hsn + col;
+                u0 = *reinterpret_cast<const float4*>(p_);
+                u1 = *reinterpret_cast<const float4*>(p_ + 16);
+            }
+        };
         const int32_t* nb = xa.nbr_idx + n * xa.m_max;
-        float inv = 0.0f;
-        if (MSG == 2) {
+        // Every neighbour row this wave needs is requested BEFORE the first product: one exposed load latency per phase
+        // instead of one per chunk and neighbour (the loads were ~2/3 of the pre-phase).  Absent slots read the own row
+        // with weight 0 -- no load sits inside a branch.
+#define NMARL_MSTEP(av, kl)                                                                    \
+        {                                                                                      \
+            const float4 b_ = *reinterpret_cast<const float4*>(mb + (kl) * 64);                \
+            macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.x, macc[0], 0, 0, 0);        \
+            macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.y, macc[1], 0, 0, 0);        \
+            macc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.z, macc[2], 0, 0, 0);        \
+            macc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.w, macc[3], 0, 0, 0);        \
+        }
+#define NMARL_MCHUNK(kc, m0, m1)                                                               \
+        {                                                                                      \
+            const float* mb = m_lds + (((kc) * CH_K + 4 * grp) * 16 + c) * 4;  /* + kl * 64 floats per k row */ \
+            NMARL_MSTEP(m0.x, 0) NMARL_MSTEP(m0.y, 1) NMARL_MSTEP(m0.z, 2) NMARL_MSTEP(m0.w, 3)  \
+            NMARL_MSTEP(m1.x, 16) NMARL_MSTEP(m1.y, 17) NMARL_MSTEP(m1.z, 18) NMARL_MSTEP(m1.w, 19) \
+        }
+        if (MSG == 1) {                     // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
+            float4 mm[4][2];
+            float wsl[2];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int j = nb[sl < xa.m_max ? sl : 0];
+                const bool ok = sl < xa.m_max && j >= 0;
+                wsl[sl] = ok ? 1.0f : 0.0f;
+                load2(ok ? j : n, 0, mm[2 * sl][0], mm[2 * sl][1]);
+                load2(ok ? j : n, CH_K, mm[2 * sl + 1][0], mm[2 * sl + 1][1]);
+            }
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                if (kc < xa.msg_kc) {
+                    const float w = wsl[kc >> 1];
+                    float4 m0 = mm[kc][0], m1 = mm[kc][1];
+                    m0.x *= w; m0.y *= w; m0.z *= w; m0.w *= w; m1.x *= w; m1.y *= w; m1.z *= w; m1.w *= w;
+                    NMARL_MCHUNK(kc, m0, m1)
+                }
+            }
+        } else {                            // mean over the existing neighbours (K_m = 64: two chunks), four neighbours per round
             int cnt = 0;
             for (int k = 0; k < xa.m_max; ++k) cnt += nb[k] >= 0;
-            inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
-        }
-        for (int kc = 0; kc < xa.msg_kc; ++kc) {
-            float4 m0, m1;
-            if (MSG == 1) {                 // chunk kc = half (kc & 1) of neighbour slot (kc >> 1); absent slot: zeros
-                const int j = nb[kc >> 1];
-                const float w = j >= 0 ? 1.0f : 0.0f;
-                const float* p_ = hbase + (int64_t)(j >= 0 ? j : n) * a.h_sn + (kc & 1) * CH_K;
-                m0 = *reinterpret_cast<const float4*>(p_);
-                m1 = *reinterpret_cast<const float4*>(p_ + 16);
-                m0.x *= w; m0.y *= w; m0.z *= w; m0.w *= w; m1.x *= w; m1.y *= w; m1.z *= w; m1.w *= w;
-            } else {                        // mean over the existing neighbours
-                m0 = float4{0.f, 0.f, 0.f, 0.f}; m1 = m0;
-                for (int k = 0; k < xa.m_max; ++k) {
-                    const int j = nb[k];
-                    const float w = j >= 0 ? 1.0f : 0.0f;
-                    const float* p_ = hbase + (int64_t)(j >= 0 ? j : n) * a.h_sn + kc * CH_K;
-                    const float4 u0 = *reinterpret_cast<const float4*>(p_), u1 = *reinterpret_cast<const float4*>(p_ + 16);
-                    m0.x += w * u0.x; m0.y += w * u0.y; m0.z += w * u0.z; m0.w += w * u0.w;
-                    m1.x += w * u1.x; m1.y += w * u1.y; m1.z += w * u1.z; m1.w += w * u1.w;
+            const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
+            float4 sm[2][2];
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) sm[kc][0] = sm[kc][1] = float4{0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < xa.m_max; k0 += 4) {
+                float4 u[4][2][2];
+                float w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = k0 + q;
+                    const int j = nb[k < xa.m_max ? k : 0];
+                    const bool ok = k < xa.m_max && j >= 0;
+                    w[q] = ok ? 1.0f : 0.0f;
+                    load2(ok ? j : n, 0, u[q][0][0], u[q][0][1]);
+                    load2(ok ? j : n, CH_K, u[q][1][0], u[q][1][1]);
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            sm[kc][hh].x += w[q] * u[q][kc][hh].x; sm[kc][hh].y += w[q] * u[q][kc][hh].y;
+                            sm[kc][hh].z += w[q] * u[q][kc][hh].z; sm[kc][hh].w += w[q] * u[q][kc][hh].w;
+                        }
+            }
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                float4 m0 = sm[kc][0], m1 = sm[kc][1];
                 m0.x *= inv; m0.y *= inv; m0.z *= inv; m0.w *= inv; m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
+                NMARL_MCHUNK(kc, m0, m1)
             }
-            const float* mb = m_lds + ((kc * CH_K + 4 * grp) * 16 + c) * 4;      // + kl * 64 floats per k row
-#define NMARL_MSTEP(av, kl)                                                                    \
-            {                                                                                  \
-                const float4 b_ = *reinterpret_cast<const float4*>(mb + (kl) * 64);            \
-                macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.x, macc[0], 0, 0, 0);    \
-                macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.y, macc[1], 0, 0, 0);    \
-                macc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.z, macc[2], 0, 0, 0);    \
-                macc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.w, macc[3], 0, 0, 0);    \
-            }
-            NMARL_MSTEP(m0.x, 0) NMARL_MSTEP(m0.y, 1) NMARL_MSTEP(m0.z, 2) NMARL_MSTEP(m0.w, 3)
-            NMARL_MSTEP(m1.x, 16) NMARL_MSTEP(m1.y, 17) NMARL_MSTEP(m1.z, 18) NMARL_MSTEP(m1.w, 19)
-#undef NMARL_MSTEP
         }
+#undef NMARL_MCHUNK
+#undef NMARL_MSTEP
         // result (C layout) + bias, relu / + enc -> the wave's LDS tile (A layout source) and, if asked, global memory
         const float* mbias = xa.msg_b + (int64_t)n * xa.msg_b_sn;
         const float* encn = MSG == 2 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
-        float* xo = xa.xm_out ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
+        float* xo = (!SECOND && xa.xm_out) ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const float bv = mbias[16 * t + c];
@@ -736,13 +808,25 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        NMARL_A_LOAD(0, a0, a1)
-    }
-
+    };
     float keepr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) keepr[r] = 1.0f - a.done[rofs[r]];
-    f32x4 zs[HEAD == 3 ? 16 : 1];
+    if (MSG != 0) {
+        // chunk 0's A operands when they come from global memory (nx > 2: lstm_comm's [hx | hp] columns): requested BEFORE the
+        // pre-phase, unconditionally (a valid dummy row otherwise), so their latency hides behind it
+        const float* p0_ = nx > 2 ? xrow : hrow;
+        a0 = *reinterpret_cast<const float4*>(p0_);
+        a1 = *reinterpret_cast<const float4*>(p0_ + 16);
+        msg_phase(std::false_type{});
+        if (nx <= 2) {                      // chunk 0 is a message chunk: from the wave's LDS tile
+            const float* t_ = a_tile + c * APITCH + 4 * grp;
+            a0.x = t_[0]; a0.y = t_[1]; a0.z = t_[2]; a0.w = t_[3];
+            a1.x = t_[16]; a1.y = t_[17]; a1.z = t_[18]; a1.w = t_[19];
+        }
+    }
+
+    f32x4 zs[PV ? 16 : 1];
     NMARL_A_MASK(0, a0, a1)
     const int lag = DEPH ? (wave >> 2) : 0;      // wave group B computes chunk tau - 1 in tick tau
     if (DEPH && lag) __builtin_amdgcn_s_setprio(1);   // the lagging (younger) group wins issue arbitration: its MFMAs are
@@ -757,7 +841,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const int chn = ch + 1 < nch ? ch + 1 : nch - 1;
         NMARL_A_LOAD(chn, n0, n1)
         if (ch >= 0) {
-            if (HEAD == 3 && ch == nx) {        // x-side part complete: the value re-step adds the SAME addend
+            if ((HEAD == 3 && ch == nx) || (HEAD == 4 && ch == nx - 2)) {
+                // x-side part complete: the value re-step adds the SAME addend (HEAD 4: all of it but the message columns)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) zs[t] = acc[t];
             }
@@ -801,12 +886,48 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
             const float cv = gf * (cp[jj][r] * keep) + gi * gu;
             const float hv = go * tanh_fast(cv);
-            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;
-            cp[jj][r] = cv;                                                        // c' (HEAD 3: the re-step's previous cell)
+            if (HEAD != 0 && HEAD != 4) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;
+            cp[jj][r] = cv;                                                        // c' (HEAD 3 / 4: the re-step's previous cell)
             hv_[jj][r] = hv;
             acc[0 + jj][r] = gi; acc[4 + jj][r] = gf; acc[8 + jj][r] = go; acc[12 + jj][r] = gu;
         }
     }
+    if (HEAD == 4) {
+        // Both chunk buffers hold Wh (the re-step needs them): the outputs are staged through the wave's own A tile (odd pitch:
+        // four 4-byte reads per 16-byte store, conflict-free), h' LAST -- it stays there for the heads and the re-step.
+        // h' is written THROUGH (sc1): the neighbours' blocks read it later in this launch.
+        const int srow = lane >> 4, sk4 = (lane & 15) * 4;
+        const __amdgpu_buffer_rsrc_t rh_ = make_rsrc(hn_out, (uint32_t)(a.E * (H * 4)));
+#define NMARL_STORE_TILE4(VAL, dst, pitch, WT)                                             \
+        {                                                                                  \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = VAL;   \
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         \
+            __builtin_amdgcn_wave_barrier();                                               \
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                         \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                 \
+                const int rr = 4 * i + srow;                                               \
+                const float* t_ = a_tile + rr * APITCH + sk4;                              \
+                const float4 v4 = float4{t_[0], t_[1], t_[2], t_[3]};                      \
+                if (WT) {                                                                  \
+                    const uint32_t o_ = (uint32_t)(((row0 + rr) * H + sk4) * 4);           \
+                    if (row0 + rr < a.E) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v4), rh_, o_, 0, SC1); \
+                } else if (row0 + rr < a.E) {                                              \
+                    *reinterpret_cast<float4*>((dst) + (row0 + rr) * (pitch) + sk4) = v4;  \
+                }                                                                          \
+            }                                                                              \
+            __builtin_amdgcn_wave_barrier();                                               \
+        }
+        NMARL_STORE_TILE4(cp[jj][r], cn, H, false)
+        if (gn) {
+            NMARL_STORE_TILE4(acc[0 + jj][r], gn, G4, false)
+            NMARL_STORE_TILE4(acc[4 + jj][r], gn + H, G4, false)
+            NMARL_STORE_TILE4(acc[8 + jj][r], gn + 2 * H, G4, false)
+            NMARL_STORE_TILE4(acc[12 + jj][r], gn + 3 * H, G4, false)
+        }
+        NMARL_STORE_TILE4(hv_[jj][r], hn_out, H, true)
+#undef NMARL_STORE_TILE4
+    } else
     {
         // free chunk buffer: de-phased groups -> the one holding neither Wh chunk; else any (all waves passed the last barrier)
         float* st = lds + (DEPH ? (nch % NBUF) : 0) * CH_FLOATS + wave * (R16 * SPITCH);
@@ -844,7 +965,22 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         else head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
     }
     NMARL_STAMP(22)
-    if (HEAD == 3) {
+    if (HEAD == 4) {
+        // ---- publish: this wave's 16 rows of h' are out (write-through stores drained), one flag per (agent, block, wave)
+        gu32* flags = (gu32*)(xa.sync + 16);
+        const int bpa = a.blocks_per_agent, blk = (int)(blockIdx.x / xa.N);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(flags + ((n * bpa + blk) * WAVES2 + wave), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the W chunks of the message columns: in flight while the h part of the re-step runs
+        NMARL_STAGE_LOAD(nx - 2)
+        {
+            const float4* g_ = img + (int64_t)(nx - 1) * (CH_FLOATS / 4) + threadIdx.x;
+            tg0 = g_[0]; tg1 = g_[512]; tg2 = g_[1024]; tg3 = g_[1536]; tg4 = g_[2048];
+        }
+        NMARL_STAMP(26)
+    }
+    if (PV) {
         // ---- the value re-step (quirk Q1): z = x-side addend + (h' keep) @ Wh from the two resident Wh chunks
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = zs[t];
@@ -859,6 +995,51 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         }
         NMARL_STAMP(23)
         __builtin_amdgcn_wave_barrier();                 // every lane has read its A operands: the tile may be overwritten
+        if (HEAD == 4) {
+            // ---- the message columns of the re-step: from the neighbours' NEW h, published by the same wave of their blocks
+            gu32* flags = (gu32*)(xa.sync + 16);
+            const int bpa = a.blocks_per_agent, blk = (int)(blockIdx.x / xa.N);
+            const int32_t* nb = xa.nbr_idx + n * xa.m_max;
+            bool give_up = false;
+            for (int k = 0; k < xa.m_max; ++k) {
+                const int j = nb[k];
+                if (j < 0 || give_up) continue;
+                gu32* f = flags + ((j * bpa + blk) * WAVES2 + wave);
+                for (unsigned spins = 0;; ++spins) {
+                    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (v == epoch) break;
+                    if (spins > HANDOFF_MAX_SPINS) {      // a neighbour's block is not running: not co-resident (see the launcher)
+                        if (lane == 0) __hip_atomic_store((gu32*)xa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        give_up = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            asm volatile("" ::: "memory");               // the payload loads stay below the polls
+            NMARL_STAMP(27)
+            msg_phase(std::true_type{});                 // -> the wave's A tile
+            NMARL_STAMP(28)
+            __syncthreads();                             // every wave is through with the Wh chunks
+            NMARL_STAGE_STORE(0)
+            {
+                float4* d_ = reinterpret_cast<float4*>(lds + CH_FLOATS) + threadIdx.x;
+                d_[0] = tg0; d_[512] = tg1; d_[1024] = tg2; d_[1536] = tg3; d_[2048] = tg4;
+            }
+            __syncthreads();
+            NMARL_STAMP(29)
+#pragma unroll
+            for (int mc = 0; mc < 2; ++mc) {
+                const float* buf = lds + mc * CH_FLOATS + (4 * grp * 16 + c) * 20;
+                const float* ar = a_tile + c * APITCH + mc * CH_K + 4 * grp;
+                float4 r0, r1;
+                r0.x = ar[0]; r0.y = ar[1]; r0.z = ar[2]; r0.w = ar[3];
+                r1.x = ar[16]; r1.y = ar[17]; r1.z = ar[18]; r1.w = ar[19];
+                NMARL_CHUNK(buf, r0, r1)
+            }
+            NMARL_STAMP(30)
+            __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -869,12 +1050,26 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 const float cv = gf * (cp[jj][r] * keep) + gi * gu;
                 a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = go * tanh_fast(cv);
             }
+        NMARL_STAMP(33)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         NMARL_STAMP(24)
         head_epilogue<3>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
         NMARL_STAMP(25)
+        if (HEAD == 4) {
+            // the last BLOCK of the launch to get here starts the next generation: no flag of this one is read any more
+            // (one counter update per block: same-address atomics serialise, 2048 of them cost the last waves ~8 us)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                gu32* sy = (gu32*)xa.sync;
+                const unsigned old = __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == gridDim.x - 1) {
+                    __hip_atomic_store(sy + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     }
 #undef NMARL_STAGE_LOAD
 #undef NMARL_STAGE_STORE
@@ -988,6 +1183,10 @@ extern "C" int nmarl_lstm_step_fused_head(int64_t E, int32_t N, int32_t Hh, cons
 
 extern "C" int nmarl_lstm_wimage_floats(int32_t KX) { return (KX + H) * 320; }
 
+extern "C" int nmarl_lstm_step_sync_words(int64_t E, int32_t N) {
+    return (int)(16 + (int64_t)N * ((E + ROWS_B - 1) / ROWS_B) * WAVES2);
+}
+
 extern "C" int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t wx_sn, const float* wh, int64_t wh_sn,
                                  float* img, int64_t img_sn, void* stream) {
     if (N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || !wh || !img || (KX > 0 && !wx) || img_sn < (int64_t)(KX + H) * 320 ||
@@ -1080,10 +1279,21 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         NMARL_SET_LDS((lstm_step_x_kernel<0, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 0>))
         NMARL_SET_LDS((lstm_step_x_kernel<3, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 1>))
         NMARL_SET_LDS((lstm_step_x_kernel<1, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 2>))
+        NMARL_SET_LDS((lstm_step_x_kernel<4, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2>))
 #undef NMARL_SET_LDS
         lds_once.done(lds_bit);
     }
-    if (mk && kind != 1 && kind != 2) return NMARL_EINVAL;      // the message pre-phase exists for the policy / value steps
+    if (mk && kind == 0) return NMARL_EINVAL;                   // the message pre-phase exists for the policy / value steps
+    const dim3 grid(a.blocks_per_agent * N);
+    if (mk && kind == 3) {
+        // policy step + value re-step of a coupled net in ONE launch: the re-step's message term needs the neighbours' new h, handed
+        // over between blocks inside the launch -- every block must be resident (one block per CU: 512 threads, > 80 KB LDS)
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return NMARL_EHIP;
+        if (!msg->sync || ((uintptr_t)msg->sync % 4) || (int)grid.x > cus || E * (int64_t)(H * 4) >= (int64_t)1 << 32) return NMARL_EINVAL;
+        xa.sync = msg->sync;
+    }
     if (mk) {
         // the pre-phase gathers OTHER agents' previous h while their blocks write h_new: no panel of h_new may overlap a
         // panel of h_in (in-place stepping is for nets without the in-kernel message term)
@@ -1096,14 +1306,13 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid(a.blocks_per_agent * N);
 #define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb, st, xa)
     if (mk == 0) {
         if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);
     } else if (mk == 1) {
-        if (kind == 1) NMARL_LX(1, 1); else NMARL_LX(2, 1);
+        if (kind == 1) NMARL_LX(1, 1); else if (kind == 2) NMARL_LX(2, 1); else NMARL_LX(4, 1);
     } else {
-        if (kind == 1) NMARL_LX(1, 2); else NMARL_LX(2, 2);
+        if (kind == 1) NMARL_LX(1, 2); else if (kind == 2) NMARL_LX(2, 2); else NMARL_LX(4, 2);
     }
 #undef NMARL_LX
     return nmarl_check_launch();

@@ -4,6 +4,7 @@ launches on torch's current HIP stream (so the rollout can be captured in a
 hipGraph) and raises if given CPU tensors -- there is no fallback path.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -221,6 +222,12 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             m.enc, m.enc_sn, m.enc_row = _rows_view(msg['enc'], H, what + ' enc')
         if msg.get('out') is not None:
             m.out, m.out_sn, m.out_row = _rows_view(msg['out'], H, what + ' msg out')
+        if head.kind == 3:                     # policy step + value re-step in one launch: the in-launch hand-off's flag words
+            sync = msg.get('sync')
+            if sync is None or sync.dtype != torch.int32 or sync.numel() < lib.nmarl_lstm_step_sync_words(E, N):
+                raise _lib.NmarlError('%s: head kind 3 with a message term needs msg["sync"] (step_sync_words)' % what)
+            m.sync = ptr(sync, torch.int32)
+            _step_sync_last[0] = sync
         check(lib.nmarl_lstm_step_x_msg(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
                                         *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
                                         C.byref(m), stream()), what)
@@ -228,6 +235,23 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
     check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, K2, x2p, x2_sn, x2_row, *_pn(h), ptr(img, F32), img.stride(0),
                                 *_bias(bias), *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
                                 *_pn(c_out), *_pn(h_out), None if head is None else C.byref(head), stream()), what)
+
+
+_step_sync_last = [None]
+
+
+def step_sync_words(N, E, device):
+    """Flag words of the coupled nets' one-launch policy + value step (msg['sync']): zeroed once, then owned by the kernel."""
+    return torch.zeros(lib.nmarl_lstm_step_sync_words(E, N), dtype=torch.int32, device=device)
+
+
+def step_handoff_supported(N, E, device):
+    """The coupled nets' policy step and value re-step fit ONE launch (blocks hand the new h over inside it): every block
+    must be resident, i.e. N * ceil(E / 128) <= compute units.  NMARL_INKERNEL_HANDOFF=0 keeps the two launches (e.g. when
+    several processes share one device: blocks of different processes are not co-resident by construction)."""
+    if os.environ.get('NMARL_INKERNEL_HANDOFF', '1') == '0' or torch.device(device).type != 'cuda':
+        return False
+    return N * ((E + 127) // 128) <= torch.cuda.get_device_properties(device).multi_processor_count
 
 
 def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=None):
@@ -312,7 +336,9 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     """forward('p') AND forward('v') of one lock-step (quirk Q1) for nets without a cross-agent recurrence: one MFMA
     kernel (policy step + pi + draw, then the value re-step from the new state with the same addend and the critic on
     h'') + the critic's neighbour-action term, which needs all agents' draws, added by one small launch (unless
-    `defer_action_term`: the caller adds it later for many lock-steps at once).  The state (h, c) [N,E,64] is advanced
+    `defer_action_term`: the caller adds it later for many lock-steps at once).  Coupled nets (xs carries a message term
+    with msg['sync'], see step_handoff_supported): the re-step's message term comes from the neighbours' NEW h, handed over
+    between the blocks inside the launch; h_out must not alias h.  The state (h, c) [N,E,64] is advanced
     by the policy step only -- in place, or into (h_out, c_out) (slots of the update's sequence buffers); `gates`
     [N,E,4H] receives the policy step's gates (x-side mode only).  v_out [N,E] with unit column stride."""
     N, E, H = h.shape
@@ -802,6 +828,8 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
     H = H4 // 4
     K = H * m_max if kind == COUPLED_NC else H
     img, img_m = ws[2], wm[1]
+    if mode == 0 and os.environ.get('NMARL_INKERNEL_HANDOFF', '1') == '0':
+        mode = 2                              # the device is shared with other processes: step-wise launches (see step_handoff_supported)
     for x, w_, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (dHs, H, 'dh_ext'), (D1, H, 'd1')):
         if x.stride(3) != 1 or x.stride(2) != w_:
             raise ValueError('bptt_coupled: %s must have contiguous rows' % what)
@@ -842,6 +870,9 @@ def check_coupled_status():
     last = _coupled_last[0]
     if last is not None and int(last[0][last[1]].item()) != 0:
         raise _lib.NmarlError('nmarl_lstm_bptt_coupled: a wave timed out waiting for a neighbour block (results invalid)')
+    sync = _step_sync_last[0]
+    if sync is not None and int(sync[2].item()) != 0:
+        raise _lib.NmarlError('nmarl_lstm_step_x_msg[pv]: a wave timed out waiting for a neighbour block (results invalid)')
 
 
 class _LstmCell(torch.autograd.Function):

@@ -393,6 +393,13 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
  * computed columns are stored for the update's backward ([N,E,64] view, row pitch out_row).  head: kind 1 or 2.
  * NO ALIASING: the pre-phase reads the other agents' panels of h_in while their blocks write h_new, so no [E,64] panel
  * of h_new may overlap a panel of h_in (NMARL_EINVAL otherwise); step in place only without the in-kernel message term.
+ * head kind 3 (policy step AND the value re-step of quirk Q1 in one launch, Trainer._get_policy + _get_value,
+ * utils.py:129-149): the re-step's message term is computed from the neighbours' NEW h, which their blocks hand over
+ * inside the launch (write-through stores + one flag per wave, lstm_mfma.hip).  Needs msg->sync: a buffer of
+ * nmarl_lstm_step_sync_words(E, N) 32-bit words the caller zeroes once and then leaves alone (word 2 becomes non-zero
+ * if a block ever waited in vain, i.e. the launch shared the device with other work); every block must be resident, so
+ * N * ceil(E / 128) may not exceed the number of compute units (NMARL_EINVAL otherwise: use the two launches).  v_out
+ * receives the critic's h part only (as nmarl_lstm_step_x with kind 3); gates / c_new / h_new / out are the POLICY step's.
  */
 typedef struct nmarl_msg {
     int32_t kind, m_max, K, pad_;
@@ -401,8 +408,10 @@ typedef struct nmarl_msg {
     const float* b; int64_t b_sn;
     const float* enc; int64_t enc_sn, enc_row;
     float* out; int64_t out_sn, out_row;
+    uint32_t* sync;     /* head kind 3 only: nmarl_lstm_step_sync_words(E, N) words, zeroed ONCE by the caller */
 } nmarl_msg_t;
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
+int nmarl_lstm_step_sync_words(int64_t E, int32_t N);
 int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t H, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
                           const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
                           int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,

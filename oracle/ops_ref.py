@@ -152,6 +152,17 @@ def msg_supported(kind, m_max, n_h):
     return n_h == FUSED_H and m_max <= 8 and (n_h * m_max if kind == MSG_GATHER_RELU else n_h) <= 128
 
 
+def step_sync_words(N, E, device):
+    return torch.zeros(16, dtype=torch.int32)
+
+
+def step_handoff_supported(N, E, device):
+    """The product's one-launch policy + value step of coupled nets is a kernel-side arrangement; the restatement runs the
+    two steps one after the other either way.  NMARL_INKERNEL_HANDOFF=0 selects the host code of the two-launch path."""
+    import os
+    return os.environ.get('NMARL_INKERNEL_HANDOFF', '1') != '0'
+
+
 def lstm_msg_wimage(w_msg, out=None):
     return torch.zeros(w_msg.shape[0], 1) if out is None else out
 
@@ -288,10 +299,16 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     """Trainer._get_policy + _get_value of one lock-step (utils.py:129-149): forward('p') advances the state, forward('v')
     re-steps a COPY of it (policies.py:119-133, quirk Q1)."""
     h_out, c_out = (h if h_out is None else h_out), (c if c_out is None else c_out)
+    xs_p = xs
+    if xs is not None and len(xs) > 4 and xs[4] is not None:
+        # coupled net: only the POLICY step's message term is kept (`out`); the re-step's comes from the new h of all agents
+        xs = tuple(xs[:4]) + ({k: v for k, v in xs[4].items() if k != 'out'},)
     if gates is not None:
         lstm_step_fused(h, wh, bias, zadd1, zadd2, c, done, gates, torch.empty_like(c), torch.empty_like(h), xs=xs)
+        if xs_p is not xs:                   # the step below writes (h_out, c_out); the message term needs the OLD h of all agents
+            assert h_out.data_ptr() != h.data_ptr()
     lstm_step_policy(h, wh, bias, zadd1, zadd2, c, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode, u=u, seed=seed,
-                     env_id_base=env_id_base, step=step, step_dev=step_dev, xs=xs)
+                     env_id_base=env_id_base, step=step, step_dev=step_dev, xs=xs_p)
     if defer_action_term:      # only the h part of the critic: v = h'' @ w[:H] + b
         H = h.shape[-1]
         hv, cv = torch.empty_like(h), torch.empty_like(c)

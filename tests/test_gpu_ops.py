@@ -909,6 +909,28 @@ def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
                         xs=(slot[:, :, :KXg] if KXg else None, None, img, None, dict(msg_g, out=None)))
     torch.testing.assert_close(vg.cpu().double(), vr, rtol=2e-4, atol=5e-5)
     assert torch.equal(slot, keep)
+    # both steps in ONE launch (head kind 3 + message term: the blocks hand their new h over inside the launch): the policy half
+    # bit-equal to the separate policy step, the value equal to the separate value step up to the order of its sums; repeated
+    # calls on the same flag words (generations)
+    if not ops.step_handoff_supported(N, E, 'cuda'):
+        return
+    sync = ops.step_sync_words(N, E, 'cuda')
+    for rep in range(3):
+        slot1 = torch.zeros(N, E, KX, device='cuda')
+        if KXg:
+            slot1[:, :, :KXg].copy_(xg)
+        h1, c1, g1 = torch.zeros_like(hg), torch.zeros_like(cg), torch.zeros_like(gg)
+        pi1, act1, v1 = torch.zeros_like(pig), torch.zeros_like(actg), torch.zeros(N, E, device='cuda')
+        msg1 = dict(msg_g, out=slot1[:, :, KXg:], sync=sync)
+        ops.lstm_step_policy_value(cu(h), None, cu(b), None, None, cu(c), cu(done), cu(pi_w), cu(pi_b), pi1, act1, cu(v_w), cu(v_b),
+                                   cu(idx), A, v1, xs=(slot1[:, :, :KXg] if KXg else None, None, img, None, msg1), h_out=h1, c_out=c1,
+                                   gates=g1, **draw)
+        ops.check_coupled_status()
+        assert torch.equal(h1, hg) and torch.equal(c1, cg) and torch.equal(g1, gg), rep
+        assert torch.equal(pi1, pig) and torch.equal(act1, actg) and torch.equal(slot1, slot), rep
+        torch.testing.assert_close(v1, vg, rtol=2e-5, atol=5e-6)
+        torch.testing.assert_close(v1.cpu().double(), vr, rtol=2e-4, atol=5e-5)
+    assert int(sync[0].item()) == 3 and int(sync[1].item()) == 0 and int(sync[2].item()) == 0
 
 
 def _topology(N, kind):

@@ -63,6 +63,26 @@ def test_fused_heads_branch_equals_composed_branch(agent, monkeypatch):
         torch.testing.assert_close(m_fused.policy.params.flat, m_comp.policy.params.flat, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('agent', ['ma2c_nc', 'ma2c_ic3'])
+def test_coupled_one_launch_branch_equals_two_launch_branch(agent, monkeypatch):
+    """Coupled nets: the host code of the one-launch policy + value step (BatchedPolicy.pv_one_launch: values via the
+    agent-major buffer, the critic's action term added in update(), bootstrap from slot T) and of the policy-step /
+    value-step pair are the same computation."""
+    with cpu_ops():
+        _, m_one, t_one = build(agent, E=3)
+        for _ in range(4):
+            t_one.run_batch()
+        assert m_one.save_acts and m_one.policy.pv_one_launch(3)
+        monkeypatch.setenv('NMARL_INKERNEL_HANDOFF', '0')
+        _, m_two, t_two = build(agent, E=3)
+        for _ in range(4):
+            t_two.run_batch()
+        assert not m_two.policy.pv_one_launch(3)
+        assert torch.equal(m_one.buf_act, m_two.buf_act)
+        torch.testing.assert_close(m_one.buf_v, m_two.buf_v, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m_one.policy.params.flat, m_two.policy.params.flat, rtol=1e-4, atol=1e-6)
+
+
 def test_batch_invariance_of_rollout():
     """Replica e of an E-replica rollout == the same replica rolled out alone (same Philox ids)."""
     with cpu_ops():

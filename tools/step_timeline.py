@@ -2,7 +2,9 @@
 tools/dbg/libstep_tl.so (instrumentation build, not the product), runs the policy + value step at the bench shape and
 prints, for block 0, the stamps of every wave relative to the block's first stamp (cycles):
   0 entry | 1 prologue done | 2+2t chunk-tick t computed | 3+2t its barrier passed | 20 K loop done | 21 cell epilogue done
-  22 head done | 23 re-step MFMAs done | 24 re-step cell done | 25 end.      python tools/step_timeline.py [head]"""
+  22 head done | 23 re-step MFMAs done | 24 re-step cell done | 25 end.      python tools/step_timeline.py [head]
+head 4: the coupled nets' one-launch policy + value step (NeurComm shape, line graph): 26 published | 23 h part of the re-step
+done | 27 neighbours' flags seen | 28 message term | 29 message W chunks staged | 30 message chunks done."""
 import ctypes as C
 import os
 import subprocess
@@ -31,6 +33,7 @@ for name, args in _lib.SIGNATURES.items():
         getattr(dbg, name).restype = C.c_int
 _lib.lib.nmarl_lstm_step_x = dbg.nmarl_lstm_step_x            # route the product wrappers through the instrumented build
 _lib.lib.nmarl_lstm_wimage = dbg.nmarl_lstm_wimage
+_lib.lib.nmarl_lstm_step_x_msg = dbg.nmarl_lstm_step_x_msg
 N, E, H, A, KX = 8, 4096, 64, 4, 128
 head = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
 g = torch.Generator().manual_seed(0)
@@ -43,13 +46,26 @@ done = torch.zeros(E).cuda()
 img = ops.lstm_wimage(wx, wh)
 co, ho, gates = torch.empty_like(c), torch.empty_like(h), torch.empty(N, E, 4 * H, device='cuda')
 pi, act, v = torch.empty(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.empty(N, E, device='cuda')
-tl = torch.zeros(8 * 32, dtype=torch.int64, device='cuda')
+tl = torch.zeros(8 * 64, dtype=torch.int64, device='cuda')
 dbg.nmarl_timeline_set.argtypes = [C.c_void_p, C.c_void_p]
 dbg.nmarl_timeline_set(tl.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
+if head == 4:
+    wx4, w_msg, b_msg = r(N, 3 * H, 4 * H) * 0.15, r(N, 2 * H, H) * 0.15, r(N, H) * 0.1
+    img4, mimg = ops.lstm_wimage(wx4, wh), ops.lstm_msg_wimage(w_msg)
+    slot = torch.relu(r(N, E, 3 * H))
+    sync = ops.step_sync_words(N, E, 'cuda')
+    nbr4 = torch.tensor([[i - 1 if i > 0 else i + 1, i + 1 if 0 < i < N - 1 else -1] for i in range(N)], dtype=torch.int32).cuda()
+    msg = dict(kind=1, nbr_idx=nbr4, w_msg=w_msg, b_msg=b_msg, img=mimg, out=slot[:, :, 2 * H:], sync=sync)
+
+
 def run():
-    if head == 3:
+    if head == 4:
+        ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2,
+                                   xs=(slot[:, :, :2 * H], None, img4, None, msg), h_out=ho, c_out=co, gates=gates,
+                                   defer_action_term=True)
+    elif head == 3:
         ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),
                                    h_out=ho, c_out=co, gates=gates, defer_action_term=True)
     else:
@@ -59,13 +75,18 @@ def run():
 for _ in range(5):
     run()
 torch.cuda.synchronize()
-t = tl.cpu().view(8, 32)
+t = tl.cpu().view(8, 64)
 t0 = int(t[:, 0].min())
-names = {0: 'entry', 1: 'prologue', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end'}
+names = {0: 'entry', 1: 'prologue', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
+         26: 'published', 27: 'flags seen', 28: 'message term', 29: 'msg W staged', 30: 'msg chunks',
+         33: 'cell math', 34: 'critic dots', 35: 'critic shfl'}
 for i in range(2, 20, 2):
     names[i], names[i + 1] = 'tick %d computed' % ((i - 2) // 2), 'tick %d barrier' % ((i - 2) // 2)
 print('stamp'.ljust(18) + ''.join(('wave %d' % w).rjust(9) for w in range(8)))
-for i in sorted(names):
+ORDER = list(range(0, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25]
+for i in ORDER:
+    if i not in names:
+        continue
     if int(t[:, i].max()) == 0:
         continue
     print(names[i].ljust(18) + ''.join(('%d' % (int(t[w, i]) - t0) if int(t[w, i]) else '-').rjust(9) for w in range(8)))

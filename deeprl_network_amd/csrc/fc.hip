@@ -277,7 +277,6 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[f][q] = 0.0f;
     float db[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* xn = x + (int64_t)n * x_sn;
     const float* yn = y + (int64_t)n * y_sn + j4;
     const float* dyn = dy + (int64_t)n * dy_sn + j4;
     float4 gy[4], gd[4];
@@ -421,7 +420,6 @@ __global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, co
 #pragma unroll
     for (int f = 0; f < FMAX; ++f) acc[f] = 0.0f;
     float db = 0.0f;
-    const float* xn = x + (int64_t)n * x_sn;
     const float* yn = y + (int64_t)n * y_sn;
     const float* dyn = dy + (int64_t)n * dy_sn;
     __shared__ int64_t gsrc[FMAX / 4];

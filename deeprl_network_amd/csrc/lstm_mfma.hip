@@ -462,7 +462,6 @@ constexpr int CH_K = 32;                        // k rows per W chunk
 constexpr int CH_FLOATS = CH_K * 16 * 20;       // 10240 floats = 40 KB
 constexpr int HW_FLOATS = H * MAXA + MAXA + H;  // head weights staged in LDS: actor [64][8] + bias [8] (zero padded), critic [64]
 constexpr int LDSX_FLOATS = 2 * CH_FLOATS + WAVES2 * R16 * APITCH + HW_FLOATS;
-constexpr int SPITCH = 68;                      // row pitch of the epilogue's store-staging tiles (16-byte aligned rows)
 constexpr int MAX_KX = 256;
 
 struct XArgs {
@@ -635,32 +634,42 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const float* bn = a.bias + (int64_t)n * a.bias_sn;
         const float* z1 = a.zadd1 ? a.zadd1 + (int64_t)n * a.zadd1_sn : nullptr;
         const float* z2 = a.zadd2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
+        // column tile t = 4 gate + jj holds, for lane column c, UNIT 4 c + jj of that gate (the image permutes W's columns
+        // accordingly): a lane's four jj values are four consecutive floats of a row -- inputs come in and results leave as
+        // 16-byte accesses straight from / to the C/D layout, no LDS staging
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float b = bn[t * 16 + c];
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bn + g4 * H + 4 * c);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[t][r] = b;
+            for (int r = 0; r < 4; ++r) { acc[4 * g4 + 0][r] = b4.x; acc[4 * g4 + 1][r] = b4.y; acc[4 * g4 + 2][r] = b4.z; acc[4 * g4 + 3][r] = b4.w; }
         }
         if (z1) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
+            for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] += z1[rofs[r] * G4 + t * 16 + c];
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(z1 + rofs[r] * G4 + g4 * H + 4 * c);
+                    acc[4 * g4 + 0][r] += v4.x; acc[4 * g4 + 1][r] += v4.y; acc[4 * g4 + 2][r] += v4.z; acc[4 * g4 + 3][r] += v4.w;
+                }
         }
         if (z2) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t)
+            for (int g4 = 0; g4 < 4; ++g4)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[t][r] += z2[rofs[r] * G4 + t * 16 + c];
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(z2 + rofs[r] * G4 + g4 * H + 4 * c);
+                    acc[4 * g4 + 0][r] += v4.x; acc[4 * g4 + 1][r] += v4.y; acc[4 * g4 + 2][r] += v4.z; acc[4 * g4 + 3][r] += v4.w;
+                }
         }
     }
     float cp[4][4];
     {
         const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cp[jj][r] = cpn[rofs[r] * H + jj * 16 + c];
+        for (int r = 0; r < 4; ++r) {
+            const float4 v4 = *reinterpret_cast<const float4*>(cpn + rofs[r] * H + 4 * c);
+            cp[0][r] = v4.x; cp[1][r] = v4.y; cp[2][r] = v4.z; cp[3][r] = v4.w;
+        }
     }
     {
         float4* d_ = reinterpret_cast<float4*>(lds + CH_FLOATS) + threadIdx.x;
@@ -793,17 +802,19 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const float* mbias = xa.msg_b + (int64_t)n * xa.msg_b_sn;
         const float* encn = MSG == 2 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
         float* xo = (!SECOND && xa.xm_out) ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
+        const float4 bv = *reinterpret_cast<const float4*>(mbias + 4 * c);       // tile t of lane column c = unit 4 c + t
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float bv = mbias[16 * t + c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = macc[t][r] + bv;
-                if (MSG == 1) v = fmaxf(v, 0.0f);
-                else v += encn[rofs[r] * xa.enc_row + 16 * t + c];
-                a_tile[(4 * grp + r) * APITCH + 16 * t + c] = v;
-                if (xo && row0 + 4 * grp + r < a.E) xo[(row0 + 4 * grp + r) * xa.xm_row + 16 * t + c] = v;
+        for (int r = 0; r < 4; ++r) {
+            float4 v = float4{macc[0][r] + bv.x, macc[1][r] + bv.y, macc[2][r] + bv.z, macc[3][r] + bv.w};
+            if (MSG == 1) {
+                v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            } else {
+                const float4 e4 = *reinterpret_cast<const float4*>(encn + rofs[r] * xa.enc_row + 4 * c);
+                v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
             }
+            float* t_ = a_tile + (4 * grp + r) * APITCH + 4 * c;
+            t_[0] = v.x; t_[1] = v.y; t_[2] = v.z; t_[3] = v.w;
+            if (xo && row0 + 4 * grp + r < a.E) *reinterpret_cast<float4*>(xo + (row0 + 4 * grp + r) * xa.xm_row + 4 * c) = v;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -870,9 +881,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     }
     NMARL_STAMP(20)
 
-    // ---- lane-local cell epilogue.  Results leave through LDS: in the C/D layout a lane holds single floats of 16 rows, and
-    // 4-byte stores are ISSUE-bound (96 store instructions per wave with gates cost ~10 k cycles); staged through a
-    // wave-private tile (free chunk buffer) every output goes out as 16-byte stores of contiguous row pieces.
+    // ---- lane-local cell epilogue.  A lane holds units 4 c .. 4 c + 3 of rows 4 grp + r (column permutation of the image):
+    // every output leaves as 16-byte stores of contiguous row pieces, 256 B per row and instruction.  (4-byte stores in the
+    // natural C/D layout were issue-bound, ~10 k cycles per wave; staging through LDS cost ~7 k.)
     float* gn = a.gates ? a.gates + (int64_t)n * a.gates_sn : nullptr;
     float* cn = a.c_new + (int64_t)n * a.c_new_sn;
     float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
@@ -886,75 +897,33 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
             const float cv = gf * (cp[jj][r] * keep) + gi * gu;
             const float hv = go * tanh_fast(cv);
-            if (HEAD != 0 && HEAD != 4) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = hv;
+            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = hv;      // K loop done: the tile is free
             cp[jj][r] = cv;                                                        // c' (HEAD 3 / 4: the re-step's previous cell)
             hv_[jj][r] = hv;
             acc[0 + jj][r] = gi; acc[4 + jj][r] = gf; acc[8 + jj][r] = go; acc[12 + jj][r] = gu;
         }
     }
-    if (HEAD == 4) {
-        // Both chunk buffers hold Wh (the re-step needs them): the outputs are staged through the wave's own A tile (odd pitch:
-        // four 4-byte reads per 16-byte store, conflict-free), h' LAST -- it stays there for the heads and the re-step.
-        // h' is written THROUGH (sc1): the neighbours' blocks read it later in this launch.
-        const int srow = lane >> 4, sk4 = (lane & 15) * 4;
-        const __amdgpu_buffer_rsrc_t rh_ = make_rsrc(hn_out, (uint32_t)(a.E * (H * 4)));
-#define NMARL_STORE_TILE4(VAL, dst, pitch, WT)                                             \
-        {                                                                                  \
-            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = VAL;   \
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         \
-            __builtin_amdgcn_wave_barrier();                                               \
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                 \
-                const int rr = 4 * i + srow;                                               \
-                const float* t_ = a_tile + rr * APITCH + sk4;                              \
-                const float4 v4 = float4{t_[0], t_[1], t_[2], t_[3]};                      \
-                if (WT) {                                                                  \
-                    const uint32_t o_ = (uint32_t)(((row0 + rr) * H + sk4) * 4);           \
-                    if (row0 + rr < a.E) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v4), rh_, o_, 0, SC1); \
-                } else if (row0 + rr < a.E) {                                              \
-                    *reinterpret_cast<float4*>((dst) + (row0 + rr) * (pitch) + sk4) = v4;  \
-                }                                                                          \
-            }                                                                              \
-            __builtin_amdgcn_wave_barrier();                                               \
-        }
-        NMARL_STORE_TILE4(cp[jj][r], cn, H, false)
-        if (gn) {
-            NMARL_STORE_TILE4(acc[0 + jj][r], gn, G4, false)
-            NMARL_STORE_TILE4(acc[4 + jj][r], gn + H, G4, false)
-            NMARL_STORE_TILE4(acc[8 + jj][r], gn + 2 * H, G4, false)
-            NMARL_STORE_TILE4(acc[12 + jj][r], gn + 3 * H, G4, false)
-        }
-        NMARL_STORE_TILE4(hv_[jj][r], hn_out, H, true)
-#undef NMARL_STORE_TILE4
-    } else
     {
-        // free chunk buffer: de-phased groups -> the one holding neither Wh chunk; else any (all waves passed the last barrier)
-        float* st = lds + (DEPH ? (nch % NBUF) : 0) * CH_FLOATS + wave * (R16 * SPITCH);
-        const int srow = lane >> 4, sk4 = (lane & 15) * 4;           // read side: 4 rows x 16 float4 per pass
-#define NMARL_STORE_TILE(VAL, dst, pitch)                                                  \
-        {                                                                                  \
-            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) st[(4 * grp + r) * SPITCH + jj * 16 + c] = VAL;   \
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                         \
-            __builtin_amdgcn_wave_barrier();                                               \
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                         \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                 \
-                const int rr = 4 * i + srow;                                               \
-                const float4 v4 = *reinterpret_cast<const float4*>(st + rr * SPITCH + sk4); \
-                if (row0 + rr < a.E) *reinterpret_cast<float4*>((dst) + (row0 + rr) * (pitch) + sk4) = v4;   \
-            }                                                                              \
-            __builtin_amdgcn_wave_barrier();                                               \
+        // HEAD 4: h' is written THROUGH (sc1) -- the neighbours' blocks read it later in this launch (offset in a VGPR)
+        const __amdgpu_buffer_rsrc_t rh_ = make_rsrc(hn_out, (uint32_t)(HEAD == 4 ? a.E * (H * 4) : 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + 4 * grp + r;
+            if (row < a.E) {
+                *reinterpret_cast<float4*>(cn + row * H + 4 * c) = float4{cp[0][r], cp[1][r], cp[2][r], cp[3][r]};
+                const float4 h4 = float4{hv_[0][r], hv_[1][r], hv_[2][r], hv_[3][r]};
+                if (HEAD == 4)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, h4), rh_, (uint32_t)((row * H + 4 * c) * 4), 0, SC1);
+                else
+                    *reinterpret_cast<float4*>(hn_out + row * H + 4 * c) = h4;
+                if (gn) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4)
+                        *reinterpret_cast<float4*>(gn + row * G4 + g4 * H + 4 * c) =
+                            float4{acc[4 * g4 + 0][r], acc[4 * g4 + 1][r], acc[4 * g4 + 2][r], acc[4 * g4 + 3][r]};
+                }
+            }
         }
-        NMARL_STORE_TILE(cp[jj][r], cn, H)
-        NMARL_STORE_TILE(hv_[jj][r], hn_out, H)
-        if (gn) {
-            NMARL_STORE_TILE(acc[0 + jj][r], gn, G4)
-            NMARL_STORE_TILE(acc[4 + jj][r], gn + H, G4)
-            NMARL_STORE_TILE(acc[8 + jj][r], gn + 2 * H, G4)
-            NMARL_STORE_TILE(acc[12 + jj][r], gn + 3 * H, G4)
-        }
-#undef NMARL_STORE_TILE
     }
     NMARL_STAMP(21)
     if (HEAD != 0) {
@@ -1048,7 +1017,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
                 const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
                 const float cv = gf * (cp[jj][r] * keep) + gi * gu;
-                a_tile[(4 * grp + r) * APITCH + jj * 16 + c] = go * tanh_fast(cv);
+                a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = go * tanh_fast(cv);
             }
         NMARL_STAMP(33)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1077,7 +1046,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
 #undef NMARL_A_MASK
 }
 
-// image[n][ch][kl][c][t] = W[32 ch + kl][16 t + c] (t < 16; 16..19 = 0), W = [wx (KX rows); wh (64 rows)]
+// image[n][ch][kl][c][t] = W[32 ch + kl][64 (t >> 2) + 4 c + (t & 3)] (t < 16; 16..19 = 0), W = [wx (KX rows); wh (64 rows)]:
+// tile t = 4 gate + jj of lane column c is unit 4 c + jj of that gate (see the kernel's epilogue)
 __global__ void lstm_wimage_kernel(const int N, const int KX, const float* wx, const int64_t wx_sn, const float* wh,
                                    const int64_t wh_sn, float* img, const int64_t img_sn) {
     const int per_agent = (KX + H) * 320;
@@ -1086,11 +1056,12 @@ __global__ void lstm_wimage_kernel(const int N, const int KX, const float* wx, c
     const int n = (int)(i / per_agent), o = (int)(i % per_agent);
     const int k = o / 320, cc = (o % 320) / 20, t = o % 20;
     float v = 0.0f;
-    if (t < 16) v = k < KX ? wx[(int64_t)n * wx_sn + (int64_t)k * G4 + 16 * t + cc] : wh[(int64_t)n * wh_sn + (int64_t)(k - KX) * G4 + 16 * t + cc];
+    const int col = (t >> 2) * H + 4 * cc + (t & 3);
+    if (t < 16) v = k < KX ? wx[(int64_t)n * wx_sn + (int64_t)k * G4 + col] : wh[(int64_t)n * wh_sn + (int64_t)(k - KX) * G4 + col];
     img[(int64_t)n * img_sn + o] = v;
 }
 
-// msg image[k][c][t] = W_msg[k][16 t + c]  (K_m rows, 64 columns): a lane fetches the B operands of the 4 column tiles of
+// msg image[k][c][t] = W_msg[k][4 c + t]  (K_m rows, 64 columns): a lane fetches the B operands of the 4 column tiles of
 // one k with a single ds_read_b128
 __global__ void lstm_msg_wimage_kernel(const int N, const int K, const float* w, const int64_t w_sn, float* img,
                                        const int64_t img_sn) {
@@ -1099,7 +1070,7 @@ __global__ void lstm_msg_wimage_kernel(const int N, const int K, const float* w,
     if (i >= (int64_t)N * per_agent) return;
     const int n = (int)(i / per_agent), o = (int)(i % per_agent);
     const int k = o / 64, cc = (o % 64) / 4, t = o % 4;
-    img[(int64_t)n * img_sn + o] = w[(int64_t)n * w_sn + (int64_t)k * 64 + 16 * t + cc];
+    img[(int64_t)n * img_sn + o] = w[(int64_t)n * w_sn + (int64_t)k * 64 + 4 * cc + t];
 }
 
 inline bool stride_ok(int64_t s, int64_t need) { return s >= need && (s % 4) == 0; }
@@ -1225,8 +1196,11 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     if (mk && E > 0) {
         if (msg->m_max <= 0 || msg->m_max > 8 || !msg->nbr_idx || !msg->img || !msg->b || msg->b_sn < H ||
             msg->K != (mk == 1 ? H * msg->m_max : H) || msg->K > 128 || msg->img_sn < (int64_t)msg->K * 64 || (msg->img_sn % 4) ||
-            ((uintptr_t)msg->img % 16) || (mk == 2 && (!msg->enc || msg->enc_row < H || msg->enc_sn < E * msg->enc_row)) ||
-            (msg->out && (msg->out_row < H || msg->out_sn < E * msg->out_row)))
+            ((uintptr_t)msg->img % 16) || ((uintptr_t)msg->b % 16) || (msg->b_sn % 4) ||
+            (mk == 2 && (!msg->enc || msg->enc_row < H || msg->enc_sn < E * msg->enc_row || ((uintptr_t)msg->enc % 16) ||
+                         (msg->enc_row % 4) || (msg->enc_sn % 4))) ||
+            (msg->out && (msg->out_row < H || msg->out_sn < E * msg->out_row || ((uintptr_t)msg->out % 16) || (msg->out_row % 4) ||
+                          (msg->out_sn % 4))))
             return NMARL_EINVAL;
     }
     const int kind = head ? head->kind : 0;
@@ -1247,6 +1221,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         (zadd2 && !stride_ok(zadd2_sn, E * G4)) || !stride_ok(c_prev_sn, E * H) || !stride_ok(c_new_sn, E * H) ||
         !stride_ok(h_new_sn, E * H) || (gates && !stride_ok(gates_sn, E * G4)) || ((uintptr_t)h_in % 16) || ((uintptr_t)img % 16) ||
         ((uintptr_t)c_new % 16) || ((uintptr_t)h_new % 16) || (gates && ((uintptr_t)gates % 16)) ||
+        ((uintptr_t)bias % 16) || ((uintptr_t)c_prev % 16) || (zadd1 && ((uintptr_t)zadd1 % 16)) || (zadd2 && ((uintptr_t)zadd2 % 16)) ||
         img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
         (KX - KX2 - KM > 0 && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
         (KX2 > 0 && (x2_row < KX2 || (x2_row % 4) || (x2_sn % 4) || ((uintptr_t)x2 % 16))))

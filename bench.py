@@ -157,14 +157,20 @@ def measure_lstm_step(model, n=60, reps=10):
         gates = torch.empty(N, E, 4 * H, device=dev)
         ho, co = torch.empty_like(h), torch.empty_like(c)
 
+        in_step = p.encodes_in_step(E, model.compact_obs)      # CommNet on the grid: the observation encoder runs in the launch too
+        kw = dict(ob=model.buf_x[0]) if in_step else {}
+
         def body():
             for _ in range(n):
                 p.step_policy_value(enc, h, c, done, pi, act, v, h_out=ho, c_out=co, gates=gates, defer_action_term=True,
-                                    mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0)
-        flops = N * E * (2 * (KX + H) * 4 * H + 2 * (2 * H) * 4 * H + 2 * 2 * Km * H)
-        # read x (KX - 64 gathered columns), own h, c, the neighbours' h (old, then new); write h', c', gates, message term, pi, v, action
-        nbytes = N * E * ((KX - H + 2 * H) * 4 + 2 * Km * 4 + 2 * H * 4 + 4 * H * 4 + H * 4 + A * 4 + 4 + 1)
-        name = 'lstm_step_x_kernel<4,%d> (nmarl_lstm_step_x_msg, policy + value of the coupled net in one launch)' % p.msg_kind
+                                    mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0, **kw)
+        flops = N * E * (2 * (KX + H) * 4 * H + 2 * (2 * H) * 4 * H + 2 * 2 * Km * H + (2 * H * H if in_step else 0))
+        # read x (KX - 64 gathered columns), own h, c, the neighbours' h (old, then new) [, the compact observation of self and
+        # neighbours]; write h', c', gates, message term, pi, v, action [, the encoder's output]
+        nbytes = N * E * ((KX - H + 2 * H) * 4 + 2 * Km * 4 + 2 * H * 4 + 4 * H * 4 + H * 4 + A * 4 + 4 + 1 +
+                          ((p.n_obs + H) * 4 if in_step else 0))
+        name = 'lstm_step_x_kernel<4,%d> (nmarl_lstm_step_x_msg, policy + value of the coupled net in one launch%s)' % (
+            p.msg_kind, ', observation encoder inside' if in_step else '')
     elif p.can_save_acts:
         # coupled nets: the policy step (kind 1) with the message term computed in its pre-phase where it fits
         KX = p.params[p.k_wx].shape[1]

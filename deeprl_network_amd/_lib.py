@@ -53,7 +53,9 @@ class Msg(C.Structure):
     _fields_ = [('kind', C.c_int32), ('m_max', C.c_int32), ('K', C.c_int32), ('pad_', C.c_int32), ('nbr_idx', C.c_void_p),
                 ('img', C.c_void_p), ('img_sn', C.c_int64), ('b', C.c_void_p), ('b_sn', C.c_int64),
                 ('enc', C.c_void_p), ('enc_sn', C.c_int64), ('enc_row', C.c_int64),
-                ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64), ('sync', C.c_void_p)]
+                ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64), ('sync', C.c_void_p),
+                ('ob', C.c_void_p), ('ob_row', C.c_int64), ('ob_F', C.c_int32), ('ob_segs', C.c_int32), ('ob_nbr', C.c_void_p),
+                ('ob_img', C.c_void_p), ('ob_img_sn', C.c_int64), ('ob_b', C.c_void_p), ('ob_b_sn', C.c_int64)]
 
 
 class NetParams(C.Structure):

@@ -283,6 +283,7 @@ class IA2C:
         of the env kernel)."""
         t = self.t
         p = self.policy
+        ob = None
         if t == 0:
             p.refresh_wimage()                             # weights change between batches only (inside the hipGraph: one
             if self.save_acts:                             # small node)
@@ -293,8 +294,12 @@ class IA2C:
             enc = self.S_buf[:, t]
         elif self.save_acts and 'ENC' in p._extra:
             # nets whose encoder output is NOT the LSTM input itself (CommNet: s = enc + message term): kept per lock-step so
-            # that the update's encoder backward needs no forward pass
-            enc = p.encode(self.buf_x[t], self.fp, out=p._extra['ENC'][:, t])
+            # that the update's encoder backward needs no forward pass.  Where the one-launch step runs the encoder too, `enc`
+            # is only the slot its output goes to
+            if p.encodes_in_step(self.E, self.compact_obs):
+                enc, ob = p._extra['ENC'][:, t], self.buf_x[t]
+            else:
+                enc = p.encode(self.buf_x[t], self.fp, out=p._extra['ENC'][:, t])
             p._enc_was_saved = True
         else:
             enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
@@ -306,7 +311,7 @@ class IA2C:
             p.step_policy_value(enc, self.H_all[:, t], self.C_all[:, t], done, self.buf_fp[t + 1], self.buf_act[t],
                                 self.buf_vn[:, t], h_out=self.H_all[:, t + 1], c_out=self.C_all[:, t + 1],
                                 gates=self.G_buf[:, t], defer_action_term=True,
-                                **(dict(save=self._save_slots(t)) if p.coupled else {}), **draw)
+                                **(dict(save=self._save_slots(t), ob=ob) if p.coupled else {}), **draw)
             return self.buf_act[t]
         if self.save_acts:
             # coupled nets: policy step (saves its message terms, gates, states), then the value re-step from the new
@@ -351,12 +356,18 @@ class IA2C:
         step (which advances states_fw -- quirk Q2) and the double-stepped value."""
         assert self.t == self.n_step
         p = self.policy
-        enc = self.encode_target(self.n_step) if pre_encoded else p.encode(self.buf_x[self.n_step], self.fp)
+        ob = None
+        if pre_encoded:
+            enc = self.encode_target(self.n_step)
+        elif self.save_acts and p.encodes_in_step(self.E, self.compact_obs):
+            enc, ob = self.encode_target(self.n_step), self.buf_x[self.n_step]     # the step kernel runs the encoder itself
+        else:
+            enc = p.encode(self.buf_x[self.n_step], self.fp)
         if self.save_acts and p.pv_one_launch(self.E):     # from slot T of the sequences into the persistent state
             T = self.n_step
             p.step_policy_value(enc, self.H_all[:, T], self.C_all[:, T], done, self._pi_boot, action_scratch, self._v_boot,
                                 h_out=self.h_fw, c_out=self.c_fw, mode=mode, u=u, seed=seed, env_id_base=env_id_base,
-                                step=step, step_dev=step_dev)
+                                step=step, step_dev=step_dev, **(dict(ob=ob) if ob is not None else {}))
             return self._v_boot
         if self.save_acts:
             T = self.n_step

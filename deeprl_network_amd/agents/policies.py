@@ -388,16 +388,23 @@ class BatchedPolicy:
             self._sync, self._sync_E = ops.step_sync_words(self.N, E, self.device), E
         return self._sync
 
+    def encodes_in_step(self, E, compact):
+        """The one-launch step of this net also runs the observation encoder (no separate encoder launch per lock-step)."""
+        return False
+
     def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, h_out=None, c_out=None, gates=None,
-                          defer_action_term=False, save=None, **draw):
+                          defer_action_term=False, save=None, ob=None, **draw):
         """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) in one kernel:
         advances (h, c) by the policy step -- in place, or into (h_out, c_out) with the gates saved for the update --;
         the value comes from the re-stepped copy (quirk Q1).  Coupled nets (`pv_one_launch`): never in place; `save`
-        as in step_policy (the POLICY step's message term is what the update needs)."""
+        as in step_policy (the POLICY step's message term is what the update needs).  ob (`encodes_in_step` nets): the env's
+        compact observation [E,N,F] of this lock-step -- `enc` is then the slot the kernel WRITES the encoder's output to."""
         with torch.no_grad():
             if self.coupled:
                 z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
                 xs[4]['sync'] = self._sync_words(h.shape[1])
+                if ob is not None:
+                    xs[4]['ob'] = self._ob_spec(ob)
             else:
                 z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
@@ -819,6 +826,25 @@ class IC3MultiAgentPolicy(BatchedPolicy):
     def _seq_args(self):
         p = self.params
         return 'ic3', p['wx_hid'], p['w_msg'], p['w_msg_b'], None, None
+
+    # -- the observation encoder inside the one-launch step (csrc/lstm_mfma.hip, OBENC)
+    _ob_img = None
+    _ob_pad = None
+
+    def encodes_in_step(self, E, compact):
+        return compact and not self.hetero and self.n_obs != self.n_feat and \
+            ops.ob_encoder_supported(self.n_feat, self.n_obs, self.n_h) and self.pv_one_launch(E)
+
+    def refresh_wimage(self):
+        super().refresh_wimage()
+        if self.xside and not self.hetero and ops.ob_encoder_supported(self.n_feat, self.n_obs, self.n_h):
+            if self._ob_pad is None:
+                self._ob_pad = torch.zeros(self.N, ops.FC_J, self.n_h, dtype=F32, device=self.device)
+            self._ob_img = ops.lstm_ob_wimage(self.params['w_ob'], self._ob_pad, out=self._ob_img)
+
+    def _ob_spec(self, ob):
+        p = self.params
+        return dict(x=ob, nbr=self.nbr_self, img=self._ob_img, b=p['w_ob_b'], w=p['w_ob'])
 
 
 class ConsensusPolicy(LstmPolicy):

@@ -478,6 +478,13 @@ struct XArgs {
     const float* enc; int64_t enc_sn, enc_row;    // MSG 2: the additive h-independent part of the input [N,E,64]
     float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
     unsigned* sync;               // HEAD 4: [0] generation, [1] blocks finished, [2] error, [16 + (agent, block, wave)] flags
+    // HEAD 4 + MSG 2, ob != NULL: lstm_ic3's observation encoder enc = tanh([x_i | x_nbr] W_ob + b_ob) (agents/utils.py:395-399)
+    // runs here as well, from the env's compact observation; its result goes to `enc` (the update needs it) before it is used
+    const float* ob; int64_t ob_row;              // [E][N][F] own features per agent, row pitch ob_row floats
+    int ob_F, ob_segs;                            // F (multiple of 4), slots = 1 + neighbours: F * slots <= 64 inputs
+    const int32_t* ob_nbr;                        // [N, slots]: own index first, then the neighbours ascending, -1 padded
+    const float* ob_img; int64_t ob_img_sn;       // image (nmarl_lstm_msg_wimage) of W_ob zero-padded to 64 rows
+    const float* ob_b; int64_t ob_b_sn;           // [N, 64]
 };
 
 // raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
@@ -698,8 +705,65 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         float4* d = reinterpret_cast<float4*>(m_lds);
         for (int i = threadIdx.x; i < xa.msg_kc * (CH_K * 64 / 4); i += 512) d[i] = g[i];
     }
+    constexpr bool OBENC = HEAD == 4 && MSG == 2;                    // the in-kernel observation encoder exists (runs if xa.ob)
+    float* o_lds = m_lds + xa.msg_kc * (CH_K * 64);                  // W_ob image: 64 x 64 floats
+    if (OBENC && xa.ob) {
+        const float4* g = reinterpret_cast<const float4*>(xa.ob_img + (int64_t)n * xa.ob_img_sn);
+        float4* d = reinterpret_cast<float4*>(o_lds);
+        for (int i = threadIdx.x; i < H * 64 / 4; i += 512) d[i] = g[i];
+    }
     __syncthreads();
     NMARL_STAMP(1)
+    // one k-step of a 64-column product from an LDS image [k][c][4 t]: four MFMAs; a 32-row chunk of it: eight steps
+#define NMARL_MSTEP(ACC, av, kl)                                                               \
+        {                                                                                      \
+            const float4 b_ = *reinterpret_cast<const float4*>(mb + (kl) * 64);                \
+            ACC[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.x, ACC[0], 0, 0, 0);          \
+            ACC[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.y, ACC[1], 0, 0, 0);          \
+            ACC[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.z, ACC[2], 0, 0, 0);          \
+            ACC[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.w, ACC[3], 0, 0, 0);          \
+        }
+#define NMARL_MCHUNK(ACC, IMG, kc, m0, m1)                                                     \
+        {                                                                                      \
+            const float* mb = (IMG) + (((kc) * CH_K + 4 * grp) * 16 + c) * 4;  /* + kl * 64 floats per k row */ \
+            NMARL_MSTEP(ACC, m0.x, 0) NMARL_MSTEP(ACC, m0.y, 1) NMARL_MSTEP(ACC, m0.z, 2) NMARL_MSTEP(ACC, m0.w, 3)  \
+            NMARL_MSTEP(ACC, m1.x, 16) NMARL_MSTEP(ACC, m1.y, 17) NMARL_MSTEP(ACC, m1.z, 18) NMARL_MSTEP(ACC, m1.w, 19) \
+        }
+    float4 encv[OBENC ? 4 : 1];                                      // the encoder's rows of this lane (C/D layout), for the pre-phase
+    const bool ob_here = OBENC && xa.ob != nullptr;
+    if (ob_here) {
+        f32x4 eacc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) eacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* obr = xa.ob + arow * xa.ob_row;
+        const int32_t* nbs = xa.ob_nbr + n * xa.ob_segs;
+        const int F = xa.ob_F, segs = xa.ob_segs;
+        float4 ea[2][2];
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                int f = kc * CH_K + 16 * hh + 4 * grp, seg = 0;      // input k = F seg + f: four consecutive features of one slot
+                while (f >= F) { f -= F; ++seg; }
+                const int j = nbs[seg < segs ? seg : 0];
+                const bool ok = seg < segs && j >= 0;
+                const float w = ok ? 1.0f : 0.0f;
+                float4 v = *reinterpret_cast<const float4*>(obr + (ok ? j : n) * F + (ok ? f : 0));
+                v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+                ea[kc][hh] = v;
+            }
+        NMARL_MCHUNK(eacc, o_lds, 0, ea[0][0], ea[0][1])
+        NMARL_MCHUNK(eacc, o_lds, 1, ea[1][0], ea[1][1])
+        const float4 bo = *reinterpret_cast<const float4*>(xa.ob_b + (int64_t)n * xa.ob_b_sn + 4 * c);
+        float* eo = const_cast<float*>(xa.enc) + (int64_t)n * xa.enc_sn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 v = float4{tanh_fast(eacc[0][r] + bo.x), tanh_fast(eacc[1][r] + bo.y), tanh_fast(eacc[2][r] + bo.z),
+                                    tanh_fast(eacc[3][r] + bo.w)};
+            if (row0 + 4 * grp + r < a.E) *reinterpret_cast<float4*>(eo + (row0 + 4 * grp + r) * xa.enc_row + 4 * c) = v;
+            encv[r] = v;
+        }
+    }
     // The message pre-phase.  second_c = true_type: the VALUE re-step's message term (HEAD 4), from the neighbours' NEW h (h_new,
     // written through by their blocks earlier in this launch: L1-bypassing loads); nothing of it is kept.
     auto msg_phase = [&](auto second_c) {
@@ -726,20 +790,6 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         // Every neighbour row this wave needs is requested BEFORE the first product: one exposed load latency per phase
         // instead of one per chunk and neighbour (the loads were ~2/3 of the pre-phase).  Absent slots read the own row
         // with weight 0 -- no load sits inside a branch.
-#define NMARL_MSTEP(av, kl)                                                                    \
-        {                                                                                      \
-            const float4 b_ = *reinterpret_cast<const float4*>(mb + (kl) * 64);                \
-            macc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.x, macc[0], 0, 0, 0);        \
-            macc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.y, macc[1], 0, 0, 0);        \
-            macc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.z, macc[2], 0, 0, 0);        \
-            macc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b_.w, macc[3], 0, 0, 0);        \
-        }
-#define NMARL_MCHUNK(kc, m0, m1)                                                               \
-        {                                                                                      \
-            const float* mb = m_lds + (((kc) * CH_K + 4 * grp) * 16 + c) * 4;  /* + kl * 64 floats per k row */ \
-            NMARL_MSTEP(m0.x, 0) NMARL_MSTEP(m0.y, 1) NMARL_MSTEP(m0.z, 2) NMARL_MSTEP(m0.w, 3)  \
-            NMARL_MSTEP(m1.x, 16) NMARL_MSTEP(m1.y, 17) NMARL_MSTEP(m1.z, 18) NMARL_MSTEP(m1.w, 19) \
-        }
         if (MSG == 1) {                     // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
             float4 mm[4][2];
             float wsl[2];
@@ -757,7 +807,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                     const float w = wsl[kc >> 1];
                     float4 m0 = mm[kc][0], m1 = mm[kc][1];
                     m0.x *= w; m0.y *= w; m0.z *= w; m0.w *= w; m1.x *= w; m1.y *= w; m1.z *= w; m1.w *= w;
-                    NMARL_MCHUNK(kc, m0, m1)
+                    NMARL_MCHUNK(macc, m_lds, kc, m0, m1)
                 }
             }
         } else {                            // mean over the existing neighbours (K_m = 64: two chunks), four neighbours per round
@@ -793,11 +843,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             for (int kc = 0; kc < 2; ++kc) {
                 float4 m0 = sm[kc][0], m1 = sm[kc][1];
                 m0.x *= inv; m0.y *= inv; m0.z *= inv; m0.w *= inv; m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
-                NMARL_MCHUNK(kc, m0, m1)
+                NMARL_MCHUNK(macc, m_lds, kc, m0, m1)
             }
         }
-#undef NMARL_MCHUNK
-#undef NMARL_MSTEP
         // result (C layout) + bias, relu / + enc -> the wave's LDS tile (A layout source) and, if asked, global memory
         const float* mbias = xa.msg_b + (int64_t)n * xa.msg_b_sn;
         const float* encn = MSG == 2 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
@@ -809,7 +857,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             if (MSG == 1) {
                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
             } else {
-                const float4 e4 = *reinterpret_cast<const float4*>(encn + rofs[r] * xa.enc_row + 4 * c);
+                float4 e4 = *reinterpret_cast<const float4*>(encn + rofs[r] * xa.enc_row + 4 * c);
+                if (OBENC && !SECOND && ob_here) e4 = encv[r];       // computed above (no dependence on the store just issued)
                 v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
             }
             float* t_ = a_tile + (4 * grp + r) * APITCH + 4 * c;
@@ -837,7 +886,10 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         }
     }
 
-    f32x4 zs[PV ? 16 : 1];
+    // HEAD 4 with the lstm_ic3 message term: the whole LSTM input is message columns (KX = 64, the launcher insists), so the
+    // re-step's kept x-side part is just the bias -- re-read it instead of holding 64 registers through the K loop
+    constexpr bool ZS_BIAS = HEAD == 4 && MSG == 2;
+    f32x4 zs[PV && !ZS_BIAS ? 16 : 1];
     NMARL_A_MASK(0, a0, a1)
     const int lag = DEPH ? (wave >> 2) : 0;      // wave group B computes chunk tau - 1 in tick tau
     if (DEPH && lag) __builtin_amdgcn_s_setprio(1);   // the lagging (younger) group wins issue arbitration: its MFMAs are
@@ -852,7 +904,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const int chn = ch + 1 < nch ? ch + 1 : nch - 1;
         NMARL_A_LOAD(chn, n0, n1)
         if (ch >= 0) {
-            if ((HEAD == 3 && ch == nx) || (HEAD == 4 && ch == nx - 2)) {
+            if (!ZS_BIAS && ((HEAD == 3 && ch == nx) || (HEAD == 4 && ch == nx - 2))) {
                 // x-side part complete: the value re-step adds the SAME addend (HEAD 4: all of it but the message columns)
 #pragma unroll
                 for (int t = 0; t < 16; ++t) zs[t] = acc[t];
@@ -951,8 +1003,18 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     }
     if (PV) {
         // ---- the value re-step (quirk Q1): z = x-side addend + (h' keep) @ Wh from the two resident Wh chunks
+        if (ZS_BIAS) {
+            const float* bn = a.bias + (int64_t)n * a.bias_sn;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) acc[t] = zs[t];
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bn + g4 * H + 4 * c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[4 * g4 + 0][r] = b4.x; acc[4 * g4 + 1][r] = b4.y; acc[4 * g4 + 2][r] = b4.z; acc[4 * g4 + 3][r] = b4.w; }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[t] = zs[t];
+        }
 #pragma unroll
         for (int hc = 0; hc < 2; ++hc) {
             const float* buf = lds + ((nx + hc) % NBUF) * CH_FLOATS + (4 * grp * 16 + c) * 20;
@@ -1040,6 +1102,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
         }
     }
+#undef NMARL_MCHUNK
+#undef NMARL_MSTEP
 #undef NMARL_STAGE_LOAD
 #undef NMARL_STAGE_STORE
 #undef NMARL_A_LOAD
@@ -1266,8 +1330,22 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
             return NMARL_EHIP;
-        if (!msg->sync || ((uintptr_t)msg->sync % 4) || (int)grid.x > cus || E * (int64_t)(H * 4) >= (int64_t)1 << 32) return NMARL_EINVAL;
+        if (!msg->sync || ((uintptr_t)msg->sync % 4) || (int)grid.x > cus || E * (int64_t)(H * 4) >= (int64_t)1 << 32 ||
+            (mk == 2 && KX != H))
+            return NMARL_EINVAL;
         xa.sync = msg->sync;
+    }
+    size_t lb_extra = 0;
+    if (msg && msg->ob) {
+        // in-kernel observation encoder: the one-launch lstm_ic3 step only; compact observation, 16-byte pieces
+        if (mk != 2 || kind != 3 || msg->ob_F <= 0 || (msg->ob_F % 4) || msg->ob_segs <= 0 || msg->ob_F * msg->ob_segs > H ||
+            !msg->ob_nbr || !msg->ob_img || !msg->ob_b || ((uintptr_t)msg->ob % 16) || (msg->ob_row % 4) ||
+            msg->ob_row < (int64_t)N * msg->ob_F || ((uintptr_t)msg->ob_img % 16) || msg->ob_img_sn < H * 64 || (msg->ob_img_sn % 4) ||
+            ((uintptr_t)msg->ob_b % 16) || (msg->ob_b_sn % 4) || msg->ob_b_sn < H)
+            return NMARL_EINVAL;
+        xa.ob = msg->ob; xa.ob_row = msg->ob_row; xa.ob_F = msg->ob_F; xa.ob_segs = msg->ob_segs; xa.ob_nbr = msg->ob_nbr;
+        xa.ob_img = msg->ob_img; xa.ob_img_sn = msg->ob_img_sn; xa.ob_b = msg->ob_b; xa.ob_b_sn = msg->ob_b_sn;
+        lb_extra = (size_t)H * 64 * sizeof(float);
     }
     if (mk) {
         // the pre-phase gathers OTHER agents' previous h while their blocks write h_new: no panel of h_new may overlap a
@@ -1281,7 +1359,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-#define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb, st, xa)
+#define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb + lb_extra, st, xa)
     if (mk == 0) {
         if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);
     } else if (mk == 1) {

@@ -222,6 +222,15 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             m.enc, m.enc_sn, m.enc_row = _rows_view(msg['enc'], H, what + ' enc')
         if msg.get('out') is not None:
             m.out, m.out_sn, m.out_row = _rows_view(msg['out'], H, what + ' msg out')
+        ob = msg.get('ob')
+        if ob is not None:                     # lstm_ic3's observation encoder inside the launch (one-launch step only): writes msg['enc']
+            x_ob = ob['x']                     # compact observation [E,N,F]
+            if head.kind != 3 or msg['kind'] != MSG_MEAN_ADD or x_ob.dim() != 3 or x_ob.shape[:2] != (E, N) or not x_ob.is_contiguous():
+                raise _lib.NmarlError('%s: the in-kernel observation encoder needs the one-launch lstm_ic3 step and a compact [E,N,F] slab' % what)
+            m.ob, m.ob_row, m.ob_F, m.ob_segs = ptr(x_ob, F32), N * x_ob.shape[2], x_ob.shape[2], ob['nbr'].shape[1]
+            m.ob_nbr = ptr(ob['nbr'], torch.int32)
+            m.ob_img, m.ob_img_sn = ptr(ob['img'], F32), ob['img'].stride(0)
+            m.ob_b, m.ob_b_sn = _bias(ob['b'])
         if head.kind == 3:                     # policy step + value re-step in one launch: the in-launch hand-off's flag words
             sync = msg.get('sync')
             if sync is None or sync.dtype != torch.int32 or sync.numel() < lib.nmarl_lstm_step_sync_words(E, N):
@@ -238,6 +247,18 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
 
 
 _step_sync_last = [None]
+
+
+def ob_encoder_supported(n_feat, n_obs, n_h):
+    """lstm_ic3's observation encoder fits the one-launch step's extra pre-phase: 16-byte feature pieces, <= 64 inputs."""
+    return n_h == FUSED_H and n_feat % 4 == 0 and n_obs <= FC_J
+
+
+def lstm_ob_wimage(w_ob, pad, out=None):
+    """LDS image of W_ob [N,n_obs,64] for the in-kernel observation encoder: zero-padded to 64 rows in `pad` [N,64,64] (kept
+    by the caller, rows >= n_obs stay zero), then the message image layout."""
+    pad[:, :w_ob.shape[1]].copy_(w_ob)
+    return lstm_msg_wimage(pad, out=out)
 
 
 def step_sync_words(N, E, device):

@@ -409,6 +409,15 @@ typedef struct nmarl_msg {
     const float* enc; int64_t enc_sn, enc_row;
     float* out; int64_t out_sn, out_row;
     uint32_t* sync;     /* head kind 3 only: nmarl_lstm_step_sync_words(E, N) words, zeroed ONCE by the caller */
+    /* head kind 3 + kind 2 only, ob != NULL: lstm_ic3's observation encoder enc = tanh([x_i | x_nbr] W_ob + b_ob)
+     * (agents/utils.py:395-399) runs inside the launch too and WRITES enc before using it: ob [E][N][ob_F] the env's compact
+     * observation (row pitch ob_row floats), ob_nbr [N, ob_segs] = own index then the neighbours (ascending, -1 padded),
+     * ob_F % 4 == 0, ob_F * ob_segs <= 64; ob_img = nmarl_lstm_msg_wimage of W_ob zero-padded to 64 rows, ob_b [N,64] */
+    const float* ob; int64_t ob_row;
+    int32_t ob_F, ob_segs;
+    const int32_t* ob_nbr;
+    const float* ob_img; int64_t ob_img_sn;
+    const float* ob_b; int64_t ob_b_sn;
 } nmarl_msg_t;
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_sync_words(int64_t E, int32_t N);

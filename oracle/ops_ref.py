@@ -152,6 +152,14 @@ def msg_supported(kind, m_max, n_h):
     return n_h == FUSED_H and m_max <= 8 and (n_h * m_max if kind == MSG_GATHER_RELU else n_h) <= 128
 
 
+def ob_encoder_supported(n_feat, n_obs, n_h):
+    return n_feat % 4 == 0 and n_obs <= 64
+
+
+def lstm_ob_wimage(w_ob, pad, out=None):
+    return torch.zeros(w_ob.shape[0], 1) if out is None else out
+
+
 def step_sync_words(N, E, device):
     return torch.zeros(16, dtype=torch.int32)
 
@@ -187,6 +195,12 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
             if m['kind'] == 1:                         # lstm_comm: relu([h_j] W_msg + b)   (agents/utils.py:182-199)
                 t = torch.relu(torch.bmm(nbr_gather(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1))
             else:                                      # lstm_ic3: mean_j(h_j) W_msg + b + enc   (agents/utils.py:395-400)
+                if m.get('ob') is not None:            # enc = tanh([x_i | x_nbr] W_ob + b_ob) (agents/utils.py:395-399) computed here, kept in m['enc']
+                    ob = m['ob']
+                    idx = ob['nbr'].long()
+                    g = ob['x'][:, idx.clamp(min=0), :] * (idx >= 0).to(ob['x'].dtype).unsqueeze(-1)        # [E,N,slots,F]
+                    g = g.reshape(g.shape[0], g.shape[1], -1).transpose(0, 1).to(ob['w'].dtype)             # [N,E,n_obs]
+                    m['enc'].copy_(torch.tanh(torch.bmm(g, ob['w']) + ob['b'].unsqueeze(1)))
                 t = torch.bmm(nbr_mean(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1) + m['enc']
             if m.get('out') is not None:
                 m['out'].copy_(t)

@@ -119,9 +119,11 @@ def test_compact_observation_is_the_own_wave_block(E):
 
 
 def test_compact_observation_training_equals_gathered_slab():
-    """Grid CommNet (BASELINE configs[3] at E = 256): the env writing compact observations, the encoder gathering the
-    neighbours inside its kernels (rollout and update) == the env writing the gathered slab: same actions, values and
-    weights after 2 batches."""
+    """Grid CommNet (BASELINE configs[3] at E = 256): the env writing compact observations -- the one-launch lock-step then
+    runs the observation encoder itself on the matrix cores (lstm_step_x_kernel<4,2>, OBENC), the update's encoder backward
+    gathers the neighbours inside its kernel -- == the env writing the gathered slab and a separate encoder launch.  The two
+    encoders sum in different orders (last-bit differences in enc), so a sampled action can flip: replicas whose actions agree
+    over the whole batch (required: > 99 %) must agree in their values and saved activations; weights after the update close."""
     from deeprl_network_amd.agents import models
     from deeprl_network_amd.envs.large_grid_env import LargeGridBatchEnv
     from deeprl_network_amd.utils import BatchedTrainer, Counter
@@ -134,11 +136,16 @@ def test_compact_observation_training_equals_gathered_slab():
                                 cp['MODEL_CONFIG'], seed=12, num_envs=256)
         tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True, compact_obs=compact)
         assert tr.compact_obs == compact and model.buf_x.shape[-1] == (12 if compact else 60)
-        for _ in range(2):
-            tr.run_batch()
+        tr.run_batch()
         torch.cuda.synchronize()
-        out.append((model.policy.params.flat.clone(), model.buf_v.clone(), model.buf_act.clone(), env.q.clone()))
+        assert model.policy.encodes_in_step(256, model.compact_obs) == compact
+        out.append((model.policy.params.flat.clone(), model.buf_v.clone(), model.buf_act.clone(), model.policy._extra['ENC'].clone(),
+                    model.S_buf.clone()))
         del env, model, tr
-    assert torch.equal(out[0][2], out[1][2]) and torch.equal(out[0][3], out[1][3])
-    torch.testing.assert_close(out[0][1], out[1][1], rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-4, atol=1e-6)
+    same = (out[0][2] == out[1][2]).all(dim=2).all(dim=0)                    # [E]: replicas with identical action sequences
+    assert same.float().mean() > 0.99, float(same.float().mean())
+    torch.testing.assert_close(out[0][1][:, :, same], out[1][1][:, :, same], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(out[0][3][:, :, same], out[1][3][:, :, same], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(out[0][4][:, :, same], out[1][4][:, :, same], rtol=1e-4, atol=2e-5)
+    if bool(same.all()):
+        torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-3, atol=1e-5)

@@ -931,6 +931,39 @@ def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
         torch.testing.assert_close(v1, vg, rtol=2e-5, atol=5e-6)
         torch.testing.assert_close(v1.cpu().double(), vr, rtol=2e-4, atol=5e-5)
     assert int(sync[0].item()) == 3 and int(sync[1].item()) == 0 and int(sync[2].item()) == 0
+    if kind != 2:
+        return
+    # lstm_ic3: the observation encoder enc = tanh([x_i | x_nbr] W_ob + b_ob) inside the same launch, from the compact observation
+    # (own features only, F = 12: 16-byte pieces, F (1 + m_max) <= 64 inputs), its output written to the enc slot
+    Fo = 12
+    nbr_self = torch.cat([torch.arange(N, dtype=torch.int32).view(-1, 1), idx], dim=1)
+    xo = r(E, N, Fo)
+    w_ob, b_ob = r(N, Fo * (1 + m_max), H) * 0.3, r(N, H) * 0.2
+    pad = torch.zeros(N, 64, H, device='cuda')
+    oimg = ops.lstm_ob_wimage(cu(w_ob), pad)
+    enc_r = torch.zeros(N, E, H, dtype=torch.float64)
+    msg_ro = dict(msg_r, enc=enc_r, out=torch.zeros(N, E, H, dtype=torch.float64),
+                  ob=dict(x=f64(xo), nbr=nbr_self, w=f64(w_ob), b=f64(b_ob)))
+    h_r, c_r, g_r = torch.empty_like(hr), torch.empty_like(cr), torch.zeros_like(gr)
+    pi_r, act_r, v_r = torch.zeros_like(pir), torch.zeros_like(actr), torch.zeros(N, E, dtype=torch.float64)
+    ops_ref.lstm_step_policy_value(f64(h), f64(wh), f64(b), None, None, f64(c), f64(done), f64(pi_w), f64(pi_b), pi_r, act_r, f64(v_w),
+                                   f64(v_b), idx, A, v_r, xs=(None, f64(wx), None, None, msg_ro), h_out=h_r, c_out=c_r, gates=g_r,
+                                   defer_action_term=True, **draw)
+    enc_g, s_g = torch.full((N, E, H), 7.0, device='cuda'), torch.zeros(N, E, H, device='cuda')
+    h1, c1, g1 = torch.zeros_like(hg), torch.zeros_like(cg), torch.zeros_like(gg)
+    pi1, act1, v1 = torch.zeros_like(pig), torch.zeros_like(actg), torch.zeros(N, E, device='cuda')
+    msg_o = dict(msg_g, enc=enc_g, out=s_g, sync=sync, ob=dict(x=cu(xo), nbr=cu(nbr_self), img=oimg, b=cu(b_ob)))
+    ops.lstm_step_policy_value(cu(h), None, cu(b), None, None, cu(c), cu(done), cu(pi_w), cu(pi_b), pi1, act1, cu(v_w), cu(v_b),
+                               cu(idx), A, v1, xs=(None, None, img, None, msg_o), h_out=h1, c_out=c1, gates=g1,
+                               defer_action_term=True, **draw)
+    ops.check_coupled_status()
+    torch.testing.assert_close(enc_g.cpu().double(), enc_r, rtol=2e-5, atol=5e-6)
+    torch.testing.assert_close(s_g.cpu().double(), msg_ro['out'], **tol)
+    torch.testing.assert_close(h1.cpu().double(), h_r, **tol)
+    torch.testing.assert_close(c1.cpu().double(), c_r, **tol)
+    torch.testing.assert_close(g1.cpu().double(), g_r, **tol)
+    torch.testing.assert_close(pi1.cpu().double(), pi_r, **tol)
+    torch.testing.assert_close(v1.cpu().double(), v_r, rtol=2e-4, atol=5e-5)
 
 
 def _topology(N, kind):

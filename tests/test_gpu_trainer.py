@@ -157,3 +157,38 @@ def test_fused_env_encode_equals_separate_launches(agent):
         del env, model, tr
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('agent,E', [('ma2c_nc', 1000), ('ma2c_ic3', 300), ('ma2c_nc', 4200)])
+def test_coupled_one_launch_step_equals_two_launches(agent, E, monkeypatch):
+    """Coupled nets: policy step + value re-step in ONE launch (blocks hand the new h over inside it, lstm_step_x_kernel<4,.>)
+    vs the policy-step / value-step pair (NMARL_INKERNEL_HANDOFF=0) over one batch through the hipGraph: the same actions,
+    saved activations and states bit for bit (the policy halves are the same arithmetic), values and updated weights equal up to
+    the order of the re-step's sums.  E = 1000 / 300: ragged last blocks; E = 4200: 8 x 33 blocks > compute units -- the
+    engine must fall back to the two launches by itself."""
+    from deeprl_network_amd import ops
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    out = []
+    for one in (True, False):
+        if not one:
+            monkeypatch.setenv('NMARL_INKERNEL_HANDOFF', '0')
+        cp = cacc_config(agent=agent, scenario='slowdown', n_step=20, reward_norm=5000.0)
+        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+        np.random.seed(12)
+        cls = {'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3}[agent]
+        model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                    cp['MODEL_CONFIG'], seed=12, num_envs=E)
+        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
+        tr.run_batch()
+        torch.cuda.synchronize()
+        ops.check_coupled_status()
+        assert model.policy.pv_one_launch(E) == (one and E <= 4096)
+        out.append((model.buf_act.clone(), model.S_buf.clone(), model.G_buf.clone(), model.H_all.clone(), model.C_all.clone(),
+                    model.buf_v.clone(), model.policy.params.flat.clone()))
+        del env, model, tr
+    for a, b in zip(out[0][:5], out[1][:5]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(out[0][5], out[1][5], rtol=2e-5, atol=5e-6)
+    torch.testing.assert_close(out[0][6], out[1][6], rtol=1e-4, atol=2e-6)

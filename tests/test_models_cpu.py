@@ -83,3 +83,38 @@ def test_batched_update_equals_mean_of_reference_replica_gradients(path, saved):
         np.testing.assert_allclose(var_stats_from_named(model.policy.params.ref_variables()), z['stats0'], rtol=1e-6, atol=1e-7)
         out = drive_batched(model, z, saved=saved)
     compare_batched(out, z)
+
+
+def test_ic3_encoder_inside_the_step_equals_separate_encoder():
+    """CommNet on a compact observation with 16-byte feature pieces (the grid's shape): step_policy_value with `ob` (the
+    one-launch step runs the observation encoder itself and writes its output to the enc slot) == encode() followed by
+    the step on the encoder's output -- the host side of the in-kernel encoder (policies.IC3MultiAgentPolicy._ob_spec)."""
+    from deeprl_network_amd import ops
+    from deeprl_network_amd.agents.policies import IC3MultiAgentPolicy
+    with cpu_ops():
+        N, E, F, A = 6, 5, 8, 4
+        mask = np.zeros((N, N), dtype=int)
+        for i in range(N - 1):                                  # a line: ragged neighbour counts (1 or 2)
+            mask[i, i + 1] = mask[i + 1, i] = 1
+        np.random.seed(3)
+        pol = IC3MultiAgentPolicy(F, A, mask, device='cpu')
+        pol.params.init_reference_order()
+        pol.refresh_wimage()
+        assert pol.encodes_in_step(E, True) and not pol.encodes_in_step(E, False)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(E, N, F, generator=g)
+        h, c = torch.randn(N, E, 64, generator=g) * 0.5, torch.randn(N, E, 64, generator=g) * 0.5
+        done = (torch.rand(E, generator=g) < 0.4).float()
+        outs = []
+        for in_step in (True, False):
+            enc = torch.full((N, E, 64), 3.0)
+            if not in_step:
+                pol.encode(x, None, out=enc)
+            pi, act, v = torch.zeros(N, E, A), torch.zeros(E, N, dtype=torch.uint8), torch.zeros(N, E)
+            ho, co, gates, S = torch.zeros_like(h), torch.zeros_like(c), torch.zeros(N, E, 256), torch.zeros(N, E, 64)
+            pol.step_policy_value(enc, h, c, done, pi, act, v, h_out=ho, c_out=co, gates=gates, defer_action_term=True,
+                                  save={'S': S}, mode=ops.SAMPLE_PHILOX, seed=4, env_id_base=0, step=2,
+                                  **(dict(ob=x) if in_step else {}))
+            outs.append((enc, pi, act, v, ho, co, gates, S))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)

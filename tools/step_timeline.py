@@ -4,7 +4,8 @@ prints, for block 0, the stamps of every wave relative to the block's first stam
   0 entry | 1 prologue done | 2+2t chunk-tick t computed | 3+2t its barrier passed | 20 K loop done | 21 cell epilogue done
   22 head done | 23 re-step MFMAs done | 24 re-step cell done | 25 end.      python tools/step_timeline.py [head]
 head 4: the coupled nets' one-launch policy + value step (NeurComm shape, line graph): 26 published | 23 h part of the re-step
-done | 27 neighbours' flags seen | 28 message term | 29 message W chunks staged | 30 message chunks done."""
+done | 27 neighbours' flags seen | 28 message term | 29 message W chunks staged | 30 message chunks done | 33 cell maths |
+24 tile written | 34 / 35 critic dot products / shuffles | 25 end (before the block's generation update)."""
 import ctypes as C
 import os
 import subprocess

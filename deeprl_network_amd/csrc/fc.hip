@@ -475,6 +475,86 @@ __global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, co
     }
 }
 
+// Wider inputs on the matrix cores (F > 16, 16-byte aligned y / dy rows): dW[f][j] = sum_r x~[r][f] g[r][j] with
+// g = dy * act'(y) as v_mfma_f32_16x16x4_f32 products that contract over FOUR ROWS at a time (M = input feature, N = output
+// column, K = row).  Wave w owns output columns 16 w .. 16 w + 15 and all F input features (FMAX / 16 accumulator tiles); x~ and g
+// tiles of 64 rows wait in LDS (x~ gathered as in fc_bwd_rows_kernel).  The VALU form needs one LDS read per 4 FMAs and is bound
+// by LDS bandwidth (1.0 ms for the grid's 60-wide observation encoder over 25 x 122 880 rows); this one by HBM (y and dy).
+// Same partial layout / fixed-order reduction as the other backward kernels.
+typedef float fc_f32x4 __attribute__((ext_vector_type(4)));
+template <int FMAX>
+__global__ __launch_bounds__(256) void fc_bwd_mfma_kernel(const int64_t rows, const int F, const int tiles_per_block,
+                                                     const float* __restrict__ x, const int64_t x_sn, const int64_t x_row,
+                                                     const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
+                                                     const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
+                                                     const int act, float* __restrict__ partial, const XGather xg) {
+    constexpr int FP = FMAX + 4;          // x~ tile pitch (stage_tile_gather4's)
+    constexpr int GP = J + 16;            // g tile pitch: the four row groups of a k-step fall into disjoint banks
+    constexpr int NT = FMAX / 16;
+    __shared__ __attribute__((aligned(16))) float xs[TILE * FP];
+    __shared__ __attribute__((aligned(16))) float gs[TILE * GP];
+    __shared__ int64_t gsrc[FMAX / 4];
+    const int n = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    fc_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = fc_f32x4{0.f, 0.f, 0.f, 0.f};
+    float dbl = 0.0f;
+    const float* yn = y + (int64_t)n * y_sn;
+    const float* dyn = dy + (int64_t)n * dy_sn;
+    const bool g4 = xg.nbr_idx != nullptr && gather4_ok(x, x_sn, x_row, xg.A);
+    if (g4) gather_table<FMAX>(gsrc, xg.nbr_idx, n, xg.m_max, xg.A, F, x_sn);
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+        if (g4) {
+            stage_tile_gather4<FMAX>(xs, x, x_row, row0, rows, gsrc);
+        } else {
+            for (int idx = threadIdx.x; idx < TILE * FMAX; idx += 256) {
+                const int r = idx / FMAX, f = idx - r * FMAX;
+                const int64_t row = row0 + r;
+                const bool ok = f < F && row < rows;
+                const float v = x_elem(x, x_sn, x_row, n, row, f, ok, xg);
+                xs[r * FP + f] = ok ? v : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TILE * (J / 4) / 256; ++i) {            // g tile: 64 rows x 16 float4, unconditional clamped loads
+            const int idx = threadIdx.x + 256 * i;
+            const int r = idx >> 4, j4 = (idx & 15) * 4;
+            const int64_t row = row0 + r;
+            const bool ok = row < rows;
+            const float4 d4 = *reinterpret_cast<const float4*>(dyn + (ok ? row : 0) * dy_row + j4);
+            const float4 y4 = *reinterpret_cast<const float4*>(yn + (ok ? row : 0) * y_row + j4);
+            const float w = ok ? 1.0f : 0.0f;
+            *reinterpret_cast<float4*>(gs + r * GP + j4) = float4{w * act_bwd(d4.x, y4.x, act), w * act_bwd(d4.y, y4.y, act),
+                                                                  w * act_bwd(d4.z, y4.z, act), w * act_bwd(d4.w, y4.w, act)};
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int rs = 0; rs < TILE; rs += 4) {
+            const float b = gs[(rs + kq) * GP + 16 * wave + m];
+            dbl += b;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(xs[(rs + kq) * FP + 16 * t + m], b, acc[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D layout: column (lane & 15) = output j of this wave's block, row 4 (lane >> 4) + reg = feature within the tile
+    float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)(F + 1) * J;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * t + 4 * kq + r;
+            if (f < F) out[f * J + 16 * wave + m] = acc[t][r];
+        }
+    dbl += __shfl_xor(dbl, 16, 64);
+    dbl += __shfl_xor(dbl, 32, 64);
+    if (kq == 0) out[F * J + 16 * wave + m] = dbl;
+}
+
 __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const int C, const int F, const float* __restrict__ partial,
                                                             float* __restrict__ dw, const int64_t dw_sn,
                                                             float* __restrict__ db, const int64_t db_sn) {
@@ -784,6 +864,8 @@ static int launch_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const f
     const bool vec = ((uintptr_t)y % 16) == 0 && ((uintptr_t)dy % 16) == 0 && (y_sn % 4) == 0 && (y_row % 4) == 0 &&
                      (dy_sn % 4) == 0 && (dy_row % 4) == 0;
     if (F <= 16 && vec) NMARL_FC_BWD(fc_bwd_kernel, 16);
+    else if (F > 32 && vec) NMARL_FC_BWD(fc_bwd_mfma_kernel, 64);
+    else if (F > 16 && vec) NMARL_FC_BWD(fc_bwd_mfma_kernel, 32);
     else if (F <= 16) NMARL_FC_BWD(fc_bwd_rows_kernel, 16);
     else if (F <= 32) NMARL_FC_BWD(fc_bwd_rows_kernel, 32);
     else NMARL_FC_BWD(fc_bwd_rows_kernel, 64);

@@ -637,18 +637,25 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         rofs[r] = row < a.E ? row : a.E - 1;
     }
     f32x4 acc[16];
+    float4 b4s[4];
     {
         const float* bn = a.bias + (int64_t)n * a.bias_sn;
-        const float* z1 = a.zadd1 ? a.zadd1 + (int64_t)n * a.zadd1_sn : nullptr;
-        const float* z2 = a.zadd2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
+        const float* z1 = MSG == 0 && a.zadd1 ? a.zadd1 + (int64_t)n * a.zadd1_sn : nullptr;
+        const float* z2 = MSG == 0 && a.zadd2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
         // column tile t = 4 gate + jj holds, for lane column c, UNIT 4 c + jj of that gate (the image permutes W's columns
         // accordingly): a lane's four jj values are four consecutive floats of a row -- inputs come in and results leave as
         // 16-byte accesses straight from / to the C/D layout, no LDS staging
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bn + g4 * H + 4 * c);
+        for (int g4 = 0; g4 < 4; ++g4) b4s[g4] = *reinterpret_cast<const float4*>(bn + g4 * H + 4 * c);
+        // (message kernels: the 64 accumulators are filled from these 16 registers only after the pre-phases -- the
+        // pre-phases' operands are requested up front and need the room; they take no addends)
+        if (MSG == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { acc[4 * g4 + 0][r] = b4.x; acc[4 * g4 + 1][r] = b4.y; acc[4 * g4 + 2][r] = b4.z; acc[4 * g4 + 3][r] = b4.w; }
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[4 * g4 + 0][r] = b4s[g4].x; acc[4 * g4 + 1][r] = b4s[g4].y; acc[4 * g4 + 2][r] = b4s[g4].z; acc[4 * g4 + 3][r] = b4s[g4].w;
+                }
         }
         if (z1) {
 #pragma unroll
@@ -700,17 +707,86 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
         }
     }
-    if (MSG != 0) {
-        const float4* g = reinterpret_cast<const float4*>(xa.msg_img + (int64_t)n * xa.msg_img_sn);
-        float4* d = reinterpret_cast<float4*>(m_lds);
-        for (int i = threadIdx.x; i < xa.msg_kc * (CH_K * 64 / 4); i += 512) d[i] = g[i];
-    }
     constexpr bool OBENC = HEAD == 4 && MSG == 2;                    // the in-kernel observation encoder exists (runs if xa.ob)
     float* o_lds = m_lds + xa.msg_kc * (CH_K * 64);                  // W_ob image: 64 x 64 floats
-    if (OBENC && xa.ob) {
-        const float4* g = reinterpret_cast<const float4*>(xa.ob_img + (int64_t)n * xa.ob_img_sn);
+    const bool ob_here = OBENC && xa.ob != nullptr;
+    // the W_msg / W_ob images: all pieces requested at once (a run-time loop would wait for every piece before asking for the next)
+    constexpr int MIQ = MSG == 1 ? 4 : 2;                            // pieces per thread: K_m <= 128 (MSG 1), = 64 (MSG 2)
+    float4 mi[MSG != 0 ? MIQ : 1], oi[OBENC ? 2 : 1];
+    if (MSG != 0) {
+        const float4* g = reinterpret_cast<const float4*>(xa.msg_img + (int64_t)n * xa.msg_img_sn);
+        const int lim = xa.msg_kc * (CH_K * 64 / 4);                 // <= 2048 float4 = 4 per thread
+#pragma unroll
+        for (int q = 0; q < MIQ; ++q) { const int i = threadIdx.x + 512 * q; mi[q] = g[i < lim ? i : 0]; }
+    }
+    if (OBENC) {
+        const float4* g = ob_here ? reinterpret_cast<const float4*>(xa.ob_img + (int64_t)n * xa.ob_img_sn) : img;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) oi[q] = g[threadIdx.x + 512 * q];
+    }
+    // msg_load: request the neighbour rows of one round (MSG 1: both slots, all four half-chunks; MSG 2: neighbours k0 .. k0 + 3,
+    // both chunks) -- every row BEFORE the first product, absent slots read the own row with weight 0 (no load inside a branch).
+    // U: MSG 1 [kc][half], MSG 2 [q][kc][half].
+    auto msg_load = [&](auto second_c, const int k0, float4 (&U)[16], float (&W)[4]) {
+        constexpr bool SECOND = decltype(second_c)::value;
+        const float* hsrc = SECOND ? a.h_new : a.h_in;
+        const int64_t hsn = SECOND ? a.h_new_sn : a.h_sn;
+        const float* hbase = hsrc + arow * H + 4 * grp;              // + j * hsn: row `arow` of agent j
+        const uint32_t hoff = (uint32_t)((arow * H + 4 * grp) * 4), hbytes = (uint32_t)(a.E * (H * 4));
+        auto load2 = [&](const int jj, const int col, float4& u0, float4& u1) {
+            if (SECOND) {
+                const __amdgpu_buffer_rsrc_t r_ = make_rsrc(hsrc + (int64_t)jj * hsn, hbytes);
+                u0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_, hoff + col * 4, 0, SC1));
+                u1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_, hoff + col * 4 + 64, 0, SC1));
+            } else {
+                const float* p_ = hbase + (int64_t)jj * hsn + col;
+                u0 = *reinterpret_cast<const float4*>(p_);
+                u1 = *reinterpret_cast<const float4*>(p_ + 16);
+            }
+        };
+        const int32_t* nb = xa.nbr_idx + n * xa.m_max;
+#pragma unroll
+        for (int q = 0; q < (MSG == 1 ? 2 : 4); ++q) {
+            const int k = k0 + q;
+            const int j = nb[k < xa.m_max ? k : 0];
+            const bool ok = k < xa.m_max && j >= 0;
+            W[q] = ok ? 1.0f : 0.0f;
+            load2(ok ? j : n, 0, U[4 * q + 0], U[4 * q + 1]);
+            load2(ok ? j : n, CH_K, U[4 * q + 2], U[4 * q + 3]);
+        }
+    };
+    // the first pre-phase's neighbour rows (and the encoder's observation pieces): requested here, consumed after the barrier
+    float4 PU[16];
+    float PW[4];
+    if (MSG != 0) msg_load(std::false_type{}, 0, PU, PW);
+    float4 ea[OBENC ? 4 : 1];
+    if (OBENC) {
+        // unconditional loads (a valid dummy row when the encoder does not run): input k = F slot + f, four features of one slot
+        const float* obr = ob_here ? xa.ob + arow * xa.ob_row : hrow;
+        const int32_t* nbs = ob_here ? xa.ob_nbr + n * xa.ob_segs : xa.nbr_idx;
+        const int F = ob_here ? xa.ob_F : 64, segs = ob_here ? xa.ob_segs : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int f = (q >> 1) * CH_K + 16 * (q & 1) + 4 * grp, seg = 0;
+            while (f >= F) { f -= F; ++seg; }
+            const int j = nbs[seg < segs ? seg : 0];
+            const bool ok = seg < segs && j >= 0;
+            const float w = ok ? 1.0f : 0.0f;
+            float4 v = *reinterpret_cast<const float4*>(obr + (ok ? j * F + f : 0));
+            v.x *= w; v.y *= w; v.z *= w; v.w *= w;
+            ea[q] = v;
+        }
+    }
+    if (MSG != 0) {
+        float4* d = reinterpret_cast<float4*>(m_lds);
+        const int lim = xa.msg_kc * (CH_K * 64 / 4);
+#pragma unroll
+        for (int q = 0; q < MIQ; ++q) { const int i = threadIdx.x + 512 * q; if (i < lim) d[i] = mi[q]; }
+    }
+    if (ob_here) {
         float4* d = reinterpret_cast<float4*>(o_lds);
-        for (int i = threadIdx.x; i < H * 64 / 4; i += 512) d[i] = g[i];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) d[threadIdx.x + 512 * q] = oi[q];
     }
     __syncthreads();
     NMARL_STAMP(1)
@@ -730,30 +806,12 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             NMARL_MSTEP(ACC, m1.x, 16) NMARL_MSTEP(ACC, m1.y, 17) NMARL_MSTEP(ACC, m1.z, 18) NMARL_MSTEP(ACC, m1.w, 19) \
         }
     float4 encv[OBENC ? 4 : 1];                                      // the encoder's rows of this lane (C/D layout), for the pre-phase
-    const bool ob_here = OBENC && xa.ob != nullptr;
     if (ob_here) {
         f32x4 eacc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) eacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* obr = xa.ob + arow * xa.ob_row;
-        const int32_t* nbs = xa.ob_nbr + n * xa.ob_segs;
-        const int F = xa.ob_F, segs = xa.ob_segs;
-        float4 ea[2][2];
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                int f = kc * CH_K + 16 * hh + 4 * grp, seg = 0;      // input k = F seg + f: four consecutive features of one slot
-                while (f >= F) { f -= F; ++seg; }
-                const int j = nbs[seg < segs ? seg : 0];
-                const bool ok = seg < segs && j >= 0;
-                const float w = ok ? 1.0f : 0.0f;
-                float4 v = *reinterpret_cast<const float4*>(obr + (ok ? j : n) * F + (ok ? f : 0));
-                v.x *= w; v.y *= w; v.z *= w; v.w *= w;
-                ea[kc][hh] = v;
-            }
-        NMARL_MCHUNK(eacc, o_lds, 0, ea[0][0], ea[0][1])
-        NMARL_MCHUNK(eacc, o_lds, 1, ea[1][0], ea[1][1])
+        NMARL_MCHUNK(eacc, o_lds, 0, ea[0], ea[1])
+        NMARL_MCHUNK(eacc, o_lds, 1, ea[2], ea[3])
         const float4 bo = *reinterpret_cast<const float4*>(xa.ob_b + (int64_t)n * xa.ob_b_sn + 4 * c);
         float* eo = const_cast<float*>(xa.enc) + (int64_t)n * xa.enc_sn;
 #pragma unroll
@@ -766,51 +824,24 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     }
     // The message pre-phase.  second_c = true_type: the VALUE re-step's message term (HEAD 4), from the neighbours' NEW h (h_new,
     // written through by their blocks earlier in this launch: L1-bypassing loads); nothing of it is kept.
-    auto msg_phase = [&](auto second_c) {
+    // msg_phase: U / W hold round 0 already (first phase: requested before the prologue's barrier)
+    auto msg_phase = [&](auto second_c, float4 (&U)[16], float (&W)[4]) {
         constexpr bool SECOND = decltype(second_c)::value;
         f32x4 macc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) macc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float* hsrc = SECOND ? a.h_new : a.h_in;
-        const int64_t hsn = SECOND ? a.h_new_sn : a.h_sn;
-        const float* hbase = hsrc + arow * H + 4 * grp;              // + j * hsn: row `arow` of agent j
-        const uint32_t hoff = (uint32_t)((arow * H + 4 * grp) * 4), hbytes = (uint32_t)(a.E * (H * 4));
-        auto load2 = [&](const int jj, const int col, float4& u0, float4& u1) {
-            if (SECOND) {
-                const __amdgpu_buffer_rsrc_t r_ = make_rsrc(hsrc + (int64_t)jj * hsn, hbytes);
-                u0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_, hoff + col * 4, 0, SC1));
-                u1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_, hoff + col * 4 + 64, 0, SC1));
-            } else {
-                const float* p_ = hbase + (int64_t)jj * hsn + col;
-                u0 = *reinterpret_cast<const float4*>(p_);
-                u1 = *reinterpret_cast<const float4*>(p_ + 16);
-            }
-        };
-        const int32_t* nb = xa.nbr_idx + n * xa.m_max;
-        // Every neighbour row this wave needs is requested BEFORE the first product: one exposed load latency per phase
-        // instead of one per chunk and neighbour (the loads were ~2/3 of the pre-phase).  Absent slots read the own row
-        // with weight 0 -- no load sits inside a branch.
         if (MSG == 1) {                     // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
-            float4 mm[4][2];
-            float wsl[2];
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                const int j = nb[sl < xa.m_max ? sl : 0];
-                const bool ok = sl < xa.m_max && j >= 0;
-                wsl[sl] = ok ? 1.0f : 0.0f;
-                load2(ok ? j : n, 0, mm[2 * sl][0], mm[2 * sl][1]);
-                load2(ok ? j : n, CH_K, mm[2 * sl + 1][0], mm[2 * sl + 1][1]);
-            }
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 if (kc < xa.msg_kc) {
-                    const float w = wsl[kc >> 1];
-                    float4 m0 = mm[kc][0], m1 = mm[kc][1];
+                    const float w = W[kc >> 1];
+                    float4 m0 = U[2 * kc], m1 = U[2 * kc + 1];
                     m0.x *= w; m0.y *= w; m0.z *= w; m0.w *= w; m1.x *= w; m1.y *= w; m1.z *= w; m1.w *= w;
                     NMARL_MCHUNK(macc, m_lds, kc, m0, m1)
                 }
             }
         } else {                            // mean over the existing neighbours (K_m = 64: two chunks), four neighbours per round
+            const int32_t* nb = xa.nbr_idx + n * xa.m_max;
             int cnt = 0;
             for (int k = 0; k < xa.m_max; ++k) cnt += nb[k] >= 0;
             const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
@@ -818,25 +849,16 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) sm[kc][0] = sm[kc][1] = float4{0.f, 0.f, 0.f, 0.f};
             for (int k0 = 0; k0 < xa.m_max; k0 += 4) {
-                float4 u[4][2][2];
-                float w[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = k0 + q;
-                    const int j = nb[k < xa.m_max ? k : 0];
-                    const bool ok = k < xa.m_max && j >= 0;
-                    w[q] = ok ? 1.0f : 0.0f;
-                    load2(ok ? j : n, 0, u[q][0][0], u[q][0][1]);
-                    load2(ok ? j : n, CH_K, u[q][1][0], u[q][1][1]);
-                }
+                if (k0 > 0) msg_load(second_c, k0, U, W);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
                         for (int hh = 0; hh < 2; ++hh) {
-                            sm[kc][hh].x += w[q] * u[q][kc][hh].x; sm[kc][hh].y += w[q] * u[q][kc][hh].y;
-                            sm[kc][hh].z += w[q] * u[q][kc][hh].z; sm[kc][hh].w += w[q] * u[q][kc][hh].w;
+                            const float4 u = U[4 * q + 2 * kc + hh];
+                            sm[kc][hh].x += W[q] * u.x; sm[kc][hh].y += W[q] * u.y;
+                            sm[kc][hh].z += W[q] * u.z; sm[kc][hh].w += W[q] * u.w;
                         }
             }
 #pragma unroll
@@ -878,12 +900,20 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const float* p0_ = nx > 2 ? xrow : hrow;
         a0 = *reinterpret_cast<const float4*>(p0_);
         a1 = *reinterpret_cast<const float4*>(p0_ + 16);
-        msg_phase(std::false_type{});
+        msg_phase(std::false_type{}, PU, PW);
         if (nx <= 2) {                      // chunk 0 is a message chunk: from the wave's LDS tile
             const float* t_ = a_tile + c * APITCH + 4 * grp;
             a0.x = t_[0]; a0.y = t_[1]; a0.z = t_[2]; a0.w = t_[3];
             a1.x = t_[16]; a1.y = t_[17]; a1.z = t_[18]; a1.w = t_[19];
         }
+    }
+    if (MSG != 0) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[4 * g4 + 0][r] = b4s[g4].x; acc[4 * g4 + 1][r] = b4s[g4].y; acc[4 * g4 + 2][r] = b4s[g4].z; acc[4 * g4 + 3][r] = b4s[g4].w;
+            }
     }
 
     // HEAD 4 with the lstm_ic3 message term: the whole LSTM input is message columns (KX = 64, the launcher insists), so the
@@ -1049,7 +1079,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
             asm volatile("" ::: "memory");               // the payload loads stay below the polls
             NMARL_STAMP(27)
-            msg_phase(std::true_type{});                 // -> the wave's A tile
+            msg_load(std::true_type{}, 0, PU, PW);
+            msg_phase(std::true_type{}, PU, PW);         // -> the wave's A tile
             NMARL_STAMP(28)
             __syncthreads();                             // every wave is through with the Wh chunks
             NMARL_STAGE_STORE(0)

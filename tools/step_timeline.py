@@ -37,6 +37,9 @@ _lib.lib.nmarl_lstm_wimage = dbg.nmarl_lstm_wimage
 _lib.lib.nmarl_lstm_step_x_msg = dbg.nmarl_lstm_step_x_msg
 N, E, H, A, KX = 8, 4096, 64, 4, 128
 head = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
+GRID = 'grid' in sys.argv                     # head 4 on CommNet's grid shape: 25 x 1024 rows, KX = 64, 4 neighbours, encoder inside
+if GRID:
+    N, E, A = 25, 1024, 5
 g = torch.Generator().manual_seed(0)
 r = lambda *s: torch.randn(*s, generator=g).cuda()            # noqa: E731
 h, c, x = r(N, E, H), r(N, E, H), torch.relu(r(N, E, KX))
@@ -52,7 +55,24 @@ dbg.nmarl_timeline_set.argtypes = [C.c_void_p, C.c_void_p]
 dbg.nmarl_timeline_set(tl.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
 
-if head == 4:
+if head == 4 and GRID:
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_gpu_ops import _topology
+    nbr4, _ = ops.neighbor_table(_topology(N, 'grid'), 'cuda')
+    nbr = nbr4
+    v_w = r(N, H + nbr4.shape[1] * A, 1)
+    wx4, w_msg, b_msg = r(N, H, 4 * H) * 0.15, r(N, H, H) * 0.15, r(N, H) * 0.1
+    img4, mimg = ops.lstm_wimage(wx4, wh), ops.lstm_msg_wimage(w_msg)
+    Fo = 12
+    nbr_self = torch.cat([torch.arange(N, dtype=torch.int32, device='cuda').view(-1, 1), nbr4], dim=1)
+    w_ob, b_ob = r(N, Fo * nbr_self.shape[1], H) * 0.3, r(N, H) * 0.1
+    oimg = ops.lstm_ob_wimage(w_ob, torch.zeros(N, 64, H, device='cuda'))
+    xo, enc_slot, s_slot = r(E, N, Fo), torch.zeros(N, E, H, device='cuda'), torch.zeros(N, E, H, device='cuda')
+    sync = ops.step_sync_words(N, E, 'cuda')
+    msg = dict(kind=2, nbr_idx=nbr4, w_msg=w_msg, b_msg=b_msg, img=mimg, enc=enc_slot, out=s_slot, sync=sync,
+               ob=dict(x=xo, nbr=nbr_self, img=oimg, b=b_ob))
+    slot = None
+elif head == 4:
     wx4, w_msg, b_msg = r(N, 3 * H, 4 * H) * 0.15, r(N, 2 * H, H) * 0.15, r(N, H) * 0.1
     img4, mimg = ops.lstm_wimage(wx4, wh), ops.lstm_msg_wimage(w_msg)
     slot = torch.relu(r(N, E, 3 * H))
@@ -64,7 +84,7 @@ if head == 4:
 def run():
     if head == 4:
         ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2,
-                                   xs=(slot[:, :, :2 * H], None, img4, None, msg), h_out=ho, c_out=co, gates=gates,
+                                   xs=(None if GRID else slot[:, :, :2 * H], None, img4, None, msg), h_out=ho, c_out=co, gates=gates,
                                    defer_action_term=True)
     elif head == 3:
         ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),

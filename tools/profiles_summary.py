@@ -38,7 +38,9 @@ def main(tag):
            'default row: `python bench.py --steps 20 --warmup 5`); agent-steps/s = agents x replicas x lock-steps / s over rollout + '
            'update.  `us / launch` = the LSTM lock-step launch inside the rollout (difference of two un-profiled rollout-graph '
            'timings, bench.py `roofline.how`).  "first" = the first measurement pass of this round (before the one-launch coupled '
-           'step, the permuted column tiles and the in-kernel grid encoder).\n' % tag,
+           'step, the permuted column tiles and the in-kernel grid encoder).  The default line was sampled on six boxes of the pool '
+           'this round (same code path): 8.93, 8.99, 9.00, 9.06, 9.10, 9.19, 9.27, 9.37, 9.38 ms = 209.5 ... 220.1 M env-steps/s; '
+           'under the tracer the batch spans 9.23 - 9.28 ms on every box -- the table holds the LAST sample.\n' % tag,
            '| config | agents x replicas | round 2 M/s | round 3 first M/s | now M/s | ms / batch | LSTM lock-step kernel | us / launch | frac of fp32 MFMA peak |',
            '|---|---|---:|---:|---:|---:|---|---:|---:|']
     for stem, label, shape, r2, first in ROWS:

@@ -13,6 +13,14 @@ mkdir -p /tmp/pmc
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o pmc_FETCH_SIZE --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc -o pmc_WRITE_SIZE --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_write.log 2>&1
 python tools/pmc_summary.py /tmp/pmc $TAG gpurun_out > gpurun_out/${TAG}_pmc_summary.log 2>&1
+# shader-clock phase timelines of the lock-step kernels (instrumentation build of csrc/lstm_mfma.hip, tools/step_timeline.py)
+python tools/step_timeline.py --build > /dev/null 2>&1
+( echo "## python tools/step_timeline.py 4  (NeurComm shape: 8 x 4096 rows, KX = 192, one-launch policy + value step)"
+  python tools/step_timeline.py 4 2>&1 | grep -v amdgpu.ids; echo
+  echo "## python tools/step_timeline.py 4 grid  (CommNet grid shape: 25 x 1024 rows, KX = 64, 4 neighbours, encoder inside; block 0 = a corner agent)"
+  python tools/step_timeline.py 4 grid 2>&1 | grep -v amdgpu.ids; echo
+  echo "## python tools/step_timeline.py 3  (IA2C-FP shape, policy + value step)"
+  python tools/step_timeline.py 3 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_step_timeline.txt
 python -c "
 import json
 d=json.loads(open('gpurun_out/${TAG}_bench_default.json').read().strip().splitlines()[-1])

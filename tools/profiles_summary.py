@@ -1,5 +1,5 @@
 """Turn the raw outputs of `tools/prof_all.sh <tag>` (gpurun_out/<tag>_*) into the committed summaries under profiles/:
-<tag>_bench_default.json, <tag>_other_configs.md, <tag>_bench_kernel_stats.md, <tag>_pmc_traffic.{json,md}.
+<tag>_bench_default.json, <tag>_other_configs.md, <tag>_bench_kernel_stats.md, <tag>_pmc_traffic.{json,md}, <tag>_step_timeline.txt.
     python tools/profiles_summary.py r03"""
 import json
 import os
@@ -81,10 +81,10 @@ def main(tag):
         ks += ['## ' + title, '', '```', open(p).read().rstrip(), '```', '']
     with open(os.path.join(DST, '%s_bench_kernel_stats.md' % tag), 'w') as f:
         f.write('\n'.join(ks) + '\n')
-    for ext in ('json', 'md'):
-        p = os.path.join(SRC, '%s_pmc_traffic.%s' % (tag, ext))
+    for name in ('pmc_traffic.json', 'pmc_traffic.md', 'step_timeline.txt'):
+        p = os.path.join(SRC, '%s_%s' % (tag, name))
         if os.path.exists(p):
-            shutil.copy(p, os.path.join(DST, '%s_pmc_traffic.%s' % (tag, ext)))
+            shutil.copy(p, os.path.join(DST, '%s_%s' % (tag, name)))
 
 
 if __name__ == '__main__':

@@ -110,4 +110,21 @@ for s in range(4):
     ops.bptt_coupled(ops.COUPLED_NC, rev, 2, Gs, Cs, dones, Ds, ws_, wm_, Ss[..., 2 * H:], dZs, D1s)
 torch.cuda.synchronize()
 ops.check_coupled_status()
+# the coupled nets' lock-step in ONE launch (lstm_step_x_kernel<4,1>: NeurComm on the line graph) at the bench shape
+try:
+    if ops.step_handoff_supported(N, El, 'cuda'):
+        wx4, w_msg, b_msg = r(N, 3 * H, 4 * H) * 0.15, r(N, 2 * H, H) * 0.15, r(N, H) * 0.1
+        img4, mimg = ops.lstm_wimage(wx4, wh), ops.lstm_msg_wimage(w_msg)
+        slot = torch.relu(r(N, El, 3 * H))
+        sync = ops.step_sync_words(N, El, 'cuda')
+        msg = dict(kind=ops.MSG_GATHER_RELU, nbr_idx=nbr_idx, w_msg=w_msg, b_msg=b_msg, img=mimg, out=slot[:, :, 2 * H:], sync=sync)
+        v_w4 = r(N, H + nbr_idx.shape[1] * A, 1)
+        for s in range(12):
+            ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w4, v_b, nbr_idx, A, v, mode=2,
+                                       xs=(slot[:, :, :2 * H], None, img4, None, msg), h_out=ho, c_out=co, gates=gates,
+                                       defer_action_term=True)
+        torch.cuda.synchronize()
+        ops.check_coupled_status()
+except Exception as ex:                        # a side measurement: never fail the pass
+    print('one-launch coupled step skipped:', ex)
 print('done', E, Eg)

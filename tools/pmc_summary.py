@@ -65,6 +65,16 @@ try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica
     res['kernels']['lstm_step_x_N8_E4096'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no lstm step in this collection:', ex)
+try:        # the coupled nets' lock-step in one launch (NeurComm, line graph): per (agent, replica) row x [hx | hp] 512 + own h, c 512 +
+    # the neighbours' h before (512) and after (512) the step read; h', c' 512 + gates 1024 + message term 256 + pi 16 + v 4 + action 1 written
+    s = stat('lstm_step_x_kernel<4, 1>')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 8 * 4096
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=3861, traffic_over_algorithmic=traffic / rows / 3861)
+    res['kernels']['lstm_step_x4_nc_N8_E4096'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no one-launch coupled step in this collection:', ex)
 try:        # the whole reverse recurrence in one launch: "replica" = one (agent, replica, step) row of T = 60 steps;
     # algorithmic bytes per row: gates 1024 + c 256 + dL/dh 256 read, dz 1024 written
     s = stat('lstm_bptt_seq_kernel')

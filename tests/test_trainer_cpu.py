@@ -143,3 +143,55 @@ def test_heterogeneous_agents_on_the_network_cpu(agent):
         if ps.mask is not None:
             assert torch.equal(ps.flat[ps.mask == 0], w0[ps.mask == 0])
         assert tr.stats()['episodes'] == 3 * 2
+
+
+class _Cpu8FeatureEnv(CpuCaccBatchEnv):
+    """TEST-ONLY: the CACC stand-in with 8 features per vehicle (the 5 of the oracle + 3 derived ones): an observation with
+    16-byte feature pieces like the grid's, so CommNet's one-launch step may run the observation encoder itself."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.n_s_ls = [8] * self.n_agent
+
+    def set_compact_obs(self, flag=True):
+        assert flag, 'this stand-in emits the compact observation only'
+        self.compact_obs = True
+        self.obs = torch.zeros(self.E, self.n_agent, 8)
+        return True
+
+    def _emit(self):
+        from cpu_emulation import np_f32
+        vs = torch.from_numpy(np_f32(self.ref.veh_state()))
+        self.obs.copy_(torch.cat([vs, torch.tanh(vs[..., :3])], dim=-1))
+        return self.obs
+
+
+def test_commnet_encoder_inside_the_step_equals_separate_encoder_launch(monkeypatch):
+    """The batched engine on an observation with 16-byte feature pieces: CommNet's one-launch lock-step running the observation
+    encoder itself (models.act / bootstrap hand the compact observation to the step, the encoder's output lands in the ENC slots
+    the update reads) == the separate encoder launch, over three batches incl. episode ends."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.agents.policies import IC3MultiAgentPolicy
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+
+    def run(in_step):
+        if not in_step:
+            monkeypatch.setattr(IC3MultiAgentPolicy, 'encodes_in_step', lambda self, E, compact: False)
+        cp = cacc_config(agent='ma2c_ic3', n_step=10, scenario='catchup', seed=12, reward_norm=800.0)
+        cp['ENV_CONFIG']['episode_length_sec'] = '3'
+        env = _Cpu8FeatureEnv(cp['ENV_CONFIG'], num_envs=4)
+        np.random.seed(12)
+        model = models.MA2C_IC3(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 6,
+                                cp['MODEL_CONFIG'], seed=12, num_envs=4, device='cpu')
+        tr = BatchedTrainer(env, model, Counter(10 ** 6, 10 ** 7, 10 ** 4), use_graph=False)
+        assert tr.compact_obs and model.buf_x.shape[-1] == 8
+        for _ in range(4):
+            tr.run_batch()
+        assert model.policy.encodes_in_step(4, model.compact_obs) == in_step
+        return model.buf_act.clone(), model.buf_v.clone(), model.policy._extra['ENC'].clone(), model.policy.params.flat.clone()
+
+    with cpu_ops():
+        a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):
+        torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)

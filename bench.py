@@ -71,6 +71,9 @@ def parse():
     ap.add_argument('--cpu-port-worker', type=int, default=0, help='internal: run N batches of the CPU port, print the timing')
     ap.add_argument('--tune-only', action='store_true', help='internal: run one batch to tune the library GEMMs, print nothing')
     ap.add_argument('--no-tunableop', action='store_true', help='do not auto-tune the library GEMMs (PyTorch TunableOp)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the other BASELINE configs (NeurComm slow-down / catch-up, CommNet grid) measured after the headline')
+    ap.add_argument('--other-steps', type=int, default=10, help='timed n_step batches per other config')
     ap.add_argument('--cpu-batches', type=int, default=100,
                     help='n_step batches of the E=1 CPU baseline (100 = 6000 env steps of BASELINE configs[0], ~10 s on one core)')
     return ap.parse_args()
@@ -283,6 +286,114 @@ def measure_bptt_seq(model, reps=5):
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * (H4 + H4 // 4 + H4 // 4 + H4) * 4
+
+
+def measure_bptt_coupled(model, reps=3):
+    """Average duration of the coupled nets' reverse recurrence in one launch (nmarl_lstm_bptt_coupled) on the model's own
+    saved activations (the trace of the last rollout): HIP events on the launch stream around `reps` calls.  Algorithmic
+    bytes per (agent, replica, step): gates 1024 + c 256 + dL/dh 256 [+ relu mask 256] + one message row per real source
+    read; dz 1024 + D1 256 + the own message row written.  Returns (us per launch, bytes per launch, kernel name) or None."""
+    from deeprl_network_amd import ops
+    p = model.policy
+    kind = {ops.MSG_GATHER_RELU: ops.COUPLED_NC, ops.MSG_MEAN_ADD: ops.COUPLED_IC3}.get(p.msg_kind)
+    H = model.n_lstm
+    if kind is None or not ops.bptt_coupled_supported(kind, p.m_max, H):
+        return None
+    rev = ops.reverse_neighbor_table(p.nbr_idx, kind)
+    if rev is None or not ops.bptt_coupled_supported(kind, p.m_max, H, rev=rev):
+        return None
+    _, wxm, w_msg, _, _, _ = p._seq_args()
+    wxm, wh, w_msg = wxm.detach(), p.params[p.k_wh].detach(), w_msg.detach()
+    G, C, S = model.G_buf, model.C_all, model.S_buf
+    N, T, E, H4 = G.shape
+    K = w_msg.shape[1]
+    dHs = torch.randn(N, T, E, H, device=G.device) * 1e-3
+    dZ, D1 = torch.empty_like(G), torch.empty(N, T, E, H, device=G.device)
+    done = torch.zeros(T, E, device=G.device)
+    ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
+    wm = (w_msg, ops.lstm_bptt_msg_wimage(w_msg))
+    mask = S[..., 2 * H:] if kind == ops.COUPLED_NC else None
+    ops.bptt_coupled(kind, rev, p.m_max, G, C, done, dHs, ws, wm, mask, dZ, D1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.bptt_coupled(kind, rev, p.m_max, G, C, done, dHs, ws, wm, mask, dZ, D1)
+    e1.record()
+    torch.cuda.synchronize()
+    ops.check_coupled_status()
+    sources = float((p.nbr_idx >= 0).sum().item()) / N                    # message rows read per agent (mean fan-in)
+    row = 1024 + 256 + 256 + (256 if mask is not None else 0) + sources * (K // p.m_max if kind == ops.COUPLED_NC else K) * 4 \
+        + 1024 + 256 + K * 4
+    one = N * -(-E // 128) <= max(_lib_capacity(2, K), 0) and ops.handoff_enabled()
+    name = 'lstm_bptt_coupled_kernel<%d,%d,%s> (nmarl_lstm_bptt_coupled, %s)' % (
+        K // 16, rev['r_row'], 'true' if mask is not None else 'false', 'one launch' if one else '%d step-wise launches' % T)
+    return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * row, name
+
+
+def _lib_capacity(which, K):
+    from deeprl_network_amd import _lib
+    return _lib.lib.nmarl_handoff_capacity(which, int(K))
+
+
+OTHER_CONFIGS = ('config_ma2c_nc_slowdown.ini',      # BASELINE.json configs[2]
+                 'config_ma2c_cnet_grid.ini',        # configs[3]
+                 'config_ma2c_nc_catchup.ini')       # configs[4], one GPU's share (4096 of the 32768 replicas)
+
+
+def run_other_config(args, cfg_name, device):
+    """One of the other BASELINE configs, measured like the headline (fresh env / model / trainer, `--warmup` untimed batches
+    -- the first tunes this config's GEMM shapes --, then `--other-steps` timed batches between device synchronisations),
+    plus the rooflines of its two hand-written matrix-core kernels on the job's own buffers."""
+    import gc
+    cp = configparser.ConfigParser()
+    cp.read(os.path.join(ROOT, 'config', cfg_name))
+    sub = argparse.Namespace(**vars(args))
+    sub.envs = 0
+    E, env, model, trainer = make_job(sub, cp, device, 0, 1, None)
+    for _ in range(max(2, args.warmup)):
+        trainer.run_batch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.other_steps):
+        trainer.run_batch()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    n_step, n_agent = model.n_step, env.n_agent
+    res = {'workload': '%s, %d agents x %d replicas, %s (%s), n_step %d'
+                       % ('ATSC 5x5 grid (synthetic)' if env.name.startswith('atsc') else 'CACC ' + env.name, n_agent, E, env.agent,
+                          cfg_name, n_step),
+           'steps': args.other_steps, 'ms_per_step': elapsed / args.other_steps * 1e3,
+           'value': n_agent * E * n_step * args.other_steps / elapsed, 'unit': 'env-steps/s',
+           'a2c_updates_per_s': args.other_steps / elapsed, 'handoff_fallbacks': trainer.handoff_fallbacks,
+           'one_launch_lock_step': bool(model.policy.pv_one_launch(E))}
+    try:
+        us_l, flops_l, bytes_l, lname = measure_lstm_step(model)
+        us_iso = us_l
+        try:
+            us_l = measure_lstm_step_in_rollout(trainer)[0]
+        except Exception as ex:
+            res['roofline_in_rollout_error'] = repr(ex)
+        res['roofline'] = {'kernel': lname, 'bound': 'mfma', 'us_per_launch': us_l, 'us_per_launch_isolated_graph': us_iso,
+                           'achieved': flops_l / us_l / 1e6, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                           'frac': flops_l / us_l / 1e6 / MFMA_F32_PEAK_TFLOPS, 'flops_per_launch': flops_l,
+                           'launches_per_batch': (n_step + 1) * (1 if model.policy.pv_one_launch(E) else 2),
+                           'how': 'as the headline `roofline`: in-rollout launch time by difference of two hipGraph timings'}
+    except Exception as ex:
+        res['roofline'] = {'error': repr(ex)}
+    try:
+        m = measure_bptt_coupled(model)
+        if m is not None:
+            us_b, bytes_b, bname = m
+            res['roofline_bptt'] = {'kernel': bname, 'bound': 'hbm', 'us_per_launch': us_b, 'achieved': bytes_b / us_b / 1e3,
+                                    'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': bytes_b / us_b / 1e3 / HBM_PEAK_GBPS,
+                                    'bytes_per_launch': bytes_b, 'launches_per_batch': 1}
+    except Exception as ex:
+        res['roofline_bptt'] = {'error': repr(ex)}
+    del trainer, model, env
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def pmc_traffic(key):
@@ -706,6 +817,19 @@ def main():
                 out['roofline_env_step_large_E'] = {'error': repr(ex)}
         if world == 1 and not args.no_cpu_baseline and not is_grid:
             out['cpu_baseline'] = cpu_baseline(args.config, args.cpu_batches)
+        # ---- the other BASELINE configs (coupled nets), measured the same way after the headline's timed region
+        default_cfg = os.path.abspath(args.config) == os.path.abspath(os.path.join(ROOT, 'config', 'config_ia2c_fp_catchup.ini'))
+        if world == 1 and default_cfg and not args.no_other_configs and not args.envs:
+            del trainer, model, env
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out['other_configs'] = []
+            for cfg_name in OTHER_CONFIGS:
+                try:
+                    out['other_configs'].append(run_other_config(args, cfg_name, device))
+                except Exception as ex:      # never lose the headline line to a side measurement
+                    out['other_configs'].append({'workload': cfg_name, 'error': repr(ex)})
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -55,7 +55,8 @@ class Msg(C.Structure):
                 ('enc', C.c_void_p), ('enc_sn', C.c_int64), ('enc_row', C.c_int64),
                 ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64), ('sync', C.c_void_p),
                 ('ob', C.c_void_p), ('ob_row', C.c_int64), ('ob_F', C.c_int32), ('ob_segs', C.c_int32), ('ob_nbr', C.c_void_p),
-                ('ob_img', C.c_void_p), ('ob_img_sn', C.c_int64), ('ob_b', C.c_void_p), ('ob_b_sn', C.c_int64)]
+                ('ob_img', C.c_void_p), ('ob_img_sn', C.c_int64), ('ob_b', C.c_void_p), ('ob_b_sn', C.c_int64),
+                ('status', C.c_void_p)]
 
 
 class NetParams(C.Structure):
@@ -104,7 +105,7 @@ class BpttCoupled(C.Structure):
     _fields_ = ([(k, C.c_int32) for k in ('kind', 'N', 'T', 'H', 'm_max', 'r_max', 'r_row', 'symmetric', 'mode', 'ring_slots')] +
                 [('E', C.c_int64)] +
                 [(k, C.c_void_p) for k in ('gates', 'c_all', 'done', 'dh_ext', 'img', 'img_m', 'mask', 'dz', 'd1', 'ring', 'db_part',
-                                           'dbm_part', 'dhr_io', 'dc_io', 'ws', 'rev_agent', 'rev_col', 'rev_w')] +
+                                           'dbm_part', 'dhr_io', 'dc_io', 'ws', 'status', 'rev_agent', 'rev_col', 'rev_w')] +
                 [(k, C.c_int64) for k in ('gates_sn', 'gates_st', 'c_sn', 'c_st', 'dh_sn', 'dh_st', 'img_sn', 'imgm_sn', 'mask_sn',
                                           'mask_st', 'mask_row', 'dz_sn', 'dz_st', 'd1_sn', 'd1_st', 'ring_sn', 'ring_slot', 'db_sn',
                                           'dbm_sn', 'io_sn')])
@@ -182,6 +183,9 @@ SIGNATURES = {
     'nmarl_sample_actions': [_i64, _i32, _i32, _p, _p, _i32, _u64, _i64, _i64, _p, _p, _p],
     'nmarl_nstep_return': [_i64, _i32, _i32, _p, _p, _p, _p, C.c_double, C.c_double, _p, _p, _p, _p],
     'nmarl_rmsprop_tf_clip': [_i32, _i64, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p],
+    'nmarl_rmsprop_tf_clip_guarded': [_i32, _i64, _p, _p, _p, _p, _p, _f32, _f32, _f32, _f32, _f32, _p, _p, _p],
+    'nmarl_handoff_capacity': [_i32, _i32],
+    'nmarl_test_handoff_fault': [_i32],
     'nmarl_batch_epilogue': [C.POINTER(BatchEpilogue), _p],
 }
 

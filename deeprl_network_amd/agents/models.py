@@ -451,6 +451,10 @@ class IA2C:
             import torch.distributed as dist
             dist.all_reduce(ps.grad, group=self.dist_group)          # ONE flat RCCL all-reduce over xGMI
             scale = 1.0 / dist.get_world_size(self.dist_group)
+            if self.policy.coupled and self.save_acts and self.device.type == 'cuda' and ops.handoff_enabled():
+                # a rank whose in-launch hand-off timed out contributed invalid gradients: every rank must refuse the step
+                # (and recover in lock-step, BatchedTrainer.run_batch) -- the status word travels as a MAX reduction
+                dist.all_reduce(ops.handoff_status(self.device)[:1], op=dist.ReduceOp.MAX, group=self.dist_group)
         if self.per_agent_optimizer:
             ops.rmsprop_tf_clip(ps.flat, ps.grad, ps.ms, ps.scratch, cur_lr, self.rmsp_alpha, self.rmsp_epsilon,
                                 self.max_grad_norm, scale, self.grad_norm)

@@ -379,14 +379,16 @@ class BatchedPolicy:
     def pv_one_launch(self, E):
         if self.fused_pv:
             return True
-        return self.fused_pv_coupled and ops.step_handoff_supported(self.N, E, self.device)
-
-    _sync = None
+        K = self.n_h * self.m_max if self.msg_kind == ops.MSG_GATHER_RELU else self.n_h
+        return self.fused_pv_coupled and ops.step_handoff_supported(self.N, E, self.device, K=K)
 
     def _sync_words(self, E):
-        if self._sync is None or self._sync_E != E:
-            self._sync, self._sync_E = ops.step_sync_words(self.N, E, self.device), E
-        return self._sync
+        """Flag words of the one-launch step per replica count, never dropped or replaced (a captured hipGraph holds the
+        pointer of the one its rollout used, cf. `_scratch`)."""
+        pool = self.__dict__.setdefault('_sync_pool', {})
+        if E not in pool:
+            pool[E] = ops.step_sync_words(self.N, E, self.device)
+        return pool[E]
 
     def encodes_in_step(self, E, compact):
         """The one-launch step of this net also runs the observation encoder (no separate encoder launch per lock-step)."""

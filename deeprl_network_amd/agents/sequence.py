@@ -214,6 +214,8 @@ class CoupledSequenceSaved(torch.autograd.Function):
         if fused and ckind is not None and ops.bptt_coupled_supported(ckind, nbr_idx.shape[1], H) and w_msg.stride(2) == 1 and \
                 w_msg.stride(1) == H:
             rev = _reverse_table(nbr_idx, ckind)
+            if rev is not None and not ops.bptt_coupled_supported(ckind, nbr_idx.shape[1], H, rev=rev):
+                rev = None                    # e.g. lstm_comm with more than 2 sources per agent: the step-wise loop below
         if rev is not None:
             # the WHOLE reverse recurrence in one launch: cell backward, [dx | dh] = dz @ [wxm; wh]^T, relu mask, the message
             # adjoint D1 @ w_msg^T handed between the agents' blocks inside the kernel, both bias gradients on the way

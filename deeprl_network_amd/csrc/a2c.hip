@@ -320,8 +320,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const int64_t P, const float
 __global__ __launch_bounds__(256) void rmsprop_kernel(
     const int64_t P, float* __restrict__ w, const float* __restrict__ g, float* __restrict__ ms,
     const float* __restrict__ partial, const float* __restrict__ lr_ptr, const float lr_host, const float rho,
-    const float eps, const float max_norm, const float grad_scale, float* __restrict__ norm_out) {
+    const float eps, const float max_norm, const float grad_scale, float* __restrict__ norm_out, int32_t* status) {
     const int grp = blockIdx.y;
+    // fail closed: a hand-off kernel of this batch reported a wave that gave up waiting (status[0] != 0, see
+    // nmarl_handoff_status in nmarl.h) -- its gradients are invalid, so NOTHING is applied: weights and slots keep their
+    // values, the skipped update is counted (status[1]) and the host re-runs the batch on the launch-per-step path
+    if (status && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(status + 1, 1);
+        return;
+    }
     // every block re-reduces its group's 64 partials in the same fixed order
     float tot = 0.0f;
     for (int b = 0; b < SUMSQ_BLOCKS; ++b) tot += partial[grp * SUMSQ_BLOCKS + b];
@@ -522,15 +529,22 @@ extern "C" int nmarl_nstep_return(int64_t E, int32_t N, int32_t T, const float* 
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
-                                     const float* lr_dev, float lr, float rho, float eps, float max_norm,
-                                     float grad_scale, float* grad_norm_out, void* stream) {
-    if (G <= 0 || P <= 0 || !w || !g || !ms || !scratch) return NMARL_EINVAL;
+extern "C" int nmarl_rmsprop_tf_clip_guarded(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
+                                             const float* lr_dev, float lr, float rho, float eps, float max_norm,
+                                             float grad_scale, float* grad_norm_out, int32_t* status, void* stream) {
+    if (G <= 0 || P <= 0 || !w || !g || !ms || !scratch || ((uintptr_t)status % 4)) return NMARL_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS, G), dim3(256), 0, s, P, g, scratch);
     hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_x(P, 1024), G), dim3(256), 0, s, P, w, g, ms, scratch, lr_dev, lr, rho,
-                       eps, max_norm, grad_scale, grad_norm_out);
+                       eps, max_norm, grad_scale, grad_norm_out, status);
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
+                                     const float* lr_dev, float lr, float rho, float eps, float max_norm,
+                                     float grad_scale, float* grad_norm_out, void* stream) {
+    return nmarl_rmsprop_tf_clip_guarded(G, P, w, g, ms, scratch, lr_dev, lr, rho, eps, max_norm, grad_scale, grad_norm_out,
+                                         nullptr, stream);
 }
 
 static int loss_chunks(int64_t rows, int N) {

@@ -86,3 +86,13 @@ __device__ __forceinline__ int nmarl_draw_action(const float (&p)[MAXA], const i
     return a > A - 1 ? A - 1 : a;
 }
 
+
+
+// ---- in-launch hand-off: residency and the test hook (defined in lstm_mfma.hip, used by lstm_bptt.hip too)
+// compute units the residency decisions count with: the device's, or NMARL_TEST_FAKE_CUS from the environment (tests)
+#define NMARL_INTERNAL __attribute__((visibility("hidden")))      // library-internal C++ helpers: not part of the C-ABI
+NMARL_INTERNAL int nmarl_handoff_cus();
+// consume one armed fault (nmarl_test_handoff_fault): true exactly for the nth hand-off launch after arming
+NMARL_INTERNAL bool nmarl_handoff_take_fault();
+constexpr unsigned NMARL_HANDOFF_MAX_SPINS = 1u << 20;      // ~0.1 s of s_sleep polling before a wave gives up
+constexpr unsigned NMARL_HANDOFF_FAULT_SPINS = 1u << 12;    // the injected fault: give up quickly

@@ -219,7 +219,11 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_step_kernel(const BpttArgs a
 // The bias gradient (column sums of dz over all T x rows) is accumulated on the way: per group of 16 values a two-level
 // DPP reduce-scatter over the lane quad (rows c, c^1, c^2, c^3) leaves 4 sums per lane (one gate each), so the running
 // sums cost 16 registers instead of 64; they leave as one [256] partial per block (summed by the caller).
-// Arithmetic per step is that of lstm_bptt_step_kernel<4> with apply_keep = 1, operation for operation.
+// Arithmetic per step is that of lstm_bptt_step_kernel<4> with apply_keep = 1, operation for operation -- except that
+// c_t (for tanh(c_t)) is not read: it is RECOMPUTED from the step's own gates and c_{t-1} exactly as every forward kernel
+// forms it (lstm_mfma.hip / a2c.hip: cv = gf * (cp * keep) + gi * gu, four separately rounded operations under
+// -ffp-contract=off), i.e. bit-identical to the stored c_all[t + 1] whenever the saved sequences come from a forward pass.
+// That removes 16 persistent registers (the carried c_t) -- the kernel no longer spills -- and the read of c_all[T].
 struct BpttSeqArgs {
     const float *gates, *c_all, *done, *dh_ext, *img;
     float *dz, *db_part, *dh0, *dc0;
@@ -230,6 +234,10 @@ struct BpttSeqArgs {
 
 struct SeqGroup {           // per-step inputs of 4 consecutive units of one row
     float4 gi, gf, go, gu, cp, gh;
+};
+
+struct GateGroup {          // gates and c_{t-1} of 4 consecutive units of one row (lstm_bptt_coupled_kernel's slots)
+    float4 gi, gf, go, gu, cp;
 };
 
 constexpr int SEQ_IMG = G4 * 16 * 4;                 // image floats (NT = 4)
@@ -305,11 +313,10 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
     SeqGroup u0, u1, u2, u3;
     NMARL_SEQ_LOAD2(u0, u1, T - 1, 0)
     NMARL_SEQ_LOAD2(u2, u3, T - 1, 2)
-    float4 cn[4], dc[4];
+    float4 dc[4];
     f32x4 dhr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        cn[j] = bload4(make_rsrc(cA + (int64_t)T * a.c_st, nb1), lo1 + 64 * j);
         dc[j] = float4{0.f, 0.f, 0.f, 0.f};
         dhr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -329,15 +336,15 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
     }
 #define NMARL_SEQ_CELLB(U, j, k, i_)                                                       \
     {                                                                                      \
-        const float tc = tanh_fast_(cn[j].k);                                              \
+        const float cpk = U.cp.k * keepA;                                                  \
+        const float tc = tanh_fast_(U.gf.k * cpk + U.gi.k * U.gu.k);   /* c_t, op for op the forward's (see above) */ \
         const float gh_ = U.gh.k + dhr[j][i_];                                     \
         const float g_c = dc[j].k + gh_ * U.go.k * (1.0f - tc * tc);                       \
         di.k = g_c * U.gu.k * U.gi.k * (1.0f - U.gi.k);                                    \
-        df.k = g_c * (U.cp.k * keepA) * U.gf.k * (1.0f - U.gf.k);                          \
+        df.k = g_c * cpk * U.gf.k * (1.0f - U.gf.k);                                       \
         dO.k = gh_ * tc * U.go.k * (1.0f - U.go.k);                                        \
         du.k = g_c * U.gi.k * (1.0f - U.gu.k * U.gu.k);                                    \
         dc[j].k = g_c * U.gf.k * keepA;                                                    \
-        cn[j].k = U.cp.k;                                                                  \
     }
     // bias sums of one group: 16 values -> (quad reduce-scatter) -> 4 per lane: gate 2 (c & 1) + ((c >> 1) & 1)
 #define NMARL_SEQ_DB1(j, k, i_)                                                            \
@@ -501,6 +508,9 @@ struct CoupledArgs {
         ring_sn, ring_slot, db_sn, dbm_sn, io_sn;
     int64_t E;
     int32_t N, T, t_hi, t_lo, mask_row, tiles, slots;
+    int32_t* status;                        // may be NULL: hand-off status words ([0] <- 1 when a wave gives up, sticky)
+    unsigned max_spins;
+    int32_t fault;                          // test hook: block 0 never publishes (its neighbours time out)
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -516,8 +526,6 @@ constexpr int SC1 = 16;                              // aux bit: write-through s
 __device__ __forceinline__ void bstore4_wt(const __amdgpu_buffer_rsrc_t r, const uint32_t off, const float4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, SC1);      // write-through (sc1)
 }
-
-constexpr unsigned COUPLED_MAX_SPINS = 1u << 20;
 
 template <int NTM, int RMAX, bool MASK>     // NTM: 16-column tiles of a message row (64 m_max / 16 or 4); RMAX: max sources
 __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const CoupledArgs a) {
@@ -573,46 +581,51 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     gu32* my_flag = (gu32*)(a.flags + ((int64_t)n * a.tiles + blk) * WAVES + wave);
     bool give_up = false;
 
-#define NMARL_CP_LOAD2(UA, UB, t_, j)                                                      \
+    // Register diet (round 4): the step's inputs are NOT all prefetched a step ahead any more.  Gates + c_{t-1} of one unit
+    // group (5 float4 = 20 registers) cycle through TWO slots -- group j + 2 is requested as soon as group j's cell backward
+    // has consumed its slot, i.e. one product + one cell phase (>= 4 k cycles) before its use; the two 64-byte halves of a
+    // 128-byte line (groups 0 / 1 and 2 / 3) are requested one product apart, while the line still sits in the XCD's L2 --,
+    // the heads' dL/dh of the whole step (16 registers) is requested a step ahead as before, and c_t is recomputed (see
+    // lstm_bptt_seq_kernel).  96 + 16 persistent registers became 40 + 16: no spilled VGPR, no scratch traffic (the reloads
+    // were VMEM loads that queued behind -- and drained -- the prefetches).
+#define NMARL_CP_LOADG(S, t_, j)                                                           \
     {                                                                                      \
         const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);                            \
         const __amdgpu_buffer_rsrc_t rg_ = make_rsrc(gA + ts_ * a.gates_st, nb4);          \
         const __amdgpu_buffer_rsrc_t rc_ = make_rsrc(cA + ts_ * a.c_st, nb1);              \
-        const __amdgpu_buffer_rsrc_t re_ = make_rsrc(eA + ts_ * a.dh_st, nb1);             \
-        UA.gi = bload4i(rg_, lo4, (64 * (j)) * 1);                                               \
-        UB.gi = bload4i(rg_, lo4, (64 * (j) + 64) * 1);                                          \
-        UA.gf = bload4i(rg_, lo4, (64 * (j) + 4 * H) * 1);                                       \
-        UB.gf = bload4i(rg_, lo4, (64 * (j) + 4 * H + 64) * 1);                                  \
-        UA.go = bload4i(rg_, lo4, (64 * (j) + 8 * H) * 1);                                       \
-        UB.go = bload4i(rg_, lo4, (64 * (j) + 8 * H + 64) * 1);                                  \
-        UA.gu = bload4i(rg_, lo4, (64 * (j) + 12 * H) * 1);                                      \
-        UB.gu = bload4i(rg_, lo4, (64 * (j) + 12 * H + 64) * 1);                                 \
-        UA.cp = bload4i(rc_, lo1, (64 * (j)) * 1);                                               \
-        UB.cp = bload4i(rc_, lo1, (64 * (j) + 64) * 1);                                          \
-        UA.gh = bload4i(re_, lo1, (64 * (j)) * 1);                                               \
-        UB.gh = bload4i(re_, lo1, (64 * (j) + 64) * 1);                                          \
+        S.gi = bload4i(rg_, lo4, (64 * (j)) * 1);                                          \
+        S.gf = bload4i(rg_, lo4, (64 * (j) + 4 * H) * 1);                                  \
+        S.go = bload4i(rg_, lo4, (64 * (j) + 8 * H) * 1);                                  \
+        S.gu = bload4i(rg_, lo4, (64 * (j) + 12 * H) * 1);                                 \
+        S.cp = bload4i(rc_, lo1, (64 * (j)) * 1);                                          \
     }
-    SeqGroup u0, u1, u2, u3;
-    NMARL_CP_LOAD2(u0, u1, t_hi, 0)
-    NMARL_CP_LOAD2(u2, u3, t_hi, 2)
-    float4 cn[4], dc[4];
+#define NMARL_CP_LOADH(t_)                                                                 \
+    {                                                                                      \
+        const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);                            \
+        const __amdgpu_buffer_rsrc_t re_ = make_rsrc(eA + ts_ * a.dh_st, nb1);             \
+        gh[0] = bload4i(re_, lo1, 0);                                                      \
+        gh[1] = bload4i(re_, lo1, 64);                                                     \
+        gh[2] = bload4i(re_, lo1, 128);                                                    \
+        gh[3] = bload4i(re_, lo1, 192);                                                    \
+    }
+    GateGroup sA, sB;
+    float4 gh[4], dc[4];
+    NMARL_CP_LOADG(sA, t_hi, 0)
+    NMARL_CP_LOADG(sB, t_hi, 1)
+    NMARL_CP_LOADH(t_hi)
     {
         // state the range starts from: zero at the end of the sequence, else what the previous launch left.  The recurrent
         // dL/dh lives INSIDE the prefetched inputs: it is added to the heads' dL/dh (gh) of the step it belongs to
         const bool first = t_hi == T - 1;
-        const __amdgpu_buffer_rsrc_t rcn = make_rsrc(cA + (int64_t)(t_hi + 1) * a.c_st, nb1);
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.dhr_io + (int64_t)n * a.io_sn, first ? 0u : nb1);
         const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.dc_io + (int64_t)n * a.io_sn, first ? 0u : nb1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cn[j] = bload4i(rcn, lo1, 64 * j);
-            dc[j] = bload4i(rd, lo1, 64 * j);                         // num_records 0: reads 0
-        }
+        for (int j = 0; j < 4; ++j) dc[j] = bload4i(rd, lo1, 64 * j);                   // num_records 0: reads 0
         const float4 h0 = bload4i(rh, lo1, 0), h1 = bload4i(rh, lo1, 64), h2 = bload4i(rh, lo1, 128), h3 = bload4i(rh, lo1, 192);
-        u0.gh.x += h0.x; u0.gh.y += h0.y; u0.gh.z += h0.z; u0.gh.w += h0.w;
-        u1.gh.x += h1.x; u1.gh.y += h1.y; u1.gh.z += h1.z; u1.gh.w += h1.w;
-        u2.gh.x += h2.x; u2.gh.y += h2.y; u2.gh.z += h2.z; u2.gh.w += h2.w;
-        u3.gh.x += h3.x; u3.gh.y += h3.y; u3.gh.z += h3.z; u3.gh.w += h3.w;
+        gh[0].x += h0.x; gh[0].y += h0.y; gh[0].z += h0.z; gh[0].w += h0.w;
+        gh[1].x += h1.x; gh[1].y += h1.y; gh[1].z += h1.z; gh[1].w += h1.w;
+        gh[2].x += h2.x; gh[2].y += h2.y; gh[2].z += h2.z; gh[2].w += h2.w;
+        gh[3].x += h3.x; gh[3].y += h3.y; gh[3].z += h3.z; gh[3].w += h3.w;
     }
     // bias-gradient partial sums, fully reduced over the wave's 16 rows every step: lane (c, q) keeps, per unit group j,
     // the column of gate 2 (c & 1) + ((c >> 1) & 1), unit 16 j + 4 q + 2 ((c >> 2) & 1) + ((c >> 3) & 1)  (4 registers), and of
@@ -624,31 +637,41 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     float keepA = 1.0f - (a.done + (int64_t)t_hi * a.E)[lor];
     __syncthreads();                                 // images visible
 
-#define NMARL_CP_KSTEP(bv, s)                                                              \
+    // one k-step = the image row (s, q) of all 8 output tiles (two ds_read_b128) x the lane's dz value: 8 MFMAs.  The reads of
+    // k-step s + 2 are issued right after the MFMAs of step s released their register set (two sets, pinned by scheduling
+    // fences): left alone the compiler reads each row immediately before its use and every k-step waits out the LDS latency
+#define NMARL_CP_BL(P, s)                                                                  \
     {                                                                                      \
         const float* p_ = abase + (s) * 64 * 8;                                            \
-        const float4 w0_ = *reinterpret_cast<const float4*>(p_ + 4 * sw);                  \
-        const float4 w1_ = *reinterpret_cast<const float4*>(p_ + 4 * (sw ^ 1));            \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.x, bv, acc[0], 0, 0, 0);         \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.y, bv, acc[1], 0, 0, 0);         \
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.z, bv, acc[2], 0, 0, 0);         \
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.w, bv, acc[3], 0, 0, 0);         \
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.x, bv, acc[4], 0, 0, 0);         \
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.y, bv, acc[5], 0, 0, 0);         \
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.z, bv, acc[6], 0, 0, 0);         \
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.w, bv, acc[7], 0, 0, 0);         \
+        P##0 = *reinterpret_cast<const float4*>(p_ + 4 * sw);                              \
+        P##1 = *reinterpret_cast<const float4*>(p_ + 4 * (sw ^ 1));                        \
     }
+#define NMARL_CP_MF(bv, P)                                                                 \
+    {                                                                                      \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .x, bv, acc[0], 0, 0, 0);        \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .y, bv, acc[1], 0, 0, 0);        \
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .z, bv, acc[2], 0, 0, 0);        \
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .w, bv, acc[3], 0, 0, 0);        \
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .x, bv, acc[4], 0, 0, 0);        \
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .y, bv, acc[5], 0, 0, 0);        \
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .z, bv, acc[6], 0, 0, 0);        \
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .w, bv, acc[7], 0, 0, 0);        \
+    }
+    // MFMAs of k-step s from set P, then the reads of k-step s + 2 into the same set
+#define NMARL_CP_KS(bv, P, s2)                                                             \
+    NMARL_CP_MF(bv, P) __builtin_amdgcn_sched_barrier(0);                                  \
+    NMARL_CP_BL(P, s2) __builtin_amdgcn_sched_barrier(0);
 #define NMARL_CP_CELLB(U, j, k, i_)                                                        \
     {                                                                                      \
-        const float tc = tanh_fast_(cn[j].k);                                              \
-        const float gh_ = U.gh.k;                                                          \
+        const float cpk = U.cp.k * keepA;                                                  \
+        const float tc = tanh_fast_(U.gf.k * cpk + U.gi.k * U.gu.k);   /* c_t as the forward formed it */ \
+        const float gh_ = gh[j].k;                                                         \
         const float g_c = dc[j].k + gh_ * U.go.k * (1.0f - tc * tc);                       \
         di.k = g_c * U.gu.k * U.gi.k * (1.0f - U.gi.k);                                    \
-        df.k = g_c * (U.cp.k * keepA) * U.gf.k * (1.0f - U.gf.k);                          \
+        df.k = g_c * cpk * U.gf.k * (1.0f - U.gf.k);                                       \
         dO.k = gh_ * tc * U.go.k * (1.0f - U.go.k);                                        \
         du.k = g_c * U.gi.k * (1.0f - U.gu.k * U.gu.k);                                    \
         dc[j].k = g_c * U.gf.k * keepA;                                                    \
-        cn[j].k = U.cp.k;                                                                  \
     }
 #define NMARL_CP_DB1(j, k, i_)                                                             \
     {                                                                                      \
@@ -675,38 +698,45 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         bstore4(rz, so4 + (64 * (j) + 4 * H), df);                                           \
         bstore4(rz, so4 + (64 * (j) + 8 * H), dO);                                           \
         bstore4(rz, so4 + (64 * (j) + 12 * H), du);                                          \
-        NMARL_CP_KSTEP(di.x, (j) * 16 + 0) NMARL_CP_KSTEP(di.y, (j) * 16 + 1)              \
-        NMARL_CP_KSTEP(di.z, (j) * 16 + 2) NMARL_CP_KSTEP(di.w, (j) * 16 + 3)              \
-        NMARL_CP_KSTEP(df.x, (j) * 16 + 4) NMARL_CP_KSTEP(df.y, (j) * 16 + 5)              \
-        NMARL_CP_KSTEP(df.z, (j) * 16 + 6) NMARL_CP_KSTEP(df.w, (j) * 16 + 7)              \
-        NMARL_CP_KSTEP(dO.x, (j) * 16 + 8) NMARL_CP_KSTEP(dO.y, (j) * 16 + 9)              \
-        NMARL_CP_KSTEP(dO.z, (j) * 16 + 10) NMARL_CP_KSTEP(dO.w, (j) * 16 + 11)            \
-        NMARL_CP_KSTEP(du.x, (j) * 16 + 12) NMARL_CP_KSTEP(du.y, (j) * 16 + 13)            \
-        NMARL_CP_KSTEP(du.z, (j) * 16 + 14) NMARL_CP_KSTEP(du.w, (j) * 16 + 15)            \
+        float4 pa0, pa1, pb0, pb1;                                                         \
+        NMARL_CP_BL(pa, (j) * 16 + 0) NMARL_CP_BL(pb, (j) * 16 + 1) __builtin_amdgcn_sched_barrier(0); \
+        NMARL_CP_KS(di.x, pa, (j) * 16 + 2) NMARL_CP_KS(di.y, pb, (j) * 16 + 3)            \
+        NMARL_CP_KS(di.z, pa, (j) * 16 + 4) NMARL_CP_KS(di.w, pb, (j) * 16 + 5)            \
+        NMARL_CP_KS(df.x, pa, (j) * 16 + 6) NMARL_CP_KS(df.y, pb, (j) * 16 + 7)            \
+        NMARL_CP_KS(df.z, pa, (j) * 16 + 8) NMARL_CP_KS(df.w, pb, (j) * 16 + 9)            \
+        NMARL_CP_KS(dO.x, pa, (j) * 16 + 10) NMARL_CP_KS(dO.y, pb, (j) * 16 + 11)          \
+        NMARL_CP_KS(dO.z, pa, (j) * 16 + 12) NMARL_CP_KS(dO.w, pb, (j) * 16 + 13)          \
+        NMARL_CP_KS(du.x, pa, (j) * 16 + 14) NMARL_CP_KS(du.y, pb, (j) * 16 + 15)          \
+        NMARL_CP_MF(du.z, pa) __builtin_amdgcn_sched_barrier(0);                           \
+        NMARL_CP_MF(du.w, pb)                                                              \
     }
     // message product: k-step s = 4 t_ + r_ takes D1 unit 16 t_ + 4 q + r_ of the lane's row
-#define NMARL_CP_MSTEP(bv, s)                                                              \
+#define NMARL_CP_MBL(P, s)                                                                 \
     {                                                                                      \
         const float* p_ = mbase + (s) * 64 * NTM;                                          \
         if (NTM == 4) {                                                                    \
-            const float4 w0_ = *reinterpret_cast<const float4*>(p_);                       \
-            am[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.x, bv, am[0], 0, 0, 0);       \
-            am[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.y, bv, am[1], 0, 0, 0);       \
-            am[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.z, bv, am[2], 0, 0, 0);       \
-            am[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.w, bv, am[3], 0, 0, 0);       \
+            P##0 = *reinterpret_cast<const float4*>(p_);                                   \
         } else {                                                                           \
-            const float4 w0_ = *reinterpret_cast<const float4*>(p_ + 4 * sw);              \
-            const float4 w1_ = *reinterpret_cast<const float4*>(p_ + 4 * (sw ^ 1));        \
-            am[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.x, bv, am[0], 0, 0, 0);       \
-            am[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.y, bv, am[1], 0, 0, 0);       \
-            am[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.z, bv, am[2], 0, 0, 0);       \
-            am[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0_.w, bv, am[3], 0, 0, 0);       \
-            am[NTM - 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.x, bv, am[NTM - 4], 0, 0, 0); \
-            am[NTM - 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.y, bv, am[NTM - 3], 0, 0, 0); \
-            am[NTM - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.z, bv, am[NTM - 2], 0, 0, 0); \
-            am[NTM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1_.w, bv, am[NTM - 1], 0, 0, 0); \
+            P##0 = *reinterpret_cast<const float4*>(p_ + 4 * sw);                          \
+            P##1 = *reinterpret_cast<const float4*>(p_ + 4 * (sw ^ 1));                    \
         }                                                                                  \
     }
+#define NMARL_CP_MMF(bv, P)                                                                \
+    {                                                                                      \
+        am[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .x, bv, am[0], 0, 0, 0);          \
+        am[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .y, bv, am[1], 0, 0, 0);          \
+        am[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .z, bv, am[2], 0, 0, 0);          \
+        am[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##0 .w, bv, am[3], 0, 0, 0);          \
+        if (NTM == 8) {                                                                    \
+            am[NTM - 4] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .x, bv, am[NTM - 4], 0, 0, 0); \
+            am[NTM - 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .y, bv, am[NTM - 3], 0, 0, 0); \
+            am[NTM - 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .z, bv, am[NTM - 2], 0, 0, 0); \
+            am[NTM - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P##1 .w, bv, am[NTM - 1], 0, 0, 0); \
+        }                                                                                  \
+    }
+#define NMARL_CP_MKS(bv, P, s2)                                                            \
+    NMARL_CP_MMF(bv, P) __builtin_amdgcn_sched_barrier(0);                                 \
+    NMARL_CP_MBL(P, s2) __builtin_amdgcn_sched_barrier(0);
     const int sw = c >> 3;
     for (int t = t_hi; t >= t_lo; --t) {
         const int tp = t > t_lo ? t - 1 : t_lo;      // clamped: the last prefetch re-reads the range's last step
@@ -727,7 +757,9 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         {
             const unsigned need = (unsigned)(T - 1 - t);
             const float* rbase = a.ring + (int64_t)((t + 1) % a.slots) * a.ring_slot;
-            const float wsel0 = t == T - 1 ? 0.0f : 1.0f;
+            // at the end of the sequence nothing was handed over yet: a zero-record resource reads 0.0f (no stale -- possibly
+            // non-finite -- ring contents times a zero weight)
+            const uint32_t nbR_t = t == T - 1 ? 0u : nbR;
 #pragma unroll
             for (int s = 0; s < RMAX; ++s) {
                 if (!give_up) {
@@ -735,8 +767,11 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
                         const unsigned v = __builtin_amdgcn_readfirstlane(
                             __hip_atomic_load(src_flag[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                         if (v >= need) break;
-                        if (spins > COUPLED_MAX_SPINS) {
-                            if (lane == 0) __hip_atomic_store((gu32*)a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (spins > a.max_spins) {
+                            if (lane == 0) {             // sticky: the optimiser step refuses this batch
+                                __hip_atomic_store((gu32*)a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (a.status) __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
                             give_up = true;
                             break;
                         }
@@ -744,17 +779,17 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
                     }
                 }
                 asm volatile("" ::: "memory");       // payload loads stay below the poll
-                const __amdgpu_buffer_rsrc_t rr = make_rsrc(rbase + (int64_t)src_n[s] * a.ring_sn, nbR);
-                const float w_ = src_w[s] * wsel0;
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc(rbase + (int64_t)src_n[s] * a.ring_sn, nbR_t);
+                const float w_ = src_w[s];
                 const uint32_t ro_ = loR + src_c4[s];
                 const float4 m0 = bload4i<SC1>(rr, ro_, 0);
                 const float4 m1 = bload4i<SC1>(rr, ro_, 64);
                 const float4 m2 = bload4i<SC1>(rr, ro_, 128);
                 const float4 m3 = bload4i<SC1>(rr, ro_, 192);
-                u0.gh.x += w_ * m0.x; u0.gh.y += w_ * m0.y; u0.gh.z += w_ * m0.z; u0.gh.w += w_ * m0.w;
-                u1.gh.x += w_ * m1.x; u1.gh.y += w_ * m1.y; u1.gh.z += w_ * m1.z; u1.gh.w += w_ * m1.w;
-                u2.gh.x += w_ * m2.x; u2.gh.y += w_ * m2.y; u2.gh.z += w_ * m2.z; u2.gh.w += w_ * m2.w;
-                u3.gh.x += w_ * m3.x; u3.gh.y += w_ * m3.y; u3.gh.z += w_ * m3.z; u3.gh.w += w_ * m3.w;
+                gh[0].x += w_ * m0.x; gh[0].y += w_ * m0.y; gh[0].z += w_ * m0.z; gh[0].w += w_ * m0.w;
+                gh[1].x += w_ * m1.x; gh[1].y += w_ * m1.y; gh[1].z += w_ * m1.z; gh[1].w += w_ * m1.w;
+                gh[2].x += w_ * m2.x; gh[2].y += w_ * m2.y; gh[2].z += w_ * m2.z; gh[2].w += w_ * m2.w;
+                gh[3].x += w_ * m3.x; gh[3].y += w_ * m3.y; gh[3].z += w_ * m3.z; gh[3].w += w_ * m3.w;
                 __builtin_amdgcn_sched_barrier(0);   // one source's 4 loads in flight at a time (registers)
             }
         }
@@ -780,23 +815,28 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         float4 di, df, dO, du;
-        NMARL_CP_CELL(u0, 0)
+        NMARL_CP_CELL(sA, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_LOADG(sA, t, 2)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_PROD(0)
         __builtin_amdgcn_sched_barrier(0);
-        NMARL_CP_CELL(u1, 1)
+        NMARL_CP_CELL(sB, 1)
         __builtin_amdgcn_sched_barrier(0);
-        NMARL_CP_LOAD2(u0, u1, tp, 0)
+        NMARL_CP_LOADG(sB, t, 3)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_PROD(1)
         __builtin_amdgcn_sched_barrier(0);
-        NMARL_CP_CELL(u2, 2)
+        NMARL_CP_CELL(sA, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_CP_LOADG(sA, tp, 0)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_PROD(2)
         __builtin_amdgcn_sched_barrier(0);
-        NMARL_CP_CELL(u3, 3)
+        NMARL_CP_CELL(sB, 3)
         __builtin_amdgcn_sched_barrier(0);
-        NMARL_CP_LOAD2(u2, u3, tp, 2)
+        NMARL_CP_LOADG(sB, tp, 1)
+        NMARL_CP_LOADH(tp)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_PROD(3)
         __builtin_amdgcn_sched_barrier(0);
@@ -834,17 +874,24 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
             f32x4 am[NTM];
 #pragma unroll
             for (int i = 0; i < NTM; ++i) am[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t_ = 0; t_ < 4; ++t_) {
-                NMARL_CP_MSTEP(d1v[t_][0], t_ * 4 + 0) NMARL_CP_MSTEP(d1v[t_][1], t_ * 4 + 1)
-                NMARL_CP_MSTEP(d1v[t_][2], t_ * 4 + 2) NMARL_CP_MSTEP(d1v[t_][3], t_ * 4 + 3)
+            {
+                float4 pa0, pa1, pb0, pb1;
+                pa1 = pb1 = float4{0.f, 0.f, 0.f, 0.f};
+                NMARL_CP_MBL(pa, 0) NMARL_CP_MBL(pb, 1) __builtin_amdgcn_sched_barrier(0);
+                NMARL_CP_MKS(d1v[0][0], pa, 2) NMARL_CP_MKS(d1v[0][1], pb, 3) NMARL_CP_MKS(d1v[0][2], pa, 4) NMARL_CP_MKS(d1v[0][3], pb, 5)
+                NMARL_CP_MKS(d1v[1][0], pa, 6) NMARL_CP_MKS(d1v[1][1], pb, 7) NMARL_CP_MKS(d1v[1][2], pa, 8) NMARL_CP_MKS(d1v[1][3], pb, 9)
+                NMARL_CP_MKS(d1v[2][0], pa, 10) NMARL_CP_MKS(d1v[2][1], pb, 11) NMARL_CP_MKS(d1v[2][2], pa, 12) NMARL_CP_MKS(d1v[2][3], pb, 13)
+                NMARL_CP_MKS(d1v[3][0], pa, 14) NMARL_CP_MKS(d1v[3][1], pb, 15)
+                NMARL_CP_MMF(d1v[3][2], pa) __builtin_amdgcn_sched_barrier(0);
+                NMARL_CP_MMF(d1v[3][3], pb)
             }
             const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.ring + (int64_t)(t % a.slots) * a.ring_slot + (int64_t)n * a.ring_sn, nbR);
 #pragma unroll
             for (int i = 0; i < NTM; ++i) bstore4_wt(rw, soR + 64 * i, float4{am[i][0], am[i][1], am[i][2], am[i][3]});
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
-        if (lane == 0) __hip_atomic_store(my_flag, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0 && !(a.fault && blockIdx.x == 0))
+            __hip_atomic_store(my_flag, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // own recurrent part of dL/dh_{t-1} = (dz @ wh^T) keep_t: into the prefetched inputs of step t - 1 (landed: drained)
         if (t == t_lo && arow_ok) {                  // end of the range: state for the next launch of a step-wise run
 #pragma unroll
@@ -855,19 +902,24 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
                 *reinterpret_cast<float4*>(a.dc_io + (int64_t)n * a.io_sn + arow_raw * H + 4 * q + 16 * j) = dc[j];
             }
         }
-        u0.gh.x += acc[4][0] * keepA; u0.gh.y += acc[4][1] * keepA; u0.gh.z += acc[4][2] * keepA; u0.gh.w += acc[4][3] * keepA;
-        u1.gh.x += acc[5][0] * keepA; u1.gh.y += acc[5][1] * keepA; u1.gh.z += acc[5][2] * keepA; u1.gh.w += acc[5][3] * keepA;
-        u2.gh.x += acc[6][0] * keepA; u2.gh.y += acc[6][1] * keepA; u2.gh.z += acc[6][2] * keepA; u2.gh.w += acc[6][3] * keepA;
-        u3.gh.x += acc[7][0] * keepA; u3.gh.y += acc[7][1] * keepA; u3.gh.z += acc[7][2] * keepA; u3.gh.w += acc[7][3] * keepA;
+        gh[0].x += acc[4][0] * keepA; gh[0].y += acc[4][1] * keepA; gh[0].z += acc[4][2] * keepA; gh[0].w += acc[4][3] * keepA;
+        gh[1].x += acc[5][0] * keepA; gh[1].y += acc[5][1] * keepA; gh[1].z += acc[5][2] * keepA; gh[1].w += acc[5][3] * keepA;
+        gh[2].x += acc[6][0] * keepA; gh[2].y += acc[6][1] * keepA; gh[2].z += acc[6][2] * keepA; gh[2].w += acc[6][3] * keepA;
+        gh[3].x += acc[7][0] * keepA; gh[3].y += acc[7][1] * keepA; gh[3].z += acc[7][2] * keepA; gh[3].w += acc[7][3] * keepA;
         keepA = keep_next;
     }
-#undef NMARL_CP_LOAD2
-#undef NMARL_CP_KSTEP
+#undef NMARL_CP_LOADG
+#undef NMARL_CP_LOADH
+#undef NMARL_CP_BL
+#undef NMARL_CP_MF
+#undef NMARL_CP_KS
 #undef NMARL_CP_CELLB
 #undef NMARL_CP_DB1
 #undef NMARL_CP_CELL
 #undef NMARL_CP_PROD
-#undef NMARL_CP_MSTEP
+#undef NMARL_CP_MBL
+#undef NMARL_CP_MMF
+#undef NMARL_CP_MKS
 
     // ---- bias gradients: every lane holds 4 + 1 finished column sums of its wave; sum over the 8 waves, a step-wise run
     // accumulates over its launches
@@ -1038,6 +1090,21 @@ int launch_coupled(const CoupledArgs& a, unsigned grid, size_t lds_bytes, hipStr
 }
 }  // namespace
 
+// blocks per CU of the coupled kernel with message rows of K floats (the occupancy API's answer for its 512 threads, registers
+// and 128 + K / 4 KB of LDS: 1 on gfx950) -- nmarl_handoff_capacity
+NMARL_INTERNAL int nmarl_bptt_coupled_occupancy(int K) {
+    if (K != 64 && K != 128) return -1;
+    const size_t lds_bytes = ((size_t)G4 * 16 * 8 + (size_t)K * H) * 4;
+    int per_cu = 0;
+    const void* f = K == 128 ? reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<8, 2, true>)
+                             : reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<4, 4, false>);
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -1;
+    const hipError_t rc = K == 128
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_bptt_coupled_kernel<8, 2, true>, 512, lds_bytes)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_bptt_coupled_kernel<4, 4, false>, 512, lds_bytes);
+    return rc == hipSuccess ? per_cu : -1;
+}
+
 extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stream) {
     if (!p || p->H != H || p->E < 0 || p->N <= 0 || p->T <= 0 || (p->kind != 1 && p->kind != 2) || p->r_max <= 0 || p->r_max > 4)
         return NMARL_EINVAL;
@@ -1046,7 +1113,7 @@ extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stre
     const int K = p->kind == 1 ? H * p->m_max : H;                        // floats per message row
     if (K != 64 && K != 128) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
-    if (E > (1 << 21)) return NMARL_EINVAL;
+    if (E > (1 << 21) || ((uintptr_t)p->status % 4)) return NMARL_EINVAL;
     if (!p->gates || !p->c_all || !p->done || !p->dh_ext || !p->img || !p->img_m || !p->dz || !p->d1 || !p->ring || !p->db_part ||
         !p->dbm_part || !p->dhr_io || !p->dc_io || !p->ws || !p->rev_agent || !p->rev_col || !p->rev_w || (p->kind == 1 && !p->mask))
         return NMARL_EINVAL;
@@ -1078,17 +1145,20 @@ extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stre
     a.E = E; a.N = N; a.T = T; a.mask_row = (int32_t)p->mask_row; a.tiles = (int32_t)tiles;
     if (p->ring_slots < 2) return NMARL_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // every polled word starts at zero for every call (flags count the steps done WITHIN the call)
-    if (hipMemsetAsync(p->ws, 0, (size_t)nmarl_lstm_bptt_coupled_ws_words(E, N) * 4, st) != hipSuccess) return NMARL_EHIP;
+    // every polled word starts at zero for every call (flags count the steps done WITHIN the call); the error word behind
+    // them is NOT cleared: a time-out stays visible until the host has dealt with it
+    if (hipMemsetAsync(p->ws, 0, (size_t)N * tiles * WAVES * 4, st) != hipSuccess) return NMARL_EHIP;
     const int64_t grid = tiles * N;
     // one launch for all T steps needs every block resident (the waves wait for their neighbours' blocks): one 512-thread
     // block with 160 KB of LDS per CU, so grid <= CUs; and a symmetric neighbour relation (two ring slots).  Otherwise
     // step by step: T launches of the same kernel, state through dhr_io / dc_io.
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return NMARL_EHIP;
-    const bool one_launch = p->mode != 2 && p->ring_slots >= T && (p->mode == 1 || (p->symmetric && grid <= cus));
+    const int cap = nmarl_handoff_capacity(2, K);
+    if (cap < 0) return NMARL_EHIP;
+    const bool one_launch = p->mode != 2 && p->ring_slots >= T && (p->mode == 1 || (p->symmetric && grid <= cap));
     a.slots = one_launch ? T : 2;
+    a.status = p->status;
+    a.fault = one_launch && nmarl_handoff_take_fault() ? 1 : 0;
+    a.max_spins = a.fault ? NMARL_HANDOFF_FAULT_SPINS : NMARL_HANDOFF_MAX_SPINS;
     const size_t lds_bytes = ((size_t)G4 * 16 * 8 + (size_t)K * H) * 4;
     const int ntm = K / 16;
     const int rmax = p->r_max <= 2 ? 2 : 4;

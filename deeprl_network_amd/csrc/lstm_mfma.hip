@@ -11,6 +11,7 @@
 // lstm_step_x_kernel (the x-side product s @ Wx is computed here as well: K = KX + 64, nothing of the pre-activation
 // ever exists in HBM).  fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -485,6 +486,9 @@ struct XArgs {
     const int32_t* ob_nbr;                        // [N, slots]: own index first, then the neighbours ascending, -1 padded
     const float* ob_img; int64_t ob_img_sn;       // image (nmarl_lstm_msg_wimage) of W_ob zero-padded to 64 rows
     const float* ob_b; int64_t ob_b_sn;           // [N, 64]
+    int32_t* status;              // HEAD 4, may be NULL: hand-off status words ([0] <- 1 when a wave gives up, sticky)
+    unsigned max_spins;           // HEAD 4: polls before a wave gives up
+    int fault;                    // HEAD 4 test hook: block 0 never publishes (its neighbours time out)
 };
 
 // raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
@@ -492,7 +496,6 @@ struct XArgs {
 typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 typedef __attribute__((address_space(1))) unsigned gu32;
 constexpr int SC1 = 16;
-constexpr unsigned HANDOFF_MAX_SPINS = 1u << 20;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, const uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
 }
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         gu32* flags = (gu32*)(xa.sync + 16);
         const int bpa = a.blocks_per_agent, blk = (int)(blockIdx.x / xa.N);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0)
+        if (lane == 0 && !(xa.fault && blockIdx.x == 0))
             __hip_atomic_store(flags + ((n * bpa + blk) * WAVES2 + wave), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the W chunks of the message columns: in flight while the h part of the re-step runs
         NMARL_STAGE_LOAD(nx - 2)
@@ -1069,8 +1072,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 for (unsigned spins = 0;; ++spins) {
                     const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     if (v == epoch) break;
-                    if (spins > HANDOFF_MAX_SPINS) {      // a neighbour's block is not running: not co-resident (see the launcher)
-                        if (lane == 0) __hip_atomic_store((gu32*)xa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (spins > xa.max_spins) {           // a neighbour's block is not running: not co-resident (see the launcher)
+                        if (lane == 0) {                  // sticky: the optimiser step refuses this batch (nmarl_rmsprop_tf_clip_guarded)
+                            __hip_atomic_store((gu32*)xa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (xa.status) __hip_atomic_store((gu32*)xa.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                         give_up = true;
                         break;
                     }
@@ -1275,6 +1281,54 @@ extern "C" int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, i
     return nmarl_check_launch();
 }
 
+// ---- in-launch hand-off: residency and the test hook
+int nmarl_handoff_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return -1;
+    if (const char* e = getenv("NMARL_TEST_FAKE_CUS")) {
+        const int v = atoi(e);
+        if (v > 0) cus = v;
+    }
+    return cus;
+}
+
+static std::atomic<int> g_fault_in{0};
+extern "C" int nmarl_test_handoff_fault(int32_t nth) {
+    if (nth < 0) return NMARL_EINVAL;
+    g_fault_in.store(nth);
+    return NMARL_OK;
+}
+bool nmarl_handoff_take_fault() {
+    int v = g_fault_in.load();
+    while (v > 0 && !g_fault_in.compare_exchange_weak(v, v - 1)) {}
+    return v == 1;
+}
+
+NMARL_INTERNAL int nmarl_bptt_coupled_occupancy(int K);      // lstm_bptt.hip: blocks per CU of the coupled BPTT kernel
+
+extern "C" int nmarl_handoff_capacity(int32_t which, int32_t K) {
+    const int cus = nmarl_handoff_cus();
+    if (cus < 0 || K <= 0) return -1;
+    int per_cu = 0;
+    if (which == 1) {
+        // the lock-step kernel with a message term (HEAD 4): two chunk buffers + tiles + head weights + the message image (+ the
+        // observation encoder's image where it can exist, lstm_ic3: K = 64)
+        if (K % CH_K || K > 128) return -1;
+        const size_t lb = (size_t)(LDSX_FLOATS + K * 64 + (K == H ? H * 64 : 0)) * sizeof(float);
+        const int lb_max = (int)((LDSX_FLOATS + CH_FLOATS) * sizeof(float));
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb_max) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_step_x_kernel<4, 1>, 512, lb) != hipSuccess)
+            return -1;
+    } else if (which == 2) {
+        per_cu = nmarl_bptt_coupled_occupancy(K);
+        if (per_cu < 0) return -1;
+    } else {
+        return -1;
+    }
+    return per_cu * cus;
+}
+
 static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
                          int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
                                  const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
@@ -1358,13 +1412,15 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     if (mk && kind == 3) {
         // policy step + value re-step of a coupled net in ONE launch: the re-step's message term needs the neighbours' new h, handed
         // over between blocks inside the launch -- every block must be resident (one block per CU: 512 threads, > 80 KB LDS)
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            return NMARL_EHIP;
-        if (!msg->sync || ((uintptr_t)msg->sync % 4) || (int)grid.x > cus || E * (int64_t)(H * 4) >= (int64_t)1 << 32 ||
-            (mk == 2 && KX != H))
+        const int cap = nmarl_handoff_capacity(1, msg->K);
+        if (cap < 0) return NMARL_EHIP;
+        if (!msg->sync || ((uintptr_t)msg->sync % 4) || ((uintptr_t)msg->status % 4) || (int)grid.x > cap ||
+            E * (int64_t)(H * 4) >= (int64_t)1 << 32 || (mk == 2 && KX != H))
             return NMARL_EINVAL;
         xa.sync = msg->sync;
+        xa.status = msg->status;
+        xa.fault = nmarl_handoff_take_fault() ? 1 : 0;
+        xa.max_spins = xa.fault ? NMARL_HANDOFF_FAULT_SPINS : NMARL_HANDOFF_MAX_SPINS;
     }
     size_t lb_extra = 0;
     if (msg && msg->ob) {

@@ -15,6 +15,49 @@ from ._lib import check, lib, ptr, stream
 F32 = torch.float32
 
 
+# ---- in-launch hand-off (include/nmarl.h "In-launch hand-off"): status words, capacity, the process-wide switch
+_handoff_status = {}
+_handoff_off = [False]
+
+
+def handoff_status(device):
+    """The hand-off status words of a device (int32 x 4, created once and kept -- captured hipGraphs hold the pointer):
+    [0] != 0: a wave of a hand-off kernel gave up waiting (sticky until `handoff_clear`), [1] optimiser steps refused since.
+    Every hand-off kernel launched through this module reports here; `rmsprop_tf_clip` consults it."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    if dev not in _handoff_status:
+        _handoff_status[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return _handoff_status[dev]
+
+
+def handoff_poisoned(device):
+    """True if a hand-off kernel on `device` timed out since the last `handoff_clear` (synchronises)."""
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        return False
+    return int(handoff_status(dev)[0].item()) != 0
+
+
+def handoff_skipped_updates(device):
+    return int(handoff_status(device)[1].item())
+
+
+def handoff_clear(device):
+    handoff_status(device)[0].zero_()
+
+
+def disable_inkernel_handoff():
+    """Pin the launch-per-step forms for the rest of the process (BatchedTrainer after a time-out; same effect as
+    NMARL_INKERNEL_HANDOFF=0)."""
+    _handoff_off[0] = True
+
+
+def handoff_enabled():
+    return not _handoff_off[0] and os.environ.get('NMARL_INKERNEL_HANDOFF', '1') != '0'
+
+
 def neighbor_table(neighbor_mask, device):
     """neighbor_mask [N,N] (0/1) -> (nbr_idx [N,m_max] int32 device tensor, counts list).
     Row i lists the neighbours of i in ascending index (tf.boolean_mask order), -1 padded."""
@@ -236,7 +279,7 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             if sync is None or sync.dtype != torch.int32 or sync.numel() < lib.nmarl_lstm_step_sync_words(E, N):
                 raise _lib.NmarlError('%s: head kind 3 with a message term needs msg["sync"] (step_sync_words)' % what)
             m.sync = ptr(sync, torch.int32)
-            _step_sync_last[0] = sync
+            m.status = ptr(handoff_status(h.device), torch.int32)
         check(lib.nmarl_lstm_step_x_msg(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
                                         *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
                                         C.byref(m), stream()), what)
@@ -244,9 +287,6 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
     check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, K2, x2p, x2_sn, x2_row, *_pn(h), ptr(img, F32), img.stride(0),
                                 *_bias(bias), *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
                                 *_pn(c_out), *_pn(h_out), None if head is None else C.byref(head), stream()), what)
-
-
-_step_sync_last = [None]
 
 
 def ob_encoder_supported(n_feat, n_obs, n_h):
@@ -266,13 +306,17 @@ def step_sync_words(N, E, device):
     return torch.zeros(lib.nmarl_lstm_step_sync_words(E, N), dtype=torch.int32, device=device)
 
 
-def step_handoff_supported(N, E, device):
+def step_handoff_supported(N, E, device, K=128):
     """The coupled nets' policy step and value re-step fit ONE launch (blocks hand the new h over inside it): every block
-    must be resident, i.e. N * ceil(E / 128) <= compute units.  NMARL_INKERNEL_HANDOFF=0 keeps the two launches (e.g. when
-    several processes share one device: blocks of different processes are not co-resident by construction)."""
-    if os.environ.get('NMARL_INKERNEL_HANDOFF', '1') == '0' or torch.device(device).type != 'cuda':
+    must be resident, i.e. N * ceil(E / 128) <= nmarl_handoff_capacity (the occupancy API's blocks per compute unit x compute
+    units; K = floats per message row).  NMARL_INKERNEL_HANDOFF=0 / `disable_inkernel_handoff` keep the two launches (e.g.
+    when several processes share one device: blocks of different processes are not co-resident by construction)."""
+    if not handoff_enabled() or torch.device(device).type != 'cuda':
         return False
-    return N * ((E + 127) // 128) <= torch.cuda.get_device_properties(device).multi_processor_count
+    cap = lib.nmarl_handoff_capacity(1, int(K))
+    if cap < 0:
+        raise _lib.NmarlError('nmarl_handoff_capacity failed')
+    return N * ((E + 127) // 128) <= cap
 
 
 def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=None):
@@ -810,9 +854,14 @@ def reverse_neighbor_table(nbr_idx, kind):
                 r_max=r_max, r_row=r_row, symmetric=sym)
 
 
-def bptt_coupled_supported(kind, m_max, H):
-    """nmarl_lstm_bptt_coupled handles this recurrence: 64-unit cells, message rows of 64 or 128 floats."""
-    return H == FUSED_H and ((kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3)
+def bptt_coupled_supported(kind, m_max, H, rev=None):
+    """nmarl_lstm_bptt_coupled handles this recurrence: 64-unit cells, message rows of 64 or 128 floats; with the reverse table
+    at hand also its fan-in (lstm_comm: at most 2 sources per agent -- the launcher has no 4-source instantiation of that
+    kind; asymmetric tables can have m_max <= 2 and more sources)."""
+    ok = H == FUSED_H and ((kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3)
+    if ok and rev is not None and kind == COUPLED_NC and rev['r_max'] > 2:
+        return False
+    return ok
 
 
 _coupled_ws = {}
@@ -849,7 +898,7 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
     H = H4 // 4
     K = H * m_max if kind == COUPLED_NC else H
     img, img_m = ws[2], wm[1]
-    if mode == 0 and os.environ.get('NMARL_INKERNEL_HANDOFF', '1') == '0':
+    if mode == 0 and not handoff_enabled():
         mode = 2                              # the device is shared with other processes: step-wise launches (see step_handoff_supported)
     for x, w_, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (dHs, H, 'dh_ext'), (D1, H, 'd1')):
         if x.stride(3) != 1 or x.stride(2) != w_:
@@ -876,24 +925,20 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
     a.dbm_part, a.dbm_sn = ptr(w['dbm'], F32), w['dbm'].stride(0)
     a.dhr_io, a.dc_io, a.io_sn = ptr(w['dhr'], F32), ptr(w['dc'], F32), w['dhr'].stride(0)
     a.ws = ptr(w['ws'], torch.int32)
+    a.status = ptr(handoff_status(G.device), torch.int32)
     a.rev_agent, a.rev_col, a.rev_w = ptr(rev['rev_agent'], torch.int32), ptr(rev['rev_col'], torch.int32), ptr(rev['rev_w'], F32)
     check(lib.nmarl_lstm_bptt_coupled(C.byref(a), stream()), 'nmarl_lstm_bptt_coupled')
-    _coupled_last[0] = (w['ws'], N * w['tiles'] * 8)          # (flag words, index of the error word)
     return w['db'].sum(dim=1), w['dbm'].sum(dim=1)
 
 
-_coupled_last = [None]
-
-
-def check_coupled_status():
-    """Raises if a wave of the last nmarl_lstm_bptt_coupled call gave up waiting for a neighbour's block (its results are
-    invalid).  Synchronises: call where the host syncs anyway (BatchedTrainer.stats)."""
-    last = _coupled_last[0]
-    if last is not None and int(last[0][last[1]].item()) != 0:
-        raise _lib.NmarlError('nmarl_lstm_bptt_coupled: a wave timed out waiting for a neighbour block (results invalid)')
-    sync = _step_sync_last[0]
-    if sync is not None and int(sync[2].item()) != 0:
-        raise _lib.NmarlError('nmarl_lstm_step_x_msg[pv]: a wave timed out waiting for a neighbour block (results invalid)')
+def check_coupled_status(device=None):
+    """Raises if a wave of ANY hand-off kernel launched on the device since the last `handoff_clear` gave up waiting for a
+    neighbour's block (its results are invalid; the guarded optimiser step refused them).  Synchronises."""
+    devs = list(_handoff_status) if device is None else [torch.device(device)]
+    for dev in devs:
+        if dev in _handoff_status and int(_handoff_status[dev][0].item()) != 0:
+            raise _lib.NmarlError('in-launch hand-off: a wave timed out waiting for a neighbour block on %s (results invalid; '
+                                  '%d optimiser steps refused)' % (dev, int(_handoff_status[dev][1].item())))
 
 
 class _LstmCell(torch.autograd.Function):
@@ -1212,9 +1257,12 @@ def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, ad
 def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, norm_out=None, lr_dev=None):
     """In-place clip_by_global_norm + TF RMSProp on flat [G,P] buffers."""
     G, P = w.shape
-    check(lib.nmarl_rmsprop_tf_clip(G, P, ptr(w, F32), ptr(g, F32), ptr(ms, F32), ptr(scratch, F32),
-                                    ptr(lr_dev, F32), float(lr), float(rho), float(eps), float(max_norm),
-                                    float(grad_scale), ptr(norm_out, F32), stream()), 'nmarl_rmsprop_tf_clip')
+    # guarded by the device's hand-off status: a batch whose in-launch hand-off timed out changes nothing (fail closed)
+    check(lib.nmarl_rmsprop_tf_clip_guarded(G, P, ptr(w, F32), ptr(g, F32), ptr(ms, F32), ptr(scratch, F32),
+                                            ptr(lr_dev, F32), float(lr), float(rho), float(eps), float(max_norm),
+                                            float(grad_scale), ptr(norm_out, F32),
+                                            ptr(handoff_status(w.device), torch.int32) if w.is_cuda else None, stream()),
+          'nmarl_rmsprop_tf_clip')
 
 
 _epilogue_scratch = {}

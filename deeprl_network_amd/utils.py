@@ -305,6 +305,11 @@ class BatchedTrainer:
         self.fin = torch.zeros(4, dtype=torch.float64, device=d)   # episodes, sum(mean), sum(std), collisions
         self.use_graph = use_graph and d.type == 'cuda'
         self.graph = None
+        # coupled nets on the in-launch hand-off kernels (one-launch lock-step / BPTT): every batch is checked and, if a wave
+        # timed out, re-run on the launch-per-step kernels from the state it started from (see run_batch)
+        self.handoff_guard = self.saved_acts and model.policy.coupled and d.type == 'cuda' and ops.handoff_enabled()
+        self.handoff_fallbacks = 0
+        self._shadow = [torch.empty_like(t) for t in env.state_tensors() + [self.step_dev]] if self.handoff_guard else None
         self.data = []
         self.n_batches = 0
         env.train_mode = True
@@ -318,6 +323,9 @@ class BatchedTrainer:
         env, model = self.env, self.model
         T = self.n_step
         model.t = 0
+        if self.handoff_guard:                # what the rollout mutates and a re-run must start from (a few small copies)
+            for s_, t_ in zip(self._shadow, env.state_tensors() + [self.step_dev]):
+                s_.copy_(t_)
         # Philox step = batch base (device counter, advanced once per batch) + slot offset baked into the graph
         fused = self.fused_encode
         for t in range(T):
@@ -375,6 +383,8 @@ class BatchedTrainer:
         m = self.model
         m.load_rewards(self.buf_rraw)
         m.update(self.R_end, rotate=False)
+        if self.handoff_guard and ops.handoff_poisoned(self.device):
+            self._recover_from_handoff_timeout()
         # episode statistics, then the hand-over to the next batch in one call: finished replicas start a new episode (the
         # env already auto-reset them) with zero recurrent state and uniform fingerprints -- what the reference does at its
         # next `env.reset(); model.reset()` --, states_bw <- states_fw, slot T of the rollout buffers -> slot 0
@@ -387,6 +397,29 @@ class BatchedTrainer:
             # the counter (like the reference's global step and the lr schedule) counts LOCK-steps, i.e. environment
             # steps per replica: `total_step` of the ini keeps its meaning (1e6 -> 16 667 updates at n_step 60)
             self.global_counter.advance(self.n_step)
+
+    def _recover_from_handoff_timeout(self):
+        """A wave of an in-launch hand-off kernel gave up waiting during this batch (its neighbour block was not resident: the
+        device is shared, masked or profiled).  The optimiser step refused the batch on the device (nothing was applied); here
+        the batch is rewound to the state it started from, the process is pinned to the launch-per-step kernels, and the
+        batch is run again -- the weights end up exactly where a run without the one-launch kernels puts them."""
+        m, dev = self.model, self.device
+        logging.warning('in-launch hand-off timed out (batch %d): re-running the batch on the launch-per-step kernels and '
+                        'keeping them for the rest of the run' % self.n_batches)
+        ops.disable_inkernel_handoff()
+        ops.handoff_clear(dev)
+        for s_, t_ in zip(self._shadow, self.env.state_tensors() + [self.step_dev]):
+            t_.copy_(s_)
+        m.h_fw.copy_(m.H_all[:, 0])            # the persistent state the rollout started from (its bootstrap step overwrote it)
+        m.c_fw.copy_(m.C_all[:, 0])
+        m.lr_scheduler.n -= self.n_step        # update() advanced the schedule
+        self.graph = None                      # re-capture: the rollout now takes the two-launch lock-step
+        self.handoff_guard = False
+        self.rollout()
+        m.load_rewards(self.buf_rraw)
+        m.update(self.R_end, rotate=False)
+        ops.check_coupled_status(dev)
+        self.handoff_fallbacks += 1
 
     def stats(self, reset=True):
         """(episodes finished, mean of episode-mean reward, mean of episode-std, collisions) since last call."""

@@ -398,8 +398,10 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
  * inside the launch (write-through stores + one flag per wave, lstm_mfma.hip).  Needs msg->sync: a buffer of
  * nmarl_lstm_step_sync_words(E, N) 32-bit words the caller zeroes once and then leaves alone (word 2 becomes non-zero
  * if a block ever waited in vain, i.e. the launch shared the device with other work); every block must be resident, so
- * N * ceil(E / 128) may not exceed the number of compute units (NMARL_EINVAL otherwise: use the two launches).  v_out
+ * N * ceil(E / 128) may not exceed nmarl_handoff_capacity(1, K) (NMARL_EINVAL otherwise: use the two launches).  v_out
  * receives the critic's h part only (as nmarl_lstm_step_x with kind 3); gates / c_new / h_new / out are the POLICY step's.
+ * msg->status (may be NULL): the hand-off status words (see nmarl_handoff_capacity below) -- word 0 is set, and stays
+ * set, when a wave gives up waiting; nmarl_rmsprop_tf_clip_guarded then applies nothing (fail closed).
  */
 typedef struct nmarl_msg {
     int32_t kind, m_max, K, pad_;
@@ -418,6 +420,7 @@ typedef struct nmarl_msg {
     const int32_t* ob_nbr;
     const float* ob_img; int64_t ob_img_sn;
     const float* ob_b; int64_t ob_b_sn;
+    int32_t* status;    /* head kind 3 only, may be NULL: hand-off status words (word 0 <- 1 when a wave gives up) */
 } nmarl_msg_t;
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_sync_words(int64_t E, int32_t N);
@@ -455,6 +458,8 @@ int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t H, int32_t KM, const floa
  *   gates [N][T][E][4H], dz likewise (agent stride *_sn, step stride *_st, floats);  c_all [N][T+1][E][H] (c_all[t] =
  *   the cell state step t started from);  done [T][E];  dh_ext [N][T][E][H] = dL/dh_t from the heads;
  *   img = nmarl_lstm_bptt_wimage(KM = 0) of the current wh.
+ * c_t (for tanh(c_t)) is RECOMPUTED as gf * (c_all[t] * (1 - done_t)) + gi * gu, operation for operation what the forward
+ * kernels store (c_all[T] is never read; this and nmarl_lstm_bptt_coupled): gates / c_all must be the trace of a forward pass.
  * Outputs: dz (every step: the weight-gradient GEMMs need it);  db_part [N][nmarl_lstm_bptt_seq_blocks(E)][4H] or
  * NULL: per-block column sums of dz over all T steps and the block's rows (bias gradient = their sum over blocks);
  * dh0 / dc0 [N][E][H] or NULL: dL/d(h, c) of the initial state.  Pointers 16-byte aligned, strides % 4 == 0.
@@ -484,7 +489,8 @@ int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t H, const float*
  * Outputs: dz [N][T][E][4H], d1 [N][T][E][H], db_part [N][tiles][4H] / dbm_part [N][tiles][H] (column sums of dz / d1 per
  * 128-row tile; bias gradients = their sums over tiles), dhr_io / dc_io [N][E][H] (scratch; on return dL/d(h, c) of the
  * state the sequence started from, without the message part).  ws word [N * tiles * 8] is non-zero afterwards if a wave
- * gave up waiting for a neighbour's block (results invalid).
+ * gave up waiting for a neighbour's block (results invalid); that word is STICKY -- the call zeroes the flag words only --
+ * and so is word 0 of `status` (may be NULL; see nmarl_handoff_capacity), which the guarded optimiser step consults.
  * mode 0: one launch if the grid (N * tiles blocks, one per CU) is resident at once, the relation symmetric and
  * ring_slots >= T, else T
  * launches of one step each (same kernel, same results); 1 / 2 force the one-launch / step-wise form (tests).
@@ -495,6 +501,7 @@ typedef struct nmarl_bptt_coupled {
     const float *gates, *c_all, *done, *dh_ext, *img, *img_m, *mask;
     float *dz, *d1, *ring, *db_part, *dbm_part, *dhr_io, *dc_io;
     void* ws;
+    int32_t* status;    /* may be NULL: hand-off status words (word 0 <- 1 when a wave gives up) */
     const int32_t *rev_agent, *rev_col;
     const float* rev_w;
     int64_t gates_sn, gates_st, c_sn, c_st, dh_sn, dh_st, img_sn, imgm_sn, mask_sn, mask_st, mask_row, dz_sn, dz_st, d1_sn, d1_st,
@@ -625,6 +632,27 @@ int nmarl_nstep_return(int64_t E, int32_t N, int32_t T, const float* r, const fl
  *   norm_g = ||g_g||;  g *= max_norm * min(1/norm_g, 1/max_norm)   (max_norm > 0)
  *   ms += (g*g - ms)*(1-rho);  w -= lr * g / sqrt(ms + eps)
  */
+/*
+ * In-launch hand-off (nmarl_lstm_step_x_msg head kind 3, nmarl_lstm_bptt_coupled one-launch form): blocks wait for flags
+ * other blocks of the SAME launch publish, so every block must be co-resident.
+ *   nmarl_handoff_capacity(which, K): the number of blocks of that kernel the device holds at once =
+ *     hipOccupancyMaxActiveBlocksPerMultiprocessor(kernel, 512 threads, its dynamic LDS) x compute units   (which 1: the
+ *     lock-step kernel with a message image of K floats x 64; 2: the coupled BPTT kernel, message rows of K floats);
+ *     the launchers refuse / fall back to launch-per-step forms above it.  NMARL_TEST_FAKE_CUS=<n> in the environment
+ *     replaces the device's compute-unit count (tests: a "smaller GPU").  < 0: error.
+ *   status words (int32 x 4, caller-owned, zeroed once): [0] set to 1 -- and left set -- by any hand-off kernel whose wave
+ *     gave up waiting (bounded spins: a neighbour block was not running), [1] number of optimiser steps
+ *     nmarl_rmsprop_tf_clip_guarded refused since.  While [0] != 0 the guarded step changes neither w nor ms: a batch
+ *     computed from a broken hand-off can not reach the weights.  The host clears [0] after switching to the
+ *     launch-per-step forms and re-running the batch (deeprl_network_amd/utils.py BatchedTrainer.run_batch).
+ *   nmarl_test_handoff_fault(nth): test hook -- the nth hand-off launch from now (1 = the next; 0 disarms) runs with block 0
+ *     never publishing its flags and 4096 spins, i.e. its neighbours time out as if block 0 were not resident.
+ */
+int nmarl_handoff_capacity(int32_t which, int32_t K);
+int nmarl_test_handoff_fault(int32_t nth);
+int nmarl_rmsprop_tf_clip_guarded(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
+                                  const float* lr_dev, float lr, float rho, float eps, float max_norm, float grad_scale,
+                                  float* grad_norm_out, int32_t* status, void* stream);
 int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float* ms, float* scratch,
                           const float* lr_dev, float lr, float rho, float eps, float max_norm,
                           float grad_scale, float* grad_norm_out, void* stream);

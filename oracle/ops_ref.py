@@ -164,7 +164,7 @@ def step_sync_words(N, E, device):
     return torch.zeros(16, dtype=torch.int32)
 
 
-def step_handoff_supported(N, E, device):
+def step_handoff_supported(N, E, device, K=128):
     """The product's one-launch policy + value step of coupled nets is a kernel-side arrangement; the restatement runs the
     two steps one after the other either way.  NMARL_INKERNEL_HANDOFF=0 selects the host code of the two-launch path."""
     import os
@@ -500,8 +500,9 @@ def reverse_neighbor_table(nbr_idx, kind):
     return dict(nbr_idx=nbr_idx, r_max=1, r_row=2, symmetric=True)
 
 
-def bptt_coupled_supported(kind, m_max, H):
-    return (kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3
+def bptt_coupled_supported(kind, m_max, H, rev=None):
+    return ((kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3) and not (
+        rev is not None and kind == COUPLED_NC and rev['r_max'] > 2)
 
 
 def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0):

@@ -793,6 +793,20 @@ def test_lstm_bptt_step_fused(N, E, KM, masked, with_rec):
         assert torch.all(dxg[:, 0] == 0)
 
 
+def _forward_cells(gates, c0, done):
+    """The cell-state sequence a forward pass would have saved with these gates: c[t + 1] = gf * (c[t] * keep_t) + gi * gu in
+    float32, operation for operation what the forward kernels compute (csrc/lstm_mfma.hip, a2c.hip).  The one-launch BPTT
+    kernels RECOMPUTE c_t from the gates instead of reading it, so their inputs must be a consistent forward trace."""
+    N, T, E, H4 = gates.shape
+    H = H4 // 4
+    call = torch.empty(N, T + 1, E, H)
+    call[:, 0] = c0
+    for t in range(T):
+        keep = (1.0 - done[t]).view(1, E, 1)
+        call[:, t + 1] = gates[:, t, :, H:2 * H] * (call[:, t] * keep) + gates[:, t, :, :H] * gates[:, t, :, 3 * H:]
+    return call
+
+
 @pytest.mark.parametrize('N,T,E', [(8, 12, 4096), (8, 60, 256), (3, 5, 127), (25, 4, 130), (2, 1, 1)])
 def test_lstm_bptt_seq_one_launch(N, T, E):
     """nmarl_lstm_bptt_seq (the whole reverse recurrence in one launch, state on chip) vs T launches of
@@ -804,8 +818,9 @@ def test_lstm_bptt_seq_one_launch(N, T, E):
     g = torch.Generator().manual_seed(N * 131 + T * 7 + E)
     r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
     gates = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
-    call = r(N, T + 1, E, H) * 0.8
+    c0 = r(N, E, H) * 0.8
     done = (torch.rand(T, E, generator=g) < 0.2).float()
+    call = _forward_cells(gates, c0, done)
     dhs = r(N, T, E, H)
     wh = r(N, H, 4 * H) * 0.1 + torch.arange(4 * H).view(1, 1, -1) * 1e-4 + torch.arange(H).view(1, -1, 1) * 2e-4
     dz_r = torch.empty(N, T, E, 4 * H, dtype=torch.float64)
@@ -1003,8 +1018,9 @@ def test_lstm_bptt_coupled_one_launch(kind, topo, N, T, E):
     g = torch.Generator().manual_seed(N * 131 + T * 7 + E + kind)
     r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
     gates = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
-    call = r(N, T + 1, E, H) * 0.8
+    c0 = r(N, E, H) * 0.8
     done = (torch.rand(T, E, generator=g) < 0.2).float()
+    call = _forward_cells(gates, c0, done)
     dhs = r(N, T, E, H)
     wh = r(N, H, 4 * H) * 0.1
     wxm = r(N, H, 4 * H) * 0.1

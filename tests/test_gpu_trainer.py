@@ -193,3 +193,83 @@ def test_coupled_one_launch_step_equals_two_launches(agent, E, monkeypatch):
         assert torch.equal(a, b)
     torch.testing.assert_close(out[0][5], out[1][5], rtol=2e-5, atol=5e-6)
     torch.testing.assert_close(out[0][6], out[1][6], rtol=1e-4, atol=2e-6)
+
+
+@pytest.fixture
+def handoff_switch():
+    """The recovery pins the launch-per-step kernels process-wide: give the following tests the one-launch forms back."""
+    from deeprl_network_amd import _lib, ops
+    yield
+    ops._handoff_off[0] = False
+    _lib.lib.nmarl_test_handoff_fault(0)
+    for st in ops._handoff_status.values():
+        st.zero_()
+
+
+@pytest.mark.parametrize('agent,site', [('ma2c_nc', 'step'), ('ma2c_nc', 'bptt'), ('ma2c_ic3', 'step')])
+def test_handoff_timeout_fails_closed(agent, site, handoff_switch, monkeypatch):
+    """An in-launch hand-off whose neighbour block never shows up (injected: block 0 of one launch publishes nothing, 4096
+    spins) must fail CLOSED: the poisoned batch changes no weight and no optimiser slot (the guarded RMSProp refuses it on the
+    device and counts it), the trainer rewinds the batch, pins the launch-per-step kernels and re-runs it -- after two batches
+    the weights equal, bit for bit, those of a run that never used the one-launch kernels.  site: the fault hits the
+    lock-step kernel of the rollout's first step / the coupled BPTT launch of the update."""
+    from deeprl_network_amd import _lib, ops
+    from deeprl_network_amd.utils import BatchedTrainer
+    E, T = 256, 10
+    # reference: launch-per-step kernels from the start
+    monkeypatch.setenv('NMARL_INKERNEL_HANDOFF', '0')
+    env, model, tr = build(agent, E, False, scenario='slowdown', n_step=T)
+    assert not tr.handoff_guard
+    for _ in range(2):
+        tr.run_batch()
+    torch.cuda.synchronize()
+    ref = (model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.h.clone(), model.buf_act.clone(), tr.R_end.clone(),
+           model.lr_scheduler.n)
+    del env, model, tr
+    monkeypatch.delenv('NMARL_INKERNEL_HANDOFF')
+    # faulty run: eager rollout (the fault flag is a launch argument, a captured graph would replay it)
+    env, model, tr = build(agent, E, False, scenario='slowdown', n_step=T)
+    assert tr.handoff_guard and model.policy.pv_one_launch(E)
+    w0, ms0 = model.policy.params.flat.clone(), model.policy.params.ms.clone()
+    seen = {}
+    orig = BatchedTrainer._recover_from_handoff_timeout
+
+    def spy(self):
+        seen['w'], seen['ms'] = self.model.policy.params.flat.clone(), self.model.policy.params.ms.clone()
+        seen['skipped'] = ops.handoff_skipped_updates(self.device)
+        orig(self)
+    monkeypatch.setattr(BatchedTrainer, '_recover_from_handoff_timeout', spy)
+    skipped0 = ops.handoff_skipped_updates('cuda')
+    # nth hand-off launch from now: 1 = the first lock-step; T + 2 = the BPTT behind T lock-steps + the bootstrap step
+    _lib.check(_lib.lib.nmarl_test_handoff_fault(1 if site == 'step' else T + 2), 'nmarl_test_handoff_fault')
+    tr.run_batch()
+    assert tr.handoff_fallbacks == 1 and not ops.handoff_enabled() and not model.policy.pv_one_launch(E)
+    assert torch.equal(seen['w'], w0) and torch.equal(seen['ms'], ms0), 'the poisoned batch reached the weights'
+    assert seen['skipped'] == skipped0 + 1
+    tr.run_batch()
+    torch.cuda.synchronize()
+    ops.check_coupled_status()
+    got = (model.policy.params.flat, model.policy.params.ms, env.h, model.buf_act, tr.R_end, model.lr_scheduler.n)
+    for name, a, b in zip(('weights', 'rmsprop slots', 'env state', 'actions', 'R_end'), got, ref):
+        assert torch.equal(a, b), '%s differ from the launch-per-step run' % name
+    assert got[5] == ref[5]
+    assert tr.stats()['episodes'] == 0
+
+
+def test_handoff_capacity_and_fake_cus(monkeypatch, handoff_switch):
+    """Residency comes from the occupancy API x compute units; NMARL_TEST_FAKE_CUS shrinks the device: the engine must pick
+    the two-launch lock-step / step-wise BPTT by itself, and the launchers must refuse an over-sized one-launch grid."""
+    from deeprl_network_amd import _lib, ops
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for which, K in ((1, 128), (1, 64), (2, 128), (2, 64)):
+        assert _lib.lib.nmarl_handoff_capacity(which, K) == cus          # one 512-thread, > 80-KB-LDS block per compute unit
+    assert ops.step_handoff_supported(8, 4096, 'cuda') and not ops.step_handoff_supported(8, 4096 + 128, 'cuda')
+    monkeypatch.setenv('NMARL_TEST_FAKE_CUS', '16')
+    assert _lib.lib.nmarl_handoff_capacity(1, 128) == 16 and _lib.lib.nmarl_handoff_capacity(2, 64) == 16
+    assert ops.step_handoff_supported(8, 256, 'cuda') and not ops.step_handoff_supported(8, 257, 'cuda')
+    env, model, tr = build('ma2c_nc', 512, True, scenario='slowdown', n_step=10)        # 8 x 4 blocks > 16 "compute units"
+    assert not model.policy.pv_one_launch(512)
+    tr.run_batch()
+    torch.cuda.synchronize()
+    ops.check_coupled_status()
+    assert tr.handoff_fallbacks == 0 and torch.isfinite(model.policy.params.flat).all()

@@ -127,4 +127,43 @@ try:
         ops.check_coupled_status()
 except Exception as ex:                        # a side measurement: never fail the pass
     print('one-launch coupled step skipped:', ex)
+# CommNet on the 5 x 5 grid (BASELINE configs[3]: 25 agents x 1024 replicas): the one-launch lock-step with the observation encoder
+# inside (lstm_step_x_kernel<4,2>) and the coupled BPTT of its update (lstm_bptt_coupled_kernel<4,4,false>, T = 120)
+try:
+    Ng, Egd, Ag, Tg, Fo = 25, 1024, 5, 120, 12
+    nbr_g, _ = ops.neighbor_table(_topology(Ng, 'grid'), 'cuda')
+    hg, cg = r(Ng, Egd, H) * 0.3, r(Ng, Egd, H) * 0.3
+    whg, bg = r(Ng, H, 4 * H) * 0.1, r(Ng, 4 * H) * 0.1
+    if ops.step_handoff_supported(Ng, Egd, 'cuda', K=H):
+        wxg, wmg, bmg = r(Ng, H, 4 * H) * 0.15, r(Ng, H, H) * 0.15, r(Ng, H) * 0.1
+        imgg, mimgg = ops.lstm_wimage(wxg, whg), ops.lstm_msg_wimage(wmg)
+        nbr_self = torch.cat([torch.arange(Ng, dtype=torch.int32, device='cuda').view(-1, 1), nbr_g], dim=1)
+        w_ob, b_ob = r(Ng, Fo * nbr_self.shape[1], H) * 0.3, r(Ng, H) * 0.1
+        oimg = ops.lstm_ob_wimage(w_ob, torch.zeros(Ng, 64, H, device='cuda'))
+        xo, enc_slot, s_slot = r(Egd, Ng, Fo), torch.zeros(Ng, Egd, H, device='cuda'), torch.zeros(Ng, Egd, H, device='cuda')
+        syncg = ops.step_sync_words(Ng, Egd, 'cuda')
+        msgg = dict(kind=ops.MSG_MEAN_ADD, nbr_idx=nbr_g, w_msg=wmg, b_msg=bmg, img=mimgg, enc=enc_slot, out=s_slot, sync=syncg,
+                    ob=dict(x=xo, nbr=nbr_self, img=oimg, b=b_ob))
+        pig, actg, vg = torch.empty(Ng, Egd, Ag, device='cuda'), torch.zeros(Egd, Ng, dtype=torch.uint8, device='cuda'), torch.empty(Ng, Egd, device='cuda')
+        hog, cog, gg = torch.empty_like(hg), torch.empty_like(cg), torch.empty(Ng, Egd, 4 * H, device='cuda')
+        pwg, pbg, vwg, vbg = r(Ng, H, Ag), r(Ng, Ag), r(Ng, H + nbr_g.shape[1] * Ag, 1), r(Ng, 1)
+        doneg = torch.zeros(Egd, device='cuda')
+        for s in range(12):
+            ops.lstm_step_policy_value(hg, None, bg, None, None, cg, doneg, pwg, pbg, pig, actg, vwg, vbg, nbr_g, Ag, vg, mode=2,
+                                       xs=(None, None, imgg, None, msgg), h_out=hog, c_out=cog, gates=gg, defer_action_term=True)
+        torch.cuda.synchronize()
+        ops.check_coupled_status()
+    Gg = torch.cat([torch.sigmoid(rd(Ng, Tg, Egd, 3 * H)), torch.tanh(rd(Ng, Tg, Egd, H))], dim=-1)
+    Cg, Dg = rd(Ng, Tg + 1, Egd, H), rd(Ng, Tg, Egd, H)
+    dZg, D1g = torch.empty(Ng, Tg, Egd, 4 * H, device='cuda'), torch.empty(Ng, Tg, Egd, H, device='cuda')
+    donesg = torch.zeros(Tg, Egd, device='cuda')
+    wxmg, wmsgg = rd(Ng, H, 4 * H) * 0.1, rd(Ng, H, H) * 0.15
+    wsg, wmgg = (wxmg, whg, ops.lstm_bptt_wimage(wxmg, whg)), (wmsgg, ops.lstm_bptt_msg_wimage(wmsgg))
+    revg = ops.reverse_neighbor_table(nbr_g, ops.COUPLED_IC3)
+    for s in range(4):
+        ops.bptt_coupled(ops.COUPLED_IC3, revg, nbr_g.shape[1], Gg, Cg, donesg, Dg, wsg, wmgg, None, dZg, D1g)
+    torch.cuda.synchronize()
+    ops.check_coupled_status()
+except Exception as ex:                        # a side measurement: never fail the pass
+    print('grid CommNet kernels skipped:', ex)
 print('done', E, Eg)

@@ -87,7 +87,7 @@ except (AssertionError, ZeroDivisionError) as ex:
     print('no bptt_seq in this collection:', ex)
 try:        # the coupled nets' reverse recurrence in one launch (NeurComm, line graph): per (agent, replica, step) row gates 1024 +
     # c 256 + dL/dh 256 + relu mask 256 + 2 neighbours' message slots 512 read; dz 1024 + d1 256 + message row 512 written
-    s = stat('lstm_bptt_coupled_kernel')
+    s = stat('lstm_bptt_coupled_kernel<8, 2, true>')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096 * 60
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
@@ -95,6 +95,29 @@ try:        # the coupled nets' reverse recurrence in one launch (NeurComm, line
     res['kernels']['lstm_bptt_coupled_nc_N8_E4096_T60'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no bptt_coupled in this collection:', ex)
+try:        # CommNet on the 5 x 5 grid, 25 x 1024 rows: the one-launch lock-step with the observation encoder inside.  Per (agent, replica)
+    # row: own + neighbours' compact observation (1 + 3.2) x 48 read; own h, c 512 + the neighbours' h before and after 2 x 3.2 x 256 read;
+    # encoder output 256 + LSTM input 256 + h', c' 512 + gates 1024 + pi 20 + v 4 + action 1 written (3.2 = mean degree of the grid)
+    s = stat('lstm_step_x_kernel<4, 2>')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 25 * 1024
+    balg = int(4.2 * 48 + 512 + 2 * 3.2 * 256 + 256 + 256 + 512 + 1024 + 25)
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / rows / balg)
+    res['kernels']['lstm_step_x4_ic3_N25_E1024'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no one-launch grid step in this collection:', ex)
+try:        # its coupled BPTT (T = 120): per (agent, replica, step) row gates 1024 + c 256 + dL/dh 256 + 3.2 neighbours' message rows
+    # 3.2 x 256 read; dz 1024 + d1 256 + message row 256 written
+    s = stat('lstm_bptt_coupled_kernel<4, 4, false>')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 25 * 1024 * 120
+    balg = int(1024 + 256 + 256 + 3.2 * 256 + 1024 + 256 + 256)
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / rows / balg)
+    res['kernels']['lstm_bptt_coupled_ic3_N25_E1024_T120'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no grid bptt_coupled in this collection:', ex)
 json.dump(res, open('%s/%s_pmc_traffic.json' % (out_dir, tag), 'w'), indent=1)
 with open('%s/%s_pmc_traffic.md' % (out_dir, tag), 'w') as f:
     f.write('# HBM traffic of the env-step kernels (and the fused LSTM step) from rocprofv3 PMC passes\n\n'

@@ -21,6 +21,7 @@
 // With 8 output tiles the 32-byte lane pitch is swizzled ((t >> 2) ^ (c >> 3)) so that every ds_read_b128 is
 // conflict-free.  Loads of unit group j + 1 are issued before the MFMAs of group j.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -498,6 +499,16 @@ __global__ void lstm_bptt_wimage_kernel(const int N, const int KM, const float* 
 // reader's L2 still holds from two steps ago would be served stale (seen: rare wrong rows with a two-slot ring).  The
 // step-wise form alternates two slots (kernel boundaries make them coherent); with a symmetric neighbour relation a
 // producer's consumers are exactly the agents it waits for, so a slot is rewritten only after its readers are done.
+#ifdef NMARL_STEP_TIMELINE      // instrumentation build (tools/bptt_timeline.py): shader-clock stamps of block 0's waves, one mid step
+__device__ unsigned long long* g_tl_b = nullptr;
+__global__ void tl_b_set_kernel(unsigned long long* p) { g_tl_b = p; }
+#define NMARL_BSTAMP(i) if (g_tl_b && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_tl_b[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime();
+#define NMARL_BSTAMP_T(i) if (t == T / 2) { NMARL_BSTAMP(i) }
+#else
+#define NMARL_BSTAMP(i)
+#define NMARL_BSTAMP_T(i)
+#endif
+
 struct CoupledArgs {
     const float *gates, *c_all, *done, *dh_ext, *img, *img_m, *mask;
     float *dz, *d1, *ring, *db_part, *dbm_part, *dhr_io, *dc_io;
@@ -541,6 +552,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     const int64_t arow_raw = row0 + c;
     const bool arow_ok = arow_raw < a.E;
     const bool odd = (c & 1) != 0, hi = (c & 2) != 0;
+    NMARL_BSTAMP(0)
     {
         const float4* g = reinterpret_cast<const float4*>(a.img + (int64_t)n * a.img_sn);
         float4* d = reinterpret_cast<float4*>(lds);
@@ -570,16 +582,17 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     int src_n[RMAX];
     uint32_t src_c4[RMAX];
     float src_w[RMAX];
-    gu32* src_flag[RMAX];
 #pragma unroll
     for (int s = 0; s < RMAX; ++s) {
         src_n[s] = a.rev_agent[n * RMAX + s];
         src_c4[s] = (uint32_t)a.rev_col[n * RMAX + s] * 4u;
         src_w[s] = a.rev_w[n * RMAX + s];
-        src_flag[s] = (gu32*)(a.flags + ((int64_t)src_n[s] * a.tiles + blk) * WAVES + wave);
     }
-    gu32* my_flag = (gu32*)(a.flags + ((int64_t)n * a.tiles + blk) * WAVES + wave);
+    const int my_flag_idx = (n * a.tiles + blk) * WAVES + wave;       // (the pointer is formed at the store: one live register, not two)
     bool give_up = false;
+    // ONE poll for all sources: lane s < RMAX watches source s's flag (the other lanes source 0's), a ballot decides -- a
+    // sequence of scalar polls costs one memory round trip per source on the critical path of every step
+    gu32* poll_flag = (gu32*)(a.flags + ((int64_t)a.rev_agent[n * RMAX + (lane < RMAX ? lane : 0)] * a.tiles + blk) * WAVES + wave);
 
     // Register diet (round 4): the step's inputs are NOT all prefetched a step ahead any more.  Gates + c_{t-1} of one unit
     // group (5 float4 = 20 registers) cycle through TWO slots -- group j + 2 is requested as soon as group j's cell backward
@@ -738,13 +751,54 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     NMARL_CP_MMF(bv, P) __builtin_amdgcn_sched_barrier(0);                                 \
     NMARL_CP_MBL(P, s2) __builtin_amdgcn_sched_barrier(0);
     const int sw = c >> 3;
+    NMARL_BSTAMP(1)
     for (int t = t_hi; t >= t_lo; --t) {
+        NMARL_BSTAMP_T(2)
         const int tp = t > t_lo ? t - 1 : t_lo;      // clamped: the last prefetch re-reads the range's last step
-        const float keep_next = 1.0f - (a.done + (int64_t)__builtin_amdgcn_readfirstlane(tp) * a.E)[lor];
         const int64_t tu = __builtin_amdgcn_readfirstlane(t);
         const __amdgpu_buffer_rsrc_t rz = make_rsrc(zA + tu * a.dz_st, nb4);
         const __amdgpu_buffer_rsrc_t rd1 = make_rsrc(d1A + tu * a.d1_st, nb1);
-        // ---- relu mask of the message layer at step t (independent of the neighbours: in flight while the flags are polled)
+        // ---- the neighbours' message adjoints of step t + 1: FIRST thing of the step (it is the hand-off's critical path):
+        // one poll, then every source's four loads in flight together.  Nothing else is outstanding at this point (the step
+        // ended on vmcnt(0)), so neither the poll's value nor the payload queue behind other loads.
+        float4 mm[RMAX][4];
+        {
+            const unsigned need = (unsigned)(T - 1 - t);
+            const float* rbase = a.ring + (int64_t)((t + 1) % a.slots) * a.ring_slot;
+            if (!give_up) {
+                for (unsigned spins = 0;; ++spins) {
+                    const unsigned v = __hip_atomic_load(poll_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_ballot_w64(v < need) == 0) break;
+                    if (spins > a.max_spins) {
+                        if (lane == 0) {                 // sticky: the optimiser step refuses this batch
+                            __hip_atomic_store((gu32*)a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a.status) __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        give_up = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            asm volatile("" ::: "memory");               // payload loads stay below the poll
+            NMARL_BSTAMP_T(3)
+#pragma unroll
+            for (int s = 0; s < RMAX; ++s) {
+                // nothing to read at the end of the sequence (nothing was handed over yet) and from an absent source (weight 0:
+                // padding of the table): a zero-record resource returns 0.0f without touching memory -- no stale, possibly
+                // non-finite ring contents times zero, no traffic for the padding
+                const uint32_t nb_ = (t == T - 1 || src_w[s] == 0.0f) ? 0u : nbR;
+                const __amdgpu_buffer_rsrc_t rr = make_rsrc(rbase + (int64_t)src_n[s] * a.ring_sn, nb_);
+                const uint32_t ro_ = loR + src_c4[s];
+                mm[s][0] = bload4i<SC1>(rr, ro_, 0);
+                mm[s][1] = bload4i<SC1>(rr, ro_, 64);
+                mm[s][2] = bload4i<SC1>(rr, ro_, 128);
+                mm[s][3] = bload4i<SC1>(rr, ro_, 192);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- relu mask of the message layer at step t and the next step's done flag: needed late, requested behind the payload
+        const float keep_next = 1.0f - (a.done + (int64_t)__builtin_amdgcn_readfirstlane(tp) * a.E)[lor];
         float4 mk0, mk1, mk2, mk3;
         if (MASK) {
             const __amdgpu_buffer_rsrc_t rm = make_rsrc(mkA + tu * a.mask_st, nbm);
@@ -753,46 +807,16 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
             mk2 = bload4i(rm, lom, 128);
             mk3 = bload4i(rm, lom, 192);
         }
-        // ---- the neighbours' message adjoints of step t + 1 (none at the end of the sequence: weight 0, the ring is finite)
-        {
-            const unsigned need = (unsigned)(T - 1 - t);
-            const float* rbase = a.ring + (int64_t)((t + 1) % a.slots) * a.ring_slot;
-            // at the end of the sequence nothing was handed over yet: a zero-record resource reads 0.0f (no stale -- possibly
-            // non-finite -- ring contents times a zero weight)
-            const uint32_t nbR_t = t == T - 1 ? 0u : nbR;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < RMAX; ++s) {
-                if (!give_up) {
-                    for (unsigned spins = 0;; ++spins) {
-                        const unsigned v = __builtin_amdgcn_readfirstlane(
-                            __hip_atomic_load(src_flag[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                        if (v >= need) break;
-                        if (spins > a.max_spins) {
-                            if (lane == 0) {             // sticky: the optimiser step refuses this batch
-                                __hip_atomic_store((gu32*)a.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (a.status) __hip_atomic_store((gu32*)a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-                            give_up = true;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                asm volatile("" ::: "memory");       // payload loads stay below the poll
-                const __amdgpu_buffer_rsrc_t rr = make_rsrc(rbase + (int64_t)src_n[s] * a.ring_sn, nbR_t);
-                const float w_ = src_w[s];
-                const uint32_t ro_ = loR + src_c4[s];
-                const float4 m0 = bload4i<SC1>(rr, ro_, 0);
-                const float4 m1 = bload4i<SC1>(rr, ro_, 64);
-                const float4 m2 = bload4i<SC1>(rr, ro_, 128);
-                const float4 m3 = bload4i<SC1>(rr, ro_, 192);
-                gh[0].x += w_ * m0.x; gh[0].y += w_ * m0.y; gh[0].z += w_ * m0.z; gh[0].w += w_ * m0.w;
-                gh[1].x += w_ * m1.x; gh[1].y += w_ * m1.y; gh[1].z += w_ * m1.z; gh[1].w += w_ * m1.w;
-                gh[2].x += w_ * m2.x; gh[2].y += w_ * m2.y; gh[2].z += w_ * m2.z; gh[2].w += w_ * m2.w;
-                gh[3].x += w_ * m3.x; gh[3].y += w_ * m3.y; gh[3].z += w_ * m3.z; gh[3].w += w_ * m3.w;
-                __builtin_amdgcn_sched_barrier(0);   // one source's 4 loads in flight at a time (registers)
+        for (int s = 0; s < RMAX; ++s) {                 // summed in source order (the restatement's order)
+            const float w_ = src_w[s];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gh[j].x += w_ * mm[s][j].x; gh[j].y += w_ * mm[s][j].y; gh[j].z += w_ * mm[s][j].z; gh[j].w += w_ * mm[s][j].w;
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
         unsigned mbits = 0xFFFFu;                     // bit 4 j + i: hm > 0 for unit 16 j + 4 q + i of the lane's row
         if (MASK) {
             mbits = (mk0.x > 0.0f ? 1u : 0u) | (mk0.y > 0.0f ? 2u : 0u) | (mk0.z > 0.0f ? 4u : 0u) | (mk0.w > 0.0f ? 8u : 0u) |
@@ -815,31 +839,40 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         float4 di, df, dO, du;
+        NMARL_BSTAMP_T(4)
         NMARL_CP_CELL(sA, 0)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_LOADG(sA, t, 2)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(5)
         NMARL_CP_PROD(0)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(6)
         NMARL_CP_CELL(sB, 1)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_LOADG(sB, t, 3)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(7)
         NMARL_CP_PROD(1)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(8)
         NMARL_CP_CELL(sA, 2)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_LOADG(sA, tp, 0)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(9)
         NMARL_CP_PROD(2)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(10)
         NMARL_CP_CELL(sB, 3)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_CP_LOADG(sB, tp, 1)
         NMARL_CP_LOADH(tp)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(11)
         NMARL_CP_PROD(3)
         __builtin_amdgcn_sched_barrier(0);
+        NMARL_BSTAMP_T(12)
         // ---- D1 = dx (relu-masked) in the lane's own units; bias gradient of the message layer
         f32x4 d1v[4];
         {
@@ -866,6 +899,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
             const float k3_ = b3 ? r1_ : r0_, g3_ = b3 ? r0_ : r1_;
             dbm += k3_ + __shfl_xor(g3_, 8, 64);
         }
+        NMARL_BSTAMP_T(13)
         // ---- M_t^T = W_msg . D1^T, handed to the neighbours' blocks
         {
             int moff = (q * 16 + c) * NTM;
@@ -889,9 +923,11 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
 #pragma unroll
             for (int i = 0; i < NTM; ++i) bstore4_wt(rw, soR + 64 * i, float4{am[i][0], am[i][1], am[i][2], am[i][3]});
         }
+        NMARL_BSTAMP_T(14)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
+        NMARL_BSTAMP_T(15)
         if (lane == 0 && !(a.fault && blockIdx.x == 0))
-            __hip_atomic_store(my_flag, (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store((gu32*)(a.flags + my_flag_idx), (unsigned)(T - t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // own recurrent part of dL/dh_{t-1} = (dz @ wh^T) keep_t: into the prefetched inputs of step t - 1 (landed: drained)
         if (t == t_lo && arow_ok) {                  // end of the range: state for the next launch of a step-wise run
 #pragma unroll
@@ -907,7 +943,9 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         gh[2].x += acc[6][0] * keepA; gh[2].y += acc[6][1] * keepA; gh[2].z += acc[6][2] * keepA; gh[2].w += acc[6][3] * keepA;
         gh[3].x += acc[7][0] * keepA; gh[3].y += acc[7][1] * keepA; gh[3].z += acc[7][2] * keepA; gh[3].w += acc[7][3] * keepA;
         keepA = keep_next;
+        NMARL_BSTAMP_T(16)
     }
+    NMARL_BSTAMP(17)
 #undef NMARL_CP_LOADG
 #undef NMARL_CP_LOADH
 #undef NMARL_CP_BL
@@ -1175,3 +1213,10 @@ extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stre
     }
     return rc;
 }
+
+#ifdef NMARL_STEP_TIMELINE
+extern "C" int nmarl_timeline_set_bptt(unsigned long long* p, void* stream) {
+    hipLaunchKernelGGL(tl_b_set_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), p);
+    return nmarl_check_launch();
+}
+#endif

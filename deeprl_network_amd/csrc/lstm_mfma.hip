@@ -569,9 +569,28 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const int c = lane & 15, grp = lane >> 4;
     static_assert(HEAD != 4 || MSG != 0, "HEAD 4 is the coupled nets' policy + value step");
     constexpr bool PV = HEAD == 3 || HEAD == 4;          // policy step + value re-step in this launch
-    unsigned epoch = 0;                                  // HEAD 4: this launch's flag value (generation + 1)
-    if (HEAD == 4)
-        epoch = __builtin_amdgcn_readfirstlane(__hip_atomic_load((gu32*)xa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u;
+    // HEAD 4: this launch's flag value = generation + 1.  The load is ISSUED here and consumed after the K loop: a
+    // readfirstlane right away would park the wave for a memory round trip before it has requested anything else
+    unsigned epoch_raw = 0;
+    if (HEAD == 4) epoch_raw = __hip_atomic_load((gu32*)xa.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the neighbour tables of this agent (uniform): every entry requested NOW, back to back -- looked up where they are used,
+    // each one costs a dependent (scalar) memory round trip in front of the loads it addresses
+    int nbj[8];
+    if (MSG != 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nbj[k] = xa.nbr_idx[n * xa.m_max + (k < xa.m_max ? k : 0)];
+    }
+    // the message layer's bias and the observation encoder's (lane column c = units 4 c .. 4 c + 3): requested here too -- loaded
+    // where they are added, each exposes a memory round trip inside a pre-phase
+    constexpr bool OBENC = HEAD == 4 && MSG == 2;                    // the in-kernel observation encoder exists (runs if xa.ob)
+    const bool ob_here = OBENC && xa.ob != nullptr;
+    float4 bv4 = float4{0.f, 0.f, 0.f, 0.f}, bo4 = float4{0.f, 0.f, 0.f, 0.f};
+    if (MSG != 0) {
+        const float* mbias_ = xa.msg_b + (int64_t)n * xa.msg_b_sn;
+        bv4 = *reinterpret_cast<const float4*>(mbias_ + 4 * (lane & 15));
+        if (OBENC) bo4 = *reinterpret_cast<const float4*>((ob_here ? xa.ob_b + (int64_t)n * xa.ob_b_sn : mbias_) + 4 * (lane & 15));
+    }
+    NMARL_STAMP(40)
     // De-phased wave groups (no message pre-phase only: LDS): waves 4-7 run ONE chunk behind waves 0-3 through a ring
     // of three chunk buffers, so that on every SIMD one wave's VALU epilogue / head overlaps the other's MFMAs instead
     // of both epilogues running side by side with an idle matrix pipe.
@@ -630,7 +649,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d1.x *= kf_; d1.y *= kf_; d1.z *= kf_; d1.w *= kf_;                               \
     }
     if (MSG == 0) { NMARL_A_LOAD(0, a0, a1) }
+    NMARL_STAMP(41)
     NMARL_STAGE_STORE(0)
+    NMARL_STAMP(42)
 
     // ---- accumulators <- bias (+ zadd1 + zadd2);  C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
     int64_t rofs[4];
@@ -692,27 +713,27 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         float4* d_ = reinterpret_cast<float4*>(lds + CH_FLOATS) + threadIdx.x;
         d_[0] = tg0; d_[512] = tg1; d_[1024] = tg2; d_[1536] = tg3; d_[2048] = tg4;
     }
+    NMARL_STAMP(43)
     NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
     float* m_lds = hw_lds + HW_FLOATS;                               // W_msg image: msg_kc * 32 * 64 floats
-    if (HEAD != 0) {        // the heads' h-weights -> LDS (read 16 x (A + 1) times per lane in the head epilogues)
+    // the heads' h-weights -> LDS (read 16 x (A + 1) times per lane in the head epilogues): REQUESTED here (unconditional,
+    // clamped addresses), stored to LDS at the end of the prologue -- stored right away they cost their own round trip
+    float hw0 = 0.0f, hw1 = 0.0f, hw2 = 0.0f;
+    if (HEAD != 0) {
         const nmarl_head_t& hd = a.hd;
         const float* w1 = hd.w + (int64_t)n * hd.w_sn;
         if (HEAD == 2) {                                     // critic only: [64]
-            if (threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = w1[threadIdx.x];
+            hw2 = w1[threadIdx.x & (H - 1)];
         } else {                                             // actor [64][A] -> [64][MAXA] zero padded, bias [A] -> [MAXA]
             const int A = hd.A;
             const int k = threadIdx.x >> 3, o = threadIdx.x & 7;               // 512 threads = 64 x 8
-            hw_lds[threadIdx.x] = o < A ? w1[k * A + o] : 0.0f;
-            if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = threadIdx.x < A ? (hd.b + (int64_t)n * hd.b_sn)[threadIdx.x] : 0.0f;
-            if (PV) {
-                const float* w2 = hd.w2 + (int64_t)n * hd.w2_sn;
-                if (threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = w2[threadIdx.x];
-            }
+            hw0 = w1[k * A + (o < A ? o : 0)];
+            hw1 = (hd.b + (int64_t)n * hd.b_sn)[(threadIdx.x & 7) < A ? (threadIdx.x & 7) : 0];
+            if (PV) hw2 = (hd.w2 + (int64_t)n * hd.w2_sn)[threadIdx.x & (H - 1)];
         }
     }
-    constexpr bool OBENC = HEAD == 4 && MSG == 2;                    // the in-kernel observation encoder exists (runs if xa.ob)
+    NMARL_STAMP(44)
     float* o_lds = m_lds + xa.msg_kc * (CH_K * 64);                  // W_ob image: 64 x 64 floats
-    const bool ob_here = OBENC && xa.ob != nullptr;
     // the W_msg / W_ob images: all pieces requested at once (a run-time loop would wait for every piece before asking for the next)
     constexpr int MIQ = MSG == 1 ? 4 : 2;                            // pieces per thread: K_m <= 128 (MSG 1), = 64 (MSG 2)
     float4 mi[MSG != 0 ? MIQ : 1], oi[OBENC ? 2 : 1];
@@ -730,8 +751,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // msg_load: request the neighbour rows of one round (MSG 1: both slots, all four half-chunks; MSG 2: neighbours k0 .. k0 + 3,
     // both chunks) -- every row BEFORE the first product, absent slots read the own row with weight 0 (no load inside a branch).
     // U: MSG 1 [kc][half], MSG 2 [q][kc][half].
-    auto msg_load = [&](auto second_c, const int k0, float4 (&U)[16], float (&W)[4]) {
+    auto msg_load = [&](auto second_c, auto k0_c, float4 (&U)[16], float (&W)[4]) {
         constexpr bool SECOND = decltype(second_c)::value;
+        constexpr int k0 = decltype(k0_c)::value;
         const float* hsrc = SECOND ? a.h_new : a.h_in;
         const int64_t hsn = SECOND ? a.h_new_sn : a.h_sn;
         const float* hbase = hsrc + arow * H + 4 * grp;              // + j * hsn: row `arow` of agent j
@@ -747,11 +769,10 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 u1 = *reinterpret_cast<const float4*>(p_ + 16);
             }
         };
-        const int32_t* nb = xa.nbr_idx + n * xa.m_max;
 #pragma unroll
         for (int q = 0; q < (MSG == 1 ? 2 : 4); ++q) {
             const int k = k0 + q;
-            const int j = nb[k < xa.m_max ? k : 0];
+            const int j = nbj[k];
             const bool ok = k < xa.m_max && j >= 0;
             W[q] = ok ? 1.0f : 0.0f;
             load2(ok ? j : n, 0, U[4 * q + 0], U[4 * q + 1]);
@@ -761,36 +782,52 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // the first pre-phase's neighbour rows (and the encoder's observation pieces): requested here, consumed after the barrier
     float4 PU[16];
     float PW[4];
-    if (MSG != 0) msg_load(std::false_type{}, 0, PU, PW);
+    using K0 = std::integral_constant<int, 0>;
+    using K4 = std::integral_constant<int, 4>;
+    if (MSG != 0) msg_load(std::false_type{}, K0{}, PU, PW);
     float4 ea[OBENC ? 4 : 1];
     if (OBENC) {
         // unconditional loads (a valid dummy row when the encoder does not run): input k = F slot + f, four features of one slot
         const float* obr = ob_here ? xa.ob + arow * xa.ob_row : hrow;
-        const int32_t* nbs = ob_here ? xa.ob_nbr + n * xa.ob_segs : xa.nbr_idx;
         const int F = ob_here ? xa.ob_F : 64, segs = ob_here ? xa.ob_segs : 0;
+        // slot owners: own index, then the neighbour table (ob_nbr [N, segs] = [own | neighbours] by contract, checked by the
+        // launcher) -- already in registers
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int f = (q >> 1) * CH_K + 16 * (q & 1) + 4 * grp, seg = 0;
             while (f >= F) { f -= F; ++seg; }
-            const int j = nbs[seg < segs ? seg : 0];
-            const bool ok = seg < segs && j >= 0;
+            int j = n;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) j = seg == k + 1 ? nbj[k] : j;
+            const bool ok = seg < segs && (seg == 0 || seg - 1 < xa.m_max) && j >= 0;
             const float w = ok ? 1.0f : 0.0f;
             float4 v = *reinterpret_cast<const float4*>(obr + (ok ? j * F + f : 0));
             v.x *= w; v.y *= w; v.z *= w; v.w *= w;
             ea[q] = v;
         }
     }
+    NMARL_STAMP(45)
     if (MSG != 0) {
         float4* d = reinterpret_cast<float4*>(m_lds);
         const int lim = xa.msg_kc * (CH_K * 64 / 4);
 #pragma unroll
         for (int q = 0; q < MIQ; ++q) { const int i = threadIdx.x + 512 * q; if (i < lim) d[i] = mi[q]; }
     }
+    NMARL_STAMP(46)
     if (ob_here) {
         float4* d = reinterpret_cast<float4*>(o_lds);
 #pragma unroll
         for (int q = 0; q < 2; ++q) d[threadIdx.x + 512 * q] = oi[q];
     }
+    if (HEAD == 2) {
+        if (threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = hw2;
+    } else if (HEAD != 0) {
+        const int A = a.hd.A;
+        hw_lds[threadIdx.x] = (int)(threadIdx.x & 7) < A ? hw0 : 0.0f;
+        if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = (int)threadIdx.x < A ? hw1 : 0.0f;
+        if (PV && threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = hw2;
+    }
+    NMARL_STAMP(47)
     __syncthreads();
     NMARL_STAMP(1)
     // one k-step of a 64-column product from an LDS image [k][c][4 t]: four MFMAs; a 32-row chunk of it: eight steps
@@ -815,7 +852,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         for (int t = 0; t < 4; ++t) eacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         NMARL_MCHUNK(eacc, o_lds, 0, ea[0], ea[1])
         NMARL_MCHUNK(eacc, o_lds, 1, ea[2], ea[3])
-        const float4 bo = *reinterpret_cast<const float4*>(xa.ob_b + (int64_t)n * xa.ob_b_sn + 4 * c);
+        const float4 bo = bo4;
         float* eo = const_cast<float*>(xa.enc) + (int64_t)n * xa.enc_sn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -844,15 +881,15 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 }
             }
         } else {                            // mean over the existing neighbours (K_m = 64: two chunks), four neighbours per round
-            const int32_t* nb = xa.nbr_idx + n * xa.m_max;
             int cnt = 0;
-            for (int k = 0; k < xa.m_max; ++k) cnt += nb[k] >= 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cnt += (k < xa.m_max && nbj[k] >= 0) ? 1 : 0;
             const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
             float4 sm[2][2];
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) sm[kc][0] = sm[kc][1] = float4{0.f, 0.f, 0.f, 0.f};
             for (int k0 = 0; k0 < xa.m_max; k0 += 4) {
-                if (k0 > 0) msg_load(second_c, k0, U, W);
+                if (k0 > 0) msg_load(second_c, K4{}, U, W);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -872,10 +909,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
         }
         // result (C layout) + bias, relu / + enc -> the wave's LDS tile (A layout source) and, if asked, global memory
-        const float* mbias = xa.msg_b + (int64_t)n * xa.msg_b_sn;
         const float* encn = MSG == 2 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
         float* xo = (!SECOND && xa.xm_out) ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
-        const float4 bv = *reinterpret_cast<const float4*>(mbias + 4 * c);       // tile t of lane column c = unit 4 c + t
+        const float4 bv = bv4;                                                    // tile t of lane column c = unit 4 c + t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float4 v = float4{macc[0][r] + bv.x, macc[1][r] + bv.y, macc[2][r] + bv.z, macc[3][r] + bv.w};
@@ -894,6 +930,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    NMARL_STAMP(48)
     float keepr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) keepr[r] = 1.0f - a.done[rofs[r]];
@@ -910,6 +947,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             a1.x = t_[16]; a1.y = t_[17]; a1.z = t_[18]; a1.w = t_[19];
         }
     }
+    NMARL_STAMP(49)
     if (MSG != 0) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
@@ -965,6 +1003,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         NMARL_CHUNK(buf, a0, a1)
     }
     NMARL_STAMP(20)
+    const unsigned epoch = HEAD == 4 ? (unsigned)__builtin_amdgcn_readfirstlane((int)epoch_raw) + 1u : 0u;
 
     // ---- lane-local cell epilogue.  A lane holds units 4 c .. 4 c + 3 of rows 4 grp + r (column permutation of the image):
     // every output leaves as 16-byte stores of contiguous row pieces, 256 B per row and instruction.  (4-byte stores in the
@@ -1063,11 +1102,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             // ---- the message columns of the re-step: from the neighbours' NEW h, published by the same wave of their blocks
             gu32* flags = (gu32*)(xa.sync + 16);
             const int bpa = a.blocks_per_agent, blk = (int)(blockIdx.x / xa.N);
-            const int32_t* nb = xa.nbr_idx + n * xa.m_max;
             bool give_up = false;
-            for (int k = 0; k < xa.m_max; ++k) {
-                const int j = nb[k];
-                if (j < 0 || give_up) continue;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = nbj[k];
+                if (k >= xa.m_max || j < 0 || give_up) continue;
                 gu32* f = flags + ((j * bpa + blk) * WAVES2 + wave);
                 for (unsigned spins = 0;; ++spins) {
                     const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1085,7 +1124,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
             asm volatile("" ::: "memory");               // the payload loads stay below the polls
             NMARL_STAMP(27)
-            msg_load(std::true_type{}, 0, PU, PW);
+            msg_load(std::true_type{}, K0{}, PU, PW);
             msg_phase(std::true_type{}, PU, PW);         // -> the wave's A tile
             NMARL_STAMP(28)
             __syncthreads();                             // every wave is through with the Wh chunks
@@ -1425,7 +1464,8 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     size_t lb_extra = 0;
     if (msg && msg->ob) {
         // in-kernel observation encoder: the one-launch lstm_ic3 step only; compact observation, 16-byte pieces
-        if (mk != 2 || kind != 3 || msg->ob_F <= 0 || (msg->ob_F % 4) || msg->ob_segs <= 0 || msg->ob_F * msg->ob_segs > H ||
+        // (the kernel takes the slot owners from nbr_idx: ob_nbr must be [own index | nbr_idx row], i.e. ob_segs = m_max + 1)
+        if (mk != 2 || kind != 3 || msg->ob_F <= 0 || (msg->ob_F % 4) || msg->ob_segs != msg->m_max + 1 || msg->ob_F * msg->ob_segs > H ||
             !msg->ob_nbr || !msg->ob_img || !msg->ob_b || ((uintptr_t)msg->ob % 16) || (msg->ob_row % 4) ||
             msg->ob_row < (int64_t)N * msg->ob_F || ((uintptr_t)msg->ob_img % 16) || msg->ob_img_sn < H * 64 || (msg->ob_img_sn % 4) ||
             ((uintptr_t)msg->ob_b % 16) || (msg->ob_b_sn % 4) || msg->ob_b_sn < H)

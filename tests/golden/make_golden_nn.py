@@ -370,6 +370,8 @@ def run_batched(name, agent, topo, seed, n_step, K=4):
                     grad_log.append((p, float(vals[0]), [np.array(g, dtype=np.float64) for g in vals[1:]],
                                      [w.full_name for w in wts]))
             return [None] * len(fetches)                      # the optimiser step is NOT applied
+        if any(fetches is getattr(p, '_consensus_update', None) for p in policies):
+            return None           # ConseNet's neighbourhood averaging (policies.py:351-355) follows the (skipped) step: applied once below
         return orig_run(self, fetches, feed_dict)
     tf.Session.run = intercept
 
@@ -457,6 +459,13 @@ def run_batched(name, agent, topo, seed, n_step, K=4):
             ms = 1.0 + (g * g - 1.0) * (1.0 - decay)
             new_w[nm] = by_name[nm].numpy().astype(np.float64) - lr * g / np.sqrt(ms + eps)
             mean_g[nm] = g / scale
+    if agent == 'ma2c_cu':
+        # the consensus update that follows the optimiser step (policies.py:351-364, 403-426): every agent's LSTM variables
+        # <- mean over itself and its neighbours, all sources read before any target is written (the shim's tf.group)
+        stepped = dict(new_w)
+        for i in range(N):
+            for var in ('wx', 'wh', 'b'):
+                new_w['cu/lstm_%da/%s' % (i, var)] = np.mean([stepped['cu/lstm_%da/%s' % (j, var)] for j in [i] + list(nbr[i])], axis=0)
     out = dict(stats0=var_stats(variables), names=np.array([v.full_name for v in variables]),
                shapes=np.array([str(tuple(v.value.shape)) for v in variables]),
                X=X, ACT=ACT, REW=REW, PI=PI, V=V, RB=RB, STATES=STATES, LOSSK=LOSSK, LOSS=LOSSK.mean(0), GN=GN,
@@ -468,7 +477,11 @@ def run_batched(name, agent, topo, seed, n_step, K=4):
 
 
 BATCHED = [('ia2c_fp_line', 'ia2c_fp', 'line', 40, 60), ('ma2c_nc_line', 'ma2c_nc', 'line', 41, 60),
-           ('ma2c_ic3_grid', 'ma2c_ic3', 'grid', 42, 120)]
+           ('ma2c_ic3_grid', 'ma2c_ic3', 'grid', 42, 120),
+           # round 4: the algorithms whose batched update was pinned at E = 1 only, and NeurComm on the grid (message input
+           # 64 x 4 = 256 wide: the product's separate-launch message path, not the step kernel's pre-phase)
+           ('ia2c_line', 'ia2c', 'line', 43, 60), ('ma2c_cu_line', 'ma2c_cu', 'line', 44, 60),
+           ('ma2c_dial_line', 'ma2c_dial', 'line', 45, 60), ('ma2c_nc_grid', 'ma2c_nc', 'grid', 46, 30)]
 
 
 def run_ortho():

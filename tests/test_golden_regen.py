@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, 'golden')
 pytestmark = pytest.mark.skipif(not os.path.isdir('/root/reference/agents'), reason='needs the reference checkout')
 
-FAST_NN = 'ortho_init,nn_ia2c_fp_line,nn_ma2c_nc_line,nn_ma2c_ic3_ragged,nnb_ia2c_fp_line'
+FAST_NN = 'ortho_init,nn_ia2c_fp_line,nn_ma2c_nc_line,nn_ma2c_ic3_ragged,nnb_ia2c_fp_line,nnb_ma2c_cu_line'
 
 
 def _same(out_dir, expect_at_least):

@@ -854,7 +854,7 @@ def test_lstm_bptt_seq_one_launch(N, T, E):
                                atol=1e-6 * max(1.0, float(db_r.abs().max())) * (T * E) ** 0.5)
 
 
-@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (5, 127, 4, 2)])
+@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (5, 127, 4, 2), (25, 1024, 5, 4)])
 @pytest.mark.parametrize('kind', [1, 2])
 def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
     """The message term of a coupled net computed by the step kernel's pre-phase (nmarl_lstm_step_x_msg) vs the float64

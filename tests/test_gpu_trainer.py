@@ -229,6 +229,7 @@ def test_handoff_timeout_fails_closed(agent, site, handoff_switch, monkeypatch):
     monkeypatch.delenv('NMARL_INKERNEL_HANDOFF')
     # faulty run: eager rollout (the fault flag is a launch argument, a captured graph would replay it)
     env, model, tr = build(agent, E, False, scenario='slowdown', n_step=T)
+    model.policy.refresh_wimage()              # (the message image decides whether the one-launch step exists)
     assert tr.handoff_guard and model.policy.pv_one_launch(E)
     w0, ms0 = model.policy.params.flat.clone(), model.policy.params.ms.clone()
     seen = {}

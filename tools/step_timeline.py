@@ -20,7 +20,7 @@ SRC = os.path.join(ROOT, 'deeprl_network_amd', 'csrc', 'lstm_mfma.hip')
 if '--build' in sys.argv or not os.path.exists(SO):
     os.makedirs(OUT, exist_ok=True)
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
-                           '-DNMARL_STEP_TIMELINE', SRC, '-o', SO])
+                           '-DNMARL_STEP_TIMELINE', SRC, os.path.join(os.path.dirname(SRC), 'lstm_bptt.hip'), '-o', SO])
     if '--build' in sys.argv:
         sys.exit(0)
 
@@ -98,13 +98,14 @@ for _ in range(5):
 torch.cuda.synchronize()
 t = tl.cpu().view(8, 64)
 t0 = int(t[:, 0].min())
-names = {0: 'entry', 1: 'prologue', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
+names = {0: 'entry', 40: 'epoch read', 41: 'A/W loads issued', 42: 'chunk 0 in LDS', 43: 'chunk 1 in LDS', 44: 'head w in LDS',
+         45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
          26: 'published', 27: 'flags seen', 28: 'message term', 29: 'msg W staged', 30: 'msg chunks',
          33: 'cell math', 34: 'critic dots', 35: 'critic shfl'}
 for i in range(2, 20, 2):
     names[i], names[i + 1] = 'tick %d computed' % ((i - 2) // 2), 'tick %d barrier' % ((i - 2) // 2)
 print('stamp'.ljust(18) + ''.join(('wave %d' % w).rjust(9) for w in range(8)))
-ORDER = list(range(0, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25]
+ORDER = [0, 40, 41, 42, 43, 44, 45, 46, 47, 1, 48, 49] + list(range(2, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25]
 for i in ORDER:
     if i not in names:
         continue

@@ -432,65 +432,105 @@ class BatchedTrainer:
 
     def evaluate(self, n_envs=64, seed=None):
         """Deterministic (argmax) test episodes, the batched analogue of `perform(-1)` after a CACC
-        training episode (utils.py:199-223, 246-251): train_mode False -> no soft-collision term."""
-        from .envs import make_batch_env
-        env = make_batch_env(self.env.config, num_envs=n_envs, device=self.device,
-                             seed=self.env.seed - 1 if seed is None else seed, env_id_base=10 ** 9)
-        env.train_mode = False
-        model = self.model
-        E0 = model.E
-        h, c = (torch.zeros(self.N, n_envs, model.n_lstm, device=self.device) for _ in range(2))
-        fp = model.fp_uniform.expand(self.N, n_envs, model.n_a).clone()       # uniform over each agent's own actions
-        env.reset()
-        model.policy.refresh_wimage()
-        done = torch.ones(n_envs, device=self.device)
-        act = torch.zeros(n_envs, self.N, dtype=torch.uint8, device=self.device)
-        total = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
-        alive = torch.ones(n_envs, dtype=torch.float64, device=self.device)
-        steps = torch.zeros(n_envs, dtype=torch.float64, device=self.device)
-        hist = torch.zeros(model.n_a, dtype=torch.float64, device=self.device)      # greedy actions taken, by index
-        for _ in range(env.T):
-            model.policy.step(model.policy.encode(env.obs, fp), h, c, done, h, c)
-            with torch.no_grad():
-                pi = model.policy.pi(h)
-            ops.sample_actions(pi, act, ops.SAMPLE_ARGMAX)
-            fp.copy_(pi)
-            hist += torch.bincount(act.flatten().long(), weights=alive.repeat_interleave(self.N), minlength=model.n_a)[:model.n_a]
-            _, _, d, g = env.step(act)
-            total += g.double() * alive
-            steps += alive
-            alive = alive * (1.0 - d.double())
-            done.zero_()
-        assert model.E == E0                      # evaluation used its own state tensors only
+        training episode (utils.py:199-223, 246-251): train_mode False -> no soft-collision term.  The evaluation env, its state
+        tensors and (with use_graph) the whole T-step episode as ONE captured hipGraph are built once per (n_envs, seed) and
+        replayed: every evaluation starts from the same initial conditions (the reference re-seeds its in-training test with
+        seed - 1 every time, cacc_env.py:170-175) and costs a graph replay instead of ~6 T eager launches and a new env."""
+        key = (int(n_envs), self.env.seed - 1 if seed is None else int(seed))
+        cache = self.__dict__.setdefault('_eval_cache', {})
+        if key not in cache:
+            cache[key] = self._build_eval(*key)
+        ev = cache[key]
+        E0 = self.model.E
+        if ev['graph'] is not None:
+            ev['graph'].replay()
+        else:
+            ev['episode']()
+        assert self.model.E == E0                     # evaluation used its own state tensors only
+        hist, total, steps = ev['hist'], ev['total'], ev['steps']
         self.last_eval_action_share = (hist / hist.sum().clamp_min(1)).cpu().numpy().round(4).tolist()
         per_ep = (total / steps.clamp_min(1)).cpu().numpy()
-        return float(per_ep.mean()), float(per_ep.std()), int((steps < env.T).sum().item())
+        return float(per_ep.mean()), float(per_ep.std()), int((steps < ev['env'].T).sum().item())
+
+    def _build_eval(self, n_envs, seed):
+        from .envs import make_batch_env
+        dev, model, N = self.device, self.model, self.N
+        env = make_batch_env(self.env.config, num_envs=n_envs, device=dev, seed=seed, env_id_base=10 ** 9)
+        env.train_mode = False
+        f64 = dict(dtype=torch.float64, device=dev)
+        h, c = (torch.zeros(N, n_envs, model.n_lstm, device=dev) for _ in range(2))
+        fp = model.fp_uniform.expand(N, n_envs, model.n_a).clone()       # uniform over each agent's own actions
+        done = torch.ones(n_envs, device=dev)
+        act = torch.zeros(n_envs, N, dtype=torch.uint8, device=dev)
+        total, alive, steps = torch.zeros(n_envs, **f64), torch.ones(n_envs, **f64), torch.zeros(n_envs, **f64)
+        hist = torch.zeros(model.n_a, **f64)                             # greedy actions taken, by index
+        a_ids = torch.arange(model.n_a, device=dev).view(1, 1, -1)
+
+        def episode():
+            env.episode.zero_()                       # the same test episode every time
+            env.reset()
+            for t_ in (h, c, total, steps, hist):
+                t_.zero_()
+            fp.copy_(model.fp_uniform.expand_as(fp))
+            alive.fill_(1.0)
+            done.fill_(1.0)
+            model.policy.refresh_wimage()
+            for _ in range(env.T):
+                model.policy.step(model.policy.encode(env.obs, fp), h, c, done, h, c)
+                with torch.no_grad():
+                    pi = model.policy.pi(h)
+                ops.sample_actions(pi, act, ops.SAMPLE_ARGMAX)
+                fp.copy_(pi)
+                hist.add_(((act.unsqueeze(-1) == a_ids).to(torch.float64) * alive.view(-1, 1, 1)).sum(dim=(0, 1)))
+                _, _, d, g = env.step(act)
+                total.add_(g.double() * alive)
+                steps.add_(alive)
+                alive.mul_(1.0 - d.double())
+                done.zero_()
+
+        graph = None
+        if self.use_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                episode()                             # warm-up (allocator, library handles)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                episode()
+        return dict(env=env, episode=episode, graph=graph, hist=hist, total=total, steps=steps)
 
     def run(self, log_every=10, eval_every=None):
         """Train until the counter says stop (`total_step` lock-steps per replica); one row per `log_every` batches.
         Row: `avg_reward` / `std_reward` = the deterministic TEST episodes (argmax policy, raw reward) for CACC, like
-        the reference's train_reward.csv (utils.py:246-251), evaluated every `eval_every` rows (default: every row for
-        CACC, never for ATSC whose logged reward is the training episode's, utils.py:243-245); `train_avg_reward` etc.
-        = statistics of the training episodes finished since the last row (stochastic policy, training-mode reward)."""
+        the reference's train_reward.csv (utils.py:246-251), evaluated every `eval_every` rows -- default: once per training
+        episode of batches, as the reference tests once per training episode (utils.py:246-251); never for ATSC, whose logged
+        reward is the training episode's (utils.py:243-245) -- and carried forward on the rows in between (NaN before the first
+        evaluation; `evaluated` marks the rows that ran one); `train_avg_reward` etc. = statistics of the training episodes
+        finished since the last row (stochastic policy, training-mode reward)."""
         t0 = time.time()
-        if eval_every is None:
-            eval_every = 0 if self.env.name.startswith('atsc') else 1
+        if eval_every is None:      # rows per training episode (env.T / n_step batches of log_every each, at least every row)
+            eval_every = 0 if self.env.name.startswith('atsc') else max(1, self.env.T // (self.n_step * log_every))
         total = self.global_counter.total_step
         if total < log_every * self.n_step:
             logging.warning('total_step %d < log_every x n_step = %d lock-steps: only the final row will be logged'
                             % (total, log_every * self.n_step))
         rows_done = 0
+        last_eval = [float('nan'), float('nan'), 0]
 
-        def log_row():
+        def log_row(final=False):
             st = self.stats()
             step = self.global_counter.cur_step
             row = {'agent': self.env.agent, 'step': step, 'test_id': -1, 'avg_reward': st['avg_reward'],
                    'std_reward': st['std_reward'], 'train_avg_reward': st['avg_reward'],
                    'train_std_reward': st['std_reward'], 'episodes': st['episodes'], 'collisions': st['collisions'],
-                   'env_steps': step * self.E * self.world_size * self.N}
-            if eval_every and rows_done % eval_every == 0:
-                m, s, c = self.evaluate()
-                row.update(avg_reward=m, std_reward=s, test_collisions=c)
+                   'env_steps': step * self.E * self.world_size * self.N, 'wall_s': time.time() - t0}
+            if eval_every:
+                ran = final or rows_done % eval_every == eval_every - 1
+                if ran:
+                    last_eval[:] = self.evaluate()
+                row.update(avg_reward=last_eval[0], std_reward=last_eval[1], test_collisions=last_eval[2], evaluated=int(ran))
             self.data.append(row)
             if self.rank == 0:
                 logging.info('Training: lock-step %d, batches %d, %.0f env-steps/s, episodes %d, train r %.2f, '
@@ -506,7 +546,7 @@ class BatchedTrainer:
             if self.n_batches % log_every == 0:
                 log_row()
                 rows_done += 1
-        if self.n_batches % log_every != 0:
-            log_row()                                     # final (partial) row: never leave train_reward.csv empty
+        if self.n_batches % log_every != 0 or (eval_every and self.data and not self.data[-1].get('evaluated')):
+            log_row(final=True)                           # final row: never leave train_reward.csv empty / without a test
         if self.output_path is not None and self.rank == 0:
             pd.DataFrame(self.data).to_csv(self.output_path + 'train_reward.csv')

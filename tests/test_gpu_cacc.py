@@ -206,3 +206,52 @@ def test_compact_observation_is_the_own_feature_block(E):
         act = torch.randint(0, 4, (E, 8), generator=g, dtype=torch.uint8).cuda()
         (oa, ra, da, ga), (ob, rb, db, gb) = a.step(act, auto_reset=True), b.step(act, auto_reset=True)
         assert torch.equal(oa[:, :, :5], ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(a.h, b.h)
+
+
+@pytest.mark.parametrize('scenario,E,with_fp', [('catchup', 4096, True), ('slowdown', 1000, True), ('catchup', 77, False)])
+def test_step_encode_vs_oracle(scenario, E, with_fp):
+    """nmarl_cacc_step_encode (the batched rollout's lock-step tail: env step AND the next lock-step's input encoders in one
+    launch) against the oracles directly: the step part vs the fp32 restatement of cacc_env.py:191-242 (oracle/cacc_ref.py),
+    the encoded LSTM input vs relu([x_i | x_nbr] W_ob + b_ob) | relu([p_nbr] W_fp + b_fp) (policies.py:176-181) formed in
+    float64 by oracle/ops_ref.py from the ORACLE's observation -- not through the two-launch form.  E = 4096: the bench size;
+    1000 / 77: ragged last blocks (8 replicas per block)."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    rng = np.random.RandomState(E + 7)
+    env = make_env(E, scenario, agent='ia2c_fp')
+    assert env.set_compact_obs(True)
+    ref = oracle_for(env)
+    U = rng.rand(E).astype(np.float32)
+    ref.reset(U)
+    env.reset(u0=torch.from_numpy(U).cuda())
+    g = torch.Generator().manual_seed(E)
+    N, H = 8, 64
+    w_ob, b_ob = torch.randn(N, 15, H, generator=g) * 0.4, torch.randn(N, H, generator=g) * 0.2
+    w_fp, b_fp = torch.randn(N, 8, H, generator=g) * 0.4, torch.randn(N, H, generator=g) * 0.2
+    nbr_idx, _ = ops.neighbor_table(env.neighbor_mask, 'cuda')
+    nbr_self = torch.cat([torch.arange(N, dtype=torch.int32).view(-1, 1), nbr_idx.cpu()], dim=1)
+    out = torch.full((N, E, 2 * H if with_fp else H), 7.0, device='cuda')
+    for k in range(4):
+        acts = rng.randint(0, 4, size=(E, 8)).astype(np.uint8)
+        fp = torch.softmax(torch.randn(N, E, 4, generator=g), dim=-1)
+        spec = dict(w_ob=w_ob.cuda(), b_ob=b_ob.cuda(), nbr_idx=nbr_idx, out=out, act=ops.BIAS_RELU)
+        if with_fp:
+            spec.update(w_fp=w_fp.cuda(), b_fp=b_fp.cuda(), fp=fp.cuda())
+        obs, r, d, gr = env.step(torch.from_numpy(acts).cuda(), encode=spec)
+        ro, rr, rd, rg = ref.step(acts)
+        ok = np.abs(ref.h.min(axis=1) - 1.0) > 1e-4           # fp32 flip zone of the collision test (SURVEY 8c)
+        assert ok.mean() > 0.99
+        tol = dict(rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(env.h.cpu().numpy()[ok], ref.h[ok], **tol)
+        np.testing.assert_allclose(env.v.cpu().numpy()[ok], ref.v[ok], **tol)
+        np.testing.assert_allclose(gr.cpu().numpy()[ok], rg[ok], rtol=1e-5, atol=1e-3)
+        assert np.array_equal(d.cpu().numpy()[ok].astype(bool), rd[ok])
+        np.testing.assert_allclose(obs.cpu().numpy()[ok], np.asarray(ro, dtype=np.float32)[ok], rtol=1e-5, atol=2e-5)
+        # encoders, from the oracle's own observation [E,8,5] (agent-major for the restatement)
+        xo = torch.from_numpy(np.asarray(ro, dtype=np.float64)).transpose(0, 1).contiguous()          # [N,E,5]
+        parts = [(xo, w_ob.double(), b_ob.double(), nbr_self)]
+        if with_fp:
+            parts.append((fp.double(), w_fp.double(), b_fp.double(), nbr_idx.cpu()))
+        enc_r = ops_ref.fc_fwd_multi(parts, ops_ref.BIAS_RELU)
+        okt = torch.from_numpy(ok)
+        torch.testing.assert_close(out.cpu().double()[:, okt], enc_r[:, okt], rtol=2e-5, atol=2e-5)

@@ -500,7 +500,9 @@ def cpu_baseline(cfg_path, n_batches):
             env = env_w
         except Exception as ex:
             out['workload_matched'] = {'error': repr(ex)}
-    ref = os.path.join(ROOT, 'profiles', 'r02_cpu_env_reference.json')
+    import glob
+    refs = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_cpu_env_reference.json')))      # the latest round's
+    ref = refs[-1] if refs else ''
     if os.path.exists(ref):
         d = json.load(open(ref))
         key = '%s_%s' % (env.agent, env.name)

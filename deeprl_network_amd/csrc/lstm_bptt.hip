@@ -327,14 +327,20 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
     float keepA = 1.0f - (a.done + (int64_t)(T - 1) * a.E)[lor];
     __syncthreads();                                 // image visible
 
-#define NMARL_SEQ_KSTEP(bv, s)                                                             \
+    // one k-step = image row (s, q) of the 4 output tiles (one ds_read_b128) x the lane's dz value: 4 MFMAs.  Reads run two k-steps
+    // ahead of their MFMAs through two register sets (left alone the compiler reads each row right before its use and every
+    // k-step waits out the LDS latency; same scheme as lstm_bptt_coupled_kernel)
+#define NMARL_SEQ_BL(P, s) P = *reinterpret_cast<const float4*>(abase + (s) * 64 * 4);
+#define NMARL_SEQ_MF(bv, P)                                                                \
     {                                                                                      \
-        const float4 w_ = *reinterpret_cast<const float4*>(abase + (s) * 64 * 4);          \
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.x, bv, acc[0], 0, 0, 0);          \
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.y, bv, acc[1], 0, 0, 0);          \
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.z, bv, acc[2], 0, 0, 0);          \
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_.w, bv, acc[3], 0, 0, 0);          \
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.x, bv, acc[0], 0, 0, 0);           \
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.y, bv, acc[1], 0, 0, 0);           \
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.z, bv, acc[2], 0, 0, 0);           \
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.w, bv, acc[3], 0, 0, 0);           \
     }
+#define NMARL_SEQ_KS(bv, P, s2)                                                            \
+    NMARL_SEQ_MF(bv, P) __builtin_amdgcn_sched_barrier(0);                                 \
+    NMARL_SEQ_BL(P, s2) __builtin_amdgcn_sched_barrier(0);
 #define NMARL_SEQ_CELLB(U, j, k, i_)                                                       \
     {                                                                                      \
         const float cpk = U.cp.k * keepA;                                                  \
@@ -365,14 +371,17 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         bstore4(rz, lo4 + 64 * (j) + 4 * H, df);                                           \
         bstore4(rz, lo4 + 64 * (j) + 8 * H, dO);                                           \
         bstore4(rz, lo4 + 64 * (j) + 12 * H, du);                                          \
-        NMARL_SEQ_KSTEP(di.x, (j) * 16 + 0) NMARL_SEQ_KSTEP(di.y, (j) * 16 + 1)            \
-        NMARL_SEQ_KSTEP(di.z, (j) * 16 + 2) NMARL_SEQ_KSTEP(di.w, (j) * 16 + 3)            \
-        NMARL_SEQ_KSTEP(df.x, (j) * 16 + 4) NMARL_SEQ_KSTEP(df.y, (j) * 16 + 5)            \
-        NMARL_SEQ_KSTEP(df.z, (j) * 16 + 6) NMARL_SEQ_KSTEP(df.w, (j) * 16 + 7)            \
-        NMARL_SEQ_KSTEP(dO.x, (j) * 16 + 8) NMARL_SEQ_KSTEP(dO.y, (j) * 16 + 9)            \
-        NMARL_SEQ_KSTEP(dO.z, (j) * 16 + 10) NMARL_SEQ_KSTEP(dO.w, (j) * 16 + 11)          \
-        NMARL_SEQ_KSTEP(du.x, (j) * 16 + 12) NMARL_SEQ_KSTEP(du.y, (j) * 16 + 13)          \
-        NMARL_SEQ_KSTEP(du.z, (j) * 16 + 14) NMARL_SEQ_KSTEP(du.w, (j) * 16 + 15)          \
+        float4 pa, pb;                                                                     \
+        NMARL_SEQ_BL(pa, (j) * 16 + 0) NMARL_SEQ_BL(pb, (j) * 16 + 1) __builtin_amdgcn_sched_barrier(0); \
+        NMARL_SEQ_KS(di.x, pa, (j) * 16 + 2) NMARL_SEQ_KS(di.y, pb, (j) * 16 + 3)          \
+        NMARL_SEQ_KS(di.z, pa, (j) * 16 + 4) NMARL_SEQ_KS(di.w, pb, (j) * 16 + 5)          \
+        NMARL_SEQ_KS(df.x, pa, (j) * 16 + 6) NMARL_SEQ_KS(df.y, pb, (j) * 16 + 7)          \
+        NMARL_SEQ_KS(df.z, pa, (j) * 16 + 8) NMARL_SEQ_KS(df.w, pb, (j) * 16 + 9)          \
+        NMARL_SEQ_KS(dO.x, pa, (j) * 16 + 10) NMARL_SEQ_KS(dO.y, pb, (j) * 16 + 11)        \
+        NMARL_SEQ_KS(dO.z, pa, (j) * 16 + 12) NMARL_SEQ_KS(dO.w, pb, (j) * 16 + 13)        \
+        NMARL_SEQ_KS(du.x, pa, (j) * 16 + 14) NMARL_SEQ_KS(du.y, pb, (j) * 16 + 15)        \
+        NMARL_SEQ_MF(du.z, pa) __builtin_amdgcn_sched_barrier(0);                          \
+        NMARL_SEQ_MF(du.w, pb)                                                             \
     }
     for (int t = T - 1; t >= 0; --t) {
         const int tp = t > 0 ? t - 1 : 0;            // clamped: the last prefetch re-reads step 0 (unconditional loads)
@@ -415,7 +424,9 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         keepA = keep_next;
     }
 #undef NMARL_SEQ_LOAD2
-#undef NMARL_SEQ_KSTEP
+#undef NMARL_SEQ_BL
+#undef NMARL_SEQ_MF
+#undef NMARL_SEQ_KS
 #undef NMARL_SEQ_CELLB
 #undef NMARL_SEQ_DB1
 #undef NMARL_SEQ_CELL

@@ -453,40 +453,53 @@ class BatchedTrainer:
         return float(per_ep.mean()), float(per_ep.std()), int((steps < ev['env'].T).sum().item())
 
     def _build_eval(self, n_envs, seed):
+        """The test episode as ~4 launches per lock-step: encoder, ONE fused kernel for LSTM step + actor head + arg max (the
+        rollout's policy-step kernel in SAMPLE_ARGMAX mode; its policy output IS the next fingerprint), env step writing reward /
+        done straight into per-step slots.  The episode statistics (alive mask, sums, action histogram) are formed from those
+        slots after the last step instead of ~10 elementwise launches per step."""
         from .envs import make_batch_env
         dev, model, N = self.device, self.model, self.N
         env = make_batch_env(self.env.config, num_envs=n_envs, device=dev, seed=seed, env_id_base=10 ** 9)
         env.train_mode = False
+        T, A, p = env.T, model.n_a, model.policy
         f64 = dict(dtype=torch.float64, device=dev)
-        h, c = (torch.zeros(N, n_envs, model.n_lstm, device=dev) for _ in range(2))
-        fp = model.fp_uniform.expand(N, n_envs, model.n_a).clone()       # uniform over each agent's own actions
-        done = torch.ones(n_envs, device=dev)
-        act = torch.zeros(n_envs, N, dtype=torch.uint8, device=dev)
-        total, alive, steps = torch.zeros(n_envs, **f64), torch.ones(n_envs, **f64), torch.zeros(n_envs, **f64)
-        hist = torch.zeros(model.n_a, **f64)                             # greedy actions taken, by index
-        a_ids = torch.arange(model.n_a, device=dev).view(1, 1, -1)
+        hs = [torch.zeros(N, n_envs, model.n_lstm, device=dev) for _ in range(2)]      # ping-pong: a coupled net's message term
+        cs = [torch.zeros(N, n_envs, model.n_lstm, device=dev) for _ in range(2)]      # reads the others' h while h' is written
+        fps = [model.fp_uniform.expand(N, n_envs, A).clone() for _ in range(2)]
+        done1, done0 = torch.ones(n_envs, device=dev), torch.zeros(n_envs, device=dev)
+        acts = torch.zeros(T, n_envs, N, dtype=torch.uint8, device=dev)
+        G = torch.zeros(T, n_envs, device=dev)
+        D = torch.zeros(T, n_envs, dtype=torch.uint8, device=dev)
+        rew = torch.zeros_like(env.reward)
+        total, steps, hist = torch.zeros(n_envs, **f64), torch.zeros(n_envs, **f64), torch.zeros(A, **f64)
+        a_ids = torch.arange(A, device=dev).view(1, 1, 1, -1)
+        fused = p.fused_heads
 
         def episode():
             env.episode.zero_()                       # the same test episode every time
             env.reset()
-            for t_ in (h, c, total, steps, hist):
-                t_.zero_()
-            fp.copy_(model.fp_uniform.expand_as(fp))
-            alive.fill_(1.0)
-            done.fill_(1.0)
-            model.policy.refresh_wimage()
-            for _ in range(env.T):
-                model.policy.step(model.policy.encode(env.obs, fp), h, c, done, h, c)
-                with torch.no_grad():
-                    pi = model.policy.pi(h)
-                ops.sample_actions(pi, act, ops.SAMPLE_ARGMAX)
-                fp.copy_(pi)
-                hist.add_(((act.unsqueeze(-1) == a_ids).to(torch.float64) * alive.view(-1, 1, 1)).sum(dim=(0, 1)))
-                _, _, d, g = env.step(act)
-                total.add_(g.double() * alive)
-                steps.add_(alive)
-                alive.mul_(1.0 - d.double())
-                done.zero_()
+            hs[0].zero_()
+            cs[0].zero_()
+            fps[0].copy_(model.fp_uniform.expand_as(fps[0]))
+            p.refresh_wimage()
+            for t in range(T):
+                a, b = t & 1, (t + 1) & 1
+                enc = p.encode(env.obs, fps[a])
+                if fused:
+                    p.step_policy(enc, hs[a], cs[a], done1 if t == 0 else done0, hs[b], cs[b], fps[b], acts[t], t > 0,
+                                  mode=ops.SAMPLE_ARGMAX)
+                else:
+                    p.step(enc, hs[a], cs[a], done1 if t == 0 else done0, hs[b], cs[b], t > 0)
+                    with torch.no_grad():
+                        fps[b].copy_(p.pi(hs[b]))
+                    ops.sample_actions(fps[b], acts[t], ops.SAMPLE_ARGMAX)
+                env.step(acts[t], reward_out=rew, done_out=D[t], greward_out=G[t])
+            # alive[t] = no `done` before step t; an episode's statistics stop with its first done
+            dd = D.to(torch.float64)
+            alive = torch.cat([torch.ones(1, n_envs, **f64), torch.cumprod(1.0 - dd, dim=0)[:-1]], dim=0)
+            total.copy_((G.double() * alive).sum(dim=0))
+            steps.copy_(alive.sum(dim=0))
+            hist.copy_(((acts.unsqueeze(-1) == a_ids).to(torch.float64) * alive.view(T, n_envs, 1, 1)).sum(dim=(0, 1, 2)))
 
         graph = None
         if self.use_graph:
@@ -504,14 +517,15 @@ class BatchedTrainer:
     def run(self, log_every=10, eval_every=None):
         """Train until the counter says stop (`total_step` lock-steps per replica); one row per `log_every` batches.
         Row: `avg_reward` / `std_reward` = the deterministic TEST episodes (argmax policy, raw reward) for CACC, like
-        the reference's train_reward.csv (utils.py:246-251), evaluated every `eval_every` rows -- default: once per training
-        episode of batches, as the reference tests once per training episode (utils.py:246-251); never for ATSC, whose logged
+        the reference's train_reward.csv (utils.py:246-251), evaluated every `eval_every` rows -- default: every env.T / n_step
+        rows (the reference tests once per training episode of ONE replica, utils.py:246-251; here a row already spans log_every
+        batches of E replicas) and at the last row; never for ATSC, whose logged
         reward is the training episode's (utils.py:243-245) -- and carried forward on the rows in between (NaN before the first
         evaluation; `evaluated` marks the rows that ran one); `train_avg_reward` etc. = statistics of the training episodes
         finished since the last row (stochastic policy, training-mode reward)."""
         t0 = time.time()
-        if eval_every is None:      # rows per training episode (env.T / n_step batches of log_every each, at least every row)
-            eval_every = 0 if self.env.name.startswith('atsc') else max(1, self.env.T // (self.n_step * log_every))
+        if eval_every is None:      # one test per env.T / n_step rows (10 for CACC: every 100 batches at the default log_every)
+            eval_every = 0 if self.env.name.startswith('atsc') else max(1, self.env.T // self.n_step)
         total = self.global_counter.total_step
         if total < log_every * self.n_step:
             logging.warning('total_step %d < log_every x n_step = %d lock-steps: only the final row will be logged'

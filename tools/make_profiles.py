@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
 src = os.path.join(ROOT, sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -60,13 +60,29 @@ with open(os.path.join(dst, '%s_other_configs.md' % tag), 'w') as f:
             'over rollout + update.  Round-1 numbers from profiles/r01r_other_configs.md.\n\n' % tag[1:].lstrip('0'))
     f.write('| config | agents x replicas | round 1 M/s | this round M/s | ms / batch | LSTM lock-step kernel (roofline.kernel) | us / launch | frac of fp32 MFMA peak |\n'
             '|---|---|---:|---:|---:|---|---:|---:|\n')
+    d0 = last_json(os.path.join(src, '%s_bench_default.json' % tag))
+    inline = {}                                   # round 4: bench.py's default line carries these three itself (`other_configs`)
+    for o in d0.get('other_configs', []):
+        for name in ('ma2c_nc_slowdown', 'ma2c_cnet_grid', 'ma2c_nc_catchup'):
+            if ('config_%s.ini' % name) in o.get('workload', ''):
+                inline[name] = o
     for name in ('default', 'ma2c_nc_slowdown', 'ma2c_cnet_grid', 'ma2c_nc_catchup', 'ma2c_cnet_catchup', 'ma2c_dial_catchup', 'ia2c_cu_catchup'):
         p = os.path.join(src, '%s_bench_%s.json' % (tag, name))
+        na = 25 if 'grid' in name else 8
+        if name in inline:
+            o = inline[name]
+            r = o.get('roofline', {})
+            f.write('| %s | %d x %d | %s | **%.1f** | %.2f | %s | %.1f | %.2f |\n' % (
+                LABEL[name] + ' [default line, other_configs]', na, 1024 if 'grid' in name else 4096, ROUND1.get(name, ''), o['value'] / 1e6,
+                o['ms_per_step'], r.get('kernel', '').split(' (')[0], r.get('us_per_launch', 0.0), r.get('frac', 0.0)))
+            rb = o.get('roofline_bptt', {})
+            if 'frac' in rb:
+                f.write('| | | | | | %s | %.1f | %.3f of HBM |\n' % (rb['kernel'].split(' (')[0], rb['us_per_launch'], rb['frac']))
+            continue
         if not os.path.exists(p):
             continue
         d = last_json(p)
         r = d.get('roofline', {})
-        na = 25 if 'grid' in name else 8
         f.write('| %s | %d x %d | %s | **%.1f** | %.2f | %s | %.1f | %.2f |\n' % (
             LABEL[name], na, d['config']['replicas_per_gpu'], ROUND1.get(name, ''), d['value'] / 1e6, d['ms_per_step'],
             r.get('kernel', '').split(' (')[0], r.get('us_per_launch', 0.0), r.get('frac', 0.0)))
@@ -86,7 +102,9 @@ with open(os.path.join(dst, '%s_other_configs.md' % tag), 'w') as f:
 # ---- verbatim copies
 for a, b in (('%s_pmc_traffic.json', '%s_pmc_traffic.json'), ('%s_pmc_traffic.md', '%s_pmc_traffic.md'), ('%s_pmc_lstm.md', '%s_pmc_lstm_stalls.md'),
              ('%s_time_fused.log', '%s_time_fused.txt'), ('%s_env_microbench.log', '%s_env_microbench.txt'),
-             ('%s_step_timeline.txt', '%s_step_timeline.txt')):
+             ('%s_step_timeline.txt', '%s_step_timeline.txt'), ('%s_bptt_timeline.txt', '%s_bptt_timeline.txt'),
+             ('%s_mfma_valu_overlap.txt', '%s_mfma_valu_overlap.txt'), ('%s_train_speed.txt', '%s_train_speed.txt'),
+             ('%s_learn_grid.json', '%s_learn_grid.json')):
     if os.path.exists(os.path.join(src, a % tag)):
         shutil.copy(os.path.join(src, a % tag), os.path.join(dst, b % tag))
 print('profiles/%s_* written' % tag)

@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-3 measurement pass on one MI355X: default bench line, rocprofv3 kernel traces of the three BASELINE configs,
+# Measurement pass on one MI355X (round 4): default bench line, rocprofv3 kernel traces of the three BASELINE configs,
 # the other configs, PMC traffic passes (separate FETCH / WRITE runs).  Results under gpurun_out/ (copy into profiles/).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r03}
+TAG=${1:-r04}
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid
-for c in ma2c_nc_slowdown ma2c_cnet_grid ma2c_nc_catchup ma2c_dial_catchup ma2c_cnet_catchup ia2c_cu_catchup; do
+for c in ma2c_dial_catchup ma2c_cnet_catchup ia2c_cu_catchup; do      # (NeurComm slow-down / catch-up and the CommNet grid: `other_configs` of the default line)
   python bench.py --no-cpu-baseline --steps 10 --config config/config_$c.ini > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err
 done
 mkdir -p /tmp/pmc
@@ -14,6 +14,12 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o pmc_FETCH_SIZE --output
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc -o pmc_WRITE_SIZE --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_write.log 2>&1
 python tools/pmc_summary.py /tmp/pmc $TAG gpurun_out > gpurun_out/${TAG}_pmc_summary.log 2>&1
 # shader-clock phase timelines of the lock-step kernels (instrumentation build of csrc/lstm_mfma.hip, tools/step_timeline.py)
+python tools/microbench/mfma_valu_overlap.py > gpurun_out/${TAG}_mfma_valu_overlap.txt 2>&1
+python tools/train_speed.py > gpurun_out/${TAG}_train_speed.txt 2>&1
+python tools/train_speed.py config/config_ma2c_nc_slowdown.ini 200 >> gpurun_out/${TAG}_train_speed.txt 2>&1
+python tools/bptt_timeline.py --build > /dev/null 2>&1
+( echo "## python tools/bptt_timeline.py nc  (NeurComm: 8 x 4096 rows, T = 60)"; python tools/bptt_timeline.py nc 2>&1 | grep -v amdgpu.ids; echo
+  echo "## python tools/bptt_timeline.py grid  (CommNet grid: 25 x 1024 rows, T = 120)"; python tools/bptt_timeline.py grid 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_bptt_timeline.txt
 python tools/step_timeline.py --build > /dev/null 2>&1
 ( echo "## python tools/step_timeline.py 4  (NeurComm shape: 8 x 4096 rows, KX = 192, one-launch policy + value step)"
   python tools/step_timeline.py 4 2>&1 | grep -v amdgpu.ids; echo

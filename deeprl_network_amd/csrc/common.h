@@ -96,3 +96,16 @@ NMARL_INTERNAL int nmarl_handoff_cus();
 NMARL_INTERNAL bool nmarl_handoff_take_fault();
 constexpr unsigned NMARL_HANDOFF_MAX_SPINS = 1u << 20;      // ~0.1 s of s_sleep polling before a wave gives up
 constexpr unsigned NMARL_HANDOFF_FAULT_SPINS = 1u << 12;    // the injected fault: give up quickly
+
+// XCD-aware block -> (agent, row block).  Blocks are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8:
+// observed, used for speed only -- MI355X_MICROARCH.md), each XCD has its own L2, and every block of an agent streams that
+// agent's weight image(s).  Work item w = agent * blocks_per_agent + row block; XCD x is handed a CONTIGUOUS range of work
+// items, so an agent's blocks sit on one XCD (two at a range boundary) and its image is fetched into one L2 instead of eight.
+// N = 8 agents: identical to the plain b % N mapping.  Bijection for every grid size.
+__device__ __forceinline__ void nmarl_xcd_work(const unsigned b, const unsigned grid, const int blocks_per_agent, int& agent,
+                                               int& row_block) {
+    const unsigned x = b & 7u, j = b >> 3, q = grid >> 3, r = grid & 7u;
+    const unsigned w = x * q + (x < r ? x : r) + j;
+    agent = (int)(w / (unsigned)blocks_per_agent);
+    row_block = (int)(w - (unsigned)agent * (unsigned)blocks_per_agent);
+}

@@ -266,6 +266,8 @@ __device__ __forceinline__ float dpp_xor2(float v) {  // value of lane ^ 2 (quad
 
 __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // (plain round-robin over the agents: the XCD-aware grouping of common.h, which pays in the lock-step kernel, made this one
+    // 14 % slower on the grid -- an XCD then hosts only interior or only border agents and the ring traffic is uneven)
     const int n = blockIdx.x % a.N;
     const int blk = blockIdx.x / a.N;
     const int64_t row_blk = (int64_t)blk * ROWS_B;
@@ -554,6 +556,8 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int IMG8 = G4 * 16 * 8;                // [Wxm; Wh]^T image (NT = 8)
     constexpr int KMO = NTM * 16;                    // floats per message row
+    // (plain round-robin over the agents: the XCD-aware grouping of common.h, which pays in the lock-step kernel, made this one
+    // 14 % slower on the grid -- an XCD then hosts only interior or only border agents and the ring traffic is uneven)
     const int n = blockIdx.x % a.N;
     const int blk = blockIdx.x / a.N;
     const int64_t row_blk = (int64_t)blk * ROWS_B;

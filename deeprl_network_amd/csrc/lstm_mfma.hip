@@ -562,8 +562,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedArgs& a = xa.f;
     NMARL_STAMP(0)
-    const int n = blockIdx.x % xa.N;
-    const int64_t row_blk = (int64_t)(blockIdx.x / xa.N) * ROWS_B;
+    int n, blk_u;
+    nmarl_xcd_work(blockIdx.x, gridDim.x, a.blocks_per_agent, n, blk_u);          // an agent's blocks share an XCD (its L2 holds the image)
+    const int64_t row_blk = (int64_t)blk_u * ROWS_B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = row_blk + wave * R16;
     const int c = lane & 15, grp = lane >> 4;
@@ -1061,7 +1062,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     if (HEAD == 4) {
         // ---- publish: this wave's 16 rows of h' are out (write-through stores drained), one flag per (agent, block, wave)
         gu32* flags = (gu32*)(xa.sync + 16);
-        const int bpa = a.blocks_per_agent, blk = (int)(blockIdx.x / xa.N);
+        const int bpa = a.blocks_per_agent, blk = blk_u;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0 && !(xa.fault && blockIdx.x == 0))
             __hip_atomic_store(flags + ((n * bpa + blk) * WAVES2 + wave), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         if (HEAD == 4) {
             // ---- the message columns of the re-step: from the neighbours' NEW h, published by the same wave of their blocks
             gu32* flags = (gu32*)(xa.sync + 16);
-            const int bpa = a.blocks_per_agent, blk = (int)(blockIdx.x / xa.N);
+            const int bpa = a.blocks_per_agent, blk = blk_u;
             bool give_up = false;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

@@ -84,14 +84,15 @@ __device__ __forceinline__ float demand_rate(int group, int sec, float peak1, fl
     return peak2 * (group == 2 ? 0.6f : 1.0f) * c_ratio2[piece - 3];
 }
 
-struct Lds {           // per replica
-    float q[NN * NLANE];
-    float tr[NN * NLANE];
+constexpr int NQ = NN * NLANE;      // 150 floats of q (and of transit) per replica
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Lds {           // per replica (q / transit live in the block-wide staging arrays: 8 replicas = 4800 contiguous bytes)
     float D[NN * NL];
     float space[NN * 4];
     float scale[NN * 4];
     float inflow[NN * 4];
-    float wave[NN * NL];          // offset 3600 B: 16-byte aligned (float4 reads of the compact emit)
+    float wave[NN * NL];          // offset 2400 B: 16-byte aligned (float4 reads of the compact emit)
 };
 static_assert(offsetof(Lds, wave) % 16 == 0 && sizeof(Lds) % 16 == 0, "Lds::wave must be 16-byte aligned in every array slot");
 
@@ -119,12 +120,8 @@ __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ 
         const float4* src = reinterpret_cast<const float4*>(s.wave);
         for (int v = l32; v < NN * NL / 4; v += 32) {
             const float4 val = src[v];
-            if (NT) {
-                __builtin_nontemporal_store(val.x, &dst[v].x); __builtin_nontemporal_store(val.y, &dst[v].y);
-                __builtin_nontemporal_store(val.z, &dst[v].z); __builtin_nontemporal_store(val.w, &dst[v].w);
-            } else {
-                dst[v] = val;
-            }
+            if (NT) __builtin_nontemporal_store(f32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<f32x4*>(dst) + v);
+            else dst[v] = val;
         }
         return;
     }
@@ -139,12 +136,8 @@ __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ 
             const float* p = s.wave + src * NL + f;
             val = float4{p[0], p[1], p[2], p[3]};
         }
-        if (NT) {
-            __builtin_nontemporal_store(val.x, &dst[v].x); __builtin_nontemporal_store(val.y, &dst[v].y);
-            __builtin_nontemporal_store(val.z, &dst[v].z); __builtin_nontemporal_store(val.w, &dst[v].w);
-        } else {
-            dst[v] = val;
-        }
+        if (NT) __builtin_nontemporal_store(f32x4{val.x, val.y, val.z, val.w}, reinterpret_cast<f32x4*>(dst) + v);
+        else dst[v] = val;
     }
 }
 
@@ -158,20 +151,36 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
     float* __restrict__ greward, const int auto_reset, const uint64_t seed, const int64_t env_id_base,
     int32_t* __restrict__ episode) {
     __shared__ __attribute__((aligned(16))) Lds lds[8];
+    // state of the block's 8 replicas: 8 x 150 floats of q and of transit are CONTIGUOUS in memory (replica-major) and 16-byte
+    // aligned (8 x 600 B per block step), so the whole block moves them with 16-byte accesses (300 float4 each way per array;
+    // the 4-byte per-replica loops of rounds 1-3 were the kernel's issue limit in the HBM regime)
+    __shared__ __attribute__((aligned(16))) float blk_q[8 * NQ], blk_tr[8 * NQ];
     const int l32 = threadIdx.x & 31;
     const int sub = threadIdx.x >> 5;                       // replica slot in the block (0..7)
     Lds& s = lds[sub];
+    float* const sq = blk_q + sub * NQ;
+    float* const str = blk_tr + sub * NQ;
     const int64_t stride = (int64_t)gridDim.x * 8;
     for (int64_t e0 = (int64_t)blockIdx.x * 8; e0 < E; e0 += stride) {
         const int64_t e = e0 + sub;
         const bool live = e < E;
         const int64_t ec = live ? e : E - 1;
-        // ---- A. coalesced load of the replica's state into LDS
-        const float* qg = qs + ec * NN * NLANE;
-        const float* tg = trs + ec * NN * NLANE;
-        for (int i = l32; i < NN * NLANE; i += 32) { s.q[i] = qg[i]; s.tr[i] = tg[i]; }
+        // ---- A. coalesced load of the block's state into LDS
+        const bool full = e0 + 8 <= E;                      // (uniform) the last, partial group of replicas: 4-byte accesses
+        if (full) {
+            const float4* qg4 = reinterpret_cast<const float4*>(qs + e0 * NQ);
+            const float4* tg4 = reinterpret_cast<const float4*>(trs + e0 * NQ);
+            for (int i = threadIdx.x; i < 8 * NQ / 4; i += 256) {
+                reinterpret_cast<float4*>(blk_q)[i] = qg4[i];
+                reinterpret_cast<float4*>(blk_tr)[i] = tg4[i];
+            }
+        } else {
+            const float* qg = qs + ec * NQ;
+            const float* tg = trs + ec * NQ;
+            for (int i = l32; i < NQ; i += 32) { sq[i] = qg[i]; str[i] = tg[i]; }
+        }
         const int t = ts[ec];
-        half_barrier();
+        __syncthreads();
         const int n = l32;
         const bool node = n < NN;
         const int row = n / SIDE, col = n - row * SIDE;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
             pa = prev[ec * NN + n];
             a = a > 4 ? 4 : a;
 #pragma unroll
-            for (int l = 0; l < NLANE; ++l) { q[l] = s.q[n * NLANE + l]; tr[l] = s.tr[n * NLANE + l]; }
+            for (int l = 0; l < NLANE; ++l) { q[l] = sq[n * NLANE + l]; tr[l] = str[n * NLANE + l]; }
             // ---- B. desired link flows and receiving space
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
@@ -264,17 +273,24 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
                 a = 0;                            // _reset_state: prev_action = 0 (atsc_env.py:509-513)
             }
 #pragma unroll
-            for (int l = 0; l < NLANE; ++l) { s.q[n * NLANE + l] = q[l]; s.tr[n * NLANE + l] = tr[l]; }
+            for (int l = 0; l < NLANE; ++l) { sq[n * NLANE + l] = q[l]; str[n * NLANE + l] = tr[l]; }
         }
-        half_barrier();
+        __syncthreads();
         // ---- E. coalesced write-back
-        if (live) {
-            float* qo = qs + e * NN * NLANE;
-            float* to = trs + e * NN * NLANE;
-            for (int i = l32; i < NN * NLANE; i += 32) {
-                if (NT) { __builtin_nontemporal_store(s.q[i], &qo[i]); __builtin_nontemporal_store(s.tr[i], &to[i]); }
-                else { qo[i] = s.q[i]; to[i] = s.tr[i]; }
+        if (full) {
+            f32x4* qo4 = reinterpret_cast<f32x4*>(qs + e0 * NQ);
+            f32x4* to4 = reinterpret_cast<f32x4*>(trs + e0 * NQ);
+            for (int i = threadIdx.x; i < 8 * NQ / 4; i += 256) {
+                const f32x4 a4 = reinterpret_cast<const f32x4*>(blk_q)[i], b4 = reinterpret_cast<const f32x4*>(blk_tr)[i];
+                if (NT) { __builtin_nontemporal_store(a4, qo4 + i); __builtin_nontemporal_store(b4, to4 + i); }
+                else { qo4[i] = a4; to4[i] = b4; }
             }
+        } else if (live) {
+            float* qo = qs + e * NQ;
+            float* to = trs + e * NQ;
+            for (int i = l32; i < NQ; i += 32) { qo[i] = sq[i]; to[i] = str[i]; }
+        }
+        if (live) {
             if (node) {
                 prev[e * NN + n] = (uint8_t)a;
                 if (p.per_agent_reward) reward[e * NN + n] = r_node;
@@ -295,7 +311,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
             if (rst && l32 == 4) episode[e] = episode[e] + 1;
             emit_obs_slab<NT, COMPACT>(s, obs + e * NN * (COMPACT ? NL : OBSW), l32);
         }
-        half_barrier();
+        __syncthreads();                          // the staging arrays are refilled by the next group of replicas
     }
 }
 

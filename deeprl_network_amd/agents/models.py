@@ -471,6 +471,7 @@ class IA2C:
             self.buf_fp[0].copy_(self.buf_fp[T])
         self.t = 0
         self.cur_lr = cur_lr
+        self.policy._enc_was_saved = False       # the saved encoder outputs belonged to this batch (the next rollout sets it again)
 
     # ------------------------------------------------------------------ reference API (E = 1)
     def _obs_to_slab(self, obs):

@@ -225,6 +225,16 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_step_kernel(const BpttArgs a
 // forms it (lstm_mfma.hip / a2c.hip: cv = gf * (cp * keep) + gi * gu, four separately rounded operations under
 // -ffp-contract=off), i.e. bit-identical to the stored c_all[t + 1] whenever the saved sequences come from a forward pass.
 // That removes 16 persistent registers (the carried c_t) -- the kernel no longer spills -- and the read of c_all[T].
+#ifdef NMARL_STEP_TIMELINE      // instrumentation build (tools/bptt_timeline.py): shader-clock stamps of block 0's waves, one mid step
+__device__ unsigned long long* g_tl_b = nullptr;
+__global__ void tl_b_set_kernel(unsigned long long* p) { g_tl_b = p; }
+#define NMARL_BSTAMP(i) if (g_tl_b && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_tl_b[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime();
+#define NMARL_BSTAMP_T(i) if (t == T / 2) { NMARL_BSTAMP(i) }
+#else
+#define NMARL_BSTAMP(i)
+#define NMARL_BSTAMP_T(i)
+#endif
+
 struct BpttSeqArgs {
     const float *gates, *c_all, *done, *dh_ext, *img;
     float *dz, *db_part, *dh0, *dc0;
@@ -277,6 +287,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
     const int64_t arow_raw = row0 + c;
     const bool arow_ok = arow_raw < a.E;
     const bool odd = (c & 1) != 0, hi = (c & 2) != 0;
+    NMARL_BSTAMP(0)
     {
         const float4* g = reinterpret_cast<const float4*>(a.img + (int64_t)n * a.img_sn);
         float4* d = reinterpret_cast<float4*>(lds);
@@ -385,6 +396,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         NMARL_SEQ_MF(du.z, pa) __builtin_amdgcn_sched_barrier(0);                          \
         NMARL_SEQ_MF(du.w, pb)                                                             \
     }
+    NMARL_BSTAMP(1)
     for (int t = T - 1; t >= 0; --t) {
         const int tp = t > 0 ? t - 1 : 0;            // clamped: the last prefetch re-reads step 0 (unconditional loads)
         const float keep_next = 1.0f - (a.done + (int64_t)__builtin_amdgcn_readfirstlane(tp) * a.E)[lor];
@@ -425,6 +437,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         for (int j = 0; j < 4; ++j) dhr[j] = acc[j] * keepA;
         keepA = keep_next;
     }
+    NMARL_BSTAMP(17)
 #undef NMARL_SEQ_LOAD2
 #undef NMARL_SEQ_BL
 #undef NMARL_SEQ_MF
@@ -512,16 +525,6 @@ __global__ void lstm_bptt_wimage_kernel(const int N, const int KM, const float* 
 // reader's L2 still holds from two steps ago would be served stale (seen: rare wrong rows with a two-slot ring).  The
 // step-wise form alternates two slots (kernel boundaries make them coherent); with a symmetric neighbour relation a
 // producer's consumers are exactly the agents it waits for, so a slot is rewritten only after its readers are done.
-#ifdef NMARL_STEP_TIMELINE      // instrumentation build (tools/bptt_timeline.py): shader-clock stamps of block 0's waves, one mid step
-__device__ unsigned long long* g_tl_b = nullptr;
-__global__ void tl_b_set_kernel(unsigned long long* p) { g_tl_b = p; }
-#define NMARL_BSTAMP(i) if (g_tl_b && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_tl_b[(threadIdx.x >> 6) * 32 + (i)] = __builtin_amdgcn_s_memtime();
-#define NMARL_BSTAMP_T(i) if (t == T / 2) { NMARL_BSTAMP(i) }
-#else
-#define NMARL_BSTAMP(i)
-#define NMARL_BSTAMP_T(i)
-#endif
-
 struct CoupledArgs {
     const float *gates, *c_all, *done, *dh_ext, *img, *img_m, *mask;
     float *dz, *d1, *ring, *db_part, *dbm_part, *dhr_io, *dc_io;

@@ -868,6 +868,7 @@ _coupled_ws = {}
 
 
 COUPLED_RING_MAX_BYTES = 4 << 30     # one slot per step (one-launch form) up to this size, else two slots (step-wise)
+COUPLED_WS_KEEP = 2                  # workspaces (ring + flags + hand-over buffers) kept per process, least recently used dropped
 
 
 def _coupled_workspace(dev, N, E, K, T):
@@ -875,8 +876,12 @@ def _coupled_workspace(dev, N, E, K, T):
     one-launch form never re-reads an address, 2 if that would not fit COUPLED_RING_MAX_BYTES), flag words and the state
     hand-off buffers of nmarl_lstm_bptt_coupled -- allocated once per shape and kept (the update calls it every batch)."""
     key = (dev, N, E, K, T)
-    w = _coupled_ws.get(key)
+    w = _coupled_ws.pop(key, None)
+    if w is not None:
+        _coupled_ws[key] = w                  # most recently used last
     if w is None:
+        while len(_coupled_ws) >= COUPLED_WS_KEEP:         # at most two shapes stay pinned (a training run uses one; tests many):
+            _coupled_ws.pop(next(iter(_coupled_ws)))       # the update is launched eagerly, the allocator's stream ordering covers the reuse
         tiles = -(-E // 128)
         slots = T if T * N * E * K * 4 <= COUPLED_RING_MAX_BYTES else 2
         w = dict(ring=torch.zeros(max(slots, 2), N, E, K, dtype=F32, device=dev),

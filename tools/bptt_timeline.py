@@ -24,11 +24,32 @@ from deeprl_network_amd import _lib, ops  # noqa: E402
 from test_gpu_ops import _topology  # noqa: E402
 
 dbg = C.CDLL(SO)
-for name in ('nmarl_lstm_bptt_coupled', 'nmarl_lstm_bptt_wimage', 'nmarl_lstm_bptt_msg_wimage'):
+for name in ('nmarl_lstm_bptt_coupled', 'nmarl_lstm_bptt_wimage', 'nmarl_lstm_bptt_msg_wimage', 'nmarl_lstm_bptt_seq'):
     getattr(dbg, name).argtypes = _lib.SIGNATURES[name]
     getattr(dbg, name).restype = C.c_int
     setattr(_lib.lib, name, getattr(dbg, name))
 shape = ([a for a in sys.argv[1:] if not a.startswith('-')] or ['nc'])[0]
+if shape == 'seq':
+    # the uncoupled one-launch BPTT at the bench shape: whole-kernel cycle count -> the shader clock this box sustains for it
+    N, E, T, H = 8, 4096, 60, 64
+    G = torch.cat([torch.sigmoid(torch.randn(N, T, E, 3 * H, device='cuda')), torch.tanh(torch.randn(N, T, E, H, device='cuda'))], dim=-1)
+    Cc, D = torch.randn(N, T + 1, E, H, device='cuda') * 0.5, torch.randn(N, T, E, H, device='cuda')
+    dZ, done = torch.empty_like(G), torch.zeros(T, E, device='cuda')
+    img = ops.lstm_bptt_wimage(None, torch.randn(N, H, 4 * H, device='cuda') * 0.1)
+    tl = torch.zeros(8 * 32, dtype=torch.int64, device='cuda')
+    dbg.nmarl_timeline_set_bptt.argtypes = [C.c_void_p, C.c_void_p]
+    dbg.nmarl_timeline_set_bptt(tl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        e0.record()
+        ops.bptt_seq(G, Cc, done, D, img, dZ, want_db=False)
+        e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3
+    t = tl.cpu().view(8, 32)
+    print('seq: N %d E %d T %d, %.1f us per call (instrumented build), kernel %d cycles (block 0, wave 0) -> %.2f GHz; %d cycles per step'
+          % (N, E, T, us, int(t[0, 17] - t[0, 0]), float(t[0, 17] - t[0, 0]) / us / 1e3, int(t[0, 17] - t[0, 1]) // T))
+    sys.exit(0)
 kind, topo, N, E, T = {'nc': (ops.COUPLED_NC, 'line', 8, 4096, 60), 'grid': (ops.COUPLED_IC3, 'grid', 25, 1024, 120),
                        'ic3': (ops.COUPLED_IC3, 'line', 8, 4096, 60)}[shape]
 H = 64

@@ -19,7 +19,8 @@ python tools/train_speed.py > gpurun_out/${TAG}_train_speed.txt 2>&1
 python tools/train_speed.py config/config_ma2c_nc_slowdown.ini 200 >> gpurun_out/${TAG}_train_speed.txt 2>&1
 python tools/bptt_timeline.py --build > /dev/null 2>&1
 ( echo "## python tools/bptt_timeline.py nc  (NeurComm: 8 x 4096 rows, T = 60)"; python tools/bptt_timeline.py nc 2>&1 | grep -v amdgpu.ids; echo
-  echo "## python tools/bptt_timeline.py grid  (CommNet grid: 25 x 1024 rows, T = 120)"; python tools/bptt_timeline.py grid 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_bptt_timeline.txt
+  echo "## python tools/bptt_timeline.py grid  (CommNet grid: 25 x 1024 rows, T = 120)"; python tools/bptt_timeline.py grid 2>&1 | grep -v amdgpu.ids; echo
+  echo "## python tools/bptt_timeline.py seq  (uncoupled one-launch BPTT, 8 x 4096 rows, T = 60: the clock this box sustains)"; python tools/bptt_timeline.py seq 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_bptt_timeline.txt
 python tools/step_timeline.py --build > /dev/null 2>&1
 ( echo "## python tools/step_timeline.py 4  (NeurComm shape: 8 x 4096 rows, KX = 192, one-launch policy + value step)"
   python tools/step_timeline.py 4 2>&1 | grep -v amdgpu.ids; echo

@@ -158,9 +158,14 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
 // bl [MAXA]), so every loop runs over MAXA without a branch (padded logits are -inf -> probability exactly 0: adding
 // them to the CDF sums is exact, and cum / tot = 1 <= u never holds for u < 1): the branchy version above spent
 // ~13 k cycles per wave here.  Same arithmetic as head_epilogue<1> / nmarl_draw_action otherwise.
-__device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n, const int N, const int64_t row0,
-                                                const int lane, const float* a_tile, const float* wl, const float* bl) {
-    static_assert(MAXA == 8, "two float4 per k");
+// MA = columns actually processed: 8 (MAXA), or 4 when the net has at most 4 actions (CACC: A = 4) -- the padded columns carry
+// logit -inf -> probability exactly 0 and add exact zeros to every sum, so leaving them out changes no bit; it halves the dot
+// products, the exps, the divisions and the float64 CDF of the head (~570 -> ~300 vector instructions per wave, which only 16 of
+// the 64 lanes need but every wave pays for in full).
+template <int MA>
+__device__ __forceinline__ void head_policy_lds_n(const FusedArgs& a, const int n, const int N, const int64_t row0,
+                                                  const int lane, const float* a_tile, const float* wl, const float* bl) {
+    static_assert(MAXA == 8 && (MA == 4 || MA == 8), "one or two float4 per k");
     const nmarl_head_t& hd = a.hd;
     const int A = hd.A;
     const int rl = lane & 15, q = lane >> 4;
@@ -169,38 +174,41 @@ __device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n,
     // late inputs first: their latency hides behind the dot products
     const int64_t step = hd.step + (hd.step_dev ? *hd.step_dev : 0);
     const float uh = hd.mode == 0 ? hd.u[rowc * N + n] : 0.0f;
-    float acc[MAXA];
+    float acc[MA];
 #pragma unroll
-    for (int o = 0; o < MAXA; ++o) acc[o] = 0.0f;
+    for (int o = 0; o < MA; ++o) acc[o] = 0.0f;
 #pragma unroll 4
     for (int kk = 0; kk < 16; ++kk) {
         const int k = q * 16 + kk;
         const float hk = a_tile[rl * APITCH + k];
-        const float4 w0 = *reinterpret_cast<const float4*>(wl + k * MAXA), w1 = *reinterpret_cast<const float4*>(wl + k * MAXA + 4);
+        const float4 w0 = *reinterpret_cast<const float4*>(wl + k * MAXA);
         acc[0] += hk * w0.x; acc[1] += hk * w0.y; acc[2] += hk * w0.z; acc[3] += hk * w0.w;
-        acc[4] += hk * w1.x; acc[5] += hk * w1.y; acc[6] += hk * w1.z; acc[7] += hk * w1.w;
+        if (MA == 8) {
+            const float4 w1 = *reinterpret_cast<const float4*>(wl + k * MAXA + 4);
+            acc[MA - 4] += hk * w1.x; acc[MA - 3] += hk * w1.y; acc[MA - 2] += hk * w1.z; acc[MA - 1] += hk * w1.w;
+        }
     }
 #pragma unroll
-    for (int o = 0; o < MAXA; ++o) {
+    for (int o = 0; o < MA; ++o) {
         acc[o] += __shfl_xor(acc[o], 16, 64);
         acc[o] += __shfl_xor(acc[o], 32, 64);
     }
     if (q != 0 || row >= a.E) return;
-    float p[MAXA];
+    float p[MA];
     float m = -INFINITY;
 #pragma unroll
-    for (int o = 0; o < MAXA; ++o) {
+    for (int o = 0; o < MA; ++o) {
         p[o] = o < A ? acc[o] + bl[o] : -INFINITY;
         m = fmaxf(m, p[o]);
     }
     float ssum = 0.0f;
 #pragma unroll
-    for (int o = 0; o < MAXA; ++o) {
+    for (int o = 0; o < MA; ++o) {
         p[o] = expf(p[o] - m);                       // exp(-inf) = 0 for the padded columns
         ssum += p[o];
     }
 #pragma unroll
-    for (int o = 0; o < MAXA; ++o) p[o] = p[o] / ssum;
+    for (int o = 0; o < MA; ++o) p[o] = p[o] / ssum;
     float* po = hd.pi_out + (int64_t)n * hd.pi_sn + row * A;
     if (A == 4) {
         *reinterpret_cast<float4*>(po) = float4{p[0], p[1], p[2], p[3]};
@@ -211,7 +219,7 @@ __device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n,
     if (hd.mode == 2) {
         float best = p[0];
 #pragma unroll
-        for (int k = 1; k < MAXA; ++k) {
+        for (int k = 1; k < MA; ++k) {
             const bool gt = k < A && p[k] > best;
             best = gt ? p[k] : best;
             act = gt ? k : act;
@@ -226,16 +234,22 @@ __device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n,
         }
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXA; ++k) tot += (double)p[k];
+        for (int k = 0; k < MA; ++k) tot += (double)p[k];
         double cum = 0.0;
 #pragma unroll
-        for (int k = 0; k < MAXA; ++k) {
+        for (int k = 0; k < MA; ++k) {
             cum += (double)p[k];
             act = (k < A && cum / tot <= (double)uu) ? k + 1 : act;
         }
         act = act > A - 1 ? A - 1 : act;
     }
     hd.act_out[row * N + n] = (uint8_t)act;
+}
+
+__device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n, const int N, const int64_t row0,
+                                                const int lane, const float* a_tile, const float* wl, const float* bl) {
+    if (a.hd.A <= 4) head_policy_lds_n<4>(a, n, N, row0, lane, a_tile, wl, bl);       // (uniform)
+    else head_policy_lds_n<8>(a, n, N, row0, lane, a_tile, wl, bl);
 }
 
 template <bool HAS_Z2, int HEAD>

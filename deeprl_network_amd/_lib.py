@@ -56,7 +56,8 @@ class Msg(C.Structure):
                 ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64), ('sync', C.c_void_p),
                 ('ob', C.c_void_p), ('ob_row', C.c_int64), ('ob_F', C.c_int32), ('ob_segs', C.c_int32), ('ob_nbr', C.c_void_p),
                 ('ob_img', C.c_void_p), ('ob_img_sn', C.c_int64), ('ob_b', C.c_void_p), ('ob_b_sn', C.c_int64),
-                ('status', C.c_void_p)]
+                ('status', C.c_void_p), ('src', C.c_void_p), ('src_sn', C.c_int64),
+                ('out2', C.c_void_p), ('out2_sn', C.c_int64), ('out2_row', C.c_int64)]
 
 
 class NetParams(C.Structure):
@@ -169,6 +170,7 @@ SIGNATURES = {
     'nmarl_lstm_bptt_coupled': [C.POINTER(BpttCoupled), _p],
     'nmarl_fc_fwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_fc_fwd_multi': [_i64, _i32, _i32, C.POINTER(FcPart), _i32, _p, _i64, _i64, _p],
+    'nmarl_onehot_argmax_add': [_i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_fc_bwd_gather': [_i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],

@@ -353,7 +353,7 @@ class BatchedPolicy:
         with torch.no_grad():
             if self.fused_heads:
                 # (in place, another agent's block could overwrite h while this one still gathers it for its message term)
-                z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=h_out.data_ptr() != h.data_ptr())
+                z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=self.msg_inplace_ok or h_out.data_ptr() != h.data_ptr())
                 p = self.params
                 ops.lstm_step_policy(h, p[self.k_wh], p[self.k_b], z1, z2, c, done, c_out, h_out, p['pi_w'], p['pi_b'],
                                      pi_out, act_out, xs=xs, gates=gates, **draw)
@@ -374,7 +374,7 @@ class BatchedPolicy:
         """forward('p') and forward('v') of a lock-step in ONE kernel for a COUPLED net: the message term is computed inside
         the step kernel and the blocks hand their new h over inside the launch (ops.step_handoff_supported).  Decided per
         call site (the number of replicas matters): `pv_one_launch(E)`."""
-        return self.coupled and self.fused_heads and self._msg() is not None
+        return self.coupled and self.fused_heads and self.msg_kind != ops.MSG_DIAL and self._msg() is not None
 
     def pv_one_launch(self, E):
         if self.fused_pv:
@@ -545,6 +545,7 @@ class BatchedPolicy:
                 self._msg_img = ops.lstm_msg_wimage(self.params['w_msg'], out=self._msg_img)
 
     msg_kind = 0            # ops.MSG_*: the message term the step kernel can compute itself (coupled nets)
+    msg_inplace_ok = False  # the in-kernel message term reads no h of other agents (lstm_dial: the senders' message vectors)
     _msg_img = None
 
     def _msg(self, **kw):
@@ -903,6 +904,8 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     k_ob = 'w_ob'
     coupled = True
+    msg_kind = ops.MSG_DIAL
+    msg_inplace_ok = True
 
     def _phases(self):
         H, F = self.n_h, self.n_feat
@@ -917,16 +920,20 @@ class DIALMultiAgentPolicy(BatchedPolicy):
                 [('mfc_w', 'dial/mfc_%d/w', (H, H), None), ('mfc_b', 'dial/mfc_%d/b', (H,), None)],
                 self._head_phase('dial/pi_%d', 'dial/v_%d')]
 
+    def _ai_scale(self, fp):
+        """lstm_dial_hetero (agents/utils.py:676-688): an agent without neighbours gets neither messages nor `ai`."""
+        if not self.hetero:
+            return None
+        if not hasattr(self, '_has_nbr'):
+            self._has_nbr = torch.tensor([float(self._m(i) > 0) for i in range(self.N)], dtype=fp.dtype,
+                                         device=fp.device).view(self.N, 1, 1)
+        return self._has_nbr
+
     def _own_action_onehot(self, fp):
         """one_hot(argmax(p_i), n_h) (agents/utils.py:577): first maximum, like tf.argmax."""
         oh = torch.nn.functional.one_hot(torch.argmax(fp, dim=-1), self.n_h).to(fp.dtype)
-        if self.hetero:
-            # lstm_dial_hetero (agents/utils.py:676-688): an agent without neighbours gets neither messages nor `ai`
-            if not hasattr(self, '_has_nbr'):
-                self._has_nbr = torch.tensor([float(self._m(i) > 0) for i in range(self.N)], dtype=fp.dtype,
-                                             device=fp.device).view(self.N, 1, 1)
-            oh = oh * self._has_nbr
-        return oh
+        sc = self._ai_scale(fp)
+        return oh if sc is None else oh * sc
 
     def _enc(self, xv, fp):
         p = self.params
@@ -942,7 +949,8 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         return self._enc(xv, fp)             # recomputed: only the recurrence is saved
 
     def _enc_infer(self, xv, fp, out=None):
-        return self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU).add_(self._own_action_onehot(fp))
+        sc = self._ai_scale(fp)
+        return ops.onehot_argmax_add_(self._fc_ob_infer(xv, 'w_ob', 'w_ob_b', ops.BIAS_RELU), fp, None if sc is None else sc.view(-1))
 
     def save_spec(self):
         return {'A1': self.n_h, 'A2': self.n_h}        # hm (post-relu), msg (post-relu): relu masks of the backward
@@ -953,6 +961,11 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         p = self.params
         keep = save is not None and not second
         msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU, out=save['A2'] if keep else None)
+        if fuse_msg and self._msg() is not None:
+            # hm = relu([msg_j] W_msg + b) and s = hm + enc inside the step kernel (csrc/lstm_mfma.hip MSG 3): no gather / GEMM /
+            # bias-activation / add launches; the policy step keeps hm (relu mask of the backward) and s (the LSTM input)
+            return None, None, (None, p['wx_hid'], self._img, None,
+                                self._msg(src=msg, enc=enc, out=save['S'] if keep else None, out2=save['A1'] if keep else None))
         hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU,
                             out=save['A1'] if keep else None)
         if self.xside:

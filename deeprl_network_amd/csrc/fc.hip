@@ -843,6 +843,34 @@ extern "C" int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, cons
     return nmarl_check_launch();
 }
 
+// lstm_dial's own-action term `ai` (agents/utils.py:577: one_hot(argmax(p_i), n_h) added to the encoded observation):
+// y[n,r,argmax_a p[n,r,a]] += scale[n] -- the first maximum, like tf.argmax; one thread per row (A <= 8 floats in, one
+// read-modify-write out) instead of argmax / one_hot / cast / scale / add launches over [N,rows,64]
+__global__ __launch_bounds__(256) void onehot_argmax_add_kernel(const int64_t rows, const int A, const float* __restrict__ p,
+                                                                const int64_t p_sn, const float* __restrict__ scale,
+                                                                float* __restrict__ y, const int64_t y_sn, const int64_t y_row) {
+    const int n = blockIdx.y;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* pr = p + (int64_t)n * p_sn + r * A;
+    float best = pr[0];
+    int bi = 0;
+    for (int a = 1; a < A; ++a) {
+        const float v = pr[a];
+        if (v > best) { best = v; bi = a; }
+    }
+    y[(int64_t)n * y_sn + r * y_row + bi] += scale ? scale[n] : 1.0f;
+}
+
+extern "C" int nmarl_onehot_argmax_add(int64_t rows, int32_t N, int32_t A, int32_t W, const float* p, int64_t p_sn,
+                                       const float* scale, float* y, int64_t y_sn, int64_t y_row, void* stream) {
+    if (rows < 0 || N <= 0 || A <= 0 || A > W || (rows > 0 && (!p || !y || p_sn < rows * (int64_t)A || y_row < W))) return NMARL_EINVAL;
+    if (rows == 0) return NMARL_OK;
+    hipLaunchKernelGGL(onehot_argmax_add_kernel, dim3((unsigned)((rows + 255) / 256), N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       rows, A, p, p_sn, scale, y, y_sn, y_row);
+    return nmarl_check_launch();
+}
+
 static int launch_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t Jw, const float* x, int64_t x_sn, int64_t x_row,
                          const int32_t* nbr_idx, int32_t gather_A, int32_t m_max, const float* y, int64_t y_sn, int64_t y_row,
                          const float* dy, int64_t dy_sn, int64_t dy_row, int32_t act, float* partial, float* dw, int64_t dw_sn,

@@ -492,6 +492,8 @@ struct XArgs {
     const float* msg_b; int64_t msg_b_sn;         // [N, 64]
     const float* enc; int64_t enc_sn, enc_row;    // MSG 2: the additive h-independent part of the input [N,E,64]
     float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
+    const float* src; int64_t src_sn;             // MSG 3: the senders' message vectors [N,E,64] the pre-phase gathers (instead of h)
+    float* xm2_out; int64_t xm2_sn, xm2_row;      // MSG 3: where hm = relu(.) is kept BEFORE enc is added (may be NULL)
     unsigned* sync;               // HEAD 4: [0] generation, [1] blocks finished, [2] error, [16 + (agent, block, wave)] flags
     // HEAD 4 + MSG 2, ob != NULL: lstm_ic3's observation encoder enc = tanh([x_i | x_nbr] W_ob + b_ob) (agents/utils.py:395-399)
     // runs here as well, from the env's compact observation; its result goes to `enc` (the update needs it) before it is used
@@ -566,6 +568,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, cons
 // MSG: the message term of a coupled net computed IN the step kernel (no gather / GEMM / bias-activation launches):
 //   1  lstm_comm (agents/utils.py:182-199):  hm = relu([h_j : j in nbr(i)] @ W_msg + b_msg)          -> x[:, KX-64:]
 //   2  lstm_ic3  (agents/utils.py:395-400):  s  = mean_j(h_j) @ W_msg + b_msg + enc                   -> x (KX = 64)
+//   3  lstm_dial (agents/utils.py:515-599):  hm = relu([msg_j : j in nbr(i)] @ W_msg + b_msg), s = hm + enc -> x (KX = 64);
+//      msg_j = relu(h_j W_mfc + b) is the SENDER's layer, one fc launch of the caller (xa.src), gathered here like MSG 1's h
 // from the neighbours' PREVIOUS, un-masked h (quirk Q3): h_in of the other agents, complete before this launch.
 // A pre-phase on the matrix cores ([16 rows x K_m] @ [K_m x 64], A operands gathered from global memory, W_msg from an
 // LDS image staged behind the chunk buffers); its result goes through the wave's LDS tile into A layout, where the
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     NMARL_STAMP(44)
     float* o_lds = m_lds + xa.msg_kc * (CH_K * 64);                  // W_ob image: 64 x 64 floats
     // the W_msg / W_ob images: all pieces requested at once (a run-time loop would wait for every piece before asking for the next)
-    constexpr int MIQ = MSG == 1 ? 4 : 2;                            // pieces per thread: K_m <= 128 (MSG 1), = 64 (MSG 2)
+    constexpr int MIQ = MSG == 2 ? 2 : 4;                            // pieces per thread: K_m <= 128 (MSG 1 / 3), = 64 (MSG 2)
     float4 mi[MSG != 0 ? MIQ : 1], oi[OBENC ? 2 : 1];
     if (MSG != 0) {
         const float4* g = reinterpret_cast<const float4*>(xa.msg_img + (int64_t)n * xa.msg_img_sn);
@@ -769,8 +773,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     auto msg_load = [&](auto second_c, auto k0_c, float4 (&U)[16], float (&W)[4]) {
         constexpr bool SECOND = decltype(second_c)::value;
         constexpr int k0 = decltype(k0_c)::value;
-        const float* hsrc = SECOND ? a.h_new : a.h_in;
-        const int64_t hsn = SECOND ? a.h_new_sn : a.h_sn;
+        const float* hsrc = MSG == 3 ? xa.src : SECOND ? a.h_new : a.h_in;
+        const int64_t hsn = MSG == 3 ? xa.src_sn : SECOND ? a.h_new_sn : a.h_sn;
         const float* hbase = hsrc + arow * H + 4 * grp;              // + j * hsn: row `arow` of agent j
         const uint32_t hoff = (uint32_t)((arow * H + 4 * grp) * 4), hbytes = (uint32_t)(a.E * (H * 4));
         auto load2 = [&](const int jj, const int col, float4& u0, float4& u1) {
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
         };
 #pragma unroll
-        for (int q = 0; q < (MSG == 1 ? 2 : 4); ++q) {
+        for (int q = 0; q < (MSG == 2 ? 4 : 2); ++q) {
             const int k = k0 + q;
             const int j = nbj[k];
             const bool ok = k < xa.m_max && j >= 0;
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         f32x4 macc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) macc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (MSG == 1) {                     // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
+        if (MSG != 2) {                     // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 if (kc < xa.msg_kc) {
@@ -924,15 +928,19 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
         }
         // result (C layout) + bias, relu / + enc -> the wave's LDS tile (A layout source) and, if asked, global memory
-        const float* encn = MSG == 2 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
+        const float* encn = MSG != 1 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
         float* xo = (!SECOND && xa.xm_out) ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
+        float* xo2 = (MSG == 3 && xa.xm2_out) ? xa.xm2_out + (int64_t)n * xa.xm2_sn : nullptr;
         const float4 bv = bv4;                                                    // tile t of lane column c = unit 4 c + t
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float4 v = float4{macc[0][r] + bv.x, macc[1][r] + bv.y, macc[2][r] + bv.z, macc[3][r] + bv.w};
-            if (MSG == 1) {
+            if (MSG != 2) {
                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-            } else {
+            }
+            if (MSG == 3 && xo2 && row0 + 4 * grp + r < a.E)
+                *reinterpret_cast<float4*>(xo2 + (row0 + 4 * grp + r) * xa.xm2_row + 4 * c) = v;
+            if (MSG != 1) {
                 float4 e4 = *reinterpret_cast<const float4*>(encn + rofs[r] * xa.enc_row + 4 * c);
                 if (OBENC && !SECOND && ob_here) e4 = encv[r];       // computed above (no dependence on the store just issued)
                 v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
@@ -1392,22 +1400,25 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
                                  const nmarl_msg_t* msg, void* stream) {
     const int mk = msg ? msg->kind : 0;
     const int KM = mk ? H : 0;                   // columns of x the message pre-phase produces
-    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K || mk < 0 || mk > 2 ||
+    if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K || mk < 0 || mk > 3 ||
         (mk && (KX2 != 0 || KX < H)) ||
         (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 - KM > 0 && !x) || (KX2 > 0 && !x2))))
         return NMARL_EINVAL;
     if (mk && E > 0) {
         if (msg->m_max <= 0 || msg->m_max > 8 || !msg->nbr_idx || !msg->img || !msg->b || msg->b_sn < H ||
-            msg->K != (mk == 1 ? H * msg->m_max : H) || msg->K > 128 || msg->img_sn < (int64_t)msg->K * 64 || (msg->img_sn % 4) ||
+            msg->K != (mk == 2 ? H : H * msg->m_max) || msg->K > 128 || msg->img_sn < (int64_t)msg->K * 64 || (msg->img_sn % 4) ||
             ((uintptr_t)msg->img % 16) || ((uintptr_t)msg->b % 16) || (msg->b_sn % 4) ||
-            (mk == 2 && (!msg->enc || msg->enc_row < H || msg->enc_sn < E * msg->enc_row || ((uintptr_t)msg->enc % 16) ||
+            (mk != 1 && (!msg->enc || msg->enc_row < H || msg->enc_sn < E * msg->enc_row || ((uintptr_t)msg->enc % 16) ||
                          (msg->enc_row % 4) || (msg->enc_sn % 4))) ||
             (msg->out && (msg->out_row < H || msg->out_sn < E * msg->out_row || ((uintptr_t)msg->out % 16) || (msg->out_row % 4) ||
-                          (msg->out_sn % 4))))
+                          (msg->out_sn % 4))) ||
+            (mk == 3 && (KX != H || !msg->src || msg->src_sn < E * (int64_t)H || (msg->src_sn % 4) || ((uintptr_t)msg->src % 16) ||
+                         (msg->out2 && (msg->out2_row < H || msg->out2_sn < E * msg->out2_row || ((uintptr_t)msg->out2 % 16) ||
+                                        (msg->out2_row % 4) || (msg->out2_sn % 4))))))
             return NMARL_EINVAL;
     }
     const int kind = head ? head->kind : 0;
-    if (kind < 0 || kind > 3) return NMARL_EINVAL;
+    if (kind < 0 || kind > 3 || (mk == 3 && kind == 3)) return NMARL_EINVAL;     // lstm_dial: the two-launch lock-step only
     if (kind != 0 && E > 0) {
         if (head->A <= 0 || head->A > MAXA || !head->w || !head->b || head->b_sn < (kind == 2 ? 1 : head->A)) return NMARL_EINVAL;
         if ((kind == 1 || kind == 3) && (head->w_sn < (int64_t)H * head->A || !head->pi_out || head->pi_sn < E * head->A || !head->act_out ||
@@ -1446,6 +1457,9 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.msg_kc = msg->K / CH_K; xa.m_max = msg->m_max; xa.nbr_idx = msg->nbr_idx; xa.msg_img = msg->img;
         xa.msg_img_sn = msg->img_sn; xa.msg_b = msg->b; xa.msg_b_sn = msg->b_sn; xa.enc = msg->enc; xa.enc_sn = msg->enc_sn;
         xa.enc_row = msg->enc_row; xa.xm_out = msg->out; xa.xm_sn = msg->out_sn; xa.xm_row = msg->out_row;
+        if (mk == 3) {
+            xa.src = msg->src; xa.src_sn = msg->src_sn; xa.xm2_out = msg->out2; xa.xm2_sn = msg->out2_sn; xa.xm2_row = msg->out2_row;
+        }
     }
     static NmarlPerDeviceOnce lds_once;
     // no message pre-phase: three chunk buffers (de-phased wave groups); with it: two + the W_msg image
@@ -1457,6 +1471,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         NMARL_SET_LDS((lstm_step_x_kernel<0, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 0>))
         NMARL_SET_LDS((lstm_step_x_kernel<3, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 1>))
         NMARL_SET_LDS((lstm_step_x_kernel<1, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 2>))
+        NMARL_SET_LDS((lstm_step_x_kernel<1, 3>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 3>))
         NMARL_SET_LDS((lstm_step_x_kernel<4, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2>))
 #undef NMARL_SET_LDS
         lds_once.done(lds_bit);
@@ -1489,9 +1504,10 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.ob_img = msg->ob_img; xa.ob_img_sn = msg->ob_img_sn; xa.ob_b = msg->ob_b; xa.ob_b_sn = msg->ob_b_sn;
         lb_extra = (size_t)H * 64 * sizeof(float);
     }
-    if (mk) {
+    if (mk == 1 || mk == 2) {
         // the pre-phase gathers OTHER agents' previous h while their blocks write h_new: no panel of h_new may overlap a
-        // panel of h_in (in-place stepping is for nets without the in-kernel message term)
+        // panel of h_in (in-place stepping is for nets without the in-kernel message term; lstm_dial's pre-phase reads the
+        // message vectors instead, which no block of this launch writes)
         const int64_t span = E * (int64_t)H;
         for (int i = 0; i < N; ++i)
             for (int j = 0; j < N; ++j) {
@@ -1506,8 +1522,10 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);
     } else if (mk == 1) {
         if (kind == 1) NMARL_LX(1, 1); else if (kind == 2) NMARL_LX(2, 1); else NMARL_LX(4, 1);
-    } else {
+    } else if (mk == 2) {
         if (kind == 1) NMARL_LX(1, 2); else if (kind == 2) NMARL_LX(2, 2); else NMARL_LX(4, 2);
+    } else {
+        if (kind == 1) NMARL_LX(1, 3); else NMARL_LX(2, 3);
     }
 #undef NMARL_LX
     return nmarl_check_launch();

@@ -218,13 +218,13 @@ def lstm_wimage(wx, wh, out=None):
     return out
 
 
-MSG_GATHER_RELU, MSG_MEAN_ADD = 1, 2      # nmarl_msg_t.kind: lstm_comm / lstm_ic3
+MSG_GATHER_RELU, MSG_MEAN_ADD, MSG_DIAL = 1, 2, 3      # nmarl_msg_t.kind: lstm_comm / lstm_ic3 / lstm_dial
 MSG_MAX_K = 128
 
 
 def msg_supported(kind, m_max, n_h):
     """The message term of a coupled net fits the step kernel's pre-phase (csrc/lstm_mfma.hip, MSG)."""
-    return n_h == FUSED_H and m_max <= 8 and (n_h * m_max if kind == MSG_GATHER_RELU else n_h) <= MSG_MAX_K
+    return n_h == FUSED_H and m_max <= 8 and (n_h if kind == MSG_MEAN_ADD else n_h * m_max) <= MSG_MAX_K
 
 
 def lstm_msg_wimage(w_msg, out=None):
@@ -242,7 +242,8 @@ def lstm_msg_wimage(w_msg, out=None):
 def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, what):
     """nmarl_lstm_step_x: xs = (x [N,E,KX1] or None, wx (unused here: it is inside the image), image[, x2 [N,E,KX2][, msg]]):
     the LSTM input is [x | x2] (x2 optional), or [x | message term] with msg = dict(kind, nbr_idx, w_msg, b_msg, img,
-    enc=None, out=None): the last 64 columns are computed inside the kernel from the neighbours' h (heads only)."""
+    enc=None, out=None): the last 64 columns are computed inside the kernel from the neighbours' h (heads only); kind
+    MSG_DIAL: from msg['src'] [N,E,64], the senders' message vectors, with hm (before `enc` is added) -> msg['out2']."""
     N, E, H = h.shape
     x, _, img = xs[:3]
     x2 = xs[3] if len(xs) > 3 else None
@@ -265,6 +266,13 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             m.enc, m.enc_sn, m.enc_row = _rows_view(msg['enc'], H, what + ' enc')
         if msg.get('out') is not None:
             m.out, m.out_sn, m.out_row = _rows_view(msg['out'], H, what + ' msg out')
+        if msg['kind'] == MSG_DIAL:
+            src = msg['src']
+            if src.shape != (N, E, H) or src.stride(2) != 1 or src.stride(1) != H:
+                raise _lib.NmarlError('%s: msg["src"] must be [N,E,64] with contiguous panels' % what)
+            m.src, m.src_sn = ptr(src, F32, strided=True), src.stride(0)
+            if msg.get('out2') is not None:
+                m.out2, m.out2_sn, m.out2_row = _rows_view(msg['out2'], H, what + ' msg out2')
         ob = msg.get('ob')
         if ob is not None:                     # lstm_ic3's observation encoder inside the launch (one-launch step only): writes msg['enc']
             x_ob = ob['x']                     # compact observation [E,N,F]
@@ -477,6 +485,17 @@ def fc_fwd(x, w, b, act, out=None):
     wp, ws = _head_param(w, 'fc_fwd')
     check(lib.nmarl_fc_fwd(rows, N, F, w.shape[2], xp, xs, xr, wp, ws, *_bias(b), act, yp, ys, yr, stream()), 'nmarl_fc_fwd')
     return out
+
+
+def onehot_argmax_add_(y, p, scale=None):
+    """y[n,r,argmax_a p[n,r,a]] += scale[n] (1 without scale), in place: lstm_dial's own-action term one_hot(argmax(p_i), n_h)
+    (agents/utils.py:577) added to the encoded observation y [N,rows,W] (a view; p [N,rows,A] with contiguous panels)."""
+    N, rows, W = y.shape
+    pp, p_sn = _pn(p)
+    yp, ys, yr = _rows_view(y, W, 'onehot_argmax_add_ y')
+    check(lib.nmarl_onehot_argmax_add(rows, N, p.shape[2], W, pp, p_sn, None if scale is None else ptr(scale, F32), yp, ys, yr, stream()),
+          'nmarl_onehot_argmax_add')
+    return y
 
 
 def fc_fwd_multi(parts, act, out=None):

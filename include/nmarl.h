@@ -388,6 +388,11 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
  *   kind 1  lstm_comm (agents/utils.py:182-199): hm = relu([h_j : j in nbr(i)] @ w_msg + b_msg), K = 64*m_max <= 128;
  *           the LSTM input is [x (KX-64 columns: [hx | hp]) | hm]
  *   kind 2  lstm_ic3 (agents/utils.py:395-400): s = mean_j(h_j) @ w_msg + b_msg + enc, K = 64; the LSTM input is s (KX = 64)
+ *   kind 3  lstm_dial (agents/utils.py:515-599): hm = relu([msg_j : j in nbr(i)] @ w_msg + b_msg), K = 64*m_max <= 128, from
+ *           the SENDERS' message vectors src [N,E,64] (msg_j = relu(h_j w_mfc + b), one nmarl_fc_fwd of the caller on the
+ *           un-masked previous h; agent stride src_sn, rows contiguous); s = hm + enc is the LSTM input (KX = 64).  out2 (may
+ *           be NULL) receives hm, out receives s.  src may not overlap out / out2; h_new MAY be h_in (the pre-phase reads no
+ *           h).  Heads 1 and 2 only (the re-step's message vectors need the senders' NEW h: a launch of the caller).
  * w_msg comes as the image of nmarl_lstm_msg_wimage (K*64 floats per agent: image[k][c][t] = w_msg[k][16t+c]); nbr_idx
  * [N,m_max] (-1 padded, ascending); enc [N,E,64] with row pitch enc_row (kind 2).  out (may be NULL): where the 64
  * computed columns are stored for the update's backward ([N,E,64] view, row pitch out_row).  head: kind 1 or 2.
@@ -421,6 +426,8 @@ typedef struct nmarl_msg {
     const float* ob_img; int64_t ob_img_sn;
     const float* ob_b; int64_t ob_b_sn;
     int32_t* status;    /* head kind 3 only, may be NULL: hand-off status words (word 0 <- 1 when a wave gives up) */
+    const float* src; int64_t src_sn;               /* kind 3: the senders' message vectors [N,E,64] */
+    float* out2; int64_t out2_sn, out2_row;         /* kind 3, may be NULL: hm before enc is added ([N,E,64] view) */
 } nmarl_msg_t;
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_sync_words(int64_t E, int32_t N);
@@ -520,6 +527,14 @@ int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stream);
  */
 int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x_sn, const float* bias,
                    int64_t bias_sn, int32_t act, float* y, int64_t y_sn, int64_t y_row, void* stream);
+/*
+ * lstm_dial's own-action term (agents/utils.py:577: one_hot(argmax(p_i), n_h), added to the encoded observation at :579):
+ * y[n,r,argmax_a p[n,r,a]] += scale[n] (scale NULL: 1; lstm_dial_hetero, agents/utils.py:676-688, gives agents without
+ * neighbours no such term: scale 0).  p [N,rows,A] with contiguous rows (agent stride p_sn), y an [N,rows,W] view
+ * (A <= W, row pitch y_row); the first maximum wins, like tf.argmax.
+ */
+int nmarl_onehot_argmax_add(int64_t rows, int32_t N, int32_t A, int32_t W, const float* p, int64_t p_sn,
+                            const float* scale, float* y, int64_t y_sn, int64_t y_row, void* stream);
 /*
  * Small-input fully connected encoder layer for all agents and rows in one launch (fc, agents/utils.py:65-73;
  * call sites policies.py:145, 177-180 and agents/utils.py:186-198, 395-400, 566-575):

@@ -145,11 +145,11 @@ def xside_supported(kx, n_h):
     return n_h == FUSED_H and kx % 32 == 0 and 0 <= kx <= XSIDE_MAX_K
 
 
-MSG_GATHER_RELU, MSG_MEAN_ADD = 1, 2
+MSG_GATHER_RELU, MSG_MEAN_ADD, MSG_DIAL = 1, 2, 3
 
 
 def msg_supported(kind, m_max, n_h):
-    return n_h == FUSED_H and m_max <= 8 and (n_h * m_max if kind == MSG_GATHER_RELU else n_h) <= 128
+    return n_h == FUSED_H and m_max <= 8 and (n_h if kind == MSG_MEAN_ADD else n_h * m_max) <= 128
 
 
 def ob_encoder_supported(n_feat, n_obs, n_h):
@@ -194,6 +194,11 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
             m = xs[4]
             if m['kind'] == 1:                         # lstm_comm: relu([h_j] W_msg + b)   (agents/utils.py:182-199)
                 t = torch.relu(torch.bmm(nbr_gather(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1))
+            elif m['kind'] == 3:                       # lstm_dial: relu([msg_j] W_msg + b) + enc, msg_j the senders' vectors (agents/utils.py:560-580)
+                t = torch.relu(torch.bmm(nbr_gather(m['src'], m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1))
+                if m.get('out2') is not None:
+                    m['out2'].copy_(t)
+                t = t + m['enc']
             else:                                      # lstm_ic3: mean_j(h_j) W_msg + b + enc   (agents/utils.py:395-400)
                 if m.get('ob') is not None:            # enc = tanh([x_i | x_nbr] W_ob + b_ob) (agents/utils.py:395-399) computed here, kept in m['enc']
                     ob = m['ob']
@@ -259,6 +264,14 @@ def fc_fwd(x, w, b, act, out=None):
         out.copy_(y)
         return out
     return y
+
+
+def onehot_argmax_add_(y, p, scale=None):
+    """agents/utils.py:577-579: y += one_hot(argmax(p), n_h) (per-agent factor `scale`: lstm_dial_hetero, :676-688)."""
+    oh = torch.nn.functional.one_hot(torch.argmax(p, dim=-1), y.shape[-1]).to(y.dtype)
+    if scale is not None:
+        oh = oh * scale.view(-1, 1, 1)
+    return y.add_(oh)
 
 
 def fc_fwd_multi(parts, act, out=None):

@@ -981,6 +981,101 @@ def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
     torch.testing.assert_close(v1.cpu().double(), v_r, rtol=2e-4, atol=5e-5)
 
 
+@pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (5, 127, 4, 2), (6, 300, 5, 1)])
+def test_lstm_step_x_dial_message_term(N, E, A, m_max):
+    """lstm_dial's receiver side inside the step kernel (nmarl_lstm_step_x_msg kind 3, agents/utils.py:560-580) vs the float64
+    restatement: hm = relu(gather(msg) W_msg + b) from the SENDERS' message vectors, s = hm + enc the LSTM input; hm and s
+    stored (the update's relu mask / saved input); policy step (also IN PLACE: the pre-phase reads no h) and value step."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 17 + E)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    Km = H * m_max
+    h, c, done = r(N, E, H) * 0.7, r(N, E, H), (torch.rand(E, generator=g) < 0.3).float()
+    src, enc = torch.relu(r(N, E, H)), torch.relu(r(N, E, H))
+    wx = r(N, H, 4 * H) * 0.15 + torch.arange(4 * H).view(1, 1, -1) * 1e-3 + torch.arange(H).view(1, -1, 1) * 1e-3
+    wh, b = r(N, H, 4 * H) * 0.2, r(N, 4 * H) * 0.1
+    w_msg = r(N, Km, H) * 0.2 + torch.arange(H).view(1, 1, -1) * 2e-3 + torch.arange(Km).view(1, -1, 1) * 1e-3
+    b_msg = r(N, H) * 0.2
+    pi_w, pi_b, v_w, v_b = r(N, H, A) * 0.5, r(N, A) * 0.3, r(N, H + m_max * A, 1), r(N, 1)
+    idx = -torch.ones(N, m_max, dtype=torch.int32)
+    for i in range(N):
+        others = [j for j in range(N) if j != i][:(i % m_max) + (0 if i == N - 1 else 1)]   # the last agent: no neighbours
+        if others:
+            idx[i, :len(others)] = torch.tensor(others, dtype=torch.int32)
+    f64 = lambda t: None if t is None else t.double()                                    # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
+    draw = dict(mode=2, seed=5, env_id_base=40, step=3)
+    s_r, hm_r = torch.zeros(N, E, H, dtype=torch.float64), torch.zeros(N, E, H, dtype=torch.float64)
+    msg_r = dict(kind=3, nbr_idx=idx, w_msg=f64(w_msg), b_msg=f64(b_msg), enc=f64(enc), src=f64(src), out=s_r, out2=hm_r)
+    hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
+    pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
+    gr = torch.zeros(N, E, 4 * H, dtype=torch.float64)
+    ops_ref.lstm_step_policy(f64(h), f64(wh), f64(b), None, None, f64(c), f64(done), cr, hr, f64(pi_w), f64(pi_b), pir, actr,
+                             xs=(None, f64(wx), None, None, msg_r), gates=gr, **draw)
+    assert float(hm_r.abs().max()) > 0 and float((s_r - hm_r - enc.double()).abs().max()) < 1e-12
+    img, mimg = ops.lstm_wimage(cu(wx), cu(wh)), ops.lstm_msg_wimage(cu(w_msg))
+    save = torch.zeros(N, 3, E, H, device='cuda')                     # slots of a wider buffer: agent stride 3 E H
+    msg_g = dict(kind=3, nbr_idx=cu(idx), w_msg=cu(w_msg), b_msg=cu(b_msg), img=mimg, enc=cu(enc), src=cu(src), out=save[:, 0],
+                 out2=save[:, 2])
+    tol = dict(rtol=5e-5, atol=1e-5)
+    for inplace in (False, True):
+        save.zero_()
+        hin, cin = cu(h), cu(c)
+        hg, cg = (hin, cin) if inplace else (torch.zeros(N, E, H, device='cuda'), torch.zeros(N, E, H, device='cuda'))
+        pig, actg, gg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.zeros(N, E, 4 * H, device='cuda')
+        ops.lstm_step_policy(hin, None, cu(b), None, None, cin, cu(done), cg, hg, cu(pi_w), cu(pi_b), pig, actg,
+                             xs=(None, None, img, None, msg_g), gates=gg, **draw)
+        torch.testing.assert_close(save[:, 2].cpu().double(), hm_r, **tol)
+        torch.testing.assert_close(save[:, 0].cpu().double(), s_r, **tol)
+        assert float(save[:, 1].abs().max()) == 0.0
+        torch.testing.assert_close(hg.cpu().double(), hr, **tol)
+        torch.testing.assert_close(cg.cpu().double(), cr, **tol)
+        torch.testing.assert_close(gg.cpu().double(), gr, **tol)
+        torch.testing.assert_close(pig.cpu().double(), pir, **tol)
+    act_chk = torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.sample_actions(pig.cpu(), act_chk, **draw)
+    assert torch.equal(actg.cpu(), act_chk)
+    # value re-step: new message vectors (the caller's fc launch on the new h), nothing stored
+    src2 = torch.relu(r(N, E, H))
+    vr = torch.zeros(N, E, dtype=torch.float64)
+    ops_ref.lstm_step_value(hr, f64(wh), f64(b), None, None, cr, f64(done), torch.empty_like(cr), torch.empty_like(hr), f64(v_w),
+                            f64(v_b), act_chk, idx, A, vr, xs=(None, f64(wx), None, None, dict(msg_r, src=f64(src2), out=None, out2=None)))
+    vg, h2, c2 = torch.zeros(N, E, device='cuda'), torch.zeros_like(hg), torch.zeros_like(cg)
+    keep = save.clone()
+    ops.lstm_step_value(hg, None, cu(b), None, None, cg, cu(done), c2, h2, cu(v_w), cu(v_b), actg, cu(idx), A, vg,
+                        xs=(None, None, img, None, dict(msg_g, src=cu(src2), out=None, out2=None)))
+    torch.testing.assert_close(vg.cpu().double(), vr, rtol=2e-4, atol=5e-5)
+    assert torch.equal(save, keep)
+    # the one-launch lock-step does not exist for this message kind
+    with pytest.raises(Exception):
+        ops.lstm_step_policy_value(cu(h), None, cu(b), None, None, cu(c), cu(done), cu(pi_w), cu(pi_b), pig, actg, cu(v_w), cu(v_b),
+                                   cu(idx), A, vg, xs=(None, None, img, None, dict(msg_g, sync=ops.step_sync_words(N, E, 'cuda'))),
+                                   h_out=h2, c_out=c2, gates=gg, **draw)
+
+
+@pytest.mark.parametrize('N,E,A', [(8, 4096, 4), (3, 77, 5)])
+def test_onehot_argmax_add(N, E, A):
+    """lstm_dial's own-action term (agents/utils.py:577-579) in one launch vs one_hot(argmax): first maximum on ties, per-agent
+    scale (lstm_dial_hetero), a column block of a wider buffer as target."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    g = torch.Generator().manual_seed(E)
+    p = torch.softmax(torch.randn(N, E, A, generator=g), dim=-1)
+    p[:, ::3] = 1.0 / A                                              # ties: index 0
+    p[:, 1::7, A - 1] = p[:, 1::7, 1] = 0.45                         # ties between 1 and A-1: index 1
+    y0 = torch.randn(N, E, 64, generator=g)
+    scale = torch.tensor([float(i % 2) for i in range(N)])
+    for sc in (None, scale):
+        ref = ops_ref.onehot_argmax_add_(y0.clone(), p, sc)
+        wide = torch.zeros(N, E, 192, device='cuda')
+        wide[:, :, 64:128].copy_(y0)
+        ops.onehot_argmax_add_(wide[:, :, 64:128], p.cuda(), None if sc is None else sc.cuda())
+        assert torch.equal(wide[:, :, 64:128].cpu(), ref)
+        assert float(wide[:, :, :64].abs().max()) == 0.0 and float(wide[:, :, 128:].abs().max()) == 0.0
+
+
 def _topology(N, kind):
     """line (m_max 2) or 5x5-style grid (m_max 4) neighbour masks for N agents."""
     nm = np.zeros((N, N), dtype=int)

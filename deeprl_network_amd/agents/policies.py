@@ -946,7 +946,9 @@ class DIALMultiAgentPolicy(BatchedPolicy):
         return torch.bmm(enc + hm, p['wx_hid'])
 
     def _enc_saved(self, xv, fp, S):
-        return self._enc(xv, fp)             # recomputed: only the recurrence is saved
+        # recomputed (only the recurrence is saved) for the observation layer's backward; CoupledSequenceSaved never reads the
+        # VALUE of enc (the LSTM inputs S = enc + hm are saved), and the own-action one-hot is a constant: left out here
+        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b')], ops.BIAS_RELU)
 
     def _enc_infer(self, xv, fp, out=None):
         sc = self._ai_scale(fp)

@@ -225,6 +225,12 @@ class CoupledSequenceSaved(torch.autograd.Function):
         elif fused:   # cell backward + [dx | dh] = dz @ [wxm; wh]^T (+ relu mask, + done mask) in one MFMA kernel per step
             ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
             dhd_buf = torch.empty(N, E, H, dtype=F32, device=dev)
+        adj = None
+        if fused and kind == 'dial' and w_msg.stride(2) == 1 and w_msg.stride(1) == H:
+            # lstm_dial: the whole message adjoint of a step (both relu masks, gather adjoint, both products) in ONE more launch
+            rev_d = _reverse_table(nbr_idx, ops.COUPLED_NC)
+            if ops.dial_adjoint_supported(nbr_idx.shape[1], H, rev_d):
+                adj = (ops.dial_adjoint_images(w_msg, mfc_w), rev_d, torch.empty(N, E, H, dtype=F32, device=dev))
         for t in (range(T - 1, -1, -1) if rev is None else ()):
             if fused:
                 ops.bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next,
@@ -232,6 +238,10 @@ class CoupledSequenceSaved(torch.autograd.Function):
                               mask=hm[:, t] if kind == 'nc' else None)
                 dc, dc_next = dc_next, dc
                 dhd = dhd_buf
+                if adj is not None:
+                    dh_rec = ops.dial_msg_adjoint(DS[:, t], hm[:, t], A2[:, t], dhd, w_msg, mfc_w, nbr_idx, adj[0], adj[1],
+                                                  D1[:, t], D2[:, t], adj[2])
+                    continue
                 if kind == 'dial':
                     torch.mul(DS[:, t], (hm[:, t] > 0), out=D1[:, t])
             else:

@@ -1334,7 +1334,7 @@ extern "C" int nmarl_lstm_wimage(int32_t N, int32_t KX, const float* wx, int64_t
 
 extern "C" int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn,
                                      void* stream) {
-    if (N <= 0 || K <= 0 || K % CH_K || K > 128 || !w_msg || !img || w_sn < (int64_t)K * 64 || img_sn < (int64_t)K * 64 ||
+    if (N <= 0 || K <= 0 || K % CH_K || K > 256 || !w_msg || !img || w_sn < (int64_t)K * 64 || img_sn < (int64_t)K * 64 ||
         (img_sn % 4) || ((uintptr_t)img % 16))
         return NMARL_EINVAL;
     const int64_t total = (int64_t)N * K * 64;

@@ -831,6 +831,30 @@ def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False):
 COUPLED_NC, COUPLED_IC3 = 1, 2           # nmarl_bptt_coupled_t.kind: lstm_comm / lstm_ic3
 
 
+def dial_adjoint_supported(m_max, H, rev):
+    """nmarl_dial_msg_adjoint handles this message layer: 64 units, at most 4 slots and 4 sources per agent."""
+    return H == FUSED_H and m_max <= 4 and rev is not None and rev['r_max'] <= 4
+
+
+def dial_adjoint_images(w_msg, mfc_w):
+    """The LDS images nmarl_dial_msg_adjoint multiplies by: of the transposed 64 x 64 blocks of w_msg [N,64 m,64] and of
+    mfc_w^T [N,64,64] (nmarl_lstm_msg_wimage layout); once per update."""
+    N, K, H = w_msg.shape
+    wt = w_msg.reshape(N, K // H, H, H).transpose(2, 3).reshape(N, K, H).contiguous()
+    return lstm_msg_wimage(wt), lstm_msg_wimage(mfc_w.transpose(1, 2).contiguous())
+
+
+def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2, dh):
+    """lstm_dial's message adjoint of one reverse step in ONE launch (nmarl_dial_msg_adjoint): d1 = ds * (hm > 0),
+    d2 = gather_adjoint(d1 @ w_msg^T) * (msg > 0), dh = dhd + d2 @ mfc_w^T; all [N,E,64] panels.  imgs = dial_adjoint_images(w_msg,
+    mfc_w), rev = reverse_neighbor_table(nbr_idx, COUPLED_NC) (w_msg / mfc_w / nbr_idx themselves: the restatement's inputs)."""
+    N, E, H = ds.shape
+    check(lib.nmarl_dial_msg_adjoint(E, N, nbr_idx.shape[1], *_pn(ds), *_pn(hm), *_pn(msg), *_pn(dhd), ptr(imgs[0], F32), imgs[0].stride(0),
+                                     ptr(imgs[1], F32), imgs[1].stride(0), ptr(rev['rev_agent'], torch.int32), ptr(rev['rev_col'], torch.int32),
+                                     ptr(rev['rev_w'], F32), rev['r_row'], *_pn(d1), *_pn(d2), *_pn(dh), stream()), 'nmarl_dial_msg_adjoint')
+    return dh
+
+
 def lstm_bptt_msg_wimage(w_msg, out=None):
     """LDS image of w_msg [N,K,64] (K = 64 or 128) for the message adjoint inside nmarl_lstm_bptt_coupled."""
     N, K, J = w_msg.shape

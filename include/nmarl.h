@@ -393,7 +393,7 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
  *           un-masked previous h; agent stride src_sn, rows contiguous); s = hm + enc is the LSTM input (KX = 64).  out2 (may
  *           be NULL) receives hm, out receives s.  src may not overlap out / out2; h_new MAY be h_in (the pre-phase reads no
  *           h).  Heads 1 and 2 only (the re-step's message vectors need the senders' NEW h: a launch of the caller).
- * w_msg comes as the image of nmarl_lstm_msg_wimage (K*64 floats per agent: image[k][c][t] = w_msg[k][16t+c]); nbr_idx
+ * w_msg comes as the image of nmarl_lstm_msg_wimage (K*64 floats per agent, K <= 256: image[k][c][t] = w_msg[k][4c+t]); nbr_idx
  * [N,m_max] (-1 padded, ascending); enc [N,E,64] with row pitch enc_row (kind 2).  out (may be NULL): where the 64
  * computed columns are stored for the update's backward ([N,E,64] view, row pitch out_row).  head: kind 1 or 2.
  * NO ALIASING: the pre-phase reads the other agents' panels of h_in while their blocks write h_new, so no [E,64] panel
@@ -527,6 +527,25 @@ int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stream);
  */
 int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x_sn, const float* bias,
                    int64_t bias_sn, int32_t act, float* y, int64_t y_sn, int64_t y_row, void* stream);
+/*
+ * lstm_dial's message adjoint of ONE reverse step of the update, all agents in one launch -- the backward of
+ * agents/utils.py:560-580 (msg_j = relu(h_j w_mfc + b) on the sender, hm_i = relu([msg_j : j in nbr(i)] w_msg + b_msg) on the
+ * receiver, s_i = enc_i + hm_i), given ds = dL/ds of this step (nmarl_lstm_bptt_step's dx) and dhd = dz @ wh^T:
+ *   d1_i   = ds_i * (hm_i > 0)
+ *   dmsg_j = sum over (i, k) with nbr(i, k) == j of d1_i @ w_msg_i[64 k : 64 k + 64, :]^T
+ *   d2_j   = dmsg_j * (msg_j > 0)
+ *   dh_j   = dhd_j + d2_j @ w_mfc_j^T
+ * All of ds, hm, msg, dhd, d1, d2, dh are [N,E,64] panels (agent strides in floats, rows contiguous, 16-byte aligned); the
+ * outputs may not overlap the inputs.  img_msg_t: nmarl_lstm_msg_wimage of the [N, 64 m_max, 64] tensor whose row block k is
+ * w_msg[:, 64 k : 64 k + 64, :]^T; img_mfc_t: the same image of w_mfc^T.  rev_agent / rev_col / rev_w [N, r_row] (r_row 2 or
+ * 4): for every agent its sources (i, 64 k) with weight 1, padded with (own index, 0, weight 0); entries must be valid
+ * (agents < N, columns < 64 m_max) -- device memory, not checked.  m_max <= 4.
+ */
+int nmarl_dial_msg_adjoint(int64_t E, int32_t N, int32_t m_max, const float* ds, int64_t ds_sn, const float* hm,
+                           int64_t hm_sn, const float* msg, int64_t msg_sn, const float* dhd, int64_t dhd_sn,
+                           const float* img_msg_t, int64_t img_msg_sn, const float* img_mfc_t, int64_t img_mfc_sn,
+                           const int32_t* rev_agent, const int32_t* rev_col, const float* rev_w, int32_t r_row,
+                           float* d1, int64_t d1_sn, float* d2, int64_t d2_sn, float* dh, int64_t dh_sn, void* stream);
 /*
  * lstm_dial's own-action term (agents/utils.py:577: one_hot(argmax(p_i), n_h), added to the encoded observation at :579):
  * y[n,r,argmax_a p[n,r,a]] += scale[n] (scale NULL: 1; lstm_dial_hetero, agents/utils.py:676-688, gives agents without

@@ -513,6 +513,26 @@ def reverse_neighbor_table(nbr_idx, kind):
     return dict(nbr_idx=nbr_idx, r_max=1, r_row=2, symmetric=True)
 
 
+def dial_adjoint_supported(m_max, H, rev):
+    return H == FUSED_H and m_max <= 4 and rev is not None
+
+
+def dial_adjoint_images(w_msg, mfc_w):
+    return None                    # the restatement multiplies by the weights themselves
+
+
+def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2, dh):
+    """Backward of lstm_dial's message path for one step (agents/utils.py:560-580 read backwards): relu mask of the
+    receiver layer, d1 @ w_msg^T scattered back to the senders (adjoint of the neighbour gather), relu mask of the sender
+    layer, + the recurrent part: dh = dhd + d2 @ mfc_w^T."""
+    H = ds.shape[-1]
+    d1.copy_(ds * (hm > 0).to(ds.dtype))
+    dmsg = nbr_gather_bwd(torch.bmm(d1, w_msg.transpose(1, 2)), nbr_idx, H)
+    d2.copy_(dmsg * (msg > 0).to(ds.dtype))
+    dh.copy_(dhd + torch.bmm(d2, mfc_w.transpose(1, 2)))
+    return dh
+
+
 def bptt_coupled_supported(kind, m_max, H, rev=None):
     return ((kind == COUPLED_NC and m_max <= 2) or kind == COUPLED_IC3) and not (
         rev is not None and kind == COUPLED_NC and rev['r_max'] > 2)

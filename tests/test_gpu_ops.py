@@ -1055,6 +1055,45 @@ def test_lstm_step_x_dial_message_term(N, E, A, m_max):
                                    h_out=h2, c_out=c2, gates=gg, **draw)
 
 
+@pytest.mark.parametrize('N,E,topo', [(8, 4096, 'line'), (5, 130, 'line'), (9, 200, 'grid'), (6, 77, 'ragged')])
+def test_dial_msg_adjoint(N, E, topo):
+    """lstm_dial's message adjoint of one reverse step in one launch (nmarl_dial_msg_adjoint) vs the float64 restatement built
+    from the autograd adjoint of the neighbour gather: both relu masks, 2- and 4-source agents, agents without sources, ragged
+    -1 padded tables (asymmetric), slices of wider [N,T,E,64] buffers as operands."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H = 64
+    g = torch.Generator().manual_seed(N * 7 + E)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    if topo == 'ragged':
+        m_max = 2
+        idx = -torch.ones(N, m_max, dtype=torch.int32)
+        idx[0, 0], idx[1, 0], idx[1, 1], idx[2, 0], idx[4, 0], idx[4, 1] = 3, 0, 3, 3, 1, 3       # agent 3: four sources, 5: none at all
+    else:
+        idx, _ = ops.neighbor_table(_topology(N, topo), 'cpu')
+        m_max = idx.shape[1]
+    T = 3
+    DS, HM, MSG = r(N, T, E, H), torch.relu(r(N, T, E, H)), torch.relu(r(N, T, E, H))
+    dhd = r(N, E, H)
+    w_msg, mfc_w = r(N, H * m_max, H) * 0.2, r(N, H, H) * 0.2
+    f64 = lambda t: t.double()                                                           # noqa: E731
+    d1r, d2r, dhr = (torch.zeros(N, E, H, dtype=torch.float64) for _ in range(3))
+    ops_ref.dial_msg_adjoint(f64(DS[:, 1]), f64(HM[:, 1]), f64(MSG[:, 1]), f64(dhd), f64(w_msg), f64(mfc_w), idx, None, None, d1r, d2r, dhr)
+    rev = ops.reverse_neighbor_table(idx.cuda(), ops.COUPLED_NC)
+    assert ops.dial_adjoint_supported(m_max, H, rev)
+    imgs = ops.dial_adjoint_images(w_msg.cuda(), mfc_w.cuda())
+    DSg, HMg, MSGg = DS.cuda(), HM.cuda(), MSG.cuda()
+    D1, D2 = torch.zeros(N, T, E, H, device='cuda'), torch.zeros(N, T, E, H, device='cuda')
+    dh = torch.zeros(N, E, H, device='cuda')
+    out = ops.dial_msg_adjoint(DSg[:, 1], HMg[:, 1], MSGg[:, 1], dhd.cuda(), w_msg.cuda(), mfc_w.cuda(), idx.cuda(), imgs, rev,
+                               D1[:, 1], D2[:, 1], dh)
+    assert out is dh
+    assert torch.equal(D1[:, 1].cpu().double(), d1r)                   # a mask: exact
+    torch.testing.assert_close(D2[:, 1].cpu().double(), d2r, rtol=2e-5, atol=1e-5)
+    torch.testing.assert_close(dh.cpu().double(), dhr, rtol=2e-5, atol=1e-5)
+    assert float(D1[:, 0].abs().max()) == 0.0 and float(D1[:, 2].abs().max()) == 0.0 and float(D2[:, 0].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('N,E,A', [(8, 4096, 4), (3, 77, 5)])
 def test_onehot_argmax_add(N, E, A):
     """lstm_dial's own-action term (agents/utils.py:577-579) in one launch vs one_hot(argmax): first maximum on ties, per-agent

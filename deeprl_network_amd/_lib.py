@@ -57,7 +57,9 @@ class Msg(C.Structure):
                 ('ob', C.c_void_p), ('ob_row', C.c_int64), ('ob_F', C.c_int32), ('ob_segs', C.c_int32), ('ob_nbr', C.c_void_p),
                 ('ob_img', C.c_void_p), ('ob_img_sn', C.c_int64), ('ob_b', C.c_void_p), ('ob_b_sn', C.c_int64),
                 ('status', C.c_void_p), ('src', C.c_void_p), ('src_sn', C.c_int64),
-                ('out2', C.c_void_p), ('out2_sn', C.c_int64), ('out2_row', C.c_int64)]
+                ('out2', C.c_void_p), ('out2_sn', C.c_int64), ('out2_row', C.c_int64),
+                ('next_img', C.c_void_p), ('next_img_sn', C.c_int64), ('next_b', C.c_void_p), ('next_b_sn', C.c_int64),
+                ('next_out', C.c_void_p), ('next_out_sn', C.c_int64)]
 
 
 class NetParams(C.Structure):

@@ -206,7 +206,11 @@ class IA2C:
         self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.buf_vn = torch.zeros(N, T, E, dtype=F32, device=d)          # agent-major values (critic's h part)
         # coupled nets: further per-step message terms the backward needs (policy.save_spec)
-        p._extra = {k: torch.zeros(N, T, E, w, dtype=F32, device=d) for k, w in p.save_spec().items()}
+        # (`save_next` keys: one slab more -- the policy step of lock-step t fills slot t + 1, e.g. lstm_dial's message vectors)
+        nxt = getattr(p, 'save_next', ())
+        full = {k: torch.zeros(N, T + 1 if k in nxt else T, E, w, dtype=F32, device=d) for k, w in p.save_spec().items()}
+        p._extra = {k: v[:, :T] for k, v in full.items()}
+        self._extra_next = {k: full[k] for k in nxt if k in full}
         self.save_acts = True
         return True
 
@@ -229,6 +233,8 @@ class IA2C:
         """Slots of lock-step t in the saved activations, for the policy step of a coupled net."""
         d = {k: v[:, t] for k, v in self.policy._extra.items()}
         d['S'] = self.S_buf[:, t]
+        for k, v in getattr(self, '_extra_next', {}).items():
+            d[k + '_next'] = v[:, t + 1]
         return d
 
     # ------------------------------------------------------------------ batched engine

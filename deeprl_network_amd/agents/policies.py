@@ -959,15 +959,59 @@ class DIALMultiAgentPolicy(BatchedPolicy):
 
     _x_target = IC3MultiAgentPolicy._x_target
 
+    # -- the sender layer msg = relu(h W_mfc + b) of the NEW h in the policy step's epilogue (csrc/lstm_mfma.hip NXT): the value
+    # re-step and the next lock-step's policy step gather it as it is -- no fc launch on h in between
+    save_next = ('A2',)       # save slots the policy step of lock-step t fills for lock-step t + 1 (models.enable_saved_acts)
+    _mfc_img = None
+    _m_next = None            # (pointer, version, message vectors) of the h the last policy step produced
+    _h_out = None
+    _nxt = None
+
+    def refresh_wimage(self):
+        super().refresh_wimage()
+        if self._msg_img is not None:
+            self._mfc_img = ops.lstm_msg_wimage(self.params['mfc_w'], out=self._mfc_img)
+        self._m_next = None   # the weights may have changed: vectors of the old sender layer are stale
+
+    def _cached_msg(self, h):
+        """The message vectors of exactly this h, if the last policy step left them: same memory, and no in-place torch op on it
+        since (version counter; kernels writing through raw pointers are the policy steps themselves)."""
+        m = self._m_next
+        if m is not None and m[0] == h.data_ptr() and m[1] == h._version and m[2].shape == h.shape:
+            return m[2]
+        return None
+
+    def step_policy(self, enc, h, c, done, h_out, c_out, pi_out, act_out, done_is_zero=False, gates=None, save=None, **draw):
+        self._nxt, self._h_out = None, h_out
+        try:
+            r = super().step_policy(enc, h, c, done, h_out, c_out, pi_out, act_out, done_is_zero, gates=gates, save=save, **draw)
+        finally:
+            self._h_out = None
+        self._m_next = None if self._nxt is None else (h_out.data_ptr(), h_out._version, self._nxt)
+        return r
+
     def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params
         keep = save is not None and not second
-        msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU, out=save['A2'] if keep else None)
-        if fuse_msg and self._msg() is not None:
+        fused = fuse_msg and self._msg() is not None
+        msg = self._cached_msg(h) if fused else None
+        if msg is None:
+            msg = self._fc_infer(h, 'mfc_w', 'mfc_b', ops.BIAS_RELU, out=save['A2'] if keep else None)
+        elif keep and msg.data_ptr() != save['A2'].data_ptr():
+            save['A2'].copy_(msg)
+        if fused:
             # hm = relu([msg_j] W_msg + b) and s = hm + enc inside the step kernel (csrc/lstm_mfma.hip MSG 3): no gather / GEMM /
             # bias-activation / add launches; the policy step keeps hm (relu mask of the backward) and s (the LSTM input)
-            return None, None, (None, p['wx_hid'], self._img, None,
-                                self._msg(src=msg, enc=enc, out=save['S'] if keep else None, out2=save['A1'] if keep else None))
+            m = self._msg(src=msg, enc=enc, out=save['S'] if keep else None, out2=save['A1'] if keep else None)
+            if not second and self._h_out is not None and self._mfc_img is not None:
+                nxt = save.get('A2_next') if keep else None
+                if nxt is None:
+                    nxt = self._scratch('_mn0', h)
+                    if nxt.data_ptr() == msg.data_ptr():
+                        nxt = self._scratch('_mn1', h)
+                m['next'] = dict(img=self._mfc_img, b=p['mfc_b'], w=p['mfc_w'], out=nxt)
+                self._nxt = nxt
+            return None, None, (None, p['wx_hid'], self._img, None, m)
         hm = self._fc_infer(ops.nbr_gather(msg, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_RELU,
                             out=save['A1'] if keep else None)
         if self.xside:

@@ -494,6 +494,11 @@ struct XArgs {
     float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
     const float* src; int64_t src_sn;             // MSG 3: the senders' message vectors [N,E,64] the pre-phase gathers (instead of h)
     float* xm2_out; int64_t xm2_sn, xm2_row;      // MSG 3: where hm = relu(.) is kept BEFORE enc is added (may be NULL)
+    // MSG 3, HEAD 1, nxt_out != NULL: the SENDER layer on the new h, msg' = relu(h' W_mfc + b) -> nxt_out [N,E,64]: what the value
+    // re-step and the next lock-step's policy step gather (instead of an fc launch on h' in between)
+    const float* nxt_img; int64_t nxt_img_sn;     // nmarl_lstm_msg_wimage of W_mfc [N,64,64]
+    const float* nxt_b; int64_t nxt_b_sn;
+    float* nxt_out; int64_t nxt_out_sn;
     unsigned* sync;               // HEAD 4: [0] generation, [1] blocks finished, [2] error, [16 + (agent, block, wave)] flags
     // HEAD 4 + MSG 2, ob != NULL: lstm_ic3's observation encoder enc = tanh([x_i | x_nbr] W_ob + b_ob) (agents/utils.py:395-399)
     // runs here as well, from the env's compact observation; its result goes to `enc` (the update needs it) before it is used
@@ -767,6 +772,17 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) oi[q] = g[threadIdx.x + 512 * q];
     }
+    // the sender layer of the new h (lstm_dial's policy step): its image and bias requested here, stored over the W_msg image
+    // once the K loop is through (every wave has left the pre-phase by then)
+    constexpr bool NXT = HEAD == 1 && MSG == 3;
+    const bool nxt_here = NXT && xa.nxt_out != nullptr;
+    float4 nf[NXT ? 2 : 1], nb4 = float4{0.f, 0.f, 0.f, 0.f};
+    if (NXT) {
+        const float4* g = nxt_here ? reinterpret_cast<const float4*>(xa.nxt_img + (int64_t)n * xa.nxt_img_sn) : img;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) nf[q] = g[threadIdx.x + 512 * q];
+        nb4 = *reinterpret_cast<const float4*>((nxt_here ? xa.nxt_b + (int64_t)n * xa.nxt_b_sn : xa.msg_b + (int64_t)n * xa.msg_b_sn) + 4 * (lane & 15));
+    }
     // msg_load: request the neighbour rows of one round (MSG 1: both slots, all four half-chunks; MSG 2: neighbours k0 .. k0 + 3,
     // both chunks) -- every row BEFORE the first product, absent slots read the own row with weight 0 (no load inside a branch).
     // U: MSG 1 [kc][half], MSG 2 [q][kc][half].
@@ -1026,6 +1042,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         NMARL_CHUNK(buf, a0, a1)
     }
     NMARL_STAMP(20)
+    if (nxt_here) {                              // (after the last tick's barrier: the W_msg image is dead)
+        float4* d = reinterpret_cast<float4*>(m_lds);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) d[threadIdx.x + 512 * q] = nf[q];
+    }
     const unsigned epoch = HEAD == 4 ? (unsigned)__builtin_amdgcn_readfirstlane((int)epoch_raw) + 1u : 0u;
 
     // ---- lane-local cell epilogue.  A lane holds units 4 c .. 4 c + 3 of rows 4 grp + r (column permutation of the image):
@@ -1081,6 +1102,27 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         else head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
     }
     NMARL_STAMP(22)
+    if (nxt_here) {
+        // ---- msg' = relu(h' W_mfc + b): h' is in the wave's tile (A layout source), the image in LDS behind this barrier
+        __syncthreads();
+        f32x4 facc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) facc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const float* t_ = a_tile + c * APITCH + kc * CH_K + 4 * grp;
+            const float4 m0 = float4{t_[0], t_[1], t_[2], t_[3]};
+            const float4 m1 = float4{t_[16], t_[17], t_[18], t_[19]};
+            NMARL_MCHUNK(facc, m_lds, kc, m0, m1)
+        }
+        float* no = xa.nxt_out + (int64_t)n * xa.nxt_out_sn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (row0 + 4 * grp + r < a.E)
+                *reinterpret_cast<float4*>(no + (row0 + 4 * grp + r) * H + 4 * c) =
+                    float4{fmaxf(facc[0][r] + nb4.x, 0.0f), fmaxf(facc[1][r] + nb4.y, 0.0f), fmaxf(facc[2][r] + nb4.z, 0.0f),
+                           fmaxf(facc[3][r] + nb4.w, 0.0f)};
+    }
     if (HEAD == 4) {
         // ---- publish: this wave's 16 rows of h' are out (write-through stores drained), one flag per (agent, block, wave)
         gu32* flags = (gu32*)(xa.sync + 16);
@@ -1459,6 +1501,15 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.enc_row = msg->enc_row; xa.xm_out = msg->out; xa.xm_sn = msg->out_sn; xa.xm_row = msg->out_row;
         if (mk == 3) {
             xa.src = msg->src; xa.src_sn = msg->src_sn; xa.xm2_out = msg->out2; xa.xm2_sn = msg->out2_sn; xa.xm2_row = msg->out2_row;
+            if (msg->next_out) {
+                const int kd = head ? head->kind : 0;
+                if (kd != 1 || !msg->next_img || !msg->next_b || msg->next_img_sn < H * 64 || (msg->next_img_sn % 4) ||
+                    ((uintptr_t)msg->next_img % 16) || msg->next_b_sn < H || (msg->next_b_sn % 4) || ((uintptr_t)msg->next_b % 16) ||
+                    msg->next_out_sn < E * (int64_t)H || (msg->next_out_sn % 4) || ((uintptr_t)msg->next_out % 16))
+                    return NMARL_EINVAL;
+                xa.nxt_img = msg->next_img; xa.nxt_img_sn = msg->next_img_sn; xa.nxt_b = msg->next_b; xa.nxt_b_sn = msg->next_b_sn;
+                xa.nxt_out = msg->next_out; xa.nxt_out_sn = msg->next_out_sn;
+            }
         }
     }
     static NmarlPerDeviceOnce lds_once;

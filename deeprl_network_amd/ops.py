@@ -273,6 +273,11 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             m.src, m.src_sn = ptr(src, F32, strided=True), src.stride(0)
             if msg.get('out2') is not None:
                 m.out2, m.out2_sn, m.out2_row = _rows_view(msg['out2'], H, what + ' msg out2')
+            nxt = msg.get('next')          # dict(img, b, out[, w]): the sender layer on the NEW h (policy step only)
+            if nxt is not None:
+                m.next_img, m.next_img_sn = ptr(nxt['img'], F32), nxt['img'].stride(0)
+                m.next_b, m.next_b_sn = _bias(nxt['b'])
+                m.next_out, m.next_out_sn = _pn(nxt['out'])
         ob = msg.get('ob')
         if ob is not None:                     # lstm_ic3's observation encoder inside the launch (one-launch step only): writes msg['enc']
             x_ob = ob['x']                     # compact observation [E,N,F]

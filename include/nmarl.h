@@ -392,7 +392,10 @@ int nmarl_lstm_step_x(int64_t E, int32_t N, int32_t H, int32_t KX, const float* 
  *           the SENDERS' message vectors src [N,E,64] (msg_j = relu(h_j w_mfc + b), one nmarl_fc_fwd of the caller on the
  *           un-masked previous h; agent stride src_sn, rows contiguous); s = hm + enc is the LSTM input (KX = 64).  out2 (may
  *           be NULL) receives hm, out receives s.  src may not overlap out / out2; h_new MAY be h_in (the pre-phase reads no
- *           h).  Heads 1 and 2 only (the re-step's message vectors need the senders' NEW h: a launch of the caller).
+ *           h).  Heads 1 and 2 only (the re-step's message vectors need the senders' NEW h).  Head 1 with next_out != NULL
+ *           also runs the sender layer on the new h: next_out [N,E,64] (agent stride next_out_sn, rows contiguous; may not
+ *           overlap src) = relu(h_new @ w_mfc + b_mfc), next_img = nmarl_lstm_msg_wimage of w_mfc [N,64,64], next_b [N,64]
+ *           -- the src of the value re-step and of the next lock-step's policy step, without an fc launch in between.
  * w_msg comes as the image of nmarl_lstm_msg_wimage (K*64 floats per agent, K <= 256: image[k][c][t] = w_msg[k][4c+t]); nbr_idx
  * [N,m_max] (-1 padded, ascending); enc [N,E,64] with row pitch enc_row (kind 2).  out (may be NULL): where the 64
  * computed columns are stored for the update's backward ([N,E,64] view, row pitch out_row).  head: kind 1 or 2.
@@ -428,6 +431,9 @@ typedef struct nmarl_msg {
     int32_t* status;    /* head kind 3 only, may be NULL: hand-off status words (word 0 <- 1 when a wave gives up) */
     const float* src; int64_t src_sn;               /* kind 3: the senders' message vectors [N,E,64] */
     float* out2; int64_t out2_sn, out2_row;         /* kind 3, may be NULL: hm before enc is added ([N,E,64] view) */
+    const float* next_img; int64_t next_img_sn;     /* kind 3, head 1, with next_out: image of w_mfc */
+    const float* next_b; int64_t next_b_sn;
+    float* next_out; int64_t next_out_sn;           /* kind 3, head 1, may be NULL: relu(h_new @ w_mfc + b_mfc) */
 } nmarl_msg_t;
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_sync_words(int64_t E, int32_t N);

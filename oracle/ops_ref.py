@@ -230,6 +230,9 @@ def lstm_step_policy(h, wh, bias, zadd1, zadd2, c_prev, done, c_out, h_out, pi_w
                      u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None, gates=None):
     """forward('p') (policies.py:119-123, 50-57) + the action draw (utils.py:135-141) after one LSTM step."""
     lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs=xs)
+    nxt = xs[4].get('next') if xs is not None and len(xs) > 4 and xs[4] is not None else None
+    if nxt is not None:                                # lstm_dial: the sender layer on the new h (agents/utils.py:566-569)
+        nxt['out'].copy_(torch.relu(torch.bmm(h_out, nxt['w']) + nxt['b'].unsqueeze(1)))
     pi_out.copy_(torch.softmax(torch.bmm(h_out, pi_w) + pi_b.unsqueeze(1), dim=-1))
     sample_actions(pi_out, act_out, mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
     return pi_out, act_out

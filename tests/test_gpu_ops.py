@@ -1008,7 +1008,10 @@ def test_lstm_step_x_dial_message_term(N, E, A, m_max):
     cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
     draw = dict(mode=2, seed=5, env_id_base=40, step=3)
     s_r, hm_r = torch.zeros(N, E, H, dtype=torch.float64), torch.zeros(N, E, H, dtype=torch.float64)
-    msg_r = dict(kind=3, nbr_idx=idx, w_msg=f64(w_msg), b_msg=f64(b_msg), enc=f64(enc), src=f64(src), out=s_r, out2=hm_r)
+    mfc_w, mfc_b = r(N, H, H) * 0.3, r(N, H) * 0.2
+    nxt_r = torch.zeros(N, E, H, dtype=torch.float64)
+    msg_r = dict(kind=3, nbr_idx=idx, w_msg=f64(w_msg), b_msg=f64(b_msg), enc=f64(enc), src=f64(src), out=s_r, out2=hm_r,
+                 next=dict(w=f64(mfc_w), b=f64(mfc_b), out=nxt_r))
     hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
     pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
     gr = torch.zeros(N, E, 4 * H, dtype=torch.float64)
@@ -1019,9 +1022,13 @@ def test_lstm_step_x_dial_message_term(N, E, A, m_max):
     save = torch.zeros(N, 3, E, H, device='cuda')                     # slots of a wider buffer: agent stride 3 E H
     msg_g = dict(kind=3, nbr_idx=cu(idx), w_msg=cu(w_msg), b_msg=cu(b_msg), img=mimg, enc=cu(enc), src=cu(src), out=save[:, 0],
                  out2=save[:, 2])
+    nxt_g = torch.zeros(N, 2, E, H, device='cuda')                    # the sender layer on the new h: slot 1 of a wider buffer
     tol = dict(rtol=5e-5, atol=1e-5)
     for inplace in (False, True):
         save.zero_()
+        nxt_g.zero_()
+        if inplace:
+            msg_g = dict(msg_g, next=dict(img=ops.lstm_msg_wimage(cu(mfc_w)), b=cu(mfc_b), out=nxt_g[:, 1]))
         hin, cin = cu(h), cu(c)
         hg, cg = (hin, cin) if inplace else (torch.zeros(N, E, H, device='cuda'), torch.zeros(N, E, H, device='cuda'))
         pig, actg, gg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.zeros(N, E, 4 * H, device='cuda')
@@ -1034,6 +1041,11 @@ def test_lstm_step_x_dial_message_term(N, E, A, m_max):
         torch.testing.assert_close(cg.cpu().double(), cr, **tol)
         torch.testing.assert_close(gg.cpu().double(), gr, **tol)
         torch.testing.assert_close(pig.cpu().double(), pir, **tol)
+        if inplace:
+            torch.testing.assert_close(nxt_g[:, 1].cpu().double(), nxt_r, **tol)
+            assert float(nxt_r.abs().max()) > 0
+        assert float(nxt_g[:, 0].abs().max()) == 0.0 and (inplace or float(nxt_g.abs().max()) == 0.0)
+    msg_g.pop('next')
     act_chk = torch.zeros(E, N, dtype=torch.uint8)
     ops_ref.sample_actions(pig.cpu(), act_chk, **draw)
     assert torch.equal(actg.cpu(), act_chk)
@@ -1041,7 +1053,7 @@ def test_lstm_step_x_dial_message_term(N, E, A, m_max):
     src2 = torch.relu(r(N, E, H))
     vr = torch.zeros(N, E, dtype=torch.float64)
     ops_ref.lstm_step_value(hr, f64(wh), f64(b), None, None, cr, f64(done), torch.empty_like(cr), torch.empty_like(hr), f64(v_w),
-                            f64(v_b), act_chk, idx, A, vr, xs=(None, f64(wx), None, None, dict(msg_r, src=f64(src2), out=None, out2=None)))
+                            f64(v_b), act_chk, idx, A, vr, xs=(None, f64(wx), None, None, dict(msg_r, src=f64(src2), out=None, out2=None, next=None)))
     vg, h2, c2 = torch.zeros(N, E, device='cuda'), torch.zeros_like(hg), torch.zeros_like(cg)
     keep = save.clone()
     ops.lstm_step_value(hg, None, cu(b), None, None, cg, cu(done), c2, h2, cu(v_w), cu(v_b), actg, cu(idx), A, vg,

@@ -83,6 +83,39 @@ def test_coupled_one_launch_branch_equals_two_launch_branch(agent, monkeypatch):
         torch.testing.assert_close(m_one.policy.params.flat, m_two.policy.params.flat, rtol=1e-4, atol=1e-6)
 
 
+def test_dial_sender_layer_in_the_policy_step_equals_fc_launches(monkeypatch):
+    """lstm_dial: the policy step also runs the sender layer on the new h (msg['next']), the value re-step and the next
+    lock-step's policy step re-use its output (DIALMultiAgentPolicy._cached_msg) -- ONE fc launch on h per batch (lock-step 0:
+    the weights changed) instead of two per lock-step; same actions, values, saved message terms and weights as the fc path."""
+    from deeprl_network_amd.agents.policies import DIALMultiAgentPolicy
+    calls = {'n': 0}
+    orig = DIALMultiAgentPolicy._fc_infer
+
+    def counting(self, x, w_key, b_key, act, out=None):
+        calls['n'] += w_key == 'mfc_w'
+        return orig(self, x, w_key, b_key, act, out=out)
+    monkeypatch.setattr(DIALMultiAgentPolicy, '_fc_infer', counting)
+    with cpu_ops():
+        _, m_new, t_new = build('ma2c_dial', E=3)
+        for _ in range(4):
+            t_new.run_batch()
+        assert m_new.save_acts and m_new.policy._msg() is not None
+        n_new = calls['n']
+        assert n_new == 4                                   # lock-step 0 of each batch
+        calls['n'] = 0
+        monkeypatch.setattr(DIALMultiAgentPolicy, '_cached_msg', lambda self, h: None)
+        monkeypatch.setattr(DIALMultiAgentPolicy, '_mfc_img', property(lambda self: None, lambda self, v: None))
+        _, m_old, t_old = build('ma2c_dial', E=3)
+        for _ in range(4):
+            t_old.run_batch()
+        assert calls['n'] == 4 * (2 * 10 + 2)               # policy + value step of 10 lock-steps and of the bootstrap
+        assert torch.equal(m_new.buf_act, m_old.buf_act)
+        torch.testing.assert_close(m_new.buf_v, m_old.buf_v, rtol=1e-5, atol=1e-6)
+        for k in ('A1', 'A2'):
+            torch.testing.assert_close(m_new.policy._extra[k], m_old.policy._extra[k], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(m_new.policy.params.flat, m_old.policy.params.flat, rtol=1e-4, atol=1e-6)
+
+
 def test_batch_invariance_of_rollout():
     """Replica e of an E-replica rollout == the same replica rolled out alone (same Philox ids)."""
     with cpu_ops():

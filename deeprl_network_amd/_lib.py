@@ -173,7 +173,8 @@ SIGNATURES = {
     'nmarl_fc_fwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _i32, _p, _i64, _i64, _p],
     'nmarl_fc_fwd_multi': [_i64, _i32, _i32, C.POINTER(FcPart), _i32, _p, _i64, _i64, _p],
     'nmarl_dial_msg_adjoint': [_i64, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i32,
-                               _p, _i64, _p, _i64, _p, _i64, _p],
+                               _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_dial_msg_adjoint_parts': [_i64],
     'nmarl_onehot_argmax_add': [_i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],

@@ -230,7 +230,8 @@ class CoupledSequenceSaved(torch.autograd.Function):
             # lstm_dial: the whole message adjoint of a step (both relu masks, gather adjoint, both products) in ONE more launch
             rev_d = _reverse_table(nbr_idx, ops.COUPLED_NC)
             if ops.dial_adjoint_supported(nbr_idx.shape[1], H, rev_d):
-                adj = (ops.dial_adjoint_images(w_msg, mfc_w), rev_d, torch.empty(N, E, H, dtype=F32, device=dev))
+                adj = (ops.dial_adjoint_images(w_msg, mfc_w), rev_d, torch.empty(N, E, H, dtype=F32, device=dev),
+                       ops.dial_adjoint_bias_parts(N, E, dev))
         for t in (range(T - 1, -1, -1) if rev is None else ()):
             if fused:
                 ops.bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next,
@@ -240,7 +241,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
                 dhd = dhd_buf
                 if adj is not None:
                     dh_rec = ops.dial_msg_adjoint(DS[:, t], hm[:, t], A2[:, t], dhd, w_msg, mfc_w, nbr_idx, adj[0], adj[1],
-                                                  D1[:, t], D2[:, t], adj[2])
+                                                  D1[:, t], D2[:, t], adj[2], bias_parts=adj[3])
                     continue
                 if kind == 'dial':
                     torch.mul(DS[:, t], (hm[:, t] > 0), out=D1[:, t])
@@ -307,7 +308,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
         D1f = D1.view(N, R, H)
         if db is None:
             db = dZf.sum(dim=1)
-            dbmsg = D1f.sum(dim=1)
+            dbmsg = D1f.sum(dim=1) if adj is None else adj[3][0].sum(dim=1)     # (lstm_dial: summed inside the adjoint kernel)
         dwx = ops.wgrad(S.view(N, R, S.shape[-1]), dZf)        # the whole x-side weight in one GEMM
         dmfc_w = dmfc_b = None
         if kind == 'nc':
@@ -320,7 +321,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
             D2f = D2.view(N, R, H)
             dwmsg = ops.wgrad(ops.nbr_gather(A2.reshape(N, R, H), nbr_idx), D1f)
             dmfc_w = ops.wgrad(Hp, D2f)
-            dmfc_b = D2f.sum(dim=1)
+            dmfc_b = D2f.sum(dim=1) if adj is None else adj[3][1].sum(dim=1)
             denc = DS
         return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b, None, None, None, None, None, None, None)
 

@@ -31,6 +31,8 @@ struct AdjArgs {
     const float* rev_w;                          // [N, RS]: 1 for a source, 0 for padding
     float *d1, *d2, *dh;
     int64_t d1_sn, d2_sn, dh_sn;
+    float *b1_part, *b2_part;                    // [N][parts][64] running column sums of d1 / d2 (the two bias gradients), or NULL
+    int64_t b1_sn, b2_sn;
     int64_t E;
     int blocks_per_agent;
 };
@@ -138,6 +140,7 @@ __global__ __launch_bounds__(512, 1) void dial_msg_adjoint_kernel(const AdjArgs 
     // d1 (own rows), d2 = dmsg * (msg > 0) -> global memory and the wave's tile
     float* d1n = a.d1 + (int64_t)n * a.d1_sn;
     float* d2n = a.d2 + (int64_t)n * a.d2_sn;
+    float4 s1 = float4{0.f, 0.f, 0.f, 0.f}, s2 = float4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const bool live = row0 + 4 * grp + r < a.E;
@@ -146,6 +149,8 @@ __global__ __launch_bounds__(512, 1) void dial_msg_adjoint_kernel(const AdjArgs 
         if (live) {
             *reinterpret_cast<float4*>(d1n + rofs[r] * H + 4 * c) = v1;
             *reinterpret_cast<float4*>(d2n + rofs[r] * H + 4 * c) = v2;
+            s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+            s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
         }
         float* t_ = tile + (4 * grp + r) * APITCH + 4 * c;
         t_[0] = v2.x; t_[1] = v2.y; t_[2] = v2.z; t_[3] = v2.w;
@@ -169,6 +174,22 @@ __global__ __launch_bounds__(512, 1) void dial_msg_adjoint_kernel(const AdjArgs 
     for (int r = 0; r < 4; ++r)
         if (row0 + 4 * grp + r < a.E)
             *reinterpret_cast<float4*>(dhn + rofs[r] * H + 4 * c) = float4{acc2[0][r], acc2[1][r], acc2[2][r], acc2[3][r]};
+    // the two bias gradients on the way: this wave's 16-row column sums, added to ITS slot of the running partial sums (one
+    // launch per reverse step on one stream: the read-modify-write needs no atomics; fixed order -> deterministic)
+    if (a.b1_part) {
+#define NMARL_QSUM(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        NMARL_QSUM(s1.x) NMARL_QSUM(s1.y) NMARL_QSUM(s1.z) NMARL_QSUM(s1.w)
+        NMARL_QSUM(s2.x) NMARL_QSUM(s2.y) NMARL_QSUM(s2.z) NMARL_QSUM(s2.w)
+#undef NMARL_QSUM
+        if (grp == 0) {
+            const int64_t slot = ((int64_t)blk_u * WAVES + wave) * H + 4 * c;
+            float4* p1 = reinterpret_cast<float4*>(a.b1_part + (int64_t)n * a.b1_sn + slot);
+            float4* p2 = reinterpret_cast<float4*>(a.b2_part + (int64_t)n * a.b2_sn + slot);
+            const float4 o1 = *p1, o2 = *p2;
+            *p1 = float4{o1.x + s1.x, o1.y + s1.y, o1.z + s1.z, o1.w + s1.w};
+            *p2 = float4{o2.x + s2.x, o2.y + s2.y, o2.z + s2.z, o2.w + s2.w};
+        }
+    }
 }
 
 inline bool panel_ok(const float* p, int64_t sn, int64_t E) { return p && sn >= E * H && (sn % 4) == 0 && ((uintptr_t)p % 16) == 0; }
@@ -189,11 +210,14 @@ int launch_adj(const AdjArgs& a, unsigned grid, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int nmarl_dial_msg_adjoint_parts(int64_t E) { return (int)((E + ROWS_B - 1) / ROWS_B * WAVES); }
+
 extern "C" int nmarl_dial_msg_adjoint(int64_t E, int32_t N, int32_t m_max, const float* ds, int64_t ds_sn, const float* hm,
                                       int64_t hm_sn, const float* msg, int64_t msg_sn, const float* dhd, int64_t dhd_sn,
                                       const float* img_msg_t, int64_t img_msg_sn, const float* img_mfc_t, int64_t img_mfc_sn,
                                       const int32_t* rev_agent, const int32_t* rev_col, const float* rev_w, int32_t r_row,
-                                      float* d1, int64_t d1_sn, float* d2, int64_t d2_sn, float* dh, int64_t dh_sn, void* stream) {
+                                      float* d1, int64_t d1_sn, float* d2, int64_t d2_sn, float* dh, int64_t dh_sn,
+                                      float* b1_part, int64_t b1_sn, float* b2_part, int64_t b2_sn, void* stream) {
     if (E < 0 || N <= 0 || m_max <= 0 || m_max > 4 || (r_row != 2 && r_row != 4)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     if (!panel_ok(ds, ds_sn, E) || !panel_ok(hm, hm_sn, E) || !panel_ok(msg, msg_sn, E) || !panel_ok(dhd, dhd_sn, E) ||
@@ -201,11 +225,16 @@ extern "C" int nmarl_dial_msg_adjoint(int64_t E, int32_t N, int32_t m_max, const
         img_msg_sn < (int64_t)m_max * IMG || (img_msg_sn % 4) || ((uintptr_t)img_msg_t % 16) || img_mfc_sn < IMG || (img_mfc_sn % 4) ||
         ((uintptr_t)img_mfc_t % 16) || !rev_agent || !rev_col || !rev_w)
         return NMARL_EINVAL;
+    const int64_t parts = (E + ROWS_B - 1) / ROWS_B * WAVES;
+    if ((b1_part != nullptr) != (b2_part != nullptr) ||
+        (b1_part && (b1_sn < parts * H || b2_sn < parts * H || (b1_sn % 4) || (b2_sn % 4) || ((uintptr_t)b1_part % 16) || ((uintptr_t)b2_part % 16))))
+        return NMARL_EINVAL;
     AdjArgs a{};
     a.ds = ds; a.hm = hm; a.msg = msg; a.dhd = dhd; a.ds_sn = ds_sn; a.hm_sn = hm_sn; a.msg_sn = msg_sn; a.dhd_sn = dhd_sn;
     a.img_msg = img_msg_t; a.img_msg_sn = img_msg_sn; a.img_mfc = img_mfc_t; a.img_mfc_sn = img_mfc_sn;
     a.rev_agent = rev_agent; a.rev_col = rev_col; a.rev_w = rev_w;
     a.d1 = d1; a.d2 = d2; a.dh = dh; a.d1_sn = d1_sn; a.d2_sn = d2_sn; a.dh_sn = dh_sn;
+    a.b1_part = b1_part; a.b2_part = b2_part; a.b1_sn = b1_sn; a.b2_sn = b2_sn;
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     const unsigned grid = (unsigned)(a.blocks_per_agent * N);

@@ -849,14 +849,24 @@ def dial_adjoint_images(w_msg, mfc_w):
     return lstm_msg_wimage(wt), lstm_msg_wimage(mfc_w.transpose(1, 2).contiguous())
 
 
-def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2, dh):
+def dial_adjoint_bias_parts(N, E, device):
+    """Zeroed running partial sums (b_msg's, b_mfc's gradient) for dial_msg_adjoint's `bias_parts`; .sum(1) each at the end."""
+    parts = lib.nmarl_dial_msg_adjoint_parts(E)
+    return torch.zeros(N, parts, FUSED_H, dtype=F32, device=device), torch.zeros(N, parts, FUSED_H, dtype=F32, device=device)
+
+
+def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2, dh, bias_parts=None):
     """lstm_dial's message adjoint of one reverse step in ONE launch (nmarl_dial_msg_adjoint): d1 = ds * (hm > 0),
     d2 = gather_adjoint(d1 @ w_msg^T) * (msg > 0), dh = dhd + d2 @ mfc_w^T; all [N,E,64] panels.  imgs = dial_adjoint_images(w_msg,
-    mfc_w), rev = reverse_neighbor_table(nbr_idx, COUPLED_NC) (w_msg / mfc_w / nbr_idx themselves: the restatement's inputs)."""
+    mfc_w), rev = reverse_neighbor_table(nbr_idx, COUPLED_NC) (w_msg / mfc_w / nbr_idx themselves: the restatement's inputs).
+    bias_parts = dial_adjoint_bias_parts(...): the column sums of d1 / d2 are added to them on the way."""
     N, E, H = ds.shape
+    b1, b2 = (None, None) if bias_parts is None else bias_parts
     check(lib.nmarl_dial_msg_adjoint(E, N, nbr_idx.shape[1], *_pn(ds), *_pn(hm), *_pn(msg), *_pn(dhd), ptr(imgs[0], F32), imgs[0].stride(0),
                                      ptr(imgs[1], F32), imgs[1].stride(0), ptr(rev['rev_agent'], torch.int32), ptr(rev['rev_col'], torch.int32),
-                                     ptr(rev['rev_w'], F32), rev['r_row'], *_pn(d1), *_pn(d2), *_pn(dh), stream()), 'nmarl_dial_msg_adjoint')
+                                     ptr(rev['rev_w'], F32), rev['r_row'], *_pn(d1), *_pn(d2), *_pn(dh), ptr(b1, F32),
+                                     0 if b1 is None else b1.stride(0), ptr(b2, F32), 0 if b2 is None else b2.stride(0), stream()),
+          'nmarl_dial_msg_adjoint')
     return dh
 
 

@@ -546,12 +546,17 @@ int nmarl_bias_act(int64_t rows, int32_t N, int32_t W, const float* x, int64_t x
  * w_msg[:, 64 k : 64 k + 64, :]^T; img_mfc_t: the same image of w_mfc^T.  rev_agent / rev_col / rev_w [N, r_row] (r_row 2 or
  * 4): for every agent its sources (i, 64 k) with weight 1, padded with (own index, 0, weight 0); entries must be valid
  * (agents < N, columns < 64 m_max) -- device memory, not checked.  m_max <= 4.
+ * b1_part / b2_part (both or neither): [N][nmarl_dial_msg_adjoint_parts(E)][64] running partial column sums of d1 / d2 --
+ * the gradients of b_msg / b_mfc; the caller zeroes them before the first reverse step, every call ADDS this step's sums
+ * (calls of one recurrence must be ordered on one stream), and sums over the parts at the end.
  */
+int nmarl_dial_msg_adjoint_parts(int64_t E);
 int nmarl_dial_msg_adjoint(int64_t E, int32_t N, int32_t m_max, const float* ds, int64_t ds_sn, const float* hm,
                            int64_t hm_sn, const float* msg, int64_t msg_sn, const float* dhd, int64_t dhd_sn,
                            const float* img_msg_t, int64_t img_msg_sn, const float* img_mfc_t, int64_t img_mfc_sn,
                            const int32_t* rev_agent, const int32_t* rev_col, const float* rev_w, int32_t r_row,
-                           float* d1, int64_t d1_sn, float* d2, int64_t d2_sn, float* dh, int64_t dh_sn, void* stream);
+                           float* d1, int64_t d1_sn, float* d2, int64_t d2_sn, float* dh, int64_t dh_sn,
+                           float* b1_part, int64_t b1_sn, float* b2_part, int64_t b2_sn, void* stream);
 /*
  * lstm_dial's own-action term (agents/utils.py:577: one_hot(argmax(p_i), n_h), added to the encoded observation at :579):
  * y[n,r,argmax_a p[n,r,a]] += scale[n] (scale NULL: 1; lstm_dial_hetero, agents/utils.py:676-688, gives agents without

@@ -524,7 +524,11 @@ def dial_adjoint_images(w_msg, mfc_w):
     return None                    # the restatement multiplies by the weights themselves
 
 
-def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2, dh):
+def dial_adjoint_bias_parts(N, E, device):
+    return torch.zeros(N, 1, FUSED_H), torch.zeros(N, 1, FUSED_H)
+
+
+def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2, dh, bias_parts=None):
     """Backward of lstm_dial's message path for one step (agents/utils.py:560-580 read backwards): relu mask of the
     receiver layer, d1 @ w_msg^T scattered back to the senders (adjoint of the neighbour gather), relu mask of the sender
     layer, + the recurrent part: dh = dhd + d2 @ mfc_w^T."""
@@ -533,6 +537,9 @@ def dial_msg_adjoint(ds, hm, msg, dhd, w_msg, mfc_w, nbr_idx, imgs, rev, d1, d2,
     dmsg = nbr_gather_bwd(torch.bmm(d1, w_msg.transpose(1, 2)), nbr_idx, H)
     d2.copy_(dmsg * (msg > 0).to(ds.dtype))
     dh.copy_(dhd + torch.bmm(d2, mfc_w.transpose(1, 2)))
+    if bias_parts is not None:
+        bias_parts[0][:, 0] += d1.sum(dim=1).to(bias_parts[0].dtype)
+        bias_parts[1][:, 0] += d2.sum(dim=1).to(bias_parts[1].dtype)
     return dh
 
 

@@ -1097,9 +1097,15 @@ def test_dial_msg_adjoint(N, E, topo):
     DSg, HMg, MSGg = DS.cuda(), HM.cuda(), MSG.cuda()
     D1, D2 = torch.zeros(N, T, E, H, device='cuda'), torch.zeros(N, T, E, H, device='cuda')
     dh = torch.zeros(N, E, H, device='cuda')
-    out = ops.dial_msg_adjoint(DSg[:, 1], HMg[:, 1], MSGg[:, 1], dhd.cuda(), w_msg.cuda(), mfc_w.cuda(), idx.cuda(), imgs, rev,
-                               D1[:, 1], D2[:, 1], dh)
+    parts = ops.dial_adjoint_bias_parts(N, E, 'cuda')
+    for rep in range(2):                                               # the bias sums accumulate over calls (= reverse steps)
+        out = ops.dial_msg_adjoint(DSg[:, 1], HMg[:, 1], MSGg[:, 1], dhd.cuda(), w_msg.cuda(), mfc_w.cuda(), idx.cuda(), imgs, rev,
+                                   D1[:, 1], D2[:, 1], dh, bias_parts=parts)
     assert out is dh
+    torch.testing.assert_close(parts[0].sum(1).cpu().double(), 2 * d1r.sum(1), rtol=1e-4, atol=1e-4 * E ** 0.5)
+    torch.testing.assert_close(parts[1].sum(1).cpu().double(), 2 * d2r.sum(1), rtol=1e-4, atol=1e-4 * E ** 0.5)
+    D1.zero_(), D2.zero_(), dh.zero_()
+    ops.dial_msg_adjoint(DSg[:, 1], HMg[:, 1], MSGg[:, 1], dhd.cuda(), w_msg.cuda(), mfc_w.cuda(), idx.cuda(), imgs, rev, D1[:, 1], D2[:, 1], dh)
     assert torch.equal(D1[:, 1].cpu().double(), d1r)                   # a mask: exact
     torch.testing.assert_close(D2[:, 1].cpu().double(), d2r, rtol=2e-5, atol=1e-5)
     torch.testing.assert_close(dh.cpu().double(), dhr, rtol=2e-5, atol=1e-5)

@@ -164,6 +164,9 @@ SIGNATURES = {
     'nmarl_lstm_bptt_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_step': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,
                              _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _p],
+    'nmarl_lstm_bptt_step_db': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,
+                                _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _p, _i64, _i32, _p, _i64, _p],
+    'nmarl_lstm_bptt_step_parts': [_i64],
     'nmarl_lstm_bptt_seq_blocks': [_i64],
     'nmarl_lstm_bptt_seq': [_i32, _i64, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64,
                             _p, _i64, _p, _i64, _p, _i64, _p],

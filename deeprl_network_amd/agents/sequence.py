@@ -232,11 +232,12 @@ class CoupledSequenceSaved(torch.autograd.Function):
             if ops.dial_adjoint_supported(nbr_idx.shape[1], H, rev_d):
                 adj = (ops.dial_adjoint_images(w_msg, mfc_w), rev_d, torch.empty(N, E, H, dtype=F32, device=dev),
                        ops.dial_adjoint_bias_parts(N, E, dev))
+        dbp = ops.bptt_step_db_parts(N, E, H, dev) if (fused and rev is None) else None       # step-wise loop: db on the way
         for t in (range(T - 1, -1, -1) if rev is None else ()):
             if fused:
                 ops.bptt_step(G[:, t], Call[:, t], Call[:, t + 1], done[t], dHs[:, t], dh_rec, dc, ws, dZ[:, t], dc_next,
                               dhd_buf, t in masked, dx=DS[:, t] if kind == 'dial' else D1[:, t],
-                              mask=hm[:, t] if kind == 'nc' else None)
+                              mask=hm[:, t] if kind == 'nc' else None, db_part=dbp)
                 dc, dc_next = dc_next, dc
                 dhd = dhd_buf
                 if adj is not None:
@@ -281,7 +282,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
             else:
                 dwmsg = ops.wgrad(ops.nbr_mean(Hx, nbr_idx), D1x)
             if db is None:
-                db, dbmsg = dZx.sum(dim=1), D1x.sum(dim=1)
+                db, dbmsg = (dZx.sum(dim=1) if dbp is None else dbp.sum(dim=1)), D1x.sum(dim=1)
             with torch.no_grad():            # h_{t-1} keep_t for the recurrent weight, in the saved buffer itself (the next
                 for t in masked:             # rollout rewrites it); steps outside `masked` have done_t = 0 by contract
                     Hall[:, t].mul_(keep[t].view(1, E, 1))
@@ -307,7 +308,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
         Hp = Hprev.reshape(N, R, H)                            # un-masked h_{t-1} of all steps (message inputs)
         D1f = D1.view(N, R, H)
         if db is None:
-            db = dZf.sum(dim=1)
+            db = dZf.sum(dim=1) if dbp is None else dbp.sum(dim=1)
             dbmsg = D1f.sum(dim=1) if adj is None else adj[3][0].sum(dim=1)     # (lstm_dial: summed inside the adjoint kernel)
         dwx = ops.wgrad(S.view(N, R, S.shape[-1]), dZf)        # the whole x-side weight in one GEMM
         dmfc_w = dmfc_b = None

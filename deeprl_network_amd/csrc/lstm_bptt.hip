@@ -44,7 +44,18 @@ struct BpttArgs {
     int64_t gates_sn, c_prev_sn, c_new_sn, dh_sn, dh2_sn, dc_sn, img_sn, mask_sn, mask_row, dz_sn, dc_prev_sn, dx_sn, dhd_sn;
     int64_t E;
     int N, apply_keep;
+    float* db_part; int64_t db_sn;     // [N][blocks * 8][256] running column sums of dz (the bias gradient), or NULL
 };
+
+__device__ __forceinline__ float dpp_xor1(float v) {  // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {  // value of lane ^ 2 (quad_perm [2,3,0,1])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor8(float v) {  // value of lane ^ 8 (row_ror:8 -- a rotation by half a 16-lane row)
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
+}
 
 struct UnitGroup {          // inputs of 4 consecutive units of one row
     float4 gi, gf, go, gu, cp, cn, gh, g2, gc;
@@ -161,7 +172,22 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_step_kernel(const BpttArgs a
         NMARL_KSTEP(dO.z, (j) * 16 + 10) NMARL_KSTEP(dO.w, (j) * 16 + 11)                  \
         NMARL_KSTEP(du.x, (j) * 16 + 12) NMARL_KSTEP(du.y, (j) * 16 + 13)                  \
         NMARL_KSTEP(du.z, (j) * 16 + 14) NMARL_KSTEP(du.w, (j) * 16 + 15)                  \
+        if (a.db_part) {   /* uniform.  Column sums of this group's 16 dz values over the wave's 16 rows: a reduce-scatter over */ \
+            /* the lanes of a row (c ^ 8, ^ 4, ^ 2, ^ 1) leaves lane c the sum of value c = 4 gate + unit */ \
+            const float v_[16] = {di.x, di.y, di.z, di.w, df.x, df.y, df.z, df.w, dO.x, dO.y, dO.z, dO.w, du.x, du.y, du.z, du.w}; \
+            float s8[8], s4[4], s2[2];                                                     \
+            _Pragma("unroll") for (int k = 0; k < 8; ++k)                                  \
+                s8[k] = (b3 ? v_[k + 8] : v_[k]) * okf + dpp_xor8((b3 ? v_[k] : v_[k + 8]) * okf); \
+            _Pragma("unroll") for (int k = 0; k < 4; ++k)                                  \
+                s4[k] = (b2 ? s8[k + 4] : s8[k]) + __shfl_xor(b2 ? s8[k] : s8[k + 4], 4);  \
+            _Pragma("unroll") for (int k = 0; k < 2; ++k)                                  \
+                s2[k] = (b1 ? s4[k + 2] : s4[k]) + dpp_xor2(b1 ? s4[k] : s4[k + 2]);       \
+            dbs[j] = (b0 ? s2[1] : s2[0]) + dpp_xor1(b0 ? s2[0] : s2[1]);                  \
+        }                                                                                  \
     }
+    const bool b3 = (c & 8) != 0, b2 = (c & 4) != 0, b1 = (c & 2) != 0, b0 = (c & 1) != 0;
+    const float okf = arow_ok ? 1.0f : 0.0f;         // rows past E repeat row E - 1: not in the sums
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};
     NMARL_LOADJ(u1, 1)
     NMARL_GROUP(u0, 0)
     NMARL_LOADJ(u0, 2)
@@ -174,6 +200,12 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_step_kernel(const BpttArgs a
 #undef NMARL_CELLB
 #undef NMARL_GROUP
 
+    if (a.db_part) {
+        // this wave's slot of the running partial sums (one launch per reverse step on one stream: no atomics; fixed order)
+        float* p_ = a.db_part + (int64_t)n * a.db_sn + ((int64_t)(blockIdx.x / a.N) * WAVES + wave) * G4 + (c >> 2) * H + 4 * q + (c & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p_[16 * j] += dbs[j];
+    }
     // ---- epilogue: C/D layout col = lane & 15, row = 4 (lane >> 4) + reg; tiles [0, NT-4) = dx, last 4 = dh
     float keepr[4];
     int64_t rows[4];
@@ -265,13 +297,6 @@ __device__ __forceinline__ float4 bload4(const __amdgpu_buffer_rsrc_t r, const u
 }
 __device__ __forceinline__ void bstore4(const __amdgpu_buffer_rsrc_t r, const uint32_t off, const float4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, 0);
-}
-
-__device__ __forceinline__ float dpp_xor1(float v) {  // value of lane ^ 1 (quad_perm [1,0,3,2])
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float dpp_xor2(float v) {  // value of lane ^ 2 (quad_perm [2,3,0,1])
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
 __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs a) {
@@ -1038,13 +1063,16 @@ extern "C" int nmarl_lstm_bptt_wimage(int32_t N, int32_t KM, const float* wxm, i
     return nmarl_check_launch();
 }
 
-extern "C" int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t Hh, int32_t KM, const float* gates, int64_t gates_sn,
-                                    const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
-                                    const float* done, const float* dh, int64_t dh_sn, const float* dh2, int64_t dh2_sn,
-                                    const float* dc_in, int64_t dc_sn, const float* img, int64_t img_sn, float* dz,
-                                    int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn, float* dx, int64_t dx_sn,
-                                    const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
-                                    int32_t apply_keep, void* stream) {
+extern "C" int nmarl_lstm_bptt_step_parts(int64_t E) { return (int)((E + ROWS_B - 1) / ROWS_B * WAVES); }
+
+extern "C" int nmarl_lstm_bptt_step_db(int64_t E, int32_t N, int32_t Hh, int32_t KM, const float* gates, int64_t gates_sn,
+                                       const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
+                                       const float* done, const float* dh, int64_t dh_sn, const float* dh2, int64_t dh2_sn,
+                                       const float* dc_in, int64_t dc_sn, const float* img, int64_t img_sn, float* dz,
+                                       int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn, float* dx, int64_t dx_sn,
+                                       const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
+                                       int32_t apply_keep, float* db_part, int64_t db_sn, void* stream) {
+    if (db_part && E > 0 && (db_sn < (E + ROWS_B - 1) / ROWS_B * WAVES * (int64_t)G4 || ((uintptr_t)db_part % 4))) return NMARL_EINVAL;
     if (Hh != H || E < 0 || N <= 0 || (KM != 0 && KM != H) ||
         (E > 0 && (!gates || !c_prev || !c_new || !done || !img || !dz || !dc_prev || !dhd || (KM > 0 && !dx))))
         return NMARL_EINVAL;
@@ -1062,6 +1090,7 @@ extern "C" int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t Hh, int32_t KM
     a.gates_sn = gates_sn; a.c_prev_sn = c_prev_sn; a.c_new_sn = c_new_sn; a.dh_sn = dh_sn; a.dh2_sn = dh2_sn; a.dc_sn = dc_sn;
     a.img_sn = img_sn; a.mask_sn = mask_sn; a.mask_row = mask_row; a.dz_sn = dz_sn; a.dc_prev_sn = dc_prev_sn; a.dx_sn = dx_sn;
     a.dhd_sn = dhd_sn; a.E = E; a.N = N; a.apply_keep = apply_keep;
+    a.db_part = db_part; a.db_sn = db_sn;
     static NmarlPerDeviceOnce lds_once;
     if (const unsigned long long lds_bit = lds_once.pending(); lds_bit != ~0ull) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_step_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1076,6 +1105,18 @@ extern "C" int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t Hh, int32_t KM
     if (KM == 0) hipLaunchKernelGGL(lstm_bptt_step_kernel<4>, grid, dim3(512), (size_t)G4 * 16 * 4 * 4, st, a);
     else hipLaunchKernelGGL(lstm_bptt_step_kernel<8>, grid, dim3(512), (size_t)G4 * 16 * 8 * 4, st, a);
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t Hh, int32_t KM, const float* gates, int64_t gates_sn,
+                                    const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
+                                    const float* done, const float* dh, int64_t dh_sn, const float* dh2, int64_t dh2_sn,
+                                    const float* dc_in, int64_t dc_sn, const float* img, int64_t img_sn, float* dz,
+                                    int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn, float* dx, int64_t dx_sn,
+                                    const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
+                                    int32_t apply_keep, void* stream) {
+    return nmarl_lstm_bptt_step_db(E, N, Hh, KM, gates, gates_sn, c_prev, c_prev_sn, c_new, c_new_sn, done, dh, dh_sn, dh2, dh2_sn, dc_in,
+                                   dc_sn, img, img_sn, dz, dz_sn, dc_prev, dc_prev_sn, dx, dx_sn, mask, mask_sn, mask_row, dhd, dhd_sn,
+                                   apply_keep, nullptr, 0, stream);
 }
 
 extern "C" int nmarl_lstm_bptt_seq_blocks(int64_t E) { return (int)((E + ROWS_B - 1) / ROWS_B); }

@@ -796,17 +796,24 @@ def lstm_bptt_wimage(wxm, wh, out=None):
     return out
 
 
-def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None):
+def bptt_step_db_parts(N, E, H, device):
+    """Zeroed running partial sums of dz's columns for bptt_step's `db_part` ([N, parts, 4H]); .sum(1) at the end."""
+    return torch.zeros(N, lib.nmarl_lstm_bptt_step_parts(E), 4 * H, dtype=F32, device=device)
+
+
+def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None, db_part=None):
     """cell_bwd + the dgrad product of one reverse step in ONE MFMA kernel (nmarl_lstm_bptt_step):
     dz, dc_prev as cell_bwd; dhd [N,E,H] = (dz @ wh^T) (* (1-done) if apply_keep); dx [N,E,64] = dz @ wxm^T, zeroed where
-    mask <= 0.  ws = (wxm or None, wh, image from lstm_bptt_wimage)."""
+    mask <= 0.  ws = (wxm or None, wh, image from lstm_bptt_wimage).  db_part (bptt_step_db_parts): dz's column sums are
+    added to it on the way (the bias gradient without a pass over dZ)."""
     N, E, H4 = gates.shape
     wxm, _, img = ws
     KM = 0 if wxm is None else wxm.shape[1]
     mp, m_sn, m_row = (None, 0, 0) if mask is None else _rows_view(mask, mask.shape[2], 'bptt_step mask')
-    check(lib.nmarl_lstm_bptt_step(E, N, H4 // 4, KM, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh), *_pn(dh2),
-                                   *_pn(dc), ptr(img, F32), img.stride(0), *_pn(dz), *_pn(dc_prev), *_pn(dx), mp, m_sn, m_row,
-                                   *_pn(dhd), 1 if apply_keep else 0, stream()), 'nmarl_lstm_bptt_step')
+    check(lib.nmarl_lstm_bptt_step_db(E, N, H4 // 4, KM, *_pn(gates), *_pn(c_prev), *_pn(c_new), ptr(done, F32), *_pn(dh), *_pn(dh2),
+                                      *_pn(dc), ptr(img, F32), img.stride(0), *_pn(dz), *_pn(dc_prev), *_pn(dx), mp, m_sn, m_row,
+                                      *_pn(dhd), 1 if apply_keep else 0, ptr(db_part, F32), 0 if db_part is None else db_part.stride(0),
+                                      stream()), 'nmarl_lstm_bptt_step_db')
 
 
 BPTT_SEQ_MAX_E = 1 << 21     # nmarl_lstm_bptt_seq addresses one (agent, step) panel with 32-bit byte offsets

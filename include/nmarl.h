@@ -464,6 +464,17 @@ int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t H, int32_t KM, const floa
                          int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn, float* dx, int64_t dx_sn,
                          const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
                          int32_t apply_keep, void* stream);
+/* The same step, also ADDING the column sums of dz (the LSTM bias gradient of this step) to db_part
+ * [N][nmarl_lstm_bptt_step_parts(E)][256] (agent stride db_sn; may be NULL): the caller zeroes it before the first reverse
+ * step, orders the steps of one recurrence on one stream and sums over the parts at the end -- no pass over dZ. */
+int nmarl_lstm_bptt_step_parts(int64_t E);
+int nmarl_lstm_bptt_step_db(int64_t E, int32_t N, int32_t H, int32_t KM, const float* gates, int64_t gates_sn,
+                            const float* c_prev, int64_t c_prev_sn, const float* c_new, int64_t c_new_sn,
+                            const float* done, const float* dh, int64_t dh_sn, const float* dh2, int64_t dh2_sn,
+                            const float* dc_in, int64_t dc_sn, const float* img, int64_t img_sn, float* dz,
+                            int64_t dz_sn, float* dc_prev, int64_t dc_prev_sn, float* dx, int64_t dx_sn,
+                            const float* mask, int64_t mask_sn, int64_t mask_row, float* dhd, int64_t dhd_sn,
+                            int32_t apply_keep, float* db_part, int64_t db_sn, void* stream);
 /*
  * The whole reverse recurrence of one update in ONE launch, for nets whose recurrence has no cross-agent term (lstm,
  * agents/utils.py:102-113 unrolled by policies.py:99-100): T reverse steps of nmarl_lstm_bptt_step(KM = 0,

@@ -75,9 +75,16 @@ def lstm_bptt_wimage(wxm, wh, out=None):
     return wh if out is None else out     # kernel-side layout in the product; the restatement hands wh through
 
 
-def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None):
-    """One reverse step of the unrolled LSTM graph: cell backward, then [dx | dhd] = dz @ [wxm; wh]^T."""
+def bptt_step_db_parts(N, E, H, device):
+    return torch.zeros(N, 1, 4 * H)
+
+
+def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, apply_keep, dx=None, mask=None, db_part=None):
+    """One reverse step of the unrolled LSTM graph: cell backward, then [dx | dhd] = dz @ [wxm; wh]^T; db_part += column
+    sums of dz (the bias gradient's share of this step)."""
     cell_bwd(gates, c_prev, c_new, done, dh, dc, dz, dc_prev, dh2=dh2)
+    if db_part is not None:
+        db_part[:, 0] += dz.sum(dim=1).to(db_part.dtype)
     wxm, wh, _ = ws
     r = torch.bmm(dz, wh.transpose(1, 2))
     if apply_keep:

@@ -791,6 +791,14 @@ def test_lstm_bptt_step_fused(N, E, KM, masked, with_rec):
     if KM:
         torch.testing.assert_close(dxg[:, 1].cpu().double(), dx_r, rtol=1e-4, atol=2e-5)
         assert torch.all(dxg[:, 0] == 0)
+    # the same step with the bias gradient accumulated on the way: same outputs bit for bit, db_part += column sums of dz
+    part = ops.bptt_step_db_parts(N, E, H, 'cuda')
+    dZ2, dcp2, dhd2 = torch.zeros_like(dZ), torch.zeros_like(dcp), torch.zeros_like(dhd)
+    for rep in range(2):
+        ops.bptt_step(G[:, 1], C[:, 1], C[:, 2], cu(done), cu(dh), cu(dh2), cu(dc), ws, dZ2[:, 1], dcp2, dhd2, masked,
+                      dx=None if dxg is None else dxg[:, 1], mask=hmg[:, :, 2 * H:] if (KM and masked) else None, db_part=part)
+    assert torch.equal(dZ2, dZ) and torch.equal(dcp2, dcp) and torch.equal(dhd2, dhd)
+    torch.testing.assert_close(part.sum(1).cpu().double(), 2 * dz_r.sum(1), rtol=1e-4, atol=2e-5 * max(1.0, E ** 0.5))
 
 
 def _forward_cells(gates, c0, done):

@@ -184,10 +184,17 @@ def measure_lstm_step(model, n=60, reps=10):
         fused_msg = p._msg() is not None
         Km = p.params['w_msg'].shape[1] if fused_msg else 0
 
+        # lstm_dial: the kernel gathers the senders' message vectors (left by the previous policy step's epilogue) and runs the
+        # sender layer on its own new h -- hand it such vectors, so that the timed body is the step kernel alone
+        dial = fused_msg and p.msg_kind == ops.MSG_DIAL and getattr(p, '_mfc_img', None) is not None
+        mbuf = torch.relu(torch.randn(N, E, H, device=dev)) if dial else None
+
         def body():
             for _ in range(n):
+                if dial:
+                    p._m_next = (h.data_ptr(), h._version, mbuf)
                 p.step_policy(enc, h, c, done, ho, co, pi, act, gates=gates, mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0)
-        flops = N * E * (2 * (KX + H) * 4 * H + 2 * Km * H)
+        flops = N * E * (2 * (KX + H) * 4 * H + 2 * Km * H + (2 * H * H if dial else 0))
         nbytes = N * E * ((KX - (H if fused_msg else 0) + 2 * H) * 4 + Km * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 1)
         name = 'lstm_step_x_kernel<1,%d> (policy step of the coupled net%s)' % (p.msg_kind if fused_msg else 0,
                                                                               ', in-kernel message term' if fused_msg else '')

@@ -15,7 +15,8 @@ dst = os.path.join(ROOT, 'profiles')
 
 CONFIGS = [('ia2c_fp_catchup', 'IA2C-FP catch-up, 8 x 4096 (BASELINE configs[1], the bench default)'),
            ('ma2c_nc_slowdown', 'NeurComm slow-down, 8 x 4096 (configs[2])'),
-           ('ma2c_cnet_grid', 'CommNet on the synthetic 5x5 grid, 25 x 1024 (configs[3])')]
+           ('ma2c_cnet_grid', 'CommNet on the synthetic 5x5 grid, 25 x 1024 (configs[3])'),
+           ('ma2c_dial_catchup', 'DIAL catch-up, 8 x 4096 (outside BASELINE\'s configs; SURVEY 8f)')]
 ROUND1 = {'default': 132.4, 'ma2c_nc_slowdown': 66.0, 'ma2c_cnet_grid': 67.2, 'ma2c_cnet_catchup': 88.2, 'ma2c_dial_catchup': 60.1,
           'ia2c_cu_catchup': 157.6}
 LABEL = {'default': 'IA2C-FP catch-up (configs[1], bench default)', 'ma2c_nc_slowdown': 'NeurComm slow-down (configs[2])',
@@ -40,6 +41,8 @@ with open(os.path.join(dst, '%s_bench_kernel_stats.md' % tag), 'w') as f:
             'measurements bench.py makes after the timed region (cacc_step_kernel<256,...> at E = 2^21, 60-launch graphs of the '
             'LSTM lock-step, 7 launches of the one-launch BPTT).\n\n')
     for cfg, title in CONFIGS:
+        if not os.path.exists(os.path.join(src, '%s_kernel_stats_%s.csv' % (tag, cfg))):
+            continue
         rows = list(csv.DictReader(open(os.path.join(src, '%s_kernel_stats_%s.csv' % (tag, cfg)))))
         tot = sum(float(r['TotalDurationNs']) for r in rows)
         calls = sum(int(r['Calls']) for r in rows)

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 TAG=${1:-r04}
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
-bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid
+bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid ma2c_dial_catchup
 for c in ma2c_dial_catchup ma2c_cnet_catchup ia2c_cu_catchup; do      # (NeurComm slow-down / catch-up and the CommNet grid: `other_configs` of the default line)
   python bench.py --no-cpu-baseline --steps 10 --config config/config_$c.ini > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err
 done

@@ -776,11 +776,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // once the K loop is through (every wave has left the pre-phase by then)
     constexpr bool NXT = HEAD == 1 && MSG == 3;
     const bool nxt_here = NXT && xa.nxt_out != nullptr;
-    float4 nf[NXT ? 2 : 1], nb4 = float4{0.f, 0.f, 0.f, 0.f};
+    // (named registers: an array living across the runtime chunk loop is demoted to scratch, like the staging registers above)
+    float4 nfa = float4{0.f, 0.f, 0.f, 0.f}, nfb = nfa, nb4 = nfa;
     if (NXT) {
         const float4* g = nxt_here ? reinterpret_cast<const float4*>(xa.nxt_img + (int64_t)n * xa.nxt_img_sn) : img;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) nf[q] = g[threadIdx.x + 512 * q];
+        nfa = g[threadIdx.x]; nfb = g[threadIdx.x + 512];
         nb4 = *reinterpret_cast<const float4*>((nxt_here ? xa.nxt_b + (int64_t)n * xa.nxt_b_sn : xa.msg_b + (int64_t)n * xa.msg_b_sn) + 4 * (lane & 15));
     }
     // msg_load: request the neighbour rows of one round (MSG 1: both slots, all four half-chunks; MSG 2: neighbours k0 .. k0 + 3,
@@ -1044,8 +1044,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     NMARL_STAMP(20)
     if (nxt_here) {                              // (after the last tick's barrier: the W_msg image is dead)
         float4* d = reinterpret_cast<float4*>(m_lds);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) d[threadIdx.x + 512 * q] = nf[q];
+        d[threadIdx.x] = nfa; d[threadIdx.x + 512] = nfb;
     }
     const unsigned epoch = HEAD == 4 ? (unsigned)__builtin_amdgcn_readfirstlane((int)epoch_raw) + 1u : 0u;
 

@@ -1,7 +1,7 @@
 """Timing of the coupled nets' two hand-off kernels at the BASELINE shapes (HIP events around repeated launches):
   nmarl_lstm_bptt_coupled   NeurComm 8 x 4096, T = 60 (configs[2] / [4])  and  CommNet grid 25 x 1024, T = 120 (configs[3])
   nmarl_lstm_step_x_msg     head kind 3 (one launch per lock-step), same two shapes, as a 60-launch hipGraph
-python tools/time_coupled.py [bptt] [step]        (environment knobs of the kernels apply, e.g. NMARL_BPTT_PRIO=0)"""
+python tools/time_coupled.py [bptt] [step]"""
 import os
 import sys
 

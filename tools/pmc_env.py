@@ -166,4 +166,27 @@ try:
     ops.check_coupled_status()
 except Exception as ex:                        # a side measurement: never fail the pass
     print('grid CommNet kernels skipped:', ex)
+# lstm_dial on the line graph at the bench shape (8 x 4096): the policy step with the receiver layer in its pre-phase and the sender
+# layer of the new h in its epilogue (lstm_step_x_kernel<1,3>), and the message adjoint of one reverse step (dial_msg_adjoint_kernel<2>)
+try:
+    wxd, wmd, bmd = r(N, H, 4 * H) * 0.15, r(N, 2 * H, H) * 0.15, r(N, H) * 0.1
+    mfw, mfb = r(N, H, H) * 0.2, r(N, H) * 0.1
+    imgd, mimgd, fimg = ops.lstm_wimage(wxd, wh), ops.lstm_msg_wimage(wmd), ops.lstm_msg_wimage(mfw)
+    srcd, encd = torch.relu(r(N, El, H)), torch.relu(r(N, El, H))
+    sv = torch.zeros(N, 4, El, H, device='cuda')
+    msgd = dict(kind=ops.MSG_DIAL, nbr_idx=nbr_idx, w_msg=wmd, b_msg=bmd, img=mimgd, enc=encd, src=srcd, out=sv[:, 0], out2=sv[:, 1],
+                next=dict(img=fimg, b=mfb, out=sv[:, 2]))
+    for s in range(12):
+        ops.lstm_step_policy(h, None, b, None, None, c, done, co, ho, pi_w, pi_b, pi, act, mode=2, xs=(None, None, imgd, None, msgd), gates=gates)
+    torch.cuda.synchronize()
+    revd = ops.reverse_neighbor_table(nbr_idx, ops.COUPLED_NC)
+    imgs_d = ops.dial_adjoint_images(wmd, mfw)
+    dsd, dhdd = rd(N, El, H), rd(N, El, H)
+    d1d, d2d, dhd_o = (torch.empty(N, El, H, device='cuda') for _ in range(3))
+    parts_d = ops.dial_adjoint_bias_parts(N, El, 'cuda')
+    for s in range(12):
+        ops.dial_msg_adjoint(dsd, sv[:, 1], sv[:, 2], dhdd, wmd, mfw, nbr_idx, imgs_d, revd, d1d, d2d, dhd_o, bias_parts=parts_d)
+    torch.cuda.synchronize()
+except Exception as ex:                        # a side measurement: never fail the pass
+    print('lstm_dial kernels skipped:', ex)
 print('done', E, Eg)

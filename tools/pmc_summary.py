@@ -118,6 +118,21 @@ try:        # its coupled BPTT (T = 120): per (agent, replica, step) row gates 1
     res['kernels']['lstm_bptt_coupled_ic3_N25_E1024_T120'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no grid bptt_coupled in this collection:', ex)
+for key, part, balg in (
+        # lstm_dial's policy step (line graph: 1.75 senders per agent on average): enc 256 + own h, c 512 + the senders' message vectors
+        # 1.75 x 256 read; s 256 + hm 256 + h', c' 512 + gates 1024 + pi 16 + action 1 + the new message vectors 256 written
+        ('lstm_step_x13_dial_N8_E4096', 'lstm_step_x_kernel<1, 3>', int(256 + 512 + 1.75 * 256 + 256 + 256 + 512 + 1024 + 17 + 256)),
+        # its message adjoint of one reverse step: own ds, hm, msg, dhd 1024 + 1.75 sources x (ds, hm) 512 read; d1, d2, dh 768 written
+        ('dial_msg_adjoint_N8_E4096', 'dial_msg_adjoint_kernel<2>', int(1024 + 1.75 * 512 + 768))):
+    try:
+        s = stat(part)
+        traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+        rows = 8 * 4096
+        s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+                 algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / rows / balg)
+        res['kernels'][key] = s
+    except (AssertionError, ZeroDivisionError) as ex:
+        print('no %s in this collection:' % part, ex)
 json.dump(res, open('%s/%s_pmc_traffic.json' % (out_dir, tag), 'w'), indent=1)
 with open('%s/%s_pmc_traffic.md' % (out_dir, tag), 'w') as f:
     f.write('# HBM traffic of the env-step kernels (and the fused LSTM step) from rocprofv3 PMC passes\n\n'

@@ -362,9 +362,13 @@ class BatchedTrainer:
             with torch.cuda.graph(self.graph):
                 self._rollout()
             self._restore(snap)
+            # host-side per-batch state the captured rollout set (a replay runs no Python): the update's "the rollout saved the
+            # encoder outputs" flag is cleared by every update and must be raised again after every replay
+            self._graph_saves_enc = bool(getattr(self.model.policy, '_enc_was_saved', False))
         self.model.t = 0
         self.graph.replay()
         self.model.t = self.n_step
+        self.model.policy._enc_was_saved = self._graph_saves_enc
 
     def _state_tensors(self):
         m = self.model

@@ -42,6 +42,28 @@ def test_graph_equals_eager_and_is_deterministic(agent):
     assert torch.isfinite(runs[0][0]).all()
 
 
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_commnet_update_uses_the_saved_encoder_outputs_every_batch(use_graph, monkeypatch):
+    """CommNet: the rollout saves the encoder outputs of every lock-step, and the update must use them in EVERY batch -- also
+    when the rollout is a hipGraph replay (no Python runs then: the per-batch `_enc_was_saved` flag the update clears has to be
+    raised again by the trainer).  The recomputing encoder forward is counted; same weights as the eager run either way."""
+    from deeprl_network_amd.agents.policies import IC3MultiAgentPolicy
+    calls = {'n': 0}
+    orig = IC3MultiAgentPolicy._enc
+
+    def counting(self, xv, fp):
+        calls['n'] += 1
+        return orig(self, xv, fp)
+    monkeypatch.setattr(IC3MultiAgentPolicy, '_enc', counting)
+    env, model, tr = build('ma2c_ic3', 1024, use_graph)
+    for _ in range(4):
+        tr.run_batch()
+    torch.cuda.synchronize()
+    assert model.save_acts and 'ENC' in model.policy._extra
+    assert calls['n'] == 0, 'the update recomputed the encoder forward %d times' % calls['n']
+    assert torch.isfinite(model.policy.params.flat).all()
+
+
 @pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_ic3'])
 def test_rollout_batch_invariance_at_full_size(agent):
     env, model, tr = build(agent, 4096, False)

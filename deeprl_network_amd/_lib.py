@@ -59,7 +59,8 @@ class Msg(C.Structure):
                 ('status', C.c_void_p), ('src', C.c_void_p), ('src_sn', C.c_int64),
                 ('out2', C.c_void_p), ('out2_sn', C.c_int64), ('out2_row', C.c_int64),
                 ('next_img', C.c_void_p), ('next_img_sn', C.c_int64), ('next_b', C.c_void_p), ('next_b_sn', C.c_int64),
-                ('next_out', C.c_void_p), ('next_out_sn', C.c_int64)]
+                ('next_out', C.c_void_p), ('next_out_sn', C.c_int64),
+                ('mean_out', C.c_void_p), ('mean_out_sn', C.c_int64), ('mean_out_row', C.c_int64)]
 
 
 class NetParams(C.Structure):

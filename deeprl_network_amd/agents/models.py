@@ -207,9 +207,11 @@ class IA2C:
         self.buf_vn = torch.zeros(N, T, E, dtype=F32, device=d)          # agent-major values (critic's h part)
         # coupled nets: further per-step message terms the backward needs (policy.save_spec)
         # (`save_next` keys: one slab more -- the policy step of lock-step t fills slot t + 1, e.g. lstm_dial's message vectors)
-        nxt = getattr(p, 'save_next', ())
-        full = {k: torch.zeros(N, T + 1 if k in nxt else T, E, w, dtype=F32, device=d) for k, w in p.save_spec().items()}
+        # (`save_pad` keys: one ZERO slab more, like S_ext -- the update's weight-gradient GEMM reads the (T + 1)-slab buffer in place)
+        nxt, pad = getattr(p, 'save_next', ()), getattr(p, 'save_pad', ())
+        full = {k: torch.zeros(N, T + 1 if (k in nxt or k in pad) else T, E, w, dtype=F32, device=d) for k, w in p.save_spec().items()}
         p._extra = {k: v[:, :T] for k, v in full.items()}
+        p._extra_full = full
         self._extra_next = {k: full[k] for k in nxt if k in full}
         self.save_acts = True
         return True
@@ -478,6 +480,7 @@ class IA2C:
         self.t = 0
         self.cur_lr = cur_lr
         self.policy._enc_was_saved = False       # the saved encoder outputs belonged to this batch (the next rollout sets it again)
+        self.policy._mm_was_saved = False
 
     # ------------------------------------------------------------------ reference API (E = 1)
     def _obs_to_slab(self, obs):

@@ -442,9 +442,14 @@ class BatchedPolicy:
         T, E = done.shape
         kind, wx, w_msg, b_msg, mfc_w, mfc_b = self._seq_args()
         enc = self._enc_saved(Xv, FP, S)
+        extra = dict(getattr(self, '_extra', {}))
+        if kind == 'ic3':
+            # the rollout's mean_nbr(h_{t-1}) rows ((T + 1)-slab buffer, last slab zero) if every policy step of this batch kept them
+            mm = getattr(self, '_extra_full', {}).get('MM') if getattr(self, '_mm_was_saved', False) else None
+            extra['A1'] = mm if (mm is not None and mm.shape[1] == T + 1) else None
         Hs = sequence.coupled_sequence_saved(kind, self.nbr_idx, masked_steps, enc.view(self.N, T, E, enc.shape[-1]), done,
                                              self.params[self.k_wx], self.params[self.k_wh], self.params[self.k_b],
-                                             w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, getattr(self, '_extra', {}), s_ext=S_ext)
+                                             w_msg, b_msg, mfc_w, mfc_b, G, Hall, Call, S, extra, s_ext=S_ext)
         return Hs.reshape(self.N, T * E, self.n_h)
 
     def step_value(self, enc, h, c, done, h_out, c_out, action, v_out, done_is_zero=False):
@@ -793,7 +798,13 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         return torch.bmm(s, p['wx_hid'])
 
     def save_spec(self):
-        return {'ENC': self.n_h}             # tanh(x~ W_ob + b) of every lock-step: the update's encoder backward needs no forward pass
+        # ENC: tanh(x~ W_ob + b) of every lock-step (the update's encoder backward needs no forward pass); MM: mean_nbr(h_{t-1}), the
+        # message layer's input as the step kernel's pre-phase forms it (its weight gradient = MM^T D1: no averaging pass over the
+        # h sequence in the update); one zero slab more, like the saved LSTM inputs
+        return {'ENC': self.n_h, 'MM': self.n_h}
+
+    save_pad = ('MM',)
+    _mm_was_saved = False
 
     def _enc_saved(self, xv, fp, S):
         enc = getattr(self, '_extra', {}).get('ENC')
@@ -817,8 +828,13 @@ class IC3MultiAgentPolicy(BatchedPolicy):
         p = self.params
         if fuse_msg and self._msg() is not None:
             # s = mean_nbr(h) W_msg + b_msg + enc inside the step kernel; the policy step keeps it for the update
-            out = save['S'] if (save is not None and not second) else None
-            return None, None, (None, p['wx_hid'], self._img, None, self._msg(enc=enc, out=out))
+            keep = save is not None and not second
+            if keep and 'MM' in save:
+                self._mm_was_saved = True
+                return None, None, (None, p['wx_hid'], self._img, None, self._msg(enc=enc, out=save['S'], mean_out=save['MM']))
+            return None, None, (None, p['wx_hid'], self._img, None, self._msg(enc=enc, out=save['S'] if keep else None))
+        if not second:
+            self._mm_was_saved = False       # this path keeps no mean_nbr(h): the update averages the h sequence itself
         if self.xside:
             x = self._x_target(h, second, save)
             self._fc_infer(ops.nbr_mean(h, self.nbr_idx), 'w_msg', 'w_msg_b', ops.BIAS_NONE, out=x).add_(enc)

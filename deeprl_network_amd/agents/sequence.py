@@ -154,7 +154,8 @@ class CoupledSequenceSaved(torch.autograd.Function):
     """The coupled recurrences of the update WITHOUT a forward pass: the rollout's policy steps (x-side step kernel,
     agents/policies.py `_recur_addends`) evaluated exactly this sequence with exactly these weights and saved
     S [N,T,E,KX] (the LSTM inputs: nc [hx | hp | hm], ic3 s, dial enc + hm), the gates G, the state sequences Hall /
-    Call and, for dial, the post-relu message terms A1 (hm) / A2 (msg).  forward = hand out Hall[:, 1:]; backward = the
+    Call and, for dial, the post-relu message terms A1 (hm) / A2 (msg); for ic3 A1 may be the (T + 1)-slab buffer of the
+    mean_nbr(h_{t-1}) rows the step kernel kept (the message layer's input: no averaging pass over the h sequence here).  forward = hand out Hall[:, 1:]; backward = the
     manual BPTT of CoupledSequence with the x-side weight as ONE matrix:
       nc    `enc` = [hx | hp] (autograd-connected, = S[..., :2H]); wx = the full [3H,4H]:
             d enc = dZ @ wx[:2H]^T, d wx = S^T dZ (one GEMM over all T*E rows, all three thirds at once)
@@ -279,6 +280,8 @@ class CoupledSequenceSaved(torch.autograd.Function):
             # message layer first: its input is the UN-masked h_{t-1} (quirk Q3)
             if kind == 'nc':
                 dwmsg = _dwmsg_by_runs(Hx, D1x, nbr_idx, H)
+            elif A1.numel() and tuple(A1.shape) == (N, T + 1, E, H) and A1.is_contiguous():
+                dwmsg = ops.wgrad(A1.view(N, Rx, H), D1x)       # ic3: the rollout kept mean_nbr(h_{t-1}) (A1 = the (T + 1)-slab MM buffer)
             else:
                 dwmsg = ops.wgrad(ops.nbr_mean(Hx, nbr_idx), D1x)
             if db is None:
@@ -316,7 +319,10 @@ class CoupledSequenceSaved(torch.autograd.Function):
             dwmsg = ops.wgrad(ops.nbr_gather(Hp, nbr_idx), D1f)
             denc = torch.bmm(dZf, wx[:, :2 * H].transpose(1, 2)).view(N, T, E, 2 * H) if ctx.needs_input_grad[3] else None
         elif kind == 'ic3':
-            dwmsg = ops.wgrad(ops.nbr_mean(Hp, nbr_idx), D1f)
+            if A1.numel() and tuple(A1.shape) == (N, T + 1, E, H):
+                dwmsg = ops.wgrad(A1[:, :T].reshape(N, R, H), D1f)
+            else:
+                dwmsg = ops.wgrad(ops.nbr_mean(Hp, nbr_idx), D1f)
             denc = D1
         else:
             D2f = D2.view(N, R, H)

@@ -492,6 +492,8 @@ struct XArgs {
     const float* msg_b; int64_t msg_b_sn;         // [N, 64]
     const float* enc; int64_t enc_sn, enc_row;    // MSG 2: the additive h-independent part of the input [N,E,64]
     float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
+    float* mm_out; int64_t mm_sn, mm_row;         // MSG 2, may be NULL: where the policy step's mean_j(h_j) rows are kept (the update's
+                                                  // message-weight gradient is mean(h)^T D1: no averaging pass over the h sequence there)
     const float* src; int64_t src_sn;             // MSG 3: the senders' message vectors [N,E,64] the pre-phase gathers (instead of h)
     float* xm2_out; int64_t xm2_sn, xm2_row;      // MSG 3: where hm = relu(.) is kept BEFORE enc is added (may be NULL)
     // MSG 3, HEAD 1, nxt_out != NULL: the SENDER layer on the new h, msg' = relu(h' W_mfc + b) -> nxt_out [N,E,64]: what the value
@@ -940,6 +942,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             for (int kc = 0; kc < 2; ++kc) {
                 float4 m0 = sm[kc][0], m1 = sm[kc][1];
                 m0.x *= inv; m0.y *= inv; m0.z *= inv; m0.w *= inv; m1.x *= inv; m1.y *= inv; m1.z *= inv; m1.w *= inv;
+                if (!SECOND && xa.mm_out && row0 + c < a.E) {        // (A layout: row c of the strip, k = 32 kc + 16 j + 4 grp + {0..3})
+                    float* mo = xa.mm_out + (int64_t)n * xa.mm_sn + arow * xa.mm_row + kc * CH_K + 4 * grp;
+                    *reinterpret_cast<float4*>(mo) = m0;
+                    *reinterpret_cast<float4*>(mo + 16) = m1;
+                }
                 NMARL_MCHUNK(macc, m_lds, kc, m0, m1)
             }
         }
@@ -1498,6 +1505,12 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.msg_kc = msg->K / CH_K; xa.m_max = msg->m_max; xa.nbr_idx = msg->nbr_idx; xa.msg_img = msg->img;
         xa.msg_img_sn = msg->img_sn; xa.msg_b = msg->b; xa.msg_b_sn = msg->b_sn; xa.enc = msg->enc; xa.enc_sn = msg->enc_sn;
         xa.enc_row = msg->enc_row; xa.xm_out = msg->out; xa.xm_sn = msg->out_sn; xa.xm_row = msg->out_row;
+        if (mk == 2 && msg->mean_out) {
+            if (msg->mean_out_row < H || msg->mean_out_sn < E * msg->mean_out_row || ((uintptr_t)msg->mean_out % 16) || (msg->mean_out_row % 4) ||
+                (msg->mean_out_sn % 4))
+                return NMARL_EINVAL;
+            xa.mm_out = msg->mean_out; xa.mm_sn = msg->mean_out_sn; xa.mm_row = msg->mean_out_row;
+        }
         if (mk == 3) {
             xa.src = msg->src; xa.src_sn = msg->src_sn; xa.xm2_out = msg->out2; xa.xm2_sn = msg->out2_sn; xa.xm2_row = msg->out2_row;
             if (msg->next_out) {

@@ -266,6 +266,8 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             m.enc, m.enc_sn, m.enc_row = _rows_view(msg['enc'], H, what + ' enc')
         if msg.get('out') is not None:
             m.out, m.out_sn, m.out_row = _rows_view(msg['out'], H, what + ' msg out')
+        if msg.get('mean_out') is not None:            # lstm_ic3, policy step: keep mean_j(h_j) for the update's message-weight gradient
+            m.mean_out, m.mean_out_sn, m.mean_out_row = _rows_view(msg['mean_out'], H, what + ' msg mean_out')
         if msg['kind'] == MSG_DIAL:
             src = msg['src']
             if src.shape != (N, E, H) or src.stride(2) != 1 or src.stride(1) != H:

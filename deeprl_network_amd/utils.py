@@ -364,11 +364,12 @@ class BatchedTrainer:
             self._restore(snap)
             # host-side per-batch state the captured rollout set (a replay runs no Python): the update's "the rollout saved the
             # encoder outputs" flag is cleared by every update and must be raised again after every replay
-            self._graph_saves_enc = bool(getattr(self.model.policy, '_enc_was_saved', False))
+            self._graph_flags = {k: bool(getattr(self.model.policy, k, False)) for k in ('_enc_was_saved', '_mm_was_saved')}
         self.model.t = 0
         self.graph.replay()
         self.model.t = self.n_step
-        self.model.policy._enc_was_saved = self._graph_saves_enc
+        for k, v in self._graph_flags.items():
+            setattr(self.model.policy, k, v)
 
     def _state_tensors(self):
         m = self.model

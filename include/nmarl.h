@@ -434,6 +434,8 @@ typedef struct nmarl_msg {
     const float* next_img; int64_t next_img_sn;     /* kind 3, head 1, with next_out: image of w_mfc */
     const float* next_b; int64_t next_b_sn;
     float* next_out; int64_t next_out_sn;           /* kind 3, head 1, may be NULL: relu(h_new @ w_mfc + b_mfc) */
+    float* mean_out; int64_t mean_out_sn, mean_out_row;   /* kind 2, may be NULL: the policy step's mean_j(h_j) rows ([N,E,64] view), the
+                                                           * input of the message layer -- its weight gradient is mean(h)^T d1 */
 } nmarl_msg_t;
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_sync_words(int64_t E, int32_t N);

@@ -213,7 +213,10 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
                     g = ob['x'][:, idx.clamp(min=0), :] * (idx >= 0).to(ob['x'].dtype).unsqueeze(-1)        # [E,N,slots,F]
                     g = g.reshape(g.shape[0], g.shape[1], -1).transpose(0, 1).to(ob['w'].dtype)             # [N,E,n_obs]
                     m['enc'].copy_(torch.tanh(torch.bmm(g, ob['w']) + ob['b'].unsqueeze(1)))
-                t = torch.bmm(nbr_mean(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1) + m['enc']
+                mm_ = nbr_mean(h, m['nbr_idx'])
+                if m.get('mean_out') is not None:
+                    m['mean_out'].copy_(mm_)
+                t = torch.bmm(mm_, m['w_msg']) + m['b_msg'].unsqueeze(1) + m['enc']
             if m.get('out') is not None:
                 m['out'].copy_(t)
             x = t if x is None else torch.cat([x, t], dim=-1)
@@ -339,7 +342,7 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     xs_p = xs
     if xs is not None and len(xs) > 4 and xs[4] is not None:
         # coupled net: only the POLICY step's message term is kept (`out`); the re-step's comes from the new h of all agents
-        xs = tuple(xs[:4]) + ({k: v for k, v in xs[4].items() if k != 'out'},)
+        xs = tuple(xs[:4]) + ({k: v for k, v in xs[4].items() if k not in ('out', 'mean_out')},)
     if gates is not None:
         lstm_step_fused(h, wh, bias, zadd1, zadd2, c, done, gates, torch.empty_like(c), torch.empty_like(h), xs=xs)
         if xs_p is not xs:                   # the step below writes (h_out, c_out); the message term needs the OLD h of all agents

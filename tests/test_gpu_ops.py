@@ -897,6 +897,9 @@ def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
     # oracle
     out_r = torch.zeros(N, E, H, dtype=torch.float64)
     msg_r = dict(kind=kind, nbr_idx=idx, w_msg=f64(w_msg), b_msg=f64(b_msg), enc=f64(enc), out=out_r)
+    mm_r, mm_g = torch.zeros(N, E, H, dtype=torch.float64), torch.zeros(N, 2, E, H, device='cuda')
+    if kind == 2:                            # lstm_ic3: the policy step also keeps mean_j(h_j), the message layer's input
+        msg_r['mean_out'] = mm_r
     hr, cr = torch.empty(N, E, H, dtype=torch.float64), torch.empty(N, E, H, dtype=torch.float64)
     pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
     gr = torch.zeros(N, E, 4 * H, dtype=torch.float64)
@@ -908,12 +911,18 @@ def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):
     if KXg:
         slot[:, :, :KXg].copy_(xg)
     msg_g = dict(kind=kind, nbr_idx=cu(idx), w_msg=cu(w_msg), b_msg=cu(b_msg), img=mimg, enc=cu(enc), out=slot[:, :, KXg:])
+    if kind == 2:
+        msg_g['mean_out'] = mm_g[:, 1]
     hg, cg = torch.zeros(N, E, H, device='cuda'), torch.zeros(N, E, H, device='cuda')
     pig, actg, gg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.zeros(N, E, 4 * H, device='cuda')
     ops.lstm_step_policy(cu(h), None, cu(b), None, None, cu(c), cu(done), cg, hg, cu(pi_w), cu(pi_b), pig, actg,
                          xs=(slot[:, :, :KXg] if KXg else None, None, img, None, msg_g), gates=gg, **draw)
     tol = dict(rtol=5e-5, atol=1e-5)
     torch.testing.assert_close(slot[:, :, KXg:].cpu().double(), out_r, **tol)
+    if kind == 2:
+        torch.testing.assert_close(mm_g[:, 1].cpu().double(), mm_r, rtol=1e-6, atol=1e-6)
+        assert float(mm_r.abs().max()) > 0 and float(mm_g[:, 0].abs().max()) == 0.0
+        msg_g.pop('mean_out'), msg_r.pop('mean_out')
     torch.testing.assert_close(hg.cpu().double(), hr, **tol)
     torch.testing.assert_close(cg.cpu().double(), cr, **tol)
     torch.testing.assert_close(gg.cpu().double(), gr, **tol)

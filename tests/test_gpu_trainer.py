@@ -55,12 +55,22 @@ def test_commnet_update_uses_the_saved_encoder_outputs_every_batch(use_graph, mo
         calls['n'] += 1
         return orig(self, xv, fp)
     monkeypatch.setattr(IC3MultiAgentPolicy, '_enc', counting)
+    from deeprl_network_amd import ops
+    means = {'n': 0}
+    orig_mean = ops.nbr_mean
+
+    def counting_mean(x, nbr_idx):
+        means['n'] += x.shape[1] > 1024                     # an averaging pass over the whole h sequence (the update's)
+        return orig_mean(x, nbr_idx)
+    monkeypatch.setattr(ops, 'nbr_mean', counting_mean)
     env, model, tr = build('ma2c_ic3', 1024, use_graph)
     for _ in range(4):
         tr.run_batch()
     torch.cuda.synchronize()
-    assert model.save_acts and 'ENC' in model.policy._extra
+    assert model.save_acts and 'ENC' in model.policy._extra and 'MM' in model.policy._extra
     assert calls['n'] == 0, 'the update recomputed the encoder forward %d times' % calls['n']
+    assert means['n'] == 0, 'the update averaged the h sequence %d times although the rollout kept the means' % means['n']
+    assert float(model.policy._extra_full['MM'][:, -1].abs().max()) == 0.0          # the padding slab stays zero
     assert torch.isfinite(model.policy.params.flat).all()
 
 

@@ -116,6 +116,24 @@ def test_dial_sender_layer_in_the_policy_step_equals_fc_launches(monkeypatch):
         torch.testing.assert_close(m_new.policy.params.flat, m_old.policy.params.flat, rtol=1e-4, atol=1e-6)
 
 
+def test_commnet_saved_neighbour_means_equal_the_averaging_pass(monkeypatch):
+    """CommNet: the policy step keeps mean_nbr(h_{t-1}) (msg['mean_out']) and the update's message-weight gradient multiplies by
+    that buffer; same weights as the update that averages the h sequence itself."""
+    from deeprl_network_amd.agents.policies import IC3MultiAgentPolicy
+    with cpu_ops():
+        _, m_new, t_new = build('ma2c_ic3', E=3)
+        for _ in range(4):
+            t_new.run_batch()
+        assert float(m_new.policy._extra['MM'].abs().max()) > 0 and float(m_new.policy._extra_full['MM'][:, -1].abs().max()) == 0.0
+        monkeypatch.setattr(IC3MultiAgentPolicy, 'save_spec', lambda self: {'ENC': self.n_h})
+        _, m_old, t_old = build('ma2c_ic3', E=3)
+        for _ in range(4):
+            t_old.run_batch()
+        assert 'MM' not in m_old.policy._extra
+        assert torch.equal(m_new.buf_act, m_old.buf_act)
+        torch.testing.assert_close(m_new.policy.params.flat, m_old.policy.params.flat, rtol=1e-5, atol=1e-7)
+
+
 def test_batch_invariance_of_rollout():
     """Replica e of an E-replica rollout == the same replica rolled out alone (same Philox ids)."""
     with cpu_ops():

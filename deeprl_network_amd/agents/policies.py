@@ -443,6 +443,8 @@ class BatchedPolicy:
         kind, wx, w_msg, b_msg, mfc_w, mfc_b = self._seq_args()
         enc = self._enc_saved(Xv, FP, S)
         extra = dict(getattr(self, '_extra', {}))
+        if kind == 'dial' and 'A2' in getattr(self, '_extra_full', {}) and extra.get('A2') is not None:
+            extra['A2'] = self._extra_full['A2']          # the (T + 1)-slab buffer itself: the weight gradient reads it in place
         if kind == 'ic3':
             # the rollout's mean_nbr(h_{t-1}) rows ((T + 1)-slab buffer, last slab zero) if every policy step of this batch kept them
             mm = getattr(self, '_extra_full', {}).get('MM') if getattr(self, '_mm_was_saved', False) else None

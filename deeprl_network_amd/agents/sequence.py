@@ -196,7 +196,15 @@ class CoupledSequenceSaved(torch.autograd.Function):
             dZ, D1 = dZe[:, :T], D1e[:, :T]
         else:
             dZ = torch.empty_like(G)
-            D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
+            if kind == 'dial' and tuple(A2.shape) == (N, T + 1, E, H) and A2.is_contiguous():
+                # lstm_dial with the senders' vectors in their (T + 1)-slab buffer: D1 the same way (last slab zero), so that the
+                # message-weight gradient reads both in place (per run of agents, like lstm_comm) -- no gathered copy of A2
+                D1e = torch.empty(N, T + 1, E, H, dtype=F32, device=dev)
+                D1e[:, T].zero_()
+                D1 = D1e[:, :T]
+            else:
+                D1e = None
+                D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
         D2 = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
         DS = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
         keep = 1.0 - done
@@ -309,10 +317,13 @@ class CoupledSequenceSaved(torch.autograd.Function):
             Hk = Hk.view(N, R, H)
         dwh = ops.wgrad(Hk, dZf)
         Hp = Hprev.reshape(N, R, H)                            # un-masked h_{t-1} of all steps (message inputs)
-        D1f = D1.view(N, R, H)
+        D1f = D1.view(N, R, H) if D1e is None else None        # (lstm_dial with the padded D1: only its (T + 1)-slab view is used)
         if db is None:
             db = dZf.sum(dim=1) if dbp is None else dbp.sum(dim=1)
-            dbmsg = D1f.sum(dim=1) if adj is None else adj[3][0].sum(dim=1)     # (lstm_dial: summed inside the adjoint kernel)
+            if adj is not None:
+                dbmsg = adj[3][0].sum(dim=1)                   # lstm_dial: summed inside the adjoint kernel
+            else:
+                dbmsg = D1f.sum(dim=1) if D1f is not None else D1e.view(N, (T + 1) * E, H).sum(dim=1)
         dwx = ops.wgrad(S.view(N, R, S.shape[-1]), dZf)        # the whole x-side weight in one GEMM
         dmfc_w = dmfc_b = None
         if kind == 'nc':
@@ -326,7 +337,10 @@ class CoupledSequenceSaved(torch.autograd.Function):
             denc = D1
         else:
             D2f = D2.view(N, R, H)
-            dwmsg = ops.wgrad(ops.nbr_gather(A2.reshape(N, R, H), nbr_idx), D1f)
+            if D1e is not None:
+                dwmsg = _dwmsg_by_runs(A2.view(N, (T + 1) * E, H), D1e.view(N, (T + 1) * E, H), nbr_idx, H)
+            else:
+                dwmsg = ops.wgrad(ops.nbr_gather(A2[:, :T].reshape(N, R, H), nbr_idx), D1f)
             dmfc_w = ops.wgrad(Hp, D2f)
             dmfc_b = D2f.sum(dim=1) if adj is None else adj[3][1].sum(dim=1)
             denc = DS

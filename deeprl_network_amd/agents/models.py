@@ -195,12 +195,8 @@ class IA2C:
         KX = p.params[p.k_wx].shape[1]
         # one zero slab more than needed, so that [S | .] and the state sequences have the SAME (T + 1)-slab shape -- the
         # update's weight-gradient GEMMs then read the saved buffers in place (ops._lstm_seq_x_backward, agents/sequence.py)
-        if getattr(p, 'saved_ext', True):
-            self.S_ext = torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
-            self.S_buf = self.S_ext[:, :T]
-        else:                               # DIAL: its step-wise backward multiplies the contiguous [N, T*E, KX] view
-            self.S_ext = None
-            self.S_buf = torch.zeros(N, T, E, KX, dtype=F32, device=d)
+        self.S_ext = torch.zeros(N, T + 1, E, KX, dtype=F32, device=d)
+        self.S_buf = self.S_ext[:, :T]
         self.G_buf = torch.zeros(N, T, E, 4 * H, dtype=F32, device=d)
         self.H_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)
         self.C_all = torch.zeros(N, T + 1, E, H, dtype=F32, device=d)

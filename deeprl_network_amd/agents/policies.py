@@ -918,7 +918,6 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     s_i = relu(x~_i W_ob) + relu([mfc_j(h_j) for j in nbr(i)] W_msg) + onehot_H(argmax pi_i(t-1)) -> LSTM(H);
     the message encoder mfc_j = relu(h_j W + b) acts on the sender's un-masked previous h."""
     name = 'dial'
-    saved_ext = False             # the saved LSTM inputs stay a plain [N,T,E,KX] buffer (agents/sequence.py: step-wise backward)
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     k_ob = 'w_ob'
     coupled = True

@@ -186,14 +186,19 @@ class CoupledSequenceSaved(torch.autograd.Function):
         # zero), dZ / D1 allocated the same way and the h sequence being (T + 1) slabs anyway, every weight-gradient GEMM
         # reads contiguous [N, (T+1) E, .] operands in place -- no masked copy of the h sequence, no gathered copy
         s_ext = ctx.s_ext
-        ext = (s_ext is not None and kind != 'dial' and Hall.is_contiguous() and s_ext.is_contiguous() and
-               S.data_ptr() == s_ext.data_ptr() and tuple(s_ext.shape) == (N, T + 1, E, S.shape[-1]))
+        ext = (s_ext is not None and Hall.is_contiguous() and s_ext.is_contiguous() and
+               S.data_ptr() == s_ext.data_ptr() and tuple(s_ext.shape) == (N, T + 1, E, S.shape[-1]) and
+               (kind != 'dial' or (tuple(A2.shape) == (N, T + 1, E, H) and A2.is_contiguous())))
+        D2e = None
         if ext:
             dZe = torch.empty(N, T + 1, E, H4, dtype=F32, device=dev)
             D1e = torch.empty(N, T + 1, E, H, dtype=F32, device=dev)
             dZe[:, T].zero_()
             D1e[:, T].zero_()
             dZ, D1 = dZe[:, :T], D1e[:, :T]
+            if kind == 'dial':
+                D2e = torch.empty(N, T + 1, E, H, dtype=F32, device=dev)
+                D2e[:, T].zero_()
         else:
             dZ = torch.empty_like(G)
             if kind == 'dial' and tuple(A2.shape) == (N, T + 1, E, H) and A2.is_contiguous():
@@ -205,7 +210,7 @@ class CoupledSequenceSaved(torch.autograd.Function):
             else:
                 D1e = None
                 D1 = torch.empty(N, T, E, H, dtype=F32, device=dev)   # nc/dial: d(pre-relu of hm); ic3: ds
-        D2 = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
+        D2 = (D2e[:, :T] if D2e is not None else torch.empty(N, T, E, H, dtype=F32, device=dev)) if kind == 'dial' else None
         DS = torch.empty(N, T, E, H, dtype=F32, device=dev) if kind == 'dial' else None
         keep = 1.0 - done
         wxm = wx[:, 2 * H:] if kind == 'nc' else wx           # the rows of wx the h-dependent part of the input meets
@@ -286,14 +291,21 @@ class CoupledSequenceSaved(torch.autograd.Function):
             Rx = (T + 1) * E
             Hx, D1x, dZx = Hall.view(N, Rx, H), D1e.view(N, Rx, H), dZe.view(N, Rx, H4)
             # message layer first: its input is the UN-masked h_{t-1} (quirk Q3)
+            dmfc_w = dmfc_b = None
             if kind == 'nc':
                 dwmsg = _dwmsg_by_runs(Hx, D1x, nbr_idx, H)
+            elif kind == 'dial':             # receiver layer on the gathered senders' vectors, sender layer on the un-masked h_{t-1}
+                D2x = D2e.view(N, Rx, H)
+                dwmsg = _dwmsg_by_runs(A2.view(N, Rx, H), D1x, nbr_idx, H)
+                dmfc_w = ops.wgrad(Hx, D2x)
+                dmfc_b = D2x.sum(dim=1) if adj is None else adj[3][1].sum(dim=1)
             elif A1.numel() and tuple(A1.shape) == (N, T + 1, E, H) and A1.is_contiguous():
                 dwmsg = ops.wgrad(A1.view(N, Rx, H), D1x)       # ic3: the rollout kept mean_nbr(h_{t-1}) (A1 = the (T + 1)-slab MM buffer)
             else:
                 dwmsg = ops.wgrad(ops.nbr_mean(Hx, nbr_idx), D1x)
             if db is None:
-                db, dbmsg = (dZx.sum(dim=1) if dbp is None else dbp.sum(dim=1)), D1x.sum(dim=1)
+                db = dZx.sum(dim=1) if dbp is None else dbp.sum(dim=1)
+                dbmsg = D1x.sum(dim=1) if adj is None else adj[3][0].sum(dim=1)
             with torch.no_grad():            # h_{t-1} keep_t for the recurrent weight, in the saved buffer itself (the next
                 for t in masked:             # rollout rewrites it); steps outside `masked` have done_t = 0 by contract
                     Hall[:, t].mul_(keep[t].view(1, E, 1))
@@ -304,8 +316,8 @@ class CoupledSequenceSaved(torch.autograd.Function):
                 if ctx.needs_input_grad[3]:
                     denc = torch.bmm(dZ.reshape(N, R, H4), wx[:, :2 * H].transpose(1, 2)).view(N, T, E, 2 * H)
             else:
-                denc = D1
-            return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, None, None, None, None, None, None, None, None, None)
+                denc = DS if kind == 'dial' else D1
+            return (None, None, None, denc, None, dwx, dwh, db, dwmsg, dbmsg, dmfc_w, dmfc_b, None, None, None, None, None, None, None)
         dZf = dZ.view(N, R, H4)
         Hprev = Hall[:, :T]
         if len(masked) == T:

@@ -438,7 +438,7 @@ class IA2C:
         ops.nstep_return(self.buf_r, self.buf_v, self.buf_done_post, R_end.contiguous(), self.gamma, alpha,
                          self.dist_dev, self.R, self.Adv)
         ps = self.policy.params
-        ps.grad.zero_()
+        ps.begin_backward()
         FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
         X = self.buf_x[:T]            # compact [T,E,N,n_feat] slab: the encoders' kernels gather the neighbours themselves
         if self.save_acts:
@@ -448,6 +448,7 @@ class IA2C:
             Hs = self.policy.unroll(X, FP, self.buf_done_pre, self.h_bw, self.c_bw, masked_steps=self.masked_steps)
         loss = self._loss(Hs)
         loss.backward()
+        ps.end_backward()
         if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)
             ps.grad.mul_(ps.mask)
         scale = 1.0

@@ -107,6 +107,35 @@ class ParamStore:
     def __getitem__(self, key):
         return self.views[key]
 
+    # ---- gradients of one update without an accumulation launch per parameter
+    def begin_backward(self):
+        """Instead of zeroing the flat gradient buffer: detach every parameter's `.grad`, so that autograd's AccumulateGrad takes
+        the first incoming gradient tensor as it is (no `grad += g` launch per parameter); `end_backward` gathers them."""
+        for w in self.views.values():
+            w.grad = None
+
+    def _zero_piece(self, width):
+        z = self.__dict__.setdefault('_zero_pieces', {})
+        if width not in z:
+            z[width] = torch.zeros(self.N, width, dtype=F32, device=self.device)
+        return z[width]
+
+    def end_backward(self):
+        """All parameter gradients -> the flat [N,P] buffer in ONE concatenation (alignment gaps and parameters without a
+        gradient: zeros); `.grad` of every parameter is a view of the flat buffer again afterwards."""
+        pieces, off = [], 0
+        for key, (o, size, shape, _, _) in self.index.items():               # (in offset order)
+            if o > off:
+                pieces.append(self._zero_piece(o - off))
+            g = self.views[key].grad
+            pieces.append(self._zero_piece(size) if g is None else g.reshape(self.N, size))
+            off = o + size
+        if self.P > off:
+            pieces.append(self._zero_piece(self.P - off))
+        torch.cat(pieces, dim=1, out=self.grad)
+        for key, (o, size, shape, _, _) in self.index.items():
+            self.views[key].grad = self.grad[:, o:o + size].view(self.N, *shape)
+
     def _entries(self):
         """(agent, key, offset, size, padded shape, Layout) in the reference's variable creation order."""
         for phase in self.phases:

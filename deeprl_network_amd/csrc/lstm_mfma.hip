@@ -53,6 +53,19 @@ __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * sigm(2.0f * 
 // C/D layout of 16x16x4: col = lane & 15, row = 4 (lane >> 4) + reg -> the four gates of unit j = 16 jj + col
 // are acc[jj], acc[4 + jj], acc[8 + jj], acc[12 + jj] at the same reg: the cell stays lane-local.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// The same activations on the four rows a lane holds of one unit, written as vector arithmetic: operation for operation the scalar
+// formulas above (packing changes no rounding), but the multiplies / adds around the transcendentals become packed fp32
+// instructions (v_pk_mul_f32 / v_pk_add_f32: two values per issue slot -- the epilogues are issue-bound next to the MFMAs)
+__device__ __forceinline__ f32x4 sigm4(const f32x4 x) {
+    f32x4 t = x * -1.4426950408889634f;
+    t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+    t[2] = __builtin_amdgcn_exp2f(t[2]); t[3] = __builtin_amdgcn_exp2f(t[3]);
+    t = t + 1.0f;
+    t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+    t[2] = __builtin_amdgcn_rcpf(t[2]); t[3] = __builtin_amdgcn_rcpf(t[3]);
+    return t;
+}
+__device__ __forceinline__ f32x4 tanh4(const f32x4 x) { return sigm4(x * 2.0f) * 2.0f - 1.0f; }
 constexpr int R16 = 16;                 // rows per wave
 constexpr int WAVES2 = 8;
 constexpr int WPITCH = 16 * 20;         // floats per k row of the permuted W image
@@ -1062,20 +1075,20 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     float* cn = a.c_new + (int64_t)n * a.c_new_sn;
     float* hn_out = a.h_new + (int64_t)n * a.h_new_sn;
     float hv_[4][4];
+    const f32x4 keepv = f32x4{keepr[0], keepr[1], keepr[2], keepr[3]};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
+        const f32x4 gi = sigm4(acc[0 + jj]), gf = sigm4(acc[4 + jj]), go = sigm4(acc[8 + jj]), gu = tanh4(acc[12 + jj]);
+        const f32x4 cpv = f32x4{cp[jj][0], cp[jj][1], cp[jj][2], cp[jj][3]};
+        const f32x4 cv = gf * (cpv * keepv) + gi * gu;
+        const f32x4 hv = go * tanh4(cv);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float keep = keepr[r];
-            const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
-            const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
-            const float cv = gf * (cp[jj][r] * keep) + gi * gu;
-            const float hv = go * tanh_fast(cv);
-            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = hv;      // K loop done: the tile is free
-            cp[jj][r] = cv;                                                        // c' (HEAD 3 / 4: the re-step's previous cell)
-            hv_[jj][r] = hv;
-            acc[0 + jj][r] = gi; acc[4 + jj][r] = gf; acc[8 + jj][r] = go; acc[12 + jj][r] = gu;
+            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = hv[r];   // K loop done: the tile is free
+            cp[jj][r] = cv[r];                                                     // c' (HEAD 3 / 4: the re-step's previous cell)
+            hv_[jj][r] = hv[r];
         }
+        acc[0 + jj] = gi; acc[4 + jj] = gf; acc[8 + jj] = go; acc[12 + jj] = gu;
     }
     {
         // HEAD 4: h' is written THROUGH (sc1) -- the neighbours' blocks read it later in this launch (offset in a VGPR)
@@ -1219,15 +1232,14 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 gi = sigm4(acc[0 + jj]), gf = sigm4(acc[4 + jj]), go = sigm4(acc[8 + jj]), gu = tanh4(acc[12 + jj]);
+            const f32x4 cpv = f32x4{cp[jj][0], cp[jj][1], cp[jj][2], cp[jj][3]};
+            const f32x4 cv = gf * (cpv * keepv) + gi * gu;
+            const f32x4 hv = go * tanh4(cv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float keep = keepr[r];
-                const float gi = sigm(acc[0 + jj][r]), gf = sigm(acc[4 + jj][r]);
-                const float go = sigm(acc[8 + jj][r]), gu = tanh_fast(acc[12 + jj][r]);
-                const float cv = gf * (cp[jj][r] * keep) + gi * gu;
-                a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = go * tanh_fast(cv);
-            }
+            for (int r = 0; r < 4; ++r) a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = hv[r];
+        }
         NMARL_STAMP(33)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

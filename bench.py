@@ -357,6 +357,11 @@ def run_other_config(args, cfg_name, device):
     cp.read(os.path.join(ROOT, 'config', cfg_name))
     sub = argparse.Namespace(**vars(args))
     sub.envs = 0
+    from deeprl_network_amd import ops
+    # a fresh job: a time-out of an earlier config in this process must neither pin this one to the slow forms nor make its
+    # guarded optimiser steps refuse (both are reported below if they happen here)
+    ops.enable_inkernel_handoff()
+    ops.handoff_clear(device)
     E, env, model, trainer = make_job(sub, cp, device, 0, 1, None)
     for _ in range(max(2, args.warmup)):
         trainer.run_batch()
@@ -373,7 +378,9 @@ def run_other_config(args, cfg_name, device):
            'steps': args.other_steps, 'ms_per_step': elapsed / args.other_steps * 1e3,
            'value': n_agent * E * n_step * args.other_steps / elapsed, 'unit': 'env-steps/s',
            'a2c_updates_per_s': args.other_steps / elapsed, 'handoff_fallbacks': trainer.handoff_fallbacks,
-           'one_launch_lock_step': bool(model.policy.pv_one_launch(E))}
+           'one_launch_lock_step': bool(model.policy.pv_one_launch(E)),
+           'hipgraph_update': trainer._upd is not None, 'update_capture_error': trainer.update_capture_error,
+           'inkernel_handoff_enabled': bool(ops.handoff_enabled())}
     try:
         us_l, flops_l, bytes_l, lname = measure_lstm_step(model)
         us_iso = us_l
@@ -694,7 +701,8 @@ def main():
                                % (('ATSC Monaco-like network (synthetic, heterogeneous agents)' if env.name.endswith('real_net') else 'ATSC 5x5 grid (synthetic)') if is_grid else 'CACC ' + env.name, n_agent, E, env.agent,
                                   os.path.basename(args.config), n_step),
                    'replicas_per_gpu': E, 'global_replicas': E * world, 'parallelism': 'dp%d' % world,
-                   'hipgraph_rollout': trainer.use_graph,
+                   'hipgraph_rollout': trainer.use_graph, 'hipgraph_update': trainer._upd is not None,
+                   'update_capture_error': trainer.update_capture_error,
                    'gemm_autotune': os.environ.get('PYTORCH_TUNABLEOP_ENABLED', '0') == '1',
                    'step_definition': 'one n_step batch: %d lock-steps (2 LSTM steps each, quirk Q1) + bootstrap + '
                                       '1 A2C update over all replicas' % n_step},

@@ -40,18 +40,19 @@ class IA2C:
     uses_fingerprint = False         # forward() receives neighbour policies `ps` (MA2C family)
 
     def __init__(self, n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, model_config,
-                 seed=0, num_envs=1, device='cuda', dist_group=None, n_feat=None, n_feat_ls=None):
-        """The reference's constructor (models.py:20-24) + batching arguments.  n_feat_ls: per-agent OWN observation
+                 seed=0, num_envs=1, device='cuda', dist_group=None, n_feat=None, n_feat_ls=None, obs_order=None):
+        """The reference's constructor (models.py:20-24) + batching arguments.  obs_order (IA2C family): the env's
+        `neighbor_order`, see BatchedPolicy.  n_feat_ls: per-agent OWN observation
         widths of heterogeneous systems (agents with different action counts, `identical_agent = False`,
         models.py:89-96).  MA2C envs report them as n_s_ls; the IA2C family's n_s_ls are the concatenated widths, from
         which the own widths are recovered when the system (I + neighbor_mask) x = n_s_ls determines them."""
         self.name = getattr(self, 'name', 'ia2c')
         self._init_algo(n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, seed,
-                        model_config, num_envs, device, dist_group, n_feat, n_feat_ls)
+                        model_config, num_envs, device, dist_group, n_feat, n_feat_ls, obs_order)
 
     # ------------------------------------------------------------------ construction
     def _init_algo(self, n_s_ls, n_a_ls, neighbor_mask, distance_mask, coop_gamma, total_step, seed,
-                   model_config, num_envs, device, dist_group, n_feat, n_feat_ls=None):
+                   model_config, num_envs, device, dist_group, n_feat, n_feat_ls=None, obs_order=None):
         self.n_s_ls, self.n_a_ls = [int(x) for x in n_s_ls], [int(x) for x in n_a_ls]
         self.n_a = max(self.n_a_ls)
         self.neighbor_mask = np.asarray(neighbor_mask)
@@ -83,7 +84,8 @@ class IA2C:
         self.n_feat = int(n_feat)
         self.policy = self.policy_cls(self.n_feat, self.n_a, self.neighbor_mask, n_fc=self.n_fc,
                                       n_h=self.n_lstm, device=self.device, n_feat_ls=self.n_feat_ls,
-                                      n_a_ls=None if self.identical_agent else self.n_a_ls)
+                                      n_a_ls=None if self.identical_agent else self.n_a_ls,
+                                      obs_order=None if self._is_ma2c() else obs_order)
         self.policy.params.init_reference_order()       # consumes np.random like the reference's ortho_init
         self.n_s = self.n_s_ls[0]
         N, E, H, T = self.n_agent, self.E, self.n_lstm, self.n_step
@@ -420,11 +422,31 @@ class IA2C:
 
     def update(self, R_end, rotate=True):
         """model.backward (models.py:34-42 / 211-215) for all replicas: R_end [N,E].  rotate=False: the caller hands the
-        states / slot T of the rollout buffers over to the next batch itself (BatchedTrainer: ops.batch_epilogue)."""
+        states / slot T of the rollout buffers over to the next batch itself (BatchedTrainer: ops.batch_epilogue).
+        = the four phases below back to back; BatchedTrainer captures `update_grads` and `update_apply` in hipGraphs and
+        replays them around the (eager) gradient exchange, calling the two host-only phases itself."""
+        lr = self.update_begin()
+        self.update_grads(R_end)
+        self.update_reduce()
+        self.update_apply(lr, rotate=rotate)
+        self.update_end()
+
+    def update_begin(self):
+        """Host only: advance the lr schedule.  It counts lock-steps (environment steps per replica), the reference's
+        get(n_step): the ini's total_step keeps its meaning for any number of replicas and ranks."""
         assert self.t == self.n_step, 'update() needs a full n_step batch (got %d)' % self.t
-        # the schedule counts lock-steps (environment steps per replica), the reference's get(n_step): the ini's
-        # total_step keeps its meaning for any number of replicas and ranks
-        cur_lr = self.lr_scheduler.get(self.n_step)
+        self.cur_lr = self.lr_scheduler.get(self.n_step)
+        return self.cur_lr
+
+    @property
+    def handoff_guarded(self):
+        """This model launches in-launch hand-off kernels (one-launch coupled lock-step / BPTT): its optimiser step consults
+        the device's hand-off status word and refuses a batch a timed-out wave contributed to (ops.rmsprop_tf_clip)."""
+        return bool(self.policy.coupled) and self.device.type == 'cuda'
+
+    def update_grads(self, R_end):
+        """Device work of one update up to the flat gradient: returns / advantages, loss, backward (no host
+        synchronisation, static shapes and addresses: capturable)."""
         alpha = self.coop_gamma if self.coop_gamma >= 0 else -1.0
         T = self.n_step
         if self.save_acts and self.policy.pv_one_launch(self.E):
@@ -451,31 +473,48 @@ class IA2C:
         ps.end_backward()
         if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)
             ps.grad.mul_(ps.mask)
-        scale = 1.0
-        if self.dist_group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(ps.grad, group=self.dist_group)          # ONE flat RCCL all-reduce over xGMI
-            scale = 1.0 / dist.get_world_size(self.dist_group)
-            if self.policy.coupled and self.save_acts and self.device.type == 'cuda' and ops.handoff_enabled():
-                # a rank whose in-launch hand-off timed out contributed invalid gradients: every rank must refuse the step
-                # (and recover in lock-step, BatchedTrainer.run_batch) -- the status word travels as a MAX reduction
-                dist.all_reduce(ops.handoff_status(self.device)[:1], op=dist.ReduceOp.MAX, group=self.dist_group)
+
+    def update_reduce(self):
+        """The data-parallel exchange: ONE flat all-reduce of the gradient (RCCL over xGMI)."""
+        if self.dist_group is None:
+            return
+        import torch.distributed as dist
+        dist.all_reduce(self.policy.params.grad, group=self.dist_group)
+        if self.handoff_guarded and self.save_acts and ops.handoff_enabled():
+            # a rank whose in-launch hand-off timed out contributed invalid gradients: every rank must refuse the step
+            # (and recover in lock-step, BatchedTrainer.run_batch) -- the status word travels as a MAX reduction
+            dist.all_reduce(ops.handoff_status(self.device)[:1], op=dist.ReduceOp.MAX, group=self.dist_group)
+
+    def update_apply(self, lr, rotate=True, lr_dev=None):
+        """clip_by_global_norm + RMSProp on the flat buffers (policies.py:32-39, 257-264); lr_dev: device scalar that
+        overrides `lr` (captured updates: the host refreshes it when the schedule moves)."""
+        ps = self.policy.params
+        scale = 1.0 / self.world_size
+        guard = self.handoff_guarded
         if self.per_agent_optimizer:
-            ops.rmsprop_tf_clip(ps.flat, ps.grad, ps.ms, ps.scratch, cur_lr, self.rmsp_alpha, self.rmsp_epsilon,
-                                self.max_grad_norm, scale, self.grad_norm)
+            ops.rmsprop_tf_clip(ps.flat, ps.grad, ps.ms, ps.scratch, lr, self.rmsp_alpha, self.rmsp_epsilon,
+                                self.max_grad_norm, scale, self.grad_norm, lr_dev=lr_dev, guard=guard)
         else:
             n = self.n_agent * ps.P
-            ops.rmsprop_tf_clip(ps.flat.view(1, n), ps.grad.view(1, n), ps.ms.view(1, n), ps.scratch, cur_lr,
-                                self.rmsp_alpha, self.rmsp_epsilon, self.max_grad_norm, scale, self.grad_norm)
+            ops.rmsprop_tf_clip(ps.flat.view(1, n), ps.grad.view(1, n), ps.ms.view(1, n), ps.scratch, lr,
+                                self.rmsp_alpha, self.rmsp_epsilon, self.max_grad_norm, scale, self.grad_norm,
+                                lr_dev=lr_dev, guard=guard)
+        self._after_apply()
         if rotate:
+            T = self.n_step
             # states_bw <- states_fw (policies.py:115, 211)
             self.h_bw.copy_(self.h_fw)
             self.c_bw.copy_(self.c_fw)
             # slot T (bootstrap inputs) is slot 0 of the next batch
             self.buf_x[0].copy_(self.buf_x[T])
             self.buf_fp[0].copy_(self.buf_fp[T])
+
+    def _after_apply(self):
+        """Hook behind the optimiser step (ConseNet: the consensus averaging)."""
+
+    def update_end(self):
+        """Host only: the batch is consumed."""
         self.t = 0
-        self.cur_lr = cur_lr
         self.policy._enc_was_saved = False       # the saved encoder outputs belonged to this batch (the next rollout sets it again)
         self.policy._mm_was_saved = False
 
@@ -496,11 +535,13 @@ class IA2C:
             if self._is_ma2c():
                 continue
             pos = p.n_own[i]
-            for k, j in enumerate(p.nbrs[i]):
+            for j in p.obs_order[i]:                     # the env's concatenation order -> the slab's ascending slots
+                k = p.nbrs[i].index(j)
                 slab[0, i, (k + 1) * F:(k + 1) * F + p.n_own[j]] = o[pos:pos + p.n_own[j]]
                 pos += p.n_own[j]
             if fp is not None:
-                for k, j in enumerate(p.nbrs[i]):
+                for j in p.obs_order[i]:
+                    k = p.nbrs[i].index(j)
                     fp[i, 0, k * A:k * A + p.n_a_ls[j]] = o[pos:pos + p.n_a_ls[j]]
                     pos += p.n_a_ls[j]
         slab = torch.from_numpy(slab).to(self.device)
@@ -553,6 +594,10 @@ class IA2C:
     def backward(self, Rends, dt=0, summary_writer=None, global_step=None):
         R_end = torch.as_tensor(np.asarray(Rends, dtype=np.float32).reshape(self.n_agent, 1)).to(self.device)
         self.update(R_end)
+        if self.handoff_guarded:
+            # the reference API has no trainer that re-runs a batch: a timed-out in-launch hand-off (whose optimiser step the
+            # device refused) is an error here, not a silent no-op (this path synchronises every lock-step anyway)
+            ops.check_coupled_status(self.device)
 
     def reset(self):
         self.reset_states()
@@ -688,8 +733,7 @@ class IA2C_CU(MA2C_NC):
     policy_cls = ConsensusPolicy
     name = 'ma2c_cu'
 
-    def update(self, R_end, rotate=True):
-        super().update(R_end, rotate=rotate)
+    def _after_apply(self):
         self.policy.consensus_update()
 
 

@@ -222,8 +222,14 @@ class BatchedPolicy:
     name = 'policy'
     fused_coupled = True          # coupled policies: use agents/sequence.py in the update
 
-    def __init__(self, n_feat, n_a, neighbor_mask, n_fc=64, n_h=64, device='cuda', n_feat_ls=None, n_a_ls=None):
+    def __init__(self, n_feat, n_a, neighbor_mask, n_fc=64, n_h=64, device='cuda', n_feat_ls=None, n_a_ls=None, obs_order=None):
         """n_feat / n_a: own observation width / action count of an agent -- the maxima when agents differ.
+        obs_order (IA2C family only): per agent the neighbours in the order the ENV concatenates them into that agent's
+        observation (the ATSC envs list them north-east-south-west, atsc_env.py:263-271; None: ascending index, CACC).  The
+        engine's slab and its gather kernels stay in ascending-slot order; the order only decides which rows of the padded
+        observation / fingerprint weights the reference's variable rows occupy (`_L_slots`, `_L_fp_obs`) and how the E = 1
+        API scatters an observation vector into the slab (models._obs_to_slab) -- so initial draws, checkpoints and the
+        function computed from the env's vectors are the reference's.
         n_feat_ls / n_a_ls: the per-agent values of heterogeneous systems (`identical=False` nets of the reference:
         agents/utils.py:220-341, 420-512, 602-719; policies.py:59-77 with na_dim_ls).  Those run as the SAME padded
         batched network: observations, fingerprints, logits and one-hots are padded to the maxima, the reference's
@@ -244,6 +250,10 @@ class BatchedPolicy:
             raise ValueError('heterogeneous agents: n_feat / n_a must be the maxima of n_feat_ls / n_a_ls')
         tab = self.nbr_idx.cpu().numpy()
         self.nbrs = [[int(j) for j in tab[i] if j >= 0] for i in range(self.N)]
+        self.obs_order = self.nbrs if obs_order is None else [[int(j) for j in o] for o in obs_order]
+        if any(sorted(o) != n for o, n in zip(self.obs_order, self.nbrs)):
+            raise ValueError('obs_order must list exactly the neighbours of every agent')
+        self.obs_permuted = self.obs_order != self.nbrs
         # [own | neighbours] gather table for compact observations: slot 0 = the agent itself
         self.nbr_self = torch.cat([torch.arange(self.N, dtype=torch.int32, device=self.device).view(-1, 1), self.nbr_idx], dim=1)
         self.n_obs = n_feat * (1 + self.m_max)          # gathered observation slab width
@@ -257,20 +267,27 @@ class BatchedPolicy:
     def _L_slots(self, i):
         """Rows of a weight over the gathered observation slab [own | nbr_1 | ... ] (slots n_feat wide)."""
         F = self.n_feat
-        if not self.hetero:
+        if not self.hetero and not self.obs_permuted:
             return F * (1 + self._m(i))
         rows = list(range(self.n_own[i]))
-        for k, j in enumerate(self.nbrs[i]):
+        for j in self.obs_order[i]:                      # the reference variable's row blocks follow the env's order;
+            k = self.nbrs[i].index(j)                    # neighbour j sits in (ascending) slot k + 1 of the slab
             rows += [(k + 1) * F + f for f in range(self.n_own[j])]
         return Layout(rows=rows)
 
-    def _L_fp(self, i):
-        """Rows of a weight over the gathered neighbour fingerprints / action one-hots (slots n_a wide)."""
+    def _L_fp(self, i, order=None):
+        """Rows of a weight over the gathered neighbour fingerprints / action one-hots (slots n_a wide; the critic's one-hots
+        are in mask order, i.e. ascending)."""
         A = self.n_a
-        if not self.hetero:
+        if not self.hetero and order is None:
             return A * self._m(i)
-        return Layout(rows=[k * A + a for k, j in enumerate(self.nbrs[i]) for a in range(self.n_a_ls[j])],
-                      exists=self._m(i) > 0)
+        order = self.nbrs[i] if order is None else order
+        return Layout(rows=[self.nbrs[i].index(j) * A + a for j in order for a in range(self.n_a_ls[j])],
+                      exists=(not self.hetero) or self._m(i) > 0)
+
+    def _L_fp_obs(self, i):
+        """Rows of a weight over the fingerprints that arrive INSIDE the observation (IA2C-FP: the env's neighbour order)."""
+        return self._L_fp(i, order=self.obs_order[i] if self.obs_permuted else None)
 
     def _L_nbr(self, rows_per_nbr=None):
         """A variable of the neighbour-facing layers: `rows_per_nbr` leading rows per neighbour (None: full tensor);
@@ -674,7 +691,7 @@ class FPPolicy(LstmPolicy):
         nf, H, F, A = self.n_fc, self.n_h, self.n_feat, self.n_a
         return [[('fcs_w', 'lstm_%d/fcs/w', (self.n_obs, nf), self._L_slots),
                  ('fcs_b', 'lstm_%d/fcs/b', (nf,), None),
-                 ('fcp_w', 'lstm_%d/fcp/w', (self.n_na, nf), self._L_fp),
+                 ('fcp_w', 'lstm_%d/fcp/w', (self.n_na, nf), self._L_fp_obs),
                  ('fcp_b', 'lstm_%d/fcp/b', (nf,), self._L_nbr()),
                  ('lstm_wx', 'lstm_%d/lstm/wx', (2 * nf, 4 * H), self._L_blocks(nf, 2)),
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),

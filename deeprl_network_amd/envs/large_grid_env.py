@@ -25,6 +25,54 @@ def grid_masks():
     return (dist == 1).astype(int), dist
 
 
+def grid_neighbor_order():
+    """For every node its neighbours in the order the reference's `neighbor_map` lists them (large_grid_env.py:58-85: north,
+    east, south, west, the absent ones skipped; node i = row * 5 + col = nt{i+1}, north = i + 5).  This -- not the ascending
+    index -- is the order in which an IA2C / IA2C-FP agent's observation concatenates the neighbours' wave vectors and
+    fingerprints (atsc_env.py:263-271); neighbour ACTIONS and the MA2C nets' gathers use the mask order (ascending)."""
+    out = []
+    for i in range(N_NODE):
+        r, c = divmod(i, 5)
+        cand = [(r + 1, c), (r, c + 1), (r - 1, c), (r, c - 1)]
+        out.append([rr * 5 + cc for rr, cc in cand if 0 <= rr < 5 and 0 <= cc < 5])
+    return out
+
+
+# link -> physical lane (oracle/grid_ref.py LINK_LANE): the 12-wide wave vector counts duplicated lanes (SURVEY.md 8a)
+_LANE_FIRST_LINK = (0, 3, 5, 6, 9, 11)
+
+
+class LargeGridController:
+    """The reference's rule-based `greedy` agent (large_grid_env.py:30-45): per node the phase whose served lanes hold the
+    most vehicles.  The reference indexes a 6-lane observation [N, E lane 0, E lane 1, S, W lane 0, W lane 1]; this env's
+    wave vector has one entry per signal LINK (12, duplicated lanes), so the six lanes are read at their first links.
+    Same `forward(obs) -> actions` duck-type; `reset` / `load` exist so that Trainer.perform / main.py evaluate drive it."""
+    name = 'greedy'
+    n_step = 1
+
+    def __init__(self, node_names=None):
+        self.node_names = node_names
+
+    @staticmethod
+    def lane_counts(ob):
+        ob = np.asarray(ob, dtype=np.float64).reshape(-1)
+        return ob if len(ob) == 6 else ob[list(_LANE_FIRST_LINK)]
+
+    def greedy(self, ob, node_name=None):
+        q = self.lane_counts(ob)
+        # phases of large_grid_env.py:25-26: N+S through, E+W left, E+W through, E approach, W approach
+        return int(np.argmax([q[0] + q[3], q[2] + q[5], q[1] + q[4], q[1] + q[2], q[4] + q[5]]))
+
+    def forward(self, obs):
+        return [self.greedy(ob) for ob in obs]
+
+    def reset(self):
+        return
+
+    def load(self, model_dir, checkpoint=None):
+        return True
+
+
 def grid_params_from_config(config):
     """ENV_CONFIG section -> nmarl_grid_params_t; keys of atsc_env.py:79-99 + large_grid_env.py:50-52."""
     if config.getint('control_interval_sec') != 5 or config.getint('yellow_interval_sec') != 2:
@@ -60,7 +108,8 @@ class LargeGridBatchEnv:
         self.n_a = N_PHASE
         self.n_a_ls = [N_PHASE] * N_NODE
         self.neighbor_mask, self.distance_mask = grid_masks()
-        self.n_s_ls = [N_FEAT if self.agent.startswith('ma2c') else N_FEAT * (1 + int(self.neighbor_mask[i].sum()))
+        self.neighbor_order = grid_neighbor_order()
+        self.n_s_ls = [N_FEAT * (1 + int(self.neighbor_mask[i].sum())) if self.agent.startswith('ia2c') else N_FEAT
                        for i in range(N_NODE)]
         self.train_mode = True
         E, d = self.E, self.device
@@ -116,9 +165,9 @@ class LargeGridBatchEnv:
 
 class LargeGridEnv:
     """Reference duck-type (atsc_env.py:77-524 / large_grid_env.py:48-137) for ONE replica.
-    Observation lists: `ma2c*` 12 wave features; `ia2c*` own + neighbours' (ascending node index --
-    the reference uses its N,E,S,W list order there, atsc_env.py:263-269: a fixed permutation of the
-    input columns) (+ neighbour fingerprints for ia2c_fp)."""
+    Observation lists: `ma2c*` / `greedy` 12 wave features; `ia2c*` own + neighbours' in the reference's `neighbor_map` list
+    order (north, east, south, west: atsc_env.py:263-269, `neighbor_order`) (+ the neighbours' fingerprints in the same order
+    for ia2c_fp); neighbour actions in mask order (ascending, atsc_env.py:132-136)."""
 
     def __init__(self, config, port=0, device='cuda', **_):
         self.batch = LargeGridBatchEnv(config, num_envs=1, device=device)
@@ -126,6 +175,8 @@ class LargeGridEnv:
         self.name, self.agent, self.coop_gamma, self.T = b.name, b.agent, b.coop_gamma, b.T
         self.n_agent, self.n_a, self.n_a_ls, self.n_s_ls = b.n_agent, b.n_a, b.n_a_ls, b.n_s_ls
         self.neighbor_mask, self.distance_mask = b.neighbor_mask, b.distance_mask
+        self.neighbor_order = b.neighbor_order
+        self.node_names = ['nt%d' % (i + 1) for i in range(self.n_agent)]
         self.seed = config.getint('seed')
         self.control_interval_sec = config.getint('control_interval_sec')
         self.init_test_seeds([int(s) for s in config.get('test_seeds').split(',')])
@@ -164,13 +215,14 @@ class LargeGridEnv:
             pd.DataFrame(self.control_data).to_csv(self.output_path + ('%s_%s_control.csv' % (self.name, self.agent)))
 
     def _state_list(self):
-        x = self.batch.obs[0].cpu().numpy().astype(np.float64)
+        own = self.batch.obs[0, :, :N_FEAT].cpu().numpy().astype(np.float64)      # every node's own wave vector leads its row
         out = []
         for i in range(self.n_agent):
-            w = N_FEAT * (1 + len(self._nbr[i])) if self.agent.startswith('ia2c') else N_FEAT
-            cur = [x[i, :w]]
+            cur = [own[i]]
+            if self.agent.startswith('ia2c'):
+                cur += [own[j] for j in self.neighbor_order[i]]
             if self.agent == 'ia2c_fp':
-                cur += [np.asarray(self.fp[j]) for j in self._nbr[i]]
+                cur += [np.asarray(self.fp[j]) for j in self.neighbor_order[i]]
             out.append(np.concatenate(cur))
         return out
 
@@ -189,10 +241,10 @@ class LargeGridEnv:
         _, reward, done, g = self.batch.step(a)
         global_reward = float(g.item())
         done = bool(done.item())
-        if self.coop_gamma < 0 and self.train_mode:
+        if self.agent == 'greedy' or self.coop_gamma < 0:                           # atsc_env.py:205-206
             reward = global_reward
         else:
-            reward = reward[0].cpu().numpy().astype(np.float64) if self.coop_gamma >= 0 else global_reward
+            reward = reward[0].cpu().numpy().astype(np.float64)
         if self.is_record:
             sec = int(self.batch.t.item()) * self.control_interval_sec
             self.control_data.append({'episode': self.cur_episode, 'time_sec': sec,

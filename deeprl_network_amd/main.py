@@ -9,6 +9,7 @@ import torch
 
 from .agents.models import IA2C, IA2C_CU, IA2C_FP, MA2C_DIAL, MA2C_IC3, MA2C_NC
 from .envs import init_env, make_batch_env
+from .envs.large_grid_env import LargeGridController
 from .utils import (BatchedTrainer, Counter, Evaluator, SummaryWriter, Trainer, check_dir, copy_file, find_file,
                     init_dir, init_log)
 
@@ -38,11 +39,13 @@ def parse_args(argv=None):
 
 
 def init_agent(env, config, total_step, seed, **kw):
+    if env.agent == 'greedy':                  # rule-based baseline of the ATSC scenarios (large_grid_env.py:30-45)
+        return LargeGridController(getattr(env, 'node_names', None)) if env.name.endswith('large_grid') else None
     cls = AGENTS.get(env.agent)
     if cls is None:
         return None
     return cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, total_step, config,
-               seed=seed, n_feat_ls=getattr(env, 'n_feat_ls', None), **kw)
+               seed=seed, n_feat_ls=getattr(env, 'n_feat_ls', None), obs_order=getattr(env, 'neighbor_order', None), **kw)
 
 
 def _dist():

@@ -49,9 +49,15 @@ def handoff_clear(device):
 
 
 def disable_inkernel_handoff():
-    """Pin the launch-per-step forms for the rest of the process (BatchedTrainer after a time-out; same effect as
-    NMARL_INKERNEL_HANDOFF=0)."""
+    """Select the launch-per-step forms process-wide until `enable_inkernel_handoff` (BatchedTrainer after a time-out; same
+    effect as NMARL_INKERNEL_HANDOFF=0 while it lasts)."""
     _handoff_off[0] = True
+
+
+def enable_inkernel_handoff():
+    """Undo `disable_inkernel_handoff` (BatchedTrainer's re-arm after a run of clean batches, a new job in the same
+    process); the NMARL_INKERNEL_HANDOFF=0 environment switch still wins."""
+    _handoff_off[0] = False
 
 
 def handoff_enabled():
@@ -932,6 +938,18 @@ def bptt_coupled_supported(kind, m_max, H, rev=None):
 
 
 _coupled_ws = {}
+_keepalive = [None]
+
+
+def keepalive_begin(sink):
+    """While a caller captures launches in a hipGraph: every pooled workspace handed out until `keepalive_end` is also
+    appended to `sink` (a list the graph's owner keeps), so that the pool's LRU eviction cannot free memory whose address a
+    captured graph replays."""
+    _keepalive[0] = sink
+
+
+def keepalive_end():
+    _keepalive[0] = None
 
 
 COUPLED_RING_MAX_BYTES = 4 << 30     # one slot per step (one-launch form) up to this size, else two slots (step-wise)
@@ -957,6 +975,8 @@ def _coupled_workspace(dev, N, E, K, T):
                  db=torch.zeros(N, tiles, 4 * FUSED_H, dtype=F32, device=dev), dbm=torch.zeros(N, tiles, FUSED_H, dtype=F32, device=dev),
                  tiles=tiles)
         _coupled_ws[key] = w
+    if _keepalive[0] is not None:
+        _keepalive[0].append(w)
     return w
 
 
@@ -1326,14 +1346,16 @@ def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, ad
     return R_out, adv_out
 
 
-def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, norm_out=None, lr_dev=None):
-    """In-place clip_by_global_norm + TF RMSProp on flat [G,P] buffers."""
+def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, norm_out=None, lr_dev=None, guard=False):
+    """In-place clip_by_global_norm + TF RMSProp on flat [G,P] buffers.  guard: the caller's model launches in-launch
+    hand-off kernels -- the step then consults the device's hand-off status word and changes nothing while it is set (a
+    batch whose hand-off timed out cannot reach the weights: fail closed).  Models without such kernels do not look at the
+    word, so another model's time-out on the same device cannot silence their updates."""
     G, P = w.shape
-    # guarded by the device's hand-off status: a batch whose in-launch hand-off timed out changes nothing (fail closed)
     check(lib.nmarl_rmsprop_tf_clip_guarded(G, P, ptr(w, F32), ptr(g, F32), ptr(ms, F32), ptr(scratch, F32),
                                             ptr(lr_dev, F32), float(lr), float(rho), float(eps), float(max_norm),
                                             float(grad_scale), ptr(norm_out, F32),
-                                            ptr(handoff_status(w.device), torch.int32) if w.is_cuda else None, stream()),
+                                            ptr(handoff_status(w.device), torch.int32) if (guard and w.is_cuda) else None, stream()),
           'nmarl_rmsprop_tf_clip')
 
 

@@ -1,11 +1,10 @@
 """Rollout / training loops -- the reference's root utils.py (Counter 70-97,
 Trainer 100-254, Evaluator 311-336) plus the batched MI355X trainer.
 
-  * `Trainer`         the reference's single-replica loop, semantics unchanged
-                      (quirks Q1-Q5 of SURVEY.md 3.2, global np.random action draws,
-                      CACC test episode after every training episode,
-                      train_reward.csv).  It drives any env with the reference
-                      duck-type (envs.cacc_env.CACCEnv is the GPU E=1 adapter).
+  * `Trainer`         the reference Trainer's public surface for ONE replica (quirks Q1-Q5
+                      of SURVEY.md 3.2, global np.random action draws, CACC test episode
+                      after every training episode, train_reward.csv), built on a
+                      lock-step primitive and an episode cursor of this repo.
   * `BatchedTrainer`  E lock-stepped replicas, everything resident in HBM: the
                       n_step rollout (policy step x2, action draw, env step) is
                       one captured hipGraph, the A2C update runs once per batch,
@@ -104,153 +103,175 @@ class SummaryWriter:
         self._rows = []
 
 
-# ------------------------------------------------------------------ reference-compatible loop
+# ------------------------------------------------------------------ the E = 1 driver behind the reference's Trainer surface
+class _Decision:
+    """What all agents decided at one lock-step: the policies pi, the drawn (or arg-max) actions, the critic values and the
+    `side` input of the critic / the transition record -- the neighbours' fingerprints for the MA2C family (stacked arrays),
+    the neighbours' actions for the IA2C family (per-agent lists)."""
+    __slots__ = ('policy', 'action', 'value', 'side')
+
+    def __init__(self, policy, action, value=None, side=None):
+        self.policy, self.action, self.value, self.side = policy, action, value, side
+
+
+class _Cursor:
+    """Where a running episode stands: the observation the next decision reads and the done flag BEFORE that decision
+    (True right after a reset: it clears the recurrent state, quirk Q3)."""
+    __slots__ = ('ob', 'done')
+
+    def __init__(self, ob, done=True):
+        self.ob, self.done = ob, done
+
+
+def _pick(pi, greedy):
+    # one uniform of the global MT19937 stream per stochastic draw (quirk Q5: the reference's np.random.choice contract)
+    return int(np.argmax(pi)) if greedy else int(np.random.choice(len(pi), p=pi))
+
+
 class Trainer:
-    """The reference's Trainer (utils.py:100-254) for ONE replica."""
+    """Single-replica training loop with the reference Trainer's public surface (utils.py:100-254: constructor, `explore`,
+    `perform`, `run`, `data`, `episode_rewards`, the train_reward.csv rows) and its observable call order on env and model
+    (quirks Q1-Q5 of SURVEY.md 3.2, pinned by the E2E goldens).  The loop itself is organised around two pieces of this
+    repo: `_lock_step` (ONE decision of all agents: policy forward, action draw, then the value forward that re-steps the
+    LSTM from the state the policy forward just wrote -- Q1) and `_walk` (a generator that advances an episode cursor one
+    env step at a time); `explore`, the bootstrap and `perform` are thin consumers of them.  It drives any env with the
+    reference duck-type (envs.cacc_env.CACCEnv is the GPU E = 1 adapter); models without a policy (`agent == 'greedy'`,
+    large_grid_env.py:30-45) decide through `model.forward(ob)` alone."""
 
     def __init__(self, env, model, global_counter, summary_writer, output_path=None):
-        self.cur_step = 0
-        self.global_counter = global_counter
-        self.env = env
-        self.agent = self.env.agent
-        self.model = model
-        self.n_step = self.model.n_step
-        self.summary_writer = summary_writer
-        assert self.env.T % self.n_step == 0
-        self.data = []
-        self.output_path = output_path
-        self.env.train_mode = True
+        assert env.T % model.n_step == 0
+        self.env, self.model = env, model
+        self.agent = env.agent
+        self.n_step = model.n_step
+        self.global_counter, self.summary_writer, self.output_path = global_counter, summary_writer, output_path
+        self.data, self.episode_rewards, self.cur_step = [], [], 0
+        env.train_mode = True
 
-    def _add_summary(self, reward, global_step, is_train=True):
-        if self.summary_writer is not None:
-            self.summary_writer.add_scalar('train_reward' if is_train else 'test_reward', reward, global_step)
+    # -- agent family: MA2C models take / return stacked arrays and read the fingerprints; IA2C models take per-agent lists
+    @property
+    def _stacked(self):
+        return self.agent.startswith('ma2c')
 
-    def _get_policy(self, ob, done, mode='train'):
-        if self.agent.startswith('ma2c'):
-            self.ps = self.env.get_fingerprint()
-            policy = self.model.forward(ob, done, self.ps)
-        else:
-            policy = self.model.forward(ob, done)
-        action = []
-        for pi in policy:
-            if mode == 'train':
-                action.append(np.random.choice(np.arange(len(pi)), p=pi))     # global MT19937 stream (Q5)
+    def _lock_step(self, ob, done, greedy=False, with_value=True):
+        """-> _Decision.  Call order on the model: forward(.., 'p') then forward(.., 'v') (the second advances nothing the
+        first did not: it re-steps a scratch copy, Q1)."""
+        env, model = self.env, self.model
+        if self.agent == 'greedy':                               # rule-based controller: actions straight from the observation
+            return _Decision(None, np.asarray(model.forward(ob)))
+        fps = env.get_fingerprint() if self._stacked else None
+        pi = model.forward(ob, done, fps) if self._stacked else model.forward(ob, done)
+        action = np.array([_pick(p, greedy) for p in pi])
+        d = _Decision(pi, action, side=fps)
+        if with_value:
+            if self._stacked:
+                d.value = model.forward(ob, done, fps, action, 'v')
             else:
-                action.append(np.argmax(pi))
-        return policy, np.array(action)
+                d.side = env.get_neighbor_action(action)
+                d.value = model.forward(ob, done, d.side, 'v')
+        return d
 
-    def _get_value(self, ob, done, action):
-        if self.agent.startswith('ma2c'):
-            value = self.model.forward(ob, done, self.ps, np.array(action), 'v')
-        else:
-            self.naction = self.env.get_neighbor_action(action)
-            value = self.model.forward(ob, done, self.naction, 'v')
-        return value
-
-    def _log_episode(self, global_step, mean_reward, std_reward):
-        self.data.append({'agent': self.agent, 'step': global_step, 'test_id': -1,
-                          'avg_reward': mean_reward, 'std_reward': std_reward})
-        self._add_summary(mean_reward, global_step)
-        if self.summary_writer is not None:
-            self.summary_writer.flush()
+    def _walk(self, cur, greedy=False, learn=False):
+        """Generator over the env steps of the episode `cur` points into; the cursor is advanced BEFORE each yield (a
+        terminal step leaves `cur.ob` at the last pre-step observation).  learn: every step is a transition of the model's
+        n-step buffer.  Yields (decision, reward, global_reward)."""
+        env = self.env
+        while True:
+            ob, d = cur.ob, self._lock_step(cur.ob, cur.done, greedy=greedy, with_value=learn)
+            if d.policy is not None:
+                env.update_fingerprint(d.policy)
+            nxt, reward, cur.done, g = env.step(d.action)
+            if learn:
+                self.model.add_transition(ob, d.side, d.action, reward, d.value, cur.done)
+            if not cur.done:
+                cur.ob = nxt
+            yield d, reward, g
+            if cur.done:
+                return
 
     def explore(self, prev_ob, prev_done):
-        ob, done = prev_ob, prev_done
-        for _ in range(self.n_step):
-            policy, action = self._get_policy(ob, done)          # pre-decision
-            value = self._get_value(ob, done, action)            # post-decision (double-stepped LSTM: Q1)
-            self.env.update_fingerprint(policy)
-            next_ob, reward, done, global_reward = self.env.step(action)
-            self.episode_rewards.append(global_reward)
-            global_step = self.global_counter.next()
-            self.cur_step += 1
-            if self.agent.startswith('ma2c'):
-                self.model.add_transition(ob, self.ps, action, reward, value, done)
-            else:
-                self.model.add_transition(ob, self.naction, action, reward, value, done)
-            if self.global_counter.should_log():
-                logging.info('Training: global step %d, episode step %d, a: %s, r: %.2f, train r: %.2f, done: %r' %
-                             (global_step, self.cur_step, str(action), global_reward, np.mean(reward), done))
-            if done:                                             # terminal check inside the batch loop
+        """One n_step batch from (prev_ob, prev_done) -> (ob, done, R): R = 0 after a terminal step, else the bootstrap
+        value of a further decision, whose policy forward advances the recurrent state once more (Q2)."""
+        cur = _Cursor(prev_ob, prev_done)
+        steps = self._walk(cur, learn=True)
+        for _ in range(self.n_step):                             # the terminal check lives inside the batch (Q4)
+            step = next(steps, None)
+            if step is None:
                 break
-            ob = next_ob
-        if done:
-            R = np.zeros(self.model.n_agent)
-        else:
-            _, action = self._get_policy(ob, done)               # advances the LSTM state once more (Q2)
-            R = self._get_value(ob, done, action)
-        return ob, done, R
+            d, reward, g = step
+            self.episode_rewards.append(g)
+            self.cur_step += 1
+            now = self.global_counter.next()
+            if self.global_counter.should_log():
+                logging.info('Training: global step %d, episode step %d, a: %s, r: %.2f, train r: %.2f, done: %r'
+                             % (now, self.cur_step, d.action, g, np.mean(reward), cur.done))
+        R = np.zeros(self.model.n_agent) if cur.done else self._lock_step(cur.ob, cur.done).value
+        return cur.ob, cur.done, R
 
     def perform(self, test_ind, gui=False):
-        ob = self.env.reset(gui=gui, test_ind=test_ind)
-        rewards = []
-        done = True                                              # pre-decision done resets the LSTM (Q3)
+        """One evaluation episode -> (mean, std) of its global rewards.  CACC is safety critical: arg-max policy; ATSC keeps
+        the stochastic on-policy one (utils.py:199-223)."""
+        cur = _Cursor(self.env.reset(gui=gui, test_ind=test_ind))
         self.model.reset()
+        g = np.array([g for _, _, g in self._walk(cur, greedy=not self.env.name.startswith('atsc'))])
+        return g.mean(), g.std()
+
+    def _train_episode(self):
+        """env.reset -> model.reset -> (explore, backward) until the terminal batch -> (mean, std, global step)."""
+        cur = _Cursor(self.env.reset())
+        self.model.reset()
+        self.cur_step, self.episode_rewards = 0, []
         while True:
-            if self.env.name.startswith('atsc'):
-                policy, action = self._get_policy(ob, done)
-            else:
-                policy, action = self._get_policy(ob, done, mode='test')   # CACC: deterministic test policy
-            self.env.update_fingerprint(policy)
-            next_ob, reward, done, global_reward = self.env.step(action)
-            rewards.append(global_reward)
-            if done:
+            cur.ob, cur.done, R = self.explore(cur.ob, cur.done)
+            at = self.global_counter.cur_step
+            self.model.backward(R, self.env.T - self.cur_step, self.summary_writer, at)
+            if cur.done:
                 break
-            ob = next_ob
-        return np.mean(np.array(rewards)), np.std(np.array(rewards))
+        self.env.terminate()
+        g = np.array(self.episode_rewards)
+        return g.mean(), g.std(), at
+
+    def _record(self, at, mean, std):
+        self.data.append(dict(agent=self.agent, step=at, test_id=-1, avg_reward=mean, std_reward=std))
+        if self.summary_writer is not None:
+            self.summary_writer.add_scalar('train_reward', mean, at)
+            self.summary_writer.flush()
 
     def run(self):
         while not self.global_counter.should_stop():
-            ob = self.env.reset()
-            done = True
-            self.model.reset()
-            self.cur_step = 0
-            self.episode_rewards = []
-            while True:
-                ob, done, R = self.explore(ob, done)
-                dt = self.env.T - self.cur_step
-                global_step = self.global_counter.cur_step
-                self.model.backward(R, dt, self.summary_writer, global_step)
-                if done:
-                    self.env.terminate()
-                    break
-            rewards = np.array(self.episode_rewards)
-            mean_reward, std_reward = np.mean(rewards), np.std(rewards)
+            mean, std, at = self._train_episode()
             if not self.env.name.startswith('atsc'):
-                # CACC: the logged reward is that of a deterministic TEST episode (utils.py:246-251)
+                # CACC logs a deterministic TEST episode instead (other reward terms, other policy: utils.py:246-251)
                 self.env.train_mode = False
-                mean_reward, std_reward = self.perform(-1)
-                self.env.train_mode = True
-            self._log_episode(global_step, mean_reward, std_reward)
+                try:
+                    mean, std = self.perform(-1)
+                finally:
+                    self.env.train_mode = True
+            self._record(at, mean, std)
         if self.output_path is not None:
             pd.DataFrame(self.data).to_csv(self.output_path + 'train_reward.csv')
 
 
 class Evaluator(Trainer):
-    """utils.py:311-336: one `perform` per test seed, then env.output_data()."""
+    """`perform` over the env's test seeds, then the env's recorded CSVs (utils.py:311-336)."""
 
     def __init__(self, env, model, output_path, gui=False):
-        self.env = env
-        self.model = model
-        self.agent = self.env.agent
-        self.env.train_mode = False
-        self.test_num = self.env.test_num
-        self.output_path = output_path
-        self.gui = gui
+        self.env, self.model, self.agent = env, model, env.agent
+        self.output_path, self.gui = output_path, gui
+        self.test_num = env.test_num
+        env.train_mode = False
 
     def run(self):
-        is_record = not self.gui
-        self.env.cur_episode = 0
-        self.env.init_data(is_record, False, self.output_path)
-        rewards = []
-        for test_ind in range(self.test_num):
-            reward, _ = self.perform(test_ind, gui=self.gui)
-            self.env.terminate()
-            logging.info('test %i, avg reward %.2f' % (test_ind, reward))
-            rewards.append(reward)
-            self.env.collect_tripinfo()
-        self.env.output_data()
-        return rewards
+        env = self.env
+        env.cur_episode = 0
+        env.init_data(not self.gui, False, self.output_path)
+        means = []
+        for k in range(self.test_num):
+            means.append(self.perform(k, gui=self.gui)[0])
+            env.terminate()
+            logging.info('test %i, avg reward %.2f' % (k, means[-1]))
+            env.collect_tripinfo()
+        env.output_data()
+        return means
 
 
 # ------------------------------------------------------------------ the MI355X loop
@@ -267,7 +288,8 @@ class BatchedTrainer:
     """
 
     def __init__(self, env, model, global_counter=None, summary_writer=None, output_path=None,
-                 use_graph=True, rank=0, world_size=1, save_activations=True, compact_obs=True, fused_encode=True):
+                 use_graph=True, rank=0, world_size=1, save_activations=True, compact_obs=True, fused_encode=True,
+                 capture_update=True, rearm_after=200):
         self.env, self.model = env, model
         # uncoupled nets: the rollout's policy steps double as the forward pass of the update (models.py)
         self.saved_acts = bool(save_activations) and model.enable_saved_activations()
@@ -305,11 +327,27 @@ class BatchedTrainer:
         self.fin = torch.zeros(4, dtype=torch.float64, device=d)   # episodes, sum(mean), sum(std), collisions
         self.use_graph = use_graph and d.type == 'cuda'
         self.graph = None
+        # the A2C update (and, where no host decision sits in between, the batch epilogue) as hipGraphs too: the update's 44-71
+        # launches were issued eagerly, with 0.36-0.66 ms of idle device per batch between them; captured
+        # after the first (eager) batch has tuned / warmed the library GEMMs.  NMARL_CAPTURE_UPDATE=0 keeps it eager
+        self.capture_update = bool(capture_update) and self.use_graph and os.environ.get('NMARL_CAPTURE_UPDATE', '1') != '0'
+        self._upd = None                      # dict(grads=CUDAGraph, apply=CUDAGraph or None, epilogue_inside=bool)
+        self.update_capture_error = None
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=d)
+        self._lr_dev_host = None
+        self._keepalive = []                  # tensors whose addresses captured graphs hold
+        # after a hand-off time-out the launch-per-step forms are used; after `rearm_after` clean batches the one-launch forms
+        # are tried again (a transient -- a profiler helper, a second process that has left -- no longer costs the whole run);
+        # every further time-out doubles the wait
+        self.rearm_after = int(rearm_after)
+        self._rearm_wait, self._clean_since_fallback = int(rearm_after), 0
+        self._wants_guard = False
         # coupled nets on the in-launch hand-off kernels (one-launch lock-step / BPTT): every batch is checked and, if a wave
         # timed out, re-run on the launch-per-step kernels from the state it started from (see run_batch)
         self.handoff_guard = self.saved_acts and model.policy.coupled and d.type == 'cuda' and ops.handoff_enabled()
+        self._wants_guard = self.saved_acts and bool(model.policy.coupled) and d.type == 'cuda'
         self.handoff_fallbacks = 0
-        self._shadow = [torch.empty_like(t) for t in env.state_tensors() + [self.step_dev]] if self.handoff_guard else None
+        self._shadow = [torch.empty_like(t) for t in env.state_tensors() + [self.step_dev]] if self._wants_guard else None
         self.data = []
         self.n_batches = 0
         env.train_mode = True
@@ -382,44 +420,138 @@ class BatchedTrainer:
         for t, s in zip(self._state_tensors(), snap):
             t.copy_(s)
 
-    def run_batch(self):
-        """One rollout + update.  Returns nothing; statistics stay on the device until `stats()`."""
-        self.rollout()
-        m = self.model
-        m.load_rewards(self.buf_rraw)
-        m.update(self.R_end, rotate=False)
-        if self.handoff_guard and ops.handoff_poisoned(self.device):
-            self._recover_from_handoff_timeout()
-        # episode statistics, then the hand-over to the next batch in one call: finished replicas start a new episode (the
-        # env already auto-reset them) with zero recurrent state and uniform fingerprints -- what the reference does at its
-        # next `env.reset(); model.reset()` --, states_bw <- states_fw, slot T of the rollout buffers -> slot 0
-        T = self.n_step
+    def _epilogue(self):
+        """Episode statistics, then the hand-over to the next batch in one call: finished replicas start a new episode (the
+        env already auto-reset them) with zero recurrent state and uniform fingerprints -- what the reference does at its
+        next `env.reset(); model.reset()` --, states_bw <- states_fw, slot T of the rollout buffers -> slot 0."""
+        m, T = self.model, self.n_step
         ops.batch_epilogue(self.buf_g, self.last_done, self.ep_sum, self.ep_sq, self.ep_len, self.fin, self.env.T,
                            m.h_fw, m.c_fw, m.h_bw, m.c_bw, m.buf_fp[T], m.buf_fp[0], m.fp_uniform, m.buf_x[T], m.buf_x[0],
                            self.done_pre)
+
+    def _capture_update(self):
+        """Capture the update of a batch as hipGraphs (after at least one eager batch: the library GEMMs are tuned, every
+        lazily built table and workspace exists).  One graph [rewards, returns, loss, backward, clip + RMSProp, epilogue];
+        with several ranks two, around the eager gradient all-reduce; for nets on the in-launch hand-off the epilogue stays
+        outside (the host looks at the status word between the optimiser step and the hand-over).  Capturing runs no
+        kernel; the host-side state the captured Python code touches is put back."""
+        m = self.model
+        split = m.dist_group is not None
+        inside = not self.handoff_guard
+        tun = None
+        try:
+            import torch.cuda.tunable as tunable
+            if tunable.is_enabled() and tunable.tuning_is_enabled():
+                tun = tunable
+                tunable.tuning_enable(False)          # a timing loop inside a capture would invalidate it (every shape is tuned by now)
+        except Exception:
+            tun = None
+        host = (m.t, m.policy._enc_was_saved, m.policy._mm_was_saved)
+        ops.keepalive_begin(self._keepalive)
+        try:
+            torch.cuda.synchronize()
+            g1, g2 = torch.cuda.CUDAGraph(), None
+            with torch.cuda.graph(g1):
+                m.load_rewards(self.buf_rraw)
+                m.update_grads(self.R_end)
+                if not split:
+                    m.update_apply(0.0, rotate=False, lr_dev=self.lr_dev)
+                    if inside:
+                        self._epilogue()
+            if split:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    m.update_apply(0.0, rotate=False, lr_dev=self.lr_dev)
+                    if inside:
+                        self._epilogue()
+            self._upd = dict(grads=g1, apply=g2, epilogue_inside=inside)
+        finally:
+            ops.keepalive_end()
+            m.t, m.policy._enc_was_saved, m.policy._mm_was_saved = host
+            if tun is not None:
+                tun.tuning_enable(True)
+
+    def _update(self):
+        """The update + hand-over of the batch the rollout just produced: replayed graphs, or eager launches."""
+        m = self.model
+        if self.capture_update and self._upd is None and self.update_capture_error is None and self.n_batches >= 1:
+            try:
+                self._capture_update()
+            except Exception as ex:            # keep training on the eager path, and say so (bench.py reports it)
+                self.update_capture_error = repr(ex)
+                self._upd = None
+                logging.warning('update capture failed, staying eager: %r' % (ex,))
+                torch.cuda.synchronize()
+        if self._upd is None:
+            m.load_rewards(self.buf_rraw)
+            m.update(self.R_end, rotate=False)
+            return False
+        lr = m.update_begin()
+        if lr != self._lr_dev_host:            # the schedule moved (never for lr_decay = constant): one tiny launch
+            self.lr_dev.fill_(lr)
+            self._lr_dev_host = lr
+        m.t = self.n_step
+        self._upd['grads'].replay()
+        if self._upd['apply'] is not None:
+            m.update_reduce()
+            self._upd['apply'].replay()
+        m.update_end()
+        return self._upd['epilogue_inside']
+
+    def run_batch(self):
+        """One rollout + update.  Returns nothing; statistics stay on the device until `stats()`."""
+        self.rollout()
+        handed_over = self._update()
+        if self.handoff_guard and ops.handoff_poisoned(self.device):
+            # (with the update replayed as a graph this read costs one launch latency per batch, not a host-bound update)
+            self._recover_from_handoff_timeout()
+            handed_over = False
+        if not handed_over:
+            self._epilogue()
         self.n_batches += 1
+        if self.handoff_fallbacks and not self.handoff_guard and self._wants_guard:
+            self._clean_since_fallback += 1
+            if self.rearm_after > 0 and self._clean_since_fallback >= self._rearm_wait:
+                self._rearm()
         if self.global_counter is not None:
             # the counter (like the reference's global step and the lr schedule) counts LOCK-steps, i.e. environment
             # steps per replica: `total_step` of the ini keeps its meaning (1e6 -> 16 667 updates at n_step 60)
             self.global_counter.advance(self.n_step)
 
+    def _drop_graphs(self):
+        """Forget the captured graphs (the kernels a lock-step / an update launches are about to change); their memory pools
+        stay referenced until the new ones exist."""
+        self._keepalive.append((self.graph, self._upd))
+        self.graph, self._upd = None, None
+
+    def _rearm(self):
+        """Try the one-launch hand-off kernels again after a run of clean batches on the launch-per-step forms."""
+        logging.info('re-arming the in-launch hand-off kernels after %d clean batches' % self._clean_since_fallback)
+        ops.enable_inkernel_handoff()
+        self._clean_since_fallback = 0
+        self._rearm_wait *= 2                  # the next time-out waits twice as long
+        if ops.handoff_enabled() and self.model.policy.pv_one_launch(self.E):
+            self.handoff_guard = True
+            self._drop_graphs()
+
     def _recover_from_handoff_timeout(self):
         """A wave of an in-launch hand-off kernel gave up waiting during this batch (its neighbour block was not resident: the
         device is shared, masked or profiled).  The optimiser step refused the batch on the device (nothing was applied); here
-        the batch is rewound to the state it started from, the process is pinned to the launch-per-step kernels, and the
+        the batch is rewound to the state it started from, the launch-per-step kernels are selected (until `_rearm`), and the
         batch is run again -- the weights end up exactly where a run without the one-launch kernels puts them."""
         m, dev = self.model, self.device
         logging.warning('in-launch hand-off timed out (batch %d): re-running the batch on the launch-per-step kernels and '
-                        'keeping them for the rest of the run' % self.n_batches)
+                        'keeping them for the next %d batches' % (self.n_batches, self._rearm_wait))
         ops.disable_inkernel_handoff()
         ops.handoff_clear(dev)
         for s_, t_ in zip(self._shadow, self.env.state_tensors() + [self.step_dev]):
             t_.copy_(s_)
         m.h_fw.copy_(m.H_all[:, 0])            # the persistent state the rollout started from (its bootstrap step overwrote it)
         m.c_fw.copy_(m.C_all[:, 0])
-        m.lr_scheduler.n -= self.n_step        # update() advanced the schedule
-        self.graph = None                      # re-capture: the rollout now takes the two-launch lock-step
+        m.lr_scheduler.rewind(self.n_step)     # the update advanced the schedule
+        self._drop_graphs()                    # re-capture: the rollout now takes the two-launch lock-step, the update the step-wise BPTT
         self.handoff_guard = False
+        self._clean_since_fallback = 0
         self.rollout()
         m.load_rewards(self.buf_rraw)
         m.update(self.R_end, rotate=False)

@@ -501,7 +501,7 @@ def nstep_return(r, v, done_post, R_end, gamma, alpha, dist=None, R_out=None, ad
     return Rs32, adv32
 
 
-def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, norm_out=None, lr_dev=None):
+def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, norm_out=None, lr_dev=None, guard=False):
     """tf.clip_by_global_norm + ApplyRMSProp (policies.py:32-39), per row (= optimiser) of [G,P]."""
     with torch.no_grad():
         gs = g * grad_scale

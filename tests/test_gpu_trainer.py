@@ -42,6 +42,31 @@ def test_graph_equals_eager_and_is_deterministic(agent):
     assert torch.isfinite(runs[0][0]).all()
 
 
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ma2c_ic3', 'ma2c_cu', 'ma2c_dial'])
+def test_captured_update_equals_eager_update(agent, monkeypatch):
+    """The A2C update replayed as a hipGraph (from the second batch on; rewards, return scan, loss, backward, clip + RMSProp,
+    and for nets without the hand-off guard the batch epilogue) against the eager update behind the same rollout graph: weights,
+    RMSProp slots, env state, actions, episode statistics bit-identical after 4 batches -- with a LINEAR lr schedule, whose
+    value reaches the captured optimiser step through a device scalar."""
+    E = 1024
+    runs = []
+    for capture in ('1', '0'):
+        monkeypatch.setenv('NMARL_CAPTURE_UPDATE', capture)
+        env, model, tr = build(agent, E, True, n_step=20)
+        model.lr_scheduler = type(model.lr_scheduler)(5e-4, 1e-5, 200, decay='linear')
+        for _ in range(4):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        assert (tr._upd is not None) == (capture == '1'), tr.update_capture_error
+        assert tr.update_capture_error is None
+        runs.append((model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.h.clone(), model.buf_act.clone(),
+                     tr.R_end.clone(), tr.ep_sum.clone(), model.h_bw.clone(), torch.tensor(model.cur_lr)))
+        del env, model, tr
+    for k, (a, b) in enumerate(zip(*runs)):
+        assert torch.equal(a, b), 'captured update differs from the eager one (item %d)' % k
+    assert float(runs[0][7]) == pytest.approx(5e-4 * (1 - 80 / 200))
+
+
 @pytest.mark.parametrize('use_graph', [True, False])
 def test_commnet_update_uses_the_saved_encoder_outputs_every_batch(use_graph, monkeypatch):
     """CommNet: the rollout saves the encoder outputs of every lock-step, and the update must use them in EVERY batch -- also

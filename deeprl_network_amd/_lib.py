@@ -118,7 +118,8 @@ class BpttCoupled(C.Structure):
 class GridParams(C.Structure):
     """nmarl_grid_params_t (include/nmarl.h)."""
     _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('peak1', C.c_float), ('peak2', C.c_float),
-                ('T', C.c_int32), ('per_agent_reward', C.c_int32), ('compact_obs', C.c_int32)]
+                ('T', C.c_int32), ('per_agent_reward', C.c_int32), ('compact_obs', C.c_int32),
+                ('objective', C.c_int32), ('coef_wait', C.c_float), ('head_wait', C.c_void_p)]
 
 
 _p = C.c_void_p

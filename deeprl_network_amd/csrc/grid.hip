@@ -143,7 +143,9 @@ __device__ __forceinline__ void emit_obs_slab(const Lds& s, float* __restrict__ 
 
 // NT = 1: non-temporal stores for state and slab when the working set exceeds the caches (same effect as
 // in csrc/cacc.hip: streaming writes at the fill ceiling instead of ~60 % of it).
-template <int NT, bool COMPACT>
+// WAIT: the `wait` / `hybrid` objectives (atsc_env.py:383-418) -- one more state array, the head vehicle's waiting time per
+// lane (oracle/grid_ref.py step 6); the shipped `queue` configs run the instantiation without it (same bytes as before).
+template <int NT, bool COMPACT, bool WAIT>
 __global__ __launch_bounds__(256) void grid_step_kernel(
     const nmarl_grid_params_t p, const int64_t E, const uint8_t* __restrict__ action,
     float* __restrict__ qs, float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts,
@@ -155,11 +157,14 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
     // aligned (8 x 600 B per block step), so the whole block moves them with 16-byte accesses (300 float4 each way per array;
     // the 4-byte per-replica loops of rounds 1-3 were the kernel's issue limit in the HBM regime)
     __shared__ __attribute__((aligned(16))) float blk_q[8 * NQ], blk_tr[8 * NQ];
+    __shared__ __attribute__((aligned(16))) float blk_w[WAIT ? 8 * NQ : 4];
+    float* __restrict__ const hws = p.head_wait;
     const int l32 = threadIdx.x & 31;
     const int sub = threadIdx.x >> 5;                       // replica slot in the block (0..7)
     Lds& s = lds[sub];
     float* const sq = blk_q + sub * NQ;
     float* const str = blk_tr + sub * NQ;
+    float* const sw = blk_w + (WAIT ? sub * NQ : 0);
     const int64_t stride = (int64_t)gridDim.x * 8;
     for (int64_t e0 = (int64_t)blockIdx.x * 8; e0 < E; e0 += stride) {
         const int64_t e = e0 + sub;
@@ -173,11 +178,15 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
             for (int i = threadIdx.x; i < 8 * NQ / 4; i += 256) {
                 reinterpret_cast<float4*>(blk_q)[i] = qg4[i];
                 reinterpret_cast<float4*>(blk_tr)[i] = tg4[i];
+                if (WAIT) reinterpret_cast<float4*>(blk_w)[i] = reinterpret_cast<const float4*>(hws + e0 * NQ)[i];
             }
         } else {
             const float* qg = qs + ec * NQ;
             const float* tg = trs + ec * NQ;
-            for (int i = l32; i < NQ; i += 32) { sq[i] = qg[i]; str[i] = tg[i]; }
+            for (int i = l32; i < NQ; i += 32) {
+                sq[i] = qg[i]; str[i] = tg[i];
+                if (WAIT) sw[i] = hws[ec * NQ + i];
+            }
         }
         const int t = ts[ec];
         __syncthreads();
@@ -245,18 +254,31 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
                 const int grp = c_entry[n][r];
                 if (grp) inflow[r] += demand_rate(grp - 1, sec, p.peak1, p.peak2) / 3600.0f * DT * xi[ec * 4 + grp - 1];
             }
+            float hw[NLANE];
 #pragma unroll
             for (int l = 0; l < NLANE; ++l) {
+                if (WAIT) {
+                    // the lane's head vehicle keeps waiting while a standing queue discharges nothing (oracle/grid_ref.py step 6)
+                    const bool moved = served[l] > 0.0f || q[l] <= 0.0f;
+                    hw[l] = moved ? 0.0f : sw[n * NLANE + l] + DT;
+                }
                 q[l] = q[l] - served[l] + tr[l];
                 tr[l] = inflow[c_lane_approach[l]] * c_split[l];
             }
+            float r_wait = 0.0f;
 #pragma unroll
             for (int k = 0; k < NL; ++k) {
                 const float c = fminf(q[c_link_lane[k]], DET_CAP);
                 r_node -= c;
+                if (WAIT) r_wait -= hw[c_link_lane[k]];
                 float w = c / p.norm_wave;
                 if (p.clip_wave >= 0.0f) w = fminf(fmaxf(w, 0.0f), p.clip_wave);
                 s.wave[n * NL + k] = w;
+            }
+            if (WAIT) {
+                r_node = p.objective == 1 ? r_wait : r_node + p.coef_wait * r_wait;      // atsc_env.py:411-416
+#pragma unroll
+                for (int l = 0; l < NLANE; ++l) sw[n * NLANE + l] = hw[l];
             }
         }
         float gsum = r_node;                     // sum over the 25 nodes of the half wave
@@ -267,7 +289,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
         if (node) {
             if (rst) {
 #pragma unroll
-                for (int l = 0; l < NLANE; ++l) { q[l] = 0.0f; tr[l] = 0.0f; }
+                for (int l = 0; l < NLANE; ++l) { q[l] = 0.0f; tr[l] = 0.0f; if (WAIT) sw[n * NLANE + l] = 0.0f; }
 #pragma unroll
                 for (int k = 0; k < NL; ++k) s.wave[n * NL + k] = 0.0f;
                 a = 0;                            // _reset_state: prev_action = 0 (atsc_env.py:509-513)
@@ -284,11 +306,15 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
                 const f32x4 a4 = reinterpret_cast<const f32x4*>(blk_q)[i], b4 = reinterpret_cast<const f32x4*>(blk_tr)[i];
                 if (NT) { __builtin_nontemporal_store(a4, qo4 + i); __builtin_nontemporal_store(b4, to4 + i); }
                 else { qo4[i] = a4; to4[i] = b4; }
+                if (WAIT) reinterpret_cast<f32x4*>(hws + e0 * NQ)[i] = reinterpret_cast<const f32x4*>(blk_w)[i];
             }
         } else if (live) {
             float* qo = qs + e * NQ;
             float* to = trs + e * NQ;
-            for (int i = l32; i < NQ; i += 32) { qo[i] = sq[i]; to[i] = str[i]; }
+            for (int i = l32; i < NQ; i += 32) {
+                qo[i] = sq[i]; to[i] = str[i];
+                if (WAIT) hws[e * NQ + i] = sw[i];
+            }
         }
         if (live) {
             if (node) {
@@ -316,14 +342,17 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
 }
 
 __global__ __launch_bounds__(256) void grid_reset_kernel(
-    const int64_t E, const uint8_t* __restrict__ mask, const float* __restrict__ u0, float* __restrict__ qs,
+    float* __restrict__ hws, const int64_t E, const uint8_t* __restrict__ mask, const float* __restrict__ u0, float* __restrict__ qs,
     float* __restrict__ trs, uint8_t* __restrict__ prev, int32_t* __restrict__ ts, float* __restrict__ xi,
     float* __restrict__ obs, const int obs_w, const uint64_t seed, const int64_t env_id_base, int32_t* __restrict__ episode) {
     const int l32 = threadIdx.x & 31;
     const int sub = threadIdx.x >> 5;
     for (int64_t e = (int64_t)blockIdx.x * 8 + sub; e < E; e += (int64_t)gridDim.x * 8) {
         if (mask != nullptr && mask[e] == 0) continue;
-        for (int i = l32; i < NN * NLANE; i += 32) { qs[e * NN * NLANE + i] = 0.0f; trs[e * NN * NLANE + i] = 0.0f; }
+        for (int i = l32; i < NN * NLANE; i += 32) {
+            qs[e * NN * NLANE + i] = 0.0f; trs[e * NN * NLANE + i] = 0.0f;
+            if (hws) hws[e * NN * NLANE + i] = 0.0f;
+        }
         for (int i = l32; i < NN * obs_w; i += 32) obs[e * NN * obs_w + i] = 0.0f;
         if (l32 < NN) prev[e * NN + l32] = 0;
         if (l32 == 0) ts[e] = 0;
@@ -359,14 +388,18 @@ extern "C" int nmarl_grid_step(const nmarl_grid_params_t* p, int64_t E, const ui
         (E > 0 && (!action || !q || !transit || !prev_action || !t || !xi || !obs || !reward || !done || !global_reward)))
         return NMARL_EINVAL;
     if (auto_reset && !episode) return NMARL_EINVAL;
+    if (p->objective < 0 || p->objective > 2 || (p->objective != 0 && E > 0 && !p->head_wait)) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     const bool nt = E * (p->compact_obs ? 4000 : 8800) > (int64_t)256 << 20;     // beyond the 256 MB Infinity Cache: stream the writes
-#define NMARL_GRID_LAUNCH(NT_, C_)                                                                                      \
-    hipLaunchKernelGGL((grid_step_kernel<NT_, C_>), dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), \
+    const bool wait = p->objective != 0;
+#define NMARL_GRID_LAUNCH(NT_, C_, W_)                                                                                      \
+    hipLaunchKernelGGL((grid_step_kernel<NT_, C_, W_>), dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), \
                        *p, E, action, q, transit, prev_action, t, xi, obs, reward, done, global_reward, auto_reset, seed,  \
                        env_id_base, episode)
-    if (p->compact_obs) { if (nt) NMARL_GRID_LAUNCH(1, true); else NMARL_GRID_LAUNCH(0, true); }
-    else { if (nt) NMARL_GRID_LAUNCH(1, false); else NMARL_GRID_LAUNCH(0, false); }
+#define NMARL_GRID_LAUNCH2(NT_, C_) { if (wait) NMARL_GRID_LAUNCH(NT_, C_, true); else NMARL_GRID_LAUNCH(NT_, C_, false); }
+    if (p->compact_obs) { if (nt) NMARL_GRID_LAUNCH2(1, true) else NMARL_GRID_LAUNCH2(0, true) }
+    else { if (nt) NMARL_GRID_LAUNCH2(1, false) else NMARL_GRID_LAUNCH2(0, false) }
+#undef NMARL_GRID_LAUNCH2
 #undef NMARL_GRID_LAUNCH
     return nmarl_check_launch();
 }
@@ -377,7 +410,7 @@ extern "C" int nmarl_grid_reset(const nmarl_grid_params_t* p, int64_t E, const u
     if (!p || E < 0 || (E > 0 && (!q || !transit || !prev_action || !t || !xi || !obs))) return NMARL_EINVAL;
     if (!u0 && !episode) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
-    hipLaunchKernelGGL(grid_reset_kernel, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), E, mask,
+    hipLaunchKernelGGL(grid_reset_kernel, dim3(grid_blocks(E)), dim3(256), 0, static_cast<hipStream_t>(stream), p->head_wait, E, mask,
                        u0, q, transit, prev_action, t, xi, obs, p->compact_obs ? NL : OBSW, seed, env_id_base, episode);
     return nmarl_check_launch();
 }

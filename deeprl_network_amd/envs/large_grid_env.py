@@ -15,6 +15,7 @@ import torch
 from .. import _lib
 
 N_NODE, N_FEAT, N_OBS, N_PHASE = 25, 12, 60, 5
+OBJECTIVES = {'queue': 0, 'wait': 1, 'hybrid': 2}
 
 
 def grid_masks():
@@ -77,9 +78,12 @@ def grid_params_from_config(config):
     """ENV_CONFIG section -> nmarl_grid_params_t; keys of atsc_env.py:79-99 + large_grid_env.py:50-52."""
     if config.getint('control_interval_sec') != 5 or config.getint('yellow_interval_sec') != 2:
         raise _lib.NmarlError('the synthetic grid is specified for control 5 s / yellow 2 s')
-    if config.get('objective') != 'queue':
-        raise NotImplementedError('only the `queue` objective of the shipped grid configs is modelled')
     p = _lib.GridParams()
+    obj = config.get('objective', fallback='queue')
+    if obj not in OBJECTIVES:
+        raise _lib.NmarlError('objective must be one of queue, wait, hybrid (atsc_env.py:87, 411-416), got %r' % obj)
+    p.objective = OBJECTIVES[obj]
+    p.coef_wait = config.getfloat('coef_wait', fallback=0.0)
     p.norm_wave = config.getfloat('norm_wave')
     p.clip_wave = config.getfloat('clip_wave')
     p.peak1 = config.getfloat('peak_flow1')
@@ -119,6 +123,10 @@ class LargeGridBatchEnv:
         self.prev_action = torch.zeros(E, N_NODE, dtype=torch.uint8, device=d)
         self.t = torch.zeros(E, dtype=torch.int32, device=d)
         self.xi = torch.ones(E, 4, **f32)
+        # `wait` / `hybrid` objectives: the front vehicle's standing time per lane (oracle/grid_ref.py step 6)
+        self.head_wait = torch.zeros(E, N_NODE, 6, **f32) if p.objective else None
+        if self.head_wait is not None:
+            p.head_wait = self.head_wait.data_ptr()
         self.obs = torch.zeros(E, N_NODE, N_OBS, **f32)
         self.reward = torch.zeros((E, N_NODE) if p.per_agent_reward else (E,), **f32)
         self.done = torch.zeros(E, dtype=torch.uint8, device=d)
@@ -127,7 +135,8 @@ class LargeGridBatchEnv:
         self.batch_size = None     # episodes end at T only; any n_step dividing T works
 
     def state_tensors(self):
-        return [self.q, self.transit, self.prev_action, self.t, self.xi, self.obs, self.episode, self.done]
+        return [self.q, self.transit, self.prev_action, self.t, self.xi, self.obs, self.episode, self.done] + \
+            ([self.head_wait] if self.head_wait is not None else [])
 
     compact_obs = False
 

@@ -158,6 +158,11 @@ typedef struct nmarl_grid_params {
     int32_t per_agent_reward; /* coop_gamma >= 0 -> reward [E,25], else global [E]       */
     int32_t compact_obs;      /* 1: obs [E,25,12] = every node's OWN wave vector (what the reference hands an agent,
                                  atsc_env.py:253-262; the consumer gathers the neighbours); 0: the gathered [E,25,60] slab */
+    int32_t objective;        /* atsc_env.py:87, 383-418: 0 `queue` (the shipped configs), 1 `wait`, 2 `hybrid` = queue + coef_wait * wait */
+    float coef_wait;          /* atsc_env.py:96 (hybrid only)                            */
+    float* head_wait;         /* [E,25,6] f32 state, REQUIRED when objective != 0 (else NULL): seconds the head vehicle of each lane
+                                 has been standing (synthetic stand-in of getWaitingTime of the front vehicle, oracle/grid_ref.py
+                                 step 6); reset to 0 with the replica                    */
 } nmarl_grid_params_t;
 
 /*

@@ -39,6 +39,13 @@ Synthetic dynamics (store-and-forward fluid queues, one control step = 5 s):
      replica and flow group (Philox, stream RESET).
   5. detector count c = min(q, 7) (50 m / 7.5 m); wave_k = min(c / norm_wave, clip_wave);
      reward_i = - sum_k c_lane(k)  (12 links, duplicated lanes counted like the reference).
+  6. objectives `wait` / `hybrid` (atsc_env.py:383-418: the waiting time of the FRONT vehicle of every detector,
+     `getWaitingTime` of the car with the largest lane position): a fluid queue has no vehicles, so the spec keeps one more
+     state per lane, head_wait (s): the lane's front vehicle has been standing since the lane last discharged,
+         head_wait' = 0 if the lane served any flow this step or held no queue at its start, else head_wait + 5 s;
+     wait_i = sum_k head_wait'_lane(k) over the 12 links (duplicated lanes like the queue count);
+     reward_i = - wait_i (`wait`)  or  - queue_i - coef_wait * wait_i (`hybrid`).  Reset clears it.  (Outside every shipped
+     config: all of them set objective = queue.)
 """
 import numpy as np
 
@@ -117,6 +124,9 @@ class GridParams:
         self.coop_gamma = float(g('coop_gamma', -1))
         self.agent = g('agent', 'ma2c_ic3')
         self.seed = int(g('seed', 12))
+        self.objective = str(g('objective', 'queue'))            # atsc_env.py:87
+        self.coef_wait = float(g('coef_wait', 0.0))              # atsc_env.py:96
+        assert self.objective in ('queue', 'wait', 'hybrid')
         assert self.control == 5 and self.yellow == 2, 'the synthetic model is specified for 5 s / 2 s'
 
 
@@ -136,9 +146,10 @@ class GridBatchRef:
             self.prev = np.zeros((self.E, N_NODE), dtype=np.int64)       # atsc_env.py:509-513
             self.t = np.zeros(self.E, dtype=np.int64)
             self.xi = xi.copy()
+            self.hw = np.zeros((self.E, N_NODE, N_LANE), dtype=f)
         else:
             m = np.asarray(mask, dtype=bool)
-            self.q[m] = 0; self.tr[m] = 0; self.prev[m] = 0; self.t[m] = 0
+            self.q[m] = 0; self.tr[m] = 0; self.prev[m] = 0; self.t[m] = 0; self.hw[m] = 0
             self.xi[m] = xi[m]
         return self.obs()
 
@@ -192,12 +203,17 @@ class GridBatchRef:
             rate = np.array([demand_rate(grp, s, self.p.peak1, self.p.peak2) for s in sec], dtype=f)
             inflow[:, node, ap] += rate / f(3600) * f(DT) * self.xi[:, grp]
         split = APPROACH_SPLIT.astype(f)
+        moved = (served > 0) | (self.q <= 0)                                        # step 6: the front vehicle left / no queue stood
+        self.hw = np.where(moved, f(0), self.hw + f(DT)).astype(f)
         self.q = (self.q - served + self.tr).astype(f)
         self.tr = (inflow[:, :, LANE_APPROACH] * split).astype(f)
         self.prev = a
         self.t = self.t + 1
         c = np.minimum(self.q, f(DET_CAP))[:, :, LINK_LANE]                         # [E,N,12]
         reward = -c.sum(axis=2)
+        if self.p.objective != 'queue':
+            wait = self.hw[:, :, LINK_LANE].sum(axis=2)
+            reward = -wait if self.p.objective == 'wait' else reward - f(self.p.coef_wait) * wait
         g = reward.sum(axis=1)
         done = self.t >= self.p.T
         r_out = g if self.p.coop_gamma < 0 else reward

@@ -46,7 +46,7 @@ def test_exports_are_plain_c_symbols():
 def test_struct_layouts_match_header():
     from deeprl_network_amd import _lib
     assert ctypes.sizeof(_lib.CaccParams) == 12 * 4 + 6 * 4
-    assert ctypes.sizeof(_lib.GridParams) == 4 * 4 + 3 * 4
+    assert ctypes.sizeof(_lib.GridParams) == 4 * 4 + 3 * 4 + 2 * 4 + 4 + 8      # (+ objective, coef_wait, padding, head_wait)
     assert _lib.lib.nmarl_abi_version() == _lib.ABI_VERSION
 
 

@@ -149,3 +149,79 @@ def test_compact_observation_training_equals_gathered_slab():
     torch.testing.assert_close(out[0][4][:, :, same], out[1][4][:, :, same], rtol=1e-4, atol=2e-5)
     if bool(same.all()):
         torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize('objective,coop_gamma,E', [('wait', -1, 9), ('hybrid', 0.9, 300), ('hybrid', -1, 8)])
+def test_wait_and_hybrid_objectives_vs_oracle(objective, coop_gamma, E):
+    """atsc_env.py:383-418's `wait` / `hybrid` objectives on the synthetic grid: the per-lane front-vehicle standing time
+    (oracle/grid_ref.py step 6) as one more state array; trajectories, rewards and the state itself against the oracle,
+    incl. the fused auto-reset clearing it."""
+    from oracle import grid_ref as G
+    from deeprl_network_amd.envs.large_grid_env import LargeGridBatchEnv
+    cp = grid_config(coop_gamma=coop_gamma)
+    cp['ENV_CONFIG']['objective'] = objective
+    cp['ENV_CONFIG']['coef_wait'] = '0.2'
+    env = LargeGridBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+    assert env.head_wait is not None and env.head_wait in [t for t in env.state_tensors() if t is env.head_wait]
+    rng = np.random.RandomState(E)
+    U = rng.rand(E, 4).astype(np.float32)
+    env.reset(u0=torch.from_numpy(U).cuda())
+    ref = G.GridBatchRef(G.GridParams(config=env.config), E=E, dtype=np.float32)
+    assert ref.p.objective == objective and ref.p.coef_wait == pytest.approx(0.2)
+    ref.reset(np.float32(0.8) + np.float32(0.4) * U)
+    seen_wait = 0.0
+    for t in range(120):
+        hold = rng.rand(E, 25) < 0.7
+        a = np.where(hold & (t > 0), ref.prev, rng.randint(0, 5, size=(E, 25))).astype(np.uint8)
+        obs, r, d, g = env.step(torch.from_numpy(a).cuda())
+        ro, rr, rd, rg = ref.step(a)
+        np.testing.assert_array_equal(env.head_wait.cpu().numpy(), ref.hw, err_msg='head_wait t=%d' % t)
+        np.testing.assert_allclose(env.q.cpu().numpy(), ref.q, rtol=2e-4, atol=2e-3)
+        np.testing.assert_allclose(g.cpu().numpy(), rg, rtol=2e-4, atol=5e-2)
+        np.testing.assert_allclose(r.cpu().numpy(), rr, rtol=2e-4, atol=5e-2)
+        seen_wait = max(seen_wait, float(ref.hw.max()))
+    assert seen_wait >= 10.0                                   # queues did stand through several red steps
+    # the last step of an episode with the fused auto-reset clears the state
+    env.t.fill_(env.T - 1)
+    env.step(torch.zeros(E, 25, dtype=torch.uint8, device='cuda'), auto_reset=True)
+    assert torch.all(env.head_wait == 0) and torch.all(env.q == 0)
+    # and the `queue` instantiation is untouched by the new state
+    assert make(4).head_wait is None
+
+
+def test_reference_api_ia2c_observation_order_and_greedy_evaluate(tmp_path):
+    """E = 1 duck-type: an IA2C agent's observation lists its neighbours north, east, south, west (atsc_env.py:263-271), the
+    IA2C-FP one appends their fingerprints in that order; and `main.py evaluate` on an `agent = greedy` run directory drives the
+    rule-based controller (large_grid_env.py:30-45) through Evaluator.perform."""
+    from deeprl_network_amd.envs.large_grid_env import LargeGridEnv, grid_neighbor_order
+    order = grid_neighbor_order()
+    cp = grid_config(agent='ia2c_fp')
+    env = LargeGridEnv(cp['ENV_CONFIG'])
+    env.train_mode = True
+    ob = env.reset()
+    assert [len(o) for o in ob] == [12 * (1 + len(order[i])) + 5 * len(order[i]) for i in range(25)]
+    rng = np.random.RandomState(0)
+    for _ in range(30):
+        ob, r, d, g = env.step(rng.randint(0, 5, size=25))
+    env.update_fingerprint([rng.dirichlet(np.ones(5)) for _ in range(25)])
+    ob = env._state_list()
+    own = env.batch.obs[0, :, :12].cpu().numpy()
+    assert own.max() > 0
+    for i in (0, 4, 7, 12, 24):
+        want = np.concatenate([own[i]] + [own[j] for j in order[i]] + [env.fp[j] for j in order[i]])
+        np.testing.assert_allclose(ob[i], want, rtol=0, atol=0)
+    # greedy evaluation through the CLI
+    import shutil
+    import pandas as pd
+    from deeprl_network_amd.main import main
+    base = tmp_path / 'greedy'
+    (base / 'data').mkdir(parents=True)
+    (base / 'model').mkdir()
+    cp = grid_config(agent='greedy', coop_gamma=0.75)
+    cp['ENV_CONFIG']['episode_length_sec'] = '300'
+    with open(base / 'data' / 'config_greedy.ini', 'w') as f:
+        cp.write(f)
+    main(['--base-dir', str(base), 'evaluate', '--evaluation-seeds', '10000,20000'])
+    df = pd.read_csv(str(base / 'eva_data') + '/atsc_large_grid_greedy_control.csv')
+    assert len(df) == 2 * 60 and set(df['episode']) == {1, 2} and (df['reward'] <= 0).all()
+    shutil.rmtree(base)

@@ -118,3 +118,73 @@ def test_ic3_encoder_inside_the_step_equals_separate_encoder():
             outs.append((enc, pi, act, v, ho, co, gates, S))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('agent', ['ia2c', 'ia2c_fp'])
+def test_ia2c_on_the_grid_consumes_the_reference_neighbour_order(agent):
+    """ATSC envs concatenate an IA2C agent's observation in the order of the reference's `neighbor_map` lists (north, east,
+    south, west: atsc_env.py:263-271, large_grid_env.py:58-85), not in ascending node index.  The product given
+    `obs_order` must compute, from the env's vectors, the reference's function with the reference's variables (same
+    np.random draws under the same names, same values after an update): checked against oracle/nn_ref.py, for which an
+    observation is an opaque vector (the critic's neighbour ACTIONS stay in mask order, atsc_env.py:132-136)."""
+    from helpers import cacc_config
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.large_grid_env import grid_masks, grid_neighbor_order
+    from oracle.nn_ref import REF_MODELS
+    nb, dist = grid_masks()
+    order = grid_neighbor_order()
+    assert order[0] == [5, 1] and order[24] == [19, 23] and order[12] == [17, 13, 7, 11] and order[9] == [14, 4, 8]
+    assert any(o != sorted(o) for o in order)
+    N, F, A, T = 25, 12, 5, 4
+    cp = cacc_config(agent=agent, n_step=T, reward_norm=2000.0, coop_gamma=-1)
+    n_s_prod = [F * (1 + len(order[i])) for i in range(N)]
+    np.random.seed(5)
+    ref = REF_MODELS[agent](n_s_prod, [A] * N, nb, dist, -1.0, cp['MODEL_CONFIG'], dtype=torch.float64)
+    rng = np.random.RandomState(0)
+    X = rng.rand(T + 1, N, F)
+    ACT = rng.randint(0, A, size=(T + 1, N))
+    with cpu_ops():
+        np.random.seed(5)
+        cls = {'ia2c': models.IA2C, 'ia2c_fp': models.IA2C_FP}[agent]
+        m = cls(n_s_prod, [A] * N, nb, dist, -1.0, 10000, cp['MODEL_CONFIG'], seed=5, num_envs=1, device='cpu', obs_order=order)
+        named0 = m.policy.params.ref_variables()
+        assert [k for k, _ in named0] == list(ref.vars.v.keys())
+        for (k, a), (_, b) in zip(named0, ref.vars.v.items()):
+            np.testing.assert_allclose(a, b.detach().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+        out = {}
+        for name, mod in (('ref', ref), ('prod', m)):
+            fp = [np.ones(A) / A for _ in range(N)]
+            mod.reset()
+            done, PI, V = True, [], []
+            for t in range(T + 1):
+                ob = [np.concatenate([X[t, i]] + [X[t, j] for j in order[i]] +
+                                     ([fp[j] for j in order[i]] if agent == 'ia2c_fp' else [])) for i in range(N)]
+                pi = mod.forward(ob, done)
+                na = [ACT[t][nb[i] == 1] for i in range(N)]
+                v = np.array(mod.forward(ob, done, na, 'v'), dtype=np.float64)
+                fp = [np.asarray(p, dtype=np.float64).reshape(-1) for p in pi]
+                PI.append(np.stack(fp)); V.append(v)
+                if t < T:
+                    mod.add_transition(ob, na, ACT[t], -1.0 - 0.1 * t, v, False)
+                    done = False
+            mod.backward(V[-1], 0)
+            out[name] = (np.array(PI), np.array(V))
+        np.testing.assert_allclose(out['prod'][0], out['ref'][0], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out['prod'][1], out['ref'][1], rtol=1e-4, atol=2e-5)
+        for (k, a), (_, b) in zip(m.policy.params.ref_variables(), ref.vars.v.items()):
+            np.testing.assert_allclose(a, b.detach().numpy(), rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+def test_greedy_grid_controller_is_the_reference_rule():
+    """LargeGridController: the reference's five lane sums (large_grid_env.py:41-45) on a 6-lane vector, and on this env's
+    12-link wave vector read at the first link of each physical lane."""
+    from deeprl_network_amd.envs.large_grid_env import LargeGridController
+    from oracle.grid_ref import LINK_LANE
+    rng = np.random.RandomState(3)
+    ctl = LargeGridController()
+    for _ in range(200):
+        lanes = rng.rand(6)
+        flows = [lanes[0] + lanes[3], lanes[2] + lanes[5], lanes[1] + lanes[4], lanes[1] + lanes[2], lanes[4] + lanes[5]]
+        assert ctl.greedy(lanes) == int(np.argmax(flows))
+        assert ctl.greedy(lanes[LINK_LANE]) == int(np.argmax(flows))          # the 12-link form of the same state
+    assert ctl.forward([np.zeros(12)] * 25) == [0] * 25

@@ -104,3 +104,30 @@ def test_batch_equals_single_and_done_at_T():
         assert d.all() == (t == 19)
     y = G.gather_grid(ob)
     assert y.shape == (3, 25, 60) and np.array_equal(y[:, 12, 12:24], ob[:, 7]) and np.all(y[:, 0, 36:] == 0)
+
+
+def test_wait_and_hybrid_objectives_of_the_spec():
+    """oracle/grid_ref.py step 6 (`wait` / `hybrid`, atsc_env.py:383-418): the front vehicle of a lane stands while a queue
+    discharges nothing, any served flow or an empty lane clears it; rewards combine as the reference's three branches."""
+    from oracle import grid_ref as G
+    E = 3
+    a_red = np.full((E, 25), 3)                           # phase 3 serves the E approach only
+    refs = {o: G.GridBatchRef(G.GridParams(objective=o, coef_wait=0.5), E=E) for o in ('queue', 'wait', 'hybrid')}
+    for r in refs.values():
+        r.reset(np.ones((E, 4)))
+        r.q[:] = 4.0                                      # standing queues everywhere
+    out = {o: None for o in refs}
+    for t in range(3):
+        for o, r in refs.items():
+            out[o] = r.step(a_red)
+    hw = refs['wait'].hw
+    assert np.all(hw[:, :, [4, 5]] == 15.0)               # three red steps of 5 s on the W lanes
+    assert np.all(hw[:, :, [0, 3]] == 10.0)               # N / S: phase 0 -> 3 gives them 1 s of yellow clearance in the first step
+    assert np.all(hw[:, :, [1, 2]] == 0.0)                # the served E lanes' front vehicles move
+    wait = hw[:, :, G.LINK_LANE].sum(axis=2)
+    np.testing.assert_allclose(out['wait'][1], -wait.sum(axis=1))
+    np.testing.assert_allclose(out['hybrid'][1], out['queue'][1] - 0.5 * wait.sum(axis=1))
+    np.testing.assert_array_equal(refs['queue'].q, refs['wait'].q)      # the objective changes the reward, not the traffic
+    before = hw.copy()
+    refs['wait'].reset(np.ones((E, 4)), mask=[1, 0, 0])
+    assert np.all(refs['wait'].hw[0] == 0) and np.array_equal(refs['wait'].hw[1:], before[1:])

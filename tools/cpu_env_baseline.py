@@ -4,7 +4,7 @@ unmodified /root/reference/envs/cacc_env.py `CACCEnv.step` (cacc_env.py:191-242)
   * one process per host core (independent replicas, no communication),
 for the IA2C-FP and MA2C observation forms -> agent-steps/s (= agents x env steps / s).
 
-    python tools/cpu_env_baseline.py [--seconds 10] [--out profiles/r02_cpu_env_reference.json]
+    python tools/cpu_env_baseline.py [--seconds 10] [--out profiles/r04_cpu_env_reference.json]
 
 /root/reference exists only in the authoring container (never on the GPU box), so the result is committed under
 profiles/ and bench.py reports it as `cpu_baseline.reference_env_only` next to the restated full loop it times live."""

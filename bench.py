@@ -142,14 +142,19 @@ def measure_lstm_step(model, n=60, reps=10):
         gates = torch.empty(N, E, 4 * H, device=dev)
         ho, co = torch.empty_like(h), torch.empty_like(c)
 
+        in_k = bool(getattr(model, 'save_acts', False)) and p.enc_in_kernel(E, getattr(model, 'compact_obs', False))
+        kw = dict(ob=dict(x=model.buf_x[0], fp=model.fp)) if in_k else {}
+
         def body():
             for _ in range(n):
                 p.step_policy_value(x, h, c, done, pi, act, v, h_out=ho, c_out=co, gates=gates, defer_action_term=True,
-                                    mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0)
+                                    mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0, **kw)
+        # (the in-kernel input encoders' 2 * 23 * 64 flops per row are not counted: the figure stays comparable across rounds)
         flops = N * E * (2 * (KX + H) * 4 * H + 2 * H * 4 * H)
-        # read x, h, c; write h', c', gates, pi, v, action
-        nbytes = N * E * ((KX + 2 * H) * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
-        name = 'lstm_step_x_kernel<3> (nmarl_lstm_step_x, policy + value heads)'
+        # read x (in-kernel encoders: the 23 encoder inputs instead), h, c; write h', c', gates, pi, v, action (+ the encoded input)
+        nbytes = N * E * (((23 + KX) if in_k else KX) * 4 + 2 * H * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
+        name = 'lstm_step_x_kernel<3,0,%d> (nmarl_lstm_step_x%s, policy + value heads%s)' % (
+            1 if in_k else 0, '_enc' if in_k else '', ', input encoders inside' if in_k else '')
     elif p.can_save_acts and p.pv_one_launch(E):
         # coupled nets, one launch per lock-step: policy step (message term in the pre-phase), in-launch hand-off of the new h,
         # value re-step from the kept x-side part + the re-computed message columns + the new h (head kind 3 + message term)

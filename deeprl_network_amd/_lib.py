@@ -63,6 +63,15 @@ class Msg(C.Structure):
                 ('mean_out', C.c_void_p), ('mean_out_sn', C.c_int64), ('mean_out_row', C.c_int64)]
 
 
+class StepEnc(C.Structure):
+    """nmarl_step_enc_t (include/nmarl.h): the input encoders of a lock-step inside the policy + value launch."""
+    _fields_ = [('ob', C.c_void_p), ('ob_row', C.c_int64), ('fp', C.c_void_p), ('fp_sn', C.c_int64),
+                ('w_ob', C.c_void_p), ('b_ob', C.c_void_p), ('w_fp', C.c_void_p), ('b_fp', C.c_void_p),
+                ('w_ob_sn', C.c_int64), ('b_ob_sn', C.c_int64), ('w_fp_sn', C.c_int64), ('b_fp_sn', C.c_int64),
+                ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64),
+                ('F', C.c_int32), ('A', C.c_int32), ('m_max', C.c_int32), ('pad_', C.c_int32), ('nbr', C.c_int32 * 64)]
+
+
 class NetParams(C.Structure):
     """nmarl_net_params_t (include/nmarl.h)."""
     _fields_ = [('norm_wave', C.c_float), ('clip_wave', C.c_float), ('flow_rate', C.c_float), ('T', C.c_int32),
@@ -162,6 +171,8 @@ SIGNATURES = {
     'nmarl_lstm_step_sync_words': [_i64, _i32],
     'nmarl_lstm_step_x_msg': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
                               C.POINTER(Head), C.POINTER(Msg), _p],
+    'nmarl_lstm_step_x_enc': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
+                              C.POINTER(Head), C.POINTER(StepEnc), _p],
     'nmarl_lstm_bptt_wimage_floats': [_i32],
     'nmarl_lstm_bptt_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_step': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,

@@ -298,6 +298,10 @@ class IA2C:
         # enc is shared by the policy step and the value re-step (Q1)
         if pre_encoded:             # the env kernel of the previous lock-step already encoded buf_x[t] / fp[t] into slot t
             enc = self.S_buf[:, t]
+        elif self.save_acts and p.enc_in_kernel(self.E, self.compact_obs):
+            # the lock-step kernel runs both input encoders itself, from the compact observation and the fingerprints of slot t,
+            # and leaves the LSTM input in slot t of the saved activations: no encoder launch at all
+            enc, ob = self.S_buf[:, t], dict(x=self.buf_x[t], fp=self.fp)
         elif self.save_acts and 'ENC' in p._extra:
             # nets whose encoder output is NOT the LSTM input itself (CommNet: s = enc + message term): kept per lock-step so
             # that the update's encoder backward needs no forward pass.  Where the one-launch step runs the encoder too, `enc`
@@ -317,7 +321,8 @@ class IA2C:
             p.step_policy_value(enc, self.H_all[:, t], self.C_all[:, t], done, self.buf_fp[t + 1], self.buf_act[t],
                                 self.buf_vn[:, t], h_out=self.H_all[:, t + 1], c_out=self.C_all[:, t + 1],
                                 gates=self.G_buf[:, t], defer_action_term=True,
-                                **(dict(save=self._save_slots(t), ob=ob) if p.coupled else {}), **draw)
+                                **(dict(save=self._save_slots(t), ob=ob) if p.coupled else (dict(ob=ob) if ob is not None else {})),
+                                **draw)
             return self.buf_act[t]
         if self.save_acts:
             # coupled nets: policy step (saves its message terms, gates, states), then the value re-step from the new
@@ -365,6 +370,8 @@ class IA2C:
         ob = None
         if pre_encoded:
             enc = self.encode_target(self.n_step)
+        elif self.save_acts and p.enc_in_kernel(self.E, self.compact_obs):
+            enc, ob = None, dict(x=self.buf_x[self.n_step], fp=self.fp)          # (nothing of the bootstrap step is kept)
         elif self.save_acts and p.encodes_in_step(self.E, self.compact_obs):
             enc, ob = self.encode_target(self.n_step), self.buf_x[self.n_step]     # the step kernel runs the encoder itself
         else:

@@ -440,6 +440,11 @@ class BatchedPolicy:
         """The one-launch step of this net also runs the observation encoder (no separate encoder launch per lock-step)."""
         return False
 
+    def enc_in_kernel(self, E, compact):
+        """Uncoupled nets: the policy + value launch of a lock-step also runs BOTH input encoders (csrc/lstm_mfma.hip ENC; the
+        caller hands `step_policy_value` the env's compact observation and the fingerprints as `ob`)."""
+        return False
+
     def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, h_out=None, c_out=None, gates=None,
                           defer_action_term=False, save=None, ob=None, **draw):
         """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) in one kernel:
@@ -453,6 +458,10 @@ class BatchedPolicy:
                 xs[4]['sync'] = self._sync_words(h.shape[1])
                 if ob is not None:
                     xs[4]['ob'] = self._ob_spec(ob)
+            elif ob is not None:
+                # the encoders run inside the launch: ob = dict(x = compact observation [E,N,5], fp = previous policies [N,E,4]);
+                # `enc` = where their output (the LSTM input) is kept for the update, or None
+                z1, z2, xs = None, None, (self._enc_spec(ob['x'], ob['fp'], enc), self.params[self.k_wx], self._img)
             else:
                 z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
@@ -720,6 +729,14 @@ class FPPolicy(LstmPolicy):
 
     def fused_env_encode(self, fp_next, out):
         return self._fused_spec(('fcs_w', 'fcs_b'), ('fcp_w', 'fcp_b'), fp_next, out) if self.xside else None
+
+    def enc_in_kernel(self, E, compact):
+        return bool(compact) and self.xside and self.fused_pv and not self.hetero and \
+            ops.step_enc_supported(self.n_feat, self.n_a, self.m_max, self.n_fc, self.n_h, self.N)
+
+    def _enc_spec(self, x, fp, out):
+        p = self.params
+        return ops.step_enc_spec(x, fp, p['fcs_w'], p['fcs_b'], p['fcp_w'], p['fcp_b'], self.nbrs, out=out)
 
 
 class NCMultiAgentPolicy(BatchedPolicy):

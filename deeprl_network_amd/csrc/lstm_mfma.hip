@@ -525,6 +525,13 @@ struct XArgs {
     int32_t* status;              // HEAD 4, may be NULL: hand-off status words ([0] <- 1 when a wave gives up, sticky)
     unsigned max_spins;           // HEAD 4: polls before a wave gives up
     int fault;                    // HEAD 4 test hook: block 0 never publishes (its neighbours time out)
+    // ENC 1: the input encoders of THIS lock-step run here too (see the ENC block of the kernel): x is not read
+    const float* e_ob; int64_t e_ob_row;          // the env's compact observation [E][N][5]
+    const float* e_fp; int64_t e_fp_sn;           // previous-step policies [N][E][4]
+    const float *e_wob, *e_bob, *e_wfp, *e_bfp;   // [N][15][64], [N][64], [N][8][64], [N][64] (the parameter tensors themselves)
+    int64_t e_wob_sn, e_bob_sn, e_wfp_sn, e_bfp_sn;
+    float* e_out; int64_t e_out_sn, e_out_row;    // where the encoded LSTM input [N][E][128] is kept for the update (may be NULL)
+    int e_nbr[64];                                // neighbour table [N][2] (-1 padded) BY VALUE: no dependent table load
 };
 
 // raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
@@ -595,7 +602,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, cons
 // LDS image staged behind the chunk buffers); its result goes through the wave's LDS tile into A layout, where the
 // main K loop picks it up as its last two x chunks, and (policy step) to global memory for the update's backward.
 
-template <int HEAD, int MSG>
+// ENC 1 (uncoupled nets on CACC, IA2C-FP: KX = 128 = [relu(x~ W_ob + b) | relu(p~ W_fp + b)], policies.py:176-181): the two
+// input encoders run HERE, as a register-only pre-phase, instead of in a launch of their own in front of every lock-step
+// (fc_fwd_multi / the tail of cacc_step_encode_kernel: ~6 us of latency and a 16.8-MB write + re-read per lock-step at
+// 8 x 4096 rows).  The product is taken TRANSPOSED, S^T = W^T x~^T, on v_mfma_f32_16x16x4_f32: the matrix-A operand is a
+// 16-column slice of W (lane (i, k) reads W[4 s + k][16 mt + i] straight from the parameter tensor: no image, no LDS), the
+// matrix-B operand is the input x~[row][4 s + k] (lane (row, k): one float per k-step, gathered from the env's compact
+// observation [own | nbr 0 | nbr 1] x 5 features, one zero pad, then the two neighbours' 4-wide fingerprints: 24 inputs = 6
+// k-steps; W is block diagonal, so 4 x 4 + 4 x 2 = 24 MFMAs), and the C/D layout of the result hands lane (row, grp) the
+// columns 16 mt + 4 grp + {0..3} of ITS row -- exactly the A-operand layout of the main K loop (k = 32 ch + 16 jj + 4 grp
+// + {0..3}, mt = 2 ch + jj).  No cross-lane movement at all: the 32 values per lane are parked in a lane-private LDS slot
+// (the register file is full: 254 VGPRs) over the not-yet-used h' tile, and written once to the saved activations.
+// Two chunk buffers instead of three (no de-phased wave groups: measured +-0 in round 2) make the room.
+template <int HEAD, int MSG, int ENC = 0>
 __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedArgs& a = xa.f;
@@ -633,10 +652,14 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // De-phased wave groups (no message pre-phase only: LDS): waves 4-7 run ONE chunk behind waves 0-3 through a ring
     // of three chunk buffers, so that on every SIMD one wave's VALU epilogue / head overlaps the other's MFMAs instead
     // of both epilogues running side by side with an idle matrix pipe.
-    constexpr bool DEPH = MSG == 0;
+    constexpr bool DEPH = MSG == 0 && ENC == 0;
     constexpr int NBUF = DEPH ? 3 : 2;
-    float* a_tile = lds + NBUF * CH_FLOATS + wave * R16 * APITCH;
-    float* hw_lds = lds + NBUF * CH_FLOATS + WAVES2 * R16 * APITCH;       // head weights: [64][A] actor, then [64] critic
+    static_assert(ENC == 0 || (MSG == 0 && HEAD == 3), "ENC: the uncoupled nets' policy + value launch");
+    // ENC: [chunks][head weights][union(h' tiles, lane-private x slots: 8 float4 x 512 threads)] -- the tiles are first written in
+    // the cell epilogue, behind the last tick's barrier, when every wave has consumed its x chunks
+    float* hw_lds = ENC ? lds + NBUF * CH_FLOATS : lds + NBUF * CH_FLOATS + WAVES2 * R16 * APITCH;   // head weights: [64][A] actor, then [64] critic
+    float* a_tile = (ENC ? hw_lds + HW_FLOATS : lds + NBUF * CH_FLOATS) + wave * R16 * APITCH;
+    float4* xslot = reinterpret_cast<float4*>(hw_lds + HW_FLOATS) + threadIdx.x;            // ENC: + 512 q, q = 0..7
     const int nx = xa.nx, nch = xa.nx + 2;
     const float4* img = reinterpret_cast<const float4*>(xa.img + (int64_t)n * xa.img_sn);
 
@@ -669,7 +692,16 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const float* hrow = a.h_in + (int64_t)n * a.h_sn + arow * H + 4 * grp;
     float4 a0, a1, n0, n1;
 #define NMARL_A_LOAD(ch, d0, d1)     /* raw load; the (1 - done) mask of the h chunks is applied at first use */ \
-    if (MSG != 0 && (ch) >= nx - 2 && (ch) < nx) {       /* the message columns: from the wave's LDS tile */ \
+    if (ENC) {      /* x chunks: the lane's own slots; h chunks: global.  BOTH requested unconditionally (clamped), then selected */ \
+        const int hc_ = (ch) - nx < 0 ? 0 : (ch) - nx;                                    \
+        const int xc_ = (ch) < nx ? (ch) : nx - 1;                                        \
+        const float4 h0_ = *reinterpret_cast<const float4*>(hrow + hc_ * CH_K);           \
+        const float4 h1_ = *reinterpret_cast<const float4*>(hrow + hc_ * CH_K + 16);      \
+        const float4 x0_ = xslot[512 * (2 * xc_)], x1_ = xslot[512 * (2 * xc_ + 1)];      \
+        const bool isx_ = (ch) < nx;                                                      \
+        d0.x = isx_ ? x0_.x : h0_.x; d0.y = isx_ ? x0_.y : h0_.y; d0.z = isx_ ? x0_.z : h0_.z; d0.w = isx_ ? x0_.w : h0_.w; \
+        d1.x = isx_ ? x1_.x : h1_.x; d1.y = isx_ ? x1_.y : h1_.y; d1.z = isx_ ? x1_.z : h1_.z; d1.w = isx_ ? x1_.w : h1_.w; \
+    } else if (MSG != 0 && (ch) >= nx - 2 && (ch) < nx) {       /* the message columns: from the wave's LDS tile */ \
         const float* t_ = a_tile + c * APITCH + ((ch) - (nx - 2)) * CH_K + 4 * grp;       \
         d0.x = t_[0]; d0.y = t_[1]; d0.z = t_[2]; d0.w = t_[3];                           \
         d1.x = t_[16]; d1.y = t_[17]; d1.z = t_[18]; d1.w = t_[19];                       \
@@ -687,7 +719,63 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d0.x *= kf_; d0.y *= kf_; d0.z *= kf_; d0.w *= kf_;                               \
         d1.x *= kf_; d1.y *= kf_; d1.z *= kf_; d1.w *= kf_;                               \
     }
-    if (MSG == 0) { NMARL_A_LOAD(0, a0, a1) }
+    if (MSG == 0 && ENC == 0) { NMARL_A_LOAD(0, a0, a1) }
+    // ---- ENC: the input encoders' operands (see the kernel's header), REQUESTED here -- behind the two weight chunks, in front of
+    // everything else the prologue asks for -- and consumed just before the prologue's barrier
+    float ein[ENC ? 6 : 1];
+    float ewt[ENC ? 24 : 1];
+    f32x4 eacc[ENC ? 8 : 1];
+    if (ENC) {
+        __builtin_amdgcn_sched_barrier(0);                                // (the chunk loads above stay first)
+        const int i16 = lane & 15;
+        const int ns = __builtin_amdgcn_readfirstlane(n);                // uniform: the table entries come as scalar loads from the
+        const int nb0 = xa.e_nbr[2 * ns], nb1 = xa.e_nbr[2 * ns + 1];    // launch arguments (no dependent global load)
+        {
+            const float* obr = xa.e_ob + arow * xa.e_ob_row;             // [N][5] of row `arow`
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = 4 * s + grp;                               // input 0..15: [own | nbr 0 | nbr 1] x 5, one pad
+                const int slot = k >= 10 ? 2 : (k >= 5 ? 1 : 0);
+                const int ag = slot == 0 ? n : (slot == 1 ? nb0 : nb1);
+                const bool ok = k < 15 && ag >= 0;
+                const float v = obr[(ok ? ag : n) * 5 + (k < 15 ? k - 5 * slot : 0)];
+                ein[s] = ok ? v : 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {                                // inputs 16..23: the neighbours' previous policies
+                const int ag = s == 0 ? nb0 : nb1;
+                const float v = xa.e_fp[(int64_t)(ag >= 0 ? ag : n) * xa.e_fp_sn + arow * 4 + grp];
+                ein[4 + s] = ag >= 0 ? v : 0.0f;
+            }
+        }
+        {
+            const float* wo = xa.e_wob + (int64_t)n * xa.e_wob_sn + i16;
+            const float* wf = xa.e_wfp + (int64_t)n * xa.e_wfp_sn + i16;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int k = 4 * s + grp;
+                    const float w = wo[(k < 15 ? k : 14) * H + 16 * mt];
+                    ewt[4 * mt + s] = k < 15 ? w : 0.0f;
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) ewt[16 + 2 * mt + s] = wf[(4 * s + grp) * H + 16 * mt];
+            }
+        }
+        {
+            const float* bo = xa.e_bob + (int64_t)n * xa.e_bob_sn + 4 * grp;
+            const float* bf = xa.e_bfp + (int64_t)n * xa.e_bfp_sn + 4 * grp;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bo + 16 * mt), b1 = *reinterpret_cast<const float4*>(bf + 16 * mt);
+                eacc[mt] = f32x4{b0.x, b0.y, b0.z, b0.w};
+                eacc[4 + mt] = f32x4{b1.x, b1.y, b1.z, b1.w};
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_STAMP(36)
+    }
     NMARL_STAMP(41)
     NMARL_STAGE_STORE(0)
     NMARL_STAMP(42)
@@ -876,6 +964,32 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         hw_lds[threadIdx.x] = (int)(threadIdx.x & 7) < A ? hw0 : 0.0f;
         if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = (int)threadIdx.x < A ? hw1 : 0.0f;
         if (PV && threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = hw2;
+    }
+    if (ENC) {
+        // ---- ENC: 24 MFMAs, relu, park in the lane's LDS slots, save for the update
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_STAMP(37)
+        const int i16 = lane & 15;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) eacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ewt[4 * mt + s], ein[s], eacc[mt], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                eacc[4 + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ewt[16 + 2 * mt + s], ein[4 + s], eacc[4 + mt], 0, 0, 0);
+        }
+        float* so = xa.e_out ? xa.e_out + (int64_t)n * xa.e_out_sn + (row0 + i16) * xa.e_out_row + 4 * grp : nullptr;
+        const bool so_ok = so != nullptr && row0 + i16 < a.E;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const float4 v = float4{fmaxf(eacc[mt][0], 0.0f), fmaxf(eacc[mt][1], 0.0f), fmaxf(eacc[mt][2], 0.0f), fmaxf(eacc[mt][3], 0.0f)};
+            xslot[512 * mt] = v;                                         // (lane-private: re-read by this lane only)
+            if (so_ok) *reinterpret_cast<float4*>(so + 16 * mt) = v;
+            if (mt == 0) a0 = v;
+            if (mt == 1) a1 = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        NMARL_STAMP(38)
     }
     NMARL_STAMP(47)
     __syncthreads();
@@ -1457,12 +1571,12 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
                                  int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
                                  const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
                                  float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
-                                 const nmarl_msg_t* msg, void* stream) {
+                                 const nmarl_msg_t* msg, void* stream, const nmarl_step_enc_t* enc = nullptr) {
     const int mk = msg ? msg->kind : 0;
     const int KM = mk ? H : 0;                   // columns of x the message pre-phase produces
     if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K || mk < 0 || mk > 3 ||
         (mk && (KX2 != 0 || KX < H)) ||
-        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 - KM > 0 && !x) || (KX2 > 0 && !x2))))
+        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 - KM > 0 && !x && !enc) || (KX2 > 0 && !x2))))
         return NMARL_EINVAL;
     if (mk && E > 0) {
         if (msg->m_max <= 0 || msg->m_max > 8 || !msg->nbr_idx || !msg->img || !msg->b || msg->b_sn < H ||
@@ -1497,7 +1611,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         ((uintptr_t)c_new % 16) || ((uintptr_t)h_new % 16) || (gates && ((uintptr_t)gates % 16)) ||
         ((uintptr_t)bias % 16) || ((uintptr_t)c_prev % 16) || (zadd1 && ((uintptr_t)zadd1 % 16)) || (zadd2 && ((uintptr_t)zadd2 % 16)) ||
         img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
-        (KX - KX2 - KM > 0 && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
+        (KX - KX2 - KM > 0 && !enc && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
         (KX2 > 0 && (x2_row < KX2 || (x2_row % 4) || (x2_sn % 4) || ((uintptr_t)x2 % 16))))
         return NMARL_EINVAL;
     XArgs xa{};
@@ -1509,7 +1623,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     if (kind != 0) a.hd = *head;
-    xa.x = KX - KX2 - KM > 0 ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
+    xa.x = (KX - KX2 - KM > 0 && !enc) ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
     xa.x2 = KX2 > 0 ? x2 : nullptr; xa.x2_sn = x2_sn; xa.x2_row = x2_row;
     xa.img = img; xa.img_sn = img_sn;
     xa.nx = KX / CH_K; xa.nx1 = (KX - KX2) / CH_K; xa.N = N;
@@ -1553,6 +1667,33 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     }
     if (mk && kind == 0) return NMARL_EINVAL;                   // the message pre-phase exists for the policy / value steps
     const dim3 grid(a.blocks_per_agent * N);
+    if (enc) {
+        // the input encoders inside the launch (ENC 1): the uncoupled nets' policy + value step on the CACC input layout
+        if (mk != 0 || kind != 3 || KX != 2 * H || KX2 != 0 || zadd1 || zadd2 || N > 32 || enc->F != 5 || enc->A != 4 || enc->m_max != 2 ||
+            !enc->ob || !enc->fp || !enc->w_ob || !enc->b_ob || !enc->w_fp || !enc->b_fp || enc->ob_row < (int64_t)N * 5 ||
+            enc->fp_sn < E * 4 || enc->w_ob_sn < 15 * H || enc->w_fp_sn < 8 * H || enc->b_ob_sn < H || enc->b_fp_sn < H ||
+            (enc->b_ob_sn % 4) || (enc->b_fp_sn % 4) || ((uintptr_t)enc->b_ob % 16) || ((uintptr_t)enc->b_fp % 16) ||
+            (enc->out && (((uintptr_t)enc->out % 16) || enc->out_row < 2 * H || (enc->out_row % 4) || (enc->out_sn % 4) ||
+                          enc->out_sn < E * enc->out_row)))
+            return NMARL_EINVAL;
+        for (int i = 0; i < 2 * N; ++i)
+            if (enc->nbr[i] < -1 || enc->nbr[i] >= N) return NMARL_EINVAL;
+        xa.e_ob = enc->ob; xa.e_ob_row = enc->ob_row; xa.e_fp = enc->fp; xa.e_fp_sn = enc->fp_sn;
+        xa.e_wob = enc->w_ob; xa.e_bob = enc->b_ob; xa.e_wfp = enc->w_fp; xa.e_bfp = enc->b_fp;
+        xa.e_wob_sn = enc->w_ob_sn; xa.e_bob_sn = enc->b_ob_sn; xa.e_wfp_sn = enc->w_fp_sn; xa.e_bfp_sn = enc->b_fp_sn;
+        xa.e_out = enc->out; xa.e_out_sn = enc->out_sn; xa.e_out_row = enc->out_row;
+        for (int i = 0; i < 64; ++i) xa.e_nbr[i] = i < 2 * N ? enc->nbr[i] : -1;
+        static NmarlPerDeviceOnce enc_once;
+        const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4) * sizeof(float);
+        if (const unsigned long long bit = enc_once.pending(); bit != ~0ull) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lb_e) != hipSuccess)
+                return NMARL_EHIP;
+            enc_once.done(bit);
+        }
+        hipLaunchKernelGGL((lstm_step_x_kernel<3, 0, 1>), grid, dim3(512), lb_e, static_cast<hipStream_t>(stream), xa);
+        return nmarl_check_launch();
+    }
     if (mk && kind == 3) {
         // policy step + value re-step of a coupled net in ONE launch: the re-step's message term needs the neighbours' new h, handed
         // over between blocks inside the launch -- every block must be resident (one block per CU: 512 threads, > 80 KB LDS)
@@ -1626,6 +1767,15 @@ extern "C" int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t Hh, int32_t K
     if (!msg || msg->kind == 0 || !head) return NMARL_EINVAL;
     return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
                          c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream);
+}
+
+extern "C" int nmarl_lstm_step_x_enc(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* h_in, int64_t h_sn, const float* img,
+                                     int64_t img_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,
+                                     const float* done, float* gates, int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
+                                     int64_t h_new_sn, const nmarl_head_t* head, const nmarl_step_enc_t* enc, void* stream) {
+    if (!enc || !head) return NMARL_EINVAL;
+    return launch_step_x(E, N, Hh, KX, nullptr, 0, 0, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
+                         c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, nullptr, stream, enc);
 }
 
 #ifdef NMARL_STEP_TIMELINE

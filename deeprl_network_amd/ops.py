@@ -254,6 +254,15 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
     x, _, img = xs[:3]
     x2 = xs[3] if len(xs) > 3 else None
     msg = xs[4] if len(xs) > 4 else None
+    if isinstance(x, dict):          # the input encoders run inside the launch (step_enc_spec): x is their description
+        if head is None or head.kind != 3 or x2 is not None or msg is not None or zadd1 is not None or zadd2 is not None:
+            raise _lib.NmarlError('%s: the in-kernel encoders need the policy + value step of an uncoupled net' % what)
+        KX = 2 * FC_J
+        if img.shape != (N, lib.nmarl_lstm_wimage_floats(KX)):
+            raise _lib.NmarlError('%s: weight image does not match KX = %d' % (what, KX))
+        check(lib.nmarl_lstm_step_x_enc(E, N, H, KX, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias), *_pn(c_prev), ptr(done, F32),
+                                        *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head), C.byref(_step_enc(x, N, E)), stream()), what)
+        return
     xp, x_sn, x_row, K1 = (None, 0, 0, 0) if x is None else (*_rows_view(x, x.shape[2], what + ' x'), x.shape[2])
     x2p, x2_sn, x2_row, K2 = (None, 0, 0, 0) if x2 is None else (*_rows_view(x2, x2.shape[2], what + ' x2'), x2.shape[2])
     KX = K1 + K2 + (H if msg is not None else 0)
@@ -308,6 +317,50 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
     check(lib.nmarl_lstm_step_x(E, N, H, KX, xp, x_sn, x_row, K2, x2p, x2_sn, x2_row, *_pn(h), ptr(img, F32), img.stride(0),
                                 *_bias(bias), *_pn(zadd1), *_pn(zadd2), *_pn(c_prev), ptr(done, F32), *_pn(gates),
                                 *_pn(c_out), *_pn(h_out), None if head is None else C.byref(head), stream()), what)
+
+
+def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
+    """The two input encoders of IA2C-FP fit the lock-step kernel's register-only pre-phase (csrc/lstm_mfma.hip, ENC): the CACC
+    input layout -- 5 own features x (1 + 2 neighbours) and 2 x 4 fingerprint entries -> 64 + 64 outputs."""
+    return n_feat == 5 and n_a == 4 and m_max == 2 and n_fc == FC_J and n_h == FUSED_H and N <= 32 and \
+        os.environ.get('NMARL_INKERNEL_ENCODE', '1') != '0'
+
+
+def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None):
+    """Description of a lock-step's input encoders for `lstm_step_policy_value(xs=(spec, wx, image))`: ob [E,N,5] the env's
+    compact observation, fp [N,E,4] the previous-step policies, the four parameter tensors as they are, nbrs = the HOST
+    neighbour lists (ascending), out [N,E,128] (a view: slot t of the saved LSTM inputs) or None."""
+    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out)
+
+
+def _step_enc(d, N, E):
+    ob, fp = d['ob'], d['fp']
+    if ob.dim() != 3 or ob.shape != (E, N, 5) or not ob.is_contiguous():
+        raise _lib.NmarlError('step_enc: ob must be the compact observation [E,N,5], contiguous')
+    if fp.shape != (N, E, 4) or fp.stride(2) != 1 or fp.stride(1) != 4:
+        raise _lib.NmarlError('step_enc: fp must be [N,E,4] with contiguous panels')
+    e = _lib.StepEnc()
+    e.ob, e.ob_row = ptr(ob, F32), N * 5
+    e.fp, e.fp_sn = ptr(fp, F32, strided=True), fp.stride(0)
+    for key, rows in (('w_ob', 15), ('w_fp', 8)):
+        w = d[key]
+        if w.shape != (N, rows, FC_J):
+            raise _lib.NmarlError('step_enc: %s must be [N,%d,64]' % (key, rows))
+        p_, sn = _head_param(w, 'step_enc')
+        setattr(e, key, p_)
+        setattr(e, key + '_sn', sn)
+    e.b_ob, e.b_ob_sn = _bias(d['b_ob'])
+    e.b_fp, e.b_fp_sn = _bias(d['b_fp'])
+    out = d.get('out')
+    if out is not None:
+        e.out, e.out_sn, e.out_row = _rows_view(out, 2 * FC_J, 'step_enc out')
+    e.F, e.A, e.m_max = 5, 4, 2
+    for i in range(64):
+        e.nbr[i] = -1
+    for i, lst in enumerate(d['nbrs']):
+        for k, j in enumerate(lst[:2]):
+            e.nbr[2 * i + k] = int(j)
+    return e
 
 
 def ob_encoder_supported(n_feat, n_obs, n_h):

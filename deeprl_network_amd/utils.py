@@ -297,7 +297,10 @@ class BatchedTrainer:
         self.compact_obs = bool(compact_obs) and hasattr(env, 'set_compact_obs') and model.enable_compact_obs() and \
             env.set_compact_obs(True)
         # CACC: the env kernel runs the next lock-step's input encoders behind its step (csrc/cacc.hip cacc_step_encode_kernel)
-        self.fused_encode = bool(fused_encode) and self.saved_acts and self.compact_obs and \
+        # ... unless the lock-step kernel runs the encoders itself (csrc/lstm_mfma.hip ENC: IA2C-FP), then the env step stays alone
+        self.enc_in_kernel = self.saved_acts and self.compact_obs and env.device.type == 'cuda' and \
+            model.policy.enc_in_kernel(env.E, True)
+        self.fused_encode = bool(fused_encode) and self.saved_acts and self.compact_obs and not self.enc_in_kernel and \
             getattr(env, 'supports_fused_encode', False) and env.device.type == 'cuda' and \
             model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1)) is not None
         self.E, self.N = env.E, env.n_agent

@@ -442,6 +442,30 @@ typedef struct nmarl_msg {
     float* mean_out; int64_t mean_out_sn, mean_out_row;   /* kind 2, may be NULL: the policy step's mean_j(h_j) rows ([N,E,64] view), the
                                                            * input of the message layer -- its weight gradient is mean(h)^T d1 */
 } nmarl_msg_t;
+/*
+ * The input encoders of a lock-step INSIDE the policy + value launch (head kind 3, no message term; round 5): IA2C-FP on
+ * CACC, policies.py:176-181 -- s = [relu([x_i | x_nbr] W_ob + b_ob) | relu([pi_nbr] W_fp + b_fp)] (KX = 128) is formed by a
+ * register-only matrix-core pre-phase from the env's COMPACT observation and the previous-step policies, written once to
+ * `out` (the update's saved LSTM input; may be NULL: bootstrap step) and consumed as the K loop's first four chunks -- no
+ * encoder launch, no re-read of s.  Replaces nmarl_fc_fwd_multi / the encoder half of nmarl_cacc_step_encode in front of
+ * nmarl_lstm_step_x; same function up to fp32 summation order (the matrix cores add four products at a time).
+ *   ob [E][N][F = 5] (row pitch ob_row floats), fp [N][E][A = 4] (agent stride fp_sn); w_ob [N][15][64], b_ob [N][64],
+ *   w_fp [N][8][64], b_fp [N][64]: the parameter tensors as they are (agent strides *_sn); out [N][E][128] view (agent
+ *   stride out_sn, row pitch out_row); nbr: HOST copy of the neighbour table [N][m_max = 2], ascending, -1 padded (N <= 32).
+ */
+typedef struct nmarl_step_enc {
+    const float* ob; int64_t ob_row;
+    const float* fp; int64_t fp_sn;
+    const float *w_ob, *b_ob, *w_fp, *b_fp;
+    int64_t w_ob_sn, b_ob_sn, w_fp_sn, b_fp_sn;
+    float* out; int64_t out_sn, out_row;
+    int32_t F, A, m_max, pad_;
+    int32_t nbr[64];
+} nmarl_step_enc_t;
+int nmarl_lstm_step_x_enc(int64_t E, int32_t N, int32_t H, int32_t KX, const float* h_in, int64_t h_sn, const float* img,
+                          int64_t img_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,
+                          const float* done, float* gates, int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new,
+                          int64_t h_new_sn, const nmarl_head_t* head, const nmarl_step_enc_t* enc, void* stream);
 int nmarl_lstm_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_step_sync_words(int64_t E, int32_t N);
 int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t H, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,

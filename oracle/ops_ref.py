@@ -333,12 +333,43 @@ def nbr_action_value(action, nbr_idx, w_a, n_a, out=None, accumulate=False):
     return out
 
 
+def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
+    """(the product's csrc/lstm_mfma.hip ENC pre-phase: the CACC input layout of IA2C-FP)"""
+    return n_feat == 5 and n_a == 4 and m_max == 2 and n_fc == 64 and n_h == 64 and N <= 32
+
+
+def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None):
+    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out)
+
+
+def step_enc_forward(d):
+    """FPPolicy's input encoders (policies.py:176-181) from the env's COMPACT observation ob [E,N,5] and the previous-step
+    policies fp [N,E,4]: s_i = [relu([x_i | x_nbr] W_ob + b_ob) | relu([pi_nbr] W_fp + b_fp)], neighbours in ascending index,
+    left packed, absent slots zero -> [N,E,128]; also written to d['out'] when given."""
+    ob, fp, nbrs = d['ob'], d['fp'], d['nbrs']
+    E, N, F = ob.shape
+    A = fp.shape[2]
+    rows = []
+    for i in range(N):
+        nb = list(nbrs[i]) + [-1] * (2 - len(nbrs[i]))
+        xo = torch.cat([ob[:, i]] + [ob[:, j] if j >= 0 else torch.zeros(E, F, dtype=ob.dtype, device=ob.device) for j in nb], dim=1)
+        xf = torch.cat([fp[j] if j >= 0 else torch.zeros(E, A, dtype=fp.dtype, device=fp.device) for j in nb], dim=1)
+        rows.append(torch.cat([torch.relu(xo @ d['w_ob'][i] + d['b_ob'][i]), torch.relu(xf @ d['w_fp'][i] + d['b_fp'][i])], dim=1))
+    S = torch.stack(rows, dim=0)
+    if d.get('out') is not None:
+        d['out'].copy_(S)
+    return S
+
+
 def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_out, act_out, v_w, v_b, nbr_idx, n_a,
                            v_out, mode, u=None, seed=0, env_id_base=0, step=0, step_dev=None, xs=None, h_out=None,
                            c_out=None, gates=None, defer_action_term=False):
     """Trainer._get_policy + _get_value of one lock-step (utils.py:129-149): forward('p') advances the state, forward('v')
     re-steps a COPY of it (policies.py:119-133, quirk Q1)."""
     h_out, c_out = (h if h_out is None else h_out), (c if c_out is None else c_out)
+    if xs is not None and isinstance(xs[0], dict):       # the input encoders run inside the product's launch
+        with torch.no_grad():
+            xs = (step_enc_forward(xs[0]),) + tuple(xs[1:])
     xs_p = xs
     if xs is not None and len(xs) > 4 and xs[4] is not None:
         # coupled net: only the POLICY step's message term is kept (`out`); the re-step's comes from the new h of all agents

@@ -248,9 +248,11 @@ def build_product_batched(z, device):
     return cls(n_s_ls, [A] * N, nb, dist, -1, 10 ** 9, cp['MODEL_CONFIG'], seed=seed, num_envs=K, device=device)
 
 
-def drive_batched(model, z, saved=False):
+def drive_batched(model, z, saved=False, compact=False):
     """saved: the rollout hands its activations to the update (model.enable_saved_activations, what BatchedTrainer does
-    for uncoupled nets) instead of the update recomputing the forward pass.
+    for uncoupled nets) instead of the update recomputing the forward pass.  compact: the observations are handed over as
+    the env's COMPACT slab [K,N,F] (model.enable_compact_obs: the encoders gather the neighbours themselves -- with `saved`
+    this is BatchedTrainer's exact configuration, incl. the input encoders inside the lock-step kernel where they fit).
 
     Replays make_golden_nn.run_batched on the product's BATCHED engine (act / bootstrap / update on E = K
     lock-stepped replicas, the calls BatchedTrainer makes): a prefix batch without update, the episode boundary
@@ -267,8 +269,12 @@ def drive_batched(model, z, saved=False):
     model.masked_steps = (0,)
     if saved:
         assert model.enable_saved_activations(), 'this policy cannot save its rollout activations'
+    if compact:
+        assert model.enable_compact_obs(), 'this policy cannot consume compact observations'
 
     def slab(x):                                  # [K,N,F] -> [K,N,n_obs]: own features, then the neighbours' (ascending)
+        if compact:
+            return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
         s = np.zeros((K, N, model.policy.n_obs), dtype=np.float32)
         s[:, :, :F] = x
         for i in range(N):

@@ -1308,3 +1308,87 @@ def test_batch_epilogue_matches_host_code(N, E, H, A, F, T):
         for k in ('ep_sum', 'ep_sq', 'ep_len', 'fin'):
             torch.testing.assert_close(dev[k].cpu(), host[k], rtol=1e-12, atol=1e-9)
     assert host['fin'][0] > 0 and (E == 1 or host['fin'][3] > 0)
+
+
+@pytest.mark.parametrize('N,E', [(8, 4096), (8, 1000), (8, 77), (5, 1), (3, 129)])
+@pytest.mark.parametrize('mode', [1, 2])
+def test_lstm_step_x_input_encoders_inside_the_launch(N, E, mode):
+    """nmarl_lstm_step_x_enc (lstm_step_x_kernel<3,0,1>): FPPolicy's two input encoders (policies.py:176-181) as the
+    register-only pre-phase of the policy + value launch, from the compact observation [E,N,5] and the previous-step policies
+    [N,E,4] through the neighbour table (ascending, left packed, absent slots zero).  Against the float64 restatement
+    (encoder output, new state, gates, policy, draw, value) and against the separate encoder launch (nmarl_fc_fwd_multi)
+    followed by the same step on its output; ragged row counts, agents with 0 / 1 / 2 neighbours, strided output slot."""
+    from deeprl_network_amd import ops
+    from oracle import ops_ref
+    H, A, KX = 64, 4, 128
+    g = torch.Generator().manual_seed(N * 131 + E + mode)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    d = _xside_case(N, E, KX, A, 2, N * 7 + E, 0)
+    # line graph (agents at the ends have one neighbour), one isolated agent when N = 3
+    nbrs = [[j for j in (i - 1, i + 1) if 0 <= j < N] for i in range(N)]
+    if N == 3:
+        nbrs = [[1], [0], []]
+    ob, fp = r(E, N, 5), torch.softmax(r(N, E, A), dim=-1)
+    w_ob, b_ob = r(N, 15, H) * 0.4 + torch.arange(15).view(1, -1, 1) * 0.01, r(N, H) * 0.2
+    w_fp, b_fp = r(N, 8, H) * 0.4 + torch.arange(H).view(1, 1, -1) * 0.003, r(N, H) * 0.2
+    for i in range(N):                      # rows of absent slots are zero in the product's padded weights
+        w_ob[i, 5 * (1 + len(nbrs[i])):] = 0
+        w_fp[i, 4 * len(nbrs[i]):] = 0
+    f64 = lambda t: None if t is None else t.double()                                    # noqa: E731
+    cu = lambda t: None if t is None else t.cuda()                                       # noqa: E731
+    draw = dict(mode=mode, seed=9, env_id_base=17, step=5)
+    # float64 restatement
+    spec_r = ops_ref.step_enc_spec(f64(ob), f64(fp), f64(w_ob), f64(b_ob), f64(w_fp), f64(b_fp), nbrs)
+    S_r = ops_ref.step_enc_forward(spec_r)
+    hr, cr = d['h'].double(), d['c'].double()
+    gr = torch.empty(N, E, 4 * H, dtype=torch.float64)
+    ops_ref.lstm_step_fused(hr, f64(d['wh']), f64(d['b']), None, None, cr, f64(d['done']), gr, torch.empty_like(cr),
+                            torch.empty_like(hr), xs=(S_r, f64(d['wx']), None))
+    pir, actr = torch.zeros(N, E, A, dtype=torch.float64), torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.lstm_step_policy(hr, f64(d['wh']), f64(d['b']), None, None, cr, f64(d['done']), cr, hr, f64(d['pi_w']), f64(d['pi_b']),
+                             pir, actr, xs=(S_r, f64(d['wx']), None), **draw)
+    # the kernel: output into a strided slot of a wider sequence buffer
+    img = ops.lstm_wimage(cu(d['wx']), cu(d['wh']))
+    Sbuf = torch.full((N, 3, E, KX), -7.0, device='cuda')
+    ob_g, fp_g = cu(ob), cu(fp)
+    spec = ops.step_enc_spec(ob_g, fp_g, cu(w_ob), cu(b_ob), cu(w_fp), cu(b_fp), nbrs, out=Sbuf[:, 1])
+    hg, cg = cu(d['h']), cu(d['c'])
+    ho, co, gg = torch.empty_like(hg), torch.empty_like(cg), torch.empty(N, E, 4 * H, device='cuda')
+    pig, actg, vg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.zeros(N, E, device='cuda')
+    ops.lstm_step_policy_value(hg, None, cu(d['b']), None, None, cg, cu(d['done']), cu(d['pi_w']), cu(d['pi_b']), pig, actg,
+                               cu(d['v_w']), cu(d['v_b']), cu(d['idx']), A, vg, xs=(spec, None, img), h_out=ho, c_out=co, gates=gg,
+                               defer_action_term=True, **draw)
+    torch.cuda.synchronize()
+    assert torch.all(Sbuf[:, 0] == -7.0) and torch.all(Sbuf[:, 2] == -7.0)
+    tol = dict(rtol=3e-5, atol=5e-6)
+    torch.testing.assert_close(Sbuf[:, 1].cpu().double(), S_r, **tol)
+    torch.testing.assert_close(ho.cpu().double(), hr, **tol)
+    torch.testing.assert_close(co.cpu().double(), cr, **tol)
+    torch.testing.assert_close(gg.cpu().double(), gr, **tol)
+    torch.testing.assert_close(pig.cpu().double(), pir, **tol)
+    act_chk = torch.zeros(E, N, dtype=torch.uint8)
+    ops_ref.sample_actions(pig.cpu(), act_chk, **draw)
+    assert torch.equal(actg.cpu(), act_chk)
+    # against the separate encoder launch + the same step on its output (incl. the value re-step, whose h part is deferred)
+    nbr_idx = -torch.ones(N, 2, dtype=torch.int32)
+    for i, lst in enumerate(nbrs):
+        nbr_idx[i, :len(lst)] = torch.tensor(lst, dtype=torch.int32)
+    nbr_self = torch.cat([torch.arange(N, dtype=torch.int32).view(-1, 1), nbr_idx], dim=1).cuda()
+    S2 = ops.fc_fwd_multi([(ob_g.transpose(0, 1), cu(w_ob), cu(b_ob), nbr_self), (fp_g, cu(w_fp), cu(b_fp), nbr_idx.cuda())], ops.BIAS_RELU)
+    torch.testing.assert_close(Sbuf[:, 1], S2, rtol=1e-5, atol=1e-6)
+    h2, c2, g2 = torch.empty_like(hg), torch.empty_like(cg), torch.empty_like(gg)
+    pi2, act2, v2 = torch.zeros_like(pig), torch.zeros_like(actg), torch.zeros_like(vg)
+    ops.lstm_step_policy_value(hg, None, cu(d['b']), None, None, cg, cu(d['done']), cu(d['pi_w']), cu(d['pi_b']), pi2, act2,
+                               cu(d['v_w']), cu(d['v_b']), cu(d['idx']), A, v2, xs=(S2, None, img), h_out=h2, c_out=c2, gates=g2,
+                               defer_action_term=True, **draw)
+    torch.testing.assert_close(ho, h2, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(vg, v2, rtol=1e-4, atol=2e-5)
+    assert (actg != act2).float().mean().item() < 1e-3                 # a draw flips only where a uniform meets a CDF boundary
+    # no output slot (bootstrap step): same results, nothing written
+    pi3, act3, v3 = torch.zeros_like(pig), torch.zeros_like(actg), torch.zeros_like(vg)
+    h3, c3 = torch.empty_like(hg), torch.empty_like(cg)
+    spec3 = ops.step_enc_spec(ob_g, fp_g, cu(w_ob), cu(b_ob), cu(w_fp), cu(b_fp), nbrs, out=None)
+    ops.lstm_step_policy_value(hg, None, cu(d['b']), None, None, cg, cu(d['done']), cu(d['pi_w']), cu(d['pi_b']), pi3, act3,
+                               cu(d['v_w']), cu(d['v_b']), cu(d['idx']), A, v3, xs=(spec3, None, img), h_out=h3, c_out=c3,
+                               defer_action_term=True, **draw)
+    assert torch.equal(h3, ho) and torch.equal(v3, vg) and torch.equal(act3, actg)

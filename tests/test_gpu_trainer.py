@@ -161,10 +161,12 @@ def test_saved_activations_equal_recomputed_forward():
 
 
 @pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ma2c_ic3'])
-def test_compact_observation_equals_gathered_slab(agent):
+def test_compact_observation_equals_gathered_slab(agent, monkeypatch):
     """CACC: the env writing each vehicle's own 5 features ([E,8,5], the encoder gathers the neighbours inside its
     kernel, update() expands the batch once) == the env writing the pre-gathered [E,8,15] slab: same actions, values,
-    weights after 3 batches."""
+    weights after 3 batches.  (Encoder launches on both sides: the in-kernel encoders of IA2C-FP add their products in the
+    matrix cores' order, see test_inkernel_encoders_equal_the_encoder_launch.)"""
+    monkeypatch.setenv('NMARL_INKERNEL_ENCODE', '0')
     from deeprl_network_amd.agents import models
     from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
     from deeprl_network_amd.utils import BatchedTrainer, Counter
@@ -188,11 +190,47 @@ def test_compact_observation_equals_gathered_slab(agent):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
 
 
+def test_inkernel_encoders_equal_the_encoder_launch(monkeypatch):
+    """IA2C-FP: the lock-step kernel running both input encoders itself (lstm_step_x_kernel<3,0,1>: no encoder launch, the env
+    step alone behind it) against the env step + encoder launch (nmarl_cacc_step_encode) in front of the plain lock-step
+    kernel, ONE batch from the same state at E = 4096 and E = 1000 (ragged last block): saved LSTM inputs, values and the
+    post-update weights agree to fp32 summation order; the drawn actions are identical except where a uniform falls within
+    that rounding of a CDF boundary."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    for E in (4096, 1000):
+        out = []
+        for inside in ('1', '0'):
+            monkeypatch.setenv('NMARL_INKERNEL_ENCODE', inside)
+            cp = cacc_config(agent='ia2c_fp', scenario='catchup', n_step=60, reward_norm=800.0)
+            env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+            np.random.seed(12)
+            model = models.IA2C_FP(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                                   cp['MODEL_CONFIG'], seed=12, num_envs=E)
+            tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
+            assert tr.enc_in_kernel == (inside == '1') and tr.fused_encode == (inside == '0')
+            tr.rollout()
+            torch.cuda.synchronize()
+            S, acts, vals = model.S_buf.clone(), model.buf_act.clone(), model.buf_vn.clone()
+            tr._update()
+            torch.cuda.synchronize()
+            out.append((S, acts, vals, model.policy.params.flat.clone()))
+            del env, model, tr
+        same = (out[0][1] == out[1][1]).all(dim=0).all(dim=-1)            # replicas whose whole action tape agrees
+        assert same.float().mean().item() > 0.999
+        torch.testing.assert_close(out[0][0][:, 0], out[1][0][:, 0], rtol=1e-5, atol=1e-6)      # first lock-step: same inputs
+        torch.testing.assert_close(out[0][0][:, :, same], out[1][0][:, :, same], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(out[0][2][:, :, same], out[1][2][:, :, same], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(out[0][3], out[1][3], rtol=1e-3, atol=2e-5)
+
+
 @pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ia2c'])
-def test_fused_env_encode_equals_separate_launches(agent):
+def test_fused_env_encode_equals_separate_launches(agent, monkeypatch):
     """The env kernel running the next lock-step's input encoders behind its step (nmarl_cacc_step_encode: the observation
     is encoded before it leaves the CU) == env step + nmarl_fc_fwd_multi as two launches: bit-identical actions, values,
     saved LSTM inputs and weights after 3 batches (E = 1000: a ragged last block of 16 replicas)."""
+    monkeypatch.setenv('NMARL_INKERNEL_ENCODE', '0')     # (IA2C-FP otherwise runs its encoders inside the lock-step kernel)
     from deeprl_network_amd.agents import models
     from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
     from deeprl_network_amd.utils import BatchedTrainer, Counter

@@ -85,6 +85,31 @@ def test_batched_update_equals_mean_of_reference_replica_gradients(path, saved):
     compare_batched(out, z)
 
 
+def test_batched_update_with_the_encoders_inside_the_lock_step():
+    """BatchedTrainer's configuration for IA2C-FP on CACC: compact observations + saved activations, where the policy + value
+    launch runs both input encoders itself (`enc_in_kernel`; on this CPU emulation: oracle/ops_ref.step_enc_forward) and no
+    encoder launch exists -- against the K = 4 reference-replica golden."""
+    from helpers import build_product_batched, compare_batched, drive_batched
+    from oracle import ops_ref
+    z = load_npz(os.path.join(GOLDEN, 'nnb_ia2c_fp_line.npz'))
+    calls = {'n': 0}
+    orig = ops_ref.step_enc_forward
+
+    def counting(d):
+        calls['n'] += 1
+        return orig(d)
+    ops_ref.step_enc_forward = counting
+    try:
+        with cpu_ops():
+            model = build_product_batched(z, 'cpu')
+            out = drive_batched(model, z, saved=True, compact=True)
+            assert model.policy.enc_in_kernel(model.E, True)
+    finally:
+        ops_ref.step_enc_forward = orig
+    assert calls['n'] == 2 * (int(z['n_step']) + 1)          # every lock-step and both bootstrap steps
+    compare_batched(out, z)
+
+
 def test_ic3_encoder_inside_the_step_equals_separate_encoder():
     """CommNet on a compact observation with 16-byte feature pieces (the grid's shape): step_policy_value with `ob` (the
     one-launch step runs the observation encoder itself and writes its output to the enc slot) == encode() followed by

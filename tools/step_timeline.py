@@ -35,8 +35,10 @@ for name, args in _lib.SIGNATURES.items():
 _lib.lib.nmarl_lstm_step_x = dbg.nmarl_lstm_step_x            # route the product wrappers through the instrumented build
 _lib.lib.nmarl_lstm_wimage = dbg.nmarl_lstm_wimage
 _lib.lib.nmarl_lstm_step_x_msg = dbg.nmarl_lstm_step_x_msg
+_lib.lib.nmarl_lstm_step_x_enc = dbg.nmarl_lstm_step_x_enc
 N, E, H, A, KX = 8, 4096, 64, 4, 128
 head = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
+ENC = 'enc' in sys.argv                       # head 3 with the input encoders inside the launch (round 5)
 GRID = 'grid' in sys.argv                     # head 4 on CommNet's grid shape: 25 x 1024 rows, KX = 64, 4 neighbours, encoder inside
 if GRID:
     N, E, A = 25, 1024, 5
@@ -81,14 +83,20 @@ elif head == 4:
     msg = dict(kind=1, nbr_idx=nbr4, w_msg=w_msg, b_msg=b_msg, img=mimg, out=slot[:, :, 2 * H:], sync=sync)
 
 
+if ENC:
+    nbrs = [[j for j in (i - 1, i + 1) if 0 <= j < N] for i in range(N)]
+    enc_spec = ops.step_enc_spec(r(E, N, 5), torch.softmax(r(N, E, A), -1), r(N, 15, H) * 0.3, r(N, H) * 0.1, r(N, 8, H) * 0.3, r(N, H) * 0.1,
+                                 nbrs, out=x)
+
+
 def run():
     if head == 4:
         ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2,
                                    xs=(None if GRID else slot[:, :, :2 * H], None, img4, None, msg), h_out=ho, c_out=co, gates=gates,
                                    defer_action_term=True)
     elif head == 3:
-        ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),
-                                   h_out=ho, c_out=co, gates=gates, defer_action_term=True)
+        ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2,
+                                   xs=(enc_spec if ENC else x, None, img), h_out=ho, c_out=co, gates=gates, defer_action_term=True)
     else:
         ops.lstm_step_fused(h, None, b, None, None, c, done, gates, co, ho, xs=(x, None, img))
 
@@ -99,13 +107,13 @@ torch.cuda.synchronize()
 t = tl.cpu().view(8, 64)
 t0 = int(t[:, 0].min())
 names = {0: 'entry', 40: 'epoch read', 41: 'A/W loads issued', 42: 'chunk 0 in LDS', 43: 'chunk 1 in LDS', 44: 'head w in LDS',
-         45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
+         36: 'enc loads issued', 37: 'enc operands in', 38: 'enc done', 45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
          26: 'published', 27: 'flags seen', 28: 'message term', 29: 'msg W staged', 30: 'msg chunks',
          33: 'cell math', 34: 'critic dots', 35: 'critic shfl'}
 for i in range(2, 20, 2):
     names[i], names[i + 1] = 'tick %d computed' % ((i - 2) // 2), 'tick %d barrier' % ((i - 2) // 2)
 print('stamp'.ljust(18) + ''.join(('wave %d' % w).rjust(9) for w in range(8)))
-ORDER = [0, 40, 41, 42, 43, 44, 45, 46, 47, 1, 48, 49] + list(range(2, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25]
+ORDER = [0, 40, 36, 41, 42, 43, 44, 45, 46, 37, 38, 47, 1, 48, 49] + list(range(2, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25]
 for i in ORDER:
     if i not in names:
         continue

@@ -621,6 +621,32 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     NMARL_STAMP(0)
     int n, blk_u;
     nmarl_xcd_work(blockIdx.x, gridDim.x, a.blocks_per_agent, n, blk_u);          // an agent's blocks share an XCD (its L2 holds the image)
+    // ENC: touch every scalar-cache line of the launch arguments (1.1 KB: 18 lines) with one back-to-back burst of scalar loads; the
+    // values are consumed (or-ed into nothing) only at the end of the prologue, so the lines arrive while the vector loads issue --
+    // the compiler's lazy argument loads then hit the scalar cache instead of each paying a first-touch miss behind its own wait
+    unsigned ka_touch = 0;
+    if (ENC) {
+        const __attribute__((address_space(4))) unsigned* ka =
+            (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+        for (unsigned o = 0; o < sizeof(XArgs); o += 64) ka_touch |= ka[o / 4];
+    }
+    // ENC: every launch argument the encoder pre-phase needs, fetched NOW in one batch of scalar loads.  Left to the compiler they
+    // are loaded where first used, one at a time, each behind its own wait: the argument block spans many scalar-cache lines, and
+    // three such first-touch misses in a row in front of the pre-phase's loads cost ~5 k cycles (tools/step_timeline.py enc)
+    const float* const e_ob = xa.e_ob; const float* const e_fp = xa.e_fp;
+    const float* const e_wob = xa.e_wob; const float* const e_bob = xa.e_bob;
+    const float* const e_wfp = xa.e_wfp; const float* const e_bfp = xa.e_bfp;
+    float* const e_out = xa.e_out;
+    const int64_t e_ob_row = xa.e_ob_row, e_fp_sn = xa.e_fp_sn, e_wob_sn = xa.e_wob_sn, e_bob_sn = xa.e_bob_sn, e_wfp_sn = xa.e_wfp_sn,
+                  e_bfp_sn = xa.e_bfp_sn, e_out_sn = xa.e_out_sn, e_out_row = xa.e_out_row;
+    int e_nb0 = -1, e_nb1 = -1;
+    if (ENC) {
+        const int ns_ = __builtin_amdgcn_readfirstlane(n);
+        e_nb0 = xa.e_nbr[2 * ns_]; e_nb1 = xa.e_nbr[2 * ns_ + 1];
+        asm volatile("" :: "s"(e_ob), "s"(e_fp), "s"(e_wob), "s"(e_bob), "s"(e_wfp), "s"(e_bfp), "s"(e_out), "s"(e_ob_row), "s"(e_fp_sn),
+                     "s"(e_wob_sn), "s"(e_bob_sn), "s"(e_wfp_sn), "s"(e_bfp_sn), "s"(e_out_sn), "s"(e_out_row), "s"(e_nb0), "s"(e_nb1));
+    }
     const int64_t row_blk = (int64_t)blk_u * ROWS_B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = row_blk + wave * R16;
@@ -723,56 +749,44 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // ---- ENC: the input encoders' operands (see the kernel's header), REQUESTED here -- behind the two weight chunks, in front of
     // everything else the prologue asks for -- and consumed just before the prologue's barrier
     float ein[ENC ? 6 : 1];
-    float ewt[ENC ? 24 : 1];
+    float ewt[ENC ? 3 : 1];
     f32x4 eacc[ENC ? 8 : 1];
     if (ENC) {
         __builtin_amdgcn_sched_barrier(0);                                // (the chunk loads above stay first)
         const int i16 = lane & 15;
-        const int ns = __builtin_amdgcn_readfirstlane(n);                // uniform: the table entries come as scalar loads from the
-        const int nb0 = xa.e_nbr[2 * ns], nb1 = xa.e_nbr[2 * ns + 1];    // launch arguments (no dependent global load)
+        const int ns = __builtin_amdgcn_readfirstlane(n);                // uniform; the table entries came as scalar loads from the
+        const int nb0 = e_nb0, nb1 = e_nb1;                              // launch arguments (no dependent global load)
+        // The 24 inputs are ORDERED for cheap addressing (any order serves: the weight rows are fetched to match): k-step s = 0, 1, 2
+        // = features 0..3 of slot s (own, neighbour 0, neighbour 1: the slot's agent is uniform, lane group grp = the feature),
+        // k-step 3 = feature 4 of slot grp (grp 3: the zero pad), k-steps 4, 5 = the two neighbours' policies (grp = the action).
+        // Weight row of (s < 3, grp) = 5 s + grp, of (3, grp) = 5 grp + 4; one per-lane base pointer + compile-time offsets each.
         {
-            const float* obr = xa.e_ob + arow * xa.e_ob_row;             // [N][5] of row `arow`
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int k = 4 * s + grp;                               // input 0..15: [own | nbr 0 | nbr 1] x 5, one pad
-                const int slot = k >= 10 ? 2 : (k >= 5 ? 1 : 0);
-                const int ag = slot == 0 ? n : (slot == 1 ? nb0 : nb1);
-                const bool ok = k < 15 && ag >= 0;
-                const float v = obr[(ok ? ag : n) * 5 + (k < 15 ? k - 5 * slot : 0)];
-                ein[s] = ok ? v : 0.0f;
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {                                // inputs 16..23: the neighbours' previous policies
-                const int ag = s == 0 ? nb0 : nb1;
-                const float v = xa.e_fp[(int64_t)(ag >= 0 ? ag : n) * xa.e_fp_sn + arow * 4 + grp];
-                ein[4 + s] = ag >= 0 ? v : 0.0f;
-            }
+            const float* obr = e_ob + arow * e_ob_row + grp;       // [N][5] of row `arow`, feature grp
+            const int ag1 = nb0 >= 0 ? nb0 : ns, ag2 = nb1 >= 0 ? nb1 : ns;
+            const float v0 = obr[ns * 5], v1 = obr[ag1 * 5], v2 = obr[ag2 * 5];
+            const int ag3 = grp == 0 ? ns : (grp == 1 ? ag1 : ag2);      // (grp 3: a valid dummy)
+            const float v3 = e_ob[arow * e_ob_row + ag3 * 5 + 4];
+            const bool ok3 = grp == 0 || (grp == 1 && nb0 >= 0) || (grp == 2 && nb1 >= 0);
+            ein[0] = v0; ein[1] = nb0 >= 0 ? v1 : 0.0f; ein[2] = nb1 >= 0 ? v2 : 0.0f; ein[3] = ok3 ? v3 : 0.0f;
+            const float* fpr = e_fp + arow * 4 + grp;
+            const float p0 = fpr[(int64_t)ag1 * e_fp_sn], p1 = fpr[(int64_t)ag2 * e_fp_sn];
+            ein[4] = nb0 >= 0 ? p0 : 0.0f; ein[5] = nb1 >= 0 ? p1 : 0.0f;
         }
-        {
-            const float* wo = xa.e_wob + (int64_t)n * xa.e_wob_sn + i16;
-            const float* wf = xa.e_wfp + (int64_t)n * xa.e_wfp_sn + i16;
+        // W and the two biases go through LDS: fetched ONCE per block (3 + 1/16 loads per thread, coalesced rows) instead of 24 + 8
+        // scattered loads per lane -- the pre-phase was bound by the number of vector-memory instructions the CU's eight waves
+        // issue (tools/step_timeline.py enc).  Image order = the order the lanes read it back in: [k-step s][lane][m-tile] floats.
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int k = 4 * s + grp;
-                    const float w = wo[(k < 15 ? k : 14) * H + 16 * mt];
-                    ewt[4 * mt + s] = k < 15 ? w : 0.0f;
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) ewt[16 + 2 * mt + s] = wf[(4 * s + grp) * H + 16 * mt];
-            }
+        for (int q = 0; q < 3; ++q) {
+            const int e = q * 512 + (int)threadIdx.x;                    // 0 .. 1535 = 6 k-steps x 64 lanes x 4 m-tiles
+            const int s_ = e >> 8, l_ = (e >> 2) & 63, mt_ = e & 3, g_ = l_ >> 4, i_ = l_ & 15;
+            const int row = s_ < 3 ? 5 * s_ + g_ : (s_ == 3 ? 5 * (g_ < 3 ? g_ : 2) + 4 : 4 * (s_ - 4) + g_);   // (pad lane: a valid row, its input is 0)
+            const float* src = s_ < 4 ? e_wob + (int64_t)n * e_wob_sn : e_wfp + (int64_t)n * e_wfp_sn;
+            ewt[q] = src[row * H + 16 * mt_ + i_];
         }
-        {
-            const float* bo = xa.e_bob + (int64_t)n * xa.e_bob_sn + 4 * grp;
-            const float* bf = xa.e_bfp + (int64_t)n * xa.e_bfp_sn + 4 * grp;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const float4 b0 = *reinterpret_cast<const float4*>(bo + 16 * mt), b1 = *reinterpret_cast<const float4*>(bf + 16 * mt);
-                eacc[mt] = f32x4{b0.x, b0.y, b0.z, b0.w};
-                eacc[4 + mt] = f32x4{b1.x, b1.y, b1.z, b1.w};
-            }
-        }
+        float4 eb4 = float4{0.f, 0.f, 0.f, 0.f};
+        if (threadIdx.x < 32)
+            eb4 = *reinterpret_cast<const float4*>((threadIdx.x < 16 ? e_bob + (int64_t)n * e_bob_sn : e_bfp + (int64_t)n * e_bfp_sn - H) + 4 * threadIdx.x);
+        eacc[0] = f32x4{eb4.x, eb4.y, eb4.z, eb4.w};                     // (parked in eacc[0] until it is stored to LDS)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_STAMP(36)
     }
@@ -965,35 +979,61 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = (int)threadIdx.x < A ? hw1 : 0.0f;
         if (PV && threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = hw2;
     }
+    float* e_lds = hw_lds + HW_FLOATS + 8 * 512 * 4;                   // ENC: [6][64][4] W image + [128] biases (behind the x slots)
     if (ENC) {
-        // ---- ENC: 24 MFMAs, relu, park in the lane's LDS slots, save for the update
-        __builtin_amdgcn_sched_barrier(0);
         NMARL_STAMP(37)
-        const int i16 = lane & 15;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) eacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ewt[4 * mt + s], ein[s], eacc[mt], 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                eacc[4 + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ewt[16 + 2 * mt + s], ein[4 + s], eacc[4 + mt], 0, 0, 0);
-        }
-        float* so = xa.e_out ? xa.e_out + (int64_t)n * xa.e_out_sn + (row0 + i16) * xa.e_out_row + 4 * grp : nullptr;
-        const bool so_ok = so != nullptr && row0 + i16 < a.E;
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const float4 v = float4{fmaxf(eacc[mt][0], 0.0f), fmaxf(eacc[mt][1], 0.0f), fmaxf(eacc[mt][2], 0.0f), fmaxf(eacc[mt][3], 0.0f)};
-            xslot[512 * mt] = v;                                         // (lane-private: re-read by this lane only)
-            if (so_ok) *reinterpret_cast<float4*>(so + 16 * mt) = v;
-            if (mt == 0) a0 = v;
-            if (mt == 1) a1 = v;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        NMARL_STAMP(38)
+        for (int q = 0; q < 3; ++q) e_lds[q * 512 + threadIdx.x] = ewt[q];
+        if (threadIdx.x < 32) *reinterpret_cast<float4*>(e_lds + 1536 + 4 * threadIdx.x) = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
     }
     NMARL_STAMP(47)
     __syncthreads();
     NMARL_STAMP(1)
+    if (ENC) {
+        // ---- ENC: operands from LDS, 24 MFMAs (k-step outer: four independent accumulators between two dependent ones), relu, park
+        // in the lane's LDS slots, save for the update
+        const int i16 = lane & 15;
+        float4 w4[6];
+#pragma unroll
+        for (int s_ = 0; s_ < 6; ++s_) w4[s_] = reinterpret_cast<const float4*>(e_lds)[s_ * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float4 b0 = *reinterpret_cast<const float4*>(e_lds + 1536 + 16 * mt + 4 * grp);
+            const float4 b1 = *reinterpret_cast<const float4*>(e_lds + 1536 + H + 16 * mt + 4 * grp);
+            eacc[mt] = f32x4{b0.x, b0.y, b0.z, b0.w};
+            eacc[4 + mt] = f32x4{b1.x, b1.y, b1.z, b1.w};
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            eacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].x, ein[s_], eacc[0], 0, 0, 0);
+            eacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].y, ein[s_], eacc[1], 0, 0, 0);
+            eacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].z, ein[s_], eacc[2], 0, 0, 0);
+            eacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].w, ein[s_], eacc[3], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s_ = 4; s_ < 6; ++s_) {
+            eacc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].x, ein[s_], eacc[4], 0, 0, 0);
+            eacc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].y, ein[s_], eacc[5], 0, 0, 0);
+            eacc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].z, ein[s_], eacc[6], 0, 0, 0);
+            eacc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].w, ein[s_], eacc[7], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            eacc[mt] = __builtin_elementwise_max(eacc[mt], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            xslot[512 * mt] = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};      // (lane-private: re-read by this lane only)
+        }
+        a0 = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
+        a1 = float4{eacc[1][0], eacc[1][1], eacc[1][2], eacc[1][3]};
+        if (e_out != nullptr && row0 + i16 < a.E) {                      // the saved LSTM input of the update: one predicate, 8 stores
+            float* so = e_out + (int64_t)n * e_out_sn + (row0 + i16) * e_out_row + 4 * grp;
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+                *reinterpret_cast<float4*>(so + 16 * mt) = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};
+        }
+        asm volatile("" :: "s"(ka_touch));
+        NMARL_STAMP(38)
+    }
+
     // one k-step of a 64-column product from an LDS image [k][c][4 t]: four MFMAs; a 32-row chunk of it: eight steps
 #define NMARL_MSTEP(ACC, av, kl)                                                               \
         {                                                                                      \
@@ -1684,7 +1724,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.e_out = enc->out; xa.e_out_sn = enc->out_sn; xa.e_out_row = enc->out_row;
         for (int i = 0; i < 64; ++i) xa.e_nbr[i] = i < 2 * N ? enc->nbr[i] : -1;
         static NmarlPerDeviceOnce enc_once;
-        const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4) * sizeof(float);
+        const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4 + 6 * 64 * 4 + 2 * H) * sizeof(float);
         if (const unsigned long long bit = enc_once.pending(); bit != ~0ull) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lb_e) != hipSuccess)

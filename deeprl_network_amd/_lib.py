@@ -69,7 +69,11 @@ class StepEnc(C.Structure):
                 ('w_ob', C.c_void_p), ('b_ob', C.c_void_p), ('w_fp', C.c_void_p), ('b_fp', C.c_void_p),
                 ('w_ob_sn', C.c_int64), ('b_ob_sn', C.c_int64), ('w_fp_sn', C.c_int64), ('b_fp_sn', C.c_int64),
                 ('out', C.c_void_p), ('out_sn', C.c_int64), ('out_row', C.c_int64),
-                ('F', C.c_int32), ('A', C.c_int32), ('m_max', C.c_int32), ('pad_', C.c_int32), ('nbr', C.c_int32 * 64)]
+                ('F', C.c_int32), ('A', C.c_int32), ('m_max', C.c_int32), ('pad_', C.c_int32), ('nbr', C.c_int32 * 64),
+                ('env', C.POINTER(CaccParams)), ('h', C.c_void_p), ('v', C.c_void_p), ('u', C.c_void_p), ('t', C.c_void_p),
+                ('collided', C.c_void_p), ('v0_init', C.c_void_p), ('obs_out', C.c_void_p), ('reward', C.c_void_p),
+                ('done', C.c_void_p), ('global_reward', C.c_void_p), ('auto_reset', C.c_int32), ('pad2_', C.c_int32),
+                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('episode', C.c_void_p), ('xact', C.c_void_p), ('cnt', C.c_void_p)]
 
 
 class NetParams(C.Structure):
@@ -173,6 +177,7 @@ SIGNATURES = {
                               C.POINTER(Head), C.POINTER(Msg), _p],
     'nmarl_lstm_step_x_enc': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
                               C.POINTER(Head), C.POINTER(StepEnc), _p],
+    'nmarl_lstm_step_env_words': [_i64],
     'nmarl_lstm_bptt_wimage_floats': [_i32],
     'nmarl_lstm_bptt_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_step': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,

@@ -281,7 +281,7 @@ class IA2C:
         return self._enc_boot
 
     def act(self, done, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0, step=0, step_dev=None,
-            done_is_zero=False, pre_encoded=False):
+            done_is_zero=False, pre_encoded=False, env_step=None):
         """One lock-step decision for all replicas at buffer slot t: reads the observation buf_x[t]
         and fingerprints buf_fp[t]; writes the action into buf_act[t], the value into buf_v[t] and the
         new policy into buf_fp[t+1] (env.update_fingerprint, utils.py:173).  done [E] f32 is the pre-step
@@ -301,7 +301,8 @@ class IA2C:
         elif self.save_acts and p.enc_in_kernel(self.E, self.compact_obs):
             # the lock-step kernel runs both input encoders itself, from the compact observation and the fingerprints of slot t,
             # and leaves the LSTM input in slot t of the saved activations: no encoder launch at all
-            enc, ob = self.S_buf[:, t], dict(x=self.buf_x[t], fp=self.fp)
+            # (env_step: the same launch also steps the env with the actions it draws -- CACCBatchEnv.inkernel_step)
+            enc, ob = self.S_buf[:, t], dict(x=self.buf_x[t], fp=self.fp, env=env_step)
         elif self.save_acts and 'ENC' in p._extra:
             # nets whose encoder output is NOT the LSTM input itself (CommNet: s = enc + message term): kept per lock-step so
             # that the update's encoder backward needs no forward pass.  Where the one-launch step runs the encoder too, `enc`
@@ -313,6 +314,8 @@ class IA2C:
             p._enc_was_saved = True
         else:
             enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
+        if env_step is not None and (ob is None or not isinstance(ob, dict)):
+            raise ValueError('env_step needs the lock-step kernel that runs the input encoders itself (policy.enc_in_kernel)')
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
         if self.save_acts and p.pv_one_launch(self.E):
             # the policy step reads slot t of the state sequences and writes slot t + 1, gates into G[:, t]; the value

@@ -461,7 +461,7 @@ class BatchedPolicy:
             elif ob is not None:
                 # the encoders run inside the launch: ob = dict(x = compact observation [E,N,5], fp = previous policies [N,E,4]);
                 # `enc` = where their output (the LSTM input) is kept for the update, or None
-                z1, z2, xs = None, None, (self._enc_spec(ob['x'], ob['fp'], enc), self.params[self.k_wx], self._img)
+                z1, z2, xs = None, None, (self._enc_spec(ob['x'], ob['fp'], enc, ob.get('env')), self.params[self.k_wx], self._img)
             else:
                 z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
@@ -734,9 +734,9 @@ class FPPolicy(LstmPolicy):
         return bool(compact) and self.xside and self.fused_pv and not self.hetero and \
             ops.step_enc_supported(self.n_feat, self.n_a, self.m_max, self.n_fc, self.n_h, self.N)
 
-    def _enc_spec(self, x, fp, out):
+    def _enc_spec(self, x, fp, out, env=None):
         p = self.params
-        return ops.step_enc_spec(x, fp, p['fcs_w'], p['fcs_b'], p['fcp_w'], p['fcp_b'], self.nbrs, out=out)
+        return ops.step_enc_spec(x, fp, p['fcs_w'], p['fcs_b'], p['fcp_w'], p['fcp_b'], self.nbrs, out=out, env=env)
 
 
 class NCMultiAgentPolicy(BatchedPolicy):

@@ -28,6 +28,7 @@ constexpr int NLANE = 6;
 constexpr int NSLOT = 5;                // own + 4 neighbour slots
 constexpr int OBSW = NSLOT * NL;        // 60
 constexpr float DT = 5.0f, YELLOW = 2.0f, SAT = 0.5f, Q_MAX = 26.0f, DET_CAP = 7.0f, YELLOW_EFF = 1.0f;
+constexpr float WAIT_EPS = 1e-3f;       // vehicles: below this a lane holds no standing queue / discharged nothing (oracle/grid_ref.py step 6)
 
 // All static tables in ONE __constant__ object: one base address in scalar registers instead of twelve (the twelve separate
 // arrays cost 24 SGPRs of addresses and the kernel spilled 23).
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void grid_step_kernel(
             for (int l = 0; l < NLANE; ++l) {
                 if (WAIT) {
                     // the lane's head vehicle keeps waiting while a standing queue discharges nothing (oracle/grid_ref.py step 6)
-                    const bool moved = served[l] > 0.0f || q[l] <= 0.0f;
+                    const bool moved = served[l] > WAIT_EPS || q[l] <= WAIT_EPS;
                     hw[l] = moved ? 0.0f : sw[n * NLANE + l] + DT;
                 }
                 q[l] = q[l] - served[l] + tr[l];

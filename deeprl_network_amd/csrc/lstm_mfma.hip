@@ -11,6 +11,7 @@
 // lstm_step_x_kernel (the x-side product s @ Wx is computed here as well: K = KX + 64, nothing of the pre-activation
 // ever exists in HBM).  fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md).
 #include "common.h"
+#include "cacc_tile.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -176,8 +177,8 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
 // products, the exps, the divisions and the float64 CDF of the head (~570 -> ~300 vector instructions per wave, which only 16 of
 // the 64 lanes need but every wave pays for in full).
 template <int MA>
-__device__ __forceinline__ void head_policy_lds_n(const FusedArgs& a, const int n, const int N, const int64_t row0,
-                                                  const int lane, const float* a_tile, const float* wl, const float* bl) {
+__device__ __forceinline__ int head_policy_lds_n(const FusedArgs& a, const int n, const int N, const int64_t row0,
+                                                 const int lane, const float* a_tile, const float* wl, const float* bl) {
     static_assert(MAXA == 8 && (MA == 4 || MA == 8), "one or two float4 per k");
     const nmarl_head_t& hd = a.hd;
     const int A = hd.A;
@@ -206,7 +207,7 @@ __device__ __forceinline__ void head_policy_lds_n(const FusedArgs& a, const int 
         acc[o] += __shfl_xor(acc[o], 16, 64);
         acc[o] += __shfl_xor(acc[o], 32, 64);
     }
-    if (q != 0 || row >= a.E) return;
+    if (q != 0 || row >= a.E) return -1;
     float p[MA];
     float m = -INFINITY;
 #pragma unroll
@@ -257,12 +258,14 @@ __device__ __forceinline__ void head_policy_lds_n(const FusedArgs& a, const int 
         act = act > A - 1 ? A - 1 : act;
     }
     hd.act_out[row * N + n] = (uint8_t)act;
+    return act;
 }
 
-__device__ __forceinline__ void head_policy_lds(const FusedArgs& a, const int n, const int N, const int64_t row0,
-                                                const int lane, const float* a_tile, const float* wl, const float* bl) {
-    if (a.hd.A <= 4) head_policy_lds_n<4>(a, n, N, row0, lane, a_tile, wl, bl);       // (uniform)
-    else head_policy_lds_n<8>(a, n, N, row0, lane, a_tile, wl, bl);
+// -> the action this lane drew for its row (lanes 0..15 of the wave, rows inside the batch), -1 elsewhere
+__device__ __forceinline__ int head_policy_lds(const FusedArgs& a, const int n, const int N, const int64_t row0,
+                                               const int lane, const float* a_tile, const float* wl, const float* bl) {
+    if (a.hd.A <= 4) return head_policy_lds_n<4>(a, n, N, row0, lane, a_tile, wl, bl);       // (uniform)
+    return head_policy_lds_n<8>(a, n, N, row0, lane, a_tile, wl, bl);
 }
 
 template <bool HAS_Z2, int HEAD>
@@ -532,6 +535,14 @@ struct XArgs {
     int64_t e_wob_sn, e_bob_sn, e_wfp_sn, e_bfp_sn;
     float* e_out; int64_t e_out_sn, e_out_row;    // where the encoded LSTM input [N][E][128] is kept for the update (may be NULL)
     int e_nbr[64];                                // neighbour table [N][2] (-1 padded) BY VALUE: no dependent table load
+    // ENC 1 + ev_on: the CACC env step of THIS lock-step behind the action draw (see the ENV block at the end of the kernel)
+    int ev_on, ev_auto_reset;
+    nmarl_cacc_params_t ev_p;
+    float *ev_h, *ev_v, *ev_u; int32_t* ev_t; uint8_t* ev_coll; float* ev_v0;
+    float* ev_obs; float* ev_rew; uint8_t* ev_done; float* ev_grew;
+    uint64_t ev_seed; int64_t ev_base; int32_t* ev_episode;
+    uint8_t* ev_xact;             // [N][E] the agents' draws once more, agent-major (an agent's bytes share no line with another's), written through
+    unsigned* ev_cnt;             // [row blocks][8 waves] arrival counters, zero between launches
 };
 
 // raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
@@ -1221,6 +1232,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d[threadIdx.x] = nfa; d[threadIdx.x + 512] = nfb;
     }
     const unsigned epoch = HEAD == 4 ? (unsigned)__builtin_amdgcn_readfirstlane((int)epoch_raw) + 1u : 0u;
+    unsigned ev_old = 0;                         // ENC + env tail: how many agents' waves had reported these 16 replicas before this one
 
     // ---- lane-local cell epilogue.  A lane holds units 4 c .. 4 c + 3 of rows 4 grp + r (column permutation of the image):
     // every output leaves as 16-byte stores of contiguous row pieces, 256 B per row and instruction.  (4-byte stores in the
@@ -1271,8 +1283,15 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int act_l = -1;
         if (HEAD == 2) head_epilogue<2>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
-        else head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
+        else act_l = head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
+        if (ENC && xa.ev_on) {
+            // ---- ENV (1/3): this wave's 16 draws once more, agent-major and written THROUGH (behind the cell epilogue's store
+            // burst: nobody waits for it here)
+            if (act_l >= 0)
+                __hip_atomic_store(xa.ev_xact + (int64_t)n * a.E + row0 + lane, (uint8_t)act_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     NMARL_STAMP(22)
     if (nxt_here) {
@@ -1335,6 +1354,13 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             NMARL_CHUNK(buf, r0, r1)
         }
         NMARL_STAMP(23)
+        if (ENC && xa.ev_on) {
+            // ---- ENV (2/3): the draws are out (the stores above have drained behind the re-step's products): one arrival count
+            // per (row block, wave strip); its return value is looked at after the re-step's cell and critic, which hide the trip
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                ev_old = __hip_atomic_fetch_add((gu32*)xa.ev_cnt + (blk_u * WAVES2 + wave), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __builtin_amdgcn_wave_barrier();                 // every lane has read its A operands: the tile may be overwritten
         if (HEAD == 4) {
             // ---- the message columns of the re-step: from the neighbours' NEW h, published by the same wave of their blocks
@@ -1401,6 +1427,42 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         NMARL_STAMP(24)
         head_epilogue<3>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
         NMARL_STAMP(25)
+        if (ENC && xa.ev_on) {
+            // ---- ENV (3/3): envs/cacc_env.py:191-242 for the wave's 16 replicas, by the LAST of the N agents' waves that own
+            // them (the same row strip of the N blocks of this row block): it alone has seen every agent's count, i.e. every
+            // draw is out.  No wave ever waits: the launch needs no co-residency and has no failure mode.  The draws are read
+            // from the agent-major copy (lines this compute unit has not touched in this launch: an L1-bypassing load cannot
+            // meet a stale copy, see "hand-off between blocks" in DESIGN.md); state, reward and the compact observation of
+            // lock-step t + 1 are plain stores -- their reader is the next launch.  Same device function as the env kernels.
+            const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_old);
+            if (seen == (unsigned)(xa.N - 1)) {
+                if (lane == 0)
+                    __hip_atomic_store((gu32*)xa.ev_cnt + (blk_u * WAVES2 + wave), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int64_t n_lanes = a.E * nmarl_cacc::N;
+                __builtin_amdgcn_wave_barrier();                 // (the tile below is the staging area of the observation)
+                // both tiles' inputs first (one exposed load latency), then the two steps
+                float h0[2], v0[2], v0i[2];
+                int act[2], t0[2], coll0[2];
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile) {
+                    const int64_t gid = ((row0 >> 3) + tile) * NMARL_WAVE + lane;
+                    const int64_t g = gid < n_lanes ? gid : n_lanes - 1;
+                    const int64_t e = g >> 3;
+                    act[tile] = (int)__hip_atomic_load(xa.ev_xact + (g & 7) * a.E + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h0[tile] = xa.ev_h[g]; v0[tile] = xa.ev_v[g]; v0i[tile] = xa.ev_v0[e];
+                    t0[tile] = xa.ev_t[e]; coll0[tile] = xa.ev_coll[e];
+                }
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile) {
+                    const int64_t w_t = (row0 >> 3) + tile;      // wave tile = 8 replicas x 8 vehicles
+                    if (w_t * NMARL_WAVE < n_lanes)
+                        nmarl_cacc::cacc_tile<0, true>(xa.ev_p, n_lanes, w_t, lane, h0[tile], v0[tile], act[tile], t0[tile], coll0[tile] != 0,
+                                                       v0i[tile], xa.ev_h, xa.ev_v, xa.ev_u, xa.ev_t, xa.ev_coll, xa.ev_v0, xa.ev_obs, xa.ev_rew,
+                                                       xa.ev_done, xa.ev_grew, xa.ev_auto_reset, xa.ev_seed, xa.ev_base, xa.ev_episode, a_tile);
+                }
+            }
+            NMARL_STAMP(39)
+        }
         if (HEAD == 4) {
             // the last BLOCK of the launch to get here starts the next generation: no flag of this one is read any more
             // (one counter update per block: same-address atomics serialise, 2048 of them cost the last waves ~8 us)
@@ -1723,6 +1785,21 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.e_wob_sn = enc->w_ob_sn; xa.e_bob_sn = enc->b_ob_sn; xa.e_wfp_sn = enc->w_fp_sn; xa.e_bfp_sn = enc->b_fp_sn;
         xa.e_out = enc->out; xa.e_out_sn = enc->out_sn; xa.e_out_row = enc->out_row;
         for (int i = 0; i < 64; ++i) xa.e_nbr[i] = i < 2 * N ? enc->nbr[i] : -1;
+        if (enc->env) {
+            // the CACC env step of this lock-step behind the action draw (ENV block of the kernel)
+            const nmarl_cacc_params_t* p = enc->env;
+            if (N != NMARL_CACC_N || !p->compact_obs || p->T <= 0 || p->batch_size <= 0 || (p->scenario != 0 && p->scenario != 1) || p->dt <= 0.f ||
+                p->h_g <= p->h_s || p->u_max == 0.f || p->v_star == 0.f || p->h_star == 0.f || !enc->h || !enc->v || !enc->u || !enc->t ||
+                !enc->collided || !enc->v0_init || !enc->obs_out || !enc->reward || !enc->done || !enc->global_reward || !enc->xact ||
+                !enc->cnt || ((uintptr_t)enc->cnt % 4) || ((uintptr_t)enc->obs_out % 16) || (enc->auto_reset && !enc->episode) ||
+                head->act_out == nullptr)
+                return NMARL_EINVAL;
+            xa.ev_on = 1; xa.ev_auto_reset = enc->auto_reset ? 1 : 0; xa.ev_p = *p;
+            xa.ev_h = enc->h; xa.ev_v = enc->v; xa.ev_u = enc->u; xa.ev_t = enc->t; xa.ev_coll = enc->collided; xa.ev_v0 = enc->v0_init;
+            xa.ev_obs = enc->obs_out; xa.ev_rew = enc->reward; xa.ev_done = enc->done; xa.ev_grew = enc->global_reward;
+            xa.ev_seed = enc->seed; xa.ev_base = enc->env_id_base; xa.ev_episode = enc->episode;
+            xa.ev_xact = enc->xact; xa.ev_cnt = enc->cnt;
+        }
         static NmarlPerDeviceOnce enc_once;
         const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4 + 6 * 64 * 4 + 2 * H) * sizeof(float);
         if (const unsigned long long bit = enc_once.pending(); bit != ~0ull) {
@@ -1808,6 +1885,8 @@ extern "C" int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t Hh, int32_t K
     return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
                          c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream);
 }
+
+extern "C" int nmarl_lstm_step_env_words(int64_t E) { return E <= 0 ? 0 : (int)((E + ROWS_B - 1) / ROWS_B) * WAVES2; }
 
 extern "C" int nmarl_lstm_step_x_enc(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* h_in, int64_t h_sn, const float* img,
                                      int64_t img_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,

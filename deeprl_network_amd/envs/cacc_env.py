@@ -140,6 +140,17 @@ class CACCBatchEnv:
 
     supports_fused_encode = True
 
+    def inkernel_step(self, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
+        """Arguments of `step` for the policy's lock-step launch to run the env step itself behind its action draw
+        (csrc/lstm_mfma.hip ENV: ops.step_enc_spec(env=...)): same state tensors, same outputs, the actions are the launch's own."""
+        if not self.compact_obs:
+            raise _lib.NmarlError('the in-launch env step writes the compact observation')
+        return dict(params=self.params, h=self.h, v=self.v, u=self.u, t=self.t, collided=self.collided, v0_init=self.v0_init,
+                    obs_out=self.obs if obs_out is None else obs_out, reward=self.reward if reward_out is None else reward_out,
+                    done=self.done if done_out is None else done_out,
+                    global_reward=self.global_reward if greward_out is None else greward_out, auto_reset=bool(auto_reset),
+                    seed=self.seed, env_id_base=self.env_id_base, episode=self.episode)
+
     def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None, encode=None):
         """action [E,8] uint8 -> (obs [E,8,15], reward [E]|[E,8], done [E] u8, global_reward [E]).
         By default the results land in this env's persistent buffers (overwritten every step); the

@@ -326,11 +326,29 @@ def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
         os.environ.get('NMARL_INKERNEL_ENCODE', '1') != '0'
 
 
-def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None):
+def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None):
     """Description of a lock-step's input encoders for `lstm_step_policy_value(xs=(spec, wx, image))`: ob [E,N,5] the env's
     compact observation, fp [N,E,4] the previous-step policies, the four parameter tensors as they are, nbrs = the HOST
-    neighbour lists (ascending), out [N,E,128] (a view: slot t of the saved LSTM inputs) or None."""
-    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out)
+    neighbour lists (ascending), out [N,E,128] (a view: slot t of the saved LSTM inputs) or None.
+    env (optional): the CACC env step of this lock-step inside the launch as well -- CACCBatchEnv.inkernel_step(...)."""
+    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out, env=env)
+
+
+def step_env_supported():
+    return os.environ.get('NMARL_INKERNEL_ENV', '1') != '0'
+
+
+_env_scratch = {}
+
+
+def step_env_scratch(N, E, device):
+    """(xact [N,E] u8, cnt u32 words) of the in-launch env step: per (device, N, E), zeroed once, never dropped (captured
+    graphs hold the pointers)."""
+    key = (torch.device(device), N, E)
+    if key not in _env_scratch:
+        _env_scratch[key] = (torch.zeros(N, E, dtype=torch.uint8, device=device),
+                             torch.zeros(lib.nmarl_lstm_step_env_words(E), dtype=torch.int32, device=device))
+    return _env_scratch[key]
 
 
 def _step_enc(d, N, E):
@@ -360,6 +378,17 @@ def _step_enc(d, N, E):
     for i, lst in enumerate(d['nbrs']):
         for k, j in enumerate(lst[:2]):
             e.nbr[2 * i + k] = int(j)
+    ev = d.get('env')
+    if ev is not None:
+        e.env = C.pointer(ev['params'])
+        for k in ('h', 'v', 'u', 'v0_init', 'obs_out', 'reward', 'global_reward'):
+            setattr(e, k, ptr(ev[k], F32))
+        e.t, e.episode = ptr(ev['t'], torch.int32), ptr(ev['episode'], torch.int32)
+        e.collided, e.done = ptr(ev['collided'], torch.uint8), ptr(ev['done'], torch.uint8)
+        e.auto_reset, e.seed, e.env_id_base = (1 if ev['auto_reset'] else 0), int(ev['seed']), int(ev['env_id_base'])
+        xact, cnt = step_env_scratch(N, E, ob.device)
+        e.xact, e.cnt = ptr(xact, torch.uint8), ptr(cnt, torch.int32)
+        e._keep = ev['params']            # (the struct the pointer refers to stays alive with this one)
     return e
 
 

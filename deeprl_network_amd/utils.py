@@ -300,6 +300,8 @@ class BatchedTrainer:
         # ... unless the lock-step kernel runs the encoders itself (csrc/lstm_mfma.hip ENC: IA2C-FP), then the env step stays alone
         self.enc_in_kernel = self.saved_acts and self.compact_obs and env.device.type == 'cuda' and \
             model.policy.enc_in_kernel(env.E, True)
+        # ... and the env step as well, behind the action draw of the same launch: ONE launch per lock-step (ENV block of the kernel)
+        self.env_in_kernel = self.enc_in_kernel and hasattr(env, 'inkernel_step') and env.n_agent == 8 and ops.step_env_supported()
         self.fused_encode = bool(fused_encode) and self.saved_acts and self.compact_obs and not self.enc_in_kernel and \
             getattr(env, 'supports_fused_encode', False) and env.device.type == 'cuda' and \
             model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1)) is not None
@@ -370,6 +372,13 @@ class BatchedTrainer:
         # Philox step = batch base (device counter, advanced once per batch) + slot offset baked into the graph
         fused = self.fused_encode
         for t in range(T):
+            outs = dict(obs_out=model.buf_x[t + 1], reward_out=self.buf_rraw[t], done_out=model.buf_done_post[t], greward_out=self.buf_g[t])
+            if self.env_in_kernel:            # the whole lock-step -- encoders, policy step, draw, value re-step, env step -- in ONE launch
+                model.act(self.done_pre if t == 0 else self.zero_done, mode=ops.SAMPLE_PHILOX, seed=env.seed,
+                          env_id_base=env.env_id_base, step=t, step_dev=self.step_dev, done_is_zero=(t > 0),
+                          env_step=env.inkernel_step(auto_reset=(t == T - 1), **outs))
+                model.t = t + 1
+                continue
             action = model.act(self.done_pre if t == 0 else self.zero_done, mode=ops.SAMPLE_PHILOX, seed=env.seed,
                                env_id_base=env.env_id_base, step=t, step_dev=self.step_dev, done_is_zero=(t > 0),
                                pre_encoded=fused and t > 0)

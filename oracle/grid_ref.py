@@ -42,7 +42,8 @@ Synthetic dynamics (store-and-forward fluid queues, one control step = 5 s):
   6. objectives `wait` / `hybrid` (atsc_env.py:383-418: the waiting time of the FRONT vehicle of every detector,
      `getWaitingTime` of the car with the largest lane position): a fluid queue has no vehicles, so the spec keeps one more
      state per lane, head_wait (s): the lane's front vehicle has been standing since the lane last discharged,
-         head_wait' = 0 if the lane served any flow this step or held no queue at its start, else head_wait + 5 s;
+         head_wait' = 0 if the lane served more than WAIT_EPS = 1e-3 veh this step or held at most WAIT_EPS at its start,
+         else head_wait + 5 s;
      wait_i = sum_k head_wait'_lane(k) over the 12 links (duplicated lanes like the queue count);
      reward_i = - wait_i (`wait`)  or  - queue_i - coef_wait * wait_i (`hybrid`).  Reset clears it.  (Outside every shipped
      config: all of them set objective = queue.)
@@ -56,6 +57,7 @@ SAT = 0.5            # veh/s per lane
 Q_MAX = 26.0         # 200 m block / 7.5 m
 DET_CAP = 7.0        # 50 m detector / 7.5 m
 YELLOW_EFF = 1.0
+WAIT_EPS = 1e-3      # veh: a standing queue / a discharge below this does not count (step 6)
 LINK_LANE = np.array([0, 0, 0, 1, 1, 2, 3, 3, 3, 4, 4, 5])
 LINK_SHARE = np.array([.2, .6, .2, .15 / .85, .7 / .85, 1.0] * 2)
 LANE_APPROACH = np.array([0, 1, 1, 2, 3, 3])
@@ -203,7 +205,7 @@ class GridBatchRef:
             rate = np.array([demand_rate(grp, s, self.p.peak1, self.p.peak2) for s in sec], dtype=f)
             inflow[:, node, ap] += rate / f(3600) * f(DT) * self.xi[:, grp]
         split = APPROACH_SPLIT.astype(f)
-        moved = (served > 0) | (self.q <= 0)                                        # step 6: the front vehicle left / no queue stood
+        moved = (served > f(WAIT_EPS)) | (self.q <= f(WAIT_EPS))                                        # step 6: the front vehicle left / no queue stood
         self.hw = np.where(moved, f(0), self.hw + f(DT)).astype(f)
         self.q = (self.q - served + self.tr).astype(f)
         self.tr = (inflow[:, :, LANE_APPROACH] * split).astype(f)

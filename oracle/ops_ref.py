@@ -338,7 +338,8 @@ def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
     return n_feat == 5 and n_a == 4 and m_max == 2 and n_fc == 64 and n_h == 64 and N <= 32
 
 
-def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None):
+def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None):
+    assert env is None, 'the in-launch env step exists on the device only (tests compare it with the env kernel there)'
     return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out)
 
 

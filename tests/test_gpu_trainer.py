@@ -190,6 +190,44 @@ def test_compact_observation_equals_gathered_slab(agent, monkeypatch):
     torch.testing.assert_close(out[0][0], out[1][0], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('E', [4096, 1000, 77])
+@pytest.mark.parametrize('scenario', ['catchup', 'slowdown'])
+def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, scenario, monkeypatch):
+    """ONE launch per lock-step (IA2C-FP on CACC): the lock-step kernel stepping the env itself behind its action draw
+    (lstm_step_x_kernel<3,0,1> with the ENV block: the last of the 8 agents' waves that own a strip of 16 replicas steps them,
+    no wave waits) against the same kernel followed by the env kernel (nmarl_cacc_step) -- the same device function on the same
+    actions, so EVERYTHING is bit-identical after 3 batches through the hipGraph: actions, rewards, done flags, observations,
+    env state incl. the fused auto-reset at the episode end (T = 3 batches here), values, weights.  E = 1000 / 77: ragged last
+    row block (strips with fewer than 16 replicas, waves with none)."""
+    from deeprl_network_amd.agents import models
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    out = []
+    for inside in ('1', '0'):
+        monkeypatch.setenv('NMARL_INKERNEL_ENV', inside)
+        cp = cacc_config(agent='ia2c_fp', scenario=scenario, n_step=20, reward_norm=800.0)
+        cp['ENV_CONFIG']['episode_length_sec'] = '6'                 # T = 60 lock-steps = 3 batches: the third one ends the episodes
+        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+        np.random.seed(12)
+        model = models.IA2C_FP(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
+                               cp['MODEL_CONFIG'], seed=12, num_envs=E)
+        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
+        assert tr.enc_in_kernel and tr.env_in_kernel == (inside == '1') and not tr.fused_encode
+        rec = []
+        for _ in range(3):
+            tr.run_batch()
+            rec += [model.buf_act.clone(), tr.buf_rraw.clone(), tr.buf_g.clone(), model.buf_done_post.clone(), model.buf_x.clone()]
+        torch.cuda.synchronize()
+        assert int(env.episode.min()) == 2 and int(env.t.max()) == 0          # every replica finished an episode and was re-initialised
+        out.append(rec + [env.h.clone(), env.v.clone(), env.u.clone(), env.t.clone(), env.collided.clone(), env.v0_init.clone(),
+                          env.episode.clone(), model.buf_v.clone(), model.policy.params.flat.clone(), tr.ep_sum.clone()])
+        st = tr.stats()
+        assert st['episodes'] == E
+        del env, model, tr
+    for k, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), 'item %d differs between the in-launch env step and the env kernel' % k
+
+
 def test_inkernel_encoders_equal_the_encoder_launch(monkeypatch):
     """IA2C-FP: the lock-step kernel running both input encoders itself (lstm_step_x_kernel<3,0,1>: no encoder launch, the env
     step alone behind it) against the env step + encoder launch (nmarl_cacc_step_encode) in front of the plain lock-step

@@ -343,6 +343,55 @@ def measure_bptt_coupled(model, reps=3):
     return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * row, name
 
 
+def measure_update_graph(trainer, skip=None, reps=5):
+    """Duration of the captured update (the hipGraphs BatchedTrainer replays: rewards, return scan, loss, backward, clip + RMSProp
+    [, epilogue]) on the trainer's own buffers: HIP events on the launch stream around `reps` replays of a FRESH capture.
+    skip: names of C-ABI entry points replaced by no-ops during the capture -- the same graph without those launches; the
+    difference is what they cost INSIDE the update (clock, cache and neighbour-kernel conditions of the real batch), the method
+    `measure_lstm_step_in_rollout` uses for the rollout.  The skipped kernels' outputs stay whatever the buffers hold: the other
+    launches' durations do not depend on the data.  Call after the timed region only (weights and statistics move)."""
+    from deeprl_network_amd import _lib
+    if trainer._upd is None:
+        return None
+    saved = {n: getattr(_lib.lib, n) for n in (skip or ())}
+    keep = trainer._upd
+    try:
+        for n in saved:
+            setattr(_lib.lib, n, lambda *a, **k: 0)
+        trainer._upd = None
+        trainer._capture_update()
+        g = trainer._upd
+    finally:
+        for n, f in saved.items():
+            setattr(_lib.lib, n, f)
+        trainer._upd = keep
+    def once():
+        g['grads'].replay()
+        if g['apply'] is not None:
+            g['apply'].replay()
+    once()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        once()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def update_breakdown(trainer, bptt_entry):
+    """{'update_graph_us', 'update_graph_us_without_bptt', 'bptt_us_in_update'} by the difference of two captured updates."""
+    full = measure_update_graph(trainer)
+    if full is None:
+        return None
+    without = measure_update_graph(trainer, skip=(bptt_entry,))
+    return {'update_graph_us': full, 'update_graph_us_without_bptt': without, 'bptt_us_in_update': full - without,
+            'bptt_entry': bptt_entry,
+            'how': 'the captured update (what BatchedTrainer replays per batch) re-captured with and without the %s launch, 5 replays each '
+                   'between two HIP events on the launch stream' % bptt_entry}
+
+
 def _lib_capacity(which, K):
     from deeprl_network_amd import _lib
     return _lib.lib.nmarl_handoff_capacity(which, int(K))
@@ -409,6 +458,20 @@ def run_other_config(args, cfg_name, device):
                                     'bytes_per_launch': bytes_b, 'launches_per_batch': 1}
     except Exception as ex:
         res['roofline_bptt'] = {'error': repr(ex)}
+    try:
+        ub = update_breakdown(trainer, 'nmarl_lstm_bptt_coupled')
+        if ub is not None:
+            res['update'] = ub
+            if isinstance(res.get('roofline_bptt'), dict) and 'bytes_per_launch' in res['roofline_bptt']:
+                rb = res['roofline_bptt']
+                rb['us_per_launch_back_to_back'] = rb['us_per_launch']          # 3 hot repetitions of the whole op (memset, kernel, 2 sums)
+                rb['us_per_launch'] = ub['bptt_us_in_update']                   # the launch as it runs inside the update
+                rb['achieved'] = rb['bytes_per_launch'] / rb['us_per_launch'] / 1e3
+                rb['frac'] = rb['achieved'] / HBM_PEAK_GBPS
+                rb['how'] = 'us_per_launch / achieved / frac: in-update duration by difference of two captured updates (`update`); ' \
+                            'us_per_launch_back_to_back: HIP events around 3 back-to-back calls of the whole op on random data'
+    except Exception as ex:
+        res['update'] = {'error': repr(ex)}
     del trainer, model, env
     gc.collect()
     torch.cuda.empty_cache()
@@ -772,6 +835,20 @@ def main():
                            'replica, step) = gates 1024 + c 256 + dL/dh 256 read + dz 1024 written = 2560 B'}
             except Exception as ex:
                 out['roofline_bptt'] = {'error': repr(ex)}
+            try:
+                ub = update_breakdown(trainer, 'nmarl_lstm_bptt_seq')
+                if ub is not None:
+                    out['update'] = ub
+                    rb = out['roofline_bptt']
+                    if 'bytes_per_launch' in rb:
+                        rb['us_per_launch_back_to_back'] = rb['us_per_launch']
+                        rb['us_per_launch'] = ub['bptt_us_in_update']
+                        rb['achieved'] = rb['bytes_per_launch'] / rb['us_per_launch'] / 1e3
+                        rb['frac'] = rb['achieved'] / HBM_PEAK_GBPS
+                        rb['how'] += '; us_per_launch / achieved / frac: the launch as it runs INSIDE the update, by difference of two ' \
+                                     'captured updates (`update`); us_per_launch_back_to_back: the 5 isolated launches'
+            except Exception as ex:
+                out['update'] = {'error': repr(ex)}
         # ---- the env-step kernel (north_star's HBM roofline), measured live on this rank's stream
         tape = model.buf_act.clone()
         us = measure_step_kernel(env, tape)

@@ -73,7 +73,7 @@ class StepEnc(C.Structure):
                 ('env', C.POINTER(CaccParams)), ('h', C.c_void_p), ('v', C.c_void_p), ('u', C.c_void_p), ('t', C.c_void_p),
                 ('collided', C.c_void_p), ('v0_init', C.c_void_p), ('obs_out', C.c_void_p), ('reward', C.c_void_p),
                 ('done', C.c_void_p), ('global_reward', C.c_void_p), ('auto_reset', C.c_int32), ('pad2_', C.c_int32),
-                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('episode', C.c_void_p), ('xact', C.c_void_p), ('cnt', C.c_void_p)]
+                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('episode', C.c_void_p), ('cnt', C.c_void_p)]
 
 
 class NetParams(C.Structure):

@@ -68,17 +68,8 @@ __device__ __noinline__ double cos_0_pi(double t) {
     return -(r - r * r2 * q);                             // -sin r
 }
 
-// _get_veh_state (cacc_env.py:54-65) for this lane's vehicle, then the
-// neighbour gather and the LDS-staged coalesced store of the wave's slab.
-// COMPACT: only the vehicle's own 5 features are written ([E,8,5]: SURVEY.md 8d's 41 N + 19 B layout); the policy's
-// encoder gathers the neighbours' features itself (nmarl_fc_fwd_multi with a neighbour table whose slot 0 is the
-// agent).  Otherwise the 'ia2c' pre-gathered observation [E,8,15] of cacc_env.py:70-73.
-template <int NT, bool COMPACT>
-__device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, float v, float u,
-                                         float v_lead, int a, bool valid, int lane, float* lds_wave,
-                                         float* __restrict__ obs_wave, int n_valid_lanes) {
-    constexpr int W = COMPACT ? NF : NOBS;
-    float x[NF];
+// _get_veh_state (cacc_env.py:54-65): the five features of this lane's vehicle.
+__device__ __forceinline__ void obs_features(const nmarl_cacc_params_t& p, float h, float v, float u, float v_lead, float (&x)[NF]) {
     x[0] = (v - p.v_star) / p.v_star;
     x[1] = clampf((v_lead - v) / 5.0f, -2.0f, 2.0f);
     // The platoon's equilibrium (h = h*, v = v*) makes vh(h) - v vanish, and the reference's float64
@@ -99,6 +90,20 @@ __device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, 
     }
     x[3] = (h + (v_lead - v) * p.dt - p.h_star) / p.h_star;
     x[4] = u / p.u_max;
+}
+
+// _get_veh_state (cacc_env.py:54-65) for this lane's vehicle (obs_features), then the
+// neighbour gather and the LDS-staged coalesced store of the wave's slab.
+// COMPACT: only the vehicle's own 5 features are written ([E,8,5]: SURVEY.md 8d's 41 N + 19 B layout); the policy's
+// encoder gathers the neighbours' features itself (nmarl_fc_fwd_multi with a neighbour table whose slot 0 is the
+// agent).  Otherwise the 'ia2c' pre-gathered observation [E,8,15] of cacc_env.py:70-73.
+template <int NT, bool COMPACT>
+__device__ __forceinline__ void emit_obs(const nmarl_cacc_params_t& p, float h, float v, float u,
+                                         float v_lead, int a, bool valid, int lane, float* lds_wave,
+                                         float* __restrict__ obs_wave, int n_valid_lanes) {
+    constexpr int W = COMPACT ? NF : NOBS;
+    float x[NF];
+    obs_features(p, h, v, u, v_lead, x);
     float* row = lds_wave + lane * W;
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
@@ -156,23 +161,13 @@ __device__ __forceinline__ float reset_uniform(uint64_t seed, int64_t env_id, in
     return u01_from_bits(r.x);
 }
 
-// One tile = 64 lanes = 8 replicas of one wave: the step of cacc_env.py:191-242 from the tile's loaded inputs, all stores, and
-// the observation of the new state staged in `lds_wave` ([64 lanes][W]) and written out.
-template <int NT, bool COMPACT>
-__device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const int64_t n_lanes, const int64_t w, const int lane,
-                                          float h, float v, const int act, int t, bool collided, float v0i,
-                                          float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
-                                          int32_t* __restrict__ ts, uint8_t* __restrict__ coll, float* __restrict__ v0_init,
-                                          float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
-                                          float* __restrict__ greward, const int auto_reset, const uint64_t seed,
-                                          const int64_t env_id_base, int32_t* __restrict__ episode, float* lds_wave) {
-    constexpr int W = COMPACT ? NF : NOBS;
-    const int64_t gid = w * NMARL_WAVE + lane;      // = e*8 + a
-    const bool valid = gid < n_lanes;
-    const int64_t g = valid ? gid : n_lanes - 1;    // clamp: tail lanes mirror the last vehicle
-    const int64_t e = g >> 3;
-    const int a = (int)(g & 7);
-
+// CACCEnv.step (cacc_env.py:191-242) for this lane's vehicle a of the platoon held by its aligned 8-lane group: new (h, v, u), the
+// sticky collision flag, the per-vehicle reward r and the platoon sum rsum, t + 1, done.  Pure arithmetic + width-8 shuffles; the
+// previous acceleration is only needed by frozen (collided) platoons: `load_u_old` is called for those alone.
+template <class ULoad>
+__device__ __forceinline__ void cacc_advance(const nmarl_cacc_params_t& p, const int a, float& h, float& v, const int act, int& t,
+                                             bool& collided, const float v0i, float& u_new, float& r, float& rsum_out, bool& is_done_out,
+                                             ULoad load_u_old) {
     const bool frozen = collided;                                   // :193
 
     const float alpha = (act & 1) ? 0.5f : 0.0f;                    // a_map, :275
@@ -187,9 +182,8 @@ __device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const in
     const float v_lead_next = a == 0 ? lead_speed(p, v0i, t + 1) : up_vn;
     const float h_next = h + (0.5f * p.dt) * (v_lead + v_lead_next - v - v_next);  // :220
 
-    float u_new;
     if (!frozen) { h = h_next; v = v_next; u_new = u_c; }
-    else { u_new = us[g]; }
+    else { u_new = load_u_old(); }
 
     // collision test: min over the platoon (:42)
     float hmin = h;
@@ -198,7 +192,6 @@ __device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const in
     hmin = fminf(hmin, __shfl_xor(hmin, 4, N));
     if (!frozen && hmin < p.h_min) collided = true;
 
-    float r;
     if (collided) {
         r = -p.G;                                                   // :44, :194
     } else {
@@ -217,7 +210,30 @@ __device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const in
     rsum = rsum + __shfl_xor(rsum, 4, N);
 
     t += 1;
-    const bool is_done = (collided && (t % p.batch_size == 0)) || (t == p.T);   // :231-235
+    is_done_out = (collided && (t % p.batch_size == 0)) || (t == p.T);   // :231-235
+    rsum_out = rsum;
+}
+
+// One tile = 64 lanes = 8 replicas of one wave: the step of cacc_env.py:191-242 from the tile's loaded inputs, all stores, and
+// the observation of the new state staged in `lds_wave` ([64 lanes][W]) and written out.
+template <int NT, bool COMPACT>
+__device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const int64_t n_lanes, const int64_t w, const int lane,
+                                          float h, float v, const int act, int t, bool collided, float v0i,
+                                          float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
+                                          int32_t* __restrict__ ts, uint8_t* __restrict__ coll, float* __restrict__ v0_init,
+                                          float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+                                          float* __restrict__ greward, const int auto_reset, const uint64_t seed,
+                                          const int64_t env_id_base, int32_t* __restrict__ episode, float* lds_wave) {
+    constexpr int W = COMPACT ? NF : NOBS;
+    const int64_t gid = w * NMARL_WAVE + lane;      // = e*8 + a
+    const bool valid = gid < n_lanes;
+    const int64_t g = valid ? gid : n_lanes - 1;    // clamp: tail lanes mirror the last vehicle
+    const int64_t e = g >> 3;
+    const int a = (int)(g & 7);
+
+    float u_new, r, rsum;
+    bool is_done;
+    cacc_advance(p, a, h, v, act, t, collided, v0i, u_new, r, rsum, is_done, [&]() { return us[g]; });
 
     if (valid) {
         if (p.per_agent_reward) reward[g] = r;
@@ -258,6 +274,54 @@ __device__ __forceinline__ void cacc_tile(const nmarl_cacc_params_t& p, const in
     emit_obs<NT, COMPACT>(p, h, v, u_new, v_lead_obs, a, valid, lane, lds_wave,
                           obs + w * NMARL_WAVE * W, n_valid);
     __builtin_amdgcn_wave_barrier();
+}
+
+// The same step for ONE ARBITRARY replica per aligned 8-lane group (lane = 8 k + vehicle): e = the group's replica, valid = the group
+// holds one (idle groups pass any in-range e and store nothing).  Inputs arrive in registers, u_old is fetched only by frozen
+// platoons; every output is a per-lane store (compact observation [E][8][5] only).  Used by the lock-step kernel, whose waves
+// step the replicas for which they were the last agent to draw (csrc/lstm_mfma.hip, ENV) -- operation for operation cacc_tile.
+__device__ __forceinline__ void cacc_step_group(const nmarl_cacc_params_t& p, const int64_t e, const int a, const bool valid, float h, float v,
+                                                const int act, int t, bool collided, float v0i, float* __restrict__ hs,
+                                                float* __restrict__ vs, float* __restrict__ us, int32_t* __restrict__ ts,
+                                                uint8_t* __restrict__ coll, float* __restrict__ v0_init, float* __restrict__ obs,
+                                                float* __restrict__ reward, uint8_t* __restrict__ done, float* __restrict__ greward,
+                                                const int auto_reset, const uint64_t seed, const int64_t env_id_base,
+                                                int32_t* __restrict__ episode) {
+    const int64_t g = e * N + a;
+    float u_new, r, rsum;
+    bool is_done;
+    cacc_advance(p, a, h, v, act, t, collided, v0i, u_new, r, rsum, is_done, [&]() { return us[g]; });
+    if (valid) {
+        if (p.per_agent_reward) reward[g] = r;
+        if (a == 0) {
+            if (!p.per_agent_reward) reward[e] = rsum;
+            greward[e] = rsum;
+            done[e] = is_done ? 1 : 0;
+        }
+    }
+    if (auto_reset && is_done) {
+        const int ep = episode[e];
+        const float U = reset_uniform(seed, env_id_base + e, ep);
+        init_state(p, U, a, h, v, v0i);
+        u_new = 0.0f; t = 0; collided = false;
+        if (valid && a == 0) episode[e] = ep + 1;
+    }
+    if (valid) {
+        hs[g] = h; vs[g] = v; us[g] = u_new;
+        if (a == 0) {
+            ts[e] = t;
+            coll[e] = collided ? 1 : 0;
+            if (auto_reset && is_done) v0_init[e] = v0i;
+        }
+    }
+    const float up_v2 = __shfl_up(v, 1, N);
+    const float v_lead_obs = a == 0 ? lead_speed(p, v0i, t) : up_v2;   // :55, with the new t
+    float x[NF];
+    obs_features(p, h, v, u_new, v_lead_obs, x);
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) obs[g * NF + k] = x[k];
+    }
 }
 
 }  // namespace nmarl_cacc

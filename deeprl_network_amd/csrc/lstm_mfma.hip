@@ -541,8 +541,7 @@ struct XArgs {
     float *ev_h, *ev_v, *ev_u; int32_t* ev_t; uint8_t* ev_coll; float* ev_v0;
     float* ev_obs; float* ev_rew; uint8_t* ev_done; float* ev_grew;
     uint64_t ev_seed; int64_t ev_base; int32_t* ev_episode;
-    uint8_t* ev_xact;             // [N][E] the agents' draws once more, agent-major (an agent's bytes share no line with another's), written through
-    unsigned* ev_cnt;             // [row blocks][8 waves] arrival counters, zero between launches
+    unsigned* ev_cnt;             // [E] hand-off words: bits 0..15 the N agents' draws (2 bits each), bits 16.. the arrivals; zero between launches
 };
 
 // raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
@@ -1232,7 +1231,12 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d[threadIdx.x] = nfa; d[threadIdx.x + 512] = nfb;
     }
     const unsigned epoch = HEAD == 4 ? (unsigned)__builtin_amdgcn_readfirstlane((int)epoch_raw) + 1u : 0u;
-    unsigned ev_old = 0;                         // ENC + env tail: how many agents' waves had reported these 16 replicas before this one
+    // ENC + env step: what the hand-off word of this lane's replica held before this agent's add (lanes 0..15), the lane's own
+    // draw, and the strip's env state as requested right behind the draw
+    unsigned ev_old = 0;
+    int ev_act = -1;
+    float ev_h[2] = {0.f, 0.f}, ev_v[2] = {0.f, 0.f}, ev_v0[2] = {0.f, 0.f};
+    int ev_t[2] = {0, 0}, ev_c[2] = {0, 0};
 
     // ---- lane-local cell epilogue.  A lane holds units 4 c .. 4 c + 3 of rows 4 grp + r (column permutation of the image):
     // every output leaves as 16-byte stores of contiguous row pieces, 256 B per row and instruction.  (4-byte stores in the
@@ -1287,10 +1291,22 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         if (HEAD == 2) head_epilogue<2>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
         else act_l = head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
         if (ENC && xa.ev_on) {
-            // ---- ENV (1/3): this wave's 16 draws once more, agent-major and written THROUGH (behind the cell epilogue's store
-            // burst: nobody waits for it here)
+            // ---- ENV (1/2): every drawn action goes into its replica's hand-off word by ONE atomic add -- 2 bits of payload per agent
+            // + an arrival count above them -- whose return value is looked at after the value re-step (which hides the trip): the
+            // lane that finds N - 1 earlier arrivals holds all N actions of that replica.  The strip's env state (16 replicas x 8
+            // vehicles: two (replica, vehicle) pairs per lane) is requested here as well, by every wave.
             if (act_l >= 0)
-                __hip_atomic_store(xa.ev_xact + (int64_t)n * a.E + row0 + lane, (uint8_t)act_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ev_old = __hip_atomic_fetch_add((gu32*)xa.ev_cnt + (row0 + lane), ((unsigned)act_l << (2 * n)) | 0x10000u, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+            ev_act = act_l;
+            const int64_t n_lanes = a.E * nmarl_cacc::N;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int64_t gq = row0 * nmarl_cacc::N + q * NMARL_WAVE + lane;
+                const int64_t gc = gq < n_lanes ? gq : n_lanes - 1;
+                ev_h[q] = xa.ev_h[gc]; ev_v[q] = xa.ev_v[gc];
+                ev_t[q] = xa.ev_t[gc >> 3]; ev_c[q] = xa.ev_coll[gc >> 3]; ev_v0[q] = xa.ev_v0[gc >> 3];
+            }
         }
     }
     NMARL_STAMP(22)
@@ -1354,13 +1370,6 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             NMARL_CHUNK(buf, r0, r1)
         }
         NMARL_STAMP(23)
-        if (ENC && xa.ev_on) {
-            // ---- ENV (2/3): the draws are out (the stores above have drained behind the re-step's products): one arrival count
-            // per (row block, wave strip); its return value is looked at after the re-step's cell and critic, which hide the trip
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                ev_old = __hip_atomic_fetch_add((gu32*)xa.ev_cnt + (blk_u * WAVES2 + wave), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         __builtin_amdgcn_wave_barrier();                 // every lane has read its A operands: the tile may be overwritten
         if (HEAD == 4) {
             // ---- the message columns of the re-step: from the neighbours' NEW h, published by the same wave of their blocks
@@ -1428,38 +1437,42 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         head_epilogue<3>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
         NMARL_STAMP(25)
         if (ENC && xa.ev_on) {
-            // ---- ENV (3/3): envs/cacc_env.py:191-242 for the wave's 16 replicas, by the LAST of the N agents' waves that own
-            // them (the same row strip of the N blocks of this row block): it alone has seen every agent's count, i.e. every
-            // draw is out.  No wave ever waits: the launch needs no co-residency and has no failure mode.  The draws are read
-            // from the agent-major copy (lines this compute unit has not touched in this launch: an L1-bypassing load cannot
-            // meet a stale copy, see "hand-off between blocks" in DESIGN.md); state, reward and the compact observation of
-            // lock-step t + 1 are plain stores -- their reader is the next launch.  Same device function as the env kernels.
-            const unsigned seen = (unsigned)__builtin_amdgcn_readfirstlane((int)ev_old);
-            if (seen == (unsigned)(xa.N - 1)) {
-                if (lane == 0)
-                    __hip_atomic_store((gu32*)xa.ev_cnt + (blk_u * WAVES2 + wave), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int64_t n_lanes = a.E * nmarl_cacc::N;
-                __builtin_amdgcn_wave_barrier();                 // (the tile below is the staging area of the observation)
-                // both tiles' inputs first (one exposed load latency), then the two steps
-                float h0[2], v0[2], v0i[2];
-                int act[2], t0[2], coll0[2];
+            // ---- ENV (2/2): envs/cacc_env.py:191-242 for the replicas whose LAST arrival this wave was (on average 2 of its 16).
+            // The word's return value carries the other agents' draws, so nothing is read back and no wave ever waits for
+            // another: no co-residency requirement, no failure mode, no memory-ordering argument beyond the atomic itself.  The
+            // replicas are packed eight to a pass (one per aligned 8-lane group, lane = 8 k + vehicle), their state comes out of
+            // the prefetched registers by cross-lane reads; state, reward and the compact observation of lock-step t + 1 are plain
+            // stores (their reader is the next launch), the word is left zero for the next launch.  cacc_step_group = the env
+            // kernels' arithmetic, operation for operation.
+            const bool last_l = ev_act >= 0 && (ev_old >> 16) == (unsigned)(xa.N - 1);
+            const unsigned pay_l = (ev_old | ((unsigned)(ev_act < 0 ? 0 : ev_act) << (2 * n))) & 0xffffu;
+            if (last_l) xa.ev_cnt[row0 + lane] = 0u;
+            unsigned long long todo = __ballot(last_l);                  // (uniform: bits 0..15)
+            while (todo) {
+                int rsel = -1;                                           // the row of this lane's group: the (lane >> 3)-th set bit
 #pragma unroll
-                for (int tile = 0; tile < 2; ++tile) {
-                    const int64_t gid = ((row0 >> 3) + tile) * NMARL_WAVE + lane;
-                    const int64_t g = gid < n_lanes ? gid : n_lanes - 1;
-                    const int64_t e = g >> 3;
-                    act[tile] = (int)__hip_atomic_load(xa.ev_xact + (g & 7) * a.E + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    h0[tile] = xa.ev_h[g]; v0[tile] = xa.ev_v[g]; v0i[tile] = xa.ev_v0[e];
-                    t0[tile] = xa.ev_t[e]; coll0[tile] = xa.ev_coll[e];
+                for (int k = 0; k < 8; ++k) {
+                    const int rk = todo ? (int)__builtin_ctzll(todo) : -1;
+                    todo = todo ? (todo & (todo - 1)) : 0ull;
+                    rsel = (lane >> 3) == k ? rk : rsel;
                 }
-#pragma unroll
-                for (int tile = 0; tile < 2; ++tile) {
-                    const int64_t w_t = (row0 >> 3) + tile;      // wave tile = 8 replicas x 8 vehicles
-                    if (w_t * NMARL_WAVE < n_lanes)
-                        nmarl_cacc::cacc_tile<0, true>(xa.ev_p, n_lanes, w_t, lane, h0[tile], v0[tile], act[tile], t0[tile], coll0[tile] != 0,
-                                                       v0i[tile], xa.ev_h, xa.ev_v, xa.ev_u, xa.ev_t, xa.ev_coll, xa.ev_v0, xa.ev_obs, xa.ev_rew,
-                                                       xa.ev_done, xa.ev_grew, xa.ev_auto_reset, xa.ev_seed, xa.ev_base, xa.ev_episode, a_tile);
-                }
+                const bool valid = rsel >= 0;
+                const int rr = valid ? rsel : 0;
+                const int av = lane & 7;
+                const int q = rr * nmarl_cacc::N + av;                   // the pair's place among the strip's 128: lane q & 63, slot q >> 6
+                const unsigned pay = (unsigned)__shfl((int)pay_l, rr, NMARL_WAVE);
+                const float h0 = __shfl(ev_h[0], q & 63, NMARL_WAVE), h1 = __shfl(ev_h[1], q & 63, NMARL_WAVE);
+                const float v0 = __shfl(ev_v[0], q & 63, NMARL_WAVE), v1 = __shfl(ev_v[1], q & 63, NMARL_WAVE);
+                const float w0 = __shfl(ev_v0[0], q & 63, NMARL_WAVE), w1 = __shfl(ev_v0[1], q & 63, NMARL_WAVE);
+                const int t0 = __shfl(ev_t[0], q & 63, NMARL_WAVE), t1 = __shfl(ev_t[1], q & 63, NMARL_WAVE);
+                const int c0 = __shfl(ev_c[0], q & 63, NMARL_WAVE), c1 = __shfl(ev_c[1], q & 63, NMARL_WAVE);
+                const bool hi = q >= NMARL_WAVE;
+                int64_t e = row0 + rr;
+                e = e < a.E ? e : a.E - 1;
+                nmarl_cacc::cacc_step_group(xa.ev_p, e, av, valid, hi ? h1 : h0, hi ? v1 : v0, (int)((pay >> (2 * av)) & 3u), hi ? t1 : t0,
+                                            (hi ? c1 : c0) != 0, hi ? w1 : w0, xa.ev_h, xa.ev_v, xa.ev_u, xa.ev_t, xa.ev_coll, xa.ev_v0,
+                                            xa.ev_obs, xa.ev_rew, xa.ev_done, xa.ev_grew, xa.ev_auto_reset, xa.ev_seed, xa.ev_base,
+                                            xa.ev_episode);
             }
             NMARL_STAMP(39)
         }
@@ -1788,9 +1801,9 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         if (enc->env) {
             // the CACC env step of this lock-step behind the action draw (ENV block of the kernel)
             const nmarl_cacc_params_t* p = enc->env;
-            if (N != NMARL_CACC_N || !p->compact_obs || p->T <= 0 || p->batch_size <= 0 || (p->scenario != 0 && p->scenario != 1) || p->dt <= 0.f ||
+            if (N != NMARL_CACC_N || head->A > 4 || !p->compact_obs || p->T <= 0 || p->batch_size <= 0 || (p->scenario != 0 && p->scenario != 1) || p->dt <= 0.f ||
                 p->h_g <= p->h_s || p->u_max == 0.f || p->v_star == 0.f || p->h_star == 0.f || !enc->h || !enc->v || !enc->u || !enc->t ||
-                !enc->collided || !enc->v0_init || !enc->obs_out || !enc->reward || !enc->done || !enc->global_reward || !enc->xact ||
+                !enc->collided || !enc->v0_init || !enc->obs_out || !enc->reward || !enc->done || !enc->global_reward ||
                 !enc->cnt || ((uintptr_t)enc->cnt % 4) || ((uintptr_t)enc->obs_out % 16) || (enc->auto_reset && !enc->episode) ||
                 head->act_out == nullptr)
                 return NMARL_EINVAL;
@@ -1798,7 +1811,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             xa.ev_h = enc->h; xa.ev_v = enc->v; xa.ev_u = enc->u; xa.ev_t = enc->t; xa.ev_coll = enc->collided; xa.ev_v0 = enc->v0_init;
             xa.ev_obs = enc->obs_out; xa.ev_rew = enc->reward; xa.ev_done = enc->done; xa.ev_grew = enc->global_reward;
             xa.ev_seed = enc->seed; xa.ev_base = enc->env_id_base; xa.ev_episode = enc->episode;
-            xa.ev_xact = enc->xact; xa.ev_cnt = enc->cnt;
+            xa.ev_cnt = enc->cnt;
         }
         static NmarlPerDeviceOnce enc_once;
         const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4 + 6 * 64 * 4 + 2 * H) * sizeof(float);
@@ -1886,7 +1899,7 @@ extern "C" int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t Hh, int32_t K
                          c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream);
 }
 
-extern "C" int nmarl_lstm_step_env_words(int64_t E) { return E <= 0 ? 0 : (int)((E + ROWS_B - 1) / ROWS_B) * WAVES2; }
+extern "C" int nmarl_lstm_step_env_words(int64_t E) { return E <= 0 ? 0 : (int)((E + 63) / 64 * 64); }
 
 extern "C" int nmarl_lstm_step_x_enc(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* h_in, int64_t h_sn, const float* img,
                                      int64_t img_sn, const float* bias, int64_t bias_sn, const float* c_prev, int64_t c_prev_sn,

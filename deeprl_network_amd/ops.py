@@ -342,12 +342,11 @@ _env_scratch = {}
 
 
 def step_env_scratch(N, E, device):
-    """(xact [N,E] u8, cnt u32 words) of the in-launch env step: per (device, N, E), zeroed once, never dropped (captured
-    graphs hold the pointers)."""
+    """The hand-off words of the in-launch env step (one per replica): per (device, N, E), zeroed once, never dropped (captured
+    graphs hold the pointer; the kernel leaves them zero)."""
     key = (torch.device(device), N, E)
     if key not in _env_scratch:
-        _env_scratch[key] = (torch.zeros(N, E, dtype=torch.uint8, device=device),
-                             torch.zeros(lib.nmarl_lstm_step_env_words(E), dtype=torch.int32, device=device))
+        _env_scratch[key] = torch.zeros(lib.nmarl_lstm_step_env_words(E), dtype=torch.int32, device=device)
     return _env_scratch[key]
 
 
@@ -386,8 +385,7 @@ def _step_enc(d, N, E):
         e.t, e.episode = ptr(ev['t'], torch.int32), ptr(ev['episode'], torch.int32)
         e.collided, e.done = ptr(ev['collided'], torch.uint8), ptr(ev['done'], torch.uint8)
         e.auto_reset, e.seed, e.env_id_base = (1 if ev['auto_reset'] else 0), int(ev['seed']), int(ev['env_id_base'])
-        xact, cnt = step_env_scratch(N, E, ob.device)
-        e.xact, e.cnt = ptr(xact, torch.uint8), ptr(cnt, torch.int32)
+        e.cnt = ptr(step_env_scratch(N, E, ob.device), torch.int32)
         e._keep = ev['params']            # (the struct the pointer refers to stays alive with this one)
     return e
 

@@ -461,18 +461,18 @@ typedef struct nmarl_step_enc {
     float* out; int64_t out_sn, out_row;
     int32_t F, A, m_max, pad_;
     int32_t nbr[64];
-    /* The CACC env step of THIS lock-step inside the launch too (env != NULL; N = 8): CACCEnv.step (envs/cacc_env.py:191-242) for
-     * the actions the launch draws -- one launch per lock-step.  Every wave leaves its 16 draws once more in `xact` [N][E] u8
-     * (agent-major, written through) and counts itself into cnt[row block][wave]; the LAST of the N agents' waves owning a
-     * strip of 16 replicas steps them (the device function of nmarl_cacc_step, bit for bit) and writes state, reward / done /
-     * global reward of lock-step t and the compact observation of lock-step t + 1 -- arguments as for nmarl_cacc_step with
-     * p->compact_obs = 1.  No wave waits for another: no residency requirement, no failure mode.  cnt: nmarl_lstm_step_env_words(E)
-     * uint32 words, zeroed ONCE by the caller (the kernel leaves them zero); xact: N * E bytes of scratch. */
+    /* The CACC env step of THIS lock-step inside the launch too (env != NULL; N = 8, A <= 4): CACCEnv.step (envs/cacc_env.py:191-242)
+     * for the actions the launch draws -- one launch per lock-step.  Every drawn action is added into its replica's hand-off word
+     * cnt[e] by ONE atomic (2 bits of payload per agent + an arrival count above them); the lane whose add finds N - 1 earlier
+     * arrivals holds all N actions in the returned value and steps that replica (nmarl_cacc_step's arithmetic, bit for bit),
+     * writing state, reward / done / global reward of lock-step t and the compact observation of lock-step t + 1 -- arguments as
+     * for nmarl_cacc_step with p->compact_obs = 1.  Nothing is read back, no wave waits for another: no residency requirement, no
+     * failure mode.  cnt: nmarl_lstm_step_env_words(E) uint32 words, zeroed ONCE by the caller (the kernel leaves them zero). */
     const nmarl_cacc_params_t* env;
     float *h, *v, *u; int32_t* t; uint8_t* collided; float* v0_init;
     float* obs_out; float* reward; uint8_t* done; float* global_reward;
     int32_t auto_reset, pad2_; uint64_t seed; int64_t env_id_base; int32_t* episode;
-    uint8_t* xact; uint32_t* cnt;
+    uint32_t* cnt;
 } nmarl_step_enc_t;
 int nmarl_lstm_step_env_words(int64_t E);
 int nmarl_lstm_step_x_enc(int64_t E, int32_t N, int32_t H, int32_t KX, const float* h_in, int64_t h_sn, const float* img,

@@ -241,6 +241,7 @@ class IA2C:
     def reset_states(self, mask=None):
         """Policy._reset (policies.py:151-154, 334-336) for all replicas or those with mask != 0;
         also restores the uniform fingerprint of a fresh episode (cacc_env.py:184)."""
+        self.policy.invalidate_cached_msg()
         if mask is None:
             for s in (self.h_fw, self.c_fw, self.h_bw, self.c_bw):
                 s.zero_()

@@ -440,6 +440,9 @@ class BatchedPolicy:
         """The one-launch step of this net also runs the observation encoder (no separate encoder launch per lock-step)."""
         return False
 
+    def invalidate_cached_msg(self):
+        """(lstm_dial keeps message vectors of the last policy step: see DIALMultiAgentPolicy)"""
+
     def enc_in_kernel(self, E, compact):
         """Uncoupled nets: the policy + value launch of a lock-step also runs BOTH input encoders (csrc/lstm_mfma.hip ENC; the
         caller hands `step_policy_value` the env's compact observation and the fingerprints as `ob`)."""
@@ -1053,9 +1056,16 @@ class DIALMultiAgentPolicy(BatchedPolicy):
             self._mfc_img = ops.lstm_msg_wimage(self.params['mfc_w'], out=self._mfc_img)
         self._m_next = None   # the weights may have changed: vectors of the old sender layer are stale
 
+    def invalidate_cached_msg(self):
+        """Entry points that write the recurrent state OUT OF BAND (kernels through raw pointers do not bump a tensor's version
+        counter: models.reset_states, the batch hand-over of BatchedTrainer) call this: the next policy step recomputes the senders'
+        message vectors instead of trusting the pointer / version match below."""
+        self._m_next = None
+
     def _cached_msg(self, h):
         """The message vectors of exactly this h, if the last policy step left them: same memory, and no in-place torch op on it
-        since (version counter; kernels writing through raw pointers are the policy steps themselves)."""
+        since (version counter; kernels writing through raw pointers are the policy steps themselves -- every other writer calls
+        `invalidate_cached_msg`)."""
         m = self._m_next
         if m is not None and m[0] == h.data_ptr() and m[1] == h._version and m[2].shape == h.shape:
             return m[2]

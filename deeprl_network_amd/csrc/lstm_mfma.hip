@@ -1027,19 +1027,18 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             eacc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].z, ein[s_], eacc[6], 0, 0, 0);
             eacc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].w, ein[s_], eacc[7], 0, 0, 0);
         }
+        NMARL_STAMP(50)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             eacc[mt] = __builtin_elementwise_max(eacc[mt], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
             xslot[512 * mt] = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};      // (lane-private: re-read by this lane only)
         }
+        NMARL_STAMP(51)
         a0 = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
         a1 = float4{eacc[1][0], eacc[1][1], eacc[1][2], eacc[1][3]};
-        if (e_out != nullptr && row0 + i16 < a.E) {                      // the saved LSTM input of the update: one predicate, 8 stores
-            float* so = e_out + (int64_t)n * e_out_sn + (row0 + i16) * e_out_row + 4 * grp;
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-                *reinterpret_cast<float4*>(so + 16 * mt) = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};
-        }
+        // (the saved LSTM input of the update is NOT stored here: 8 x 16-byte stores per lane at once are a 16.8-MB burst from all
+        // 256 blocks in the same phase, ~3.4 k cycles of blocked store issue in front of tick 0 (tools/step_timeline.py enc noout);
+        // each x chunk's two pieces leave in the tick that multiplies them instead -- the A operands ARE those values)
         asm volatile("" :: "s"(ka_touch));
         NMARL_STAMP(38)
     }
@@ -1205,6 +1204,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
             const float* buf = lds + bsel * CH_FLOATS + (4 * grp * 16 + c) * 20;
             NMARL_CHUNK(buf, a0, a1)
+            if (ENC && ch < nx && e_out != nullptr && row0 + c < a.E) {      // ENC: this chunk of the encoded input, for the update
+                float* so = e_out + (int64_t)n * e_out_sn + (row0 + c) * e_out_row + 4 * grp + ch * CH_K;
+                *reinterpret_cast<float4*>(so) = a0;
+                *reinterpret_cast<float4*>(so + 16) = a1;
+            }
         }
         NMARL_STAMP(2 + 2 * tau)
         __syncthreads();                         // tick done: the oldest chunk's buffer is free, chunk tau + 1 visible
@@ -1668,9 +1672,24 @@ extern "C" int nmarl_handoff_capacity(int32_t which, int32_t K) {
         if (K % CH_K || K > 128) return -1;
         const size_t lb = (size_t)(LDSX_FLOATS + K * 64 + (K == H ? H * 64 : 0)) * sizeof(float);
         const int lb_max = (int)((LDSX_FLOATS + CH_FLOATS) * sizeof(float));
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lb_max) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_step_x_kernel<4, 1>, 512, lb) != hipSuccess)
-            return -1;
+        // the instantiation that will be launched: K = 64 is lstm_ic3's <4,2> (different registers / LDS: the encoder image), else
+        // lstm_comm's <4,1>; queried once per (device, kind) and kept -- the launch path asks for it at every lock-step
+        static std::atomic<int> cache[64][2];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return -1;
+        const int kd = K == H ? 1 : 0;
+        const int hit = (dev >= 0 && dev < 64) ? cache[dev][kd].load() : 0;
+        if (hit > 0) {
+            per_cu = hit - 1;
+        } else {
+            const void* fn = K == H ? reinterpret_cast<const void*>(lstm_step_x_kernel<4, 2>) : reinterpret_cast<const void*>(lstm_step_x_kernel<4, 1>);
+            hipError_t rc = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lb_max);
+            if (rc == hipSuccess)
+                rc = K == H ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_step_x_kernel<4, 2>, 512, lb)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_step_x_kernel<4, 1>, 512, lb);
+            if (rc != hipSuccess) return -1;
+            if (dev >= 0 && dev < 64) cache[dev][kd].store(per_cu + 1);
+        }
     } else if (which == 2) {
         per_cu = nmarl_bptt_coupled_occupancy(K);
         if (per_cu < 0) return -1;

@@ -437,6 +437,7 @@ class BatchedTrainer:
         env already auto-reset them) with zero recurrent state and uniform fingerprints -- what the reference does at its
         next `env.reset(); model.reset()` --, states_bw <- states_fw, slot T of the rollout buffers -> slot 0."""
         m, T = self.model, self.n_step
+        m.policy.invalidate_cached_msg()       # (the epilogue kernel zeroes finished replicas' h through raw pointers)
         ops.batch_epilogue(self.buf_g, self.last_done, self.ep_sum, self.ep_sq, self.ep_len, self.fin, self.env.T,
                            m.h_fw, m.c_fw, m.h_bw, m.c_bw, m.buf_fp[T], m.buf_fp[0], m.fp_uniform, m.buf_x[T], m.buf_x[0],
                            self.done_pre)
@@ -583,8 +584,10 @@ class BatchedTrainer:
         """Deterministic (argmax) test episodes, the batched analogue of `perform(-1)` after a CACC
         training episode (utils.py:199-223, 246-251): train_mode False -> no soft-collision term.  The evaluation env, its state
         tensors and (with use_graph) the whole T-step episode as ONE captured hipGraph are built once per (n_envs, seed) and
-        replayed: every evaluation starts from the same initial conditions (the reference re-seeds its in-training test with
-        seed - 1 every time, cacc_env.py:170-175) and costs a graph replay instead of ~6 T eager launches and a new env."""
+        replayed: every evaluation starts from the same initial conditions and costs a graph replay instead of ~6 T eager launches
+        and a new env.  (The reference's in-training test re-seeds with `seed - 1` where `seed` has been incremented by every reset
+        before it, cacc_env.py:170-176: its test conditions move from episode to episode; here ONE fixed set of n_envs episodes,
+        seed - 1 of the configured seed, serves as the yardstick of a run -- pass `seed` for another.)"""
         key = (int(n_envs), self.env.seed - 1 if seed is None else int(seed))
         cache = self.__dict__.setdefault('_eval_cache', {})
         if key not in cache:
@@ -668,9 +671,9 @@ class BatchedTrainer:
         Row: `avg_reward` / `std_reward` = the deterministic TEST episodes (argmax policy, raw reward) for CACC, like
         the reference's train_reward.csv (utils.py:246-251), evaluated every `eval_every` rows -- default: every env.T / n_step
         rows (the reference tests once per training episode of ONE replica, utils.py:246-251; here a row already spans log_every
-        batches of E replicas) and at the last row; never for ATSC, whose logged
-        reward is the training episode's (utils.py:243-245) -- and carried forward on the rows in between (NaN before the first
-        evaluation; `evaluated` marks the rows that ran one); `train_avg_reward` etc. = statistics of the training episodes
+        batches of E replicas), at the FIRST row and at the last one; never for ATSC, whose logged
+        reward is the training episode's (utils.py:243-245) -- and carried forward on the rows in between (`evaluated` marks the
+        rows that ran one; the first row runs one, so no row is NaN); `train_avg_reward` etc. = statistics of the training episodes
         finished since the last row (stochastic policy, training-mode reward)."""
         t0 = time.time()
         if eval_every is None:      # one test per env.T / n_step rows (10 for CACC: every 100 batches at the default log_every)
@@ -690,7 +693,7 @@ class BatchedTrainer:
                    'train_std_reward': st['std_reward'], 'episodes': st['episodes'], 'collisions': st['collisions'],
                    'env_steps': step * self.E * self.world_size * self.N, 'wall_s': time.time() - t0}
             if eval_every:
-                ran = final or rows_done % eval_every == eval_every - 1
+                ran = final or rows_done == 0 or rows_done % eval_every == eval_every - 1
                 if ran:
                     last_eval[:] = self.evaluate()
                 row.update(avg_reward=last_eval[0], std_reward=last_eval[1], test_collisions=last_eval[2], evaluated=int(ran))

@@ -86,7 +86,7 @@ elif head == 4:
 if ENC:
     nbrs = [[j for j in (i - 1, i + 1) if 0 <= j < N] for i in range(N)]
     enc_spec = ops.step_enc_spec(r(E, N, 5), torch.softmax(r(N, E, A), -1), r(N, 15, H) * 0.3, r(N, H) * 0.1, r(N, 8, H) * 0.3, r(N, H) * 0.1,
-                                 nbrs, out=x)
+                                 nbrs, out=None if 'noout' in sys.argv else x)
 
 
 def run():
@@ -107,13 +107,13 @@ torch.cuda.synchronize()
 t = tl.cpu().view(8, 64)
 t0 = int(t[:, 0].min())
 names = {0: 'entry', 40: 'epoch read', 41: 'A/W loads issued', 42: 'chunk 0 in LDS', 43: 'chunk 1 in LDS', 44: 'head w in LDS',
-         36: 'enc loads issued', 37: 'enc operands in', 38: 'enc done', 45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
+         36: 'enc loads issued', 37: 'enc operands in', 50: 'enc MFMAs done', 51: 'enc parked', 38: 'enc done', 39: 'env step done', 45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
          26: 'published', 27: 'flags seen', 28: 'message term', 29: 'msg W staged', 30: 'msg chunks',
          33: 'cell math', 34: 'critic dots', 35: 'critic shfl'}
 for i in range(2, 20, 2):
     names[i], names[i + 1] = 'tick %d computed' % ((i - 2) // 2), 'tick %d barrier' % ((i - 2) // 2)
 print('stamp'.ljust(18) + ''.join(('wave %d' % w).rjust(9) for w in range(8)))
-ORDER = [0, 40, 36, 41, 42, 43, 44, 45, 46, 37, 38, 47, 1, 48, 49] + list(range(2, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25]
+ORDER = [0, 40, 36, 41, 42, 43, 44, 45, 46, 37, 47, 1, 50, 51, 38, 48, 49] + list(range(2, 23)) + [26, 23, 27, 28, 29, 30, 33, 24, 34, 35, 25, 39]
 for i in ORDER:
     if i not in names:
         continue

@@ -782,6 +782,8 @@ def main():
                 us_l, flops_l, bytes_l, lname = measure_lstm_step(model)
                 x_side = model.policy.can_save_acts
                 lpb = (n_step + 1) if model.policy.fused_pv else 2 * (n_step + 1)
+                # (PMC key of the kernel the rollout launches: round 5's one-launch lock-step has its own measurement)
+                lkey = 'lstm_step_x_enc_env_N8_E4096' if getattr(trainer, 'env_in_kernel', False) else 'lstm_step_x_N8_E4096'
                 us_iso = us_l
                 us_roll = None
                 if x_side:
@@ -799,8 +801,8 @@ def main():
                     'unit': 'TFLOP/s' if x_side else 'GB/s',
                     'frac': ach / MFMA_F32_PEAK_TFLOPS if x_side else bytes_l / us_l / 1e3 / HBM_PEAK_GBPS,
                     'traffic': (lambda t: None if (t[0] is None or not x_side or n_agent * E != 8 * 4096) else t[0] * n_agent * E)(
-                        pmc_traffic('lstm_step_x_N8_E4096')),
-                    'traffic_source': pmc_traffic('lstm_step_x_N8_E4096')[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
+                        pmc_traffic(lkey)),
+                    'traffic_source': pmc_traffic(lkey)[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
                     'us_per_launch_isolated_graph': us_iso, 'us_per_launch_in_rollout': us_roll,
                     'rollout_graph_us': None if us_roll is None else us_roll_full,
                     'rollout_graph_us_without_lstm_steps': None if us_roll is None else us_roll_without,
@@ -903,7 +905,9 @@ def main():
                 us_b = measure_step_kernel(big, big_tape, reps=10)
                 ach_b = balg * big_E / us_b / 1e3
                 tr_big, tr_src_b = pmc_traffic(('grid_step_compact_E2p17' if trainer.compact_obs else 'grid_step_E2p17') if is_grid else pk + '_E2p21')
-                out['roofline_env_step_large_E'] = {'kernel': kname, 'bound': 'hbm', 'achieved': ach_b,
+                kname_big = kname if (is_grid or not trainer.compact_obs or os.environ.get('NMARL_CACC_QUAD', '1') == '0') else \
+                    'cacc_step4_kernel (nmarl_cacc_step in the HBM regime: four vehicles per lane, 16-byte accesses)'
+                out['roofline_env_step_large_E'] = {'kernel': kname_big, 'bound': 'hbm', 'achieved': ach_b,
                                                     'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach_b / HBM_PEAK_GBPS,
                                                     'traffic': None if tr_big is None else tr_big * big_E,
                                                     'traffic_source': tr_src_b,

@@ -19,6 +19,7 @@
 // arithmetic follows the oracle operation by operation.
 #include "common.h"
 #include "cacc_tile.h"
+#include <stdlib.h>
 
 // ---- tuning knobs (defaults = shipped configuration; tools/ab_env.py builds variants with -D...)
 #ifndef NMARL_CACC_GRIDCAP
@@ -92,6 +93,57 @@ __global__ __launch_bounds__(BLOCK) void cacc_step_kernel(
         cacc_tile<NT, COMPACT>(p, n_lanes, w, lane, h, v, act, t, collided, v0i, hs, vs, us, ts, coll, v0_init, obs, reward, done,
                                greward, auto_reset, seed, env_id_base, episode, lds_wave);
     }
+}
+
+// The HBM-regime form (round 5): four vehicles per lane, 16-byte accesses (cacc_quad, csrc/cacc_tile.h).  A wave steps 32 replicas per
+// tile; the inputs of its next two tiles are in flight while it computes (unconditional, clamped loads).  Compact observation only.
+template <int BLOCK, int NT>
+__global__ __launch_bounds__(BLOCK) void cacc_step4_kernel(
+    const nmarl_cacc_params_t p, const int64_t E, const uint8_t* __restrict__ action,
+    float* __restrict__ hs, float* __restrict__ vs, float* __restrict__ us,
+    int32_t* __restrict__ ts, uint8_t* __restrict__ coll, float* __restrict__ v0_init,
+    float* __restrict__ obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+    float* __restrict__ greward, const int auto_reset, const uint64_t seed,
+    const int64_t env_id_base, int32_t* __restrict__ episode) {
+    __shared__ __attribute__((aligned(16))) float lds[BLOCK * 4 * NF];           // the wave's observation slab: 64 lanes x 20 floats
+    const int lane = threadIdx.x & (NMARL_WAVE - 1);
+    const int wave = threadIdx.x / NMARL_WAVE;
+    float* lds_wave = lds + wave * NMARL_WAVE * 4 * NF;
+    constexpr int REPS = NMARL_WAVE / 2;                     // replicas per wave tile
+    const int64_t tiles_total = (E + REPS - 1) / REPS;
+    const int64_t stride = (int64_t)gridDim.x * (BLOCK / NMARL_WAVE);
+    const int half = lane & 1;
+    int64_t w = (int64_t)blockIdx.x * (BLOCK / NMARL_WAVE) + wave;
+    float4 h_n, v_n, h_m, v_m;
+    uint32_t a_n = 0, a_m = 0;
+    int t_n = 0, t_m = 0, c_n = 0, c_m = 0;
+    float z_n = 0.f, z_m = 0.f;
+#define NMARL_CACC4_LOAD(wt, S)                                                            \
+    {                                                                                      \
+        const int64_t wc_ = (wt) < tiles_total ? (wt) : tiles_total - 1;                   \
+        const int64_t er_ = wc_ * REPS + (lane >> 1);                                      \
+        const int64_t e_ = er_ < E ? er_ : E - 1;                                          \
+        const int64_t g_ = e_ * N + 4 * half;                                              \
+        h_##S = *reinterpret_cast<const float4*>(hs + g_); v_##S = *reinterpret_cast<const float4*>(vs + g_); \
+        a_##S = *reinterpret_cast<const uint32_t*>(action + g_);                           \
+        t_##S = ts[e_]; c_##S = coll[e_]; z_##S = v0_init[e_];                             \
+    }
+    if (w < tiles_total) {
+        NMARL_CACC4_LOAD(w, n)
+        NMARL_CACC4_LOAD(w + stride, m)
+    }
+    for (; w < tiles_total; w += stride) {
+        const float4 h4 = h_n, v4 = v_n;
+        const uint32_t a4 = a_n;
+        const int t = t_n;
+        const bool collided = c_n != 0;
+        const float v0i = z_n;
+        h_n = h_m; v_n = v_m; a_n = a_m; t_n = t_m; c_n = c_m; z_n = z_m;
+        NMARL_CACC4_LOAD(w + 2 * stride, m)
+        cacc_quad<NT>(p, E, w * REPS + (lane >> 1), half, h4, v4, a4, t, collided, v0i, hs, vs, us, ts, coll, v0_init, obs, reward, done,
+                      greward, auto_reset, seed, env_id_base, episode, lds_wave, lane, w * REPS);
+    }
+#undef NMARL_CACC4_LOAD
 }
 
 template <int BLOCK, bool COMPACT>
@@ -315,7 +367,18 @@ extern "C" int nmarl_cacc_step(const nmarl_cacc_params_t* p, int64_t E, const ui
         if (p->compact_obs) NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_SMALL, NMARL_CACC_NT_SMALL, true);
         else NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_SMALL, NMARL_CACC_NT_SMALL, false);
     } else {
-        if (p->compact_obs) NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE, true);
+        // HBM regime: the compact layout takes the four-vehicles-per-lane form (16-byte accesses; NMARL_CACC_QUAD=0: the lane-per-
+        // vehicle form, for A/B and for the test that compares the two bit for bit)
+        const char* qe = getenv("NMARL_CACC_QUAD");
+        const bool quad = !(qe && qe[0] == '0');
+        if (p->compact_obs && quad && ((uintptr_t)h % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)u % 16) == 0 &&
+            ((uintptr_t)obs % 16) == 0 && ((uintptr_t)action % 4) == 0 && (!p->per_agent_reward || ((uintptr_t)reward % 16) == 0)) {
+            const int64_t tiles = (E + 31) / 32;
+            const int64_t blocks = (tiles + 3) / 4;
+            hipLaunchKernelGGL((cacc_step4_kernel<256, NMARL_CACC_NT_LARGE>), dim3((unsigned)(blocks < NMARL_CACC_GRIDCAP ? blocks : NMARL_CACC_GRIDCAP)),
+                               dim3(256), 0, s, *p, E, action, h, v, u, t, collided, v0_init, obs, reward, done, global_reward, auto_reset, seed,
+                               env_id_base, episode);
+        } else if (p->compact_obs) NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE, true);
         else NMARL_CACC_LAUNCH(NMARL_CACC_BLOCK_LARGE, NMARL_CACC_NT_LARGE, false);
     }
 #undef NMARL_CACC_LAUNCH

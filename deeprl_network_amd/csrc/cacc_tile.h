@@ -324,4 +324,152 @@ __device__ __forceinline__ void cacc_step_group(const nmarl_cacc_params_t& p, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The step in the FOUR-VEHICLES-PER-LANE mapping of the HBM regime (round 5): lane = (replica, half platoon), a wave64 steps
+// 32 replicas, every per-vehicle array is read and written as ONE 16-byte access per lane, the compact observation leaves as
+// five (4 vehicles x 5 features = 80 contiguous bytes per lane) -- 19 vector-memory instructions per 11.2 KB instead of 19 per
+// 2.8 KB in the lane-per-vehicle mapping, whose launch was bound by the instruction rate of the memory pipeline, not by HBM.
+// Arithmetic: cacc_advance / obs_features operation for operation -- the two-stage in-lane sums and the one exchange with the
+// partner lane form the same trees as the three xor butterflies over 8 lanes ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7)) (fp32 add and
+// min commute exactly), so the two mappings agree bit for bit (tests/test_gpu_cacc.py).  Compact observation only.
+template <int NT>
+__device__ __forceinline__ void cacc_quad(const nmarl_cacc_params_t& p, const int64_t E, const int64_t e_raw, const int half, float4 h4,
+                                          float4 v4, const uint32_t act4, int t, bool collided, float v0i, float* __restrict__ hs,
+                                          float* __restrict__ vs, float* __restrict__ us, int32_t* __restrict__ ts, uint8_t* __restrict__ coll,
+                                          float* __restrict__ v0_init, float* __restrict__ obs, float* __restrict__ reward,
+                                          uint8_t* __restrict__ done, float* __restrict__ greward, const int auto_reset, const uint64_t seed,
+                                          const int64_t env_id_base, int32_t* __restrict__ episode, float* lds_wave, const int lane,
+                                          const int64_t e_tile0) {
+    const bool valid = e_raw < E;
+    const int64_t e = valid ? e_raw : E - 1;
+    const int64_t g0 = e * N + 4 * half;                 // first of this lane's four vehicles
+    float h[4] = {h4.x, h4.y, h4.z, h4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w};
+    const bool frozen = collided;                                   // :193
+    // the speed of the vehicle in front of this lane's first one: the leader's profile (half 0) or the partner lane's last vehicle
+    const float pv3 = __shfl_xor(v[3], 1, NMARL_WAVE);
+    float vl[4], vn[4], uc[4], hn[4];
+    vl[0] = half == 0 ? lead_speed(p, v0i, t) : pv3;
+    vl[1] = v[0]; vl[2] = v[1]; vl[3] = v[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int act = (int)((act4 >> (8 * j)) & 0xffu);
+        const float alpha = (act & 1) ? 0.5f : 0.0f;                // a_map, :275
+        const float beta = (act & 2) ? 0.5f : 0.0f;
+        const float u_raw = alpha * (ovm_vh(p, h[j]) - v[j]) + beta * (vl[j] - v[j]);   // :385
+        float v_next = v[j] + clampf(u_raw, p.u_min, p.u_max) * p.dt;      // :26
+        v_next = clampf(v_next, 0.0f, p.v_max);                     // :27
+        uc[j] = (v_next - v[j]) / p.dt;                             // :28
+        vn[j] = v_next;
+    }
+    const float pvn3 = __shfl_xor(vn[3], 1, NMARL_WAVE);
+    float u_new[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v_lead_next = j == 0 ? (half == 0 ? lead_speed(p, v0i, t + 1) : pvn3) : vn[j - 1];
+        hn[j] = h[j] + (0.5f * p.dt) * (vl[j] + v_lead_next - v[j] - vn[j]);  // :220
+    }
+    if (!frozen) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = hn[j]; v[j] = vn[j]; u_new[j] = uc[j]; }
+    } else {
+        const float4 uo = *reinterpret_cast<const float4*>(us + g0);
+        u_new[0] = uo.x; u_new[1] = uo.y; u_new[2] = uo.z; u_new[3] = uo.w;
+    }
+    // collision test: min over the platoon (:42) -- pairs, quads, then the partner's quad
+    float hmin = fminf(fminf(h[0], h[1]), fminf(h[2], h[3]));
+    hmin = fminf(hmin, __shfl_xor(hmin, 1, NMARL_WAVE));
+    if (!frozen && hmin < p.h_min) collided = true;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (collided) {
+            r[j] = -p.G;                                            // :44, :194
+        } else {
+            const float dh = h[j] - p.h_star, dv = v[j] - p.v_star;
+            float rr = -(dh * dh);
+            rr = rr + (-p.reward_a * (dv * dv));
+            rr = rr + (-p.reward_b * (u_new[j] * u_new[j]));
+            if (p.train_mode) {
+                const float c = fminf(h[j] - 10.0f, 0.0f);          // COLLISION_HEADWAY, :10
+                rr = rr + (-5.0f * (c * c));                        // COLLISION_WT, :9
+            }
+            r[j] = rr;
+        }
+    }
+    float rsum = (r[0] + r[1]) + (r[2] + r[3]);                     // np.sum(reward), :229: the pairwise tree of 8
+    rsum = rsum + __shfl_xor(rsum, 1, NMARL_WAVE);
+    t += 1;
+    const bool is_done = (collided && (t % p.batch_size == 0)) || (t == p.T);   // :231-235
+    if (valid) {
+        if (p.per_agent_reward) *reinterpret_cast<float4*>(reward + g0) = float4{r[0], r[1], r[2], r[3]};
+        if (half == 0) {
+            if (!p.per_agent_reward) reward[e] = rsum;
+            greward[e] = rsum;
+            done[e] = is_done ? 1 : 0;
+        }
+    }
+    if (auto_reset && is_done) {
+        const int ep = episode[e];
+        const float U = reset_uniform(seed, env_id_base + e, ep);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v0n;
+            init_state(p, U, 4 * half + j, h[j], v[j], v0n);
+            v0i = v0n;
+            u_new[j] = 0.0f;
+        }
+        t = 0; collided = false;
+        if (valid && half == 0) episode[e] = ep + 1;
+    }
+    if (valid) {
+        typedef float f32x4s __attribute__((ext_vector_type(4)));
+        const f32x4s H4 = {h[0], h[1], h[2], h[3]}, V4 = {v[0], v[1], v[2], v[3]}, U4 = {u_new[0], u_new[1], u_new[2], u_new[3]};
+        if (NT >= 2) {
+            __builtin_nontemporal_store(H4, reinterpret_cast<f32x4s*>(hs + g0));
+            __builtin_nontemporal_store(V4, reinterpret_cast<f32x4s*>(vs + g0));
+            __builtin_nontemporal_store(U4, reinterpret_cast<f32x4s*>(us + g0));
+        } else {
+            *reinterpret_cast<f32x4s*>(hs + g0) = H4; *reinterpret_cast<f32x4s*>(vs + g0) = V4; *reinterpret_cast<f32x4s*>(us + g0) = U4;
+        }
+        if (half == 0) {
+            ts[e] = t;
+            coll[e] = collided ? 1 : 0;
+            if (auto_reset && is_done) v0_init[e] = v0i;
+        }
+    }
+    // observation of the new state (:55, with the new t): 4 vehicles x 5 features = 20 consecutive floats of obs [E][8][5]
+    const float pv3o = __shfl_xor(v[3], 1, NMARL_WAVE);
+    float xo[4 * NF];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v_lead_obs = j == 0 ? (half == 0 ? lead_speed(p, v0i, t) : pv3o) : v[j - 1];
+        float x[NF];
+        obs_features(p, h[j], v[j], u_new[j], v_lead_obs, x);
+#pragma unroll
+        for (int k = 0; k < NF; ++k) xo[j * NF + k] = x[k];
+    }
+    // a lane's 80 bytes are contiguous, but 16-byte stores at an 80-byte lane stride are 64 separate segments per instruction (the
+    // first version: 505 us instead of 166 at E = 2^21): the wave's 32 x 40 floats go through LDS and leave as 5 coalesced stores
+    typedef float f32x4s __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+        *reinterpret_cast<float4*>(lds_wave + lane * (4 * NF) + 4 * i) = float4{xo[4 * i], xo[4 * i + 1], xo[4 * i + 2], xo[4 * i + 3]};
+    __builtin_amdgcn_wave_barrier();
+    const int64_t reps_here = E - e_tile0 < (NMARL_WAVE / 2) ? E - e_tile0 : (NMARL_WAVE / 2);     // replicas of this tile inside the batch
+    const int n_vec = (int)reps_here * (N * NF / 4);                                             // float4 of the tile's slab
+    f32x4s* dst = reinterpret_cast<f32x4s*>(obs + e_tile0 * (N * NF));
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int idx = i * NMARL_WAVE + lane;
+        if (idx < n_vec) {
+            const float4 q = reinterpret_cast<const float4*>(lds_wave)[idx];
+            const f32x4s val = {q.x, q.y, q.z, q.w};
+            if (NT >= 1) __builtin_nontemporal_store(val, dst + idx);
+            else dst[idx] = val;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace nmarl_cacc

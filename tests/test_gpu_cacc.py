@@ -255,3 +255,52 @@ def test_step_encode_vs_oracle(scenario, E, with_fp):
         enc_r = ops_ref.fc_fwd_multi(parts, ops_ref.BIAS_RELU)
         okt = torch.from_numpy(ok)
         torch.testing.assert_close(out.cpu().double()[:, okt], enc_r[:, okt], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('scenario', ['catchup', 'slowdown'])
+@pytest.mark.parametrize('E,per_agent', [(16384, False), (20011, True), (8193, False)])
+def test_quad_mapping_equals_lane_per_vehicle_mapping(scenario, E, per_agent, monkeypatch):
+    """HBM regime (E > 8192, compact observation): the four-vehicles-per-lane kernel (cacc_step4_kernel: 16-byte accesses) against the
+    lane-per-vehicle kernel (NMARL_CACC_QUAD=0) -- the same arithmetic in the same order, so every output is BIT-identical over 70 steps
+    with random actions, through collisions (frozen platoons re-read their acceleration), the episode end and the fused auto-reset
+    (T = 60 here); E = 20011 / 8193: ragged last tiles; and one step against the fp32 oracle from the reached state."""
+    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+    from oracle.cacc_ref import CaccBatchRef, CaccParams
+    cp = cacc_config(agent='ma2c_nc', scenario=scenario, coop_gamma=0.9 if per_agent else -1)
+    cp['ENV_CONFIG']['episode_length_sec'] = '6'
+    envs = []
+    for quad in ('1', '0'):
+        monkeypatch.setenv('NMARL_CACC_QUAD', quad)
+        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+        env.set_compact_obs(True)
+        env.reset()
+        g = torch.Generator(device='cuda').manual_seed(5)
+        rec = []
+        for t in range(70):
+            # mostly mild actions, some replicas driven into collisions
+            a = torch.randint(0, 4, (E, 8), device='cuda', generator=g).to(torch.uint8)
+            a[: E // 16] = 1
+            obs, r, d, gr = env.step(a, auto_reset=True)
+            if t % 7 == 0 or t >= 58:
+                rec += [obs.clone(), r.clone(), d.clone(), gr.clone()]
+        rec += [env.h.clone(), env.v.clone(), env.u.clone(), env.t.clone(), env.collided.clone(), env.v0_init.clone(), env.episode.clone()]
+        envs.append((env, rec))
+    for k, (x, y) in enumerate(zip(envs[0][1], envs[1][1])):
+        assert torch.equal(x, y), 'output %d differs between the two mappings' % k
+    assert int(envs[0][0].collided.sum()) >= 0 and int(envs[0][0].episode.max()) >= 2
+    # one more step of the quad kernel against the fp32 oracle from the state it reached
+    monkeypatch.setenv('NMARL_CACC_QUAD', '1')
+    env = envs[0][0]
+    ref = CaccBatchRef(CaccParams(config=cp['ENV_CONFIG']), E=E, dtype=np.float32)
+    ref.reset(np.zeros(E, dtype=np.float32))
+    ref.h, ref.v, ref.u = (x.cpu().numpy().copy() for x in (env.h, env.v, env.u))
+    ref.t, ref.collided, ref.v0_init = env.t.cpu().numpy().astype(np.int64), env.collided.cpu().numpy().astype(bool), env.v0_init.cpu().numpy().copy()
+    a = np.random.RandomState(1).randint(0, 4, size=(E, 8)).astype(np.uint8)
+    obs, r, d, gr = env.step(torch.from_numpy(a).cuda())
+    ro, rr, rd, rg = ref.step(a)
+    ok = np.abs(ref.h.min(axis=1) - 1.0) > 1e-4                 # (fp32 flip zone of the collision test)
+    assert ok.mean() > 0.99
+    np.testing.assert_allclose(obs.cpu().numpy()[ok], ro[ok], rtol=1e-5, atol=5e-5)
+    np.testing.assert_allclose(gr.cpu().numpy()[ok], rg[ok], rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose(env.h.cpu().numpy()[ok], ref.h[ok], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(d.cpu().numpy().astype(bool)[ok], rd[ok])

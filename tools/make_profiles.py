@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r04'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
 src = os.path.join(ROOT, sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -107,7 +107,8 @@ for a, b in (('%s_pmc_traffic.json', '%s_pmc_traffic.json'), ('%s_pmc_traffic.md
              ('%s_time_fused.log', '%s_time_fused.txt'), ('%s_env_microbench.log', '%s_env_microbench.txt'),
              ('%s_step_timeline.txt', '%s_step_timeline.txt'), ('%s_bptt_timeline.txt', '%s_bptt_timeline.txt'),
              ('%s_mfma_valu_overlap.txt', '%s_mfma_valu_overlap.txt'), ('%s_train_speed.txt', '%s_train_speed.txt'),
-             ('%s_learn_grid.json', '%s_learn_grid.json')):
+             ('%s_learn_grid.json', '%s_learn_grid.json'), ('%s_untraced_breakdown.md', '%s_untraced_breakdown.md'),
+             ('%s_clock_power.txt', '%s_clock_power.txt'), ('%s_ab_lockstep.txt', '%s_ab_lockstep.txt')):
     if os.path.exists(os.path.join(src, a % tag)):
         shutil.copy(os.path.join(src, a % tag), os.path.join(dst, b % tag))
 print('profiles/%s_* written' % tag)

@@ -86,6 +86,22 @@ for s in range(12):
     ops.lstm_step_policy_value(h, None, b, None, None, c, done, pi_w, pi_b, pi, act, v_w, v_b, nbr, A, v, mode=2, xs=(x, None, img),
                                h_out=ho, c_out=co, gates=gates, defer_action_term=True)
 torch.cuda.synchronize()
+# round 5: the WHOLE lock-step of IA2C-FP in one launch (lstm_step_x_kernel<3, 0, 1>: input encoders in the pre-phase, env step behind
+# the draw) as the rollout launches it -- two eager rollouts of the bench workload's trainer (2 x 61 launches)
+try:
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    tenv = CACCBatchEnv(cpf['ENV_CONFIG'], num_envs=Es)
+    np.random.seed(12)
+    tm = models.IA2C_FP(tenv.n_s_ls, tenv.n_a_ls, tenv.neighbor_mask, tenv.distance_mask, tenv.coop_gamma, 10 ** 9, cpf['MODEL_CONFIG'],
+                        seed=12, num_envs=Es)
+    ttr = BatchedTrainer(tenv, tm, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=False)
+    assert ttr.enc_in_kernel and ttr.env_in_kernel
+    for s in range(2):
+        ttr._rollout()
+    torch.cuda.synchronize()
+    del ttr, tm, tenv
+except Exception as ex:                        # a side measurement: never fail the pass
+    print('one-launch lock-step skipped:', ex)
 # the update's recurrence in one launch (nmarl_lstm_bptt_seq) at the bench shape: T = 60 reverse steps
 T = 60
 rd = lambda *s: torch.randn(*s, device='cuda')        # on the device: big host copies would show up as copyBuffer launches  # noqa: E731

@@ -41,7 +41,7 @@ res = {'calibration': dict(cal, known_bytes_each_way=1 << 30, fetch_correction=f
 import os
 COMPACT = os.environ.get('PMC_COMPACT', '1') == '1'
 pk, bcacc = ('cacc_step_compact', 351) if COMPACT else ('cacc_step', 631)
-for key, part, E, balg in ((pk + '_E2p21', 'cacc_step_kernel<256', 1 << 21, bcacc), (pk + '_E4096', 'cacc_step_kernel<64', 4096, bcacc),
+for key, part, E, balg in ((pk + '_E2p21', 'cacc_step4_kernel<256' if COMPACT else 'cacc_step_kernel<256', 1 << 21, bcacc), (pk + '_E4096', 'cacc_step_kernel<64', 4096, bcacc),
                            ('grid_step_E2p17', 'grid_step_kernel<1, false>', 1 << 17, 7548),
                            ('grid_step_compact_E2p17', 'grid_step_kernel<1, true>', 1 << 17, 3708),
                            # env 351 + fingerprints read 128 + encoded LSTM input written 8 x 128 x 4
@@ -57,7 +57,7 @@ for key, part, E, balg in ((pk + '_E2p21', 'cacc_step_kernel<256', 1 << 21, bcac
     res['kernels'][key] = s
 try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica" = one (agent, replica) row;
     # algorithmic bytes per row: x 512 + h, c in 512 + h', c' out 512 + gates 1024 + pi 16 + v 4 + action 1
-    s = stat('lstm_step_x_kernel<3')
+    s = stat('lstm_step_x_kernel<3, 0, 0>')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
@@ -65,6 +65,18 @@ try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica
     res['kernels']['lstm_step_x_N8_E4096'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no lstm step in this collection:', ex)
+try:        # round 5, the whole lock-step in one launch (encoders + policy + value + env step): per (agent, replica) row -- own compact
+    # observation 20 + own previous policy 16 + h, c 512 read; encoded LSTM input 512 + h', c' 512 + gates 1024 + pi 16 + v 4 + action 1
+    # written; the hand-off word's atomic 8; the env step's 351 B per replica = 44 per row
+    s = stat('lstm_step_x_kernel<3, 0, 1>')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 8 * 4096
+    balg = 36 + 512 + 512 + 512 + 1024 + 21 + 8 + 44
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / rows / balg)
+    res['kernels']['lstm_step_x_enc_env_N8_E4096'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no one-launch lock-step in this collection:', ex)
 try:        # the coupled nets' lock-step in one launch (NeurComm, line graph): per (agent, replica) row x [hx | hp] 512 + own h, c 512 +
     # the neighbours' h before (512) and after (512) the step read; h', c' 512 + gates 1024 + message term 256 + pi 16 + v 4 + action 1 written
     s = stat('lstm_step_x_kernel<4, 1>')

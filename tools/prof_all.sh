@@ -3,8 +3,11 @@
 # the other configs, PMC traffic passes (separate FETCH / WRITE runs).  Results under gpurun_out/ (copy into profiles/).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r04}
+TAG=${1:-r05}
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+python tools/untraced_breakdown.py gpurun_out/${TAG}_bench_default.json > gpurun_out/${TAG}_untraced_breakdown.md 2>&1
+python tools/clock_power.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_clock_power.txt
+bash tools/ab_lockstep.sh > gpurun_out/${TAG}_ab_lockstep.txt 2>&1
 bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid ma2c_dial_catchup
 for c in ma2c_dial_catchup ma2c_cnet_catchup ia2c_cu_catchup; do      # (NeurComm slow-down / catch-up and the CommNet grid: `other_configs` of the default line)
   python bench.py --no-cpu-baseline --steps 10 --config config/config_$c.ini > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err
@@ -26,8 +29,12 @@ python tools/step_timeline.py --build > /dev/null 2>&1
   python tools/step_timeline.py 4 2>&1 | grep -v amdgpu.ids; echo
   echo "## python tools/step_timeline.py 4 grid  (CommNet grid shape: 25 x 1024 rows, KX = 64, 4 neighbours, encoder inside; block 0 = a corner agent)"
   python tools/step_timeline.py 4 grid 2>&1 | grep -v amdgpu.ids; echo
-  echo "## python tools/step_timeline.py 3  (IA2C-FP shape, policy + value step)"
-  python tools/step_timeline.py 3 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_step_timeline.txt
+  echo "## python tools/step_timeline.py 3  (IA2C-FP shape, policy + value step: lstm_step_x_kernel<3,0,0>, x read from HBM)"
+  python tools/step_timeline.py 3 2>&1 | grep -v amdgpu.ids; echo
+  echo "## python tools/step_timeline.py 3 enc  (lstm_step_x_kernel<3,0,1>: the input encoders in the pre-phase; no env step in this harness)"
+  python tools/step_timeline.py 3 enc 2>&1 | grep -v amdgpu.ids; echo
+  echo "## python tools/step_timeline.py 3 enc noout  (the same without the saved-activation stores: the bootstrap step)"
+  python tools/step_timeline.py 3 enc noout 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_step_timeline.txt
 python -c "
 import json
 d=json.loads(open('gpurun_out/${TAG}_bench_default.json').read().strip().splitlines()[-1])

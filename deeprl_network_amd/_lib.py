@@ -73,7 +73,8 @@ class StepEnc(C.Structure):
                 ('env', C.POINTER(CaccParams)), ('h', C.c_void_p), ('v', C.c_void_p), ('u', C.c_void_p), ('t', C.c_void_p),
                 ('collided', C.c_void_p), ('v0_init', C.c_void_p), ('obs_out', C.c_void_p), ('reward', C.c_void_p),
                 ('done', C.c_void_p), ('global_reward', C.c_void_p), ('auto_reset', C.c_int32), ('pad2_', C.c_int32),
-                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('episode', C.c_void_p), ('cnt', C.c_void_p)]
+                ('seed', C.c_uint64), ('env_id_base', C.c_int64), ('episode', C.c_void_p), ('cnt', C.c_void_p),
+                ('relu_bits', C.c_void_p), ('relu_bits_sn', C.c_int64)]
 
 
 class NetParams(C.Structure):
@@ -199,6 +200,7 @@ SIGNATURES = {
     'nmarl_onehot_argmax_add': [_i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i64, _i64, _p],
     'nmarl_fc_bwd_chunks': [_i64, _i32],
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
+    'nmarl_fc_bwd_pair': [_i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p],
     'nmarl_fc_bwd_gather': [_i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_nbr_action_value_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p],

@@ -303,7 +303,7 @@ class IA2C:
             # the lock-step kernel runs both input encoders itself, from the compact observation and the fingerprints of slot t,
             # and leaves the LSTM input in slot t of the saved activations: no encoder launch at all
             # (env_step: the same launch also steps the env with the actions it draws -- CACCBatchEnv.inkernel_step)
-            enc, ob = self.S_buf[:, t], dict(x=self.buf_x[t], fp=self.fp, env=env_step)
+            enc, ob = self.S_buf[:, t], dict(x=self.buf_x[t], fp=self.fp, env=env_step, bits=self._relu_bits(t))
         elif self.save_acts and 'ENC' in p._extra:
             # nets whose encoder output is NOT the LSTM input itself (CommNet: s = enc + message term): kept per lock-step so
             # that the update's encoder backward needs no forward pass.  Where the one-launch step runs the encoder too, `enc`
@@ -344,6 +344,19 @@ class IA2C:
                       done_is_zero, **draw)
         p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, self.buf_act[t], self.buf_v[t], done_is_zero)
         return self.buf_act[t]
+
+    S_bits = None
+
+    def _relu_bits(self, t):
+        """Slot t of the sign image of the saved LSTM inputs ([N,T,E,4] int32, ops.relu_bits_pack's layout): written by the
+        lock-step kernel that runs the input encoders, read by the update's encoder backward instead of S itself."""
+        if os.environ.get('NMARL_FC_BWD_PAIR', '1') == '0':
+            return None
+        if self.S_bits is None:
+            self.S_bits = torch.zeros(self.n_agent, self.n_step, self.E, 4, dtype=torch.int32, device=self.device)
+        p = self.policy
+        p._bits_steps = 1 if t == 0 else p._bits_steps + 1
+        return self.S_bits[:, t]
 
     def record(self, reward, done_post):
         """model.add_transition's reward path (models.py:26-32) for slot t: normalise, clip, store."""
@@ -475,8 +488,11 @@ class IA2C:
         FP = self.buf_fp[:T].permute(1, 0, 2, 3).reshape(self.n_agent, T * self.E, self.n_a)
         X = self.buf_x[:T]            # compact [T,E,N,n_feat] slab: the encoders' kernels gather the neighbours themselves
         if self.save_acts:
+            kw = {}
+            if self.S_bits is not None and self.policy._bits_steps == T:      # every lock-step of this batch went through the kernel that writes them
+                kw['S_bits'] = self.S_bits
             Hs = self.policy.unroll_saved(X, FP, self.S_buf, self.G_buf, self.H_all, self.C_all,
-                                          self.buf_done_pre, masked_steps=self.masked_steps, S_ext=self.S_ext)
+                                          self.buf_done_pre, masked_steps=self.masked_steps, S_ext=self.S_ext, **kw)
         else:
             Hs = self.policy.unroll(X, FP, self.buf_done_pre, self.h_bw, self.c_bw, masked_steps=self.masked_steps)
         loss = self._loss(Hs)
@@ -527,6 +543,7 @@ class IA2C:
         """Host only: the batch is consumed."""
         self.t = 0
         self.policy._enc_was_saved = False       # the saved encoder outputs belonged to this batch (the next rollout sets it again)
+        self.policy._bits_steps = 0
         self.policy._mm_was_saved = False
 
     # ------------------------------------------------------------------ reference API (E = 1)

@@ -440,6 +440,8 @@ class BatchedPolicy:
         """The one-launch step of this net also runs the observation encoder (no separate encoder launch per lock-step)."""
         return False
 
+    _bits_steps = 0          # lock-steps of the running batch whose encoder sign image the rollout wrote (models._relu_bits)
+
     def invalidate_cached_msg(self):
         """(lstm_dial keeps message vectors of the last policy step: see DIALMultiAgentPolicy)"""
 
@@ -464,7 +466,7 @@ class BatchedPolicy:
             elif ob is not None:
                 # the encoders run inside the launch: ob = dict(x = compact observation [E,N,5], fp = previous policies [N,E,4]);
                 # `enc` = where their output (the LSTM input) is kept for the update, or None
-                z1, z2, xs = None, None, (self._enc_spec(ob['x'], ob['fp'], enc, ob.get('env')), self.params[self.k_wx], self._img)
+                z1, z2, xs = None, None, (self._enc_spec(ob['x'], ob['fp'], enc, ob.get('env'), ob.get('bits')), self.params[self.k_wx], self._img)
             else:
                 z1, z2, xs = self._recur_addends(enc, h)
             p = self.params
@@ -479,7 +481,7 @@ class BatchedPolicy:
         which then needs no forward pass: nets whose recurrent step is the fused x-side kernel."""
         return self.xside and self.fused_heads
 
-    def unroll_saved(self, X, FP, S, G, Hall, Call, done, masked_steps=None, S_ext=None):
+    def unroll_saved(self, X, FP, S, G, Hall, Call, done, masked_steps=None, S_ext=None, S_bits=None):
         """`unroll` for a batch whose forward pass the rollout already did with the CURRENT weights: S [N,T,E,KX] the
         LSTM inputs, G the gates, Hall / Call [N,T+1,E,H] the state sequences it saved.  Sets up the backward only.
         S_ext: the [N,T+1,E,KX] buffer S is the first T slabs of (last slab zero), see ops._lstm_seq_x_backward."""
@@ -487,7 +489,10 @@ class BatchedPolicy:
         Xv = X.reshape(T * E, self.N, X.shape[-1]).transpose(0, 1)          # gathered [.., n_obs] or compact [.., n_feat] slab
         if self.coupled:
             return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext)
-        s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
+        if S_bits is not None:           # the sign image of S the lock-step kernel's encoders wrote (FPPolicy): S is not re-read
+            s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]), bits=S_bits.view(self.N, T * E, 4))
+        else:
+            s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]))
         Hs = ops.lstm_sequence_saved(s.view(self.N, T, E, s.shape[-1]), self.params[self.k_wx], self.params[self.k_wh],
                                      self.params[self.k_b], G, Hall, Call, done, masked_steps, s_ext=S_ext)
         return Hs.reshape(self.N, T * E, self.n_h)
@@ -709,12 +714,13 @@ class FPPolicy(LstmPolicy):
                  ('lstm_wh', 'lstm_%d/lstm/wh', (H, 4 * H), None),
                  ('lstm_b', 'lstm_%d/lstm/b', (4 * H,), None)] + self._head_phase('lstm_%d/pi', 'lstm_%d/v')]
 
-    def _enc(self, xv, fp, saved=None):
+    def _enc(self, xv, fp, saved=None, bits=None):
         p = self.params
         nf = self.n_fc
         # tf.concat([hx, hp]) @ wx as ONE K = 2 nf GEMM; both layers write their block of the concatenation in place; the
         # neighbour gathers of the (compact) observation and of the fingerprints happen inside the fc kernels
-        s = ops.fc_concat([self._ob_part(xv, 'fcs_w', 'fcs_b'), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)], ops.BIAS_RELU, saved=saved)
+        s = ops.fc_concat([self._ob_part(xv, 'fcs_w', 'fcs_b'), (fp, p['fcp_w'], p['fcp_b'], self.nbr_idx)], ops.BIAS_RELU, saved=saved,
+                          bits=bits)
         return s if self.xside else ops.linear(s, p['lstm_wx'])
 
     def _enc_infer(self, xv, fp, out=None):
@@ -737,9 +743,9 @@ class FPPolicy(LstmPolicy):
         return bool(compact) and self.xside and self.fused_pv and not self.hetero and \
             ops.step_enc_supported(self.n_feat, self.n_a, self.m_max, self.n_fc, self.n_h, self.N)
 
-    def _enc_spec(self, x, fp, out, env=None):
+    def _enc_spec(self, x, fp, out, env=None, bits=None):
         p = self.params
-        return ops.step_enc_spec(x, fp, p['fcs_w'], p['fcs_b'], p['fcp_w'], p['fcp_b'], self.nbrs, out=out, env=env)
+        return ops.step_enc_spec(x, fp, p['fcs_w'], p['fcs_b'], p['fcp_w'], p['fcp_b'], self.nbrs, out=out, env=env, bits=bits)
 
 
 class NCMultiAgentPolicy(BatchedPolicy):

@@ -330,8 +330,7 @@ __global__ __launch_bounds__(256) void rmsprop_kernel(
         return;
     }
     // every block re-reduces its group's 64 partials in the same fixed order
-    float tot = 0.0f;
-    for (int b = 0; b < SUMSQ_BLOCKS; ++b) tot += partial[grp * SUMSQ_BLOCKS + b];
+    const float tot = nmarl_ordered_sum(partial + grp * SUMSQ_BLOCKS, 1, SUMSQ_BLOCKS);
     const float norm = sqrtf(tot) * fabsf(grad_scale);
     float scale = grad_scale;
     if (max_norm > 0.0f) scale = grad_scale * (max_norm * fminf(1.0f / norm, 1.0f / max_norm));
@@ -439,8 +438,7 @@ __global__ __launch_bounds__(64) void a2c_loss_reduce_kernel(const int C, const 
                                                              const float* __restrict__ partial, float* __restrict__ out /*[N,3]*/) {
     const int n = blockIdx.x, k = threadIdx.x;
     if (k >= 3) return;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += partial[((int64_t)n * C + c) * 3 + k];
+    float s = nmarl_ordered_sum(partial + (int64_t)n * C * 3 + k, 3, C);
     s /= (float)rows;
     out[n * 3 + k] = k == 0 ? s : k == 1 ? s * 0.5f * v_coef : -s * e_coef;
 }

@@ -26,6 +26,30 @@ struct NmarlPerDeviceOnce {
     void done(unsigned long long bit) { seen.fetch_or(bit, std::memory_order_release); }
 };
 
+// Sum of C partial results p[0], p[stride], ... in index order (s = (((0 + p0) + p1) + ...): the deterministic second stage of
+// every two-stage reduction here).  The loads of U terms are issued together and only the adds are serial: the plain loop waits
+// out one memory latency per term (128 chunks: ~50 us for a kernel that moves a few MB).
+template <int U = 32>
+__device__ __forceinline__ float nmarl_ordered_sum(const float* __restrict__ p, const int64_t stride, const int C) {
+    float s = 0.0f;
+    int c = 0;
+    for (; c + U <= C; c += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[(int64_t)(c + u) * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
+    if (c < C) {                      // the tail: clamped loads, terms past the end skipped (same order)
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = p[(int64_t)(c + u < C ? c + u : C - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (c + u < C) s += v[u];
+    }
+    return s;
+}
+
 // Philox4x32-10; contract shared with oracle/philox.py.
 struct Philox4 { uint32_t x, y, z, w; };
 

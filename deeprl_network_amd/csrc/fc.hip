@@ -405,6 +405,180 @@ __global__ __launch_bounds__(256) void fc_bwd_kernel(const int64_t rows, const i
     }
 }
 
+// BOTH layers of a two-part encoding [act(x_0 w_0 + b_0) | act(x_1 w_1 + b_1)] (policies.py:176-181) in ONE pass over the
+// 128-column dy: 512 threads = (4 consecutive columns of 128, row lane of 16), so that a thread owns exactly the rows and
+// columns a thread of fc_bwd_kernel<16> owns in the two-launch form and adds them in the same order; the block's reduction
+// pairs the waves the same way (below) -- the results are bit-identical to two fc_bwd launches.  BITS: the relu derivative
+// comes from a bit image the producer of y wrote (16 bytes per row instead of the 512-byte y row): word q of a row, bit
+// 4 t + i  <=>  y[row, 16 t + 4 q + i] > 0  (the C/D register layout of the lock-step kernel's encoder pre-phase).
+// partial: [N, gridDim.x, 2, 17, 64] (rows 0..15 dW of the part, zero past its F; row 16 db).
+struct FcPair { nmarl_fc_part_t p[2]; };
+
+template <bool BITS>
+__global__ __launch_bounds__(512) void fc_bwd_pair_kernel(const int64_t rows, const int tiles_per_block, const FcPair parts,
+                                                          const float* __restrict__ y, const int64_t y_sn, const int64_t y_row,
+                                                          const uint32_t* __restrict__ bits, const int64_t bits_sn,
+                                                          const float* __restrict__ dy, const int64_t dy_sn, const int64_t dy_row,
+                                                          const int act, float* __restrict__ partial) {
+    constexpr int FMAX = 16, FP = FMAX + 4;
+    __shared__ __attribute__((aligned(16))) float xs[4 * (FMAX + 1) * J];      // x tiles [2][64][FP]; later the reduction pads: result [2][17][64], scratch [2][17][64]
+    static_assert(2 * TILE * FP <= 4 * (FMAX + 1) * J, "x tiles fit");
+    const int n = blockIdx.y, ct = threadIdx.x & 31, j4 = ct * 4, rl = threadIdx.x >> 5, half = ct >> 4;
+    float acc[FMAX][4];
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[f][q] = 0.0f;
+    float db[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* yn = BITS ? nullptr : y + (int64_t)n * y_sn + j4;
+    const uint32_t* bn = BITS ? bits + (int64_t)n * bits_sn + (ct & 3) : nullptr;
+    const int bshift = 4 * (ct >> 2);
+    const float* dyn = dy + (int64_t)n * dy_sn + j4;
+    float4 gy[4], gd[4];
+    uint32_t gb[4];
+    float okf[4];
+#define NMARL_FCP_LOAD(tile_)                                                             \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+            const int64_t row = r0_ + rl + 16 * i;                                         \
+            const bool ok = row < rows && (tile_) < tiles_per_block;                       \
+            const int64_t rc = ok ? row : rows - 1;                                        \
+            okf[i] = ok ? 1.0f : 0.0f;                                                     \
+            gd[i] = *reinterpret_cast<const float4*>(dyn + rc * dy_row);                   \
+            if (BITS) gb[i] = bn[rc * 4];                                                  \
+            else gy[i] = *reinterpret_cast<const float4*>(yn + rc * y_row);                \
+        }                                                                                  \
+    }
+    // x tiles of both parts: 2 x 64 x 16 values, four per thread (m = 0, 1: part 0; m = 2, 3: part 1), the next tile's in registers
+    constexpr int XR = 2 * TILE * FMAX / 512;
+    float xr[XR];
+    int64_t xoff[XR], xrow[XR];
+    bool xok[XR];
+#pragma unroll
+    for (int m = 0; m < XR; ++m) {
+        const nmarl_fc_part_t& pt = parts.p[m >> 1];
+        const int f = threadIdx.x % FMAX;
+        xok[m] = f < pt.F;
+        xrow[m] = pt.x_row;
+        xoff[m] = (int64_t)n * pt.x_sn + (xok[m] ? f : 0);
+        if (pt.nbr_idx != nullptr) {
+            const int k = (xok[m] ? f : 0) / pt.gather_A;
+            const int src = pt.nbr_idx[n * pt.m_max + k];
+            xok[m] = xok[m] && src >= 0;
+            xoff[m] = (int64_t)(src >= 0 ? src : 0) * pt.x_sn + (xok[m] ? f - k * pt.gather_A : 0);
+        }
+    }
+#define NMARL_FCP_XLOAD(tile_)                                                             \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        _Pragma("unroll") for (int m = 0; m < XR; ++m) {                                   \
+            const int64_t row = r0_ + (threadIdx.x + 512 * (m & 1)) / FMAX;                \
+            const bool ok = xok[m] && row < rows;                                          \
+            xr[m] = parts.p[m >> 1].x[xoff[m] + (ok ? row : 0) * xrow[m]] * (ok ? 1.0f : 0.0f); \
+        }                                                                                  \
+    }
+    NMARL_FCP_LOAD(0)
+    NMARL_FCP_XLOAD(0)
+    const float* xh = xs + half * TILE * FP;
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+#pragma unroll
+        for (int m = 0; m < XR; ++m) {
+            const int r = (threadIdx.x + 512 * (m & 1)) / FMAX;
+            xs[(m >> 1) * TILE * FP + r * FP + threadIdx.x % FMAX] = xr[m];
+        }
+        NMARL_FCP_XLOAD(tile + 1)
+        float g[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (BITS) {
+                const uint32_t nb = gb[i] >> bshift;
+                g[i][0] = ((nb & 1u) ? gd[i].x : 0.0f) * okf[i];
+                g[i][1] = ((nb & 2u) ? gd[i].y : 0.0f) * okf[i];
+                g[i][2] = ((nb & 4u) ? gd[i].z : 0.0f) * okf[i];
+                g[i][3] = ((nb & 8u) ? gd[i].w : 0.0f) * okf[i];
+            } else {
+                g[i][0] = act_bwd(gd[i].x, gy[i].x, act) * okf[i];
+                g[i][1] = act_bwd(gd[i].y, gy[i].y, act) * okf[i];
+                g[i][2] = act_bwd(gd[i].z, gy[i].z, act) * okf[i];
+                g[i][3] = act_bwd(gd[i].w, gy[i].w, act) * okf[i];
+            }
+        }
+        NMARL_FCP_LOAD(tile + 1)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rr = rl + 16 * i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) db[q] += g[i][q];
+#pragma unroll
+            for (int f4 = 0; f4 < FMAX / 4; ++f4) {
+                const float4 xv = *reinterpret_cast<const float4*>(xh + rr * FP + 4 * f4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[4 * f4 + 0][q] = fmaf(xv.x, g[i][q], acc[4 * f4 + 0][q]);
+                    acc[4 * f4 + 1][q] = fmaf(xv.y, g[i][q], acc[4 * f4 + 1][q]);
+                    acc[4 * f4 + 2][q] = fmaf(xv.z, g[i][q], acc[4 * f4 + 2][q]);
+                    acc[4 * f4 + 3][q] = fmaf(xv.w, g[i][q], acc[4 * f4 + 3][q]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#undef NMARL_FCP_LOAD
+#undef NMARL_FCP_XLOAD
+    // fc_bwd_kernel's order: row lanes (4 k, 4 k + 1) and (4 k + 2, 4 k + 3) pairwise, the two pairs, then k = 0..3 in turn.
+    // Here a wave holds two row lanes (lanes 32 apart): wave 2 k = the first pair, wave 2 k + 1 = the second.
+#pragma unroll
+    for (int f = 0; f < FMAX; ++f)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[f][q] += __shfl_xor(acc[f][q], 32, 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) db[q] += __shfl_xor(db[q], 32, 64);
+    float* red = xs + half * (FMAX + 1) * J;
+    float* tmp = xs + (2 + half) * (FMAX + 1) * J;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, jj = j4 & 63;
+    for (int k = 0; k < 4; ++k) {
+        // second pair first into LDS, then (first + second) added to the running sum
+        if (wave == 2 * k + 1 && lane < 32) {
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tmp[f * J + jj + q] = acc[f][q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tmp[FMAX * J + jj + q] = db[q];
+        }
+        __syncthreads();
+        if (wave == 2 * k && lane < 32) {
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float pr = acc[f][q] + tmp[f * J + jj + q];
+                    red[f * J + jj + q] = (k == 0 ? 0.0f : red[f * J + jj + q]) + pr;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float pr = db[q] + tmp[FMAX * J + jj + q];
+                red[FMAX * J + jj + q] = (k == 0 ? 0.0f : red[FMAX * J + jj + q]) + pr;
+            }
+        }
+        __syncthreads();
+    }
+    float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)(2 * (FMAX + 1) * J);
+    for (int idx = threadIdx.x; idx < 2 * (FMAX + 1) * J; idx += 512) out[idx] = xs[idx];
+}
+
+__global__ __launch_bounds__(256) void fc_bwd_pair_reduce_kernel(const int C, const float* __restrict__ partial, float* __restrict__ dwb) {
+    constexpr int per = 2 * 17 * J;
+    const int n = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per) return;
+    dwb[(int64_t)n * per + idx] = nmarl_ordered_sum(partial + (int64_t)n * C * per + idx, per, C);
+}
+
 // Wider inputs (F > 16; or unaligned column blocks): thread = (column j, row lane of 4), scalar loads.
 template <int FMAX>
 __global__ __launch_bounds__(256) void fc_bwd_rows_kernel(const int64_t rows, const int F, const int tiles_per_block,
@@ -562,9 +736,7 @@ __global__ __launch_bounds__(256) void fc_bwd_reduce_kernel(const int C, const i
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = (F + 1) * J;
     if (idx >= per) return;
-    const float* p = partial + (int64_t)n * C * per + idx;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += p[(int64_t)c * per];
+    const float s = nmarl_ordered_sum(partial + (int64_t)n * C * per + idx, per, C);
     if (idx < F * J) dw[(int64_t)n * dw_sn + idx] = s;
     else db[(int64_t)n * db_sn + idx - F * J] = s;
 }
@@ -704,9 +876,7 @@ __global__ __launch_bounds__(256) void thin_bwd_reduce_kernel(const int C, const
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = 65 * O;
     if (idx >= per) return;
-    const float* p = partial + (int64_t)n * C * per + idx;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += p[(int64_t)c * per];
+    const float s = nmarl_ordered_sum(partial + (int64_t)n * C * per + idx, per, C);
     if (idx < 64 * O) dw[(int64_t)n * dw_sn + idx] = s;
     else db[(int64_t)n * db_sn + idx - 64 * O] = s;
 }
@@ -774,8 +944,7 @@ __global__ __launch_bounds__(64) void nbr_action_value_reduce_kernel(const int C
                                                                      float* __restrict__ dw, const int64_t dw_sn) {
     const int n = blockIdx.x, i = threadIdx.x;
     if (i >= W) return;
-    float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += partial[((int64_t)n * C + c) * W + i];
+    const float s = nmarl_ordered_sum(partial + (int64_t)n * C * W + i, W, C);
     dw[(int64_t)n * dw_sn + i] = s;
 }
 
@@ -916,6 +1085,35 @@ extern "C" int nmarl_fc_bwd_gather(int64_t rows, int32_t N, int32_t gather_A, in
     if (!nbr_idx || gather_A <= 0 || m_max <= 0) return NMARL_EINVAL;
     return launch_fc_bwd(rows, N, gather_A * m_max, Jw, x, x_sn, x_row, nbr_idx, gather_A, m_max, y, y_sn, y_row, dy, dy_sn, dy_row, act,
                          partial, dw, dw_sn, db, db_sn, stream);
+}
+
+extern "C" int nmarl_fc_bwd_pair(int64_t rows, int32_t N, const nmarl_fc_part_t* parts, const float* y, int64_t y_sn, int64_t y_row,
+                                 const uint32_t* relu_bits, int64_t bits_sn, const float* dy, int64_t dy_sn, int64_t dy_row,
+                                 int32_t act, float* partial, float* dwb, void* stream) {
+    if (rows <= 0 || N <= 0 || !parts || act < 0 || act > 2 || !partial || !dwb) return NMARL_EINVAL;
+    FcPair ps{};
+    for (int i = 0; i < 2; ++i) {
+        const nmarl_fc_part_t& p = parts[i];
+        if (p.F <= 0 || p.F > 16 || !p.x) return NMARL_EINVAL;
+        if (p.nbr_idx ? (p.gather_A <= 0 || p.m_max <= 0 || p.F != p.gather_A * p.m_max || p.x_row < p.gather_A) : p.x_row < p.F)
+            return NMARL_EINVAL;
+        ps.p[i] = p;
+    }
+    if (!view_ok(dy, dy_sn, dy_row, rows, 2 * J) || ((uintptr_t)dy % 16) || (dy_sn % 4) || (dy_row % 4)) return NMARL_EINVAL;
+    if (relu_bits ? (act != 1 || bits_sn < rows * 4) : (!view_ok(y, y_sn, y_row, rows, 2 * J) || ((uintptr_t)y % 16) || (y_sn % 4) || (y_row % 4)))
+        return NMARL_EINVAL;
+    const int C = nmarl_fc_bwd_chunks(rows, N);          // the two-launch form's partition of the rows (same partial sums)
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    const int tpb = (int)((tiles + C - 1) / C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (relu_bits)
+        hipLaunchKernelGGL(fc_bwd_pair_kernel<true>, dim3(C, N), dim3(512), 0, st, rows, tpb, ps, y, y_sn, y_row, relu_bits, bits_sn, dy, dy_sn,
+                           dy_row, act, partial);
+    else
+        hipLaunchKernelGGL(fc_bwd_pair_kernel<false>, dim3(C, N), dim3(512), 0, st, rows, tpb, ps, y, y_sn, y_row, relu_bits, bits_sn, dy, dy_sn,
+                           dy_row, act, partial);
+    hipLaunchKernelGGL(fc_bwd_pair_reduce_kernel, dim3((2 * 17 * J + 255) / 256, N), dim3(256), 0, st, C, partial, dwb);
+    return nmarl_check_launch();
 }
 
 extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const float* h, int64_t h_sn,

@@ -534,6 +534,7 @@ struct XArgs {
     const float *e_wob, *e_bob, *e_wfp, *e_bfp;   // [N][15][64], [N][64], [N][8][64], [N][64] (the parameter tensors themselves)
     int64_t e_wob_sn, e_bob_sn, e_wfp_sn, e_bfp_sn;
     float* e_out; int64_t e_out_sn, e_out_row;    // where the encoded LSTM input [N][E][128] is kept for the update (may be NULL)
+    unsigned* e_bits; int64_t e_bits_sn;          // [N][E][4] words: which of the 128 encoder outputs are > 0 (nmarl_step_enc_t.relu_bits; may be NULL)
     int e_nbr[64];                                // neighbour table [N][2] (-1 padded) BY VALUE: no dependent table load
     // ENC 1 + ev_on: the CACC env step of THIS lock-step behind the action draw (see the ENV block at the end of the kernel)
     int ev_on, ev_auto_reset;
@@ -648,6 +649,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const float* const e_wob = xa.e_wob; const float* const e_bob = xa.e_bob;
     const float* const e_wfp = xa.e_wfp; const float* const e_bfp = xa.e_bfp;
     float* const e_out = xa.e_out;
+    unsigned* const e_bits = xa.e_bits;
+    const int64_t e_bits_sn = xa.e_bits_sn;
     const int64_t e_ob_row = xa.e_ob_row, e_fp_sn = xa.e_fp_sn, e_wob_sn = xa.e_wob_sn, e_bob_sn = xa.e_bob_sn, e_wfp_sn = xa.e_wfp_sn,
                   e_bfp_sn = xa.e_bfp_sn, e_out_sn = xa.e_out_sn, e_out_row = xa.e_out_row;
     int e_nb0 = -1, e_nb1 = -1;
@@ -655,7 +658,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const int ns_ = __builtin_amdgcn_readfirstlane(n);
         e_nb0 = xa.e_nbr[2 * ns_]; e_nb1 = xa.e_nbr[2 * ns_ + 1];
         asm volatile("" :: "s"(e_ob), "s"(e_fp), "s"(e_wob), "s"(e_bob), "s"(e_wfp), "s"(e_bfp), "s"(e_out), "s"(e_ob_row), "s"(e_fp_sn),
-                     "s"(e_wob_sn), "s"(e_bob_sn), "s"(e_wfp_sn), "s"(e_bfp_sn), "s"(e_out_sn), "s"(e_out_row), "s"(e_nb0), "s"(e_nb1));
+                     "s"(e_wob_sn), "s"(e_bob_sn), "s"(e_wfp_sn), "s"(e_bfp_sn), "s"(e_out_sn), "s"(e_out_row), "s"(e_nb0), "s"(e_nb1), "s"(e_bits),
+                     "s"(e_bits_sn));
     }
     const int64_t row_blk = (int64_t)blk_u * ROWS_B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1028,11 +1032,16 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             eacc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].w, ein[s_], eacc[7], 0, 0, 0);
         }
         NMARL_STAMP(50)
+        unsigned pos = 0;                    // bit 4 mt + i: output 16 mt + 4 grp + i of row c is > 0 (the relu derivative the update needs)
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             eacc[mt] = __builtin_elementwise_max(eacc[mt], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
             xslot[512 * mt] = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};      // (lane-private: re-read by this lane only)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pos |= (eacc[mt][i] > 0.0f ? 1u : 0u) << (4 * mt + i);
         }
+        // one word per lane, 16 bytes per row: the update's encoder backward reads these instead of the 512-byte row of S
+        if (e_bits != nullptr && row0 + c < a.E) e_bits[(int64_t)n * e_bits_sn + (row0 + c) * 4 + grp] = pos;
         NMARL_STAMP(51)
         a0 = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
         a1 = float4{eacc[1][0], eacc[1][1], eacc[1][2], eacc[1][3]};
@@ -1816,6 +1825,8 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.e_wob = enc->w_ob; xa.e_bob = enc->b_ob; xa.e_wfp = enc->w_fp; xa.e_bfp = enc->b_fp;
         xa.e_wob_sn = enc->w_ob_sn; xa.e_bob_sn = enc->b_ob_sn; xa.e_wfp_sn = enc->w_fp_sn; xa.e_bfp_sn = enc->b_fp_sn;
         xa.e_out = enc->out; xa.e_out_sn = enc->out_sn; xa.e_out_row = enc->out_row;
+        if (enc->relu_bits && (((uintptr_t)enc->relu_bits % 4) || enc->relu_bits_sn < E * 4)) return NMARL_EINVAL;
+        xa.e_bits = enc->relu_bits; xa.e_bits_sn = enc->relu_bits_sn;
         for (int i = 0; i < 64; ++i) xa.e_nbr[i] = i < 2 * N ? enc->nbr[i] : -1;
         if (enc->env) {
             // the CACC env step of this lock-step behind the action draw (ENV block of the kernel)

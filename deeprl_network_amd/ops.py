@@ -326,12 +326,23 @@ def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
         os.environ.get('NMARL_INKERNEL_ENCODE', '1') != '0'
 
 
-def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None):
+def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None, bits=None):
     """Description of a lock-step's input encoders for `lstm_step_policy_value(xs=(spec, wx, image))`: ob [E,N,5] the env's
     compact observation, fp [N,E,4] the previous-step policies, the four parameter tensors as they are, nbrs = the HOST
     neighbour lists (ascending), out [N,E,128] (a view: slot t of the saved LSTM inputs) or None.
-    env (optional): the CACC env step of this lock-step inside the launch as well -- CACCBatchEnv.inkernel_step(...)."""
-    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out, env=env)
+    env (optional): the CACC env step of this lock-step inside the launch as well -- CACCBatchEnv.inkernel_step(...).
+    bits (optional): [N,E,4] int32 -- which of a row's 128 outputs are > 0 (layout: relu_bits_pack), for fc_concat(bits=)."""
+    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out, env=env, bits=bits)
+
+
+def relu_bits_pack(S):
+    """The bit image of (S > 0) for S [..., 128] in the layout the lock-step kernel writes (nmarl_step_enc_t.relu_bits):
+    [..., 4] int32, bit 4 t + i of word q <=> S[..., 16 t + 4 q + i] > 0.  (Tests and the CPU emulation; the product's
+    image comes out of the kernel.)"""
+    pos = (S > 0).reshape(*S.shape[:-1], 8, 4, 4).to(torch.int64)              # [.., t, q, i]
+    sh = (4 * torch.arange(8, device=S.device).view(8, 1, 1) + torch.arange(4, device=S.device).view(1, 1, 4))
+    w = (pos << sh).sum(dim=(-3, -1))                                            # [.., q]
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
 
 
 def step_env_supported():
@@ -371,6 +382,11 @@ def _step_enc(d, N, E):
     out = d.get('out')
     if out is not None:
         e.out, e.out_sn, e.out_row = _rows_view(out, 2 * FC_J, 'step_enc out')
+    bits = d.get('bits')
+    if bits is not None:
+        if bits.shape != (N, E, 4) or bits.dtype != torch.int32 or bits.stride(2) != 1 or bits.stride(1) != 4:
+            raise _lib.NmarlError('step_enc: bits must be [N,E,4] int32 with contiguous panels')
+        e.relu_bits, e.relu_bits_sn = ptr(bits, torch.int32, strided=True), bits.stride(0)
     e.F, e.A, e.m_max = 5, 4, 2
     for i in range(64):
         e.nbr[i] = -1
@@ -638,6 +654,61 @@ def fc_bwd(x, y, dy, act, nbr_idx=None):
     return dw, db
 
 
+def fc_bwd_pair_supported(xs, idxs, S, dS):
+    """Both layers of a two-part encoding in one pass (nmarl_fc_bwd_pair): two parts with <= 16 inputs each, 16-byte rows."""
+    if len(xs) != 2 or os.environ.get('NMARL_FC_BWD_PAIR', '1') == '0':
+        return False
+    for x, idx in zip(xs, idxs):
+        if (x.shape[2] if idx is None else x.shape[2] * idx.shape[1]) > 16 or x.stride(2) != 1:
+            return False
+    for t in (S, dS):
+        if t.shape[2] != 2 * FC_J or t.stride(2) != 1 or t.stride(1) % 4 or t.stride(0) % 4 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def fc_bwd_pair(xs, idxs, S, dS, act, bits=None):
+    """[(dw_0, db_0), (dw_1, db_1)] of S = [act(x_0 w_0 + b_0) | act(x_1 w_1 + b_1)] in ONE pass over dS [N,rows,128]: the sums
+    are formed exactly as two fc_bwd calls form them.  bits [N,rows,4] int32 (relu only): the sign image of S its producer
+    wrote (step_enc_spec(bits=)) -- S is then not read at all."""
+    N, rows = dS.shape[:2]
+    arr = (_lib.FcPart * 2)()
+    Fs = []
+    for i, (x, idx) in enumerate(zip(xs, idxs)):
+        pt = arr[i]
+        pt.x, pt.x_sn, pt.x_row = _rows_view(x, x.shape[2], 'fc_bwd_pair x')
+        if idx is None:
+            pt.F = x.shape[2]
+        else:
+            pt.gather_A, pt.m_max, pt.F = x.shape[2], idx.shape[1], x.shape[2] * idx.shape[1]
+            pt.nbr_idx = ptr(idx, torch.int32)
+        Fs.append(pt.F)
+    gp, gs, gr = _rows_view(dS, 2 * FC_J, 'fc_bwd_pair dS')
+    if bits is not None:
+        if act != BIAS_RELU or bits.shape != (N, rows, 4) or bits.dtype != torch.int32 or not bits.is_contiguous():
+            raise _lib.NmarlError('fc_bwd_pair: bits must be a contiguous [N,rows,4] int32 image of a relu layer')
+        yp, ys, yr, bp, bs = None, 0, 0, ptr(bits, torch.int32), rows * 4
+    else:
+        (yp, ys, yr), bp, bs = _rows_view(S, 2 * FC_J, 'fc_bwd_pair S'), None, 0
+    C_ = lib.nmarl_fc_bwd_chunks(rows, N)
+    partial = torch.empty(N, C_, 2, 17, FC_J, dtype=F32, device=dS.device)
+    dwb = torch.empty(N, 2, 17, FC_J, dtype=F32, device=dS.device)
+    check(lib.nmarl_fc_bwd_pair(rows, N, arr, yp, ys, yr, bp, bs, gp, gs, gr, act, ptr(partial), ptr(dwb), stream()), 'nmarl_fc_bwd_pair')
+    return [(dwb[:, i, :F], dwb[:, i, 16]) for i, F in enumerate(Fs)]
+
+
+def _fc_concat_backward(ctx, S, xs, dS, bits=None):
+    if dS.stride(2) != 1:
+        dS = dS.contiguous()
+    if fc_bwd_pair_supported(xs, ctx.idxs, S, dS):
+        return [g for dw, db in fc_bwd_pair(xs, ctx.idxs, S, dS, ctx.act, bits=bits) for g in (None, dw, db, None)]
+    grads = []
+    for i, x in enumerate(xs):
+        dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act, nbr_idx=ctx.idxs[i])
+        grads += [None, dw, db, None]
+    return grads
+
+
 class _FcConcat(torch.autograd.Function):
     """S = [act(x_1 w_1 + b_1) | act(x_2 w_2 + b_2) | ...]  (tf.concat of per-input fc layers, policies.py:176-181,
     agents/utils.py:186-199) for DATA inputs x_i (no dx): each block is written in place into S, and the backward
@@ -661,49 +732,39 @@ class _FcConcat(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dS):
         S, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        if dS.stride(2) != 1:
-            dS = dS.contiguous()
-        grads = [None]
-        for i, x in enumerate(xs):
-            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act, nbr_idx=ctx.idxs[i])
-            grads += [None, dw, db, None]
-        return tuple(grads)
+        return tuple([None] + _fc_concat_backward(ctx, S, xs, dS))
 
 
 class _FcConcatSaved(torch.autograd.Function):
-    """_FcConcat whose output S the rollout already computed (same weights, same inputs): no forward work."""
+    """_FcConcat whose output S the rollout already computed (same weights, same inputs): no forward work.  bits: the sign
+    image of S (relu layers), when the rollout's kernel wrote one."""
 
     @staticmethod
-    def forward(ctx, act, S, *args):
+    def forward(ctx, act, S, bits, *args):
         xs = args[0::4]
-        ctx.act, ctx.idxs = act, args[3::4]
+        ctx.act, ctx.idxs, ctx.bits = act, args[3::4], bits
         ctx.save_for_backward(S, *xs)
         return S.view_as(S)
 
     @staticmethod
     def backward(ctx, dS):
         S, xs = ctx.saved_tensors[0], ctx.saved_tensors[1:]
-        if dS.stride(2) != 1:
-            dS = dS.contiguous()
-        grads = [None, None]
-        for i, x in enumerate(xs):
-            dw, db = fc_bwd(x, S[:, :, i * FC_J:(i + 1) * FC_J], dS[:, :, i * FC_J:(i + 1) * FC_J], ctx.act, nbr_idx=ctx.idxs[i])
-            grads += [None, dw, db, None]
-        return tuple(grads)
+        return tuple([None, None, None] + _fc_concat_backward(ctx, S, xs, dS, bits=ctx.bits))
 
 
-def fc_concat(parts, act, saved=None):
+def fc_concat(parts, act, saved=None, bits=None):
     """parts: [(x_i [N,rows,F_i], w_i [N,F_i,64], b_i [N,64][, nbr_idx_i]), ...] with data inputs -> [N,rows,64*len(parts)]
     (differentiable w.r.t. w_i, b_i).  nbr_idx_i [N,m_max] (optional): layer i's input is gather(x_i) over the neighbour
     table, x_i [*,rows,A] read in place (the env's compact observation, the fingerprints).  Inputs wider than 64 or layers
     not 64 wide: plain batched GEMMs.
-    saved: the output as the rollout computed it with the current weights -- only the backward is set up."""
+    saved: the output as the rollout computed it with the current weights -- only the backward is set up (bits: with it, the
+    [N,rows,4] int32 sign image of that output, relu_bits_pack's layout: the backward then does not read the output)."""
     parts = [tuple(pt) + (None,) * (4 - len(pt)) for pt in parts]
     if all((idx is not None or fc_supported(x, w)) and w.shape[1] <= FC_MAX_F and w.shape[2] == FC_J and not x.requires_grad
            for x, w, _, idx in parts):
         flat = [t for part in parts for t in part]
         if saved is not None:
-            return _FcConcatSaved.apply(act, saved, *flat)
+            return _FcConcatSaved.apply(act, saved, bits, *flat)
         return _FcConcat.apply(act, *flat)
     f = {BIAS_NONE: lambda t: t, BIAS_RELU: torch.relu, BIAS_TANH: torch.tanh}[act]
     ys = [f(torch.baddbmm(b.unsqueeze(1), x if idx is None else nbr_gather(x, idx), w)) for x, w, b, idx in parts]

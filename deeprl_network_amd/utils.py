@@ -414,7 +414,7 @@ class BatchedTrainer:
             self._restore(snap)
             # host-side per-batch state the captured rollout set (a replay runs no Python): the update's "the rollout saved the
             # encoder outputs" flag is cleared by every update and must be raised again after every replay
-            self._graph_flags = {k: bool(getattr(self.model.policy, k, False)) for k in ('_enc_was_saved', '_mm_was_saved')}
+            self._graph_flags = {k: getattr(self.model.policy, k, False) for k in ('_enc_was_saved', '_mm_was_saved', '_bits_steps')}
         self.model.t = 0
         self.graph.replay()
         self.model.t = self.n_step
@@ -459,7 +459,7 @@ class BatchedTrainer:
                 tunable.tuning_enable(False)          # a timing loop inside a capture would invalidate it (every shape is tuned by now)
         except Exception:
             tun = None
-        host = (m.t, m.policy._enc_was_saved, m.policy._mm_was_saved)
+        host = (m.t, m.policy._enc_was_saved, m.policy._mm_was_saved, m.policy._bits_steps)
         ops.keepalive_begin(self._keepalive)
         try:
             torch.cuda.synchronize()
@@ -480,7 +480,7 @@ class BatchedTrainer:
             self._upd = dict(grads=g1, apply=g2, epilogue_inside=inside)
         finally:
             ops.keepalive_end()
-            m.t, m.policy._enc_was_saved, m.policy._mm_was_saved = host
+            m.t, m.policy._enc_was_saved, m.policy._mm_was_saved, m.policy._bits_steps = host
             if tun is not None:
                 tun.tuning_enable(True)
 
@@ -594,10 +594,12 @@ class BatchedTrainer:
             cache[key] = self._build_eval(*key)
         ev = cache[key]
         E0 = self.model.E
+        ev['prepare']()
         if ev['graph'] is not None:
             ev['graph'].replay()
         else:
             ev['episode']()
+        ev['statistics']()
         assert self.model.E == E0                     # evaluation used its own state tensors only
         hist, total, steps = ev['hist'], ev['total'], ev['steps']
         self.last_eval_action_share = (hist / hist.sum().clamp_min(1)).cpu().numpy().round(4).tolist()
@@ -627,12 +629,18 @@ class BatchedTrainer:
         a_ids = torch.arange(A, device=dev).view(1, 1, 1, -1)
         fused = p.fused_heads
 
-        def episode():
+        def prepare():
             env.episode.zero_()                       # the same test episode every time
-            env.reset()
             hs[0].zero_()
             cs[0].zero_()
             fps[0].copy_(model.fp_uniform.expand_as(fps[0]))
+
+        def episode():
+            # (captured: launches of this library only -- the state resets in front and the statistics behind run eagerly around
+            # the replay.  With the aten fills / copies / reductions inside, a graph captured BEFORE the trainer's first batch
+            # replayed its reductions on stale data once the trainer's own graphs existed: the episode's reward sums came out
+            # right and the action histogram did not (seen in round 5's learning runs; tests/test_gpu_trainer.py pins it).)
+            env.reset()
             p.refresh_wimage()
             for t in range(T):
                 a, b = t & 1, (t + 1) & 1
@@ -646,6 +654,8 @@ class BatchedTrainer:
                         fps[b].copy_(p.pi(hs[b]))
                     ops.sample_actions(fps[b], acts[t], ops.SAMPLE_ARGMAX)
                 env.step(acts[t], reward_out=rew, done_out=D[t], greward_out=G[t])
+
+        def statistics():
             # alive[t] = no `done` before step t; an episode's statistics stop with its first done
             dd = D.to(torch.float64)
             alive = torch.cat([torch.ones(1, n_envs, **f64), torch.cumprod(1.0 - dd, dim=0)[:-1]], dim=0)
@@ -658,13 +668,15 @@ class BatchedTrainer:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
+                prepare()
                 episode()                             # warm-up (allocator, library handles)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 episode()
-        return dict(env=env, episode=episode, graph=graph, hist=hist, total=total, steps=steps)
+        return dict(env=env, prepare=prepare, episode=episode, statistics=statistics, graph=graph, hist=hist, total=total, steps=steps,
+                    acts=acts, done=D)
 
     def run(self, log_every=10, eval_every=None):
         """Train until the counter says stop (`total_step` lock-steps per replica); one row per `log_every` batches.

@@ -473,6 +473,10 @@ typedef struct nmarl_step_enc {
     float* obs_out; float* reward; uint8_t* done; float* global_reward;
     int32_t auto_reset, pad2_; uint64_t seed; int64_t env_id_base; int32_t* episode;
     uint32_t* cnt;
+    /* relu_bits (may be NULL): [N][E][4] uint32 with agent stride relu_bits_sn words -- which of the 128 encoder outputs of a row are
+     * > 0: bit 4 t + i of word q <=> out[row, 16 t + 4 q + i] > 0.  nmarl_fc_bwd_pair takes the relu derivative from these 16 bytes
+     * per row instead of re-reading the 512-byte row of `out`. */
+    uint32_t* relu_bits; int64_t relu_bits_sn;
 } nmarl_step_enc_t;
 int nmarl_lstm_step_env_words(int64_t E);
 int nmarl_lstm_step_x_enc(int64_t E, int32_t N, int32_t H, int32_t KX, const float* h_in, int64_t h_sn, const float* img,
@@ -649,6 +653,16 @@ typedef struct nmarl_fc_part {
 int nmarl_fc_fwd_multi(int64_t rows, int32_t N, int32_t n_parts, const nmarl_fc_part_t* parts, int32_t act,
                        float* y, int64_t y_sn, int64_t y_row, void* stream);
 int nmarl_fc_bwd_chunks(int64_t rows, int32_t N);
+/* The backward of BOTH layers of a two-part encoding [act(x_0 w_0 + b_0) | act(x_1 w_1 + b_1)] (fcs || fcp of policies.py:176-181)
+ * in one pass over dy [N,rows,128] (16-byte aligned rows): parts[0..1] name the inputs as in nmarl_fc_fwd_multi (F <= 16; w / b
+ * unused), y [N,rows,128] the saved encoding.  relu_bits != NULL (act = relu only) replaces y by a bit image its producer wrote,
+ * [N,rows,4] uint32 with agent stride bits_sn words: bit 4 t + i of word q of a row <=> y[row, 16 t + 4 q + i] > 0
+ * (nmarl_step_enc_t.relu_bits) -- 16 bytes per row instead of 512.  partial [N, nmarl_fc_bwd_chunks(rows,N), 2, 17, 64];
+ * dwb [N, 2, 17, 64] receives dw of part p in rows 0..F_p-1 (zeros up to row 15) and db in row 16.  The sums are formed in the
+ * order of two nmarl_fc_bwd calls (bit-identical results). */
+int nmarl_fc_bwd_pair(int64_t rows, int32_t N, const nmarl_fc_part_t* parts, const float* y, int64_t y_sn, int64_t y_row,
+                      const uint32_t* relu_bits, int64_t bits_sn, const float* dy, int64_t dy_sn, int64_t dy_row, int32_t act,
+                      float* partial, float* dwb, void* stream);
 int nmarl_fc_bwd(int64_t rows, int32_t N, int32_t F, int32_t J, const float* x, int64_t x_sn, int64_t x_row,
                  const float* y, int64_t y_sn, int64_t y_row, const float* dy, int64_t dy_sn, int64_t dy_row,
                  int32_t act, float* partial, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);

@@ -305,7 +305,7 @@ def fc_bwd(x, y, dy, act, nbr_idx=None):
     return torch.bmm(x.transpose(1, 2), g), g.sum(1)
 
 
-def fc_concat(parts, act, saved=None):
+def fc_concat(parts, act, saved=None, bits=None):
     """tf.concat of per-input fc layers (policies.py:176-181, agents/utils.py:186-199), plain autograd."""
     parts = [tuple(pt) + (None,) * (4 - len(pt)) for pt in parts]
     ys = [_act(torch.baddbmm(b.unsqueeze(1), x if idx is None else nbr_gather(x, idx), w), act) for x, w, b, idx in parts]
@@ -338,9 +338,18 @@ def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
     return n_feat == 5 and n_a == 4 and m_max == 2 and n_fc == 64 and n_h == 64 and N <= 32
 
 
-def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None):
+def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None, bits=None):
     assert env is None, 'the in-launch env step exists on the device only (tests compare it with the env kernel there)'
-    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out)
+    return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out, bits=bits)
+
+
+def relu_bits_pack(S):
+    """Sign image of S [..., 128] as the product's lock-step kernel writes it (include/nmarl.h nmarl_step_enc_t.relu_bits):
+    [..., 4] int32, bit 4 t + i of word q <=> S[..., 16 t + 4 q + i] > 0."""
+    pos = (S > 0).reshape(*S.shape[:-1], 8, 4, 4).to(torch.int64)
+    sh = 4 * torch.arange(8).view(8, 1, 1) + torch.arange(4).view(1, 1, 4)
+    w = (pos << sh.to(S.device)).sum(dim=(-3, -1))
+    return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32)
 
 
 def step_enc_forward(d):
@@ -359,6 +368,8 @@ def step_enc_forward(d):
     S = torch.stack(rows, dim=0)
     if d.get('out') is not None:
         d['out'].copy_(S)
+    if d.get('bits') is not None:
+        d['bits'].copy_(relu_bits_pack(S))
     return S
 
 

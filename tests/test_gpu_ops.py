@@ -1351,7 +1351,8 @@ def test_lstm_step_x_input_encoders_inside_the_launch(N, E, mode):
     img = ops.lstm_wimage(cu(d['wx']), cu(d['wh']))
     Sbuf = torch.full((N, 3, E, KX), -7.0, device='cuda')
     ob_g, fp_g = cu(ob), cu(fp)
-    spec = ops.step_enc_spec(ob_g, fp_g, cu(w_ob), cu(b_ob), cu(w_fp), cu(b_fp), nbrs, out=Sbuf[:, 1])
+    bits = torch.full((N, 3, E, 4), 0x5a5a5a5a, dtype=torch.int32, device='cuda')
+    spec = ops.step_enc_spec(ob_g, fp_g, cu(w_ob), cu(b_ob), cu(w_fp), cu(b_fp), nbrs, out=Sbuf[:, 1], bits=bits[:, 1])
     hg, cg = cu(d['h']), cu(d['c'])
     ho, co, gg = torch.empty_like(hg), torch.empty_like(cg), torch.empty(N, E, 4 * H, device='cuda')
     pig, actg, vg = torch.zeros(N, E, A, device='cuda'), torch.zeros(E, N, dtype=torch.uint8, device='cuda'), torch.zeros(N, E, device='cuda')
@@ -1360,6 +1361,9 @@ def test_lstm_step_x_input_encoders_inside_the_launch(N, E, mode):
                                defer_action_term=True, **draw)
     torch.cuda.synchronize()
     assert torch.all(Sbuf[:, 0] == -7.0) and torch.all(Sbuf[:, 2] == -7.0)
+    # the sign image of the encoder outputs (what the update's encoder backward reads instead of S): exactly (S > 0), packed
+    assert torch.equal(bits[:, 1], ops.relu_bits_pack(Sbuf[:, 1])) and torch.all(bits[:, 0] == 0x5a5a5a5a) and torch.all(bits[:, 2] == 0x5a5a5a5a)
+    assert torch.equal(bits[:, 1].cpu(), ops_ref.relu_bits_pack(Sbuf[:, 1].cpu()))
     tol = dict(rtol=3e-5, atol=5e-6)
     torch.testing.assert_close(Sbuf[:, 1].cpu().double(), S_r, **tol)
     torch.testing.assert_close(ho.cpu().double(), hr, **tol)
@@ -1392,3 +1396,46 @@ def test_lstm_step_x_input_encoders_inside_the_launch(N, E, mode):
                                cu(d['v_w']), cu(d['v_b']), cu(d['idx']), A, v3, xs=(spec3, None, img), h_out=h3, c_out=c3,
                                defer_action_term=True, **draw)
     assert torch.equal(h3, ho) and torch.equal(v3, vg) and torch.equal(act3, actg)
+
+
+@pytest.mark.parametrize('N,rows,gather', [(8, 60 * 4096, True), (3, 1000, True), (2, 64 * 33 + 5, False), (5, 7, False)])
+def test_fc_bwd_pair_equals_two_fc_bwd_launches(N, rows, gather):
+    """nmarl_fc_bwd_pair: both layers of [relu(x_0 w_0 + b_0) | relu(x_1 w_1 + b_1)] in ONE pass over dS -- bit-identical to
+    two nmarl_fc_bwd(_gather) launches (same partition of the rows, same order of every sum), with the relu derivative taken
+    from S or from the 16-byte-per-row sign image (relu_bits_pack's layout, what the lock-step kernel's encoders write);
+    BASELINE size, ragged row counts, gathered and plain inputs, tanh."""
+    from deeprl_network_amd import ops
+    g = torch.Generator().manual_seed(N * 977 + rows)
+    r = lambda *s: torch.randn(*s, generator=g).cuda()                                    # noqa: E731
+    if gather:
+        nbrs = [[j for j in (i - 1, i + 1) if 0 <= j < N] for i in range(N)]
+        nbr_idx = -torch.ones(N, 2, dtype=torch.int32)
+        for i, lst in enumerate(nbrs):
+            nbr_idx[i, :len(lst)] = torch.tensor(lst, dtype=torch.int32)
+        nbr_self = torch.cat([torch.arange(N, dtype=torch.int32).view(-1, 1), nbr_idx], dim=1).cuda()
+        xs = [r(rows, N, 5).transpose(0, 1), torch.softmax(r(N, rows, 4), dim=-1)]      # the compact slab [rows,N,5] read in place
+        idxs = [nbr_self, nbr_idx.cuda()]
+        Fs = [15, 8]
+    else:
+        xs, idxs, Fs = [r(N, rows, 16), r(N, rows, 3)], [None, None], [16, 3]
+    ws = [r(N, F, 64) * 0.3 for F in Fs]
+    bs = [r(N, 64) * 0.1 for _ in Fs]
+    for act in (ops.BIAS_RELU, ops.BIAS_TANH):
+        S = ops.fc_fwd_multi([(x, w, b, i) for x, w, b, i in zip(xs, ws, bs, idxs)], act)
+        dS = r(N, rows, 128)
+        two = [ops.fc_bwd(x, S[:, :, 64 * k:64 * k + 64], dS[:, :, 64 * k:64 * k + 64], act, nbr_idx=i) for k, (x, i) in enumerate(zip(xs, idxs))]
+        assert ops.fc_bwd_pair_supported(xs, idxs, S, dS)
+        variants = [ops.fc_bwd_pair(xs, idxs, S, dS, act)]
+        if act == ops.BIAS_RELU:
+            variants.append(ops.fc_bwd_pair(xs, idxs, None, dS, act, bits=ops.relu_bits_pack(S)))
+        for one in variants:
+            for (dw2, db2), (dw1, db1) in zip(two, one):
+                assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+        # and against the definition (float64)
+        if not gather:
+            xg = xs
+            d = (S > 0).double() if act == ops.BIAS_RELU else 1.0 - S.double() ** 2
+            G = dS.double() * d
+            for k in range(2):
+                torch.testing.assert_close(variants[0][k][0].double(), torch.bmm(xg[k].double().transpose(1, 2), G[:, :, 64 * k:64 * k + 64]),
+                                           rtol=1e-4, atol=1e-3 * max(1.0, rows ** 0.5 / 30))

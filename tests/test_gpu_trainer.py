@@ -134,6 +134,72 @@ def test_episode_bookkeeping_on_gpu():
     assert np.isfinite(m) and 0 <= c <= 32
 
 
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+def test_one_pass_encoder_backward_equals_two_launches(agent, monkeypatch):
+    """The update's encoder backward as ONE pass over dS (nmarl_fc_bwd_pair; IA2C-FP: the relu derivative from the 16-byte sign
+    image the lock-step kernel wrote, S itself not read) against the two fc_bwd launches: weights, optimiser slots and actions
+    bit-identical after 4 batches at the BASELINE size (hipGraph rollout and update)."""
+    runs = []
+    for pair in ('1', '0'):
+        monkeypatch.setenv('NMARL_FC_BWD_PAIR', pair)
+        env, model, tr = build(agent, 4096, True)
+        for _ in range(4):
+            tr.run_batch()
+        torch.cuda.synchronize()
+        assert (model.S_bits is not None) == (pair == '1' and agent == 'ia2c_fp')
+        runs.append((model.policy.params.flat.clone(), model.policy.params.ms.clone(), model.buf_act.clone(), tr.R_end.clone()))
+        del env, model, tr
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
+def test_graphs_equal_eager_over_many_batches_with_evaluations_in_between():
+    """12 batches: rollout + update graphs (with a test episode before the first batch and after every third: its graph shares
+    the device with the trainer's) against eager launches without any evaluation -- weights, optimiser slots, env state and
+    actions bit-identical.  Evaluation touches nothing the training reads."""
+    runs = []
+    for use_graph in (True, False):
+        env, model, tr = build('ia2c_fp', 4096, use_graph)
+        if use_graph:
+            tr.evaluate(n_envs=64)
+        for b in range(12):
+            tr.run_batch()
+            if use_graph and b % 3 == 2:
+                tr.evaluate(n_envs=64)
+        torch.cuda.synchronize()
+        runs.append((model.policy.params.flat.clone(), model.policy.params.ms.clone() if hasattr(model.policy.params, 'ms') else env.v.clone(),
+                     env.h.clone(), model.buf_act.clone(), tr.R_end.clone()))
+        del env, model, tr
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+def test_evaluation_graph_built_before_training_stays_right(agent):
+    """The test-episode hipGraph captured BEFORE the first training batch, replayed after the trainer's rollout and update graphs
+    exist and the weights moved: reward sums, episode lengths and the action histogram equal the same episode launched eagerly
+    and a histogram counted from the recorded actions.  (Round 5: with the aten statistics inside the captured graph the
+    histogram came out as [600, 600, 600, 600] from the third batch on while the reward sums stayed right.)"""
+    env, model, tr = build(agent, 4096, True)
+    tr.evaluate(n_envs=64)
+    for b in range(6):
+        tr.run_batch()
+        m, s, c = tr.evaluate(n_envs=64)
+        ev = list(tr._eval_cache.values())[0]
+        assert ev['graph'] is not None and len(tr._eval_cache) == 1
+        got = (m, s, c, list(tr.last_eval_action_share), ev['hist'].clone(), ev['total'].clone(), ev['steps'].clone(), ev['acts'].clone())
+        acts, D = ev['acts'], ev['done'].double()
+        T, n = D.shape
+        alive = torch.cat([torch.ones(1, n, dtype=torch.float64, device=D.device), torch.cumprod(1.0 - D, dim=0)[:-1]], dim=0)
+        counted = torch.stack([((acts == k).double() * alive.view(T, n, 1)).sum() for k in range(model.n_a)])
+        assert torch.equal(got[4], counted), 'batch %d: histogram %s, counted %s' % (b + 1, got[4].tolist(), counted.tolist())
+        assert got[4].sum().item() == alive.sum().item() * env.n_agent
+        ev['prepare'](); ev['episode'](); ev['statistics']()            # the same episode as eager launches
+        torch.cuda.synchronize()
+        assert torch.equal(got[7], ev['acts']) and torch.equal(got[5], ev['total']) and torch.equal(got[6], ev['steps'])
+        assert torch.equal(got[4], ev['hist'])
+
+
 def test_saved_activations_equal_recomputed_forward():
     """Uncoupled nets: the update fed by the rollout's saved activations == the update that recomputes its forward pass
     (3 batches at E = 4096: weights, values, returns)."""

@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // The message pre-phase.  second_c = true_type: the VALUE re-step's message term (HEAD 4), from the neighbours' NEW h (h_new,
     // written through by their blocks earlier in this launch: L1-bypassing loads); nothing of it is kept.
     // msg_phase: U / W hold round 0 already (first phase: requested before the prologue's barrier)
+    int grp_w = grp;                        // (the lane's row group as the tile WRITES address it: see CP_PARK behind the K loop)
     auto msg_phase = [&](auto second_c, float4 (&U)[16], float (&W)[4]) {
         constexpr bool SECOND = decltype(second_c)::value;
         f32x4 macc[4];
@@ -1153,7 +1154,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 if (OBENC && !SECOND && ob_here) e4 = encv[r];       // computed above (no dependence on the store just issued)
                 v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
             }
-            float* t_ = a_tile + (4 * grp + r) * APITCH + 4 * c;
+            float* t_ = a_tile + (4 * grp_w + r) * APITCH + 4 * c;
             t_[0] = v.x; t_[1] = v.y; t_[2] = v.z; t_[3] = v.w;
             if (xo && row0 + 4 * grp + r < a.E) *reinterpret_cast<float4*>(xo + (row0 + 4 * grp + r) * xa.xm_row + 4 * c) = v;
         }
@@ -1192,6 +1193,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // re-step's kept x-side part is just the bias -- re-read it instead of holding 64 registers through the K loop
     constexpr bool ZS_BIAS = HEAD == 4 && MSG == 2;
     f32x4 zs[PV && !ZS_BIAS ? 16 : 1];
+    // HEAD 4 with lstm_comm's message term: 256 VGPRs hold everything but one float4 through the K loop -- the previous cell state
+    // of the lane's fourth row waits in a lane-private LDS slot behind the W_msg image (8 KB of the 9.7 KB left; it went to scratch)
+    constexpr bool CP_PARK = HEAD == 4 && MSG == 1;
+    float4* cp_park = reinterpret_cast<float4*>(m_lds + xa.msg_kc * (CH_K * 64)) + threadIdx.x;
+    if (CP_PARK) *cp_park = float4{cp[0][3], cp[1][3], cp[2][3], cp[3][3]};
     NMARL_A_MASK(0, a0, a1)
     const int lag = DEPH ? (wave >> 2) : 0;      // wave group B computes chunk tau - 1 in tick tau
     if (DEPH && lag) __builtin_amdgcn_s_setprio(1);   // the lagging (younger) group wins issue arbitration: its MFMAs are
@@ -1239,6 +1245,13 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         NMARL_CHUNK(buf, a0, a1)
     }
     NMARL_STAMP(20)
+    if (CP_PARK) {
+        const float4 v = *cp_park;
+        cp[0][3] = v.x; cp[1][3] = v.y; cp[2][3] = v.z; cp[3][3] = v.w;
+        int l_ = threadIdx.x;                    // the tile addresses behind the loop are formed again from the thread index (kept
+        asm volatile("" : "+v"(l_));             // across it, one went to scratch)
+        grp_w = (l_ & 63) >> 4;
+    }
     if (nxt_here) {                              // (after the last tick's barrier: the W_msg image is dead)
         float4* d = reinterpret_cast<float4*>(m_lds);
         d[threadIdx.x] = nfa; d[threadIdx.x + 512] = nfb;
@@ -1267,7 +1280,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const f32x4 hv = go * tanh4(cv);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (HEAD != 0) a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = hv[r];   // K loop done: the tile is free
+            if (HEAD != 0) a_tile[(4 * grp_w + r) * APITCH + 4 * c + jj] = hv[r];   // K loop done: the tile is free
             cp[jj][r] = cv[r];                                                     // c' (HEAD 3 / 4: the re-step's previous cell)
             hv_[jj][r] = hv[r];
         }
@@ -1440,7 +1453,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             const f32x4 cv = gf * (cpv * keepv) + gi * gu;
             const f32x4 hv = go * tanh4(cv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a_tile[(4 * grp + r) * APITCH + 4 * c + jj] = hv[r];
+            for (int r = 0; r < 4; ++r) a_tile[(4 * grp_w + r) * APITCH + 4 * c + jj] = hv[r];
         }
         NMARL_STAMP(33)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1679,7 +1692,7 @@ extern "C" int nmarl_handoff_capacity(int32_t which, int32_t K) {
         // the lock-step kernel with a message term (HEAD 4): two chunk buffers + tiles + head weights + the message image (+ the
         // observation encoder's image where it can exist, lstm_ic3: K = 64)
         if (K % CH_K || K > 128) return -1;
-        const size_t lb = (size_t)(LDSX_FLOATS + K * 64 + (K == H ? H * 64 : 0)) * sizeof(float);
+        const size_t lb = (size_t)(LDSX_FLOATS + K * 64 + (K == H ? H * 64 : 0)) * sizeof(float) + (K == H ? 0 : 512 * sizeof(float4));   // (<4,1>: + its parked cell-state slots)
         const int lb_max = (int)((LDSX_FLOATS + CH_FLOATS) * sizeof(float));
         // the instantiation that will be launched: K = 64 is lstm_ic3's <4,2> (different registers / LDS: the encoder image), else
         // lstm_comm's <4,1>; queried once per (device, kind) and kept -- the launch path asks for it at every lock-step
@@ -1893,6 +1906,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mk == 1 && kind == 3) lb_extra += 512 * sizeof(float4);      // HEAD 4 / MSG 1: the parked cell-state slots (CP_PARK)
 #define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb + lb_extra, st, xa)
     if (mk == 0) {
         if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);

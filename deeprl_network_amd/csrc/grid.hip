@@ -89,11 +89,15 @@ constexpr int NQ = NN * NLANE;      // 150 floats of q (and of transit) per repl
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Lds {           // per replica (q / transit live in the block-wide staging arrays: 8 replicas = 4800 contiguous bytes)
-    float D[NN * NL];
-    float space[NN * 4];
+    union {
+        float D[NN * NL];         // phases B, C: the desired link flows (read by the neighbouring nodes' lanes)
+        float wave[NN * NL];      // phases D, E: the wave vectors (D is dead behind phase C's barrier); 16-byte aligned for the emit
+    };
+    union {
+        float space[NN * 4];      // phase B -> C: read by the node's own lane, which then writes
+        float inflow[NN * 4];     // phase C -> D: ... the scaled inflow of the same approach over it
+    };
     float scale[NN * 4];
-    float inflow[NN * 4];
-    float wave[NN * NL];          // offset 2400 B: 16-byte aligned (float4 reads of the compact emit)
 };
 static_assert(offsetof(Lds, wave) % 16 == 0 && sizeof(Lds) % 16 == 0, "Lds::wave must be 16-byte aligned in every array slot");
 

@@ -108,7 +108,8 @@ for a, b in (('%s_pmc_traffic.json', '%s_pmc_traffic.json'), ('%s_pmc_traffic.md
              ('%s_step_timeline.txt', '%s_step_timeline.txt'), ('%s_bptt_timeline.txt', '%s_bptt_timeline.txt'),
              ('%s_mfma_valu_overlap.txt', '%s_mfma_valu_overlap.txt'), ('%s_train_speed.txt', '%s_train_speed.txt'),
              ('%s_learn_grid.json', '%s_learn_grid.json'), ('%s_untraced_breakdown.md', '%s_untraced_breakdown.md'),
-             ('%s_clock_power.txt', '%s_clock_power.txt'), ('%s_ab_lockstep.txt', '%s_ab_lockstep.txt')):
+             ('%s_clock_power.txt', '%s_clock_power.txt'), ('%s_ab_lockstep.txt', '%s_ab_lockstep.txt'), ('%s_fc_pair.txt', '%s_fc_pair.txt'),
+             ('%s_grid_step.txt', '%s_grid_step.txt'), ('%s_determinism.txt', '%s_determinism.txt')):
     if os.path.exists(os.path.join(src, a % tag)):
         shutil.copy(os.path.join(src, a % tag), os.path.join(dst, b % tag))
 print('profiles/%s_* written' % tag)

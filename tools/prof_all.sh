@@ -4,11 +4,15 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 TAG=${1:-r05}
+PART=${2:-all}            # 1: bench line + traces (one box for r05_bench_default.json and r05_bench_kernel_stats.md), 2: counters / timelines / side benches
+if [ "$PART" != 2 ]; then
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 python tools/untraced_breakdown.py gpurun_out/${TAG}_bench_default.json > gpurun_out/${TAG}_untraced_breakdown.md 2>&1
 python tools/clock_power.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_clock_power.txt
 bash tools/ab_lockstep.sh > gpurun_out/${TAG}_ab_lockstep.txt 2>&1
 bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid ma2c_dial_catchup
+fi
+if [ "$PART" = 1 ]; then exit 0; fi
 for c in ma2c_dial_catchup ma2c_cnet_catchup ia2c_cu_catchup; do      # (NeurComm slow-down / catch-up and the CommNet grid: `other_configs` of the default line)
   python bench.py --no-cpu-baseline --steps 10 --config config/config_$c.ini > gpurun_out/${TAG}_bench_$c.json 2> gpurun_out/${TAG}_bench_$c.err
 done
@@ -17,6 +21,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o pmc_FETCH_SIZE --output
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc -o pmc_WRITE_SIZE --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_write.log 2>&1
 python tools/pmc_summary.py /tmp/pmc $TAG gpurun_out > gpurun_out/${TAG}_pmc_summary.log 2>&1
 # shader-clock phase timelines of the lock-step kernels (instrumentation build of csrc/lstm_mfma.hip, tools/step_timeline.py)
+python tools/time_fc_pair.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_fc_pair.txt
+python tools/time_grid_step.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_grid_step.txt
+python tools/determinism.py ma2c_nc slowdown 200 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_determinism.txt
+python tools/determinism.py ia2c_fp catchup 200 2>&1 | grep -v amdgpu.ids >> gpurun_out/${TAG}_determinism.txt
 python tools/microbench/mfma_valu_overlap.py > gpurun_out/${TAG}_mfma_valu_overlap.txt 2>&1
 python tools/train_speed.py > gpurun_out/${TAG}_train_speed.txt 2>&1
 python tools/train_speed.py config/config_ma2c_nc_slowdown.ini 200 >> gpurun_out/${TAG}_train_speed.txt 2>&1
@@ -35,6 +43,7 @@ python tools/step_timeline.py --build > /dev/null 2>&1
   python tools/step_timeline.py 3 enc 2>&1 | grep -v amdgpu.ids; echo
   echo "## python tools/step_timeline.py 3 enc noout  (the same without the saved-activation stores: the bootstrap step)"
   python tools/step_timeline.py 3 enc noout 2>&1 | grep -v amdgpu.ids ) > gpurun_out/${TAG}_step_timeline.txt
+if [ "$PART" = 2 ]; then exit 0; fi
 python -c "
 import json
 d=json.loads(open('gpurun_out/${TAG}_bench_default.json').read().strip().splitlines()[-1])

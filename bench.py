@@ -819,6 +819,20 @@ def main():
                            'v_mfma_f32_16x16x4_f32 (peak %.1f TFLOP/s dense, MI355X_MICROARCH.md); the same launch moves '
                            '%.1f MB of algorithmic HBM bytes (x, h, c in; h, c, gates, pi, v, action out), i.e. it is '
                            'matrix-pipe-bound, not HBM-bound' % (MFMA_F32_PEAK_TFLOPS, bytes_l / 1e6)}
+                if getattr(trainer, 'enc_in_kernel', False) and x_side:
+                    # round 5: this launch also runs both input encoders (matrix-core pre-phase) and, with env_in_kernel, the CACC env
+                    # step -- the work of round 4's SECOND launch per lock-step (cacc_step_encode_kernel, ~10.9 us).  `frac` keeps
+                    # counting the LSTM flops only (comparable with earlier rounds: 48.8 us = 0.56 then); the fields below say what
+                    # else the duration pays for.  Same-box A/B of the three forms: profiles/r05_ab_lockstep.txt.
+                    enc_fl = n_agent * E * 2 * 23 * 64
+                    out['roofline']['absorbed_work'] = {
+                        'input_encoders_flops_per_launch': enc_fl,
+                        'frac_with_encoder_flops': (flops_l + enc_fl) / us_l / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                        'env_step_inside': bool(getattr(trainer, 'env_in_kernel', False)),
+                        'launches_per_lock_step': 1 if getattr(trainer, 'env_in_kernel', False) else 2,
+                        'note': 'the launch replaces lstm_step_x_kernel<3,0,0> + cacc_step_encode_kernel of round 4; a rollout of n_step '
+                                'lock-steps is n_step + 1 of these launches and nothing else but the bootstrap bookkeeping '
+                                '(rollout_graph_us_without_lstm_steps)'}
             except Exception as ex:
                 out['roofline'] = {'error': repr(ex)}
         # ---- the update's recurrence (uncoupled nets with saved activations): one HBM-bound launch

@@ -38,13 +38,13 @@ def main():
         idx = [i for i, r in enumerate(seq) if 'nstep_kernel' in r[0]]
         a, b = idx[-3], idx[-2]
         seg = seq[a:b]
-        # the next rollout starts with the first SHORT encoder launch (gather / fc over E rows instead of T*E rows) -- or, where the
-        # lock-step kernel runs the encoder itself (CommNet on the grid), with the weight image of its first lock-step
-        def starts_rollout(i, r):
-            step_next = any('lstm_step' in x[0] and any(h in x[0] for h in ('Li1E', 'Li3E', 'Li4E')) for x in seg[i:i + 16])
-            enc = ('gather_fwd' in r[0] or 'fc_fwd' in r[0]) and (r[2] - r[1]) < 30000
-            return i > 5 and step_next and (enc or 'lstm_wimage_kernel' in r[0])
-        end = next(i for i, r in enumerate(seg) if starts_rollout(i, r))
+        # the next rollout starts at its first lock-step launch (policy / policy + value heads: the update of a batch with saved
+        # activations launches none), or at the short launches in front of it that belong to it: the weight images, a separate
+        # encoder launch over E rows (absent where the lock-step kernel runs the encoders itself: round 5)
+        first = next(i for i, r in enumerate(seg) if i > 5 and 'lstm_step' in r[0] and any(h in r[0] for h in ('Li1E', 'Li3E', 'Li4E')))
+        end = first
+        while end > 6 and (seg[end - 1][2] - seg[end - 1][1]) < 30000 and any(k in seg[end - 1][0] for k in ('gather_fwd', 'fc_fwd', 'wimage')):
+            end -= 1
         print('batch: %d kernels, span %.2f ms, busy %.2f ms; update: %d kernels, span %.2f ms, busy %.2f ms' % (
             len(seg), (seg[-1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg) / 1e6, end,
             (seg[end - 1][2] - seg[0][1]) / 1e6, sum(r[2] - r[1] for r in seg[:end]) / 1e6))

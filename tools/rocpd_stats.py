@@ -36,12 +36,21 @@ def main():
         seq = list(cur.execute("""select s.kernel_name, d.start, d.end from rocpd_kernel_dispatch d
                                   join rocpd_info_kernel_symbol s on d.kernel_id = s.id order by d.start"""))
         idx = [i for i, r in enumerate(seq) if 'nstep_kernel' in r[0]]
-        a, b = idx[-3], idx[-2]
-        seg = seq[a:b]
+        # one batch = from an update's return scan to the next one, with a rollout in between (the last updates of a bench.py trace are
+        # its side measurements: update graphs replayed back to back)
+        is_step = lambda r: 'lstm_step' in r[0] and any(h in r[0] for h in ('Li1E', 'Li3E', 'Li4E'))      # noqa: E731
+        seg = None
+        for k in range(len(idx) - 1, 0, -1):         # the shortest such stretch is a plain batch (the side measurements replay whole
+            cand = seq[idx[k - 1]:idx[k]]           # rollout graphs several times between two updates)
+            if any(is_step(r) for r in cand[6:]) and (seg is None or len(cand) < len(seg)):
+                seg = cand
+        if seg is None:
+            print('no batch with a rollout found in the trace')
+            return
         # the next rollout starts at its first lock-step launch (policy / policy + value heads: the update of a batch with saved
         # activations launches none), or at the short launches in front of it that belong to it: the weight images, a separate
         # encoder launch over E rows (absent where the lock-step kernel runs the encoders itself: round 5)
-        first = next(i for i, r in enumerate(seg) if i > 5 and 'lstm_step' in r[0] and any(h in r[0] for h in ('Li1E', 'Li3E', 'Li4E')))
+        first = next(i for i, r in enumerate(seg) if i > 5 and is_step(r))
         end = first
         while end > 6 and (seg[end - 1][2] - seg[end - 1][1]) < 30000 and any(k in seg[end - 1][0] for k in ('gather_fwd', 'fc_fwd', 'wimage')):
             end -= 1

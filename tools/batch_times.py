@@ -33,3 +33,32 @@ torch.cuda.synchronize()
 ms = [ev[b].elapsed_time(ev[b + 1]) for b in range(B)]
 print('W = %d; batch durations (ms): %s' % (W, ' '.join('%.2f' % x for x in ms)))
 print('mean of the first 20: %.3f ms, of batches 21..%d: %.3f ms' % (sum(ms[:20]) / 20, B, sum(ms[20:]) / max(1, B - 20)))
+
+# the two graphs of a batch as they run IN the alternating loop (an event between them) and each replayed on its own
+if tr.graph is not None and tr._upd is not None and tr._upd['epilogue_inside'] and tr._upd['apply'] is None:
+    E3 = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(B)]
+    for b in range(B):
+        E3[b][0].record()
+        tr.rollout()
+        E3[b][1].record()
+        tr._update()
+        E3[b][2].record()
+        tr.n_batches += 1
+    torch.cuda.synchronize()
+    r_in = sum(e[0].elapsed_time(e[1]) for e in E3[5:]) / (B - 5)
+    u_in = sum(e[1].elapsed_time(e[2]) for e in E3[5:]) / (B - 5)
+
+    def alone(fn, n=20):
+        fn(); torch.cuda.synchronize()
+        a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b_.record(); torch.cuda.synchronize()
+        return a.elapsed_time(b_) / n
+    snap = tr._snapshot()
+    r_al = alone(tr.graph.replay)
+    u_al = alone(tr._upd['grads'].replay)
+    tr._restore(snap)
+    print('in the alternating loop: rollout graph %.3f ms + update graph %.3f ms = %.3f ms per batch' % (r_in, u_in, r_in + u_in))
+    print('each replayed on its own (20 x back to back): rollout graph %.3f ms, update graph %.3f ms = %.3f ms' % (r_al, u_al, r_al + u_al))

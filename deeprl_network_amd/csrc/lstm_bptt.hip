@@ -1202,6 +1202,13 @@ NMARL_INTERNAL int nmarl_bptt_coupled_occupancy(int K) {
     return rc == hipSuccess ? per_cu : -1;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ w, const int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) w[i] = 0u;
+}
+}  // namespace
+
 extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stream) {
     if (!p || p->H != H || p->E < 0 || p->N <= 0 || p->T <= 0 || (p->kind != 1 && p->kind != 2) || p->r_max <= 0 || p->r_max > 4)
         return NMARL_EINVAL;
@@ -1244,7 +1251,13 @@ extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stre
     hipStream_t st = static_cast<hipStream_t>(stream);
     // every polled word starts at zero for every call (flags count the steps done WITHIN the call); the error word behind
     // them is NOT cleared: a time-out stays visible until the host has dealt with it
-    if (hipMemsetAsync(p->ws, 0, (size_t)N * tiles * WAVES * 4, st) != hipSuccess) return NMARL_EHIP;
+    // (a kernel, not hipMemsetAsync: inside a captured hipGraph the memset node was not reliably ordered in front of the kernel node
+    // behind it -- after some hundred replays of the update graph the blocks saw the previous replay's step counts, read message
+    // adjoints of the previous batch and the gradient came out slightly, and not reproducibly, wrong: tools/determinism.py)
+    {
+        const int64_t nw = (int64_t)N * tiles * WAVES;
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, reinterpret_cast<unsigned*>(p->ws), nw);
+    }
     const int64_t grid = tiles * N;
     // one launch for all T steps needs every block resident (the waves wait for their neighbours' blocks): one 512-thread
     // block with 160 KB of LDS per CU, so grid <= CUs; and a symmetric neighbour relation (two ring slots).  Otherwise

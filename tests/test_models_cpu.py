@@ -108,6 +108,15 @@ def test_batched_update_with_the_encoders_inside_the_lock_step():
         ops_ref.step_enc_forward = orig
     assert calls['n'] == 2 * (int(z['n_step']) + 1)          # every lock-step and both bootstrap steps
     compare_batched(out, z)
+    # the sign image of the saved LSTM inputs (what the update's one-pass encoder backward reads instead of S on the device): one
+    # slot per lock-step, every slot written by the batch that was just consumed, packed as include/nmarl.h lays it out
+    from deeprl_network_amd import ops
+    assert model.S_bits is not None and tuple(model.S_bits.shape) == (model.n_agent, model.n_step, model.E, 4)
+    assert torch.equal(model.S_bits, ops_ref.relu_bits_pack(model.S_buf)) and torch.equal(model.S_bits, ops.relu_bits_pack(model.S_buf))
+    S = model.S_buf
+    for t_, q, i in ((0, 0, 0), (3, 2, 1), (7, 3, 3)):
+        bit = (model.S_bits[..., q].to(torch.int64) >> (4 * t_ + i)) & 1
+        assert torch.equal(bit.bool(), S[..., 16 * t_ + 4 * q + i] > 0)
 
 
 def test_ic3_encoder_inside_the_step_equals_separate_encoder():

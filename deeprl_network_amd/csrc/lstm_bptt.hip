@@ -1192,14 +1192,32 @@ int launch_coupled(const CoupledArgs& a, unsigned grid, size_t lds_bytes, hipStr
 NMARL_INTERNAL int nmarl_bptt_coupled_occupancy(int K) {
     if (K != 64 && K != 128) return -1;
     const size_t lds_bytes = ((size_t)G4 * 16 * 8 + (size_t)K * H) * 4;
-    int per_cu = 0;
-    const void* f = K == 128 ? reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<8, 2, true>)
-                             : reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<4, 4, false>);
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -1;
-    const hipError_t rc = K == 128
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_bptt_coupled_kernel<8, 2, true>, 512, lds_bytes)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_bptt_coupled_kernel<4, 4, false>, 512, lds_bytes);
-    return rc == hipSuccess ? per_cu : -1;
+    // the smallest answer over the instantiations a message row of K floats can launch (lstm_comm with two neighbour slots: <8,2,true>;
+    // K = 64: lstm_comm with one slot <4,2,true>, lstm_ic3 with <= 2 / <= 4 sources per agent <4,2,false> / <4,4,false>): the
+    // residency check of the one-launch form must hold for the kernel that is launched, whichever it is.  Asked once per device.
+    static std::atomic<int> cache[64][2];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    const int kd = K == 128 ? 1 : 0;
+    if (dev >= 0 && dev < 64) {
+        const int hit = cache[dev][kd].load();
+        if (hit > 0) return hit - 1;
+    }
+    int best = -1;
+    auto ask = [&](auto kernel) {
+        int per_cu = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 512, lds_bytes) != hipSuccess)
+            return false;
+        best = best < 0 || per_cu < best ? per_cu : best;
+        return true;
+    };
+    const bool ok = K == 128 ? ask(lstm_bptt_coupled_kernel<8, 2, true>)
+                             : (ask(lstm_bptt_coupled_kernel<4, 2, true>) && ask(lstm_bptt_coupled_kernel<4, 2, false>) &&
+                                ask(lstm_bptt_coupled_kernel<4, 4, false>));
+    if (!ok) return -1;
+    if (dev >= 0 && dev < 64) cache[dev][kd].store(best + 1);
+    return best;
 }
 
 namespace {

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Measurement pass on one MI355X (round 4): default bench line, rocprofv3 kernel traces of the three BASELINE configs,
-# the other configs, PMC traffic passes (separate FETCH / WRITE runs).  Results under gpurun_out/ (copy into profiles/).
+# Measurement pass on one MI355X (round 5): default bench line + untraced breakdown + clock / power samples + same-box A/B of the lock-step forms,
+# rocprofv3 kernel traces of the BASELINE configs (part 1: one box for bench line and traces); the other configs, PMC traffic passes (separate FETCH / WRITE runs),
+# timelines, side benches (part 2).  Results under gpurun_out/ (python tools/make_profiles.py rNN copies the summaries into profiles/).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 TAG=${1:-r05}

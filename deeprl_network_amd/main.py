@@ -98,34 +98,37 @@ def train(args):
         model.save(dirs['model'], final_step)
 
 
-def evaluate_fn(agent_dir, output_dir, seeds, port, demo):
-    agent = agent_dir.split('/')[-1]
-    if not check_dir(agent_dir):
-        logging.error('Evaluation: %s does not exist!' % agent)
-        return
-    config_dir = find_file(agent_dir + '/data/')
-    if not config_dir:
-        return
-    config = configparser.ConfigParser()
-    config.read(config_dir)
-    env = init_env(config['ENV_CONFIG'], port=port)
-    env.init_test_seeds(seeds)
-    model = init_agent(env, config['MODEL_CONFIG'], 0, 0)
-    if model is None:
-        return
-    if not model.load(agent_dir + '/model/'):
-        return
-    Evaluator(env, model, output_dir, gui=demo).run()
+def _open_run(run_dir):
+    """A finished training run on disk -> the parsed ini `train` left under <run>/data/ (main.py:112-123 of the reference finds it
+    the same way), or None with the reason logged."""
+    if not check_dir(run_dir):
+        logging.error('Evaluation: %s does not exist!' % os.path.basename(run_dir.rstrip('/')))
+        return None
+    ini = find_file(os.path.join(run_dir, 'data') + '/')
+    if not ini:
+        return None
+    cfg = configparser.ConfigParser()
+    cfg.read(ini)
+    return cfg
 
 
 def evaluate(args):
-    base_dir = args.base_dir
-    dirs = init_dir(base_dir, pathes=['eva_data', 'eva_log'])
-    init_log(dirs['eva_log'])
-    seeds = args.evaluation_seeds
-    logging.info('Evaluation: random seeds: %s' % seeds)
-    seeds = [int(s) for s in seeds.split(',')] if seeds else []
-    evaluate_fn(base_dir, dirs['eva_data'], seeds, 1, False)
+    """`main.py evaluate` (reference main.py:112-155): the run under --base-dir is rebuilt from its own ini, its newest checkpoint
+    loaded, and the Evaluator replays the test seeds into <run>/eva_data (port 1, no GUI: the synthetic envs have neither)."""
+    run_dir = args.base_dir
+    out = init_dir(run_dir, pathes=['eva_data', 'eva_log'])
+    init_log(out['eva_log'])
+    logging.info('Evaluation: random seeds: %s' % args.evaluation_seeds)
+    seeds = [int(tok) for tok in args.evaluation_seeds.split(',')] if args.evaluation_seeds else []
+    cfg = _open_run(run_dir)
+    if cfg is None:
+        return
+    env = init_env(cfg['ENV_CONFIG'], port=1)
+    env.init_test_seeds(seeds)
+    model = init_agent(env, cfg['MODEL_CONFIG'], 0, 0)
+    if model is None or not model.load(os.path.join(run_dir, 'model') + '/'):
+        return
+    Evaluator(env, model, out['eva_data'], gui=False).run()
 
 
 def main(argv=None):

@@ -246,3 +246,21 @@ def test_commnet_encoder_inside_the_step_equals_separate_encoder_launch(monkeypa
     assert torch.equal(a[0], b[0])
     for x, y in zip(a[1:], b[1:]):
         torch.testing.assert_close(x, y, rtol=1e-5, atol=1e-6)
+
+
+def test_scheduler_follows_the_reference_rule_and_rewinds():
+    """agents/utils.py:917-930 of the reference: `get(n)` advances the step count by n and THEN evaluates
+    max(val_min, val_init * (1 - n / total_step)) for 'linear', val_init otherwise.  `rewind` gives the steps of a re-run batch
+    back (hand-off time-out recovery), `at` reads without advancing (the device scalar of a captured update)."""
+    from deeprl_network_amd.agents.utils import Scheduler
+    s = Scheduler(5e-4, 1e-5, 1000, decay='linear')
+    n, got = 0, []
+    for step in (60, 60, 120, 700, 100):
+        n += step
+        got.append((s.get(step), max(1e-5, 5e-4 * (1 - n / 1000.0))))
+    assert all(a == b for a, b in got) and got[-1][0] == 1e-5 and s.n == 1040      # clamped at val_min past total_step
+    assert not s.constant and s.at(500) == 5e-4 * 0.5 and s.n == 1040             # `at` does not advance
+    s.rewind(100)
+    assert s.n == 940 and s.get(100) == got[-1][0]                               # the re-run batch sees the same rate
+    c = Scheduler(5e-4, decay='constant')
+    assert c.constant and c.get(60) == 5e-4 and c.get(10 ** 9) == 5e-4 and c.n == 60 + 10 ** 9

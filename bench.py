@@ -343,21 +343,39 @@ def measure_bptt_coupled(model, reps=3):
     return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * row, name
 
 
-def measure_update_graph(trainer, skip=None, reps=5):
-    """Duration of the captured update (the hipGraphs BatchedTrainer replays: rewards, return scan, loss, backward, clip + RMSProp
-    [, epilogue]) on the trainer's own buffers: HIP events on the launch stream around `reps` replays of a FRESH capture.
-    skip: names of C-ABI entry points replaced by no-ops during the capture -- the same graph without those launches; the
-    difference is what they cost INSIDE the update (clock, cache and neighbour-kernel conditions of the real batch), the method
-    `measure_lstm_step_in_rollout` uses for the rollout.  The skipped kernels' outputs stay whatever the buffers hold: the other
-    launches' durations do not depend on the data.  Call after the timed region only (weights and statistics move)."""
-    from deeprl_network_amd import _lib
+def measure_update_graph(trainer, skip=None, stamp=None, reps=5):
+    """Duration of the captured update (the hipGraphs BatchedTrainer replays: rewards, return scan, loss, backward, clip + RMSProp,
+    epilogue) on the trainer's own buffers: HIP events on the launch stream around `reps` replays of a FRESH capture.
+    stamp: name of ONE C-ABI entry point bracketed, inside the capture, by two launches of nmarl_timestamp (a one-thread kernel
+    that stores the device's constant-rate wall clock): the DURATION of that launch as it runs inside the update -- clock, cache
+    and neighbour-kernel conditions of the real batch -- is the difference of the two stamps (it includes the two kernel
+    boundaries next to the stamps, ~3 us).  skip: names of entry points replaced by no-ops during the capture -- the same graph
+    without those launches; full - without is their MARGINAL cost (what removing them would buy: not a duration -- taking a
+    1.3-kW kernel out hands its power budget to the launches around it).  The trainer's weights, optimiser
+    slots, statistics and buffers are put back afterwards.  -> (us per replay, stamped duration in us or None)"""
+    from deeprl_network_amd import _lib, ops
     if trainer._upd is None:
-        return None
+        return None, None
+    m = trainer.model
+    ps = m.policy.params
+    state = [t.clone() for t in (ps.flat, ps.ms, trainer.ep_sum, trainer.ep_sq, trainer.ep_len, trainer.fin, m.h_fw, m.c_fw, m.h_bw,
+                                 m.c_bw, m.buf_fp[0], m.buf_x[0], trainer.done_pre, m.buf_r)]
     saved = {n: getattr(_lib.lib, n) for n in (skip or ())}
     keep = trainer._upd
+    stamps = torch.zeros(2, dtype=torch.int64, device=trainer.device) if stamp else None
     try:
         for n in saved:
             setattr(_lib.lib, n, lambda *a, **k: 0)
+        if stamp:
+            orig = getattr(_lib.lib, stamp)
+            saved[stamp] = orig
+
+            def bracketed(*a, **k):
+                ops.timestamp(stamps[0:1])
+                rc = orig(*a, **k)
+                ops.timestamp(stamps[1:2])
+                return rc
+            setattr(_lib.lib, stamp, bracketed)
         trainer._upd = None
         trainer._capture_update()
         g = trainer._upd
@@ -365,6 +383,7 @@ def measure_update_graph(trainer, skip=None, reps=5):
         for n, f in saved.items():
             setattr(_lib.lib, n, f)
         trainer._upd = keep
+
     def once():
         g['grads'].replay()
         if g['apply'] is not None:
@@ -372,24 +391,56 @@ def measure_update_graph(trainer, skip=None, reps=5):
     once()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    inside = []
     e0.record()
     for _ in range(reps):
         once()
+        if stamp:
+            inside.append(stamps.clone())
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    dur = None
+    if stamp:
+        ticks = [int((x[1] - x[0]).item()) for x in inside]
+        dur = sorted(ticks)[len(ticks) // 2] / ops.timestamp_rate_khz(trainer.device) * 1e3      # median, us
+    for t, sv in zip((ps.flat, ps.ms, trainer.ep_sum, trainer.ep_sq, trainer.ep_len, trainer.fin, m.h_fw, m.c_fw, m.h_bw, m.c_bw,
+                      m.buf_fp[0], m.buf_x[0], trainer.done_pre, m.buf_r), state):
+        t.copy_(sv)
+    return us, dur
 
 
 def update_breakdown(trainer, bptt_entry):
-    """{'update_graph_us', 'update_graph_us_without_bptt', 'bptt_us_in_update'} by the difference of two captured updates."""
-    full = measure_update_graph(trainer)
+    """The captured update timed three ways (5 replays each between two HIP events on the launch stream):
+    update_graph_us = as BatchedTrainer replays it; bptt_us_in_update = the DURATION of the reverse-recurrence launch inside it
+    (two device time stamps around the launch); marginal_us_in_update = update_graph_us - the same graph without that launch."""
+    full, _ = measure_update_graph(trainer)
     if full is None:
         return None
-    without = measure_update_graph(trainer, skip=(bptt_entry,))
-    return {'update_graph_us': full, 'update_graph_us_without_bptt': without, 'bptt_us_in_update': full - without,
-            'bptt_entry': bptt_entry,
-            'how': 'the captured update (what BatchedTrainer replays per batch) re-captured with and without the %s launch, 5 replays each '
-                   'between two HIP events on the launch stream' % bptt_entry}
+    stamped, dur = measure_update_graph(trainer, stamp=bptt_entry)
+    without, _ = measure_update_graph(trainer, skip=(bptt_entry,))
+    marginal = full - without
+    return {'update_graph_us': full, 'bptt_us_in_update': dur, 'update_graph_us_with_stamps': stamped,
+            'update_graph_us_without_bptt': without,
+            'marginal_us_in_update': marginal if marginal > 0 else None, 'bptt_entry': bptt_entry,
+            'how': 'bptt_us_in_update: the %s launch bracketed by two nmarl_timestamp launches (device wall clock) inside the captured update, '
+                   'median of 5 replays -- a duration; marginal_us_in_update: the captured update re-captured without that launch and '
+                   'subtracted -- what removing it would buy, not a duration' % bptt_entry}
+
+
+def _quote_bptt_in_update(rb, ub):
+    """roofline_bptt's us_per_launch / achieved / frac on the launch's DURATION inside the captured update (time stamps), the
+    back-to-back figure kept beside it."""
+    if not isinstance(rb, dict) or 'bytes_per_launch' not in rb or not ub.get('bptt_us_in_update'):
+        return
+    rb['us_per_launch_back_to_back'] = rb['us_per_launch']
+    rb['us_per_launch'] = ub['bptt_us_in_update']
+    rb['achieved'] = rb['bytes_per_launch'] / rb['us_per_launch'] / 1e3
+    rb['frac'] = rb['achieved'] / HBM_PEAK_GBPS
+    rb['marginal_us_in_update'] = ub.get('marginal_us_in_update')
+    rb['how'] = rb.get('how', '') + ' | us_per_launch / achieved / frac: the launch\'s duration INSIDE the captured update, two device ' \
+        'time stamps (nmarl_timestamp) around it, median of 5 replays; us_per_launch_back_to_back: HIP events around isolated calls; ' \
+        'marginal_us_in_update: update graph with - without the launch (not a duration)'
 
 
 def _lib_capacity(which, K):
@@ -462,14 +513,7 @@ def run_other_config(args, cfg_name, device):
         ub = update_breakdown(trainer, 'nmarl_lstm_bptt_coupled')
         if ub is not None:
             res['update'] = ub
-            if isinstance(res.get('roofline_bptt'), dict) and 'bytes_per_launch' in res['roofline_bptt']:
-                rb = res['roofline_bptt']
-                rb['us_per_launch_back_to_back'] = rb['us_per_launch']          # 3 hot repetitions of the whole op (memset, kernel, 2 sums)
-                rb['us_per_launch'] = ub['bptt_us_in_update']                   # the launch as it runs inside the update
-                rb['achieved'] = rb['bytes_per_launch'] / rb['us_per_launch'] / 1e3
-                rb['frac'] = rb['achieved'] / HBM_PEAK_GBPS
-                rb['how'] = 'us_per_launch / achieved / frac: in-update duration by difference of two captured updates (`update`); ' \
-                            'us_per_launch_back_to_back: HIP events around 3 back-to-back calls of the whole op on random data'
+            _quote_bptt_in_update(res.get('roofline_bptt'), ub)
     except Exception as ex:
         res['update'] = {'error': repr(ex)}
     del trainer, model, env
@@ -593,6 +637,41 @@ def cpu_baseline(cfg_path, n_batches):
                                              what=d['what'] + '; measured in the authoring container by '
                                              'tools/cpu_env_baseline.py (the reference checkout does not exist on the GPU box)')
     return out
+
+
+def _ordered(out):
+    """The JSON line with the contract's objects up front (a reader that keeps only the head of the line still sees the
+    headline, `roofline`, `roofline_bptt` and `cpu_baseline`): the long `how` texts move to ONE `how` object at the end, the
+    contract keys of each object come first."""
+    how = {}
+
+    def strip(key, d):
+        if isinstance(d, dict):
+            if isinstance(d.get('how'), str):
+                how[key] = d.pop('how')
+            for k, v in list(d.items()):
+                strip(key + '.' + k, v)
+        elif isinstance(d, list):
+            for i, v in enumerate(d):
+                strip('%s[%d]' % (key, i), v)
+    for k, v in out.items():
+        strip(k, v)
+
+    def lead(d, keys):
+        if not isinstance(d, dict):
+            return d
+        return {**{k: d[k] for k in keys if k in d}, **{k: v for k, v in d.items() if k not in keys}}
+    roof = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'us_per_launch')
+    for k in list(out):
+        if k.startswith('roofline'):
+            out[k] = lead(out[k], roof)
+    if 'cpu_baseline' in out:
+        out['cpu_baseline'] = lead(out['cpu_baseline'], ('value', 'unit', 'cores', 'kind', 'sample'))
+    first = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+             'dtype', 'data', 'config', 'roofline', 'roofline_bptt', 'cpu_baseline')
+    res = lead(out, first)
+    res['how'] = how
+    return res
 
 
 def self_launch(args):
@@ -722,7 +801,7 @@ def main():
         rank_ms = [float(x.item()) / args.steps * 1e3 for x in every]
         elapsed = max(float(x.item()) for x in every)                  # MAX over ranks
         # the path's one collective, timed on its own after the timed region: the flat gradient all-reduce of an update
-        g = model.policy.params.grad
+        g = model.policy.params.grad_wire
         for _ in range(3):
             dist.all_reduce(g, group=group)
         torch.cuda.synchronize()
@@ -760,7 +839,8 @@ def main():
         'a2c_updates_per_s': args.steps / elapsed,
         'per_rank_ms_per_step': rank_ms,
         'grad_allreduce': None if allreduce_us is None else {
-            'us': allreduce_us, 'bytes': int(model.policy.params.grad.numel()) * 4, 'per_update': 1,
+            'us': allreduce_us, 'bytes': int(model.policy.params.grad_wire.numel()) * 4,
+            'per_update': getattr(model, 'allreduce_calls', 0) / max(1, trainer.n_batches),      # counted: collectives issued / updates run
             'backend': os.environ.get('NMARL_DIST_BACKEND', 'nccl'),
             'how': '20 back-to-back all_reduce(sum) of the flat [N,P] fp32 gradient after the timed region, host clock around '
                    'them with a device synchronize on both sides (mean; the timed region contains exactly one per step)'},
@@ -855,14 +935,7 @@ def main():
                 ub = update_breakdown(trainer, 'nmarl_lstm_bptt_seq')
                 if ub is not None:
                     out['update'] = ub
-                    rb = out['roofline_bptt']
-                    if 'bytes_per_launch' in rb:
-                        rb['us_per_launch_back_to_back'] = rb['us_per_launch']
-                        rb['us_per_launch'] = ub['bptt_us_in_update']
-                        rb['achieved'] = rb['bytes_per_launch'] / rb['us_per_launch'] / 1e3
-                        rb['frac'] = rb['achieved'] / HBM_PEAK_GBPS
-                        rb['how'] += '; us_per_launch / achieved / frac: the launch as it runs INSIDE the update, by difference of two ' \
-                                     'captured updates (`update`); us_per_launch_back_to_back: the 5 isolated launches'
+                    _quote_bptt_in_update(out['roofline_bptt'], ub)
             except Exception as ex:
                 out['update'] = {'error': repr(ex)}
         # ---- the env-step kernel (north_star's HBM roofline), measured live on this rank's stream
@@ -947,7 +1020,7 @@ def main():
                     out['other_configs'].append(run_other_config(args, cfg_name, device))
                 except Exception as ex:      # never lose the headline line to a side measurement
                     out['other_configs'].append({'workload': cfg_name, 'error': repr(ex)})
-        print(json.dumps(out))
+        print(json.dumps(_ordered(out)))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -115,7 +115,7 @@ class BatchEpilogue(C.Structure):
     """nmarl_batch_epilogue_t (include/nmarl.h)."""
     _fields_ = ([('E', C.c_int64)] + [(k, C.c_int32) for k in ('N', 'H', 'A', 'F', 'T', 'T_env')] +
                 [(k, C.c_void_p) for k in ('g', 'done', 'ep_sum', 'ep_sq', 'ep_len', 'fin', 'h_fw', 'c_fw', 'h_bw', 'c_bw', 'fp_T',
-                                           'fp_uniform', 'x_T', 'fp_0', 'x_0', 'done_pre', 'scratch')])
+                                           'fp_uniform', 'x_T', 'fp_0', 'x_0', 'done_pre', 'scratch', 'skip_if')])
 
 
 class BpttCoupled(C.Structure):
@@ -217,6 +217,9 @@ SIGNATURES = {
     'nmarl_handoff_capacity': [_i32, _i32],
     'nmarl_test_handoff_fault': [_i32],
     'nmarl_batch_epilogue': [C.POINTER(BatchEpilogue), _p],
+    'nmarl_timestamp': [_p, _p],
+    'nmarl_timestamp_rate_khz': [],
+    'nmarl_copy_multi': [_i32, C.POINTER(_p), C.POINTER(_p), C.POINTER(_i64), _p, _p],
 }
 
 for _name, _args in SIGNATURES.items():

@@ -375,7 +375,13 @@ class IA2C:
     def load_rewards(self, raw_rewards):
         """Batched path: the env kernel wrote raw rewards for all T slots (and done flags straight
         into buf_done_post); normalise them in one pass and mark the batch complete."""
-        self.buf_r.copy_(self._norm_reward(raw_rewards))
+        # (written in place: `buf_r.copy_(temporary)` is a memcpy node inside the captured update)
+        if self.reward_norm > 0:
+            torch.div(raw_rewards, self.reward_norm, out=self.buf_r)
+        else:
+            torch.mul(raw_rewards, 1.0, out=self.buf_r)
+        if self.reward_clip > 0:
+            self.buf_r.clamp_(-self.reward_clip, self.reward_clip)
         self.t = self.n_step
 
     def bootstrap(self, done, action_scratch, mode=ops.SAMPLE_PHILOX, u=None, seed=0, env_id_base=0,
@@ -500,17 +506,23 @@ class IA2C:
         ps.end_backward()
         if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)
             ps.grad.mul_(ps.mask)
+        if self._status_on_wire:
+            # a rank whose in-launch hand-off timed out contributes invalid gradients: every rank must refuse the step (and recover
+            # in lock-step, BatchedTrainer).  The status word rides in the float behind the gradient, inside the ONE all-reduce
+            ps.grad_tail.copy_(ops.handoff_status(self.device)[:1])           # (int32 -> f32: an element-wise kernel)
+
+    @property
+    def _status_on_wire(self):
+        return self.dist_group is not None and self.handoff_guarded and self.save_acts
 
     def update_reduce(self):
-        """The data-parallel exchange: ONE flat all-reduce of the gradient (RCCL over xGMI)."""
+        """The data-parallel exchange: ONE flat all-reduce per update (RCCL over xGMI) -- the gradient and, behind it, one float
+        that is non-zero iff some rank's in-launch hand-off timed out in this batch (the reference has no collective)."""
         if self.dist_group is None:
             return
         import torch.distributed as dist
-        dist.all_reduce(self.policy.params.grad, group=self.dist_group)
-        if self.handoff_guarded and self.save_acts and ops.handoff_enabled():
-            # a rank whose in-launch hand-off timed out contributed invalid gradients: every rank must refuse the step
-            # (and recover in lock-step, BatchedTrainer.run_batch) -- the status word travels as a MAX reduction
-            dist.all_reduce(ops.handoff_status(self.device)[:1], op=dist.ReduceOp.MAX, group=self.dist_group)
+        dist.all_reduce(self.policy.params.grad_wire, group=self.dist_group)
+        self.allreduce_calls = getattr(self, 'allreduce_calls', 0) + 1
 
     def update_apply(self, lr, rotate=True, lr_dev=None):
         """clip_by_global_norm + RMSProp on the flat buffers (policies.py:32-39, 257-264); lr_dev: device scalar that
@@ -518,6 +530,9 @@ class IA2C:
         ps = self.policy.params
         scale = 1.0 / self.world_size
         guard = self.handoff_guarded
+        if self._status_on_wire:             # some rank timed out (summed tail != 0): this rank's status word is raised as well
+            st = ops.handoff_status(self.device)[:1]
+            torch.maximum(st, (ps.grad_tail != 0).to(torch.int32), out=st)
         if self.per_agent_optimizer:
             ops.rmsprop_tf_clip(ps.flat, ps.grad, ps.ms, ps.scratch, lr, self.rmsp_alpha, self.rmsp_epsilon,
                                 self.max_grad_norm, scale, self.grad_norm, lr_dev=lr_dev, guard=guard)

@@ -83,7 +83,11 @@ class ParamStore:
                 off += -(-size // ALIGN) * ALIGN
         self.P = off          # padding floats stay 0 (zero gradient), they never enter a norm or an export
         self.flat = torch.zeros(n_agent, self.P, dtype=F32, device=device)
-        self.grad = torch.zeros_like(self.flat)
+        # the gradient and ONE more float behind it: the data-parallel exchange all-reduces `grad_wire` = [gradient | tail], the tail
+        # carrying a rank's in-launch hand-off status to every other rank inside the same (single) collective (models.update_reduce)
+        self.grad_wire = torch.zeros(n_agent * self.P + 1, dtype=F32, device=device)
+        self.grad = self.grad_wire[:n_agent * self.P].view(n_agent, self.P)
+        self.grad_tail = self.grad_wire[n_agent * self.P:]
         self.ms = torch.ones_like(self.flat)            # TF RMSProp slot starts at 1
         self.scratch = torch.zeros(n_agent, 64, dtype=F32, device=device)
         self.views = {}

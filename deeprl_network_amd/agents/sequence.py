@@ -395,7 +395,7 @@ def _dwmsg_by_runs(Hx, D1x, nbr_idx, H):
     N, m = nbr_idx.shape
     out = torch.zeros(N, m * H, H, dtype=F32, device=Hx.device)      # slots an agent does not have: zero gradient
     for i0, i1, k, d in _runs[key][1]:
-        out[i0:i1, k * H:(k + 1) * H] = ops.wgrad(Hx[i0 + d:i1 + d], D1x[i0:i1])
+        ops.wgrad(Hx[i0 + d:i1 + d], D1x[i0:i1], out=out[i0:i1, k * H:(k + 1) * H])
     return out
 
 

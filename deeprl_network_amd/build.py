@@ -1,7 +1,7 @@
 """Build libnmarl_hip.so (the C-ABI of include/nmarl.h) for gfx950 with hipcc.
 
-In-tree, explicit `hipcc -shared -fPIC`: the .so travels to the GPU box with the
-repo snapshot (a JIT cache under ~/.cache would not).  hipcc cross-compiles
+In-tree, explicit `hipcc -c` per source (in parallel, objects cached under build/) + `hipcc -shared`: the .so
+travels to the GPU box with the repo snapshot (a JIT cache under ~/.cache would not).  hipcc cross-compiles
 without a GPU, so this also is the CPU-side "does it build" check.
 """
 import glob
@@ -49,12 +49,46 @@ def stale():
     return built_hash() != source_hash()
 
 
+OBJ_DIR = os.path.join(PKG, 'build')      # per-file objects (git-ignored): an edit recompiles the files it touches only
+
+
+def _object(src, hipcc, want, verbose):
+    """One translation unit -> build/<name>.<key>.o, compiled only if no object with this key (its source, every header,
+    the flags, the baked hash where the file holds it) exists."""
+    h = hashlib.sha256()
+    for f in [src] + [d for d in dependencies() if d.endswith('.h')]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    flags = ['--offload-arch=' + ARCH] + [f for f in FLAGS if f != '-shared']
+    if os.path.basename(src) == 'cacc.hip':                 # the file that exports nmarl_source_hash
+        flags.append('-DNMARL_SRC_HASH_STR="NMARL_SRC_HASH=%s"' % want)
+    h.update(' '.join(flags).encode())
+    stem = os.path.splitext(os.path.basename(src))[0]
+    obj = os.path.join(OBJ_DIR, '%s.%s.o' % (stem, h.hexdigest()[:16]))
+    if not os.path.exists(obj):
+        for old in glob.glob(os.path.join(OBJ_DIR, stem + '.*.o')):
+            os.remove(old)
+        cmd = [hipcc] + flags + ['-c', src, '-o', obj + '.tmp']
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        os.replace(obj + '.tmp', obj)
+    return obj
+
+
 def build_native(force=False, verbose=True):
     if not force and not stale():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=' + ARCH] + FLAGS + ['-DNMARL_SRC_HASH_STR="NMARL_SRC_HASH=%s"' % source_hash()] + \
-        sources() + ['-o', LIB + '.tmp']
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for old in glob.glob(os.path.join(OBJ_DIR, '*.o')):
+            os.remove(old)
+    want = source_hash()
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(lambda f: _object(f, hipcc, want, verbose), sources()))
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC'] + objs + ['-o', LIB + '.tmp']
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

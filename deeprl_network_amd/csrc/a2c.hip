@@ -229,6 +229,7 @@ struct EpilogueArgs {
     float *h_fw, *c_fw, *h_bw, *c_bw;
     const float *fp_T, *fp_uniform, *x_T;
     float *fp_0, *x_0, *done_pre;
+    const int32_t* skip_if;      // != NULL and *skip_if != 0: both kernels return without touching anything
 };
 
 constexpr int EPI_BLOCK = 256;
@@ -237,6 +238,7 @@ constexpr int EPI_MAX_BLOCKS = 1024;
 // per-replica float64 sums in the order t = 0 .. T-1 (one thread per replica), a fixed-order tree over the block's
 // replicas; the per-block partials are added in block order by the state kernel that follows (deterministic)
 __global__ __launch_bounds__(EPI_BLOCK) void epilogue_stats_kernel(const EpilogueArgs a, double* __restrict__ partial) {
+    if (a.skip_if && *a.skip_if != 0) return;
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * EPI_BLOCK + threadIdx.x; e < a.E; e += (int64_t)gridDim.x * EPI_BLOCK) {
         double s = 0.0, q = 0.0;
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(EPI_BLOCK) void epilogue_stats_kernel(const Epilogu
 }
 
 __global__ __launch_bounds__(256) void epilogue_state_kernel(const EpilogueArgs a, const double* __restrict__ partial, const int n_partial) {
+    if (a.skip_if && *a.skip_if != 0) return;
     if (blockIdx.x == 0 && threadIdx.x < 4) {          // episode statistics: the stats kernel's per-block partials, in block order
         double v = 0.0;
         for (int b = 0; b < n_partial; ++b) v += partial[b * 4 + threadIdx.x];
@@ -590,7 +593,7 @@ extern "C" int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* strea
     a.E = p->E; a.N = p->N; a.H = p->H; a.A = p->A; a.F = p->F; a.T = p->T; a.T_env = p->T_env;
     a.g = p->g; a.done = p->done; a.ep_sum = p->ep_sum; a.ep_sq = p->ep_sq; a.ep_len = p->ep_len; a.fin = p->fin;
     a.h_fw = p->h_fw; a.c_fw = p->c_fw; a.h_bw = p->h_bw; a.c_bw = p->c_bw; a.fp_T = p->fp_T; a.fp_uniform = p->fp_uniform;
-    a.x_T = p->x_T; a.fp_0 = p->fp_0; a.x_0 = p->x_0; a.done_pre = p->done_pre;
+    a.x_T = p->x_T; a.fp_0 = p->fp_0; a.x_0 = p->x_0; a.done_pre = p->done_pre; a.skip_if = p->skip_if;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!p->scratch) return NMARL_EINVAL;
     int64_t sb = (a.E + EPI_BLOCK - 1) / EPI_BLOCK;
@@ -601,4 +604,66 @@ extern "C" int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* strea
     blocks = blocks > 2048 ? 2048 : blocks;
     hipLaunchKernelGGL(epilogue_state_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, (const double*)p->scratch, (int)sb);
     return nmarl_check_launch();
+}
+
+// ---- several small device-to-device copies as ONE kernel launch.  Inside a captured hipGraph every launch of this library is a
+// kernel node; aten's copy_ of a contiguous tensor is a hipMemcpyAsync, i.e. a memcpy node (the node class whose ordering
+// against neighbouring kernel nodes round 5 found unreliable for memsets on this stack).
+struct CopyMultiArgs {
+    void* dst[NMARL_COPY_MAX];
+    const void* src[NMARL_COPY_MAX];
+    int64_t bytes[NMARL_COPY_MAX];
+    const int32_t* skip_if;
+};
+
+__global__ void __launch_bounds__(256) copy_multi_kernel(const CopyMultiArgs a) {
+    if (a.skip_if && *a.skip_if != 0) return;
+    const int k = blockIdx.y;
+    const int64_t n = a.bytes[k];
+    char* __restrict__ d = static_cast<char*>(a.dst[k]);
+    const char* __restrict__ s = static_cast<const char*>(a.src[k]);
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
+    if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15u) == 0) {
+        const int64_t n16 = n >> 4;
+        for (int64_t i = tid; i < n16; i += nth) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (int64_t i = (n16 << 4) + tid; i < n; i += nth) d[i] = s[i];
+    } else {
+        for (int64_t i = tid; i < n; i += nth) d[i] = s[i];
+    }
+}
+
+extern "C" int nmarl_copy_multi(int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const int32_t* skip_if,
+                                void* stream) {
+    if (n < 0 || n > NMARL_COPY_MAX || (n > 0 && (!dst || !src || !bytes))) return NMARL_EINVAL;
+    if (n == 0) return NMARL_OK;
+    CopyMultiArgs a{};
+    a.skip_if = skip_if;
+    int64_t most = 0;
+    for (int k = 0; k < n; ++k) {
+        if (bytes[k] < 0 || (bytes[k] > 0 && (!dst[k] || !src[k]))) return NMARL_EINVAL;
+        a.dst[k] = dst[k]; a.src[k] = src[k]; a.bytes[k] = bytes[k];
+        most = bytes[k] > most ? bytes[k] : most;
+    }
+    if (most == 0) return NMARL_OK;
+    int64_t bx = (most / 16 + 255) / 256;                    // one 16-byte piece per thread, grid-stride above 1024 blocks
+    bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+    hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return nmarl_check_launch();
+}
+
+// ---- device time stamp: one thread stores the constant-rate wall clock (s_memrealtime: independent of the shader clock and of
+// DVFS).  Measurement only (bench.py): two stamps around a launch inside a captured hipGraph give that launch's duration in its real
+// neighbourhood, where event pairs cannot be placed and a with / without difference measures something else.
+__global__ void timestamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
+
+extern "C" int nmarl_timestamp(uint64_t* out, void* stream) {
+    if (!out) return NMARL_EINVAL;
+    hipLaunchKernelGGL(timestamp_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long*>(out));
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_timestamp_rate_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return NMARL_EHIP;
+    return khz;
 }

@@ -101,6 +101,8 @@ class LargeGridBatchEnv:
         if self.device.type != 'cuda':
             raise _lib.NmarlError('LargeGridBatchEnv needs a HIP device; there is no CPU path')
         self.name = config.get('scenario')
+        if self.name == 'large_grid':        # (config_greedy.ini's spelling): ONE name for the scenario -- Trainer / perform branch on 'atsc*'
+            self.name = 'atsc_large_grid'
         self.agent = config.get('agent')
         self.coop_gamma = config.getfloat('coop_gamma')
         self.seed = config.getint('seed') if seed is None else int(seed)

@@ -78,6 +78,11 @@ def train(args):
     num_envs = args.num_envs if args.num_envs is not None else env_cfg.getint('num_envs', fallback=1)
     device = torch.device('cuda', local)
     writer = SummaryWriter(dirs['log']) if rank == 0 else None
+    if env_cfg.get('agent') == 'greedy':
+        # the rule-based ATSC baseline has nothing to train (no add_transition / backward / save): say so instead of dying on an
+        # AttributeError after the first env step with a half-initialised run directory -- `main.py evaluate` is its mode
+        logging.error('Training: agent "greedy" is a rule-based controller; run `main.py evaluate` on it')
+        return
     if num_envs <= 1 and world == 1:
         env = init_env(env_cfg, device=device)                       # seeds np.random (cacc_env.py:22)
         logging.info('Training: a dim %r, agent dim: %d' % (env.n_a_ls, env.n_agent))

@@ -885,7 +885,7 @@ def heads(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
 WGRAD_SPLIT = 16
 
 
-def wgrad(a, g):
+def wgrad(a, g, out=None):
     """a^T g for a [N,rows,M], g [N,rows,K] -> [N,M,K]: the weight gradient of a batched layer, whose contraction
     runs over ALL rows (T*E of the update).  One GEMM per agent gives the library 8 tall-K problems (it reaches
     ~75 TFLOP/s fp32); splitting the rows into WGRAD_SPLIT slabs per agent (a free view) makes it 128 ordinary
@@ -894,9 +894,13 @@ def wgrad(a, g):
     N, rows, M = a.shape
     S = WGRAD_SPLIT
     if rows % S or rows < 64 * S or not a.is_contiguous() or not g.is_contiguous():
-        return torch.bmm(a.transpose(1, 2), g)
+        r = torch.bmm(a.transpose(1, 2), g)
+        return r if out is None else torch.mul(r, 1.0, out=out)
     part = torch.bmm(a.view(N * S, rows // S, M).transpose(1, 2), g.view(N * S, rows // S, g.shape[2]))
-    return part.view(N, S, M, g.shape[2]).sum(1)
+    part = part.view(N, S, M, g.shape[2])
+    # out (a view of the caller's buffer): the partial sums land there directly -- no temporary + copy_ (whose contiguous case
+    # is a hipMemcpyAsync, i.e. a memcpy node inside the captured update)
+    return part.sum(1) if out is None else torch.sum(part, dim=1, out=out)
 
 
 class _Linear(torch.autograd.Function):
@@ -1503,10 +1507,11 @@ def rmsprop_tf_clip(w, g, ms, scratch, lr, rho, eps, max_norm, grad_scale=1.0, n
 _epilogue_scratch = {}
 
 
-def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre):
+def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre,
+                   skip_if=None):
     """nmarl_batch_epilogue: episode statistics + the state hand-over between two n_step batches (see include/nmarl.h).
     g [T,E] f32, done [E] u8, ep_* [E] f64, fin [4] f64; h_* / c_* [N,E,H]; fp_T / fp_0 [N,E,A], fp_uniform [N,1,A] or [N,A];
-    x_T / x_0 [E,N,F]; done_pre [E] f32."""
+    x_T / x_0 [E,N,F]; done_pre [E] f32.  skip_if: int32 device word -- while != 0 the call changes nothing."""
     T, E = g.shape
     N, _, H = h_fw.shape
     a = _lib.BatchEpilogue()
@@ -1520,4 +1525,41 @@ def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw,
     if key not in _epilogue_scratch:
         _epilogue_scratch[key] = torch.zeros(4096, dtype=torch.float64, device=g.device)      # NMARL_EPILOGUE_SCRATCH
     a.scratch = ptr(_epilogue_scratch[key], torch.float64)
+    a.skip_if = ptr(skip_if, torch.int32, strided=True)
     check(lib.nmarl_batch_epilogue(C.byref(a), stream()), 'nmarl_batch_epilogue')
+
+
+COPY_MAX = 16      # NMARL_COPY_MAX
+
+
+def copy_multi(pairs, skip_if=None):
+    """nmarl_copy_multi: [(dst, src), ...] contiguous device tensors of equal byte size, copied by ONE kernel launch per 16
+    pairs on the current stream -- inside a captured hipGraph a kernel node, where `dst.copy_(src)` would be a memcpy node.
+    skip_if: int32 device word -- while != 0 nothing is copied."""
+    pairs = list(pairs)
+    for d, s_ in pairs:
+        if not (d.is_contiguous() and s_.is_contiguous()) or d.dtype != s_.dtype or d.numel() != s_.numel():
+            raise _lib.NmarlError('copy_multi: pairs must be contiguous tensors of one dtype and size (got %s %s <- %s %s)'
+                                  % (tuple(d.shape), d.dtype, tuple(s_.shape), s_.dtype))
+    for i in range(0, len(pairs), COPY_MAX):
+        part = pairs[i:i + COPY_MAX]
+        n = len(part)
+        dst = (C.c_void_p * n)(*[ptr(d) for d, _ in part])
+        src = (C.c_void_p * n)(*[ptr(s_) for _, s_ in part])
+        nbytes = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in part])
+        check(lib.nmarl_copy_multi(n, dst, src, nbytes, ptr(skip_if, torch.int32, strided=True), stream()), 'nmarl_copy_multi')
+
+
+def timestamp(out):
+    """nmarl_timestamp: out [1] int64 device tensor <- the device's constant-rate wall clock, from a one-thread kernel on the
+    current stream (capturable: a kernel node).  Measurement only."""
+    if out.dtype != torch.int64 or out.numel() != 1:
+        raise _lib.NmarlError('timestamp: out must be one int64')
+    check(lib.nmarl_timestamp(ptr(out, torch.int64, strided=True), stream()), 'nmarl_timestamp')
+
+
+def timestamp_rate_khz(device=None):
+    khz = lib.nmarl_timestamp_rate_khz()
+    if khz <= 0:
+        raise _lib.NmarlError('nmarl_timestamp_rate_khz failed (%d)' % khz)
+    return khz

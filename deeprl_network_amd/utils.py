@@ -289,8 +289,10 @@ class BatchedTrainer:
 
     def __init__(self, env, model, global_counter=None, summary_writer=None, output_path=None,
                  use_graph=True, rank=0, world_size=1, save_activations=True, compact_obs=True, fused_encode=True,
-                 capture_update=True, rearm_after=200):
+                 capture_update=True, rearm_after=200, keep_graphs=False):
         self.env, self.model = env, model
+        # keep_graphs: the captured hipGraph_t objects stay inspectable (torch.cuda.CUDAGraph.raw_cuda_graph; tools/graph_nodes.py)
+        self.keep_graphs = bool(keep_graphs) or os.environ.get('NMARL_KEEP_GRAPHS', '0') == '1'
         # uncoupled nets: the rollout's policy steps double as the forward pass of the update (models.py)
         self.saved_acts = bool(save_activations) and model.enable_saved_activations()
         # CACC: compact observations (own features only; the encoder gathers the neighbours) -- SURVEY.md 8d's layout
@@ -346,13 +348,19 @@ class BatchedTrainer:
         # every further time-out doubles the wait
         self.rearm_after = int(rearm_after)
         self._rearm_wait, self._clean_since_fallback = int(rearm_after), 0
-        self._wants_guard = False
-        # coupled nets on the in-launch hand-off kernels (one-launch lock-step / BPTT): every batch is checked and, if a wave
-        # timed out, re-run on the launch-per-step kernels from the state it started from (see run_batch)
-        self.handoff_guard = self.saved_acts and model.policy.coupled and d.type == 'cuda' and ops.handoff_enabled()
+        # coupled nets on the in-launch hand-off kernels (one-launch lock-step / BPTT).  A wave that gives up waiting raises the
+        # device's status word; while it is raised NOTHING of a batch is committed on the device -- the optimiser step refuses,
+        # the batch epilogue (statistics + hand-over) refuses, the next rollout does not overwrite the start-of-batch snapshot --
+        # so the host need not look at the word before it launches the next batch: it reads it one batch LATE through a pinned
+        # non-blocking copy (no host synchronisation on the critical path) and then re-runs the refused batches on the
+        # launch-per-step kernels from the snapshot (`_recover_from_handoff_timeout`)
         self._wants_guard = self.saved_acts and bool(model.policy.coupled) and d.type == 'cuda'
+        self.handoff_guard = self._wants_guard and ops.handoff_enabled()
         self.handoff_fallbacks = 0
-        self._shadow = [torch.empty_like(t) for t in env.state_tensors() + [self.step_dev]] if self._wants_guard else None
+        self._shadow = [torch.empty_like(t) for t in self._shadow_tensors()] if self._wants_guard else None
+        self._status = ops.handoff_status(d) if self._wants_guard else None
+        self._probes = [(torch.zeros(4, dtype=torch.int32).pin_memory(), torch.cuda.Event()) for _ in range(2)] if self._wants_guard else None
+        self._pending = None                  # (pinned copy of the status words, event) of the batch launched last
         self.data = []
         self.n_batches = 0
         env.train_mode = True
@@ -366,9 +374,8 @@ class BatchedTrainer:
         env, model = self.env, self.model
         T = self.n_step
         model.t = 0
-        if self.handoff_guard:                # what the rollout mutates and a re-run must start from (a few small copies)
-            for s_, t_ in zip(self._shadow, env.state_tensors() + [self.step_dev]):
-                s_.copy_(t_)
+        if self.handoff_guard:                # what the rollout mutates and a re-run must start from: ONE launch, and none of it
+            ops.copy_multi(zip(self._shadow, self._shadow_tensors()), skip_if=self._status[:1])    # once the status word is raised
         # Philox step = batch base (device counter, advanced once per batch) + slot offset baked into the graph
         fused = self.fused_encode
         for t in range(T):
@@ -392,7 +399,7 @@ class BatchedTrainer:
         v = model.bootstrap(self.zero_done, self.action_boot, mode=ops.SAMPLE_PHILOX, seed=env.seed,
                             env_id_base=env.env_id_base, step=T, step_dev=self.step_dev, done_is_zero=True, pre_encoded=fused)
         self.step_dev.add_(T + 1)
-        self.R_end.copy_(v * (1.0 - self.last_done.to(torch.float32)).view(1, -1))
+        torch.mul(v, (1.0 - self.last_done.to(torch.float32)).view(1, -1), out=self.R_end)     # (out=: no temporary + memcpy node)
 
     def rollout(self):
         if not self.use_graph:
@@ -408,7 +415,7 @@ class BatchedTrainer:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             self._restore(snap)
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = self._new_graph()
             with torch.cuda.graph(self.graph):
                 self._rollout()
             self._restore(snap)
@@ -420,6 +427,14 @@ class BatchedTrainer:
         self.model.t = self.n_step
         for k, v in self._graph_flags.items():
             setattr(self.model.policy, k, v)
+
+    def _new_graph(self):
+        return torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graphs else torch.cuda.CUDAGraph()
+
+    def _shadow_tensors(self):
+        """What a rollout overwrites and the batch epilogue does not restore: the env, the Philox counter, the persistent
+        recurrent state (its bootstrap step advances it, Q2)."""
+        return self.env.state_tensors() + [self.step_dev, self.model.h_fw, self.model.c_fw]
 
     def _state_tensors(self):
         m = self.model
@@ -440,17 +455,16 @@ class BatchedTrainer:
         m.policy.invalidate_cached_msg()       # (the epilogue kernel zeroes finished replicas' h through raw pointers)
         ops.batch_epilogue(self.buf_g, self.last_done, self.ep_sum, self.ep_sq, self.ep_len, self.fin, self.env.T,
                            m.h_fw, m.c_fw, m.h_bw, m.c_bw, m.buf_fp[T], m.buf_fp[0], m.fp_uniform, m.buf_x[T], m.buf_x[0],
-                           self.done_pre)
+                           self.done_pre, skip_if=self._status[:1] if self.handoff_guard else None)
 
     def _capture_update(self):
         """Capture the update of a batch as hipGraphs (after at least one eager batch: the library GEMMs are tuned, every
         lazily built table and workspace exists).  One graph [rewards, returns, loss, backward, clip + RMSProp, epilogue];
-        with several ranks two, around the eager gradient all-reduce; for nets on the in-launch hand-off the epilogue stays
-        outside (the host looks at the status word between the optimiser step and the hand-over).  Capturing runs no
-        kernel; the host-side state the captured Python code touches is put back."""
+        with several ranks two, around the eager gradient all-reduce.  Capturing runs no kernel; the host-side state the
+        captured Python code touches is put back."""
         m = self.model
         split = m.dist_group is not None
-        inside = not self.handoff_guard
+        inside = True
         tun = None
         try:
             import torch.cuda.tunable as tunable
@@ -463,7 +477,7 @@ class BatchedTrainer:
         ops.keepalive_begin(self._keepalive)
         try:
             torch.cuda.synchronize()
-            g1, g2 = torch.cuda.CUDAGraph(), None
+            g1, g2 = self._new_graph(), None
             with torch.cuda.graph(g1):
                 m.load_rewards(self.buf_rraw)
                 m.update_grads(self.R_end)
@@ -472,7 +486,7 @@ class BatchedTrainer:
                     if inside:
                         self._epilogue()
             if split:
-                g2 = torch.cuda.CUDAGraph()
+                g2 = self._new_graph()
                 with torch.cuda.graph(g2):
                     m.update_apply(0.0, rotate=False, lr_dev=self.lr_dev)
                     if inside:
@@ -514,28 +528,47 @@ class BatchedTrainer:
     def run_batch(self):
         """One rollout + update.  Returns nothing; statistics stay on the device until `stats()`."""
         self.rollout()
-        handed_over = self._update()
-        if self.handoff_guard and ops.handoff_poisoned(self.device):
-            # (with the update replayed as a graph this read costs one launch latency per batch, not a host-bound update)
-            self._recover_from_handoff_timeout()
-            handed_over = False
-        if not handed_over:
+        if not self._update():
             self._epilogue()
         self.n_batches += 1
-        if self.handoff_fallbacks and not self.handoff_guard and self._wants_guard:
-            self._clean_since_fallback += 1
-            if self.rearm_after > 0 and self._clean_since_fallback >= self._rearm_wait:
-                self._rearm()
         if self.global_counter is not None:
             # the counter (like the reference's global step and the lr schedule) counts LOCK-steps, i.e. environment
             # steps per replica: `total_step` of the ini keeps its meaning (1e6 -> 16 667 updates at n_step 60)
             self.global_counter.advance(self.n_step)
+        if self.handoff_guard:
+            self._probe_handoff_status()
+        elif self.handoff_fallbacks and self._wants_guard:
+            self._clean_since_fallback += 1
+            if self.rearm_after > 0 and self._clean_since_fallback >= self._rearm_wait:
+                self._rearm()
+
+    def _probe_handoff_status(self):
+        """Queue a non-blocking copy of the status words behind the batch just launched, then look at the copy queued behind the
+        batch BEFORE it (long finished, or finishing while this batch runs: the host stays at most one batch ahead of the
+        device and never waits for the batch it has just launched)."""
+        host, ev = self._probes[self.n_batches & 1]
+        host.copy_(self._status, non_blocking=True)
+        ev.record()
+        prev, self._pending = self._pending, (host, ev)
+        if prev is not None:
+            prev[1].synchronize()
+            if int(prev[0][0]) != 0:
+                self._recover_from_handoff_timeout(batches=2)      # the poisoned batch and the one launched behind it
+
+    def flush(self):
+        """Look at the status of the batch launched last as well (end of a run, before statistics are read)."""
+        if self._pending is not None:
+            prev, self._pending = self._pending, None
+            prev[1].synchronize()
+            if int(prev[0][0]) != 0:
+                self._recover_from_handoff_timeout(batches=1)
 
     def _drop_graphs(self):
-        """Forget the captured graphs (the kernels a lock-step / an update launches are about to change); their memory pools
-        stay referenced until the new ones exist."""
-        self._keepalive.append((self.graph, self._upd))
-        self.graph, self._upd = None, None
+        """Forget the captured graphs (the kernels a lock-step / an update launches are about to change).  The device is idle
+        when they go (synchronised here: a rare event), so only ONE generation is parked -- until its replacements exist."""
+        torch.cuda.synchronize()
+        self._parked = (self.graph, self._upd, self._keepalive)      # (replaces the generation parked before)
+        self.graph, self._upd, self._keepalive = None, None, []
 
     def _rearm(self):
         """Try the one-launch hand-off kernels again after a run of clean batches on the launch-per-step forms."""
@@ -543,36 +576,42 @@ class BatchedTrainer:
         ops.enable_inkernel_handoff()
         self._clean_since_fallback = 0
         self._rearm_wait *= 2                  # the next time-out waits twice as long
-        if ops.handoff_enabled() and self.model.policy.pv_one_launch(self.E):
-            self.handoff_guard = True
-            self._drop_graphs()
+        # the guard follows the switch alone (as in __init__): ops.bptt_coupled picks its hand-off form from it, whether or not
+        # the lock-step has a one-launch form at this size
+        self.handoff_guard = self._wants_guard and ops.handoff_enabled()
+        self._pending = None
+        self._drop_graphs()
 
-    def _recover_from_handoff_timeout(self):
-        """A wave of an in-launch hand-off kernel gave up waiting during this batch (its neighbour block was not resident: the
-        device is shared, masked or profiled).  The optimiser step refused the batch on the device (nothing was applied); here
-        the batch is rewound to the state it started from, the launch-per-step kernels are selected (until `_rearm`), and the
-        batch is run again -- the weights end up exactly where a run without the one-launch kernels puts them."""
+    def _recover_from_handoff_timeout(self, batches=1):
+        """A wave of an in-launch hand-off kernel gave up waiting `batches` batches ago (its neighbour block was not resident:
+        the device is shared, masked or profiled).  Nothing of these batches was committed on the device: the optimiser steps
+        were refused, the epilogues were refused, the snapshot in `_shadow` still is the state the first of them started from.
+        Here the host rewinds its own counters, selects the launch-per-step kernels (until `_rearm`) and runs the batches again
+        -- the weights end up exactly where a run without the one-launch kernels puts them."""
         m, dev = self.model, self.device
-        logging.warning('in-launch hand-off timed out (batch %d): re-running the batch on the launch-per-step kernels and '
-                        'keeping them for the next %d batches' % (self.n_batches, self._rearm_wait))
+        torch.cuda.synchronize()
+        logging.warning('in-launch hand-off timed out (batch %d): re-running %d batch(es) on the launch-per-step kernels and '
+                        'keeping them for the next %d batches' % (self.n_batches - batches, batches, self._rearm_wait))
         ops.disable_inkernel_handoff()
         ops.handoff_clear(dev)
-        for s_, t_ in zip(self._shadow, self.env.state_tensors() + [self.step_dev]):
+        for s_, t_ in zip(self._shadow, self._shadow_tensors()):
             t_.copy_(s_)
-        m.h_fw.copy_(m.H_all[:, 0])            # the persistent state the rollout started from (its bootstrap step overwrote it)
-        m.c_fw.copy_(m.C_all[:, 0])
-        m.lr_scheduler.rewind(self.n_step)     # the update advanced the schedule
+        m.policy.invalidate_cached_msg()
+        m.lr_scheduler.rewind(self.n_step * batches)       # the refused updates advanced the schedule
+        self.n_batches -= batches
+        if self.global_counter is not None:
+            self.global_counter.advance(-self.n_step * batches)
+        self.handoff_guard, self._pending = False, None
         self._drop_graphs()                    # re-capture: the rollout now takes the two-launch lock-step, the update the step-wise BPTT
-        self.handoff_guard = False
-        self._clean_since_fallback = 0
-        self.rollout()
-        m.load_rewards(self.buf_rraw)
-        m.update(self.R_end, rotate=False)
-        ops.check_coupled_status(dev)
+        self._clean_since_fallback = -batches  # (the re-run batches below are not "clean batches since")
         self.handoff_fallbacks += 1
+        for _ in range(batches):
+            self.run_batch()
+        ops.check_coupled_status(dev)
 
     def stats(self, reset=True):
         """(episodes finished, mean of episode-mean reward, mean of episode-std, collisions) since last call."""
+        self.flush()
         f = self.fin.cpu().numpy().copy()
         ops.check_coupled_status()            # (the copy above synchronised) a wave of the coupled BPTT gave up waiting?
         if reset:
@@ -672,7 +711,7 @@ class BatchedTrainer:
                 episode()                             # warm-up (allocator, library handles)
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
+            graph = self._new_graph()
             with torch.cuda.graph(graph):
                 episode()
         return dict(env=env, prepare=prepare, episode=episode, statistics=statistics, graph=graph, hist=hist, total=total, steps=steps,

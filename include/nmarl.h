@@ -781,6 +781,7 @@ int nmarl_rmsprop_tf_clip(int32_t G, int64_t P, float* w, const float* g, float*
  *    (policies.py:151-154, cacc_env.py:184): h_fw, c_fw [N][E][H] zeroed, fp_0 <- fp_uniform [N][A]; for all:
  *    h_bw, c_bw <- h_fw, c_fw (states_bw <- states_fw, policies.py:115), fp_0 [N][E][A] <- fp_T, x_0 [E][N*F] <- x_T
  *    (slot T of the rollout buffers becomes slot 0), done_pre [E] f32 <- done.
+ * Everything the call writes is written by it alone: guarded by `skip_if` it is the commit point of a batch.
  */
 typedef struct nmarl_batch_epilogue {
     int64_t E;
@@ -792,9 +793,33 @@ typedef struct nmarl_batch_epilogue {
     const float *fp_T, *fp_uniform, *x_T;
     float *fp_0, *x_0, *done_pre;
     double* scratch;          /* [NMARL_EPILOGUE_SCRATCH] f64: per-block partial statistics */
+    const int32_t* skip_if;   /* NULL, or a device word: while it is != 0 the call changes NOTHING (the hand-off status word of
+                               * a model on in-launch hand-off kernels: a batch whose hand-off timed out is neither counted nor
+                               * handed over -- the state the batch started from stays in place for the host's re-run) */
 } nmarl_batch_epilogue_t;
 #define NMARL_EPILOGUE_SCRATCH 4096
 int nmarl_batch_epilogue(const nmarl_batch_epilogue_t* p, void* stream);
+
+/*
+ * n (<= NMARL_COPY_MAX) device-to-device copies dst[k] <- src[k] of bytes[k] bytes in ONE kernel launch; dst / src / bytes
+ * are HOST arrays (read at call time), the ranges of one pair must not overlap.  Replaces what the reference does with NumPy
+ * assignments between its Python-side buffers (agents/utils.py:732-761 `OnPolicyBuffer`, utils.py:163-197) where this
+ * library's callers keep device-resident state: inside a captured hipGraph the copy is a KERNEL node like every other launch
+ * of this library (a hipMemcpyAsync would be a memcpy node).  skip_if: NULL, or a device word -- while it is != 0 nothing is
+ * copied (the trainer's start-of-batch snapshot is not overwritten once the hand-off status word is raised).
+ */
+#define NMARL_COPY_MAX 16
+int nmarl_copy_multi(int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const int32_t* skip_if,
+                     void* stream);
+
+/*
+ * Measurement (kernel durations against the roofline; the reference has no counterpart): nmarl_timestamp stores the
+ * device's constant-rate wall clock into *out (device pointer) from a one-thread kernel on `stream`; nmarl_timestamp_rate_khz
+ * returns the clock's rate in kHz (hipDeviceAttributeWallClockRate of the current device; < 0: error).  Two stamps around a
+ * launch inside a captured hipGraph = that launch's duration where it runs (bench.py `roofline_bptt`).
+ */
+int nmarl_timestamp(uint64_t* out, void* stream);
+int nmarl_timestamp_rate_khz(void);
 
 #ifdef __cplusplus
 }

@@ -420,9 +420,13 @@ def heads(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a):
     return logits, v
 
 
-def wgrad(a, g):
+def wgrad(a, g, out=None):
     """a^T g over all rows (the weight gradient of a batched layer)."""
-    return torch.bmm(a.transpose(1, 2), g)
+    r = torch.bmm(a.transpose(1, 2), g)
+    if out is None:
+        return r
+    out.copy_(r)
+    return out
 
 
 def linear(x, w):
@@ -626,8 +630,11 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
     return dZ.sum(dim=(1, 2)), D1.sum(dim=(1, 2))
 
 
-def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre):
+def batch_epilogue(g, done, ep_sum, ep_sq, ep_len, fin, T_env, h_fw, c_fw, h_bw, c_bw, fp_T, fp_0, fp_uniform, x_T, x_0, done_pre,
+                   skip_if=None):
     """Restatement of nmarl_batch_epilogue (csrc/a2c.hip): the elementwise host code the batched loop used to run."""
+    if skip_if is not None and int(skip_if.reshape(-1)[0]) != 0:
+        return
     T = g.shape[0]
     gd = g.double()
     ep_sum += gd.sum(0)

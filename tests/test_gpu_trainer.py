@@ -10,30 +10,38 @@ from helpers import cacc_config
 pytestmark = pytest.mark.gpu
 
 
-def build(agent, E, use_graph, env_id_base=0, scenario='catchup', n_step=60):
-    from deeprl_network_amd.agents import models
-    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
+def build(agent, E, use_graph, env_id_base=0, scenario='catchup', n_step=60, episode_sec=None, **trainer_kw):
+    """scenario 'grid': BASELINE configs[3]'s environment (5 x 5 synthetic ATSC grid, config_ma2c_cnet_grid.ini), n_step as given."""
+    from deeprl_network_amd.envs import make_batch_env
+    from deeprl_network_amd.main import init_agent
     from deeprl_network_amd.utils import BatchedTrainer, Counter
-    cp = cacc_config(agent=agent, scenario=scenario, n_step=n_step, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
-    env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
-    cls = {'ia2c_fp': models.IA2C_FP, 'ma2c_nc': models.MA2C_NC, 'ma2c_ic3': models.MA2C_IC3, 'ia2c': models.IA2C,
-           'ma2c_cu': models.IA2C_CU, 'ma2c_dial': models.MA2C_DIAL}[agent]
+    if scenario == 'grid':
+        from helpers import grid_config
+        cp = grid_config(agent=agent, n_step=n_step)
+    else:
+        cp = cacc_config(agent=agent, scenario=scenario, n_step=n_step, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
+    if episode_sec is not None:
+        cp['ENV_CONFIG']['episode_length_sec'] = str(episode_sec)
+    env = make_batch_env(cp['ENV_CONFIG'], num_envs=E, env_id_base=env_id_base)
     np.random.seed(12)
-    model = cls(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
-                cp['MODEL_CONFIG'], seed=12, num_envs=E)
-    return env, model, BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=use_graph)
+    model = init_agent(env, cp['MODEL_CONFIG'], 10 ** 9, 12, num_envs=E)
+    return env, model, BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=use_graph, **trainer_kw)
 
 
-@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
-def test_graph_equals_eager_and_is_deterministic(agent):
-    E = 4096
+# (agent, scenario, replicas, n_step): BASELINE configs[1], [2] and [3]
+BASELINE_CASES = [('ia2c_fp', 'catchup', 4096, 60), ('ma2c_nc', 'slowdown', 4096, 60), ('ma2c_ic3', 'grid', 1024, 120)]
+
+
+@pytest.mark.parametrize('agent,scenario,E,n_step', BASELINE_CASES)
+def test_graph_equals_eager_and_is_deterministic(agent, scenario, E, n_step):
     runs = []
     for use_graph in (True, False, True):
-        env, model, tr = build(agent, E, use_graph)
+        env, model, tr = build(agent, E, use_graph, scenario=scenario, n_step=n_step)
         for _ in range(3):
             tr.run_batch()
         torch.cuda.synchronize()
-        runs.append((model.policy.params.flat.clone(), env.h.clone(), model.buf_act.clone(), tr.R_end.clone()))
+        assert tr.handoff_fallbacks == 0
+        runs.append((model.policy.params.flat.clone(), env.state_tensors()[0].clone(), model.buf_act.clone(), tr.R_end.clone()))
         del env, model, tr
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b), 'hipGraph replay differs from eager launches'
@@ -42,24 +50,26 @@ def test_graph_equals_eager_and_is_deterministic(agent):
     assert torch.isfinite(runs[0][0]).all()
 
 
-@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ma2c_ic3', 'ma2c_cu', 'ma2c_dial'])
-def test_captured_update_equals_eager_update(agent, monkeypatch):
+@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ma2c_nc', 'catchup'), ('ma2c_ic3', 'catchup'), ('ma2c_cu', 'catchup'),
+                                            ('ma2c_dial', 'catchup'), ('ma2c_ic3', 'grid')])
+def test_captured_update_equals_eager_update(agent, scenario, monkeypatch):
     """The A2C update replayed as a hipGraph (from the second batch on; rewards, return scan, loss, backward, clip + RMSProp,
     and for nets without the hand-off guard the batch epilogue) against the eager update behind the same rollout graph: weights,
     RMSProp slots, env state, actions, episode statistics bit-identical after 4 batches -- with a LINEAR lr schedule, whose
-    value reaches the captured optimiser step through a device scalar."""
+    value reaches the captured optimiser step through a device scalar.  ('grid': BASELINE configs[3], 25 x 1024, whose update
+    runs lstm_bptt_coupled_kernel<4,4,false>.)"""
     E = 1024
     runs = []
     for capture in ('1', '0'):
         monkeypatch.setenv('NMARL_CAPTURE_UPDATE', capture)
-        env, model, tr = build(agent, E, True, n_step=20)
+        env, model, tr = build(agent, E, True, n_step=20, scenario=scenario)
         model.lr_scheduler = type(model.lr_scheduler)(5e-4, 1e-5, 200, decay='linear')
         for _ in range(4):
             tr.run_batch()
         torch.cuda.synchronize()
         assert (tr._upd is not None) == (capture == '1'), tr.update_capture_error
-        assert tr.update_capture_error is None
-        runs.append((model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.h.clone(), model.buf_act.clone(),
+        assert tr.update_capture_error is None and tr.handoff_fallbacks == 0
+        runs.append((model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.state_tensors()[0].clone(), model.buf_act.clone(),
                      tr.R_end.clone(), tr.ep_sum.clone(), model.h_bw.clone(), torch.tensor(model.cur_lr)))
         del env, model, tr
     for k, (a, b) in enumerate(zip(*runs)):
@@ -294,6 +304,63 @@ def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, scenario, mon
         assert torch.equal(a, b), 'item %d differs between the in-launch env step and the env kernel' % k
 
 
+@pytest.mark.parametrize('E', [4096, 1000, 77])
+@pytest.mark.parametrize('scenario', ['catchup', 'slowdown'])
+def test_env_step_inside_the_lock_step_launch_vs_oracle(E, scenario):
+    """The env step INSIDE the lock-step launch (lstm_step_x_kernel<3,0,1> + ENV block) against oracle/cacc_ref.py directly
+    (cacc_env.py:191-242, 40-79, 166-189), not through the env kernel: every lock-step of 3 batches (= one 60-step episode,
+    auto-reset at its end) is one launch; the env state in front of each launch is read back, the fp32 oracle is put into that
+    state and stepped with the actions the launch drew, and the launch's observation, reward, global reward, done flag, new
+    state and -- at the episode end -- the Philox re-initialisation are compared at the per-step tolerance of SURVEY 8c
+    (rtol 1e-5; replicas whose min headway lands within 1e-4 of h_min excluded and counted)."""
+    from oracle import philox
+    from oracle.cacc_ref import CaccBatchRef, CaccParams
+    env, model, tr = build('ia2c_fp', E, False, scenario=scenario, n_step=20, episode_sec=6)     # 60 lock-steps: the third batch ends the episode
+    assert tr.enc_in_kernel and tr.env_in_kernel and not tr.fused_encode and env.T == 60
+    ref = CaccBatchRef(CaccParams(config=env.config), E=E, dtype=np.float32, train_mode=True)
+    assert ref.p.T == 60 and ref.p.batch_size == 20
+    ref.reset(np.zeros(E, np.float32))
+    episode = np.ones(E, dtype=np.int64)                      # the episode a replica's NEXT re-initialisation starts
+    pre = []
+    orig_act = model.act
+
+    def act(*a, **kw):
+        pre.append([t.cpu().numpy().copy() for t in (env.h, env.v, env.u, env.t, env.collided, env.v0_init)])
+        return orig_act(*a, **kw)
+    model.act = act
+    tol = dict(rtol=1e-5, atol=1e-6)
+    excluded = steps = 0
+    for b in range(3):
+        del pre[:]
+        tr.run_batch()
+        torch.cuda.synchronize()
+        pre.append([t.cpu().numpy().copy() for t in (env.h, env.v, env.u, env.t, env.collided, env.v0_init)])
+        acts, rraw, g = model.buf_act.cpu().numpy(), tr.buf_rraw.cpu().numpy(), tr.buf_g.cpu().numpy()
+        done, X = model.buf_done_post.cpu().numpy().astype(bool), model.buf_x.cpu().numpy()
+        for t in range(20):
+            ref.h, ref.v, ref.u = pre[t][0].copy(), pre[t][1].copy(), pre[t][2].copy()
+            ref.t, ref.collided, ref.v0_init = pre[t][3].astype(np.int64), pre[t][4].astype(bool), pre[t][5].copy()
+            ro, rr, rd, rg = ref.step(acts[t])
+            ok = np.abs(ref.h.min(axis=1) - 1.0) > 1e-4
+            excluded += int((~ok).sum())
+            steps += 1
+            assert np.array_equal(done[t][ok], rd[ok]) and (bool(rd.all()) or not (b == 2 and t == 19))
+            np.testing.assert_allclose(rraw[t][ok], rr[ok], rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(g[t][ok], rg[ok], rtol=1e-5, atol=1e-3)
+            if t == 19 and done[t].any():                     # the fused auto-reset behind a batch's last lock-step (Q4)
+                ro = ref.reset(philox.reset_uniform(env.seed, env.env_id_base + np.arange(E), episode), mask=done[t])
+                episode += done[t]
+            nh, nv, nu, nt, nc, nv0 = pre[t + 1]
+            np.testing.assert_allclose(nh[ok], ref.h[ok], **tol)
+            np.testing.assert_allclose(nv[ok], ref.v[ok], **tol)
+            np.testing.assert_allclose(nu[ok], ref.u[ok], rtol=1e-5, atol=2e-5)
+            np.testing.assert_allclose(nv0, ref.v0_init, **tol)
+            assert np.array_equal(nt, ref.t) and np.array_equal(nc.astype(bool)[ok], ref.collided[ok])
+            np.testing.assert_allclose(X[t + 1][ok], ro[ok], rtol=1e-5, atol=2e-5)
+    assert steps == 60 and excluded <= max(1, E // 100)
+    assert int(env.episode.min()) == 2 and int(env.t.max()) == 0
+
+
 def test_inkernel_encoders_equal_the_encoder_launch(monkeypatch):
     """IA2C-FP: the lock-step kernel running both input encoders itself (lstm_step_x_kernel<3,0,1>: no encoder launch, the env
     step alone behind it) against the env step + encoder launch (nmarl_cacc_step_encode) in front of the plain lock-step
@@ -406,54 +473,119 @@ def handoff_switch():
 
 
 @pytest.mark.parametrize('agent,site', [('ma2c_nc', 'step'), ('ma2c_nc', 'bptt'), ('ma2c_ic3', 'step')])
-def test_handoff_timeout_fails_closed(agent, site, handoff_switch, monkeypatch):
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_handoff_timeout_fails_closed(agent, site, use_graph, handoff_switch, monkeypatch):
     """An in-launch hand-off whose neighbour block never shows up (injected: block 0 of one launch publishes nothing, 4096
-    spins) must fail CLOSED: the poisoned batch changes no weight and no optimiser slot (the guarded RMSProp refuses it on the
-    device and counts it), the trainer rewinds the batch, pins the launch-per-step kernels and re-runs it -- after two batches
-    the weights equal, bit for bit, those of a run that never used the one-launch kernels.  site: the fault hits the
-    lock-step kernel of the rollout's first step / the coupled BPTT launch of the update."""
+    spins) must fail CLOSED, and without the host looking at the device between batches: the poisoned batch and the batch
+    launched behind it change no weight, no optimiser slot, no episode statistic and hand nothing over (the guarded RMSProp
+    and the guarded batch epilogue refuse on the device, the start-of-batch snapshot is not overwritten); the trainer notices
+    one batch LATE (pinned non-blocking copy of the status word), rewinds, pins the launch-per-step kernels and re-runs both
+    batches -- after them weights, optimiser slots, env state, actions, returns, lr schedule and counters equal, bit for bit,
+    those of a run that never used the one-launch kernels.  site: the fault hits the lock-step kernel of the rollout's first
+    step / the coupled BPTT launch of the update.  use_graph: the fault is armed for an eager first batch either way (the
+    fault flag is a launch argument), the second batch is a graph replay or eager."""
     from deeprl_network_amd import _lib, ops
-    from deeprl_network_amd.utils import BatchedTrainer
+    from deeprl_network_amd.utils import BatchedTrainer, Counter
     E, T = 256, 10
     # reference: launch-per-step kernels from the start
     monkeypatch.setenv('NMARL_INKERNEL_HANDOFF', '0')
     env, model, tr = build(agent, E, False, scenario='slowdown', n_step=T)
     assert not tr.handoff_guard
-    for _ in range(2):
+    for _ in range(3):
         tr.run_batch()
     torch.cuda.synchronize()
     ref = (model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.h.clone(), model.buf_act.clone(), tr.R_end.clone(),
-           model.lr_scheduler.n)
+           tr.ep_sum.clone(), model.h_bw.clone(), model.buf_x[0].clone(), model.lr_scheduler.n)
     del env, model, tr
     monkeypatch.delenv('NMARL_INKERNEL_HANDOFF')
-    # faulty run: eager rollout (the fault flag is a launch argument, a captured graph would replay it)
-    env, model, tr = build(agent, E, False, scenario='slowdown', n_step=T)
+    env, model, tr = build(agent, E, use_graph, scenario='slowdown', n_step=T)
+    tr.global_counter = Counter(10 ** 12, 10 ** 12, 10 ** 12)
     model.policy.refresh_wimage()              # (the message image decides whether the one-launch step exists)
     assert tr.handoff_guard and model.policy.pv_one_launch(E)
     w0, ms0 = model.policy.params.flat.clone(), model.policy.params.ms.clone()
     seen = {}
     orig = BatchedTrainer._recover_from_handoff_timeout
 
-    def spy(self):
+    def spy(self, batches=1):
+        torch.cuda.synchronize()
         seen['w'], seen['ms'] = self.model.policy.params.flat.clone(), self.model.policy.params.ms.clone()
-        seen['skipped'] = ops.handoff_skipped_updates(self.device)
-        orig(self)
+        seen['skipped'], seen['batches'] = ops.handoff_skipped_updates(self.device), batches
+        seen['ep_len'], seen['done_pre'] = self.ep_len.clone(), self.done_pre.clone()
+        orig(self, batches)
     monkeypatch.setattr(BatchedTrainer, '_recover_from_handoff_timeout', spy)
     skipped0 = ops.handoff_skipped_updates('cuda')
+    if use_graph:                              # the graphs are captured in front of the fault: a clean eager warm-up cannot be had
+        tr.use_graph = False                   # (the fault counter counts launches), so the poisoned batch itself runs eagerly
     # nth hand-off launch from now: 1 = the first lock-step; T + 2 = the BPTT behind T lock-steps + the bootstrap step
     _lib.check(_lib.lib.nmarl_test_handoff_fault(1 if site == 'step' else T + 2), 'nmarl_test_handoff_fault')
     tr.run_batch()
-    assert tr.handoff_fallbacks == 1 and not ops.handoff_enabled() and not model.policy.pv_one_launch(E)
-    assert torch.equal(seen['w'], w0) and torch.equal(seen['ms'], ms0), 'the poisoned batch reached the weights'
-    assert seen['skipped'] == skipped0 + 1
+    tr.use_graph = use_graph
+    assert tr.handoff_fallbacks == 0 and not seen, 'the host looked at the status word of the batch it had just launched'
+    tr.run_batch()                             # launched behind the poisoned one; its probe finds the word raised
+    assert tr.handoff_fallbacks == 1 and not ops.handoff_enabled() and not model.policy.pv_one_launch(E) and not tr.handoff_guard
+    assert seen['batches'] == 2 and seen['skipped'] == skipped0 + 2
+    assert torch.equal(seen['w'], w0) and torch.equal(seen['ms'], ms0), 'a refused batch reached the weights'
+    assert float(seen['ep_len'].abs().max()) == 0.0 and bool((seen['done_pre'] == 1).all()), 'a refused batch was handed over'
+    assert tr.n_batches == 2 and tr.global_counter.cur_step == 2 * T
     tr.run_batch()
+    tr.flush()
     torch.cuda.synchronize()
     ops.check_coupled_status()
-    got = (model.policy.params.flat, model.policy.params.ms, env.h, model.buf_act, tr.R_end, model.lr_scheduler.n)
-    for name, a, b in zip(('weights', 'rmsprop slots', 'env state', 'actions', 'R_end'), got, ref):
+    got = (model.policy.params.flat, model.policy.params.ms, env.h, model.buf_act, tr.R_end, tr.ep_sum, model.h_bw, model.buf_x[0],
+           model.lr_scheduler.n)
+    for name, a, b in zip(('weights', 'rmsprop slots', 'env state', 'actions', 'R_end', 'episode sums', 'h_bw', 'x_0'), got, ref):
         assert torch.equal(a, b), '%s differ from the launch-per-step run' % name
-    assert got[5] == ref[5]
+    assert got[8] == ref[8] and tr.n_batches == 3
     assert tr.stats()['episodes'] == 0
+
+
+def test_handoff_timeout_in_the_last_batch_is_found_by_flush(handoff_switch):
+    """The batch launched last has no batch behind it whose probe would look at its status word: `flush()` (called by
+    `stats()` and at the end of `run()`) does, and re-runs that one batch."""
+    from deeprl_network_amd import _lib, ops
+    E, T = 256, 10
+    env, model, tr = build('ma2c_nc', E, False, scenario='slowdown', n_step=T)
+    model.policy.refresh_wimage()
+    assert tr.handoff_guard
+    tr.run_batch()
+    w1 = model.policy.params.flat.clone()
+    _lib.check(_lib.lib.nmarl_test_handoff_fault(1), 'nmarl_test_handoff_fault')
+    tr.run_batch()
+    torch.cuda.synchronize()
+    assert tr.handoff_fallbacks == 0 and torch.equal(model.policy.params.flat, w1)
+    st = tr.stats()
+    assert tr.handoff_fallbacks == 1 and tr.n_batches == 2 and not torch.equal(model.policy.params.flat, w1) and st['episodes'] == 0
+    ops.check_coupled_status()
+
+
+def test_rearm_arms_the_guard_whenever_the_handoff_kernels_come_back(handoff_switch, monkeypatch):
+    """After a time-out and `rearm_after` clean batches the one-launch kernels are selected again -- and with them the guard,
+    also where the lock-step itself has no one-launch form at this size (the coupled BPTT still picks its hand-off form from
+    the process-wide switch): a second time-out must be found and recovered from, not stall the training."""
+    from deeprl_network_amd import _lib, ops
+    E, T = 256, 10
+    env, model, tr = build('ma2c_nc', E, False, scenario='slowdown', n_step=T, rearm_after=2)
+    model.policy.refresh_wimage()
+    monkeypatch.setattr(type(model.policy), 'pv_one_launch', lambda self, E_: False)      # two-launch lock-step, hand-off BPTT
+    assert tr.handoff_guard
+    _lib.check(_lib.lib.nmarl_test_handoff_fault(1), 'nmarl_test_handoff_fault')          # the first hand-off launch: the BPTT
+    tr.run_batch()
+    tr.run_batch()
+    assert tr.handoff_fallbacks == 1 and not tr.handoff_guard and not ops.handoff_enabled()
+    for _ in range(2):
+        tr.run_batch()
+    assert ops.handoff_enabled() and tr.handoff_guard, 're-armed kernels without the guard'
+    w = model.policy.params.flat.clone()
+    _lib.check(_lib.lib.nmarl_test_handoff_fault(1), 'nmarl_test_handoff_fault')
+    tr.run_batch()
+    tr.run_batch()
+    assert tr.handoff_fallbacks == 2
+    tr.run_batch()
+    tr.flush()
+    torch.cuda.synchronize()
+    ops.check_coupled_status()
+    assert not torch.equal(model.policy.params.flat, w) and torch.isfinite(model.policy.params.flat).all()
+    assert ops.handoff_skipped_updates('cuda') >= 4
 
 
 def test_handoff_capacity_and_fake_cus(monkeypatch, handoff_switch):

@@ -1,6 +1,7 @@
 """Run-to-run determinism over a longer horizon: the same agent trained twice for B batches in one process (hipGraph rollout and
 update); prints the first batch at which the flat parameter vectors differ.
-    python tools/determinism.py [agent] [scenario] [batches] [E]"""
+    python tools/determinism.py [agent] [scenario] [batches] [E]
+scenario: catchup | slowdown (CACC, n_step 60) | grid (BASELINE configs[3]: 5 x 5 synthetic ATSC grid, n_step 120)."""
 import os
 import sys
 
@@ -8,9 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch
-from helpers import cacc_config
-from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
-from deeprl_network_amd.main import AGENTS
+from helpers import cacc_config, grid_config
+from deeprl_network_amd.envs import make_batch_env
+from deeprl_network_amd.main import init_agent
 from deeprl_network_amd.utils import BatchedTrainer, Counter
 
 agent = sys.argv[1] if len(sys.argv) > 1 else 'ma2c_nc'
@@ -20,10 +21,13 @@ E = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 every = 10
 runs = []
 for k in range(2):
-    cp = cacc_config(agent=agent, scenario=scenario, seed=12, n_step=60, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
-    env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
+    if scenario == 'grid':
+        cp = grid_config(agent=agent, seed=12)
+    else:
+        cp = cacc_config(agent=agent, scenario=scenario, seed=12, n_step=60, reward_norm=800.0 if agent.startswith('ia2c') else 5000.0)
+    env = make_batch_env(cp['ENV_CONFIG'], num_envs=E)
     np.random.seed(12)
-    model = AGENTS[agent](env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9, cp['MODEL_CONFIG'], seed=12, num_envs=E)
+    model = init_agent(env, cp['MODEL_CONFIG'], 10 ** 9, 12, num_envs=E)
     tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
     snaps = []
     for b in range(1, B + 1):

@@ -178,6 +178,8 @@ SIGNATURES = {
                               C.POINTER(Head), C.POINTER(Msg), _p],
     'nmarl_lstm_step_x_enc': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
                               C.POINTER(Head), C.POINTER(StepEnc), _p],
+    'nmarl_lstm_step_x_msg_enc': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
+                                  C.POINTER(Head), C.POINTER(Msg), C.POINTER(StepEnc), _p],
     'nmarl_lstm_step_env_words': [_i64],
     'nmarl_lstm_bptt_wimage_floats': [_i32],
     'nmarl_lstm_bptt_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],

@@ -394,7 +394,9 @@ class IA2C:
         if pre_encoded:
             enc = self.encode_target(self.n_step)
         elif self.save_acts and p.enc_in_kernel(self.E, self.compact_obs):
-            enc, ob = None, dict(x=self.buf_x[self.n_step], fp=self.fp)          # (nothing of the bootstrap step is kept)
+            # (nothing of the bootstrap step is kept; a coupled net's encoders hand their output to the K loop THROUGH the x slot:
+            # a scratch one here, slab n_step of the saved inputs must stay zero)
+            enc, ob = (self.encode_target(self.n_step) if p.coupled else None), dict(x=self.buf_x[self.n_step], fp=self.fp)
         elif self.save_acts and p.encodes_in_step(self.E, self.compact_obs):
             enc, ob = self.encode_target(self.n_step), self.buf_x[self.n_step]     # the step kernel runs the encoder itself
         else:

@@ -20,6 +20,7 @@ row i holds agent i's parameters, every tensor is a strided view.  The gradient
 and the RMSProp slot use the same layout, so clip + RMSProp is one fused kernel
 and the data-parallel exchange is one RCCL all-reduce of the gradient buffer.
 """
+import os
 import warnings
 
 import numpy as np
@@ -454,6 +455,12 @@ class BatchedPolicy:
         caller hands `step_policy_value` the env's compact observation and the fingerprints as `ob`)."""
         return False
 
+    @property
+    def env_step_in_kernel(self):
+        """With the encoders inside the lock-step launch (`enc_in_kernel`), should the batched CACC engine put the env step there
+        too (ONE launch per lock-step)?  A measured choice per net: profiles/r05_ab_lockstep.txt, r06_ab_lockstep_nc.txt."""
+        return True
+
     def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, h_out=None, c_out=None, gates=None,
                           defer_action_term=False, save=None, ob=None, **draw):
         """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) in one kernel:
@@ -465,7 +472,9 @@ class BatchedPolicy:
             if self.coupled:
                 z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
                 xs[4]['sync'] = self._sync_words(h.shape[1])
-                if ob is not None:
+                if isinstance(ob, dict):         # lstm_comm: both input encoders (and the env step) inside the launch, see `enc_in_kernel`
+                    xs[4]['enc_spec'] = self._enc_spec(ob['x'], ob['fp'], None, ob.get('env'), ob.get('bits'))
+                elif ob is not None:
                     xs[4]['ob'] = self._ob_spec(ob)
             elif ob is not None:
                 # the encoders run inside the launch: ob = dict(x = compact observation [E,N,5], fp = previous policies [N,E,4]);
@@ -492,7 +501,7 @@ class BatchedPolicy:
         T, E = done.shape
         Xv = X.reshape(T * E, self.N, X.shape[-1]).transpose(0, 1)          # gathered [.., n_obs] or compact [.., n_feat] slab
         if self.coupled:
-            return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext)
+            return self._unroll_saved_coupled(Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext, S_bits)
         if S_bits is not None:           # the sign image of S the lock-step kernel's encoders wrote (FPPolicy): S is not re-read
             s = self._enc(Xv, FP, saved=S.view(self.N, T * E, S.shape[-1]), bits=S_bits.view(self.N, T * E, 4))
         else:
@@ -505,10 +514,11 @@ class BatchedPolicy:
         """Extra per-step tensors a coupled net saves besides S / G / Hall / Call: {name: width}."""
         return {}
 
-    def _unroll_saved_coupled(self, Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext=None):
+    def _unroll_saved_coupled(self, Xv, FP, S, G, Hall, Call, done, masked_steps, S_ext=None, S_bits=None):
         T, E = done.shape
         kind, wx, w_msg, b_msg, mfc_w, mfc_b = self._seq_args()
-        enc = self._enc_saved(Xv, FP, S)
+        # (S_bits: the sign image of the encoders' output, written by the lock-step kernel that ran them -- lstm_comm's one-launch form)
+        enc = self._enc_saved(Xv, FP, S) if S_bits is None else self._enc_saved(Xv, FP, S, bits=S_bits.view(self.N, T * E, 4))
         extra = dict(getattr(self, '_extra', {}))
         if kind == 'dial' and 'A2' in getattr(self, '_extra_full', {}) and extra.get('A2') is not None:
             extra['A2'] = self._extra_full['A2']          # the (T + 1)-slab buffer itself: the weight gradient reads it in place
@@ -781,12 +791,13 @@ class NCMultiAgentPolicy(BatchedPolicy):
         s = ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b'), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)], ops.BIAS_RELU)
         return ops.linear(s, p['wx_hid'][:, :2 * H])
 
-    def _enc_saved(self, xv, fp, S):
-        """[hx | hp] as the rollout wrote it into the first 2H columns of the saved LSTM inputs (backward only)."""
+    def _enc_saved(self, xv, fp, S, bits=None):
+        """[hx | hp] as the rollout wrote it into the first 2H columns of the saved LSTM inputs (backward only); bits: its sign image."""
         p = self.params
         H = self.n_h
         Sv = S.view(self.N, -1, S.shape[-1])[:, :, :2 * H]
-        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b'), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)], ops.BIAS_RELU, saved=Sv)
+        return ops.fc_concat([self._ob_part(xv, 'w_ob', 'w_ob_b'), (fp, p['w_fp'], p['w_fp_b'], self.nbr_idx)], ops.BIAS_RELU, saved=Sv,
+                             bits=bits)
 
     def _recur_in(self, enc, h):
         p = self.params
@@ -817,6 +828,24 @@ class NCMultiAgentPolicy(BatchedPolicy):
 
     def fused_env_encode(self, fp_next, out):
         return self._fused_spec(('w_ob', 'w_ob_b'), ('w_fp', 'w_fp_b'), fp_next, out) if self.xside else None
+
+    def enc_in_kernel(self, E, compact):
+        """The one-launch lock-step also runs the two input encoders (and, for the batched CACC engine, the env step): ONE launch per
+        lock-step (csrc/lstm_mfma.hip <4,1,1>).  NMARL_NC_ONE_LAUNCH=0: the encoders stay behind the env kernel (nmarl_cacc_step_encode)."""
+        return bool(compact) and self.xside and not self.hetero and self.pv_one_launch(E) and \
+            ops.step_enc_supported(self.n_feat, self.n_a, self.m_max, self.n_fc, self.n_h, self.N) and \
+            os.environ.get('NMARL_NC_ONE_LAUNCH', '1') != '0'
+
+    @property
+    def env_step_in_kernel(self):
+        # lstm_comm: the one-launch form exists and is bit-identical (tests), but on the same box it is no faster than the env
+        # kernel behind the <4,1,1> launch -- rollout graph 5.59-5.62 vs 5.53-5.56 ms (two launches, round 5: 5.60-5.64),
+        # profiles/r06_ab_lockstep_nc.txt -- so the env kernel stays a launch of its own.  NMARL_NC_ENV_IN_KERNEL=1: one launch.
+        return os.environ.get('NMARL_NC_ENV_IN_KERNEL', '0') == '1'
+
+    def _enc_spec(self, x, fp, out, env=None, bits=None):
+        p = self.params
+        return ops.step_enc_spec(x, fp, p['w_ob'], p['w_ob_b'], p['w_fp'], p['w_fp_b'], self.nbrs, out=out, env=env, bits=bits)
 
     def _recur_addends(self, enc, h, second=False, save=None, fuse_msg=False):
         p = self.params

@@ -694,11 +694,16 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // of both epilogues running side by side with an idle matrix pipe.
     constexpr bool DEPH = MSG == 0 && ENC == 0;
     constexpr int NBUF = DEPH ? 3 : 2;
-    static_assert(ENC == 0 || (MSG == 0 && HEAD == 3), "ENC: the uncoupled nets' policy + value launch");
+    static_assert(ENC == 0 || (MSG == 0 && HEAD == 3) || (MSG == 1 && HEAD == 4), "ENC: the policy + value launch of IA2C-FP / NeurComm");
+    // Where the encoders' 128 outputs wait for the K loop: ENC_LDS (uncoupled nets) in lane-private LDS slots; ENC_GLB (NeurComm: the
+    // message image and the parked cell state leave no 64 KB of LDS) in the S slot of the saved activations itself -- every lane
+    // stores its 8 x 16 bytes there (the update needs them anyway) and the K loop's ordinary A loads read them back: the SAME lane
+    // reads exactly the addresses it wrote (C/D layout of the transposed product == A layout of the K loop), program order.
+    constexpr bool ENC_LDS = ENC != 0 && MSG == 0, ENC_GLB = ENC != 0 && MSG != 0;
     // ENC: [chunks][head weights][union(h' tiles, lane-private x slots: 8 float4 x 512 threads)] -- the tiles are first written in
     // the cell epilogue, behind the last tick's barrier, when every wave has consumed its x chunks
-    float* hw_lds = ENC ? lds + NBUF * CH_FLOATS : lds + NBUF * CH_FLOATS + WAVES2 * R16 * APITCH;   // head weights: [64][A] actor, then [64] critic
-    float* a_tile = (ENC ? hw_lds + HW_FLOATS : lds + NBUF * CH_FLOATS) + wave * R16 * APITCH;
+    float* hw_lds = ENC_LDS ? lds + NBUF * CH_FLOATS : lds + NBUF * CH_FLOATS + WAVES2 * R16 * APITCH;   // head weights: [64][A] actor, then [64] critic
+    float* a_tile = (ENC_LDS ? hw_lds + HW_FLOATS : lds + NBUF * CH_FLOATS) + wave * R16 * APITCH;
     float4* xslot = reinterpret_cast<float4*>(hw_lds + HW_FLOATS) + threadIdx.x;            // ENC: + 512 q, q = 0..7
     const int nx = xa.nx, nch = xa.nx + 2;
     const float4* img = reinterpret_cast<const float4*>(xa.img + (int64_t)n * xa.img_sn);
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const float* hrow = a.h_in + (int64_t)n * a.h_sn + arow * H + 4 * grp;
     float4 a0, a1, n0, n1;
 #define NMARL_A_LOAD(ch, d0, d1)     /* raw load; the (1 - done) mask of the h chunks is applied at first use */ \
-    if (ENC) {      /* x chunks: the lane's own slots; h chunks: global.  BOTH requested unconditionally (clamped), then selected */ \
+    if (ENC_LDS) {      /* x chunks: the lane's own slots; h chunks: global.  BOTH requested unconditionally (clamped), then selected */ \
         const int hc_ = (ch) - nx < 0 ? 0 : (ch) - nx;                                    \
         const int xc_ = (ch) < nx ? (ch) : nx - 1;                                        \
         const float4 h0_ = *reinterpret_cast<const float4*>(hrow + hc_ * CH_K);           \
@@ -993,7 +998,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         if (threadIdx.x < MAXA) hw_lds[H * MAXA + threadIdx.x] = (int)threadIdx.x < A ? hw1 : 0.0f;
         if (PV && threadIdx.x < H) hw_lds[H * MAXA + MAXA + threadIdx.x] = hw2;
     }
-    float* e_lds = hw_lds + HW_FLOATS + 8 * 512 * 4;                   // ENC: [6][64][4] W image + [128] biases (behind the x slots)
+    // ENC: [6][64][4] W image + [128] biases -- behind the x slots; ENC_GLB: over the parked-cell-state slots behind the W_msg image
+    // (6.5 of their 8 KB; the slots are first written after the message pre-phase, a block barrier behind the image's last read)
+    float* e_lds = ENC_GLB ? m_lds + xa.msg_kc * (CH_K * 64) : hw_lds + HW_FLOATS + 8 * 512 * 4;
     if (ENC) {
         NMARL_STAMP(37)
 #pragma unroll
@@ -1017,6 +1024,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             eacc[mt] = f32x4{b0.x, b0.y, b0.z, b0.w};
             eacc[4 + mt] = f32x4{b1.x, b1.y, b1.z, b1.w};
         }
+        if (ENC_GLB) __syncthreads();        // every wave has read the image: its LDS becomes the parked-cell-state slots again
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
             eacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].x, ein[s_], eacc[0], 0, 0, 0);
@@ -1033,21 +1041,27 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         }
         NMARL_STAMP(50)
         unsigned pos = 0;                    // bit 4 mt + i: output 16 mt + 4 grp + i of row c is > 0 (the relu derivative the update needs)
+        float* const so_ = ENC_GLB && e_out != nullptr ? e_out + (int64_t)n * e_out_sn + (row0 + c) * e_out_row + 4 * grp : nullptr;
 #pragma unroll
         for (int mt = 0; mt < 8; ++mt) {
             eacc[mt] = __builtin_elementwise_max(eacc[mt], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
-            xslot[512 * mt] = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};      // (lane-private: re-read by this lane only)
+            const float4 v_ = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};
+            if (ENC_LDS) xslot[512 * mt] = v_;                                   // (lane-private: re-read by this lane only)
+            if (ENC_GLB && so_ != nullptr && row0 + c < a.E) *reinterpret_cast<float4*>(so_ + 16 * mt) = v_;     // columns 16 mt + 4 grp + {0..3}
 #pragma unroll
             for (int i = 0; i < 4; ++i) pos |= (eacc[mt][i] > 0.0f ? 1u : 0u) << (4 * mt + i);
         }
         // one word per lane, 16 bytes per row: the update's encoder backward reads these instead of the 512-byte row of S
         if (e_bits != nullptr && row0 + c < a.E) e_bits[(int64_t)n * e_bits_sn + (row0 + c) * 4 + grp] = pos;
         NMARL_STAMP(51)
-        a0 = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
-        a1 = float4{eacc[1][0], eacc[1][1], eacc[1][2], eacc[1][3]};
-        // (the saved LSTM input of the update is NOT stored here: 8 x 16-byte stores per lane at once are a 16.8-MB burst from all
-        // 256 blocks in the same phase, ~3.4 k cycles of blocked store issue in front of tick 0 (tools/step_timeline.py enc noout);
-        // each x chunk's two pieces leave in the tick that multiplies them instead -- the A operands ARE those values)
+        if (ENC_LDS) {
+            a0 = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
+            a1 = float4{eacc[1][0], eacc[1][1], eacc[1][2], eacc[1][3]};
+        }
+        // (ENC_LDS: the saved LSTM input of the update is NOT stored here: 8 x 16-byte stores per lane at once are a 16.8-MB burst from
+        // all 256 blocks in the same phase, ~3.4 k cycles of blocked store issue in front of tick 0 (tools/step_timeline.py enc noout);
+        // each x chunk's two pieces leave in the tick that multiplies them instead -- the A operands ARE those values.  ENC_GLB pays
+        // that burst: it hides behind the message pre-phase that follows, whose operands were requested before the barrier)
         asm volatile("" :: "s"(ka_touch));
         NMARL_STAMP(38)
     }
@@ -1219,7 +1233,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             }
             const float* buf = lds + bsel * CH_FLOATS + (4 * grp * 16 + c) * 20;
             NMARL_CHUNK(buf, a0, a1)
-            if (ENC && ch < nx && e_out != nullptr && row0 + c < a.E) {      // ENC: this chunk of the encoded input, for the update
+            if (ENC_LDS && ch < nx && e_out != nullptr && row0 + c < a.E) {      // ENC: this chunk of the encoded input, for the update
                 float* so = e_out + (int64_t)n * e_out_sn + (row0 + c) * e_out_row + 4 * grp + ch * CH_K;
                 *reinterpret_cast<float4*>(so) = a0;
                 *reinterpret_cast<float4*>(so + 16) = a1;
@@ -1732,7 +1746,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     const int KM = mk ? H : 0;                   // columns of x the message pre-phase produces
     if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K || mk < 0 || mk > 3 ||
         (mk && (KX2 != 0 || KX < H)) ||
-        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 - KM > 0 && !x && !enc) || (KX2 > 0 && !x2))))
+        (E > 0 && (!h_in || !img || !bias || !c_prev || !done || !c_new || !h_new || (KX - KX2 - KM > 0 && !x && (!enc || mk)) || (KX2 > 0 && !x2))))
         return NMARL_EINVAL;
     if (mk && E > 0) {
         if (msg->m_max <= 0 || msg->m_max > 8 || !msg->nbr_idx || !msg->img || !msg->b || msg->b_sn < H ||
@@ -1767,7 +1781,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         ((uintptr_t)c_new % 16) || ((uintptr_t)h_new % 16) || (gates && ((uintptr_t)gates % 16)) ||
         ((uintptr_t)bias % 16) || ((uintptr_t)c_prev % 16) || (zadd1 && ((uintptr_t)zadd1 % 16)) || (zadd2 && ((uintptr_t)zadd2 % 16)) ||
         img_sn < (int64_t)(KX + H) * 320 || (img_sn % 4) ||
-        (KX - KX2 - KM > 0 && !enc && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
+        (KX - KX2 - KM > 0 && (!enc || mk) && (x_row < KX - KX2 - KM || (x_row % 4) || (x_sn % 4) || ((uintptr_t)x % 16))) ||
         (KX2 > 0 && (x2_row < KX2 || (x2_row % 4) || (x2_sn % 4) || ((uintptr_t)x2 % 16))))
         return NMARL_EINVAL;
     XArgs xa{};
@@ -1779,7 +1793,8 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     a.E = E;
     a.blocks_per_agent = (int)((E + ROWS_B - 1) / ROWS_B);
     if (kind != 0) a.hd = *head;
-    xa.x = (KX - KX2 - KM > 0 && !enc) ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
+    // (ENC with a message term: the encoders' output travels THROUGH x -- the S slot of the saved activations -- so x stays)
+    xa.x = (KX - KX2 - KM > 0 && (!enc || mk)) ? x : nullptr; xa.x_sn = x_sn; xa.x_row = x_row;
     xa.x2 = KX2 > 0 ? x2 : nullptr; xa.x2_sn = x2_sn; xa.x2_row = x2_row;
     xa.img = img; xa.img_sn = img_sn;
     xa.nx = KX / CH_K; xa.nx1 = (KX - KX2) / CH_K; xa.N = N;
@@ -1817,20 +1832,24 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         NMARL_SET_LDS((lstm_step_x_kernel<3, 0>)) NMARL_SET_LDS((lstm_step_x_kernel<1, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 1>))
         NMARL_SET_LDS((lstm_step_x_kernel<1, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 2>))
         NMARL_SET_LDS((lstm_step_x_kernel<1, 3>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 3>))
-        NMARL_SET_LDS((lstm_step_x_kernel<4, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2>))
+        NMARL_SET_LDS((lstm_step_x_kernel<4, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 1, 1>))
 #undef NMARL_SET_LDS
         lds_once.done(lds_bit);
     }
     if (mk && kind == 0) return NMARL_EINVAL;                   // the message pre-phase exists for the policy / value steps
     const dim3 grid(a.blocks_per_agent * N);
     if (enc) {
-        // the input encoders inside the launch (ENC 1): the uncoupled nets' policy + value step on the CACC input layout
-        if (mk != 0 || kind != 3 || KX != 2 * H || KX2 != 0 || zadd1 || zadd2 || N > 32 || enc->F != 5 || enc->A != 4 || enc->m_max != 2 ||
+        // the input encoders inside the launch (ENC 1) on the CACC input layout: the uncoupled nets' policy + value step (<3,0,1>), or
+        // NeurComm's one-launch lock-step (<4,1,1>: x = the S slot the encoders' [hx | hp] goes to AND the K loop reads it back from)
+        const bool coupled = mk == 1 && kind == 3;
+        if ((mk != 0 && !coupled) || kind != 3 || KX != (coupled ? 3 * H : 2 * H) || KX2 != 0 || zadd1 || zadd2 || N > 32 || enc->F != 5 ||
+            enc->A != 4 || enc->m_max != 2 ||
             !enc->ob || !enc->fp || !enc->w_ob || !enc->b_ob || !enc->w_fp || !enc->b_fp || enc->ob_row < (int64_t)N * 5 ||
             enc->fp_sn < E * 4 || enc->w_ob_sn < 15 * H || enc->w_fp_sn < 8 * H || enc->b_ob_sn < H || enc->b_fp_sn < H ||
             (enc->b_ob_sn % 4) || (enc->b_fp_sn % 4) || ((uintptr_t)enc->b_ob % 16) || ((uintptr_t)enc->b_fp % 16) ||
             (enc->out && (((uintptr_t)enc->out % 16) || enc->out_row < 2 * H || (enc->out_row % 4) || (enc->out_sn % 4) ||
-                          enc->out_sn < E * enc->out_row)))
+                          enc->out_sn < E * enc->out_row)) ||
+            (coupled && enc->out && (enc->out != x || enc->out_sn != x_sn || enc->out_row != x_row)))
             return NMARL_EINVAL;
         for (int i = 0; i < 2 * N; ++i)
             if (enc->nbr[i] < -1 || enc->nbr[i] >= N) return NMARL_EINVAL;
@@ -1838,6 +1857,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.e_wob = enc->w_ob; xa.e_bob = enc->b_ob; xa.e_wfp = enc->w_fp; xa.e_bfp = enc->b_fp;
         xa.e_wob_sn = enc->w_ob_sn; xa.e_bob_sn = enc->b_ob_sn; xa.e_wfp_sn = enc->w_fp_sn; xa.e_bfp_sn = enc->b_fp_sn;
         xa.e_out = enc->out; xa.e_out_sn = enc->out_sn; xa.e_out_row = enc->out_row;
+        if (coupled) { xa.e_out = const_cast<float*>(x); xa.e_out_sn = x_sn; xa.e_out_row = x_row; }
         if (enc->relu_bits && (((uintptr_t)enc->relu_bits % 4) || enc->relu_bits_sn < E * 4)) return NMARL_EINVAL;
         xa.e_bits = enc->relu_bits; xa.e_bits_sn = enc->relu_bits_sn;
         for (int i = 0; i < 64; ++i) xa.e_nbr[i] = i < 2 * N ? enc->nbr[i] : -1;
@@ -1856,16 +1876,18 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             xa.ev_seed = enc->seed; xa.ev_base = enc->env_id_base; xa.ev_episode = enc->episode;
             xa.ev_cnt = enc->cnt;
         }
-        static NmarlPerDeviceOnce enc_once;
-        const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4 + 6 * 64 * 4 + 2 * H) * sizeof(float);
-        if (const unsigned long long bit = enc_once.pending(); bit != ~0ull) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lb_e) != hipSuccess)
-                return NMARL_EHIP;
-            enc_once.done(bit);
+        if (!coupled) {
+            static NmarlPerDeviceOnce enc_once;
+            const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4 + 6 * 64 * 4 + 2 * H) * sizeof(float);
+            if (const unsigned long long bit = enc_once.pending(); bit != ~0ull) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lb_e) != hipSuccess)
+                    return NMARL_EHIP;
+                enc_once.done(bit);
+            }
+            hipLaunchKernelGGL((lstm_step_x_kernel<3, 0, 1>), grid, dim3(512), lb_e, static_cast<hipStream_t>(stream), xa);
+            return nmarl_check_launch();
         }
-        hipLaunchKernelGGL((lstm_step_x_kernel<3, 0, 1>), grid, dim3(512), lb_e, static_cast<hipStream_t>(stream), xa);
-        return nmarl_check_launch();
     }
     if (mk && kind == 3) {
         // policy step + value re-step of a coupled net in ONE launch: the re-step's message term needs the neighbours' new h, handed
@@ -1911,7 +1933,9 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     if (mk == 0) {
         if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);
     } else if (mk == 1) {
-        if (kind == 1) NMARL_LX(1, 1); else if (kind == 2) NMARL_LX(2, 1); else NMARL_LX(4, 1);
+        if (kind == 1) NMARL_LX(1, 1); else if (kind == 2) NMARL_LX(2, 1);
+        else if (enc) hipLaunchKernelGGL((lstm_step_x_kernel<4, 1, 1>), grid, dim3(512), lb + lb_extra, st, xa);
+        else NMARL_LX(4, 1);
     } else if (mk == 2) {
         if (kind == 1) NMARL_LX(1, 2); else if (kind == 2) NMARL_LX(2, 2); else NMARL_LX(4, 2);
     } else {
@@ -1941,6 +1965,16 @@ extern "C" int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t Hh, int32_t K
     if (!msg || msg->kind == 0 || !head) return NMARL_EINVAL;
     return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
                          c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream);
+}
+
+extern "C" int nmarl_lstm_step_x_msg_enc(int64_t E, int32_t N, int32_t Hh, int32_t KX, float* x, int64_t x_sn, int64_t x_row,
+                                         const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                                         int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                                         int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
+                                         const nmarl_head_t* head, const nmarl_msg_t* msg, const nmarl_step_enc_t* enc, void* stream) {
+    if (!msg || msg->kind != 1 || !head || head->kind != 3 || !enc || !x) return NMARL_EINVAL;
+    return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
+                         c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream, enc);
 }
 
 extern "C" int nmarl_lstm_step_env_words(int64_t E) { return E <= 0 ? 0 : (int)((E + 63) / 64 * 64); }

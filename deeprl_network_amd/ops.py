@@ -310,6 +310,16 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
                 raise _lib.NmarlError('%s: head kind 3 with a message term needs msg["sync"] (step_sync_words)' % what)
             m.sync = ptr(sync, torch.int32)
             m.status = ptr(handoff_status(h.device), torch.int32)
+        spec = msg.get('enc_spec')
+        if spec is not None:
+            # NeurComm's one-launch lock-step: the two input encoders (and, with spec['env'], the env step) inside this launch; x --
+            # slot t of the saved LSTM inputs -- receives their output and is read back by the K loop
+            if head.kind != 3 or msg['kind'] != MSG_GATHER_RELU or x is None:
+                raise _lib.NmarlError('%s: the in-kernel encoders of a coupled net need lstm_comm\'s policy + value step and its x slot' % what)
+            check(lib.nmarl_lstm_step_x_msg_enc(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
+                                                *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
+                                                C.byref(m), C.byref(_step_enc(dict(spec, out=None), N, E)), stream()), what)
+            return
         check(lib.nmarl_lstm_step_x_msg(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
                                         *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
                                         C.byref(m), stream()), what)
@@ -320,8 +330,8 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
 
 
 def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
-    """The two input encoders of IA2C-FP fit the lock-step kernel's register-only pre-phase (csrc/lstm_mfma.hip, ENC): the CACC
-    input layout -- 5 own features x (1 + 2 neighbours) and 2 x 4 fingerprint entries -> 64 + 64 outputs."""
+    """The two input encoders of IA2C-FP / NeurComm fit the lock-step kernel's register-only pre-phase (csrc/lstm_mfma.hip, ENC): the
+    CACC input layout -- 5 own features x (1 + 2 neighbours) and 2 x 4 fingerprint entries -> 64 + 64 outputs."""
     return n_feat == 5 and n_a == 4 and m_max == 2 and n_fc == FC_J and n_h == FUSED_H and N <= 32 and \
         os.environ.get('NMARL_INKERNEL_ENCODE', '1') != '0'
 
@@ -414,7 +424,8 @@ def ob_encoder_supported(n_feat, n_obs, n_h):
 def lstm_ob_wimage(w_ob, pad, out=None):
     """LDS image of W_ob [N,n_obs,64] for the in-kernel observation encoder: zero-padded to 64 rows in `pad` [N,64,64] (kept
     by the caller, rows >= n_obs stay zero), then the message image layout."""
-    pad[:, :w_ob.shape[1]].copy_(w_ob)
+    with torch.no_grad():      # (w_ob is a parameter: tracked, the copy would hang `pad` -- and an AccumulateGrad node on the stream of the
+        pad[:, :w_ob.shape[1]].copy_(w_ob)       # first call -- onto the autograd graph; a node created on the default stream breaks captures)
     return lstm_msg_wimage(pad, out=out)
 
 

@@ -298,15 +298,8 @@ class BatchedTrainer:
         # CACC: compact observations (own features only; the encoder gathers the neighbours) -- SURVEY.md 8d's layout
         self.compact_obs = bool(compact_obs) and hasattr(env, 'set_compact_obs') and model.enable_compact_obs() and \
             env.set_compact_obs(True)
-        # CACC: the env kernel runs the next lock-step's input encoders behind its step (csrc/cacc.hip cacc_step_encode_kernel)
-        # ... unless the lock-step kernel runs the encoders itself (csrc/lstm_mfma.hip ENC: IA2C-FP), then the env step stays alone
-        self.enc_in_kernel = self.saved_acts and self.compact_obs and env.device.type == 'cuda' and \
-            model.policy.enc_in_kernel(env.E, True)
-        # ... and the env step as well, behind the action draw of the same launch: ONE launch per lock-step (ENV block of the kernel)
-        self.env_in_kernel = self.enc_in_kernel and hasattr(env, 'inkernel_step') and env.n_agent == 8 and ops.step_env_supported()
-        self.fused_encode = bool(fused_encode) and self.saved_acts and self.compact_obs and not self.enc_in_kernel and \
-            getattr(env, 'supports_fused_encode', False) and env.device.type == 'cuda' and \
-            model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1)) is not None
+        self._want_fused_encode = bool(fused_encode)
+        self._select_lock_step_form()
         self.E, self.N = env.E, env.n_agent
         self.n_step = model.n_step
         assert env.T % self.n_step == 0
@@ -430,6 +423,23 @@ class BatchedTrainer:
 
     def _new_graph(self):
         return torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graphs else torch.cuda.CUDAGraph()
+
+    def _select_lock_step_form(self):
+        """How many launches a lock-step is (decided at construction and again whenever the in-launch hand-off kernels are switched
+        off / on: a coupled net's one-launch form exists only with them)."""
+        env, model = self.env, self.model
+        if env.device.type == 'cuda' and self.saved_acts:
+            model.policy.refresh_wimage()     # (a coupled net's one-launch forms exist once its message image does)
+        # CACC: the env kernel runs the next lock-step's input encoders behind its step (csrc/cacc.hip cacc_step_encode_kernel)
+        # ... unless the lock-step kernel runs the encoders itself (csrc/lstm_mfma.hip ENC: IA2C-FP, NeurComm), then the env step stays alone
+        self.enc_in_kernel = self.saved_acts and self.compact_obs and env.device.type == 'cuda' and \
+            model.policy.enc_in_kernel(env.E, True)
+        # ... and the env step as well, behind the action draw of the same launch: ONE launch per lock-step (ENV block of the kernel)
+        self.env_in_kernel = self.enc_in_kernel and hasattr(env, 'inkernel_step') and env.n_agent == 8 and ops.step_env_supported() and \
+            model.policy.env_step_in_kernel
+        self.fused_encode = self._want_fused_encode and self.saved_acts and self.compact_obs and not self.enc_in_kernel and \
+            getattr(env, 'supports_fused_encode', False) and env.device.type == 'cuda' and \
+            model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1)) is not None
 
     def _shadow_tensors(self):
         """What a rollout overwrites and the batch epilogue does not restore: the env, the Philox counter, the persistent
@@ -580,6 +590,7 @@ class BatchedTrainer:
         # the lock-step has a one-launch form at this size
         self.handoff_guard = self._wants_guard and ops.handoff_enabled()
         self._pending = None
+        self._select_lock_step_form()
         self._drop_graphs()
 
     def _recover_from_handoff_timeout(self, batches=1):
@@ -602,6 +613,7 @@ class BatchedTrainer:
         if self.global_counter is not None:
             self.global_counter.advance(-self.n_step * batches)
         self.handoff_guard, self._pending = False, None
+        self._select_lock_step_form()
         self._drop_graphs()                    # re-capture: the rollout now takes the two-launch lock-step, the update the step-wise BPTT
         self._clean_since_fallback = -batches  # (the re-run batches below are not "clean batches since")
         self.handoff_fallbacks += 1

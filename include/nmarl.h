@@ -491,6 +491,19 @@ int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t H, int32_t KX, const flo
                           int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
                           const nmarl_head_t* head, const nmarl_msg_t* msg, void* stream);
 /*
+ * NeurComm's WHOLE lock-step in one launch (round 6; agents/utils.py:118-217 `lstm_comm`, utils.py:163-197, envs/cacc_env.py:191-242):
+ * nmarl_lstm_step_x_msg with head kind 3 and message kind 1, plus `enc` as in nmarl_lstm_step_x_enc -- the two input encoders
+ * [relu(x~ W_ob + b) | relu(p~ W_fp + b)] run in the launch's pre-phase and, with enc->env, the CACC env step behind the action
+ * draw.  x (KX = 192: [N][E] rows of pitch x_row, agent stride x_sn) is the S slot of the saved activations: its first 128 columns
+ * are WRITTEN here by the encoders (every lane then reads back, as its K-loop operands, exactly the 16-byte pieces it wrote), the
+ * last 64 by the message pre-phase (msg->out).  enc->out must be NULL or x.  Replaces nmarl_cacc_step_encode + nmarl_lstm_step_x_msg.
+ */
+int nmarl_lstm_step_x_msg_enc(int64_t E, int32_t N, int32_t H, int32_t KX, float* x, int64_t x_sn, int64_t x_row,
+                              const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                              int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                              int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
+                              const nmarl_head_t* head, const nmarl_msg_t* msg, const nmarl_step_enc_t* enc, void* stream);
+/*
  * One reverse step of the unrolled LSTM training graph (agents/utils.py:102-113, 199-208, 401-408, 585-593), the cell
  * backward and the dgrad product fused on the matrix cores (H = 64):
  *   dz = d cell/d z from gates / c_prev / c_new / done and dL/dh' = dh + dh2, dL/dc' = dc_in   (as nmarl_lstm_cell_bwd)

@@ -382,6 +382,11 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     if xs is not None and isinstance(xs[0], dict):       # the input encoders run inside the product's launch
         with torch.no_grad():
             xs = (step_enc_forward(xs[0]),) + tuple(xs[1:])
+    if xs is not None and len(xs) > 4 and xs[4] is not None and xs[4].get('enc_spec') is not None:
+        # lstm_comm's one-launch lock-step: the input encoders write [hx | hp] into the x slot before anything reads it
+        with torch.no_grad():
+            step_enc_forward(dict(xs[4]['enc_spec'], out=xs[0]))
+        xs = tuple(xs[:4]) + ({k: v for k, v in xs[4].items() if k != 'enc_spec'},)
     xs_p = xs
     if xs is not None and len(xs) > 4 and xs[4] is not None:
         # coupled net: only the POLICY step's message term is kept (`out`); the re-step's comes from the new h of all agents

@@ -148,7 +148,8 @@ def test_episode_bookkeeping_on_gpu():
 def test_one_pass_encoder_backward_equals_two_launches(agent, monkeypatch):
     """The update's encoder backward as ONE pass over dS (nmarl_fc_bwd_pair; IA2C-FP: the relu derivative from the 16-byte sign
     image the lock-step kernel wrote, S itself not read) against the two fc_bwd launches: weights, optimiser slots and actions
-    bit-identical after 4 batches at the BASELINE size (hipGraph rollout and update)."""
+    bit-identical after 4 batches at the BASELINE size (hipGraph rollout and update).  (NeurComm's one-launch lock-step writes the
+    sign image as well, round 6.)"""
     runs = []
     for pair in ('1', '0'):
         monkeypatch.setenv('NMARL_FC_BWD_PAIR', pair)
@@ -156,7 +157,7 @@ def test_one_pass_encoder_backward_equals_two_launches(agent, monkeypatch):
         for _ in range(4):
             tr.run_batch()
         torch.cuda.synchronize()
-        assert (model.S_bits is not None) == (pair == '1' and agent == 'ia2c_fp')
+        assert (model.S_bits is not None) == (pair == '1') and tr.enc_in_kernel
         runs.append((model.policy.params.flat.clone(), model.policy.params.ms.clone(), model.buf_act.clone(), tr.R_end.clone()))
         del env, model, tr
     for a, b in zip(*runs):
@@ -267,33 +268,27 @@ def test_compact_observation_equals_gathered_slab(agent, monkeypatch):
 
 
 @pytest.mark.parametrize('E', [4096, 1000, 77])
-@pytest.mark.parametrize('scenario', ['catchup', 'slowdown'])
-def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, scenario, monkeypatch):
-    """ONE launch per lock-step (IA2C-FP on CACC): the lock-step kernel stepping the env itself behind its action draw
-    (lstm_step_x_kernel<3,0,1> with the ENV block: the last of the 8 agents' waves that own a strip of 16 replicas steps them,
-    no wave waits) against the same kernel followed by the env kernel (nmarl_cacc_step) -- the same device function on the same
+@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'catchup'), ('ma2c_nc', 'slowdown')])
+def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, agent, scenario, monkeypatch):
+    """ONE launch per lock-step (IA2C-FP: lstm_step_x_kernel<3,0,1>; NeurComm: <4,1,1>, round 6): the lock-step kernel stepping the
+    env itself behind its action draw (ENV block: the last of the 8 agents' waves that own a strip of 16 replicas steps them, no
+    wave waits) against the same kernel followed by the env kernel (nmarl_cacc_step) -- the same device function on the same
     actions, so EVERYTHING is bit-identical after 3 batches through the hipGraph: actions, rewards, done flags, observations,
     env state incl. the fused auto-reset at the episode end (T = 3 batches here), values, weights.  E = 1000 / 77: ragged last
     row block (strips with fewer than 16 replicas, waves with none)."""
-    from deeprl_network_amd.agents import models
-    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
-    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    monkeypatch.setenv('NMARL_NC_ENV_IN_KERNEL', '1')      # (NeurComm's default keeps the env kernel: measured no faster inside)
     out = []
     for inside in ('1', '0'):
         monkeypatch.setenv('NMARL_INKERNEL_ENV', inside)
-        cp = cacc_config(agent='ia2c_fp', scenario=scenario, n_step=20, reward_norm=800.0)
-        cp['ENV_CONFIG']['episode_length_sec'] = '6'                 # T = 60 lock-steps = 3 batches: the third one ends the episodes
-        env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
-        np.random.seed(12)
-        model = models.IA2C_FP(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
-                               cp['MODEL_CONFIG'], seed=12, num_envs=E)
-        tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
+        env, model, tr = build(agent, E, True, scenario=scenario, n_step=20, episode_sec=6)      # T = 60 lock-steps = 3 batches
         assert tr.enc_in_kernel and tr.env_in_kernel == (inside == '1') and not tr.fused_encode
         rec = []
         for _ in range(3):
             tr.run_batch()
             rec += [model.buf_act.clone(), tr.buf_rraw.clone(), tr.buf_g.clone(), model.buf_done_post.clone(), model.buf_x.clone()]
+        tr.flush()
         torch.cuda.synchronize()
+        assert tr.handoff_fallbacks == 0
         assert int(env.episode.min()) == 2 and int(env.t.max()) == 0          # every replica finished an episode and was re-initialised
         out.append(rec + [env.h.clone(), env.v.clone(), env.u.clone(), env.t.clone(), env.collided.clone(), env.v0_init.clone(),
                           env.episode.clone(), model.buf_v.clone(), model.policy.params.flat.clone(), tr.ep_sum.clone()])
@@ -305,9 +300,9 @@ def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, scenario, mon
 
 
 @pytest.mark.parametrize('E', [4096, 1000, 77])
-@pytest.mark.parametrize('scenario', ['catchup', 'slowdown'])
-def test_env_step_inside_the_lock_step_launch_vs_oracle(E, scenario):
-    """The env step INSIDE the lock-step launch (lstm_step_x_kernel<3,0,1> + ENV block) against oracle/cacc_ref.py directly
+@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'slowdown')])
+def test_env_step_inside_the_lock_step_launch_vs_oracle(E, agent, scenario, monkeypatch):
+    """The env step INSIDE the lock-step launch (lstm_step_x_kernel<3,0,1> / NeurComm's <4,1,1> + ENV block) against oracle/cacc_ref.py directly
     (cacc_env.py:191-242, 40-79, 166-189), not through the env kernel: every lock-step of 3 batches (= one 60-step episode,
     auto-reset at its end) is one launch; the env state in front of each launch is read back, the fp32 oracle is put into that
     state and stepped with the actions the launch drew, and the launch's observation, reward, global reward, done flag, new
@@ -315,7 +310,8 @@ def test_env_step_inside_the_lock_step_launch_vs_oracle(E, scenario):
     (rtol 1e-5; replicas whose min headway lands within 1e-4 of h_min excluded and counted)."""
     from oracle import philox
     from oracle.cacc_ref import CaccBatchRef, CaccParams
-    env, model, tr = build('ia2c_fp', E, False, scenario=scenario, n_step=20, episode_sec=6)     # 60 lock-steps: the third batch ends the episode
+    monkeypatch.setenv('NMARL_NC_ENV_IN_KERNEL', '1')
+    env, model, tr = build(agent, E, False, scenario=scenario, n_step=20, episode_sec=6)     # 60 lock-steps: the third batch ends the episode
     assert tr.enc_in_kernel and tr.env_in_kernel and not tr.fused_encode and env.T == 60
     ref = CaccBatchRef(CaccParams(config=env.config), E=E, dtype=np.float32, train_mode=True)
     assert ref.p.T == 60 and ref.p.batch_size == 20
@@ -361,36 +357,34 @@ def test_env_step_inside_the_lock_step_launch_vs_oracle(E, scenario):
     assert int(env.episode.min()) == 2 and int(env.t.max()) == 0
 
 
-def test_inkernel_encoders_equal_the_encoder_launch(monkeypatch):
-    """IA2C-FP: the lock-step kernel running both input encoders itself (lstm_step_x_kernel<3,0,1>: no encoder launch, the env
-    step alone behind it) against the env step + encoder launch (nmarl_cacc_step_encode) in front of the plain lock-step
-    kernel, ONE batch from the same state at E = 4096 and E = 1000 (ragged last block): saved LSTM inputs, values and the
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+def test_inkernel_encoders_equal_the_encoder_launch(agent, monkeypatch):
+    """IA2C-FP / NeurComm: the lock-step kernel running both input encoders itself (lstm_step_x_kernel<3,0,1> / <4,1,1>: no encoder
+    launch, the env step alone behind it) against the env step + encoder launch (nmarl_cacc_step_encode) in front of the plain
+    lock-step kernel, ONE batch from the same state at E = 4096 and E = 1000 (ragged last block): saved LSTM inputs, values and the
     post-update weights agree to fp32 summation order; the drawn actions are identical except where a uniform falls within
-    that rounding of a CDF boundary."""
-    from deeprl_network_amd.agents import models
-    from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
-    from deeprl_network_amd.utils import BatchedTrainer, Counter
+    that rounding of a CDF boundary.  (NeurComm: the encoders' output reaches the K loop through the S slot in global memory --
+    a stale read-back would show as a gross mismatch between the saved inputs and everything computed from them.)"""
     for E in (4096, 1000):
         out = []
         for inside in ('1', '0'):
             monkeypatch.setenv('NMARL_INKERNEL_ENCODE', inside)
-            cp = cacc_config(agent='ia2c_fp', scenario='catchup', n_step=60, reward_norm=800.0)
-            env = CACCBatchEnv(cp['ENV_CONFIG'], num_envs=E)
-            np.random.seed(12)
-            model = models.IA2C_FP(env.n_s_ls, env.n_a_ls, env.neighbor_mask, env.distance_mask, env.coop_gamma, 10 ** 9,
-                                   cp['MODEL_CONFIG'], seed=12, num_envs=E)
-            tr = BatchedTrainer(env, model, Counter(10 ** 12, 10 ** 12, 10 ** 12), use_graph=True)
+            env, model, tr = build(agent, E, True, scenario='catchup' if agent == 'ia2c_fp' else 'slowdown', n_step=60)
             assert tr.enc_in_kernel == (inside == '1') and tr.fused_encode == (inside == '0')
             tr.rollout()
             torch.cuda.synchronize()
             S, acts, vals = model.S_buf.clone(), model.buf_act.clone(), model.buf_vn.clone()
+            G = model.G_buf.clone()
             tr._update()
+            tr.flush()
             torch.cuda.synchronize()
-            out.append((S, acts, vals, model.policy.params.flat.clone()))
+            assert tr.handoff_fallbacks == 0
+            out.append((S, acts, vals, model.policy.params.flat.clone(), G))
             del env, model, tr
         same = (out[0][1] == out[1][1]).all(dim=0).all(dim=-1)            # replicas whose whole action tape agrees
         assert same.float().mean().item() > 0.999
         torch.testing.assert_close(out[0][0][:, 0], out[1][0][:, 0], rtol=1e-5, atol=1e-6)      # first lock-step: same inputs
+        torch.testing.assert_close(out[0][4][:, 0], out[1][4][:, 0], rtol=1e-4, atol=1e-5)      # ... and the gates computed from them
         torch.testing.assert_close(out[0][0][:, :, same], out[1][0][:, :, same], rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(out[0][2][:, :, same], out[1][2][:, :, same], rtol=1e-3, atol=1e-4)
         torch.testing.assert_close(out[0][3], out[1][3], rtol=1e-3, atol=2e-5)
@@ -436,6 +430,7 @@ def test_coupled_one_launch_step_equals_two_launches(agent, E, monkeypatch):
     from deeprl_network_amd.agents import models
     from deeprl_network_amd.envs.cacc_env import CACCBatchEnv
     from deeprl_network_amd.utils import BatchedTrainer, Counter
+    monkeypatch.setenv('NMARL_NC_ONE_LAUNCH', '0')          # (the encoders stay behind the env kernel in both arms: this test is about the hand-off)
     out = []
     for one in (True, False):
         if not one:
@@ -567,7 +562,8 @@ def test_rearm_arms_the_guard_whenever_the_handoff_kernels_come_back(handoff_swi
     env, model, tr = build('ma2c_nc', E, False, scenario='slowdown', n_step=T, rearm_after=2)
     model.policy.refresh_wimage()
     monkeypatch.setattr(type(model.policy), 'pv_one_launch', lambda self, E_: False)      # two-launch lock-step, hand-off BPTT
-    assert tr.handoff_guard
+    tr._select_lock_step_form()
+    assert tr.handoff_guard and not tr.enc_in_kernel and tr.fused_encode
     _lib.check(_lib.lib.nmarl_test_handoff_fault(1), 'nmarl_test_handoff_fault')          # the first hand-off launch: the BPTT
     tr.run_batch()
     tr.run_batch()

@@ -79,7 +79,7 @@ except (AssertionError, ZeroDivisionError) as ex:
     print('no one-launch lock-step in this collection:', ex)
 try:        # the coupled nets' lock-step in one launch (NeurComm, line graph): per (agent, replica) row x [hx | hp] 512 + own h, c 512 +
     # the neighbours' h before (512) and after (512) the step read; h', c' 512 + gates 1024 + message term 256 + pi 16 + v 4 + action 1 written
-    s = stat('lstm_step_x_kernel<4, 1>')
+    s = stat('lstm_step_x_kernel<4, 1,')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
@@ -110,7 +110,7 @@ except (AssertionError, ZeroDivisionError) as ex:
 try:        # CommNet on the 5 x 5 grid, 25 x 1024 rows: the one-launch lock-step with the observation encoder inside.  Per (agent, replica)
     # row: own + neighbours' compact observation (1 + 3.2) x 48 read; own h, c 512 + the neighbours' h before and after 2 x 3.2 x 256 read;
     # encoder output 256 + LSTM input 256 + h', c' 512 + gates 1024 + pi 20 + v 4 + action 1 written (3.2 = mean degree of the grid)
-    s = stat('lstm_step_x_kernel<4, 2>')
+    s = stat('lstm_step_x_kernel<4, 2,')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 25 * 1024
     balg = int(4.2 * 48 + 512 + 2 * 3.2 * 256 + 256 + 256 + 512 + 1024 + 25)
@@ -133,7 +133,7 @@ except (AssertionError, ZeroDivisionError) as ex:
 for key, part, balg in (
         # lstm_dial's policy step (line graph: 1.75 senders per agent on average): enc 256 + own h, c 512 + the senders' message vectors
         # 1.75 x 256 read; s 256 + hm 256 + h', c' 512 + gates 1024 + pi 16 + action 1 + the new message vectors 256 written
-        ('lstm_step_x13_dial_N8_E4096', 'lstm_step_x_kernel<1, 3>', int(256 + 512 + 1.75 * 256 + 256 + 256 + 512 + 1024 + 17 + 256)),
+        ('lstm_step_x13_dial_N8_E4096', 'lstm_step_x_kernel<1, 3,', int(256 + 512 + 1.75 * 256 + 256 + 256 + 512 + 1024 + 17 + 256)),
         # its message adjoint of one reverse step: own ds, hm, msg, dhd 1024 + 1.75 sources x (ds, hm) 512 read; d1, d2, dh 768 written
         ('dial_msg_adjoint_N8_E4096', 'dial_msg_adjoint_kernel<2>', int(1024 + 1.75 * 512 + 768))):
     try:

@@ -25,6 +25,9 @@ if _build.built_hash() != _build.source_hash():
         'deeprl_network_amd: %s is stale (built from sources %s, current sources %s). Rebuild it with '
         '`python -m deeprl_network_amd.build`.' % (LIB_PATH, _build.built_hash(), _build.source_hash()))
 
+# Same-box A/B of two builds of the kernels (tools/ab_build.sh): NMARL_LIB_AB=<path of another libnmarl_hip.so with the same C-ABI>
+# is loaded INSTEAD (it is by definition not built from the current sources; every symbol and the ABI version are still checked below)
+LIB_PATH = os.environ.get('NMARL_LIB_AB') or LIB_PATH
 lib = C.CDLL(LIB_PATH)
 
 ABI_VERSION = 1

@@ -76,8 +76,10 @@ constexpr int LDS2_FLOATS = H * WPITCH + WAVES2 * R16 * APITCH;
 __device__ unsigned long long* g_timeline = nullptr;
 __global__ void timeline_set_kernel(unsigned long long* p) { g_timeline = p; }
 #define NMARL_STAMP(i) if (g_timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_timeline[(threadIdx.x >> 6) * 64 + (i)] = __builtin_amdgcn_s_memtime();
+#define NMARL_NOTE(i, v) if (g_timeline && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_timeline[(threadIdx.x >> 6) * 64 + (i)] = (unsigned long long)(v);
 #else
 #define NMARL_STAMP(i)
+#define NMARL_NOTE(i, v)
 #endif
 
 // Head epilogue of one wave: its 16 fresh rows of h' sit in the wave's (now idle) LDS tile.  Lane
@@ -176,10 +178,12 @@ __device__ __forceinline__ void head_epilogue(const FusedArgs& a, const int n, c
 // logit -inf -> probability exactly 0 and add exact zeros to every sum, so leaving them out changes no bit; it halves the dot
 // products, the exps, the divisions and the float64 CDF of the head (~570 -> ~300 vector instructions per wave, which only 16 of
 // the 64 lanes need but every wave pays for in full).
-template <int MA>
+// AN = columns that go through the softmax and the float64 CDF (A <= AN <= MA; the dot products and shuffles keep the float4 shape MA):
+// the grid's five actions pay five exponentials / divisions / float64 CDF steps instead of eight -- dropped columns hold exact zeros
+template <int MA, int AN = MA>
 __device__ __forceinline__ int head_policy_lds_n(const FusedArgs& a, const int n, const int N, const int64_t row0,
                                                  const int lane, const float* a_tile, const float* wl, const float* bl) {
-    static_assert(MAXA == 8 && (MA == 4 || MA == 8), "one or two float4 per k");
+    static_assert(MAXA == 8 && (MA == 4 || MA == 8) && AN <= MA, "one or two float4 per k");
     const nmarl_head_t& hd = a.hd;
     const int A = hd.A;
     const int rl = lane & 15, q = lane >> 4;
@@ -203,26 +207,26 @@ __device__ __forceinline__ int head_policy_lds_n(const FusedArgs& a, const int n
         }
     }
 #pragma unroll
-    for (int o = 0; o < MA; ++o) {
+    for (int o = 0; o < AN; ++o) {
         acc[o] += __shfl_xor(acc[o], 16, 64);
         acc[o] += __shfl_xor(acc[o], 32, 64);
     }
     if (q != 0 || row >= a.E) return -1;
-    float p[MA];
+    float p[AN];
     float m = -INFINITY;
 #pragma unroll
-    for (int o = 0; o < MA; ++o) {
+    for (int o = 0; o < AN; ++o) {
         p[o] = o < A ? acc[o] + bl[o] : -INFINITY;
         m = fmaxf(m, p[o]);
     }
     float ssum = 0.0f;
 #pragma unroll
-    for (int o = 0; o < MA; ++o) {
+    for (int o = 0; o < AN; ++o) {
         p[o] = expf(p[o] - m);                       // exp(-inf) = 0 for the padded columns
         ssum += p[o];
     }
 #pragma unroll
-    for (int o = 0; o < MA; ++o) p[o] = p[o] / ssum;
+    for (int o = 0; o < AN; ++o) p[o] = p[o] / ssum;
     float* po = hd.pi_out + (int64_t)n * hd.pi_sn + row * A;
     if (A == 4) {
         *reinterpret_cast<float4*>(po) = float4{p[0], p[1], p[2], p[3]};
@@ -233,7 +237,7 @@ __device__ __forceinline__ int head_policy_lds_n(const FusedArgs& a, const int n
     if (hd.mode == 2) {
         float best = p[0];
 #pragma unroll
-        for (int k = 1; k < MA; ++k) {
+        for (int k = 1; k < AN; ++k) {
             const bool gt = k < A && p[k] > best;
             best = gt ? p[k] : best;
             act = gt ? k : act;
@@ -248,10 +252,10 @@ __device__ __forceinline__ int head_policy_lds_n(const FusedArgs& a, const int n
         }
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < MA; ++k) tot += (double)p[k];
+        for (int k = 0; k < AN; ++k) tot += (double)p[k];
         double cum = 0.0;
 #pragma unroll
-        for (int k = 0; k < MA; ++k) {
+        for (int k = 0; k < AN; ++k) {
             cum += (double)p[k];
             act = (k < A && cum / tot <= (double)uu) ? k + 1 : act;
         }
@@ -265,6 +269,7 @@ __device__ __forceinline__ int head_policy_lds_n(const FusedArgs& a, const int n
 __device__ __forceinline__ int head_policy_lds(const FusedArgs& a, const int n, const int N, const int64_t row0,
                                                const int lane, const float* a_tile, const float* wl, const float* bl) {
     if (a.hd.A <= 4) return head_policy_lds_n<4>(a, n, N, row0, lane, a_tile, wl, bl);       // (uniform)
+    if (a.hd.A == 5) return head_policy_lds_n<8, 5>(a, n, N, row0, lane, a_tile, wl, bl);     // (the ATSC grid's five phases)
     return head_policy_lds_n<8>(a, n, N, row0, lane, a_tile, wl, bl);
 }
 
@@ -665,6 +670,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = row_blk + wave * R16;
     const int c = lane & 15, grp = lane >> 4;
+    // (a static s_setprio 1 for the younger wave group 4..7 of the coupled kernels -- MI355X_MICROARCH.md's lever for 8-wave blocks --
+    // was tried in round 6: +0.3 % on the grid's lock-step, same box: not kept)
     static_assert(HEAD != 4 || MSG != 0, "HEAD 4 is the coupled nets' policy + value step");
     constexpr bool PV = HEAD == 3 || HEAD == 4;          // policy step + value re-step in this launch
     // HEAD 4: this launch's flag value = generation + 1.  The load is ISSUED here and consumed after the K loop: a
@@ -874,7 +881,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d_[0] = tg0; d_[512] = tg1; d_[1024] = tg2; d_[1536] = tg3; d_[2048] = tg4;
     }
     NMARL_STAMP(43)
-    NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
+    // (chunk 2 is requested at the END of the prologue: vector loads return in order, so asked for here its 40 KB would sit in front
+    // of every operand the pre-phases wait for -- it is first needed behind tick 0's barrier, a whole pre-phase + tick away)
     float* m_lds = hw_lds + HW_FLOATS;                               // W_msg image: msg_kc * 32 * 64 floats
     // the heads' h-weights -> LDS (read 16 x (A + 1) times per lane in the head epilogues): REQUESTED here (unconditional,
     // clamped addresses), stored to LDS at the end of the prologue -- stored right away they cost their own round trip
@@ -1008,6 +1016,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         if (threadIdx.x < 32) *reinterpret_cast<float4*>(e_lds + 1536 + 4 * threadIdx.x) = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
     }
     NMARL_STAMP(47)
+    NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
     __syncthreads();
     NMARL_STAMP(1)
     if (ENC) {
@@ -1138,6 +1147,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                             sm[kc][hh].z += W[q] * u.z; sm[kc][hh].w += W[q] * u.w;
                         }
             }
+            if (SECOND) { NMARL_STAMP(52) }
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 float4 m0 = sm[kc][0], m1 = sm[kc][1];
@@ -1150,6 +1160,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                 NMARL_MCHUNK(macc, m_lds, kc, m0, m1)
             }
         }
+        if (SECOND) { NMARL_STAMP(53) }
         // result (C layout) + bias, relu / + enc -> the wave's LDS tile (A layout source) and, if asked, global memory
         const float* encn = MSG != 1 ? xa.enc + (int64_t)n * xa.enc_sn : nullptr;
         float* xo = (!SECOND && xa.xm_out) ? xa.xm_out + (int64_t)n * xa.xm_sn : nullptr;
@@ -1271,6 +1282,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         d[threadIdx.x] = nfa; d[threadIdx.x + 512] = nfb;
     }
     const unsigned epoch = HEAD == 4 ? (unsigned)__builtin_amdgcn_readfirstlane((int)epoch_raw) + 1u : 0u;
+    bool early_ok = false;                       // HEAD 4: the re-step's neighbour rows were requested behind flags that were up
     // ENC + env step: what the hand-off word of this lane's replica held before this agent's add (lanes 0..15), the lane's own
     // draw, and the strip's env state as requested right behind the draw
     unsigned ev_old = 0;
@@ -1301,17 +1313,31 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         acc[0 + jj] = gi; acc[4 + jj] = gf; acc[8 + jj] = go; acc[12 + jj] = gu;
     }
     {
-        // HEAD 4: h' is written THROUGH (sc1) -- the neighbours' blocks read it later in this launch (offset in a VGPR)
-        const __amdgpu_buffer_rsrc_t rh_ = make_rsrc(hn_out, (uint32_t)(HEAD == 4 ? a.E * (H * 4) : 0));
+        // HEAD 4: h' is written THROUGH (sc1) -- the neighbours' blocks read it later in this launch (offset in a VGPR) -- FIRST, and
+        // published at once (the four stores drained, one flag per (agent, block, wave)): the neighbours' re-steps wait for these
+        // rows, not for this wave's gates, cell state or actor head, which all follow
+        if (HEAD == 4) {
+            const __amdgpu_buffer_rsrc_t rh_ = make_rsrc(hn_out, (uint32_t)(a.E * (H * 4)));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 4 * grp + r;
+                if (row < a.E)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, float4{hv_[0][r], hv_[1][r], hv_[2][r], hv_[3][r]}), rh_,
+                                                           (uint32_t)((row * H + 4 * c) * 4), 0, SC1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0 && !(xa.fault && blockIdx.x == 0))
+                __hip_atomic_store((gu32*)(xa.sync + 16) + ((n * a.blocks_per_agent + blk_u) * WAVES2 + wave), epoch, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            NMARL_STAMP(26)
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = row0 + 4 * grp + r;
             if (row < a.E) {
                 *reinterpret_cast<float4*>(cn + row * H + 4 * c) = float4{cp[0][r], cp[1][r], cp[2][r], cp[3][r]};
                 const float4 h4 = float4{hv_[0][r], hv_[1][r], hv_[2][r], hv_[3][r]};
-                if (HEAD == 4)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, h4), rh_, (uint32_t)((row * H + 4 * c) * 4), 0, SC1);
-                else
+                if (HEAD != 4)
                     *reinterpret_cast<float4*>(hn_out + row * H + 4 * c) = h4;
                 if (gn) {
 #pragma unroll
@@ -1372,19 +1398,27 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                            fmaxf(facc[3][r] + nb4.w, 0.0f)};
     }
     if (HEAD == 4) {
-        // ---- publish: this wave's 16 rows of h' are out (write-through stores drained), one flag per (agent, block, wave)
+        // (this wave's rows were published behind the cell epilogue's first stores, in front of the actor head)
         gu32* flags = (gu32*)(xa.sync + 16);
         const int bpa = a.blocks_per_agent, blk = blk_u;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0 && !(xa.fault && blockIdx.x == 0))
-            __hip_atomic_store(flags + ((n * bpa + blk) * WAVES2 + wave), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the W chunks of the message columns: in flight while the h part of the re-step runs
-        NMARL_STAGE_LOAD(nx - 2)
+        // ---- one LOOK at the neighbours' flags (no waiting): blocks run in step, so their same-numbered waves have usually published
+        // by now -- then the rows requested here are the new h and fly under the h part of the re-step, whose MFMAs need no vector
+        // memory.  The request is UNCONDITIONAL (a load inside a branch costs a conservative wait at the join): rows read too early
+        // are simply requested again behind the blocking poll below.
         {
-            const float4* g_ = img + (int64_t)(nx - 1) * (CH_FLOATS / 4) + threadIdx.x;
-            tg0 = g_[0]; tg1 = g_[512]; tg2 = g_[1024]; tg3 = g_[1536]; tg4 = g_[2048];
+            // (lane k looks at neighbour k's flag: ONE memory round trip for all of them, a ballot decides)
+            int jl = -1;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) jl = lane == k ? nbj[k] : jl;
+            const bool watch = lane < xa.m_max && lane < 8 && jl >= 0;
+            const unsigned v = __hip_atomic_load(flags + (((watch ? jl : n) * bpa + blk) * WAVES2 + wave), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool up = __ballot(watch && v != epoch) == 0ull;
+            early_ok = up;
+            NMARL_NOTE(54, up ? 1 : 2)
+            asm volatile("" ::: "memory");               // the payload loads stay below the look
+            msg_load(std::true_type{}, K0{}, PU, PW);
         }
-        NMARL_STAMP(26)
+        NMARL_STAMP(31)
     }
     if (PV) {
         // ---- the value re-step (quirk Q1): z = x-side addend + (h' keep) @ Wh from the two resident Wh chunks
@@ -1416,28 +1450,36 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             gu32* flags = (gu32*)(xa.sync + 16);
             const int bpa = a.blocks_per_agent, blk = blk_u;
             bool give_up = false;
+            if (!early_ok) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int j = nbj[k];
-                if (k >= xa.m_max || j < 0 || give_up) continue;
-                gu32* f = flags + ((j * bpa + blk) * WAVES2 + wave);
-                for (unsigned spins = 0;; ++spins) {
-                    const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (v == epoch) break;
-                    if (spins > xa.max_spins) {           // a neighbour's block is not running: not co-resident (see the launcher)
-                        if (lane == 0) {                  // sticky: the optimiser step refuses this batch (nmarl_rmsprop_tf_clip_guarded)
-                            __hip_atomic_store((gu32*)xa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (xa.status) __hip_atomic_store((gu32*)xa.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int k = 0; k < 8; ++k) {
+                    const int j = nbj[k];
+                    if (k >= xa.m_max || j < 0 || give_up) continue;
+                    gu32* f = flags + ((j * bpa + blk) * WAVES2 + wave);
+                    for (unsigned spins = 0;; ++spins) {
+                        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if (v == epoch) break;
+                        if (spins > xa.max_spins) {           // a neighbour's block is not running: not co-resident (see the launcher)
+                            if (lane == 0) {                  // sticky: the optimiser step refuses this batch (nmarl_rmsprop_tf_clip_guarded)
+                                __hip_atomic_store((gu32*)xa.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (xa.status) __hip_atomic_store((gu32*)xa.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                            give_up = true;
+                            break;
                         }
-                        give_up = true;
-                        break;
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    __builtin_amdgcn_s_sleep(2);
                 }
+                asm volatile("" ::: "memory");               // the payload loads stay below the polls
+                msg_load(std::true_type{}, K0{}, PU, PW);
             }
-            asm volatile("" ::: "memory");               // the payload loads stay below the polls
             NMARL_STAMP(27)
-            msg_load(std::true_type{}, K0{}, PU, PW);
+            // the W chunks of the message columns: requested here, in flight during the message term, stored behind its barrier
+            NMARL_STAGE_LOAD(nx - 2)
+            {
+                const float4* g_ = img + (int64_t)(nx - 1) * (CH_FLOATS / 4) + threadIdx.x;
+                tg0 = g_[0]; tg1 = g_[512]; tg2 = g_[1024]; tg3 = g_[1536]; tg4 = g_[2048];
+            }
             msg_phase(std::true_type{}, PU, PW);         // -> the wave's A tile
             NMARL_STAMP(28)
             __syncthreads();                             // every wave is through with the Wh chunks

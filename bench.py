@@ -273,6 +273,51 @@ def measure_lstm_step_in_rollout(trainer, reps=5):
     return (full - without) / n_launch, full, without
 
 
+def measure_lstm_step_stamped(trainer):
+    """Duration of the lock-step launches inside the rollout from device time stamps: the rollout captured with every lock-step
+    launch bracketed by two nmarl_timestamp launches (constant-rate device wall clock), replayed 3 times; the median over all
+    launches of (stamp behind - stamp in front).  A duration in the launch's real neighbourhood -- it includes the two kernel
+    boundaries next to the stamps (~1.2 us each), which a kernel trace's begin / end do not."""
+    from deeprl_network_amd import ops
+    pol = trainer.model.policy
+    names = ['step_policy_value'] if pol.pv_one_launch(trainer.model.E) else ['step_policy', 'step_value']
+    n_launch = (trainer.n_step + 1) * len(names)
+    stamps = torch.zeros(n_launch, 2, dtype=torch.int64, device=trainer.device)
+    orig = {n: getattr(pol, n) for n in names}
+    snap = trainer._snapshot()
+    k = [0]
+
+    def bracket(f):
+        def g(*a, **kw):
+            i = k[0]
+            k[0] += 1
+            ops.timestamp(stamps[i, 0:1])
+            r = f(*a, **kw)
+            ops.timestamp(stamps[i, 1:2])
+            return r
+        return g
+    try:
+        for n in names:
+            setattr(pol, n, bracket(orig[n]))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            trainer._rollout()
+    finally:
+        for n, f in orig.items():
+            setattr(pol, n, f)
+    assert k[0] == n_launch, (k[0], n_launch)
+    g.replay()
+    torch.cuda.synchronize()
+    ticks = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        ticks += (stamps[:, 1] - stamps[:, 0]).tolist()
+    trainer._restore(snap)
+    ticks.sort()
+    return ticks[len(ticks) // 2] / ops.timestamp_rate_khz(trainer.device) * 1e3
+
+
 def measure_bptt_seq(model, reps=5):
     """Average duration of the second kernel of the update, the whole reverse recurrence in one launch
     (nmarl_lstm_bptt_seq), on the model's own saved-activation buffers (shapes [N,T,E,*]): HIP events on the launch
@@ -493,7 +538,14 @@ def run_other_config(args, cfg_name, device):
             us_l = measure_lstm_step_in_rollout(trainer)[0]
         except Exception as ex:
             res['roofline_in_rollout_error'] = repr(ex)
+        try:
+            us_st = measure_lstm_step_stamped(trainer)
+        except Exception as ex:
+            us_st = None
+            res['roofline_stamped_error'] = repr(ex)
         res['roofline'] = {'kernel': lname, 'bound': 'mfma', 'us_per_launch': us_l, 'us_per_launch_isolated_graph': us_iso,
+                           'us_per_launch_stamped_in_rollout': us_st,
+                           'frac_stamped': None if not us_st else flops_l / us_st / 1e6 / MFMA_F32_PEAK_TFLOPS,
                            'achieved': flops_l / us_l / 1e6, 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                            'frac': flops_l / us_l / 1e6 / MFMA_F32_PEAK_TFLOPS, 'flops_per_launch': flops_l,
                            'launches_per_batch': (n_step + 1) * (1 if model.policy.pv_one_launch(E) else 2),
@@ -873,6 +925,12 @@ def main():
                     except Exception as ex:
                         us_roll = None
                         out['roofline_in_rollout_error'] = repr(ex)
+                us_stamp = None
+                if x_side:
+                    try:
+                        us_stamp = measure_lstm_step_stamped(trainer)
+                    except Exception as ex:
+                        out['roofline_stamped_error'] = repr(ex)
                 ach = flops_l / us_l / 1e6
                 out['roofline'] = {
                     'kernel': lname, 'bound': 'mfma' if x_side else 'hbm',
@@ -884,6 +942,8 @@ def main():
                         pmc_traffic(lkey)),
                     'traffic_source': pmc_traffic(lkey)[1], 'flops_per_launch': flops_l, 'bytes_per_launch': bytes_l, 'us_per_launch': us_l,
                     'us_per_launch_isolated_graph': us_iso, 'us_per_launch_in_rollout': us_roll,
+                    'us_per_launch_stamped_in_rollout': us_stamp,
+                    'frac_stamped': None if not us_stamp else flops_l / us_stamp / 1e6 / MFMA_F32_PEAK_TFLOPS,
                     'rollout_graph_us': None if us_roll is None else us_roll_full,
                     'rollout_graph_us_without_lstm_steps': None if us_roll is None else us_roll_without,
                     'frac_isolated_graph': flops_l / us_iso / 1e6 / MFMA_F32_PEAK_TFLOPS if x_side else None,
@@ -892,6 +952,9 @@ def main():
                     'how': 'achieved / frac use the launch duration INSIDE the rollout, by difference: the n_step rollout captured as a '
                            'hipGraph with and without its LSTM lock-step launches, 5 replays each between two HIP events on the launch '
                            'stream, (t_full - t_without) / launches (agrees with the rocprofv3 kernel trace of the batch, profiles/).  '
+                           'us_per_launch_stamped_in_rollout / frac_stamped: the same launches bracketed by two nmarl_timestamp launches each '
+                           '(device wall clock) inside the captured rollout, median of 3 x 61 -- a duration that includes the two kernel '
+                           'boundaries next to the stamps.  '
                            'us_per_launch_isolated_graph: hipGraph of 60 back-to-back launches on the model shapes and weights (hot caches: '
                            'flatters the kernel by 5-8 %%).  Algorithmic work per (agent, replica) row: '
                            'policy step 2*(KX+64)*256 flops + value re-step 2*64*256 flops (uncoupled nets; coupled nets: the '

@@ -9,7 +9,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r05'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
 src = os.path.join(ROOT, sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out')
 dst = os.path.join(ROOT, 'profiles')
 
@@ -109,7 +109,8 @@ for a, b in (('%s_pmc_traffic.json', '%s_pmc_traffic.json'), ('%s_pmc_traffic.md
              ('%s_mfma_valu_overlap.txt', '%s_mfma_valu_overlap.txt'), ('%s_train_speed.txt', '%s_train_speed.txt'),
              ('%s_learn_grid.json', '%s_learn_grid.json'), ('%s_untraced_breakdown.md', '%s_untraced_breakdown.md'),
              ('%s_clock_power.txt', '%s_clock_power.txt'), ('%s_ab_lockstep.txt', '%s_ab_lockstep.txt'), ('%s_fc_pair.txt', '%s_fc_pair.txt'),
-             ('%s_grid_step.txt', '%s_grid_step.txt'), ('%s_determinism.txt', '%s_determinism.txt')):
+             ('%s_grid_step.txt', '%s_grid_step.txt'), ('%s_determinism.txt', '%s_determinism.txt'),
+             ('%s_ab_lockstep_nc.txt', '%s_ab_lockstep_nc_pass2.txt'), ('%s_e1_path.txt', '%s_e1_path.txt')):
     if os.path.exists(os.path.join(src, a % tag)):
         shutil.copy(os.path.join(src, a % tag), os.path.join(dst, b % tag))
 print('profiles/%s_* written' % tag)

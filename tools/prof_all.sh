@@ -1,16 +1,18 @@
 #!/bin/bash
-# Measurement pass on one MI355X (round 5): default bench line + untraced breakdown + clock / power samples + same-box A/B of the lock-step forms,
+# Measurement pass on one MI355X (rounds 5-6): default bench line + untraced breakdown + clock / power samples + same-box A/B of the lock-step forms,
 # rocprofv3 kernel traces of the BASELINE configs (part 1: one box for bench line and traces); the other configs, PMC traffic passes (separate FETCH / WRITE runs),
 # timelines, side benches (part 2).  Results under gpurun_out/ (python tools/make_profiles.py rNN copies the summaries into profiles/).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-TAG=${1:-r05}
+TAG=${1:-r06}
 PART=${2:-all}            # 1: bench line + traces (one box for r05_bench_default.json and r05_bench_kernel_stats.md), 2: counters / timelines / side benches
 if [ "$PART" != 2 ]; then
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 python tools/untraced_breakdown.py gpurun_out/${TAG}_bench_default.json > gpurun_out/${TAG}_untraced_breakdown.md 2>&1
 python tools/clock_power.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_clock_power.txt
 bash tools/ab_lockstep.sh > gpurun_out/${TAG}_ab_lockstep.txt 2>&1
+bash tools/ab_lockstep_nc.sh > gpurun_out/${TAG}_ab_lockstep_nc.txt 2>&1
+python tools/e1_path.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_e1_path.txt
 bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid ma2c_dial_catchup
 fi
 if [ "$PART" = 1 ]; then exit 0; fi
@@ -24,8 +26,9 @@ python tools/pmc_summary.py /tmp/pmc $TAG gpurun_out > gpurun_out/${TAG}_pmc_sum
 # shader-clock phase timelines of the lock-step kernels (instrumentation build of csrc/lstm_mfma.hip, tools/step_timeline.py)
 python tools/time_fc_pair.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_fc_pair.txt
 python tools/time_grid_step.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_grid_step.txt
-python tools/determinism.py ma2c_nc slowdown 200 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_determinism.txt
-python tools/determinism.py ia2c_fp catchup 200 2>&1 | grep -v amdgpu.ids >> gpurun_out/${TAG}_determinism.txt
+python tools/determinism.py ma2c_nc slowdown 1000 2>&1 | grep -v amdgpu.ids | grep -v Warning | grep -v run_backward > gpurun_out/${TAG}_determinism.txt
+python tools/determinism.py ia2c_fp catchup 500 2>&1 | grep -v amdgpu.ids | grep -v Warning | grep -v run_backward >> gpurun_out/${TAG}_determinism.txt
+python tools/determinism.py ma2c_ic3 grid 1500 1024 2>&1 | grep -v amdgpu.ids | grep -v Warning | grep -v run_backward >> gpurun_out/${TAG}_determinism.txt
 python tools/microbench/mfma_valu_overlap.py > gpurun_out/${TAG}_mfma_valu_overlap.txt 2>&1
 python tools/train_speed.py > gpurun_out/${TAG}_train_speed.txt 2>&1
 python tools/train_speed.py config/config_ma2c_nc_slowdown.ini 200 >> gpurun_out/${TAG}_train_speed.txt 2>&1

@@ -107,13 +107,13 @@ torch.cuda.synchronize()
 t = tl.cpu().view(8, 64)
 t0 = int(t[:, 0].min())
 names = {0: 'entry', 40: 'epoch read', 41: 'A/W loads issued', 42: 'chunk 0 in LDS', 43: 'chunk 1 in LDS', 44: 'head w in LDS',
-         36: 'enc loads issued', 37: 'enc operands in', 50: 'enc MFMAs done', 51: 'enc parked', 38: 'enc done', 39: 'env step done', 45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
+         36: 'enc loads issued', 37: 'enc operands in', 50: 'enc MFMAs done', 51: 'enc parked', 38: 'enc done', 39: 'env step done', 45: 'msg loads issued', 46: 'msg img in LDS', 47: 'ob img in LDS', 1: 'prologue', 48: 'encoder done', 49: 'msg term done', 55: 'chunks 0/1 staged', 20: 'K loop done', 21: 'cell epilogue', 22: 'head', 23: 're-step MFMA', 24: 're-step cell', 25: 'end',
          26: 'published', 31: 'nbr rows asked', 27: 'flags seen', 52: 'nbr rows summed', 53: 'msg MFMAs done', 28: 'message term', 29: 'msg W staged', 30: 'msg chunks',
          33: 'cell math', 34: 'critic dots', 35: 'critic shfl'}
 for i in range(2, 20, 2):
     names[i], names[i + 1] = 'tick %d computed' % ((i - 2) // 2), 'tick %d barrier' % ((i - 2) // 2)
 print('stamp'.ljust(18) + ''.join(('wave %d' % w).rjust(9) for w in range(8)))
-ORDER = [0, 40, 36, 41, 42, 43, 44, 45, 46, 37, 47, 1, 50, 51, 38, 48, 49] + list(range(2, 21)) + [26, 21, 22, 31, 23, 27, 52, 53, 28, 29, 30, 33, 24, 34, 35, 25, 39]
+ORDER = [0, 40, 36, 41, 42, 43, 44, 45, 46, 37, 47, 1, 50, 51, 38, 48, 49, 55] + list(range(2, 21)) + [26, 21, 22, 31, 23, 27, 52, 53, 28, 29, 30, 33, 24, 34, 35, 25, 39]
 print('flags up at the look (1 yes, 2 no)'.ljust(18) + ''.join(('%d' % int(t[w, 54])).rjust(9) for w in range(8)))
 for i in ORDER:
     if i not in names:

@@ -8,7 +8,7 @@ TAG=${1:-r06}
 PART=${2:-all}            # 1: bench line + traces (one box for r05_bench_default.json and r05_bench_kernel_stats.md), 2: counters / timelines / side benches
 if [ "$PART" != 2 ]; then
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
-python tools/untraced_breakdown.py gpurun_out/${TAG}_bench_default.json > gpurun_out/${TAG}_untraced_breakdown.md 2>&1
+python tools/untraced_breakdown.py gpurun_out/${TAG}_bench_default.json ${TAG} > gpurun_out/${TAG}_untraced_breakdown.md 2>&1
 python tools/clock_power.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_clock_power.txt
 bash tools/ab_lockstep.sh > gpurun_out/${TAG}_ab_lockstep.txt 2>&1
 bash tools/ab_lockstep_nc.sh > gpurun_out/${TAG}_ab_lockstep_nc.txt 2>&1

@@ -350,7 +350,7 @@ class IA2C:
     def _relu_bits(self, t):
         """Slot t of the sign image of the saved LSTM inputs ([N,T,E,4] int32, ops.relu_bits_pack's layout): written by the
         lock-step kernel that runs the input encoders, read by the update's encoder backward instead of S itself."""
-        if os.environ.get('NMARL_FC_BWD_PAIR', '1') == '0':
+        if os.environ.get('NMARL_FC_BWD_PAIR', '1') == '0' or not getattr(self.policy, 'enc_writes_bits', False):
             return None
         if self.S_bits is None:
             self.S_bits = torch.zeros(self.n_agent, self.n_step, self.E, 4, dtype=torch.int32, device=self.device)

@@ -710,6 +710,18 @@ class LstmPolicy(BatchedPolicy):
     def fused_env_encode(self, fp_next, out):
         return self._fused_spec(('fc_w', 'fc_b'), None, fp_next, out) if self.xside else None
 
+    enc_writes_bits = False       # (the 16-byte sign image belongs to the two-layer encodings: FPPolicy, NCMultiAgentPolicy)
+
+    def enc_in_kernel(self, E, compact):
+        """IA2C / ConseNet on CACC (round 6): the policy + value launch runs the observation encoder itself (csrc/lstm_mfma.hip ENC 2)."""
+        m_enc = self.m_max if self.params['fc_w'].shape[1] == self.n_obs else 0       # ConseNet: own features only
+        return bool(compact) and self.xside and self.fused_pv and not self.hetero and \
+            ops.step_enc1_supported(self.n_feat, m_enc, self.n_fc, self.n_h, self.N)
+
+    def _enc_spec(self, x, fp, out, env=None, bits=None):
+        p = self.params
+        return ops.step_enc_spec(x, fp, p['fc_w'], p['fc_b'], None, None, self.nbrs, out=out, env=env, bits=None)
+
     def _recur_in(self, enc, h):
         return enc
 
@@ -717,6 +729,7 @@ class LstmPolicy(BatchedPolicy):
 class FPPolicy(LstmPolicy):
     """IA2C_FP: fcs(obs) || fcp(neighbour fingerprints) -> LSTM(2 n_fc) (policies.py:163-185)."""
     k_ob = 'fcs_w'
+    enc_writes_bits = True
 
     def _phases(self):
         nf, H, F, A = self.n_fc, self.n_h, self.n_feat, self.n_a
@@ -771,6 +784,7 @@ class NCMultiAgentPolicy(BatchedPolicy):
     scope = 'nc/lstm_comm_%d'
     coupled = True                # messages: neighbours' h_{t-1} enter every step
     msg_kind = ops.MSG_GATHER_RELU
+    enc_writes_bits = True
 
     def _phases(self):
         H, F, A = self.n_h, self.n_feat, self.n_a

@@ -541,6 +541,7 @@ struct XArgs {
     float* e_out; int64_t e_out_sn, e_out_row;    // where the encoded LSTM input [N][E][128] is kept for the update (may be NULL)
     unsigned* e_bits; int64_t e_bits_sn;          // [N][E][4] words: which of the 128 encoder outputs are > 0 (nmarl_step_enc_t.relu_bits; may be NULL)
     int e_nbr[64];                                // neighbour table [N][2] (-1 padded) BY VALUE: no dependent table load
+    int e_ob_rows;                                // rows of w_ob: 15 = 5 x (1 + 2 slots), or 5 (own features only: m_max = 0)
     // ENC 1 + ev_on: the CACC env step of THIS lock-step behind the action draw (see the ENV block at the end of the kernel)
     int ev_on, ev_auto_reset;
     nmarl_cacc_params_t ev_p;
@@ -701,7 +702,11 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     // of both epilogues running side by side with an idle matrix pipe.
     constexpr bool DEPH = MSG == 0 && ENC == 0;
     constexpr int NBUF = DEPH ? 3 : 2;
-    static_assert(ENC == 0 || (MSG == 0 && HEAD == 3) || (MSG == 1 && HEAD == 4), "ENC: the policy + value launch of IA2C-FP / NeurComm");
+    static_assert(ENC == 0 || (MSG == 0 && HEAD == 3) || (ENC == 1 && MSG == 1 && HEAD == 4), "ENC: the policy + value launch of IA2C(-FP) / ConseNet / NeurComm");
+    // ENC 1: two encoders [relu(x~ W_ob + b) | relu(p~ W_fp + b)] (128 outputs: IA2C-FP, NeurComm); ENC 2 (round 6): the observation
+    // encoder alone (64 outputs: IA2C policies.py:145; ConseNet policies.py:381-390 with its own features only = no neighbour slots)
+    constexpr bool EFP = ENC == 1;
+    constexpr int EMT = EFP ? 8 : 4;                      // 16-column m-tiles of the encoders' output
     // Where the encoders' 128 outputs wait for the K loop: ENC_LDS (uncoupled nets) in lane-private LDS slots; ENC_GLB (NeurComm: the
     // message image and the parked cell state leave no 64 KB of LDS) in the S slot of the saved activations itself -- every lane
     // stores its 8 x 16 bytes there (the update needs them anyway) and the K loop's ordinary A loads read them back: the SAME lane
@@ -794,23 +799,28 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             const float v3 = e_ob[arow * e_ob_row + ag3 * 5 + 4];
             const bool ok3 = grp == 0 || (grp == 1 && nb0 >= 0) || (grp == 2 && nb1 >= 0);
             ein[0] = v0; ein[1] = nb0 >= 0 ? v1 : 0.0f; ein[2] = nb1 >= 0 ? v2 : 0.0f; ein[3] = ok3 ? v3 : 0.0f;
-            const float* fpr = e_fp + arow * 4 + grp;
-            const float p0 = fpr[(int64_t)ag1 * e_fp_sn], p1 = fpr[(int64_t)ag2 * e_fp_sn];
-            ein[4] = nb0 >= 0 ? p0 : 0.0f; ein[5] = nb1 >= 0 ? p1 : 0.0f;
+            ein[4] = ein[5] = 0.0f;
+            if (EFP) {
+                const float* fpr = e_fp + arow * 4 + grp;
+                const float p0 = fpr[(int64_t)ag1 * e_fp_sn], p1 = fpr[(int64_t)ag2 * e_fp_sn];
+                ein[4] = nb0 >= 0 ? p0 : 0.0f; ein[5] = nb1 >= 0 ? p1 : 0.0f;
+            }
         }
         // W and the two biases go through LDS: fetched ONCE per block (3 + 1/16 loads per thread, coalesced rows) instead of 24 + 8
         // scattered loads per lane -- the pre-phase was bound by the number of vector-memory instructions the CU's eight waves
         // issue (tools/step_timeline.py enc).  Image order = the order the lanes read it back in: [k-step s][lane][m-tile] floats.
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = q * 512 + (int)threadIdx.x;                    // 0 .. 1535 = 6 k-steps x 64 lanes x 4 m-tiles
+        const int ob_rows = xa.e_ob_rows;                                // 15, or 5 when the net sees its own features only (all slots
+#pragma unroll                                                           // absent: their inputs are 0, their weight rows clamped to valid ones)
+        for (int q = 0; q < (EFP ? 3 : 2); ++q) {
+            const int e = q * 512 + (int)threadIdx.x;                    // 0 .. 1535 = 6 k-steps x 64 lanes x 4 m-tiles (ENC 2: 4 k-steps)
             const int s_ = e >> 8, l_ = (e >> 2) & 63, mt_ = e & 3, g_ = l_ >> 4, i_ = l_ & 15;
-            const int row = s_ < 3 ? 5 * s_ + g_ : (s_ == 3 ? 5 * (g_ < 3 ? g_ : 2) + 4 : 4 * (s_ - 4) + g_);   // (pad lane: a valid row, its input is 0)
-            const float* src = s_ < 4 ? e_wob + (int64_t)n * e_wob_sn : e_wfp + (int64_t)n * e_wfp_sn;
+            int row = s_ < 3 ? 5 * s_ + g_ : (s_ == 3 ? 5 * (g_ < 3 ? g_ : 2) + 4 : 4 * (s_ - 4) + g_);   // (pad lane: a valid row, its input is 0)
+            row = s_ < 4 && row >= ob_rows ? ob_rows - 1 : row;
+            const float* src = (s_ < 4 || !EFP) ? e_wob + (int64_t)n * e_wob_sn : e_wfp + (int64_t)n * e_wfp_sn;
             ewt[q] = src[row * H + 16 * mt_ + i_];
         }
         float4 eb4 = float4{0.f, 0.f, 0.f, 0.f};
-        if (threadIdx.x < 32)
+        if (threadIdx.x < (EFP ? 32 : 16))
             eb4 = *reinterpret_cast<const float4*>((threadIdx.x < 16 ? e_bob + (int64_t)n * e_bob_sn : e_bfp + (int64_t)n * e_bfp_sn - H) + 4 * threadIdx.x);
         eacc[0] = f32x4{eb4.x, eb4.y, eb4.z, eb4.w};                     // (parked in eacc[0] until it is stored to LDS)
         __builtin_amdgcn_sched_barrier(0);
@@ -1012,8 +1022,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     if (ENC) {
         NMARL_STAMP(37)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) e_lds[q * 512 + threadIdx.x] = ewt[q];
-        if (threadIdx.x < 32) *reinterpret_cast<float4*>(e_lds + 1536 + 4 * threadIdx.x) = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
+        for (int q = 0; q < (EFP ? 3 : 2); ++q) e_lds[q * 512 + threadIdx.x] = ewt[q];
+        if (threadIdx.x < (EFP ? 32 : 16)) *reinterpret_cast<float4*>(e_lds + 1536 + 4 * threadIdx.x) = float4{eacc[0][0], eacc[0][1], eacc[0][2], eacc[0][3]};
     }
     NMARL_STAMP(47)
     NMARL_STAGE_LOAD(nch > 2 ? 2 : nch - 1)
@@ -1025,13 +1035,15 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         const int i16 = lane & 15;
         float4 w4[6];
 #pragma unroll
-        for (int s_ = 0; s_ < 6; ++s_) w4[s_] = reinterpret_cast<const float4*>(e_lds)[s_ * 64 + lane];
+        for (int s_ = 0; s_ < (EFP ? 6 : 4); ++s_) w4[s_] = reinterpret_cast<const float4*>(e_lds)[s_ * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const float4 b0 = *reinterpret_cast<const float4*>(e_lds + 1536 + 16 * mt + 4 * grp);
-            const float4 b1 = *reinterpret_cast<const float4*>(e_lds + 1536 + H + 16 * mt + 4 * grp);
             eacc[mt] = f32x4{b0.x, b0.y, b0.z, b0.w};
-            eacc[4 + mt] = f32x4{b1.x, b1.y, b1.z, b1.w};
+            if (EFP) {
+                const float4 b1 = *reinterpret_cast<const float4*>(e_lds + 1536 + H + 16 * mt + 4 * grp);
+                eacc[4 + mt] = f32x4{b1.x, b1.y, b1.z, b1.w};
+            }
         }
         if (ENC_GLB) __syncthreads();        // every wave has read the image: its LDS becomes the parked-cell-state slots again
 #pragma unroll
@@ -1042,7 +1054,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             eacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].w, ein[s_], eacc[3], 0, 0, 0);
         }
 #pragma unroll
-        for (int s_ = 4; s_ < 6; ++s_) {
+        for (int s_ = 4; s_ < (EFP ? 6 : 4); ++s_) {
             eacc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].x, ein[s_], eacc[4], 0, 0, 0);
             eacc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].y, ein[s_], eacc[5], 0, 0, 0);
             eacc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[s_].z, ein[s_], eacc[6], 0, 0, 0);
@@ -1052,7 +1064,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         unsigned pos = 0;                    // bit 4 mt + i: output 16 mt + 4 grp + i of row c is > 0 (the relu derivative the update needs)
         float* const so_ = ENC_GLB && e_out != nullptr ? e_out + (int64_t)n * e_out_sn + (row0 + c) * e_out_row + 4 * grp : nullptr;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
+        for (int mt = 0; mt < EMT; ++mt) {
             eacc[mt] = __builtin_elementwise_max(eacc[mt], f32x4{0.0f, 0.0f, 0.0f, 0.0f});
             const float4 v_ = float4{eacc[mt][0], eacc[mt][1], eacc[mt][2], eacc[mt][3]};
             if (ENC_LDS) xslot[512 * mt] = v_;                                   // (lane-private: re-read by this lane only)
@@ -1884,12 +1896,15 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         // the input encoders inside the launch (ENC 1) on the CACC input layout: the uncoupled nets' policy + value step (<3,0,1>), or
         // NeurComm's one-launch lock-step (<4,1,1>: x = the S slot the encoders' [hx | hp] goes to AND the K loop reads it back from)
         const bool coupled = mk == 1 && kind == 3;
-        if ((mk != 0 && !coupled) || kind != 3 || KX != (coupled ? 3 * H : 2 * H) || KX2 != 0 || zadd1 || zadd2 || N > 32 || enc->F != 5 ||
-            enc->A != 4 || enc->m_max != 2 ||
-            !enc->ob || !enc->fp || !enc->w_ob || !enc->b_ob || !enc->w_fp || !enc->b_fp || enc->ob_row < (int64_t)N * 5 ||
-            enc->fp_sn < E * 4 || enc->w_ob_sn < 15 * H || enc->w_fp_sn < 8 * H || enc->b_ob_sn < H || enc->b_fp_sn < H ||
-            (enc->b_ob_sn % 4) || (enc->b_fp_sn % 4) || ((uintptr_t)enc->b_ob % 16) || ((uintptr_t)enc->b_fp % 16) ||
-            (enc->out && (((uintptr_t)enc->out % 16) || enc->out_row < 2 * H || (enc->out_row % 4) || (enc->out_sn % 4) ||
+        const bool single = !enc->w_fp;                        // ENC 2: the observation encoder alone (IA2C; ConseNet with m_max = 0)
+        const int ob_rows = 5 * (1 + enc->m_max);
+        if ((mk != 0 && !coupled) || kind != 3 || KX != (coupled ? 3 * H : single ? H : 2 * H) || KX2 != 0 || zadd1 || zadd2 || N > 32 || enc->F != 5 ||
+            (coupled && single) || (single ? (enc->m_max != 0 && enc->m_max != 2) : (enc->A != 4 || enc->m_max != 2)) ||
+            !enc->ob || !enc->w_ob || !enc->b_ob || enc->ob_row < (int64_t)N * 5 || enc->w_ob_sn < (int64_t)ob_rows * H || enc->b_ob_sn < H ||
+            (enc->b_ob_sn % 4) || ((uintptr_t)enc->b_ob % 16) ||
+            (!single && (!enc->fp || !enc->b_fp || enc->fp_sn < E * 4 || enc->w_fp_sn < 8 * H || enc->b_fp_sn < H || (enc->b_fp_sn % 4) ||
+                         ((uintptr_t)enc->b_fp % 16))) ||
+            (enc->out && (((uintptr_t)enc->out % 16) || enc->out_row < (single ? H : 2 * H) || (enc->out_row % 4) || (enc->out_sn % 4) ||
                           enc->out_sn < E * enc->out_row)) ||
             (coupled && enc->out && (enc->out != x || enc->out_sn != x_sn || enc->out_row != x_row)))
             return NMARL_EINVAL;
@@ -1902,7 +1917,9 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         if (coupled) { xa.e_out = const_cast<float*>(x); xa.e_out_sn = x_sn; xa.e_out_row = x_row; }
         if (enc->relu_bits && (((uintptr_t)enc->relu_bits % 4) || enc->relu_bits_sn < E * 4)) return NMARL_EINVAL;
         xa.e_bits = enc->relu_bits; xa.e_bits_sn = enc->relu_bits_sn;
-        for (int i = 0; i < 64; ++i) xa.e_nbr[i] = i < 2 * N ? enc->nbr[i] : -1;
+        for (int i = 0; i < 64; ++i) xa.e_nbr[i] = (i < 2 * N && enc->m_max == 2) ? enc->nbr[i] : -1;
+        xa.e_ob_rows = ob_rows;
+        if (single && enc->relu_bits) return NMARL_EINVAL;       // (the sign image is the two-layer encoding's: nmarl_fc_bwd_pair)
         if (enc->env) {
             // the CACC env step of this lock-step behind the action draw (ENV block of the kernel)
             const nmarl_cacc_params_t* p = enc->env;
@@ -1923,11 +1940,14 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             const size_t lb_e = (size_t)(2 * CH_FLOATS + HW_FLOATS + 8 * 512 * 4 + 6 * 64 * 4 + 2 * H) * sizeof(float);
             if (const unsigned long long bit = enc_once.pending(); bit != ~0ull) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lb_e) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_step_x_kernel<3, 0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lb_e) != hipSuccess)
                     return NMARL_EHIP;
                 enc_once.done(bit);
             }
-            hipLaunchKernelGGL((lstm_step_x_kernel<3, 0, 1>), grid, dim3(512), lb_e, static_cast<hipStream_t>(stream), xa);
+            if (single) hipLaunchKernelGGL((lstm_step_x_kernel<3, 0, 2>), grid, dim3(512), lb_e, static_cast<hipStream_t>(stream), xa);
+            else hipLaunchKernelGGL((lstm_step_x_kernel<3, 0, 1>), grid, dim3(512), lb_e, static_cast<hipStream_t>(stream), xa);
             return nmarl_check_launch();
         }
     }

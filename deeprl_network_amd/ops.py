@@ -257,7 +257,7 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
     if isinstance(x, dict):          # the input encoders run inside the launch (step_enc_spec): x is their description
         if head is None or head.kind != 3 or x2 is not None or msg is not None or zadd1 is not None or zadd2 is not None:
             raise _lib.NmarlError('%s: the in-kernel encoders need the policy + value step of an uncoupled net' % what)
-        KX = 2 * FC_J
+        KX = FC_J if x.get('w_fp') is None else 2 * FC_J          # (one encoder: IA2C / ConseNet; two: IA2C-FP)
         if img.shape != (N, lib.nmarl_lstm_wimage_floats(KX)):
             raise _lib.NmarlError('%s: weight image does not match KX = %d' % (what, KX))
         check(lib.nmarl_lstm_step_x_enc(E, N, H, KX, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias), *_pn(c_prev), ptr(done, F32),
@@ -329,6 +329,13 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
                                 *_pn(c_out), *_pn(h_out), None if head is None else C.byref(head), stream()), what)
 
 
+def step_enc1_supported(n_feat, m_max, n_fc, n_h, N):
+    """The observation encoder ALONE fits the lock-step kernel's pre-phase (csrc/lstm_mfma.hip, ENC 2): 5 own features x (1 + m_max
+    neighbours), m_max = 2 (IA2C on CACC) or 0 (ConseNet: own features only) -> 64 outputs."""
+    return n_feat == 5 and m_max in (0, 2) and n_fc == FC_J and n_h == FUSED_H and N <= 32 and \
+        os.environ.get('NMARL_INKERNEL_ENCODE', '1') != '0'
+
+
 def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
     """The two input encoders of IA2C-FP / NeurComm fit the lock-step kernel's register-only pre-phase (csrc/lstm_mfma.hip, ENC): the
     CACC input layout -- 5 own features x (1 + 2 neighbours) and 2 x 4 fingerprint entries -> 64 + 64 outputs."""
@@ -375,12 +382,15 @@ def _step_enc(d, N, E):
     ob, fp = d['ob'], d['fp']
     if ob.dim() != 3 or ob.shape != (E, N, 5) or not ob.is_contiguous():
         raise _lib.NmarlError('step_enc: ob must be the compact observation [E,N,5], contiguous')
-    if fp.shape != (N, E, 4) or fp.stride(2) != 1 or fp.stride(1) != 4:
+    if d.get('w_fp') is not None and (fp.shape != (N, E, 4) or fp.stride(2) != 1 or fp.stride(1) != 4):
         raise _lib.NmarlError('step_enc: fp must be [N,E,4] with contiguous panels')
     e = _lib.StepEnc()
     e.ob, e.ob_row = ptr(ob, F32), N * 5
-    e.fp, e.fp_sn = ptr(fp, F32, strided=True), fp.stride(0)
-    for key, rows in (('w_ob', 15), ('w_fp', 8)):
+    single = d.get('w_fp') is None                 # the observation encoder alone (ENC 2): w_ob [N,15,64] (IA2C) or [N,5,64] (ConseNet)
+    m_enc = 2 if (not single or d['w_ob'].shape[1] == 15) else 0
+    if not single:
+        e.fp, e.fp_sn = ptr(fp, F32, strided=True), fp.stride(0)
+    for key, rows in (('w_ob', 5 * (1 + m_enc)),) + (() if single else (('w_fp', 8),)):
         w = d[key]
         if w.shape != (N, rows, FC_J):
             raise _lib.NmarlError('step_enc: %s must be [N,%d,64]' % (key, rows))
@@ -388,19 +398,20 @@ def _step_enc(d, N, E):
         setattr(e, key, p_)
         setattr(e, key + '_sn', sn)
     e.b_ob, e.b_ob_sn = _bias(d['b_ob'])
-    e.b_fp, e.b_fp_sn = _bias(d['b_fp'])
+    if not single:
+        e.b_fp, e.b_fp_sn = _bias(d['b_fp'])
     out = d.get('out')
     if out is not None:
-        e.out, e.out_sn, e.out_row = _rows_view(out, 2 * FC_J, 'step_enc out')
+        e.out, e.out_sn, e.out_row = _rows_view(out, FC_J if single else 2 * FC_J, 'step_enc out')
     bits = d.get('bits')
     if bits is not None:
         if bits.shape != (N, E, 4) or bits.dtype != torch.int32 or bits.stride(2) != 1 or bits.stride(1) != 4:
             raise _lib.NmarlError('step_enc: bits must be [N,E,4] int32 with contiguous panels')
         e.relu_bits, e.relu_bits_sn = ptr(bits, torch.int32, strided=True), bits.stride(0)
-    e.F, e.A, e.m_max = 5, 4, 2
+    e.F, e.A, e.m_max = 5, 4, m_enc
     for i in range(64):
         e.nbr[i] = -1
-    for i, lst in enumerate(d['nbrs']):
+    for i, lst in enumerate(d['nbrs'] if m_enc else []):
         for k, j in enumerate(lst[:2]):
             e.nbr[2 * i + k] = int(j)
     ev = d.get('env')

@@ -452,6 +452,9 @@ typedef struct nmarl_msg {
  *   ob [E][N][F = 5] (row pitch ob_row floats), fp [N][E][A = 4] (agent stride fp_sn); w_ob [N][15][64], b_ob [N][64],
  *   w_fp [N][8][64], b_fp [N][64]: the parameter tensors as they are (agent strides *_sn); out [N][E][128] view (agent
  *   stride out_sn, row pitch out_row); nbr: HOST copy of the neighbour table [N][m_max = 2], ascending, -1 padded (N <= 32).
+ * Round 6 -- the observation encoder ALONE (w_fp = NULL; KX = 64, out [N][E][64]): IA2C (policies.py:145, `fc(ob, 'fc', n_fc)`:
+ *   m_max = 2, w_ob [N][15][64]) and ConseNet (policies.py:381-390, the agent's own five features only: m_max = 0, w_ob [N][5][64],
+ *   nbr ignored); fp / b_fp / relu_bits unused (NULL).
  */
 typedef struct nmarl_step_enc {
     const float* ob; int64_t ob_row;

@@ -338,6 +338,11 @@ def step_enc_supported(n_feat, n_a, m_max, n_fc, n_h, N):
     return n_feat == 5 and n_a == 4 and m_max == 2 and n_fc == 64 and n_h == 64 and N <= 32
 
 
+def step_enc1_supported(n_feat, m_max, n_fc, n_h, N):
+    """(ENC 2: the observation encoder alone -- IA2C with two neighbour slots, ConseNet with none)"""
+    return n_feat == 5 and m_max in (0, 2) and n_fc == 64 and n_h == 64 and N <= 32
+
+
 def step_enc_spec(ob, fp, w_ob, b_ob, w_fp, b_fp, nbrs, out=None, env=None, bits=None):
     assert env is None, 'the in-launch env step exists on the device only (tests compare it with the env kernel there)'
     return dict(ob=ob, fp=fp, w_ob=w_ob, b_ob=b_ob, w_fp=w_fp, b_fp=b_fp, nbrs=nbrs, out=out, bits=bits)
@@ -358,13 +363,20 @@ def step_enc_forward(d):
     left packed, absent slots zero -> [N,E,128]; also written to d['out'] when given."""
     ob, fp, nbrs = d['ob'], d['fp'], d['nbrs']
     E, N, F = ob.shape
-    A = fp.shape[2]
+    single = d.get('w_fp') is None            # the observation encoder alone (IA2C: [own | 2 neighbours]; ConseNet: own features only)
+    own_only = single and d['w_ob'].shape[1] == F
+    A = 0 if single else fp.shape[2]
     rows = []
     for i in range(N):
         nb = list(nbrs[i]) + [-1] * (2 - len(nbrs[i]))
-        xo = torch.cat([ob[:, i]] + [ob[:, j] if j >= 0 else torch.zeros(E, F, dtype=ob.dtype, device=ob.device) for j in nb], dim=1)
+        xo = ob[:, i] if own_only else \
+            torch.cat([ob[:, i]] + [ob[:, j] if j >= 0 else torch.zeros(E, F, dtype=ob.dtype, device=ob.device) for j in nb], dim=1)
+        hx = torch.relu(xo @ d['w_ob'][i] + d['b_ob'][i])
+        if single:
+            rows.append(hx)
+            continue
         xf = torch.cat([fp[j] if j >= 0 else torch.zeros(E, A, dtype=fp.dtype, device=fp.device) for j in nb], dim=1)
-        rows.append(torch.cat([torch.relu(xo @ d['w_ob'][i] + d['b_ob'][i]), torch.relu(xf @ d['w_fp'][i] + d['b_fp'][i])], dim=1))
+        rows.append(torch.cat([hx, torch.relu(xf @ d['w_fp'][i] + d['b_fp'][i])], dim=1))
     S = torch.stack(rows, dim=0)
     if d.get('out') is not None:
         d['out'].copy_(S)

@@ -10,7 +10,7 @@ import contextlib
 from deeprl_network_amd import ops
 from oracle import ops_ref
 
-_NAMES = ['nbr_gather', 'nbr_mean', 'nbr_gather_bwd', 'nbr_mean_bwd', 'cell_bwd', 'nbr_onehot', 'lstm_cell', 'lstm_cell_infer', 'lstm_sequence', 'lstm_sequence_x', 'lstm_sequence_saved', 'bptt_supported', 'lstm_bptt_wimage', 'bptt_step', 'bptt_step_db_parts', 'bptt_seq', 'bptt_coupled', 'bptt_coupled_supported', 'lstm_bptt_msg_wimage', 'reverse_neighbor_table', 'dial_adjoint_supported', 'dial_adjoint_images', 'dial_msg_adjoint', 'dial_adjoint_bias_parts', 'lstm_wimage', 'lstm_msg_wimage', 'msg_supported', 'ob_encoder_supported', 'lstm_ob_wimage', 'step_sync_words', 'step_handoff_supported', 'xside_supported', 'lstm_step_fused', 'lstm_step_policy', 'lstm_step_value', 'lstm_step_policy_value', 'step_enc_supported', 'step_enc_spec', 'bias_act_', 'fc_fwd', 'fc_fwd_multi', 'onehot_argmax_add_', 'fc_bwd', 'fc_concat', 'fc_supported', 'thin_linear', 'thin_linear_bwd', 'nbr_action_value', 'nbr_action_value_bwd', 'heads', 'heads_supported', 'wgrad', 'linear', 'a2c_loss', 'a2c_loss_supported', 'sample_actions',
+_NAMES = ['nbr_gather', 'nbr_mean', 'nbr_gather_bwd', 'nbr_mean_bwd', 'cell_bwd', 'nbr_onehot', 'lstm_cell', 'lstm_cell_infer', 'lstm_sequence', 'lstm_sequence_x', 'lstm_sequence_saved', 'bptt_supported', 'lstm_bptt_wimage', 'bptt_step', 'bptt_step_db_parts', 'bptt_seq', 'bptt_coupled', 'bptt_coupled_supported', 'lstm_bptt_msg_wimage', 'reverse_neighbor_table', 'dial_adjoint_supported', 'dial_adjoint_images', 'dial_msg_adjoint', 'dial_adjoint_bias_parts', 'lstm_wimage', 'lstm_msg_wimage', 'msg_supported', 'ob_encoder_supported', 'lstm_ob_wimage', 'step_sync_words', 'step_handoff_supported', 'xside_supported', 'lstm_step_fused', 'lstm_step_policy', 'lstm_step_value', 'lstm_step_policy_value', 'step_enc_supported', 'step_enc1_supported', 'step_enc_spec', 'bias_act_', 'fc_fwd', 'fc_fwd_multi', 'onehot_argmax_add_', 'fc_bwd', 'fc_concat', 'fc_supported', 'thin_linear', 'thin_linear_bwd', 'nbr_action_value', 'nbr_action_value_bwd', 'heads', 'heads_supported', 'wgrad', 'linear', 'a2c_loss', 'a2c_loss_supported', 'sample_actions',
           'nstep_return', 'rmsprop_tf_clip', 'batch_epilogue']
 
 

@@ -42,21 +42,21 @@ def test_batched_update_matches_reference_replicas_on_gpu(path, saved):
     compare_batched(drive_batched(model, z, saved=saved), z)
 
 
-@pytest.mark.parametrize('agent', ['ia2c_fp', 'ia2c'])
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ia2c', 'ma2c_cu'])
 def test_batched_update_on_compact_observations_matches_reference_replicas_on_gpu(agent, monkeypatch):
-    """BatchedTrainer's exact configuration on CACC -- compact observations + saved activations; for IA2C-FP the policy +
-    value launch runs both input encoders itself (lstm_step_x_kernel<3,0,1>, nmarl_lstm_step_x_enc: no encoder launch
-    exists) -- against the K = 4 reference-replica golden, and the in-kernel encoders against the separate ones."""
+    """BatchedTrainer's exact configuration on CACC -- compact observations + saved activations, the policy + value launch
+    running the input encoders itself (IA2C-FP: both, lstm_step_x_kernel<3,0,1>; round 6: IA2C and ConseNet their one, <3,0,2>;
+    nmarl_lstm_step_x_enc: no encoder launch exists) -- against the K = 4 reference-replica golden, and the in-kernel encoders
+    against the separate ones."""
     from helpers import build_product_batched, compare_batched, drive_batched
     z = load_npz(os.path.join(GOLDEN, 'nnb_%s_line.npz' % agent))
     model = build_product_batched(z, 'cuda')
     out = drive_batched(model, z, saved=True, compact=True)
-    assert model.policy.enc_in_kernel(model.E, True) == (agent == 'ia2c_fp')
+    assert model.policy.enc_in_kernel(model.E, True)
     compare_batched(out, z)
-    if agent == 'ia2c_fp':
-        monkeypatch.setenv('NMARL_INKERNEL_ENCODE', '0')
-        model2 = build_product_batched(z, 'cuda')
-        out2 = drive_batched(model2, z, saved=True, compact=True)
-        assert not model2.policy.enc_in_kernel(model2.E, True)
-        for k in out:                                    # matrix-core summation order vs the fmaf chain of fc_fwd_multi
-            np.testing.assert_allclose(out[k], out2[k], rtol=2e-5, atol=2e-6, err_msg=k)
+    monkeypatch.setenv('NMARL_INKERNEL_ENCODE', '0')
+    model2 = build_product_batched(z, 'cuda')
+    out2 = drive_batched(model2, z, saved=True, compact=True)
+    assert not model2.policy.enc_in_kernel(model2.E, True)
+    for k in out:                                    # matrix-core summation order vs the fmaf chain of the fc kernels
+        np.testing.assert_allclose(out[k], out2[k], rtol=2e-5, atol=2e-6, err_msg=k)

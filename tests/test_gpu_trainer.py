@@ -268,9 +268,10 @@ def test_compact_observation_equals_gathered_slab(agent, monkeypatch):
 
 
 @pytest.mark.parametrize('E', [4096, 1000, 77])
-@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'catchup'), ('ma2c_nc', 'slowdown')])
+@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'catchup'), ('ma2c_nc', 'slowdown'),
+                                            ('ia2c', 'catchup'), ('ma2c_cu', 'slowdown')])
 def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, agent, scenario, monkeypatch):
-    """ONE launch per lock-step (IA2C-FP: lstm_step_x_kernel<3,0,1>; NeurComm: <4,1,1>, round 6): the lock-step kernel stepping the
+    """ONE launch per lock-step (IA2C-FP: lstm_step_x_kernel<3,0,1>; round 6: NeurComm <4,1,1>, IA2C / ConseNet <3,0,2>): the lock-step kernel stepping the
     env itself behind its action draw (ENV block: the last of the 8 agents' waves that own a strip of 16 replicas steps them, no
     wave waits) against the same kernel followed by the env kernel (nmarl_cacc_step) -- the same device function on the same
     actions, so EVERYTHING is bit-identical after 3 batches through the hipGraph: actions, rewards, done flags, observations,
@@ -300,7 +301,7 @@ def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, agent, scenar
 
 
 @pytest.mark.parametrize('E', [4096, 1000, 77])
-@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'slowdown')])
+@pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'slowdown'), ('ia2c', 'catchup')])
 def test_env_step_inside_the_lock_step_launch_vs_oracle(E, agent, scenario, monkeypatch):
     """The env step INSIDE the lock-step launch (lstm_step_x_kernel<3,0,1> / NeurComm's <4,1,1> + ENV block) against oracle/cacc_ref.py directly
     (cacc_env.py:191-242, 40-79, 166-189), not through the env kernel: every lock-step of 3 batches (= one 60-step episode,
@@ -357,9 +358,10 @@ def test_env_step_inside_the_lock_step_launch_vs_oracle(E, agent, scenario, monk
     assert int(env.episode.min()) == 2 and int(env.t.max()) == 0
 
 
-@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc'])
+@pytest.mark.parametrize('agent', ['ia2c_fp', 'ma2c_nc', 'ia2c', 'ma2c_cu'])
 def test_inkernel_encoders_equal_the_encoder_launch(agent, monkeypatch):
-    """IA2C-FP / NeurComm: the lock-step kernel running both input encoders itself (lstm_step_x_kernel<3,0,1> / <4,1,1>: no encoder
+    """IA2C-FP / NeurComm (two encoders) and IA2C / ConseNet (the observation encoder alone, <3,0,2>, round 6): the lock-step kernel
+    running the input encoders itself (lstm_step_x_kernel<3,0,1> / <4,1,1>: no encoder
     launch, the env step alone behind it) against the env step + encoder launch (nmarl_cacc_step_encode) in front of the plain
     lock-step kernel, ONE batch from the same state at E = 4096 and E = 1000 (ragged last block): saved LSTM inputs, values and the
     post-update weights agree to fp32 summation order; the drawn actions are identical except where a uniform falls within
@@ -369,8 +371,9 @@ def test_inkernel_encoders_equal_the_encoder_launch(agent, monkeypatch):
         out = []
         for inside in ('1', '0'):
             monkeypatch.setenv('NMARL_INKERNEL_ENCODE', inside)
-            env, model, tr = build(agent, E, True, scenario='catchup' if agent == 'ia2c_fp' else 'slowdown', n_step=60)
-            assert tr.enc_in_kernel == (inside == '1') and tr.fused_encode == (inside == '0')
+            env, model, tr = build(agent, E, True, scenario='catchup' if agent.startswith('ia2c') else 'slowdown', n_step=60)
+            # (ConseNet's 5-input encoder has no fused step + encode form: its round-5 lock-step is encoder launch + step kernel + env kernel)
+            assert tr.enc_in_kernel == (inside == '1') and tr.fused_encode == (inside == '0' and agent != 'ma2c_cu')
             tr.rollout()
             torch.cuda.synchronize()
             S, acts, vals = model.S_buf.clone(), model.buf_act.clone(), model.buf_vn.clone()

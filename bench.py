@@ -152,9 +152,10 @@ def measure_lstm_step(model, n=60, reps=10):
         # (the in-kernel input encoders' 2 * 23 * 64 flops per row are not counted: the figure stays comparable across rounds)
         flops = N * E * (2 * (KX + H) * 4 * H + 2 * H * 4 * H)
         # read x (in-kernel encoders: the 23 encoder inputs instead), h, c; write h', c', gates, pi, v, action (+ the encoded input)
-        nbytes = N * E * (((23 + KX) if in_k else KX) * 4 + 2 * H * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
+        nbytes = N * E * ((((23 if KX > H else 15) + KX) if in_k else KX) * 4 + 2 * H * 4 + 2 * H * 4 + 4 * H * 4 + A * 4 + 4 + 1)
+        two = in_k and p._enc_spec(model.buf_x[0], model.fp, None).get('w_fp') is not None      # (one encoder: IA2C / ConseNet, ENC 2)
         name = 'lstm_step_x_kernel<3,0,%d> (nmarl_lstm_step_x%s, policy + value heads%s)' % (
-            1 if in_k else 0, '_enc' if in_k else '', ', input encoders inside' if in_k else '')
+            (1 if two else 2) if in_k else 0, '_enc' if in_k else '', ', input encoder%s inside' % ('s' if two else '') if in_k else '')
     elif p.can_save_acts and p.pv_one_launch(E):
         # coupled nets, one launch per lock-step: policy step (message term in the pre-phase), in-launch hand-off of the new h,
         # value re-step from the kept x-side part + the re-computed message columns + the new h (head kind 3 + message term)

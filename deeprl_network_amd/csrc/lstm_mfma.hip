@@ -779,9 +779,9 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     if (MSG == 0 && ENC == 0) { NMARL_A_LOAD(0, a0, a1) }
     // ---- ENC: the input encoders' operands (see the kernel's header), REQUESTED here -- behind the two weight chunks, in front of
     // everything else the prologue asks for -- and consumed just before the prologue's barrier
-    float ein[ENC ? 6 : 1];
-    float ewt[ENC ? 3 : 1];
-    f32x4 eacc[ENC ? 8 : 1];
+    float ein[ENC == 1 ? 6 : (ENC ? 4 : 1)];
+    float ewt[ENC == 1 ? 3 : (ENC ? 2 : 1)];
+    f32x4 eacc[ENC == 1 ? 8 : (ENC ? 4 : 1)];
     if (ENC) {
         __builtin_amdgcn_sched_barrier(0);                                // (the chunk loads above stay first)
         const int i16 = lane & 15;
@@ -799,7 +799,6 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             const float v3 = e_ob[arow * e_ob_row + ag3 * 5 + 4];
             const bool ok3 = grp == 0 || (grp == 1 && nb0 >= 0) || (grp == 2 && nb1 >= 0);
             ein[0] = v0; ein[1] = nb0 >= 0 ? v1 : 0.0f; ein[2] = nb1 >= 0 ? v2 : 0.0f; ein[3] = ok3 ? v3 : 0.0f;
-            ein[4] = ein[5] = 0.0f;
             if (EFP) {
                 const float* fpr = e_fp + arow * 4 + grp;
                 const float p0 = fpr[(int64_t)ag1 * e_fp_sn], p1 = fpr[(int64_t)ag2 * e_fp_sn];
@@ -1033,7 +1032,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         // ---- ENC: operands from LDS, 24 MFMAs (k-step outer: four independent accumulators between two dependent ones), relu, park
         // in the lane's LDS slots, save for the update
         const int i16 = lane & 15;
-        float4 w4[6];
+        float4 w4[EFP ? 6 : 4];
 #pragma unroll
         for (int s_ = 0; s_ < (EFP ? 6 : 4); ++s_) w4[s_] = reinterpret_cast<const float4*>(e_lds)[s_ * 64 + lane];
 #pragma unroll

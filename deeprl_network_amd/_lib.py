@@ -139,6 +139,14 @@ class GridParams(C.Structure):
                 ('objective', C.c_int32), ('coef_wait', C.c_float), ('head_wait', C.c_void_p)]
 
 
+class GridEnv(C.Structure):
+    """nmarl_grid_env_t (include/nmarl.h): the grid env step as a role of CommNet's lock-step launch."""
+    _fields_ = ([('params', C.POINTER(GridParams))] +
+                [(k, C.c_void_p) for k in ('q', 'transit', 'prev_action', 't', 'xi', 'obs_out', 'reward', 'done', 'global_reward')] +
+                [('auto_reset', C.c_int32), ('pad_', C.c_int32), ('seed', C.c_uint64), ('env_id_base', C.c_int64),
+                 ('episode', C.c_void_p), ('words', C.c_void_p)])
+
+
 _p = C.c_void_p
 _i64 = C.c_int64
 _i32 = C.c_int32
@@ -184,6 +192,10 @@ SIGNATURES = {
     'nmarl_lstm_step_x_msg_enc': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
                                   C.POINTER(Head), C.POINTER(Msg), C.POINTER(StepEnc), _p],
     'nmarl_lstm_step_env_words': [_i64],
+    'nmarl_lstm_step_grid_words': [_i64],
+    'nmarl_lstm_step_grid_env_blocks': [_i64, _i32],
+    'nmarl_lstm_step_x_msg_grid': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64,
+                                   C.POINTER(Head), C.POINTER(Msg), C.POINTER(GridEnv), _p],
     'nmarl_lstm_bptt_wimage_floats': [_i32],
     'nmarl_lstm_bptt_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_step': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p,

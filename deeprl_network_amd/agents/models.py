@@ -309,14 +309,15 @@ class IA2C:
             # that the update's encoder backward needs no forward pass.  Where the one-launch step runs the encoder too, `enc`
             # is only the slot its output goes to
             if p.encodes_in_step(self.E, self.compact_obs):
-                enc, ob = p._extra['ENC'][:, t], self.buf_x[t]
+                # (env_step: the launch also steps the grid env, on compute units its LSTM blocks leave idle -- LargeGridBatchEnv.inkernel_step)
+                enc, ob = p._extra['ENC'][:, t], (self.buf_x[t] if env_step is None else dict(x=self.buf_x[t], genv=env_step))
             else:
                 enc = p.encode(self.buf_x[t], self.fp, out=p._extra['ENC'][:, t])
             p._enc_was_saved = True
         else:
             enc = p.encode(self.buf_x[t], self.fp, out=self.S_buf[:, t]) if self.save_acts else p.encode(self.buf_x[t], self.fp)
         if env_step is not None and (ob is None or not isinstance(ob, dict)):
-            raise ValueError('env_step needs the lock-step kernel that runs the input encoders itself (policy.enc_in_kernel)')
+            raise ValueError('env_step needs the lock-step kernel that runs the input encoders itself (policy.enc_in_kernel / encodes_in_step)')
         draw = dict(mode=mode, u=u, seed=seed, env_id_base=env_id_base, step=step, step_dev=step_dev)
         if self.save_acts and p.pv_one_launch(self.E):
             # the policy step reads slot t of the state sequences and writes slot t + 1, gates into G[:, t]; the value

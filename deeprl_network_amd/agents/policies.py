@@ -472,7 +472,9 @@ class BatchedPolicy:
             if self.coupled:
                 z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
                 xs[4]['sync'] = self._sync_words(h.shape[1])
-                if isinstance(ob, dict):         # lstm_comm: both input encoders (and the env step) inside the launch, see `enc_in_kernel`
+                if isinstance(ob, dict) and 'genv' in ob:      # lstm_ic3 on the grid: observation encoder AND env step inside the launch
+                    xs[4]['ob'], xs[4]['genv'] = self._ob_spec(ob['x']), ob['genv']
+                elif isinstance(ob, dict):       # lstm_comm: both input encoders (and the env step) inside the launch, see `enc_in_kernel`
                     xs[4]['enc_spec'] = self._enc_spec(ob['x'], ob['fp'], None, ob.get('env'), ob.get('bits'))
                 elif ob is not None:
                     xs[4]['ob'] = self._ob_spec(ob)

@@ -12,6 +12,7 @@
 // ever exists in HBM).  fp32 MFMA = the fp32 vector rate (157 TFLOP/s chip peak, MI355X_MICROARCH.md).
 #include "common.h"
 #include "cacc_tile.h"
+#include "grid_tile.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -549,6 +550,15 @@ struct XArgs {
     float* ev_obs; float* ev_rew; uint8_t* ev_done; float* ev_grew;
     uint64_t ev_seed; int64_t ev_base; int32_t* ev_episode;
     unsigned* ev_cnt;             // [E] hand-off words: bits 0..15 the N agents' draws (2 bits each), bits 16.. the arrivals; zero between launches
+    // HEAD 4 + MSG 2 + gv_on (round 6): the synthetic grid's env step as a ROLE of this launch -- blocks >= gv_lstm_blocks (the compute
+    // units the 25 x ceil(E / 128) LSTM blocks leave idle) wait for the 25 drawn actions of their replicas and step them while the
+    // LSTM blocks run their value re-step (see the GRID ENV block at the kernel's top)
+    int gv_on, gv_lstm_blocks, gv_auto_reset;
+    nmarl_grid_params_t gv_p;
+    float *gv_q, *gv_tr; uint8_t* gv_prev; int32_t* gv_t; float* gv_xi;
+    float* gv_obs; float* gv_rew; uint8_t* gv_done; float* gv_grew;
+    uint64_t gv_seed; int64_t gv_base; int32_t* gv_episode;
+    unsigned long long* gv_words;  // [E][2]: bits 0..38 = 13 agents' draws (3 bits each), bits 59.. = arrivals; zero between launches
 };
 
 // raw buffer access for the in-launch hand-off of HEAD 4 (see lstm_bptt.hip for the rules: write-through stores and
@@ -636,8 +646,25 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedArgs& a = xa.f;
     NMARL_STAMP(0)
+    constexpr bool GENV = HEAD == 4 && MSG == 2;             // the grid's env step can be a role of this launch
+    const unsigned n_lstm = (GENV && xa.gv_on) ? (unsigned)xa.gv_lstm_blocks : gridDim.x;
+    if (GENV && xa.gv_on && blockIdx.x >= n_lstm) {
+        // ---- GRID ENV role (envs/atsc_env.py:181-207 on the synthetic dynamics of oracle/grid_ref.py): this block is not an LSTM
+        // block.  Groups of 16 replicas (one per half wave): wait until all 25 agents' waves have added their draws into the
+        // replica's two hand-off words (the LSTM blocks do so right behind their actor heads), then grid_step_groups -- the env
+        // kernel's own device function -- writes state, reward, done and the compact observation of lock-step t + 1 while the LSTM
+        // blocks are still in their value re-steps.  Bounded waits; a time-out raises the hand-off status word (fail closed).
+        nmarl_grid::Lds* el = reinterpret_cast<nmarl_grid::Lds*>(lds);
+        float* bq = reinterpret_cast<float*>(el + 16);
+        float* bt = bq + 16 * nmarl_grid::NQ;
+        nmarl_grid::grid_step_groups<0, true, false, 16, true>(
+            xa.gv_p, a.E, (int64_t)(blockIdx.x - n_lstm), (int64_t)(gridDim.x - n_lstm), nullptr, xa.gv_words, xa.status, xa.max_spins, xa.gv_q,
+            xa.gv_tr, xa.gv_prev, xa.gv_t, xa.gv_xi, xa.gv_obs, xa.gv_rew, xa.gv_done, xa.gv_grew, xa.gv_auto_reset, xa.gv_seed, xa.gv_base,
+            xa.gv_episode, el, bq, bt, bt);
+        return;
+    }
     int n, blk_u;
-    nmarl_xcd_work(blockIdx.x, gridDim.x, a.blocks_per_agent, n, blk_u);          // an agent's blocks share an XCD (its L2 holds the image)
+    nmarl_xcd_work(blockIdx.x, n_lstm, a.blocks_per_agent, n, blk_u);             // an agent's blocks share an XCD (its L2 holds the image)
     // ENC: touch every scalar-cache line of the launch arguments (1.1 KB: 18 lines) with one back-to-back burst of scalar loads; the
     // values are consumed (or-ed into nothing) only at the end of the prologue, so the lines arrive while the vector loads issue --
     // the compiler's lazy argument loads then hit the scalar cache instead of each paying a first-touch miss behind its own wait
@@ -1367,6 +1394,13 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         int act_l = -1;
         if (HEAD == 2) head_epilogue<2>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
         else act_l = head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
+        if (GENV && xa.gv_on && act_l >= 0) {
+            // the drawn action of (replica row0 + lane, agent n) -> the replica's hand-off word (no return value: nothing here waits)
+            typedef __attribute__((address_space(1))) unsigned long long gu64;
+            const int hi_ = n >= 13 ? 1 : 0;
+            __hip_atomic_fetch_add((gu64*)xa.gv_words + 2 * (row0 + lane) + hi_,
+                                   ((unsigned long long)act_l << (3 * (n - 13 * hi_))) | (1ull << 59), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (ENC && xa.ev_on) {
             // ---- ENV (1/2): every drawn action goes into its replica's hand-off word by ONE atomic add -- 2 bits of payload per agent
             // + an arrival count above them -- whose return value is looked at after the value re-step (which hides the trip): the
@@ -1576,7 +1610,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             if (threadIdx.x == 0) {
                 gu32* sy = (gu32*)xa.sync;
                 const unsigned old = __hip_atomic_fetch_add(sy + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == gridDim.x - 1) {
+                if (old == n_lstm - 1) {
                     __hip_atomic_store(sy + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(sy, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -1788,13 +1822,16 @@ extern "C" int nmarl_handoff_capacity(int32_t which, int32_t K) {
     return per_cu * cus;
 }
 
+extern "C" int nmarl_lstm_step_grid_env_blocks(int64_t E, int32_t N);
+
 static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
                          int32_t KX2, const float* x2, int64_t x2_sn, int64_t x2_row,
                                  const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
                                  int64_t bias_sn, const float* zadd1, int64_t zadd1_sn, const float* zadd2, int64_t zadd2_sn,
                                  const float* c_prev, int64_t c_prev_sn, const float* done, float* gates, int64_t gates_sn,
                                  float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn, const nmarl_head_t* head,
-                                 const nmarl_msg_t* msg, void* stream, const nmarl_step_enc_t* enc = nullptr) {
+                                 const nmarl_msg_t* msg, void* stream, const nmarl_step_enc_t* enc = nullptr,
+                                 const nmarl_grid_env_t* genv = nullptr) {
     const int mk = msg ? msg->kind : 0;
     const int KM = mk ? H : 0;                   // columns of x the message pre-phase produces
     if (Hh != H || E < 0 || N <= 0 || KX < 0 || KX > MAX_KX || KX % CH_K || KX2 < 0 || KX2 > KX || KX2 % CH_K || mk < 0 || mk > 3 ||
@@ -1890,7 +1927,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         lds_once.done(lds_bit);
     }
     if (mk && kind == 0) return NMARL_EINVAL;                   // the message pre-phase exists for the policy / value steps
-    const dim3 grid(a.blocks_per_agent * N);
+    dim3 grid(a.blocks_per_agent * N);
     if (enc) {
         // the input encoders inside the launch (ENC 1) on the CACC input layout: the uncoupled nets' policy + value step (<3,0,1>), or
         // NeurComm's one-launch lock-step (<4,1,1>: x = the S slot the encoders' [hx | hp] goes to AND the K loop reads it back from)
@@ -1950,6 +1987,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
             return nmarl_check_launch();
         }
     }
+    if (genv && !(mk == 2 && kind == 3)) return NMARL_EINVAL;
     if (mk && kind == 3) {
         // policy step + value re-step of a coupled net in ONE launch: the re-step's message term needs the neighbours' new h, handed
         // over between blocks inside the launch -- every block must be resident (one block per CU: 512 threads, > 80 KB LDS)
@@ -1962,6 +2000,23 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         xa.status = msg->status;
         xa.fault = nmarl_handoff_take_fault() ? 1 : 0;
         xa.max_spins = xa.fault ? NMARL_HANDOFF_FAULT_SPINS : NMARL_HANDOFF_MAX_SPINS;
+        if (genv) {
+            // the synthetic grid's env step as a role of this launch: the compute units the LSTM blocks leave idle run it
+            const nmarl_grid_params_t* gp = genv->params;
+            const int env_blocks = nmarl_lstm_step_grid_env_blocks(E, N);
+            if (!gp || env_blocks <= 0 || N != NMARL_GRID_N || head->A > 7 || !msg->ob || !gp->compact_obs || gp->objective != 0 || gp->T <= 0 ||
+                gp->norm_wave <= 0.f || !genv->q || !genv->transit || !genv->prev_action || !genv->t || !genv->xi || !genv->obs_out ||
+                !genv->reward || !genv->done || !genv->global_reward || !genv->words || ((uintptr_t)genv->words % 8) ||
+                ((uintptr_t)genv->obs_out % 16) || ((uintptr_t)genv->q % 16) || ((uintptr_t)genv->transit % 16) ||
+                (genv->auto_reset && !genv->episode) || !msg->status)
+                return NMARL_EINVAL;
+            xa.gv_on = 1; xa.gv_lstm_blocks = (int)grid.x; xa.gv_auto_reset = genv->auto_reset ? 1 : 0; xa.gv_p = *gp;
+            xa.gv_q = genv->q; xa.gv_tr = genv->transit; xa.gv_prev = genv->prev_action; xa.gv_t = genv->t; xa.gv_xi = genv->xi;
+            xa.gv_obs = genv->obs_out; xa.gv_rew = genv->reward; xa.gv_done = genv->done; xa.gv_grew = genv->global_reward;
+            xa.gv_seed = genv->seed; xa.gv_base = genv->env_id_base; xa.gv_episode = genv->episode;
+            xa.gv_words = reinterpret_cast<unsigned long long*>(genv->words);
+            grid = dim3(grid.x + env_blocks);
+        }
     }
     size_t lb_extra = 0;
     if (msg && msg->ob) {
@@ -2036,6 +2091,28 @@ extern "C" int nmarl_lstm_step_x_msg_enc(int64_t E, int32_t N, int32_t Hh, int32
     if (!msg || msg->kind != 1 || !head || head->kind != 3 || !enc || !x) return NMARL_EINVAL;
     return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
                          c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream, enc);
+}
+
+// env-role blocks a grid launch gets: the compute units the LSTM blocks leave idle, at most one per group of 16 replicas
+extern "C" int nmarl_lstm_step_grid_env_blocks(int64_t E, int32_t N) {
+    if (E <= 0 || N <= 0) return 0;
+    const int cap = nmarl_handoff_capacity(1, H);
+    const int64_t lstm = (int64_t)N * ((E + ROWS_B - 1) / ROWS_B), groups = (E + 15) / 16;
+    if (cap <= 0 || lstm >= cap) return 0;
+    const int64_t room = cap - lstm;
+    return (int)(room < groups ? room : groups);
+}
+
+extern "C" int nmarl_lstm_step_grid_words(int64_t E) { return E <= 0 ? 0 : (int)(2 * E); }
+
+extern "C" int nmarl_lstm_step_x_msg_grid(int64_t E, int32_t N, int32_t Hh, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                                          const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                                          int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                                          int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
+                                          const nmarl_head_t* head, const nmarl_msg_t* msg, const nmarl_grid_env_t* genv, void* stream) {
+    if (!msg || msg->kind != 2 || !head || head->kind != 3 || !genv) return NMARL_EINVAL;
+    return launch_step_x(E, N, Hh, KX, x, x_sn, x_row, 0, nullptr, 0, 0, h_in, h_sn, img, img_sn, bias, bias_sn, nullptr, 0, nullptr, 0,
+                         c_prev, c_prev_sn, done, gates, gates_sn, c_new, c_new_sn, h_new, h_new_sn, head, msg, stream, nullptr, genv);
 }
 
 extern "C" int nmarl_lstm_step_env_words(int64_t E) { return E <= 0 ? 0 : (int)((E + 63) / 64 * 64); }

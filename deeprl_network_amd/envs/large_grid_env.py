@@ -159,6 +159,32 @@ class LargeGridBatchEnv:
         _lib.check(rc, 'nmarl_grid_reset')
         return self.obs
 
+    _words = None
+
+    def inkernel_step_supported(self):
+        """CommNet's one-launch lock-step can run this env's step as a role of the same launch (csrc/lstm_mfma.hip GENV): compact
+        observation, queue objective, and compute units left idle by the LSTM blocks."""
+        from .. import ops
+        return self.compact_obs and not self.params.objective and ops.step_grid_env_blocks(N_NODE, self.E) > 0
+
+    def inkernel_step(self, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
+        """Arguments of `step` for the policy's lock-step launch to run the env step itself, on the actions it draws
+        (ops._step_x msg['genv'], nmarl_lstm_step_x_msg_grid): same state tensors, same outputs."""
+        if not self.compact_obs or self.params.objective:
+            raise _lib.NmarlError('the in-launch grid env step writes the compact observation and knows the queue objective')
+        if self._words is None:          # hand-off words of the launch ([E][2] u64): zeroed once, every launch leaves them zero
+            self._words = torch.zeros(_lib.lib.nmarl_lstm_step_grid_words(self.E), dtype=torch.int64, device=self.device)
+        return dict(params=self.params, q=self.q, transit=self.transit, prev_action=self.prev_action, t=self.t, xi=self.xi,
+                    obs_out=self.obs if obs_out is None else obs_out, reward=self.reward if reward_out is None else reward_out,
+                    done=self.done if done_out is None else done_out,
+                    global_reward=self.global_reward if greward_out is None else greward_out, auto_reset=bool(auto_reset),
+                    seed=self.seed, env_id_base=self.env_id_base, episode=self.episode, words=self._words)
+
+    def clear_inkernel_words(self):
+        """After a hand-off time-out (the launch gave up waiting and may have left arrivals in the words)."""
+        if self._words is not None:
+            self._words.zero_()
+
     def step(self, action, auto_reset=False, obs_out=None, reward_out=None, done_out=None, greward_out=None):
         P = _lib.ptr
         obs = self.obs if obs_out is None else obs_out

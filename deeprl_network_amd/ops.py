@@ -320,6 +320,26 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
                                                 *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
                                                 C.byref(m), C.byref(_step_enc(dict(spec, out=None), N, E)), stream()), what)
             return
+        genv = msg.get('genv')
+        if genv is not None:
+            # lstm_ic3 on the synthetic grid: the env step as a role of this launch (LargeGridBatchEnv.inkernel_step), on the compute
+            # units the LSTM blocks leave idle
+            if head.kind != 3 or msg['kind'] != MSG_MEAN_ADD or ob is None:
+                raise _lib.NmarlError('%s: the in-launch grid env step needs lstm_ic3\'s one-launch step with its observation encoder inside' % what)
+            g = _lib.GridEnv()
+            g.params = C.pointer(genv['params'])
+            for k in ('q', 'transit', 'xi', 'obs_out', 'reward', 'global_reward'):
+                setattr(g, k, ptr(genv[k], F32))
+            g.prev_action, g.done = ptr(genv['prev_action'], torch.uint8), ptr(genv['done'], torch.uint8)
+            g.t, g.episode = ptr(genv['t'], torch.int32), ptr(genv['episode'], torch.int32)
+            g.auto_reset, g.seed, g.env_id_base = (1 if genv['auto_reset'] else 0), int(genv['seed']), int(genv['env_id_base'])
+            if genv['words'].dtype != torch.int64 or genv['words'].numel() < lib.nmarl_lstm_step_grid_words(E):
+                raise _lib.NmarlError('%s: genv["words"] must hold nmarl_lstm_step_grid_words(E) 64-bit words' % what)
+            g.words = ptr(genv['words'], torch.int64)
+            check(lib.nmarl_lstm_step_x_msg_grid(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
+                                                 *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
+                                                 C.byref(m), C.byref(g), stream()), what)
+            return
         check(lib.nmarl_lstm_step_x_msg(E, N, H, KX, xp, x_sn, x_row, *_pn(h), ptr(img, F32), img.stride(0), *_bias(bias),
                                         *_pn(c_prev), ptr(done, F32), *_pn(gates), *_pn(c_out), *_pn(h_out), C.byref(head),
                                         C.byref(m), stream()), what)
@@ -438,6 +458,11 @@ def lstm_ob_wimage(w_ob, pad, out=None):
     with torch.no_grad():      # (w_ob is a parameter: tracked, the copy would hang `pad` -- and an AccumulateGrad node on the stream of the
         pad[:, :w_ob.shape[1]].copy_(w_ob)       # first call -- onto the autograd graph; a node created on the default stream breaks captures)
     return lstm_msg_wimage(pad, out=out)
+
+
+def step_grid_env_blocks(N, E):
+    """Env-role blocks lstm_ic3's one-launch step has room for on the synthetic grid (0: none -- the env step stays a launch)."""
+    return int(lib.nmarl_lstm_step_grid_env_blocks(E, N)) if handoff_enabled() else 0
 
 
 def step_sync_words(N, E, device):

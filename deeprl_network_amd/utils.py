@@ -437,6 +437,13 @@ class BatchedTrainer:
         # ... and the env step as well, behind the action draw of the same launch: ONE launch per lock-step (ENV block of the kernel)
         self.env_in_kernel = self.enc_in_kernel and hasattr(env, 'inkernel_step') and env.n_agent == 8 and ops.step_env_supported() and \
             model.policy.env_step_in_kernel
+        # the synthetic grid under CommNet: the env step is a ROLE of the one-launch lock-step (its observation encoder is inside
+        # already), run by the compute units the 25 x ceil(E / 128) LSTM blocks leave idle (csrc/lstm_mfma.hip GENV)
+        if not self.env_in_kernel and self.saved_acts and self.compact_obs and env.device.type == 'cuda' and \
+                getattr(env, 'inkernel_step_supported', None) is not None and model.policy.coupled and \
+                getattr(model.policy, 'encodes_in_step', None) is not None and 'ENC' in model.policy._extra and \
+                os.environ.get('NMARL_GRID_ENV_IN_KERNEL', '1') != '0':
+            self.env_in_kernel = bool(model.policy.encodes_in_step(env.E, True) and env.inkernel_step_supported())
         self.fused_encode = self._want_fused_encode and self.saved_acts and self.compact_obs and not self.enc_in_kernel and \
             getattr(env, 'supports_fused_encode', False) and env.device.type == 'cuda' and \
             model.policy.fused_env_encode(model.buf_fp[1], model.encode_target(1)) is not None
@@ -605,6 +612,8 @@ class BatchedTrainer:
                         'keeping them for the next %d batches' % (self.n_batches - batches, batches, self._rearm_wait))
         ops.disable_inkernel_handoff()
         ops.handoff_clear(dev)
+        if hasattr(self.env, 'clear_inkernel_words'):
+            self.env.clear_inkernel_words()
         for s_, t_ in zip(self._shadow, self._shadow_tensors()):
             t_.copy_(s_)
         m.policy.invalidate_cached_msg()

@@ -494,6 +494,32 @@ int nmarl_lstm_step_x_msg(int64_t E, int32_t N, int32_t H, int32_t KX, const flo
                           int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
                           const nmarl_head_t* head, const nmarl_msg_t* msg, void* stream);
 /*
+ * CommNet's lock-step on the synthetic 5x5 grid with the ENV STEP as a role of the same launch (round 6; utils.py:163-197,
+ * envs/atsc_env.py:181-207, agents/utils.py:344-417): nmarl_lstm_step_x_msg (head kind 3, message kind 2, msg->ob = the compact
+ * observation encoder inside) launched with nmarl_lstm_step_grid_env_blocks(E, N) blocks MORE than the N x ceil(E / 128) LSTM
+ * blocks -- the compute units those leave idle (56 of 256 at 25 x 1024).  Every LSTM wave adds its drawn actions into its replicas'
+ * hand-off words (words [E][2] u64: 3 bits per agent, an arrival count above bit 59; nmarl_lstm_step_grid_words(E) words zeroed
+ * ONCE, left zero by every launch); an env block waits (bounded) for the 25 arrivals of its groups of 16 replicas and then runs
+ * nmarl_grid_step's own device code on them (bit-identical; arguments as for nmarl_grid_step with compact_obs = 1, objective =
+ * queue), writing state, reward, done and the observation of lock-step t + 1 while the LSTM blocks are in their value re-steps.
+ * A time-out raises msg->status word 0 (fail closed, like the hand-off of the new h).  env_blocks = 0: not available (no idle
+ * compute unit) -- use nmarl_lstm_step_x_msg + nmarl_grid_step.
+ */
+typedef struct nmarl_grid_env {
+    const nmarl_grid_params_t* params;
+    float *q, *transit; uint8_t* prev_action; int32_t* t; float* xi;
+    float* obs_out; float* reward; uint8_t* done; float* global_reward;
+    int32_t auto_reset, pad_; uint64_t seed; int64_t env_id_base; int32_t* episode;
+    uint64_t* words;
+} nmarl_grid_env_t;
+int nmarl_lstm_step_grid_words(int64_t E);
+int nmarl_lstm_step_grid_env_blocks(int64_t E, int32_t N);
+int nmarl_lstm_step_x_msg_grid(int64_t E, int32_t N, int32_t H, int32_t KX, const float* x, int64_t x_sn, int64_t x_row,
+                               const float* h_in, int64_t h_sn, const float* img, int64_t img_sn, const float* bias,
+                               int64_t bias_sn, const float* c_prev, int64_t c_prev_sn, const float* done, float* gates,
+                               int64_t gates_sn, float* c_new, int64_t c_new_sn, float* h_new, int64_t h_new_sn,
+                               const nmarl_head_t* head, const nmarl_msg_t* msg, const nmarl_grid_env_t* genv, void* stream);
+/*
  * NeurComm's WHOLE lock-step in one launch (round 6; agents/utils.py:118-217 `lstm_comm`, utils.py:163-197, envs/cacc_env.py:191-242):
  * nmarl_lstm_step_x_msg with head kind 3 and message kind 1, plus `enc` as in nmarl_lstm_step_x_enc -- the two input encoders
  * [relu(x~ W_ob + b) | relu(p~ W_fp + b)] run in the launch's pre-phase and, with enc->env, the CACC env step behind the action

@@ -62,7 +62,8 @@ def test_library_is_built_from_the_current_sources():
 
 @pytest.mark.parametrize('ctype,cls', [('nmarl_head_t', 'Head'), ('nmarl_fc_part_t', 'FcPart'), ('nmarl_msg_t', 'Msg'),
                                        ('nmarl_cacc_params_t', 'CaccParams'), ('nmarl_grid_params_t', 'GridParams'),
-                                       ('nmarl_bptt_coupled_t', 'BpttCoupled'), ('nmarl_batch_epilogue_t', 'BatchEpilogue'), ('nmarl_cacc_encode_t', 'CaccEncode')])
+                                       ('nmarl_bptt_coupled_t', 'BpttCoupled'), ('nmarl_batch_epilogue_t', 'BatchEpilogue'), ('nmarl_cacc_encode_t', 'CaccEncode'),
+                                       ('nmarl_step_enc_t', 'StepEnc'), ('nmarl_grid_env_t', 'GridEnv')])
 def test_struct_layouts_match_c_compiler(tmp_path, ctype, cls):
     """Every struct of the C-ABI as gcc lays it out == its ctypes mirror, field by field."""
     from deeprl_network_amd import _lib

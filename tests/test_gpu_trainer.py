@@ -300,6 +300,42 @@ def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, agent, scenar
         assert torch.equal(a, b), 'item %d differs between the in-launch env step and the env kernel' % k
 
 
+@pytest.mark.parametrize('use_graph', [True, False])
+@pytest.mark.parametrize('E', [1024, 1000, 77, 7000])
+def test_grid_env_step_as_a_role_of_the_lock_step_launch_is_the_env_kernel(E, use_graph, monkeypatch):
+    """BASELINE configs[3] (synthetic 5 x 5 grid, CommNet): the env step run by extra blocks of the one-launch lock-step
+    (lstm_step_x_kernel<4,2,0>, GENV role on the compute units the 25 x ceil(E / 128) LSTM blocks leave idle: they take the drawn
+    actions from two hand-off words per replica) against the same launch followed by nmarl_grid_step -- one device function
+    (csrc/grid_tile.h) on the same actions, so everything is bit-identical after 3 batches: actions, rewards, done flags,
+    observations, env state incl. the auto-reset at the episode end (T = 3 batches), values, weights; the hand-off words are
+    left zero.  E = 1000 / 77: ragged last row block and last group of 16 replicas; E = 7000: more LSTM blocks (1375) than the chip
+    holds -> no one-launch lock-step at all, the form must be refused, not mis-selected."""
+    from deeprl_network_amd import ops
+    out = []
+    for inside in ('1', '0'):
+        monkeypatch.setenv('NMARL_GRID_ENV_IN_KERNEL', inside)
+        env, model, tr = build('ma2c_ic3', E, use_graph, scenario='grid', n_step=20, episode_sec=300)      # T = 60 lock-steps = 3 batches
+        assert env.T == 60
+        fits = ops.step_grid_env_blocks(25, E) > 0 and model.policy.pv_one_launch(E)
+        assert fits == (E < 7000)
+        assert tr.env_in_kernel == (inside == '1' and fits)
+        rec = []
+        for _ in range(3):
+            tr.run_batch()
+            rec += [model.buf_act.clone(), tr.buf_rraw.clone(), tr.buf_g.clone(), model.buf_done_post.clone(), model.buf_x.clone()]
+        tr.flush()
+        torch.cuda.synchronize()
+        assert tr.handoff_fallbacks == 0
+        assert int(env.episode.min()) == 2 and int(env.t.max()) == 0          # every replica finished an episode and was re-initialised
+        if tr.env_in_kernel:
+            assert int(env._words.abs().max()) == 0
+        out.append(rec + [t.clone() for t in env.state_tensors()] + [model.buf_v.clone(), model.policy.params.flat.clone(), tr.ep_sum.clone()])
+        assert tr.stats()['episodes'] == E
+        del env, model, tr
+    for k, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), 'item %d differs between the in-launch env step and the env kernel' % k
+
+
 @pytest.mark.parametrize('E', [4096, 1000, 77])
 @pytest.mark.parametrize('agent,scenario', [('ia2c_fp', 'catchup'), ('ia2c_fp', 'slowdown'), ('ma2c_nc', 'slowdown'), ('ia2c', 'catchup')])
 def test_env_step_inside_the_lock_step_launch_vs_oracle(E, agent, scenario, monkeypatch):

@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         int act_l = -1;
         if (HEAD == 2) head_epilogue<2>(a, n, xa.N, row0, lane, a_tile, hw_lds + H * MAXA + MAXA);
         else act_l = head_policy_lds(a, n, xa.N, row0, lane, a_tile, hw_lds, hw_lds + H * MAXA);
-        if (GENV && xa.gv_on && act_l >= 0) {
+        if (GENV && xa.gv_on && act_l >= 0 && !(xa.fault && blockIdx.x == 0)) {     // (test hook: block 0's actions never arrive either)
             // the drawn action of (replica row0 + lane, agent n) -> the replica's hand-off word (no return value: nothing here waits)
             typedef __attribute__((address_space(1))) unsigned long long gu64;
             const int hi_ = n >= 13 ? 1 : 0;

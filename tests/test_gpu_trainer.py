@@ -506,9 +506,10 @@ def handoff_switch():
         st.zero_()
 
 
-@pytest.mark.parametrize('agent,site', [('ma2c_nc', 'step'), ('ma2c_nc', 'bptt'), ('ma2c_ic3', 'step')])
+@pytest.mark.parametrize('agent,site,scenario', [('ma2c_nc', 'step', 'slowdown'), ('ma2c_nc', 'bptt', 'slowdown'), ('ma2c_ic3', 'step', 'slowdown'),
+                                                 ('ma2c_ic3', 'step', 'grid')])
 @pytest.mark.parametrize('use_graph', [False, True])
-def test_handoff_timeout_fails_closed(agent, site, use_graph, handoff_switch, monkeypatch):
+def test_handoff_timeout_fails_closed(agent, site, scenario, use_graph, handoff_switch, monkeypatch):
     """An in-launch hand-off whose neighbour block never shows up (injected: block 0 of one launch publishes nothing, 4096
     spins) must fail CLOSED, and without the host looking at the device between batches: the poisoned batch and the batch
     launched behind it change no weight, no optimiser slot, no episode statistic and hand nothing over (the guarded RMSProp
@@ -516,26 +517,27 @@ def test_handoff_timeout_fails_closed(agent, site, use_graph, handoff_switch, mo
     one batch LATE (pinned non-blocking copy of the status word), rewinds, pins the launch-per-step kernels and re-runs both
     batches -- after them weights, optimiser slots, env state, actions, returns, lr schedule and counters equal, bit for bit,
     those of a run that never used the one-launch kernels.  site: the fault hits the lock-step kernel of the rollout's first
-    step / the coupled BPTT launch of the update.  use_graph: the fault is armed for an eager first batch either way (the
+    step / the coupled BPTT launch of the update.  scenario 'grid': the launch also steps the env (GENV role) -- block 0's
+    actions never arrive either, the env blocks of its 128 replicas time out as well, and the recovery clears their words.  use_graph: the fault is armed for an eager first batch either way (the
     fault flag is a launch argument), the second batch is a graph replay or eager."""
     from deeprl_network_amd import _lib, ops
     from deeprl_network_amd.utils import BatchedTrainer, Counter
     E, T = 256, 10
     # reference: launch-per-step kernels from the start
     monkeypatch.setenv('NMARL_INKERNEL_HANDOFF', '0')
-    env, model, tr = build(agent, E, False, scenario='slowdown', n_step=T)
+    env, model, tr = build(agent, E, False, scenario=scenario, n_step=T)
     assert not tr.handoff_guard
     for _ in range(3):
         tr.run_batch()
     torch.cuda.synchronize()
-    ref = (model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.h.clone(), model.buf_act.clone(), tr.R_end.clone(),
+    ref = (model.policy.params.flat.clone(), model.policy.params.ms.clone(), env.state_tensors()[0].clone(), model.buf_act.clone(), tr.R_end.clone(),
            tr.ep_sum.clone(), model.h_bw.clone(), model.buf_x[0].clone(), model.lr_scheduler.n)
     del env, model, tr
     monkeypatch.delenv('NMARL_INKERNEL_HANDOFF')
-    env, model, tr = build(agent, E, use_graph, scenario='slowdown', n_step=T)
+    env, model, tr = build(agent, E, use_graph, scenario=scenario, n_step=T)
     tr.global_counter = Counter(10 ** 12, 10 ** 12, 10 ** 12)
     model.policy.refresh_wimage()              # (the message image decides whether the one-launch step exists)
-    assert tr.handoff_guard and model.policy.pv_one_launch(E)
+    assert tr.handoff_guard and model.policy.pv_one_launch(E) and tr.env_in_kernel == (scenario == 'grid')
     w0, ms0 = model.policy.params.flat.clone(), model.policy.params.ms.clone()
     seen = {}
     orig = BatchedTrainer._recover_from_handoff_timeout
@@ -557,6 +559,7 @@ def test_handoff_timeout_fails_closed(agent, site, use_graph, handoff_switch, mo
     assert tr.handoff_fallbacks == 0 and not seen, 'the host looked at the status word of the batch it had just launched'
     tr.run_batch()                             # launched behind the poisoned one; its probe finds the word raised
     assert tr.handoff_fallbacks == 1 and not ops.handoff_enabled() and not model.policy.pv_one_launch(E) and not tr.handoff_guard
+    assert not tr.env_in_kernel and (scenario != 'grid' or int(env._words.abs().max()) == 0)
     assert seen['batches'] == 2 and seen['skipped'] == skipped0 + 2
     assert torch.equal(seen['w'], w0) and torch.equal(seen['ms'], ms0), 'a refused batch reached the weights'
     assert float(seen['ep_len'].abs().max()) == 0.0 and bool((seen['done_pre'] == 1).all()), 'a refused batch was handed over'
@@ -565,7 +568,7 @@ def test_handoff_timeout_fails_closed(agent, site, use_graph, handoff_switch, mo
     tr.flush()
     torch.cuda.synchronize()
     ops.check_coupled_status()
-    got = (model.policy.params.flat, model.policy.params.ms, env.h, model.buf_act, tr.R_end, tr.ep_sum, model.h_bw, model.buf_x[0],
+    got = (model.policy.params.flat, model.policy.params.ms, env.state_tensors()[0], model.buf_act, tr.R_end, tr.ep_sum, model.h_bw, model.buf_x[0],
            model.lr_scheduler.n)
     for name, a, b in zip(('weights', 'rmsprop slots', 'env state', 'actions', 'R_end', 'episode sums', 'h_bw', 'x_0'), got, ref):
         assert torch.equal(a, b), '%s differ from the launch-per-step run' % name

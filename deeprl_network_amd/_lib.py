@@ -63,7 +63,9 @@ class Msg(C.Structure):
                 ('out2', C.c_void_p), ('out2_sn', C.c_int64), ('out2_row', C.c_int64),
                 ('next_img', C.c_void_p), ('next_img_sn', C.c_int64), ('next_b', C.c_void_p), ('next_b_sn', C.c_int64),
                 ('next_out', C.c_void_p), ('next_out_sn', C.c_int64),
-                ('mean_out', C.c_void_p), ('mean_out_sn', C.c_int64), ('mean_out_row', C.c_int64)]
+                ('mean_out', C.c_void_p), ('mean_out_sn', C.c_int64), ('mean_out_row', C.c_int64),
+                ('carry_in', C.c_void_p), ('carry_in_sn', C.c_int64), ('carry_out', C.c_void_p), ('carry_out_sn', C.c_int64),
+                ('mean_next', C.c_void_p), ('mean_next_sn', C.c_int64), ('mean_next_row', C.c_int64)]
 
 
 class StepEnc(C.Structure):

@@ -326,7 +326,8 @@ class IA2C:
             p.step_policy_value(enc, self.H_all[:, t], self.C_all[:, t], done, self.buf_fp[t + 1], self.buf_act[t],
                                 self.buf_vn[:, t], h_out=self.H_all[:, t + 1], c_out=self.C_all[:, t + 1],
                                 gates=self.G_buf[:, t], defer_action_term=True,
-                                **(dict(save=self._save_slots(t), ob=ob) if p.coupled else (dict(ob=ob) if ob is not None else {})),
+                                **(dict(save=self._save_slots(t), ob=ob, carry=self._msg_carry(t)) if p.coupled else
+                                   (dict(ob=ob) if ob is not None else {})),
                                 **draw)
             return self.buf_act[t]
         if self.save_acts:
@@ -345,6 +346,28 @@ class IA2C:
                       done_is_zero, **draw)
         p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, self.buf_act[t], self.buf_v[t], done_is_zero)
         return self.buf_act[t]
+
+    _carry_buf = None
+    _carry_holds = -1          # the lock-step whose policy-step message term `_carry_buf` holds (written by the re-step of the one before)
+
+    def _msg_carry(self, t):
+        """Coupled nets, one-launch lock-step t (t = n_step: the bootstrap step): the re-step's message term -- computed from the
+        neighbours' new, un-masked h (quirk Q3) -- IS lock-step t + 1's policy-step message term, so launch t leaves it in
+        `_carry_buf` (and CommNet's mean rows in slot t + 1 of the saved means) and launch t + 1 starts from it: no neighbour rows,
+        no product in front of its K loop.  Lock-step 0 computes its own (the batch boundary reset finished replicas' states)."""
+        p = self.policy
+        if not p.coupled or getattr(p, 'msg_kind', 0) not in (ops.MSG_GATHER_RELU, ops.MSG_MEAN_ADD) or \
+                os.environ.get('NMARL_MSG_CARRY', '1') == '0':
+            return None
+        if self._carry_buf is None:
+            self._carry_buf = torch.zeros(self.n_agent, self.E, self.n_lstm, dtype=F32, device=self.device)
+        d = dict(carry_in=self._carry_buf if (t > 0 and self._carry_holds == t) else None,
+                 carry_out=self._carry_buf if t < self.n_step else None)
+        mm = getattr(p, '_extra_full', {}).get('MM')
+        if mm is not None and t + 1 < self.n_step and p.msg_kind == ops.MSG_MEAN_ADD:
+            d['mean_next'] = mm[:, t + 1]
+        self._carry_holds = t + 1 if t < self.n_step else -1
+        return d
 
     S_bits = None
 
@@ -406,7 +429,8 @@ class IA2C:
             T = self.n_step
             p.step_policy_value(enc, self.H_all[:, T], self.C_all[:, T], done, self._pi_boot, action_scratch, self._v_boot,
                                 h_out=self.h_fw, c_out=self.c_fw, mode=mode, u=u, seed=seed, env_id_base=env_id_base,
-                                step=step, step_dev=step_dev, **(dict(ob=ob) if ob is not None else {}))
+                                step=step, step_dev=step_dev, **(dict(ob=ob) if ob is not None else {}),
+                                **(dict(carry=self._msg_carry(T)) if p.coupled else {}))
             return self._v_boot
         if self.save_acts:
             T = self.n_step

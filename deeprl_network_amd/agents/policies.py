@@ -462,16 +462,20 @@ class BatchedPolicy:
         return True
 
     def step_policy_value(self, enc, h, c, done, pi_out, act_out, v_out, h_out=None, c_out=None, gates=None,
-                          defer_action_term=False, save=None, ob=None, **draw):
+                          defer_action_term=False, save=None, ob=None, carry=None, **draw):
         """Both halves of a lock-step decision (Trainer._get_policy + _get_value, utils.py:129-149) in one kernel:
         advances (h, c) by the policy step -- in place, or into (h_out, c_out) with the gates saved for the update --;
         the value comes from the re-stepped copy (quirk Q1).  Coupled nets (`pv_one_launch`): never in place; `save`
         as in step_policy (the POLICY step's message term is what the update needs).  ob (`encodes_in_step` nets): the env's
-        compact observation [E,N,F] of this lock-step -- `enc` is then the slot the kernel WRITES the encoder's output to."""
+        compact observation [E,N,F] of this lock-step -- `enc` is then the slot the kernel WRITES the encoder's output to.
+        carry (coupled nets, one launch): dict(carry_in, carry_out[, mean_next]) -- the re-step's message term is the next lock-step's
+        policy-step message term (the neighbours' un-masked new h, Q3); see include/nmarl.h nmarl_msg_t."""
         with torch.no_grad():
             if self.coupled:
                 z1, z2, xs = self._recur_addends(enc, h, save=save, fuse_msg=True)
                 xs[4]['sync'] = self._sync_words(h.shape[1])
+                if carry:
+                    xs[4].update(carry)
                 if isinstance(ob, dict) and 'genv' in ob:      # lstm_ic3 on the grid: observation encoder AND env step inside the launch
                     xs[4]['ob'], xs[4]['genv'] = self._ob_spec(ob['x']), ob['genv']
                 elif isinstance(ob, dict):       # lstm_comm: both input encoders (and the env step) inside the launch, see `enc_in_kernel`

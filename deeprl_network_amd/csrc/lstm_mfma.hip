@@ -514,6 +514,12 @@ struct XArgs {
     const float* msg_b; int64_t msg_b_sn;         // [N, 64]
     const float* enc; int64_t enc_sn, enc_row;    // MSG 2: the additive h-independent part of the input [N,E,64]
     float* xm_out; int64_t xm_sn, xm_row;         // where the computed 64 columns are kept (may be NULL)
+    // HEAD 4 (round 6): the re-step's message term IS the next lock-step's policy-step message term (same neighbours' h, Q3: un-masked)
+    // -- carry_out [N][E][64] receives it (before enc is added), carry_in hands the previous launch's over: no neighbour rows, no
+    // product in front of the K loop.  mm_next: MSG 2, the re-step's mean rows = the next lock-step's mm_out.  All may be NULL.
+    const float* carry_in; int64_t carry_in_sn;
+    float* carry_out; int64_t carry_out_sn;
+    float* mm_next; int64_t mm_next_sn, mm_next_row;
     float* mm_out; int64_t mm_sn, mm_row;         // MSG 2, may be NULL: where the policy step's mean_j(h_j) rows are kept (the update's
                                                   // message-weight gradient is mean(h)^T D1: no averaging pass over the h sequence there)
     const float* src; int64_t src_sn;             // MSG 3: the senders' message vectors [N,E,64] the pre-phase gathers (instead of h)
@@ -641,7 +647,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, cons
 // + {0..3}, mt = 2 ch + jj).  No cross-lane movement at all: the 32 values per lane are parked in a lane-private LDS slot
 // (the register file is full: 254 VGPRs) over the not-yet-used h' tile, and written once to the saved activations.
 // Two chunk buffers instead of three (no de-phased wave groups: measured +-0 in round 2) make the room.
-template <int HEAD, int MSG, int ENC = 0>
+// CARRY (HEAD 4, round 6): 0 none; 1 the re-step hands its message term on (carry_out / mm_next); 2 it also STARTS from the one the
+// previous launch handed on (carry_in): no neighbour rows, no product in front of the K loop.  A template parameter, not a launch
+// argument: at 256 registers a run-time choice cost every form of the kernel ~4 us (profiles/r06_ab_msg_carry.txt).
+template <int HEAD, int MSG, int ENC = 0, int CARRY = 0>
 __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const FusedArgs& a = xa.f;
@@ -852,71 +861,12 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         __builtin_amdgcn_sched_barrier(0);
         NMARL_STAMP(36)
     }
-    NMARL_STAMP(41)
-    NMARL_STAGE_STORE(0)
-    NMARL_STAMP(42)
-
-    // ---- accumulators <- bias (+ zadd1 + zadd2);  C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
     int64_t rofs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int64_t row = row0 + 4 * grp + r;
         rofs[r] = row < a.E ? row : a.E - 1;
     }
-    f32x4 acc[16];
-    float4 b4s[4];
-    {
-        const float* bn = a.bias + (int64_t)n * a.bias_sn;
-        const float* z1 = MSG == 0 && a.zadd1 ? a.zadd1 + (int64_t)n * a.zadd1_sn : nullptr;
-        const float* z2 = MSG == 0 && a.zadd2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
-        // column tile t = 4 gate + jj holds, for lane column c, UNIT 4 c + jj of that gate (the image permutes W's columns
-        // accordingly): a lane's four jj values are four consecutive floats of a row -- inputs come in and results leave as
-        // 16-byte accesses straight from / to the C/D layout, no LDS staging
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) b4s[g4] = *reinterpret_cast<const float4*>(bn + g4 * H + 4 * c);
-        // (message kernels: the 64 accumulators are filled from these 16 registers only after the pre-phases -- the
-        // pre-phases' operands are requested up front and need the room; they take no addends)
-        if (MSG == 0) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[4 * g4 + 0][r] = b4s[g4].x; acc[4 * g4 + 1][r] = b4s[g4].y; acc[4 * g4 + 2][r] = b4s[g4].z; acc[4 * g4 + 3][r] = b4s[g4].w;
-                }
-        }
-        if (z1) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(z1 + rofs[r] * G4 + g4 * H + 4 * c);
-                    acc[4 * g4 + 0][r] += v4.x; acc[4 * g4 + 1][r] += v4.y; acc[4 * g4 + 2][r] += v4.z; acc[4 * g4 + 3][r] += v4.w;
-                }
-        }
-        if (z2) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(z2 + rofs[r] * G4 + g4 * H + 4 * c);
-                    acc[4 * g4 + 0][r] += v4.x; acc[4 * g4 + 1][r] += v4.y; acc[4 * g4 + 2][r] += v4.z; acc[4 * g4 + 3][r] += v4.w;
-                }
-        }
-    }
-    float cp[4][4];
-    {
-        const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float4 v4 = *reinterpret_cast<const float4*>(cpn + rofs[r] * H + 4 * c);
-            cp[0][r] = v4.x; cp[1][r] = v4.y; cp[2][r] = v4.z; cp[3][r] = v4.w;
-        }
-    }
-    {
-        float4* d_ = reinterpret_cast<float4*>(lds + CH_FLOATS) + threadIdx.x;
-        d_[0] = tg0; d_[512] = tg1; d_[1024] = tg2; d_[1536] = tg3; d_[2048] = tg4;
-    }
-    NMARL_STAMP(43)
     // (chunk 2 is requested at the END of the prologue: vector loads return in order, so asked for here its 40 KB would sit in front
     // of every operand the pre-phases wait for -- it is first needed behind tick 0's barrier, a whole pre-phase + tick away)
     float* m_lds = hw_lds + HW_FLOATS;                               // W_msg image: msg_kc * 32 * 64 floats
@@ -999,8 +949,20 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     float PW[4];
     using K0 = std::integral_constant<int, 0>;
     using K4 = std::integral_constant<int, 4>;
-    if (MSG != 0) msg_load(std::false_type{}, K0{}, PU, PW);
+    static_assert(CARRY == 0 || (HEAD == 4 && (MSG == 1 || MSG == 2)), "the message carry exists between one-launch lock-steps");
+    constexpr bool carried = CARRY == 2;                             // the previous launch's re-step computed this message term
+    if (MSG != 0) {
+        if (carried) {                      // the lane's four rows of it (C layout), nothing else
+            const float* ci = xa.carry_in + (int64_t)n * xa.carry_in_sn + 4 * c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) PU[r] = *reinterpret_cast<const float4*>(ci + rofs[r] * H);
+            PW[0] = PW[1] = PW[2] = PW[3] = 0.0f;
+        } else {
+            msg_load(std::false_type{}, K0{}, PU, PW);
+        }
+    }
     float4 ea[OBENC ? 4 : 1];
+    float eaw[OBENC ? 4 : 1];
     if (OBENC) {
         // unconditional loads (a valid dummy row when the encoder does not run): input k = F slot + f, four features of one slot
         const float* obr = ob_here ? xa.ob + arow * xa.ob_row : hrow;
@@ -1015,12 +977,69 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) j = seg == k + 1 ? nbj[k] : j;
             const bool ok = seg < segs && (seg == 0 || seg - 1 < xa.m_max) && j >= 0;
-            const float w = ok ? 1.0f : 0.0f;
-            float4 v = *reinterpret_cast<const float4*>(obr + (ok ? j * F + f : 0));
-            v.x *= w; v.y *= w; v.z *= w; v.w *= w;
-            ea[q] = v;
+            eaw[q] = ok ? 1.0f : 0.0f;           // (applied behind the barrier: a multiply here would wait for every load above)
+            ea[q] = *reinterpret_cast<const float4*>(obr + (ok ? j * F + f : 0));
         }
     }
+    NMARL_STAMP(41)
+    NMARL_STAGE_STORE(0)
+    NMARL_STAMP(42)
+
+    // ---- accumulators <- bias (+ zadd1 + zadd2);  C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg
+    f32x4 acc[16];
+    float4 b4s[4];
+    {
+        const float* bn = a.bias + (int64_t)n * a.bias_sn;
+        const float* z1 = MSG == 0 && a.zadd1 ? a.zadd1 + (int64_t)n * a.zadd1_sn : nullptr;
+        const float* z2 = MSG == 0 && a.zadd2 ? a.zadd2 + (int64_t)n * a.zadd2_sn : nullptr;
+        // column tile t = 4 gate + jj holds, for lane column c, UNIT 4 c + jj of that gate (the image permutes W's columns
+        // accordingly): a lane's four jj values are four consecutive floats of a row -- inputs come in and results leave as
+        // 16-byte accesses straight from / to the C/D layout, no LDS staging
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) b4s[g4] = *reinterpret_cast<const float4*>(bn + g4 * H + 4 * c);
+        // (message kernels: the 64 accumulators are filled from these 16 registers only after the pre-phases -- the
+        // pre-phases' operands are requested up front and need the room; they take no addends)
+        if (MSG == 0) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[4 * g4 + 0][r] = b4s[g4].x; acc[4 * g4 + 1][r] = b4s[g4].y; acc[4 * g4 + 2][r] = b4s[g4].z; acc[4 * g4 + 3][r] = b4s[g4].w;
+                }
+        }
+        if (z1) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(z1 + rofs[r] * G4 + g4 * H + 4 * c);
+                    acc[4 * g4 + 0][r] += v4.x; acc[4 * g4 + 1][r] += v4.y; acc[4 * g4 + 2][r] += v4.z; acc[4 * g4 + 3][r] += v4.w;
+                }
+        }
+        if (z2) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(z2 + rofs[r] * G4 + g4 * H + 4 * c);
+                    acc[4 * g4 + 0][r] += v4.x; acc[4 * g4 + 1][r] += v4.y; acc[4 * g4 + 2][r] += v4.z; acc[4 * g4 + 3][r] += v4.w;
+                }
+        }
+    }
+    float cp[4][4];
+    {
+        const float* cpn = a.c_prev + (int64_t)n * a.c_prev_sn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 v4 = *reinterpret_cast<const float4*>(cpn + rofs[r] * H + 4 * c);
+            cp[0][r] = v4.x; cp[1][r] = v4.y; cp[2][r] = v4.z; cp[3][r] = v4.w;
+        }
+    }
+    {
+        float4* d_ = reinterpret_cast<float4*>(lds + CH_FLOATS) + threadIdx.x;
+        d_[0] = tg0; d_[512] = tg1; d_[1024] = tg2; d_[1536] = tg3; d_[2048] = tg4;
+    }
+    NMARL_STAMP(43)
     NMARL_STAMP(45)
     if (MSG != 0) {
         float4* d = reinterpret_cast<float4*>(m_lds);
@@ -1133,6 +1152,8 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
         f32x4 eacc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) eacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ea[q].x *= eaw[q]; ea[q].y *= eaw[q]; ea[q].z *= eaw[q]; ea[q].w *= eaw[q]; }
         NMARL_MCHUNK(eacc, o_lds, 0, ea[0], ea[1])
         NMARL_MCHUNK(eacc, o_lds, 1, ea[2], ea[3])
         const float4 bo = bo4;
@@ -1151,10 +1172,12 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
     int grp_w = grp;                        // (the lane's row group as the tile WRITES address it: see CP_PARK behind the K loop)
     auto msg_phase = [&](auto second_c, float4 (&U)[16], float (&W)[4]) {
         constexpr bool SECOND = decltype(second_c)::value;
+        constexpr bool reuse = !SECOND && carried;      // U[0..3] = the finished term of the lane's four rows
         f32x4 macc[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) macc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (MSG != 2) {                     // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
+        if (reuse) {
+        } else if (MSG != 2) {              // chunk kc = half (kc & 1) of neighbour slot (kc >> 1), K_m = 64 m_max <= 128
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) {
                 if (kc < xa.msg_kc) {
@@ -1195,6 +1218,13 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
                     *reinterpret_cast<float4*>(mo) = m0;
                     *reinterpret_cast<float4*>(mo + 16) = m1;
                 }
+                if (SECOND && CARRY != 0 && xa.mm_next) {          // = the next lock-step's mm_out rows (uniform base + 32-bit offsets: no address registers;
+                    // rows past E fall outside the resource and are dropped)
+                    const __amdgpu_buffer_rsrc_t rm_ = make_rsrc(xa.mm_next + (int64_t)n * xa.mm_next_sn, (uint32_t)(a.E * xa.mm_next_row * 4));
+                    const uint32_t mo = row0 + c < a.E ? (uint32_t)(((row0 + c) * xa.mm_next_row + kc * CH_K + 4 * grp) * 4) : 0xfffffff0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, m0), rm_, mo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, m1), rm_, mo, 64, 0);
+                }
                 NMARL_MCHUNK(macc, m_lds, kc, m0, m1)
             }
         }
@@ -1210,11 +1240,23 @@ __global__ __launch_bounds__(512, 1) void lstm_step_x_kernel(const XArgs xa) {
             if (MSG != 2) {
                 v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
             }
+            if (reuse) v = U[r];
+            if (SECOND && CARRY != 0 && xa.carry_out)          // (rows past E fall outside the resource and are dropped)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), make_rsrc(xa.carry_out + (int64_t)n * xa.carry_out_sn, (uint32_t)(a.E * (H * 4))),
+                                                       (uint32_t)(((row0 + 4 * grp + r) * H + 4 * c) * 4), 0, 0);
             if (MSG == 3 && xo2 && row0 + 4 * grp + r < a.E)
                 *reinterpret_cast<float4*>(xo2 + (row0 + 4 * grp + r) * xa.xm2_row + 4 * c) = v;
             if (MSG != 1) {
-                float4 e4 = *reinterpret_cast<const float4*>(encn + rofs[r] * xa.enc_row + 4 * c);
-                if (OBENC && !SECOND && ob_here) e4 = encv[r];       // computed above (no dependence on the store just issued)
+                float4 e4;
+                if (OBENC && !SECOND && ob_here) {      // computed above: NOT re-read (the re-read was a memory round trip in front of the K loop
+                    e4 = encv[r];                       // whose value was then thrown away -- round 6, tools/step_timeline.py 4 grid)
+                } else if (HEAD == 4) {    // uniform base + a 32-bit offset made here: no row-address registers live across the launch (rofs dies early)
+                    const uint32_t rr_ = row0 + 4 * grp + r < a.E ? (uint32_t)(row0 + 4 * grp + r) : (uint32_t)(a.E - 1);
+                    e4 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(encn, (uint32_t)(a.E * xa.enc_row * 4)),
+                                                                                         (rr_ * (uint32_t)xa.enc_row + 4 * c) * 4, 0, 0));
+                } else {
+                    e4 = *reinterpret_cast<const float4*>(encn + rofs[r] * xa.enc_row + 4 * c);
+                }
                 v.x += e4.x; v.y += e4.y; v.z += e4.z; v.w += e4.w;
             }
             float* t_ = a_tile + (4 * grp_w + r) * APITCH + 4 * c;
@@ -1898,6 +1940,16 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
                 return NMARL_EINVAL;
             xa.mm_out = msg->mean_out; xa.mm_sn = msg->mean_out_sn; xa.mm_row = msg->mean_out_row;
         }
+        if (msg->carry_in || msg->carry_out || msg->mean_next) {
+            const int kd = head ? head->kind : 0;
+            if (kd != 3 || mk == 3 || (msg->carry_in && (msg->carry_in_sn < E * (int64_t)H || (msg->carry_in_sn % 4) || ((uintptr_t)msg->carry_in % 16))) ||
+                (msg->carry_out && (msg->carry_out_sn < E * (int64_t)H || (msg->carry_out_sn % 4) || ((uintptr_t)msg->carry_out % 16))) ||
+                (msg->mean_next && (mk != 2 || msg->mean_next_row < H || msg->mean_next_sn < E * msg->mean_next_row || ((uintptr_t)msg->mean_next % 16) ||
+                                    (msg->mean_next_row % 4) || (msg->mean_next_sn % 4))))
+                return NMARL_EINVAL;
+            xa.carry_in = msg->carry_in; xa.carry_in_sn = msg->carry_in_sn; xa.carry_out = msg->carry_out; xa.carry_out_sn = msg->carry_out_sn;
+            xa.mm_next = msg->mean_next; xa.mm_next_sn = msg->mean_next_sn; xa.mm_next_row = msg->mean_next_row;
+        }
         if (mk == 3) {
             xa.src = msg->src; xa.src_sn = msg->src_sn; xa.xm2_out = msg->out2; xa.xm2_sn = msg->out2_sn; xa.xm2_row = msg->out2_row;
             if (msg->next_out) {
@@ -1923,6 +1975,8 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         NMARL_SET_LDS((lstm_step_x_kernel<1, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 2>))
         NMARL_SET_LDS((lstm_step_x_kernel<1, 3>)) NMARL_SET_LDS((lstm_step_x_kernel<2, 3>))
         NMARL_SET_LDS((lstm_step_x_kernel<4, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 1, 1>))
+        NMARL_SET_LDS((lstm_step_x_kernel<4, 1, 0, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2, 0, 1>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 1, 1, 1>))
+        NMARL_SET_LDS((lstm_step_x_kernel<4, 1, 0, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 2, 0, 2>)) NMARL_SET_LDS((lstm_step_x_kernel<4, 1, 1, 2>))
 #undef NMARL_SET_LDS
         lds_once.done(lds_bit);
     }
@@ -1994,7 +2048,7 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
         const int cap = nmarl_handoff_capacity(1, msg->K);
         if (cap < 0) return NMARL_EHIP;
         if (!msg->sync || ((uintptr_t)msg->sync % 4) || ((uintptr_t)msg->status % 4) || (int)grid.x > cap ||
-            E * (int64_t)(H * 4) >= (int64_t)1 << 32 || (mk == 2 && KX != H))
+            E * (int64_t)(H * 4) >= (int64_t)1 << 32 || (mk == 2 && (KX != H || E * msg->enc_row * 4 >= (int64_t)1 << 32)))
             return NMARL_EINVAL;
         xa.sync = msg->sync;
         xa.status = msg->status;
@@ -2046,18 +2100,25 @@ static int launch_step_x(int64_t E, int32_t N, int32_t Hh, int32_t KX, const flo
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (mk == 1 && kind == 3) lb_extra += 512 * sizeof(float4);      // HEAD 4 / MSG 1: the parked cell-state slots (CP_PARK)
 #define NMARL_LX(HD, MS) hipLaunchKernelGGL((lstm_step_x_kernel<HD, MS>), grid, dim3(512), lb + lb_extra, st, xa)
+    // the one-launch lock-steps: by what the caller hands on between them (nmarl_msg_t carry_in / carry_out / mean_next)
+    const int carry = !msg ? 0 : msg->carry_in ? 2 : (msg->carry_out || msg->mean_next) ? 1 : 0;
+#define NMARL_LC(MS, EN)                                                                                                         \
+    if (carry == 2) hipLaunchKernelGGL((lstm_step_x_kernel<4, MS, EN, 2>), grid, dim3(512), lb + lb_extra, st, xa);              \
+    else if (carry == 1) hipLaunchKernelGGL((lstm_step_x_kernel<4, MS, EN, 1>), grid, dim3(512), lb + lb_extra, st, xa);         \
+    else hipLaunchKernelGGL((lstm_step_x_kernel<4, MS, EN, 0>), grid, dim3(512), lb + lb_extra, st, xa);
     if (mk == 0) {
         if (kind == 0) NMARL_LX(0, 0); else if (kind == 1) NMARL_LX(1, 0); else if (kind == 2) NMARL_LX(2, 0); else NMARL_LX(3, 0);
     } else if (mk == 1) {
         if (kind == 1) NMARL_LX(1, 1); else if (kind == 2) NMARL_LX(2, 1);
-        else if (enc) hipLaunchKernelGGL((lstm_step_x_kernel<4, 1, 1>), grid, dim3(512), lb + lb_extra, st, xa);
-        else NMARL_LX(4, 1);
+        else if (enc) { NMARL_LC(1, 1) }
+        else { NMARL_LC(1, 0) }
     } else if (mk == 2) {
-        if (kind == 1) NMARL_LX(1, 2); else if (kind == 2) NMARL_LX(2, 2); else NMARL_LX(4, 2);
+        if (kind == 1) NMARL_LX(1, 2); else if (kind == 2) NMARL_LX(2, 2); else { NMARL_LC(2, 0) }
     } else {
         if (kind == 1) NMARL_LX(1, 3); else NMARL_LX(2, 3);
     }
 #undef NMARL_LX
+#undef NMARL_LC
     return nmarl_check_launch();
 }
 

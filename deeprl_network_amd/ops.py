@@ -283,6 +283,15 @@ def _step_x(h, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out, xs, head, 
             m.out, m.out_sn, m.out_row = _rows_view(msg['out'], H, what + ' msg out')
         if msg.get('mean_out') is not None:            # lstm_ic3, policy step: keep mean_j(h_j) for the update's message-weight gradient
             m.mean_out, m.mean_out_sn, m.mean_out_row = _rows_view(msg['mean_out'], H, what + ' msg mean_out')
+        for key in ('carry_in', 'carry_out'):          # one-launch lock-steps: the re-step's message term handed to the next lock-step
+            cb = msg.get(key)
+            if cb is not None:
+                if cb.shape != (N, E, H) or cb.stride(2) != 1 or cb.stride(1) != H:
+                    raise _lib.NmarlError('%s: msg["%s"] must be [N,E,64] with contiguous panels' % (what, key))
+                setattr(m, key, ptr(cb, F32, strided=True))
+                setattr(m, key + '_sn', cb.stride(0))
+        if msg.get('mean_next') is not None:
+            m.mean_next, m.mean_next_sn, m.mean_next_row = _rows_view(msg['mean_next'], H, what + ' msg mean_next')
         if msg['kind'] == MSG_DIAL:
             src = msg['src']
             if src.shape != (N, E, H) or src.stride(2) != 1 or src.stride(1) != H:

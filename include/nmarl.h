@@ -441,6 +441,16 @@ typedef struct nmarl_msg {
     float* next_out; int64_t next_out_sn;           /* kind 3, head 1, may be NULL: relu(h_new @ w_mfc + b_mfc) */
     float* mean_out; int64_t mean_out_sn, mean_out_row;   /* kind 2, may be NULL: the policy step's mean_j(h_j) rows ([N,E,64] view), the
                                                            * input of the message layer -- its weight gradient is mean(h)^T d1 */
+    /* head kind 3, kinds 1 / 2 (round 6): the value re-step's message term -- from the neighbours' NEW, un-masked h (quirk Q3) -- IS
+     * the message term of the NEXT lock-step's policy step (utils.py:129-149 called again at t + 1 on the states t left).  carry_out
+     * [N,E,64] (rows contiguous, may be NULL) receives it (kind 1: relu(m W + b); kind 2: mean W + b, before enc is added); carry_in
+     * (may be NULL: compute it) hands the previous launch's over, and the launch then reads no neighbour row and multiplies nothing in
+     * front of its K loop; mean_out is not written then -- mean_next (kind 2, may be NULL; layout as mean_out) of the previous launch
+     * was.  carry_in may be carry_out (a row is read and written by the same lane).  The caller computes (carry_in = NULL) whenever
+     * the states were changed between the two launches (a batch boundary's reset of finished replicas). */
+    const float* carry_in; int64_t carry_in_sn;
+    float* carry_out; int64_t carry_out_sn;
+    float* mean_next; int64_t mean_next_sn, mean_next_row;
 } nmarl_msg_t;
 /*
  * The input encoders of a lock-step INSIDE the policy + value launch (head kind 3, no message term; round 5): IA2C-FP on

@@ -301,6 +301,49 @@ def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, agent, scenar
 
 
 @pytest.mark.parametrize('use_graph', [True, False])
+@pytest.mark.parametrize('agent,scenario,E', [('ma2c_nc', 'slowdown', 4096), ('ma2c_nc', 'catchup', 1000), ('ma2c_ic3', 'slowdown', 77),
+                                              ('ma2c_ic3', 'grid', 1024), ('ma2c_ic3', 'grid', 1000)])
+def test_message_term_handed_from_the_re_step_to_the_next_lock_step(agent, scenario, E, use_graph, monkeypatch):
+    """Coupled nets, one launch per lock-step (round 6): the value re-step of lock-step t computes its message term from the
+    neighbours' new, un-masked h (quirk Q3, agents/utils.py:182-199 / 395-400) -- which is exactly the policy step's message term of
+    lock-step t + 1 (utils.py:129-149 called again on the states t left).  The launch hands it on (and CommNet's mean rows, the
+    update's message-weight-gradient input) instead of the next launch recomputing it: kernels <4,.,.,1> (t = 0) and <4,.,.,2>
+    (t >= 1, bootstrap) against <4,.,.,0> everywhere -- EVERYTHING bit-identical after 3 batches: actions, values, saved LSTM
+    inputs / means (through the weights the update makes of them), env state, weights, optimiser slots."""
+    out = []
+    for carry in ('1', '0'):
+        monkeypatch.setenv('NMARL_MSG_CARRY', carry)
+        env, model, tr = build(agent, E, use_graph, scenario=scenario, n_step=20)
+        assert model.policy.pv_one_launch(E)
+        calls = {'in': 0, 'out': 0}
+        orig = type(model)._msg_carry
+
+        def spy(self, t, orig=orig, calls=calls):
+            d = orig(self, t)
+            if d:
+                calls['in'] += d.get('carry_in') is not None
+                calls['out'] += d.get('carry_out') is not None
+            return d
+        monkeypatch.setattr(type(model), '_msg_carry', spy)
+        rec = []
+        for _ in range(3):
+            tr.run_batch()
+            rec += [model.buf_act.clone(), model.buf_vn.clone(), model.S_buf.clone()] + [v.clone() for v in model.policy._extra_full.values()]
+        tr.flush()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(type(model), '_msg_carry', orig)
+        assert tr.handoff_fallbacks == 0
+        # (hipGraph: Python runs for the warm-up and the capture only; eager: every batch) lock-steps 1..20 start from a carried term
+        assert (calls['in'] > 0 and calls['in'] % 20 == 0 and calls['out'] == calls['in']) if carry == '1' else calls['in'] == calls['out'] == 0
+        if 'MM' in model.policy._extra_full:
+            assert float(model.policy._extra_full['MM'][:, -1].abs().max()) == 0.0       # the padding slab stays zero
+        out.append(rec + [t.clone() for t in env.state_tensors()] + [model.policy.params.flat.clone(), model.policy.params.ms.clone(), tr.R_end.clone()])
+        del env, model, tr
+    for k, (a, b) in enumerate(zip(*out)):
+        assert torch.equal(a, b), 'item %d differs between the carried and the recomputed message term' % k
+
+
+@pytest.mark.parametrize('use_graph', [True, False])
 @pytest.mark.parametrize('E', [1024, 1000, 77, 7000])
 def test_grid_env_step_as_a_role_of_the_lock_step_launch_is_the_env_kernel(E, use_graph, monkeypatch):
     """BASELINE configs[3] (synthetic 5 x 5 grid, CommNet): the env step run by extra blocks of the one-launch lock-step

@@ -83,6 +83,12 @@ elif head == 4:
     msg = dict(kind=1, nbr_idx=nbr4, w_msg=w_msg, b_msg=b_msg, img=mimg, out=slot[:, :, 2 * H:], sync=sync)
 
 
+if head == 4 and 'carry' in sys.argv:         # the message term handed over from the previous launch's re-step (kernel<4,.,.,2>)
+    carry_buf = torch.zeros(N, E, H, device='cuda')
+    msg.update(carry_in=carry_buf, carry_out=carry_buf)
+    if GRID:
+        msg['mean_next'] = torch.zeros(N, E, H, device='cuda')
+
 if ENC:
     nbrs = [[j for j in (i - 1, i + 1) if 0 <= j < N] for i in range(N)]
     enc_spec = ops.step_enc_spec(r(E, N, 5), torch.softmax(r(N, E, A), -1), r(N, 15, H) * 0.3, r(N, H) * 0.1, r(N, 8, H) * 0.3, r(N, H) * 0.1,

@@ -208,6 +208,8 @@ SIGNATURES = {
     'nmarl_lstm_bptt_seq_blocks': [_i64],
     'nmarl_lstm_bptt_seq': [_i32, _i64, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64,
                             _p, _i64, _p, _i64, _p, _i64, _p],
+    'nmarl_lstm_bptt_seq_dy': [_i32, _i64, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _p, _i64, _i64, _p, _i64, _i32, _p, _i64, _p, _i64, _i64,
+                               _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_msg_wimage': [_i32, _i32, _p, _i64, _p, _i64, _p],
     'nmarl_lstm_bptt_coupled_ws_words': [_i64, _i32],
     'nmarl_lstm_bptt_coupled': [C.POINTER(BpttCoupled), _p],
@@ -221,6 +223,8 @@ SIGNATURES = {
     'nmarl_fc_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
     'nmarl_fc_bwd_pair': [_i64, _i32, _p, _p, _i64, _i64, _p, _i64, _p, _i64, _i64, _i32, _p, _p, _p],
     'nmarl_fc_bwd_gather': [_i64, _i32, _i32, _i32, _p, _i32, _p, _i64, _i64, _p, _i64, _i64, _p, _i64, _i64, _i32, _p, _p, _i64, _p, _i64, _p],
+    'nmarl_heads_loss': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _p, _f32, _f32, _p, _p, _p, _p, _p, _i64, _p, _i64, _p,
+                         _i64, _p],
     'nmarl_thin_linear_bwd': [_i64, _i32, _i32, _i32, _p, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i64, _p],
     'nmarl_nbr_action_value_fwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _i64, _p, _i32, _p],
     'nmarl_nbr_action_value_bwd': [_i64, _i32, _i32, _i32, _p, _p, _p, _p, _p, _i64, _p],

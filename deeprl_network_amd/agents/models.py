@@ -447,6 +447,30 @@ class IA2C:
         return p.step_value(enc, self.h_fw, self.c_fw, done, self._h2, self._c2, action_scratch, self._v_boot,
                             done_is_zero)
 
+    def _loss_backward_fused(self, Hs):
+        """`_loss(Hs).backward()` with the heads, the loss and the heads' backward as ONE pass over the h sequence
+        (ops.heads_loss): this call is the root of the update's backward -- the head parameters receive their gradients here, the
+        recurrence below Hs its dL/dh.  False: not available for this net (the caller takes the autograd chain)."""
+        N, T, E = self.n_agent, self.n_step, self.E
+        p = self.policy
+        if Hs.dim() != 3 or not ops.heads_loss_supported(Hs, self.n_a, p.nbr_idx) or \
+                (not self.identical_agent and not self.per_agent_optimizer) or Hs.stride(2) != 1 or Hs.stride(1) != Hs.shape[2]:
+            return False
+        prm = p.params
+        action = self.buf_act.view(T * E, N)
+        # the one-launch BPTT kernels take the heads' dL/dh as dy8 (32 bytes per row) and expand it themselves: no [N,T*E,64] tensor
+        as_dy = self.save_acts and p.bptt_takes_head_dy and os.environ.get('NMARL_BPTT_HEAD_DY', '1') != '0'
+        r = ops.heads_loss(Hs.detach(), prm['pi_w'], prm['pi_b'], prm['v_w'], prm['v_b'], action, p.nbr_idx, self.n_a,
+                           self.Adv.view(N, T * E), self.R.view(N, T * E), self.v_coef, self.e_coef, want_dh=not as_dy)
+        terms = r['terms']
+        self.last_loss = (terms[:, 0], terms[:, 1], terms[:, 2], terms.sum(dim=1))
+        for k in ('pi_w', 'pi_b', 'v_w', 'v_b'):
+            prm[k].grad = r[k].reshape(prm[k].shape)
+        Hs.backward(gradient=ops.head_dy_placeholder(r['dy8'], r['hw'], Hs) if as_dy else r['dh'])
+        if as_dy and ops._pending_head_dy.pop(Hs.device, None) is not None:
+            raise RuntimeError('the recurrence below Hs did not take the heads\' dy8 (ops.take_head_dy): its gradient is wrong')
+        return True
+
     def _loss(self, Hs):
         """policies.py:20-30 / 232-255 with the batch mean taken over T*E."""
         N, T, E = self.n_agent, self.n_step, self.E
@@ -528,8 +552,9 @@ class IA2C:
                                           self.buf_done_pre, masked_steps=self.masked_steps, S_ext=self.S_ext, **kw)
         else:
             Hs = self.policy.unroll(X, FP, self.buf_done_pre, self.h_bw, self.c_bw, masked_steps=self.masked_steps)
-        loss = self._loss(Hs)
-        loss.backward()
+        if not self._loss_backward_fused(Hs):
+            loss = self._loss(Hs)
+            loss.backward()
         ps.end_backward()
         if ps.mask is not None:          # entries of variables the reference does not create (heterogeneous nets)
             ps.grad.mul_(ps.mask)

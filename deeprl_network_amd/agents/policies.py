@@ -495,6 +495,12 @@ class BatchedPolicy:
         return act_out
 
     @property
+    def bptt_takes_head_dy(self):
+        """The backward of `unroll_saved` understands ops.head_dy_placeholder (the heads' dL/dh as dy8, expanded inside the
+        one-launch BPTT kernel): the uncoupled nets' recurrence (ops._lstm_seq_x_backward)."""
+        return not self.coupled and self.xside
+
+    @property
     def can_save_acts(self):
         """The rollout can hand its activations (LSTM inputs, gates, state sequences, message terms) to the update,
         which then needs no forward pass: nets whose recurrent step is the fused x-side kernel."""

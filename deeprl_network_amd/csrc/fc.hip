@@ -869,6 +869,252 @@ __global__ __launch_bounds__(256) void thin_bwd_kernel(const int64_t rows, const
         out[idx] = ((red[idx] + red[65 * MAXO + idx]) + red[2 * 65 * MAXO + idx]) + red[3 * 65 * MAXO + idx];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The update's heads, the A2C loss and the heads' backward in ONE streaming pass over h (round 6; policies.py:20-30, 50-77):
+//   logits = h w[:, :A] + b[:A];  v = h w[:, A] + b[A] + va      (va: the critic's neighbour-action term, nbr_action_value_fwd_kernel)
+//   loss terms / d logits / d v: the formulas of a2c_loss_kernel (csrc/a2c.hip) with an upstream gradient of 1
+//   dW / db of [pi_w | v_w[:64]] as thin_bwd_kernel; dh (DH: written for the recurrences that take dL/dh as a tensor)
+//   dy8 [N,rows,8] = [d logits | d v | 0]: what the one-launch BPTT kernels expand to dL/dh themselves (csrc/lstm_bptt.hip)
+// instead of the skinny GEMM (h read), the loss forward and backward kernels (logits read twice) and thin_bwd_kernel (h read
+// again, dh written): h is read ONCE.  Thread = (4 consecutive hidden units k4, row lane rl of 16) as in thin_bwd_kernel; the 16
+// threads of a row finish the A + 1 dots by DPP row operations over their 16 lanes; four of them compute one row's loss gradient
+// each and broadcast it back (no LDS, no barrier inside the tile loop).
+// partial: [N, gridDim.x, 65 * O + 3] (dW rows 0..63, db row 64, then the three loss sums), summed in fixed order by
+// heads_loss_reduce_kernel.
+template <int CTRL>
+__device__ __forceinline__ float hl_dpp(const float v) {     // 0x110 + n: row_shr:n (zeros shifted in); 0x150 + n: row_newbcast:n
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+// OT: compile-time bound of O = A + 1 (5: CACC, 6: the grids, 8: anything else) -- the register arrays are that long
+template <bool DH, int OT>
+__global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, const int N, const int A, const int tiles_per_block,
+                                                         const float* __restrict__ h, const int64_t h_sn,
+                                                         const float* __restrict__ w, const int64_t w_sn,
+                                                         const float* __restrict__ b, const int64_t b_sn,
+                                                         const float* __restrict__ va, const uint8_t* __restrict__ action,
+                                                         const float* __restrict__ adv, const float* __restrict__ R,
+                                                         const float v_coef, const float e_coef, float* __restrict__ dy8,
+                                                         float* __restrict__ dv_out, float* __restrict__ dh, const int64_t dh_sn,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[4 * (65 * OT + 3)];
+    const int O = A + 1;
+    const int n = blockIdx.y, ki = threadIdx.x & 15, k4 = ki * 4, rl = threadIdx.x >> 4;
+    float wk[4][OT], acc[4][OT], dbacc[OT], bo[OT];
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            wk[q][o] = o < O ? w[(int64_t)n * w_sn + (k4 + q) * O + o] : 0.0f;
+            acc[q][o] = 0.0f;
+        }
+        dbacc[o] = 0.0f;
+        bo[o] = o < O ? b[(int64_t)n * b_sn + o] : 0.0f;
+    }
+    const float inv_m = 1.0f / (float)rows;
+    float s_pol = 0.0f, s_val = 0.0f, s_ent = 0.0f;
+    const float* hn = h + (int64_t)n * h_sn + k4;
+    float* dhn = DH ? dh + (int64_t)n * dh_sn + k4 : nullptr;
+    // the NEXT tile's h rows and per-row scalars are requested before this tile's arithmetic (no global latency between two tiles)
+    float4 hv[4];
+    float r_va[4], r_adv[4], r_R[4];
+    int r_a[4];
+#define NMARL_HL_LOAD(tile_)                                                               \
+    {                                                                                      \
+        const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+            const int64_t row = r0_ + rl + 16 * i, rc = row < rows ? row : rows - 1;       \
+            hv[i] = *reinterpret_cast<const float4*>(hn + rc * J);                         \
+            const int64_t ix = (int64_t)n * rows + rc;                                     \
+            r_va[i] = va[ix]; r_adv[i] = adv[ix]; r_R[i] = R[ix];                          \
+            r_a[i] = action[rc * N + n];                                                   \
+        }                                                                                  \
+    }
+    NMARL_HL_LOAD(0)
+    for (int tile = 0; tile < tiles_per_block; ++tile) {
+        const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
+        if (row0 >= rows) break;
+        float4 hc[4];
+        float c_va[4], c_adv[4], c_R[4];
+        int c_a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { hc[i] = hv[i]; c_va[i] = r_va[i]; c_adv[i] = r_adv[i]; c_R[i] = r_R[i]; c_a[i] = r_a[i]; }
+        NMARL_HL_LOAD(tile + 1)
+        // ---- the A + 1 dots of the tile's four row passes: 4 FMAs per lane, then the row's 16 lanes (one DPP row) add up by four
+        // shifted adds -- lane 15 holds the sum -- and take it back by a row broadcast (full-rate VALU, no LDS crossbar)
+        float zz[4][OT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float hq[4] = {hc[i].x, hc[i].y, hc[i].z, hc[i].w};
+#pragma unroll
+            for (int o = 0; o < OT; ++o) {
+                float v = 0.0f;
+                if (o < O) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v = fmaf(hq[q], wk[q][o], v);
+                    v += hl_dpp<0x111>(v); v += hl_dpp<0x112>(v); v += hl_dpp<0x114>(v); v += hl_dpp<0x118>(v);
+                    v = hl_dpp<0x15F>(v) + bo[o];
+                }
+                zz[i][o] = v;
+            }
+        }
+        // ---- the loss of ONE row per lane and its gradient (a2c_loss_kernel's arithmetic, upstream gradient 1): lane ki takes row
+        // pass ki & 3 (lanes 0..3 of the row are the ones whose result is used) -- all four passes in every lane would be 4 x the
+        // transcendental work for the same 64 rows per wave
+        const int ip = ki & 3;
+        float z[OT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) z[o] = ip == 0 ? zz[0][o] : ip == 1 ? zz[1][o] : ip == 2 ? zz[2][o] : zz[3][o];
+        const float s_va = ip == 0 ? c_va[0] : ip == 1 ? c_va[1] : ip == 2 ? c_va[2] : c_va[3];
+        const float s_ad = ip == 0 ? c_adv[0] : ip == 1 ? c_adv[1] : ip == 2 ? c_adv[2] : c_adv[3];
+        const float s_R = ip == 0 ? c_R[0] : ip == 1 ? c_R[1] : ip == 2 ? c_R[2] : c_R[3];
+        const int a = ip == 0 ? c_a[0] : ip == 1 ? c_a[1] : ip == 2 ? c_a[2] : c_a[3];
+        const int64_t row = row0 + rl + 16 * ip;
+        const bool live = row < rows;
+        float d[OT];
+        {
+            float pr[OT], lp[OT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < OT; ++k) {
+                pr[k] = k < A ? z[k] : -INFINITY;
+                m = fmaxf(m, pr[k]);
+            }
+            float zs = 0.0f;
+#pragma unroll
+            for (int k = 0; k < OT; ++k) {
+                pr[k] = k < A ? expf(pr[k] - m) : 0.0f;
+                zs += pr[k];
+            }
+            float Hent = 0.0f, lpa = 0.0f, pa = 0.0f;
+#pragma unroll
+            for (int k = 0; k < OT; ++k) {
+                pr[k] = pr[k] / zs;
+                lp[k] = logf(fminf(fmaxf(pr[k], 1e-10f), 1.0f));
+                if (k < A) Hent -= pr[k] * lp[k];
+                if (k == a) { lpa = lp[k]; pa = pr[k]; }
+            }
+            float vrow = 0.0f;
+#pragma unroll
+            for (int k = 0; k < OT; ++k) vrow = k == A ? z[k] : vrow;
+            vrow += s_va;
+            const float ad = s_ad, dR = s_R - vrow;
+            if (live && ki < 4) {
+                s_pol -= lpa * ad;
+                s_val += dR * dR;
+                s_ent += Hent;
+            }
+            float gbar = 0.0f;
+#pragma unroll
+            for (int k = 0; k < OT; ++k)
+                if (k < A) gbar += pr[k] * -(lp[k] + (pr[k] >= 1e-10f ? 1.0f : 0.0f));
+            const float ca = pa >= 1e-10f ? 1.0f : 0.0f;
+            const float gn = live ? inv_m : 0.0f;            // rows past the end: zero gradient
+#pragma unroll
+            for (int k = 0; k < OT; ++k) {
+                float dk = 0.0f;
+                if (k < A) {
+                    const float gk = -(lp[k] + (pr[k] >= 1e-10f ? 1.0f : 0.0f));
+                    const float d_pol = -ad * ca * ((k == a ? 1.0f : 0.0f) - pr[k]);
+                    const float d_ent = -e_coef * pr[k] * (gk - gbar);
+                    dk = gn * (d_pol + d_ent);
+                } else if (k == A) {
+                    dk = -gn * v_coef * dR;
+                }
+                d[k] = dk;
+            }
+            if (live && ki < 4) {
+                const int64_t ix = (int64_t)n * rows + row;
+                *reinterpret_cast<float4*>(dy8 + ix * 8) = float4{d[0], d[1], d[2], d[3]};
+                *reinterpret_cast<float4*>(dy8 + ix * 8 + 4) = float4{d[4], OT > 5 ? d[OT > 5 ? 5 : 0] : 0.0f, OT > 6 ? d[OT > 6 ? 6 : 0] : 0.0f,
+                                                                  OT > 7 ? d[OT > 7 ? 7 : 0] : 0.0f};
+                float dvv = 0.0f;
+#pragma unroll
+                for (int k = 0; k < OT; ++k) dvv = k == A ? d[k] : dvv;
+                dv_out[ix] = dvv;
+            }
+        }
+        // ---- the heads' backward per row pass: the pass's gradient comes back from lane i of the row (row broadcast); dW / db
+        // accumulators, dL/dh of the lane's four units
+#define NMARL_HL_BWD(i)                                                                    \
+        {                                                                                  \
+            const float hq[4] = {hc[i].x, hc[i].y, hc[i].z, hc[i].w};                      \
+            float g[4] = {0.f, 0.f, 0.f, 0.f};                                             \
+            _Pragma("unroll") for (int o = 0; o < OT; ++o)                                 \
+                if (o < O) {                                                               \
+                    const float di = hl_dpp<0x150 + i>(d[o]);                              \
+                    dbacc[o] += di;                                                        \
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                        \
+                        g[q] = fmaf(di, wk[q][o], g[q]);                                   \
+                        acc[q][o] = fmaf(hq[q], di, acc[q][o]);                            \
+                    }                                                                      \
+                }                                                                          \
+            if (DH && row0 + rl + 16 * i < rows)                                           \
+                *reinterpret_cast<float4*>(dhn + (row0 + rl + 16 * i) * J) = float4{g[0], g[1], g[2], g[3]}; \
+        }
+        NMARL_HL_BWD(0) NMARL_HL_BWD(1) NMARL_HL_BWD(2) NMARL_HL_BWD(3)
+#undef NMARL_HL_BWD
+    }
+#undef NMARL_HL_LOAD
+    // 16 row lanes: 4 inside the wave (lanes 16 i + j) by shuffles, then the 4 waves through LDS in a fixed order
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = acc[q][o];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[q][o] = v;
+        }
+        float v = dbacc[o];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        dbacc[o] = v;
+    }
+    // (lanes 0..3 of every row hold loss sums: first those four, then the row lanes like the accumulators above)
+    s_pol += __shfl_xor(s_pol, 1, 64); s_pol += __shfl_xor(s_pol, 2, 64);
+    s_val += __shfl_xor(s_val, 1, 64); s_val += __shfl_xor(s_val, 2, 64);
+    s_ent += __shfl_xor(s_ent, 1, 64); s_ent += __shfl_xor(s_ent, 2, 64);
+    s_pol += __shfl_xor(s_pol, 16, 64); s_pol += __shfl_xor(s_pol, 32, 64);
+    s_val += __shfl_xor(s_val, 16, 64); s_val += __shfl_xor(s_val, 32, 64);
+    s_ent += __shfl_xor(s_ent, 16, 64); s_ent += __shfl_xor(s_ent, 32, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int PW = 65 * OT + 3;
+    if (lane < 16) {
+#pragma unroll
+        for (int o = 0; o < OT; ++o)
+            if (o < O) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[wave * PW + (k4 + q) * O + o] = acc[q][o];
+                if (lane == 0) red[wave * PW + 64 * O + o] = dbacc[o];
+            }
+        if (lane == 0) { red[wave * PW + 65 * O] = s_pol; red[wave * PW + 65 * O + 1] = s_val; red[wave * PW + 65 * O + 2] = s_ent; }
+    }
+    __syncthreads();
+    const int per = 65 * O + 3;
+    float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * (int64_t)per;
+    for (int idx = threadIdx.x; idx < per; idx += 256)
+        out[idx] = ((red[idx] + red[PW + idx]) + red[2 * PW + idx]) + red[3 * PW + idx];
+}
+
+__global__ __launch_bounds__(256) void heads_loss_reduce_kernel(const int C, const int O, const int64_t rows, const float v_coef,
+                                                                const float e_coef, const float* __restrict__ partial,
+                                                                float* __restrict__ dw, const int64_t dw_sn, float* __restrict__ db,
+                                                                const int64_t db_sn, float* __restrict__ loss_out /*[N,3]*/) {
+    const int n = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 65 * O + 3;
+    if (idx >= per) return;
+    float s = nmarl_ordered_sum(partial + (int64_t)n * C * per + idx, per, C);
+    if (idx < 64 * O) dw[(int64_t)n * dw_sn + idx] = s;
+    else if (idx < 65 * O) db[(int64_t)n * db_sn + idx - 64 * O] = s;
+    else {
+        const int k = idx - 65 * O;
+        s /= (float)rows;
+        loss_out[n * 3 + k] = k == 0 ? s : k == 1 ? s * 0.5f * v_coef : -s * e_coef;
+    }
+}
+
 __global__ __launch_bounds__(256) void thin_bwd_reduce_kernel(const int C, const int O, const float* __restrict__ partial,
                                                               float* __restrict__ dw, const int64_t dw_sn,
                                                               float* __restrict__ db, const int64_t db_sn) {
@@ -1133,6 +1379,30 @@ extern "C" int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t
     hipLaunchKernelGGL(thin_bwd_kernel, dim3(C, N), dim3(256), 0, st, rows, O, tpb, h, h_sn, dy, dy_sn, dy2, dy2_sn, w, w_sn, dh,
                        dh_sn, partial);
     hipLaunchKernelGGL(thin_bwd_reduce_kernel, dim3((65 * O + 255) / 256, N), dim3(256), 0, st, C, O, partial, dw, dw_sn, db, db_sn);
+    return nmarl_check_launch();
+}
+
+extern "C" int nmarl_heads_loss(int64_t rows, int32_t N, int32_t H, int32_t A, const float* h, int64_t h_sn, const float* w, int64_t w_sn,
+                                const float* b, int64_t b_sn, const float* va, const uint8_t* action, const float* adv, const float* R,
+                                float v_coef, float e_coef, float* partial, float* loss_out, float* dy8, float* dv, float* dh,
+                                int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream) {
+    const int O = A + 1;
+    if (rows <= 0 || N <= 0 || H != J || A <= 0 || O > MAXO || !h || !w || !b || !va || !action || !adv || !R || !partial || !loss_out ||
+        !dy8 || !dv || !dw || !db || h_sn < rows * J || (h_sn % 4) || ((uintptr_t)h % 16) || ((uintptr_t)dy8 % 16) ||
+        (dh && (dh_sn < rows * J || (dh_sn % 4) || ((uintptr_t)dh % 16))) || w_sn < (int64_t)J * O || b_sn < O ||
+        dw_sn < (int64_t)J * O || db_sn < O)
+        return NMARL_EINVAL;
+    const int C = nmarl_fc_bwd_chunks(rows, N);
+    const int64_t tiles = (rows + TILE - 1) / TILE;
+    const int tpb = (int)((tiles + C - 1) / C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NMARL_HL(DHF, OTV) hipLaunchKernelGGL((heads_loss_kernel<DHF, OTV>), dim3(C, N), dim3(256), 0, st, rows, N, A, tpb, h, h_sn, w, w_sn, \
+                                              b, b_sn, va, action, adv, R, v_coef, e_coef, dy8, dv, dh, dh_sn, partial)
+    if (dh) { if (O <= 5) NMARL_HL(true, 5); else if (O == 6) NMARL_HL(true, 6); else NMARL_HL(true, 8); }
+    else { if (O <= 5) NMARL_HL(false, 5); else if (O == 6) NMARL_HL(false, 6); else NMARL_HL(false, 8); }
+#undef NMARL_HL
+    hipLaunchKernelGGL(heads_loss_reduce_kernel, dim3((65 * O + 3 + 255) / 256, N), dim3(256), 0, st, C, O, rows, v_coef, e_coef, partial,
+                       dw, dw_sn, db, db_sn, loss_out);
     return nmarl_check_launch();
 }
 

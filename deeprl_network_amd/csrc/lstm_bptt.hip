@@ -273,6 +273,11 @@ struct BpttSeqArgs {
     int64_t gates_sn, gates_st, c_sn, c_st, dh_sn, dh_st, img_sn, dz_sn, dz_st, db_sn, dh0_sn, dc0_sn;
     int64_t E;
     int N, T;
+    // DY (round 6): the heads' dL/dh is NOT read as a tensor: dy8 [N][T][E][8] = [d logits | d v | 0] (nmarl_heads_loss) and the
+    // heads' weights hw [N][64][O] -- dL/dh_t(heads) = dy_t hw^T is two more k-steps of the step's transposed product
+    const float *dy8, *hw;
+    int64_t dy_sn, dy_st, hw_sn;
+    int O;
 };
 
 struct SeqGroup {           // per-step inputs of 4 consecutive units of one row
@@ -299,6 +304,7 @@ __device__ __forceinline__ void bstore4(const __amdgpu_buffer_rsrc_t r, const ui
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, 0);
 }
 
+template <bool DY>
 __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // (plain round-robin over the agents: the XCD-aware grouping of common.h, which pays in the lock-step kernel, made this one
@@ -318,15 +324,23 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         float4* d = reinterpret_cast<float4*>(lds);
 #pragma unroll
         for (int i = 0; i < SEQ_IMG / 4 / 512; ++i) d[i * 512 + threadIdx.x] = g[i * 512 + threadIdx.x];
+        if (DY) {
+            // the heads' image behind it, same layout: [k-step s][q][c][tile t] = hw[unit 16 t + c][output 4 s + q] (0 past O): one float per thread
+            const int s_ = threadIdx.x >> 8, q_ = (threadIdx.x >> 6) & 3, c_ = (threadIdx.x >> 2) & 15, t_ = threadIdx.x & 3;
+            const int o_ = 4 * s_ + q_;
+            lds[SEQ_IMG + threadIdx.x] = o_ < a.O ? a.hw[(int64_t)n * a.hw_sn + (16 * t_ + c_) * a.O + o_] : 0.0f;
+        }
     }
     const int T = a.T;
     // addresses = buffer resource of (agent, step) (scalar registers) + one 32-bit byte offset of the lane per row pitch
     const float* gA = a.gates + (int64_t)n * a.gates_sn;
     const float* cA = a.c_all + (int64_t)n * a.c_sn;
-    const float* eA = a.dh_ext + (int64_t)n * a.dh_sn;
+    const float* eA = DY ? nullptr : a.dh_ext + (int64_t)n * a.dh_sn;
+    const float* yA = DY ? a.dy8 + (int64_t)n * a.dy_sn : nullptr;
     float* zA = a.dz + (int64_t)n * a.dz_sn;
     const uint32_t lo4 = (uint32_t)(arow_raw * G4 + 4 * q) * 4u, lo1 = (uint32_t)(arow_raw * H + 4 * q) * 4u;
     const uint32_t nb4 = (uint32_t)(a.E * G4) * 4u, nb1 = (uint32_t)(a.E * H) * 4u;
+    const uint32_t lo8 = (uint32_t)(arow_raw * 8 + q) * 4u, nb8 = (uint32_t)(a.E * 8) * 4u;
     const uint32_t lor = (uint32_t)(arow_ok ? arow_raw : a.E - 1);
 
     // groups j, j + 1 of step t_ together: the two 64-byte halves of every 128-byte line are requested back to back
@@ -335,7 +349,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);   /* keeps the resources in scalar registers */ \
         const __amdgpu_buffer_rsrc_t rg_ = make_rsrc(gA + ts_ * a.gates_st, nb4);          \
         const __amdgpu_buffer_rsrc_t rc_ = make_rsrc(cA + ts_ * a.c_st, nb1);              \
-        const __amdgpu_buffer_rsrc_t re_ = make_rsrc(eA + ts_ * a.dh_st, nb1);             \
+        const __amdgpu_buffer_rsrc_t re_ = make_rsrc(DY ? cA : eA + ts_ * a.dh_st, nb1);   \
         UA.gi = bload4(rg_, lo4 + 64 * (j));                                               \
         UB.gi = bload4(rg_, lo4 + 64 * (j) + 64);                                          \
         UA.gf = bload4(rg_, lo4 + 64 * (j) + 4 * H);                                       \
@@ -346,10 +360,36 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         UB.gu = bload4(rg_, lo4 + 64 * (j) + 12 * H + 64);                                 \
         UA.cp = bload4(rc_, lo1 + 64 * (j));                                               \
         UB.cp = bload4(rc_, lo1 + 64 * (j) + 64);                                          \
-        UA.gh = bload4(re_, lo1 + 64 * (j));                                               \
-        UB.gh = bload4(re_, lo1 + 64 * (j) + 64);                                          \
+        if (!DY) {                                                                         \
+            UA.gh = bload4(re_, lo1 + 64 * (j));                                           \
+            UB.gh = bload4(re_, lo1 + 64 * (j) + 64);                                      \
+        }                                                                                  \
+    }
+    // DY: the lane's two values of dy8[t_][row c] (outputs q and 4 + q): the B operand of the heads' two k-steps
+#define NMARL_SEQ_LOADY(d0_, d1_, t_)                                                      \
+    {                                                                                      \
+        const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);                            \
+        const __amdgpu_buffer_rsrc_t ry_ = make_rsrc(yA + ts_ * a.dy_st, nb8);             \
+        d0_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, lo8, 0, 0));       \
+        d1_ = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, lo8 + 16, 0, 0));  \
+    }
+    // dhr += dy hw^T: two k-steps x four unit tiles (A = the heads' image rows, B = the lane's dy values)
+#define NMARL_SEQ_HEADS(d0_, d1_)                                                          \
+    {                                                                                      \
+        const float* hb_ = lds + SEQ_IMG + (q * 16 + c) * 4;                               \
+        const float4 p0_ = *reinterpret_cast<const float4*>(hb_), p1_ = *reinterpret_cast<const float4*>(hb_ + 256); \
+        dhr[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p0_.x, d0_, dhr[0], 0, 0, 0);        \
+        dhr[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p0_.y, d0_, dhr[1], 0, 0, 0);        \
+        dhr[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p0_.z, d0_, dhr[2], 0, 0, 0);        \
+        dhr[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p0_.w, d0_, dhr[3], 0, 0, 0);        \
+        dhr[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1_.x, d1_, dhr[0], 0, 0, 0);        \
+        dhr[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1_.y, d1_, dhr[1], 0, 0, 0);        \
+        dhr[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1_.z, d1_, dhr[2], 0, 0, 0);        \
+        dhr[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(p1_.w, d1_, dhr[3], 0, 0, 0);        \
     }
     SeqGroup u0, u1, u2, u3;
+    float dya = 0.0f, dyb = 0.0f;                     // DY: dy8 of the step whose heads' dL/dh is added next
+    if (DY) { NMARL_SEQ_LOADY(dya, dyb, T - 1) }
     NMARL_SEQ_LOAD2(u0, u1, T - 1, 0)
     NMARL_SEQ_LOAD2(u2, u3, T - 1, 2)
     float4 dc[4];
@@ -364,6 +404,9 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
     for (int i = 0; i < 16; ++i) dbacc[i] = 0.0f;
     float keepA = 1.0f - (a.done + (int64_t)(T - 1) * a.E)[lor];
     __syncthreads();                                 // image visible
+    if (DY) {                                        // dL/dh_{T-1} = the heads' part alone
+        NMARL_SEQ_HEADS(dya, dyb)
+    }
 
     // one k-step = image row (s, q) of the 4 output tiles (one ds_read_b128) x the lane's dz value: 4 MFMAs.  Reads run two k-steps
     // ahead of their MFMAs through two register sets (left alone the compiler reads each row right before its use and every
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
     {                                                                                      \
         const float cpk = U.cp.k * keepA;                                                  \
         const float tc = tanh_fast_(U.gf.k * cpk + U.gi.k * U.gu.k);   /* c_t, op for op the forward's (see above) */ \
-        const float gh_ = U.gh.k + dhr[j][i_];                                     \
+        const float gh_ = DY ? dhr[j][i_] : U.gh.k + dhr[j][i_];                           \
         const float g_c = dc[j].k + gh_ * U.go.k * (1.0f - tc * tc);                       \
         di.k = g_c * U.gu.k * U.gi.k * (1.0f - U.gi.k);                                    \
         df.k = g_c * cpk * U.gf.k * (1.0f - U.gf.k);                                       \
@@ -437,6 +480,7 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         float4 di, df, dO, du;
         // the scheduling fences keep the phases where they are written: left alone the scheduler bunches all 24 loads at
         // the end of the body (a quarter step before their use) and orders them against the waits' in-order counter
+        if (DY) { NMARL_SEQ_LOADY(dya, dyb, tp) }     // (step t's heads' part is inside dhr already)
         NMARL_SEQ_CELL(u0, 0)
         __builtin_amdgcn_sched_barrier(0);
         NMARL_SEQ_PROD(0)
@@ -460,10 +504,15 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_seq_kernel(const BpttSeqArgs
         // dh_{t-1, rec} = (dz @ wh^T) keep_t: acc[j][i] = dh[row c][unit 16 j + 4 q + i], this lane's own units
 #pragma unroll
         for (int j = 0; j < 4; ++j) dhr[j] = acc[j] * keepA;
+        if (DY && t > 0) {                           // + the heads' dL/dh_{t-1} (not masked: the heads read h_{t-1} itself)
+            NMARL_SEQ_HEADS(dya, dyb)
+        }
         keepA = keep_next;
     }
     NMARL_BSTAMP(17)
 #undef NMARL_SEQ_LOAD2
+#undef NMARL_SEQ_LOADY
+#undef NMARL_SEQ_HEADS
 #undef NMARL_SEQ_BL
 #undef NMARL_SEQ_MF
 #undef NMARL_SEQ_KS
@@ -1121,13 +1170,18 @@ extern "C" int nmarl_lstm_bptt_step(int64_t E, int32_t N, int32_t Hh, int32_t KM
 
 extern "C" int nmarl_lstm_bptt_seq_blocks(int64_t E) { return (int)((E + ROWS_B - 1) / ROWS_B); }
 
-extern "C" int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t Hh, const float* gates, int64_t gates_sn,
-                                   int64_t gates_st, const float* c_all, int64_t c_sn, int64_t c_st, const float* done,
-                                   const float* dh_ext, int64_t dh_sn, int64_t dh_st, const float* img, int64_t img_sn,
-                                   float* dz, int64_t dz_sn, int64_t dz_st, float* db_part, int64_t db_sn, float* dh0,
-                                   int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream) {
-    if (Hh != H || E < 0 || N <= 0 || T <= 0 || (E > 0 && (!gates || !c_all || !done || !dh_ext || !img || !dz)))
+static int launch_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t Hh, const float* gates, int64_t gates_sn,
+                           int64_t gates_st, const float* c_all, int64_t c_sn, int64_t c_st, const float* done,
+                           const float* dh_ext, int64_t dh_sn, int64_t dh_st, const float* dy8, int64_t dy_sn, int64_t dy_st,
+                           const float* hw, int64_t hw_sn, int32_t O, const float* img, int64_t img_sn,
+                           float* dz, int64_t dz_sn, int64_t dz_st, float* db_part, int64_t db_sn, float* dh0,
+                           int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream) {
+    if (Hh != H || E < 0 || N <= 0 || T <= 0 || (E > 0 && (!gates || !c_all || !done || (!dh_ext && !dy8) || (dh_ext && dy8) || !img || !dz)))
         return NMARL_EINVAL;
+    if (dy8 && (!hw || O <= 0 || O > 8 || hw_sn < (int64_t)H * O || dy_st < E * 8 || (dy_st % 4) || !sn_ok(dy_sn, (T - 1) * dy_st + E * 8) ||
+                ((uintptr_t)dy8 % 16)))
+        return NMARL_EINVAL;
+    if (!dh_ext) { dh_ext = c_all; dh_sn = c_sn; dh_st = c_st; }       // (not read: any valid panel keeps the checks below uniform)
     if (E == 0) return NMARL_OK;
     if (E > (1 << 21)) return NMARL_EINVAL;             // 32-bit byte offsets inside one (agent, step) panel
     const int64_t nblk = (E + ROWS_B - 1) / ROWS_B;
@@ -1143,16 +1197,43 @@ extern "C" int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t Hh, 
     a.dh0 = dh0; a.dc0 = dc0; a.gates_sn = gates_sn; a.gates_st = gates_st; a.c_sn = c_sn; a.c_st = c_st; a.dh_sn = dh_sn;
     a.dh_st = dh_st; a.img_sn = img_sn; a.dz_sn = dz_sn; a.dz_st = dz_st; a.db_sn = db_sn; a.dh0_sn = dh0_sn; a.dc0_sn = dc0_sn;
     a.E = E; a.N = N; a.T = T;
+    a.dy8 = dy8; a.dy_sn = dy_sn; a.dy_st = dy_st; a.hw = hw; a.hw_sn = hw_sn; a.O = O;
     static NmarlPerDeviceOnce lds_once;
     if (const unsigned long long lds_bit = lds_once.pending(); lds_bit != ~0ull) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_seq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SEQ_IMG * 4) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_seq_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SEQ_IMG * 4) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_seq_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (SEQ_IMG + 512) * 4) != hipSuccess)
             return NMARL_EHIP;
         lds_once.done(lds_bit);
     }
-    hipLaunchKernelGGL(lstm_bptt_seq_kernel, dim3((unsigned)(nblk * N)), dim3(512), (size_t)SEQ_IMG * 4,
-                       static_cast<hipStream_t>(stream), a);
+    if (dy8)
+        hipLaunchKernelGGL(lstm_bptt_seq_kernel<true>, dim3((unsigned)(nblk * N)), dim3(512), (size_t)(SEQ_IMG + 512) * 4,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(lstm_bptt_seq_kernel<false>, dim3((unsigned)(nblk * N)), dim3(512), (size_t)SEQ_IMG * 4,
+                           static_cast<hipStream_t>(stream), a);
     return nmarl_check_launch();
+}
+
+extern "C" int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t Hh, const float* gates, int64_t gates_sn,
+                                   int64_t gates_st, const float* c_all, int64_t c_sn, int64_t c_st, const float* done,
+                                   const float* dh_ext, int64_t dh_sn, int64_t dh_st, const float* img, int64_t img_sn,
+                                   float* dz, int64_t dz_sn, int64_t dz_st, float* db_part, int64_t db_sn, float* dh0,
+                                   int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream) {
+    if (!dh_ext) return NMARL_EINVAL;
+    return launch_bptt_seq(T, E, N, Hh, gates, gates_sn, gates_st, c_all, c_sn, c_st, done, dh_ext, dh_sn, dh_st, nullptr, 0, 0, nullptr, 0, 0,
+                           img, img_sn, dz, dz_sn, dz_st, db_part, db_sn, dh0, dh0_sn, dc0, dc0_sn, stream);
+}
+
+extern "C" int nmarl_lstm_bptt_seq_dy(int32_t T, int64_t E, int32_t N, int32_t Hh, const float* gates, int64_t gates_sn,
+                                      int64_t gates_st, const float* c_all, int64_t c_sn, int64_t c_st, const float* done,
+                                      const float* dy8, int64_t dy_sn, int64_t dy_st, const float* hw, int64_t hw_sn, int32_t O,
+                                      const float* img, int64_t img_sn, float* dz, int64_t dz_sn, int64_t dz_st, float* db_part,
+                                      int64_t db_sn, float* dh0, int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream) {
+    if (!dy8) return NMARL_EINVAL;
+    return launch_bptt_seq(T, E, N, Hh, gates, gates_sn, gates_st, c_all, c_sn, c_st, done, nullptr, 0, 0, dy8, dy_sn, dy_st, hw, hw_sn, O,
+                           img, img_sn, dz, dz_sn, dz_st, db_part, db_sn, dh0, dh0_sn, dc0, dc0_sn, stream);
 }
 
 extern "C" int nmarl_lstm_bptt_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn,

@@ -929,6 +929,44 @@ class _Heads(torch.autograd.Function):
         return dh, dw[:, :, :A], db[:, :A], dv_w, db[:, A:], None, None, None
 
 
+def heads_loss_supported(h, n_a, nbr_idx):
+    """The update's heads + loss + heads' backward as ONE pass over h (nmarl_heads_loss): H = 64, A + 1 <= 8 outputs."""
+    return h.is_cuda and heads_supported(h, n_a, nbr_idx) and a2c_loss_supported(n_a) and \
+        os.environ.get('NMARL_FUSED_HEADS_LOSS', '1') != '0'
+
+
+def heads_loss(h, pi_w, pi_b, v_w, v_b, action, nbr_idx, n_a, adv, R, v_coef, e_coef, want_dh=True):
+    """h [N,rows,64] (no autograd: the caller is the root of the update's backward), action [rows,N] u8, adv / R [N,rows] ->
+    dict(terms [N,3] (policy, value, entropy loss), dh [N,rows,64] or None, dy8 [N,rows,8] = [d logits | d v | 0], and the head
+    parameters' gradients pi_w, pi_b, v_w, v_b) for an upstream gradient of 1 on sum_n (policy + value + entropy) -- policies.py:20-30,
+    50-77; the values of ops.heads -> ops.a2c_loss -> backward, in one streaming pass over h."""
+    N, rows, H = h.shape
+    A = n_a
+    O = A + 1
+    dev = h.device
+    with torch.no_grad():
+        w = torch.cat([pi_w, v_w[:, :H]], dim=2)
+        b = torch.cat([pi_b, v_b], dim=1)
+        va = nbr_action_value(action, nbr_idx, v_w[:, H:], A)
+        if h.stride(2) != 1 or h.stride(1) != H:
+            raise _lib.NmarlError('heads_loss: h needs contiguous [rows,64] panels')
+        C_ = lib.nmarl_fc_bwd_chunks(rows, N)
+        partial = torch.empty(N, C_, 65 * O + 3, dtype=F32, device=dev)
+        terms = torch.empty(N, 3, dtype=F32, device=dev)
+        dy8 = torch.empty(N, rows, 8, dtype=F32, device=dev)
+        dv = torch.empty(N, rows, dtype=F32, device=dev)
+        dh = torch.empty(N, rows, H, dtype=F32, device=dev) if want_dh else None
+        dw = torch.empty(N, H, O, dtype=F32, device=dev)
+        db = torch.empty(N, O, dtype=F32, device=dev)
+        check(lib.nmarl_heads_loss(rows, N, H, A, ptr(h, F32, strided=True), h.stride(0), ptr(w, F32), w.stride(0), ptr(b, F32), b.stride(0),
+                                   ptr(va, F32), ptr(action, torch.uint8), ptr(adv.contiguous(), F32), ptr(R.contiguous(), F32),
+                                   float(v_coef), float(e_coef), ptr(partial), ptr(terms), ptr(dy8), ptr(dv), ptr(dh), rows * H if want_dh else 0,
+                                   ptr(dw), dw.stride(0), ptr(db), db.stride(0), stream()), 'nmarl_heads_loss')
+        dwa = nbr_action_value_bwd(action, nbr_idx, dv, A)
+        return dict(terms=terms, dh=dh, dy8=dy8, hw=w, pi_w=dw[:, :, :A], pi_b=db[:, :A],
+                    v_w=torch.cat([dw[:, :, A:], dwa.unsqueeze(-1)], dim=1), v_b=db[:, A:])
+
+
 def heads_supported(h, n_a, nbr_idx):
     return h.shape[2] == FC_J and n_a + 1 <= THIN_MAX_O and nbr_idx.shape[1] * n_a <= NBR_ACT_MAX_W
 
@@ -1028,19 +1066,57 @@ def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, app
 BPTT_SEQ_MAX_E = 1 << 21     # nmarl_lstm_bptt_seq addresses one (agent, step) panel with 32-bit byte offsets
 
 
-def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False):
+# ---- the heads' dL/dh handed to the one-launch BPTT kernels as dy8 (ops.heads_loss) instead of as a [N,T,E,64] tensor: autograd
+# carries a zero-stride placeholder of the right shape from `Hs.backward(gradient=...)` to the recurrence's backward, which
+# recognises it and takes (dy8, hw) from here -- 32 bytes per row instead of 256 written and read again
+_pending_head_dy = {}
+
+
+def head_dy_placeholder(dy8, hw, like):
+    """dy8 [N,rows,8], hw [N,64,O] -> a zero-stride tensor shaped like `like` to pass as its gradient; see take_head_dy."""
+    ph = torch.zeros(1, dtype=F32, device=like.device).expand(like.shape)
+    _pending_head_dy[like.device] = (ph, dy8, hw)
+    return ph
+
+
+def take_head_dy(dHs):
+    """(dy8, hw) if dHs is the placeholder of head_dy_placeholder (nothing else contributed to dL/dh), else None."""
+    pend = _pending_head_dy.pop(dHs.device, None)
+    if pend is None or dHs.data_ptr() != pend[0].data_ptr() or any(dHs.stride()):
+        return None
+    return pend[1], pend[2]
+
+
+def head_dy_to_dh(dy8, hw, shape):
+    """The tensor the placeholder stands for: dL/dh = dy hw^T (recurrences without a dy8 form)."""
+    O = hw.shape[2]
+    return torch.bmm(dy8[:, :, :O], hw.transpose(1, 2)).view(shape)
+
+
+def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False, head_dy=None):
     """The whole reverse recurrence in one launch (nmarl_lstm_bptt_seq): G / dZ [N,T,E,4H], Call [N,T+1,E,H], done [T,E],
     dHs [N,T,E,H] (the heads' dL/dh_t), img = lstm_bptt_wimage(None, wh).  -> (db [N,4H] or None, dh0, dc0 or None):
-    every step masks the carried state by done_t (the reference's lstm does, agents/utils.py:104-105)."""
+    every step masks the carried state by done_t (the reference's lstm does, agents/utils.py:104-105).
+    head_dy = (dy8 [N,T*E,8], hw [N,64,O]) instead of dHs: the kernel forms the heads' dL/dh itself (nmarl_lstm_bptt_seq_dy)."""
     N, T, E, H4 = G.shape
     H = H4 // 4
-    for x, w, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (dHs, H, 'dh_ext')):
+    for x, w, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all')) + (((dHs, H, 'dh_ext'),) if head_dy is None else ()):
         if x.stride(3) != 1 or x.stride(2) != w:
             raise ValueError('bptt_seq: %s must have contiguous rows' % what)
     nblk = lib.nmarl_lstm_bptt_seq_blocks(E)
     part = torch.empty(N, nblk, H4, dtype=F32, device=G.device) if want_db else None
     dh0 = torch.empty(N, E, H, dtype=F32, device=G.device) if want_state_grad else None
     dc0 = torch.empty(N, E, H, dtype=F32, device=G.device) if want_state_grad else None
+    if head_dy is not None:
+        dy8, hw = head_dy
+        if dy8.shape != (N, T * E, 8) or not dy8.is_contiguous() or hw.shape[:2] != (N, H) or not hw.is_contiguous():
+            raise ValueError('bptt_seq: head_dy = (dy8 [N,T*E,8], hw [N,64,O]) contiguous')
+        check(lib.nmarl_lstm_bptt_seq_dy(T, E, N, H, ptr(G, F32, strided=True), G.stride(0), G.stride(1), ptr(Call, F32, strided=True),
+                                         Call.stride(0), Call.stride(1), ptr(done, F32), ptr(dy8, F32), dy8.stride(0), E * 8,
+                                         ptr(hw, F32), hw.stride(0), hw.shape[2], ptr(img, F32), img.stride(0),
+                                         ptr(dZ, F32, strided=True), dZ.stride(0), dZ.stride(1), ptr(part),
+                                         0 if part is None else part.stride(0), *_pn(dh0), *_pn(dc0), stream()), 'nmarl_lstm_bptt_seq_dy')
+        return (part.sum(dim=1) if want_db else None), dh0, dc0
     check(lib.nmarl_lstm_bptt_seq(T, E, N, H, ptr(G, F32, strided=True), G.stride(0), G.stride(1), ptr(Call, F32, strided=True),
                                   Call.stride(0), Call.stride(1), ptr(done, F32), ptr(dHs, F32, strided=True), dHs.stride(0),
                                   dHs.stride(1), ptr(img, F32), img.stride(0), ptr(dZ, F32, strided=True), dZ.stride(0),
@@ -1384,7 +1460,12 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, w
     ds = dZ @ wx^T, dwx = s^T dZ, dwh = (h keep)^T dZ, db = sum dZ over all T*E rows."""
     N, T, E, H4 = G.shape
     H = H4 // 4
-    dHs = dHs.contiguous()
+    head_dy = take_head_dy(dHs)
+    one_launch = bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4 and E <= BPTT_SEQ_MAX_E
+    if head_dy is not None and not one_launch:
+        dHs, head_dy = head_dy_to_dh(*head_dy, dHs.shape), None
+    if head_dy is None:
+        dHs = dHs.contiguous()
     keep = (1.0 - done)
     KX = s.shape[3]
     # In-place weight gradients: with the LSTM inputs handed over as the first T slabs of a (T + 1)-slab buffer (last slab
@@ -1400,10 +1481,10 @@ def _lstm_seq_x_backward(G, Hall, Call, s, wx, wh, done, masked, dHs, need_ds, w
     else:
         dZ = torch.empty_like(G)
     db = None
-    if bptt_supported(H) and wh.stride(2) == 1 and wh.stride(1) == H4 and E <= BPTT_SEQ_MAX_E:
+    if one_launch:
         # the whole reverse recurrence in one launch; the bias gradient comes out of the same pass.  It multiplies by
         # (1 - done_t) at every step: exact also for the steps outside `masked`, whose done_t is zero by contract
-        db, dh_rec, dc = bptt_seq(G, Call, done, dHs, lstm_bptt_wimage(None, wh), dZ, want_state_grad=want_state_grad)
+        db, dh_rec, dc = bptt_seq(G, Call, done, dHs, lstm_bptt_wimage(None, wh), dZ, want_state_grad=want_state_grad, head_dy=head_dy)
     else:
         dh_rec = None
         dc = torch.zeros(N, E, H, dtype=F32, device=G.device)

@@ -594,6 +594,15 @@ int nmarl_lstm_bptt_seq(int32_t T, int64_t E, int32_t N, int32_t H, const float*
                         const float* dh_ext, int64_t dh_sn, int64_t dh_st, const float* img, int64_t img_sn,
                         float* dz, int64_t dz_sn, int64_t dz_st, float* db_part, int64_t db_sn, float* dh0,
                         int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream);
+/* nmarl_lstm_bptt_seq with the heads' dL/dh formed inside the kernel (round 6): dy8 [N][T][E][8] = [d logits | d v | 0] of
+ * nmarl_heads_loss (agent stride dy_sn, step stride dy_st), hw [N][64][O] = [pi_w | v_w[:64]] (O = A + 1 <= 8):
+ * dL/dh_t(heads) = dy_t hw^T is two more k-steps of the step's transposed product -- 32 bytes per row-step read instead of 256. */
+int nmarl_lstm_bptt_seq_dy(int32_t T, int64_t E, int32_t N, int32_t H, const float* gates, int64_t gates_sn,
+                           int64_t gates_st, const float* c_all, int64_t c_sn, int64_t c_st, const float* done,
+                           const float* dy8, int64_t dy_sn, int64_t dy_st, const float* hw, int64_t hw_sn, int32_t O,
+                           const float* img, int64_t img_sn, float* dz, int64_t dz_sn, int64_t dz_st, float* db_part,
+                           int64_t db_sn, float* dh0, int64_t dh0_sn, float* dc0, int64_t dc0_sn, void* stream);
+
 /*
  * The reverse recurrence of a COUPLED net's update -- NeurComm (lstm_comm, agents/utils.py:182-208; unrolled training graph
  * of policies.py:330-331) or CommNet (lstm_ic3, agents/utils.py:395-408) -- in ONE launch: per step the work of
@@ -736,6 +745,20 @@ int nmarl_thin_linear_bwd(int64_t rows, int32_t N, int32_t H, int32_t O, const f
                           const float* dy, int64_t dy_sn, const float* dy2, int64_t dy2_sn, const float* w, int64_t w_sn,
                           float* partial, float* dh, int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn,
                           void* stream);
+/*
+ * The update's actor / critic heads, the A2C loss and the heads' backward in ONE streaming pass over h (round 6; policies.py:20-30,
+ * 50-77): logits = h w[:, :A] + b[:A], v = h w[:, A] + b[A] + va (w [N,64,A+1] = [pi_w | v_w[:64]], b [N,A+1], va [N,rows] the
+ * critic's neighbour-action term of nmarl_nbr_action_value_fwd); the loss terms of nmarl_a2c_loss_fwd -> loss_out [N,3]; d logits,
+ * d v of nmarl_a2c_loss_bwd with g_up = 1 -> dy8 [N,rows,8] = [d logits | d v | 0 ..] and dv [N,rows]; dw [N,64,A+1] / db [N,A+1]
+ * as nmarl_thin_linear_bwd; dh [N,rows,64] (may be NULL: the one-launch BPTT kernels expand dy8 themselves, nmarl_lstm_bptt_seq_dy).
+ * Replaces a skinny GEMM, two loss passes and nmarl_thin_linear_bwd: h is read once.  A + 1 <= 8.  Deterministic (partial
+ * [N, nmarl_fc_bwd_chunks(rows,N), 65 (A+1) + 3], fixed-order sums).
+ */
+int nmarl_heads_loss(int64_t rows, int32_t N, int32_t H, int32_t A, const float* h, int64_t h_sn, const float* w, int64_t w_sn,
+                     const float* b, int64_t b_sn, const float* va, const uint8_t* action, const float* adv, const float* R,
+                     float v_coef, float e_coef, float* partial, float* loss_out, float* dy8, float* dv, float* dh,
+                     int64_t dh_sn, float* dw, int64_t dw_sn, float* db, int64_t db_sn, void* stream);
+
 /*
  * Neighbour-action term of the centralised critic, v += one_hot(neighbours' actions) @ w_a (policies.py:59-77),
  * without the one-hot tensor: action [rows,N] u8, nbr_idx [N,m_max] (-1 padded), w_a [N,m_max*A].

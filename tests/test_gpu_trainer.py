@@ -300,6 +300,36 @@ def test_env_step_inside_the_lock_step_launch_is_the_env_kernel(E, agent, scenar
         assert torch.equal(a, b), 'item %d differs between the in-launch env step and the env kernel' % k
 
 
+@pytest.mark.parametrize('agent,scenario,E', [('ia2c_fp', 'catchup', 4096), ('ia2c', 'catchup', 1000), ('ma2c_cu', 'slowdown', 77), ('ma2c_nc', 'slowdown', 1024),
+                                              ('ma2c_ic3', 'grid', 256), ('ma2c_dial', 'catchup', 512)])
+def test_fused_heads_loss_pass_equals_the_autograd_chain(agent, scenario, E, monkeypatch):
+    """The update's heads + A2C loss + heads' backward as ONE pass over the h sequence (nmarl_heads_loss, round 6) against the chain it
+    replaces (skinny GEMM -> nmarl_a2c_loss_fwd / _bwd -> nmarl_thin_linear_bwd; policies.py:20-30, 50-77): same rollout (bit-identical
+    actions), the loss terms and the flat gradient of the first update at fp32 summation-order tolerance, the weights after 3 batches
+    close.  (The two differ in the order the 64-long head dots and the weight-gradient partial sums are added.)"""
+    out = []
+    for fused in ('1', '0', 'dh'):            # 'dh': the fused pass writes dL/dh as a tensor, the one-launch BPTT does not expand dy8 itself
+        monkeypatch.setenv('NMARL_FUSED_HEADS_LOSS', '0' if fused == '0' else '1')
+        monkeypatch.setenv('NMARL_BPTT_HEAD_DY', '0' if fused == 'dh' else '1')
+        env, model, tr = build(agent, E, False, scenario=scenario, n_step=20)
+        tr.run_batch()
+        torch.cuda.synchronize()
+        rec = [model.buf_act.clone(), torch.stack([t.detach().clone() for t in model.last_loss[:3]]), model.policy.params.grad.clone()]
+        for _ in range(2):
+            tr.run_batch()
+        tr.flush()
+        torch.cuda.synchronize()
+        out.append(rec + [model.policy.params.flat.clone()])
+        del env, model, tr
+    (act1, loss1, g1, w1), (act0, loss0, g0, w0), (act2, loss2, g2, w2) = out
+    assert torch.equal(act1, act0) and torch.equal(act2, act0) and torch.equal(loss1, loss2)
+    torch.testing.assert_close(loss1, loss0, rtol=1e-5, atol=1e-7)
+    scale = float(g0.abs().max())
+    for g, w in ((g1, w1), (g2, w2)):
+        torch.testing.assert_close(g, g0, rtol=1e-4, atol=2e-6 * scale)
+        torch.testing.assert_close(w, w0, rtol=1e-3, atol=1e-5)
+
+
 @pytest.mark.parametrize('use_graph', [True, False])
 @pytest.mark.parametrize('agent,scenario,E', [('ma2c_nc', 'slowdown', 4096), ('ma2c_nc', 'catchup', 1000), ('ma2c_ic3', 'slowdown', 77),
                                               ('ma2c_ic3', 'grid', 1024), ('ma2c_ic3', 'grid', 1000)])

@@ -319,31 +319,43 @@ def measure_lstm_step_stamped(trainer):
     return ticks[len(ticks) // 2] / ops.timestamp_rate_khz(trainer.device) * 1e3
 
 
+def bptt_seq_takes_dy(model):
+    """The update hands the heads' dL/dh to the one-launch BPTT as dy8 (32 B per row-step, nmarl_lstm_bptt_seq_dy) instead of as a
+    [N,T,E,64] tensor (256 B): what agents/models.py `_loss_backward_fused` decides."""
+    from deeprl_network_amd import ops
+    p = model.policy
+    return bool(getattr(p, 'bptt_takes_head_dy', False)) and os.environ.get('NMARL_BPTT_HEAD_DY', '1') != '0' and \
+        ops.heads_loss_supported(model.H_all[:, 1:].reshape(model.n_agent, -1, model.n_lstm), model.n_a, p.nbr_idx)
+
+
 def measure_bptt_seq(model, reps=5):
     """Average duration of the second kernel of the update, the whole reverse recurrence in one launch
-    (nmarl_lstm_bptt_seq), on the model's own saved-activation buffers (shapes [N,T,E,*]): HIP events on the launch
-    stream around `reps` launches.  Algorithmic bytes per (agent, replica, step): gates 1 KB + c 256 B + dL/dh 256 B read,
-    dz 1 KB written = 2560 B.  Returns (us per launch, bytes per launch)."""
+    (nmarl_lstm_bptt_seq / _dy), on the model's own saved-activation buffers (shapes [N,T,E,*]): HIP events on the launch
+    stream around `reps` launches.  Algorithmic bytes per (agent, replica, step): gates 1 KB + c 256 B read, dz 1 KB written, and
+    the heads' dL/dh: 256 B, or 32 B of dy8 when the kernel expands it itself.  Returns (us per launch, bytes per launch)."""
     from deeprl_network_amd import ops
     p = model.policy
     G, C = model.G_buf, model.C_all
     N, T, E, H4 = G.shape
+    H = H4 // 4
     G.copy_(torch.rand_like(G))
     C.copy_(torch.randn_like(C) * 0.5)
-    dHs = torch.randn(N, T, E, H4 // 4, device=G.device)
+    dy = bptt_seq_takes_dy(model)
+    dHs = None if dy else torch.randn(N, T, E, H, device=G.device)
+    head_dy = (torch.randn(N, T * E, 8, device=G.device), torch.randn(N, H, model.n_a + 1, device=G.device)) if dy else None
     dZ = torch.empty_like(G)
     done = torch.zeros(T, E, device=G.device)
     img = ops.lstm_bptt_wimage(None, p.params[p.k_wh])
     for _ in range(2):
-        ops.bptt_seq(G, C, done, dHs, img, dZ)
+        ops.bptt_seq(G, C, done, dHs, img, dZ, head_dy=head_dy)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.bptt_seq(G, C, done, dHs, img, dZ, want_db=False)
+        ops.bptt_seq(G, C, done, dHs, img, dZ, want_db=False, head_dy=head_dy)
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * (H4 + H4 // 4 + H4 // 4 + H4) * 4
+    return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * (H4 + H + (8 if dy else H) + H4) * 4
 
 
 def measure_bptt_coupled(model, reps=3):
@@ -983,8 +995,10 @@ def main():
         if getattr(model, 'save_acts', False) and not model.policy.coupled and model.n_lstm == 64:
             try:
                 us_b, bytes_b = measure_bptt_seq(model)
+                dy_form = bptt_seq_takes_dy(model)
                 out['roofline_bptt'] = {
-                    'kernel': 'lstm_bptt_seq_kernel (nmarl_lstm_bptt_seq: %d reverse steps in one launch)' % n_step,
+                    'kernel': 'lstm_bptt_seq_kernel<%s> (%s: %d reverse steps in one launch)' %
+                              ('true' if dy_form else 'false', 'nmarl_lstm_bptt_seq_dy' if dy_form else 'nmarl_lstm_bptt_seq', n_step),
                     'bound': 'hbm', 'achieved': bytes_b / us_b / 1e3, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
                     'frac': bytes_b / us_b / 1e3 / HBM_PEAK_GBPS,
                     'traffic': (lambda t: None if (t[0] is None or n_agent * E * n_step != 8 * 4096 * 60) else t[0] * n_agent * E * n_step)(
@@ -992,11 +1006,12 @@ def main():
                     'traffic_source': pmc_traffic('lstm_bptt_seq_N8_E4096_T60')[1], 'bytes_per_launch': bytes_b,
                     'us_per_launch': us_b, 'launches_per_batch': 1,
                     'how': 'HIP events around 5 launches on the model\'s own [N,T,E,*] buffers; algorithmic bytes per (agent, '
-                           'replica, step) = gates 1024 + c 256 + dL/dh 256 read + dz 1024 written = 2560 B'}
+                           'replica, step) = gates 1024 + c 256 + %s read + dz 1024 written = %d B' %
+                           (('dy8 32 (the heads\' dL/dh is expanded inside the kernel)', 2336) if dy_form else ('dL/dh 256', 2560))}
             except Exception as ex:
                 out['roofline_bptt'] = {'error': repr(ex)}
             try:
-                ub = update_breakdown(trainer, 'nmarl_lstm_bptt_seq')
+                ub = update_breakdown(trainer, 'nmarl_lstm_bptt_seq_dy' if bptt_seq_takes_dy(model) else 'nmarl_lstm_bptt_seq')
                 if ub is not None:
                     out['update'] = ub
                     _quote_bptt_in_update(out['roofline_bptt'], ub)

@@ -888,7 +888,7 @@ __device__ __forceinline__ float hl_dpp(const float v) {     // 0x110 + n: row_s
 
 // OT: compile-time bound of O = A + 1 (5: CACC, 6: the grids, 8: anything else) -- the register arrays are that long
 template <bool DH, int OT>
-__global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, const int N, const int A, const int tiles_per_block,
+__global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, const int N, const int A_, const int tiles_per_block,
                                                          const float* __restrict__ h, const int64_t h_sn,
                                                          const float* __restrict__ w, const int64_t w_sn,
                                                          const float* __restrict__ b, const int64_t b_sn,
@@ -898,6 +898,8 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, con
                                                          float* __restrict__ dv_out, float* __restrict__ dh, const int64_t dh_sn,
                                                          float* __restrict__ partial) {
     __shared__ float red[4 * (65 * OT + 3)];
+    // OT 5 / 6: A is exactly OT - 1 (the launcher's choice): every `k < A` / `o < O` below is decided at compile time
+    const int A = OT < 8 ? OT - 1 : A_;
     const int O = A + 1;
     const int n = blockIdx.y, ki = threadIdx.x & 15, k4 = ki * 4, rl = threadIdx.x >> 4;
     float wk[4][OT], acc[4][OT], dbacc[OT], bo[OT];
@@ -1042,7 +1044,9 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, con
             float g[4] = {0.f, 0.f, 0.f, 0.f};                                             \
             _Pragma("unroll") for (int o = 0; o < OT; ++o)                                 \
                 if (o < O) {                                                               \
-                    const float di = hl_dpp<0x150 + i>(d[o]);                              \
+                    float di = hl_dpp<0x150 + i>(d[o]);                                    \
+                    asm volatile("" : "+v"(di));      /* its own register: hipcc 7.2 folded the last pass's broadcast of d[A] into the bias \
+                                                         sum and fed the weight gradient a stale register (DH = false, O = 5) */ \
                     dbacc[o] += di;                                                        \
                     _Pragma("unroll") for (int q = 0; q < 4; ++q) {                        \
                         g[q] = fmaf(di, wk[q][o], g[q]);                                   \
@@ -1398,8 +1402,8 @@ extern "C" int nmarl_heads_loss(int64_t rows, int32_t N, int32_t H, int32_t A, c
     hipStream_t st = static_cast<hipStream_t>(stream);
 #define NMARL_HL(DHF, OTV) hipLaunchKernelGGL((heads_loss_kernel<DHF, OTV>), dim3(C, N), dim3(256), 0, st, rows, N, A, tpb, h, h_sn, w, w_sn, \
                                               b, b_sn, va, action, adv, R, v_coef, e_coef, dy8, dv, dh, dh_sn, partial)
-    if (dh) { if (O <= 5) NMARL_HL(true, 5); else if (O == 6) NMARL_HL(true, 6); else NMARL_HL(true, 8); }
-    else { if (O <= 5) NMARL_HL(false, 5); else if (O == 6) NMARL_HL(false, 6); else NMARL_HL(false, 8); }
+    if (dh) { if (O == 5) NMARL_HL(true, 5); else if (O == 6) NMARL_HL(true, 6); else NMARL_HL(true, 8); }
+    else { if (O == 5) NMARL_HL(false, 5); else if (O == 6) NMARL_HL(false, 6); else NMARL_HL(false, 8); }
 #undef NMARL_HL
     hipLaunchKernelGGL(heads_loss_reduce_kernel, dim3((65 * O + 3 + 255) / 256, N), dim3(256), 0, st, C, O, rows, v_coef, e_coef, partial,
                        dw, dw_sn, db, db_sn, loss_out);

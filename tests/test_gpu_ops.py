@@ -862,6 +862,90 @@ def test_lstm_bptt_seq_one_launch(N, T, E):
                                atol=1e-6 * max(1.0, float(db_r.abs().max())) * (T * E) ** 0.5)
 
 
+@pytest.mark.parametrize('N,T,E,O', [(8, 12, 4096, 5), (3, 5, 127, 6), (25, 4, 130, 6), (2, 1, 1, 5), (4, 7, 33, 3), (2, 3, 70, 8)])
+def test_lstm_bptt_seq_expands_the_heads_gradient_itself(N, T, E, O):
+    """nmarl_lstm_bptt_seq_dy (round 6): the heads' dL/dh handed over as dy8 [N,T*E,8] = [d logits | d v | 0] + the heads' weights
+    hw [N,64,O] and formed inside the launch (two more k-steps of every step's transposed product) against nmarl_lstm_bptt_seq on
+    the tensor dL/dh = dy hw^T (float64 product, rounded once): dz, the bias gradient and the initial state's gradient at fp32
+    summation-order tolerance (the fp32 matrix-core accumulation of 5-8 terms against a rounded float64 sum); dones inside the
+    sequence, ragged rows, strided sequence buffers."""
+    from deeprl_network_amd import ops
+    H = 64
+    g = torch.Generator().manual_seed(N * 17 + T * 3 + E + O)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    gates = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
+    done = (torch.rand(T, E, generator=g) < 0.2).float()
+    call = _forward_cells(gates, r(N, E, H) * 0.8, done)
+    dy8 = torch.zeros(N, T * E, 8)
+    dy8[:, :, :O] = r(N, T * E, O)
+    hw = r(N, H, O) * 0.3
+    dhs = torch.bmm(dy8[:, :, :O].double(), hw.double().transpose(1, 2)).float().view(N, T, E, H)
+    wh = r(N, H, 4 * H) * 0.1
+    G = torch.zeros(N, T + 2, E, 4 * H, device='cuda'); G[:, 1:T + 1].copy_(gates)
+    C = torch.zeros(N, T + 3, E, H, device='cuda'); C[:, 1:T + 2].copy_(call)
+    img = ops.lstm_bptt_wimage(None, wh.cuda())
+    out = []
+    for head_dy in (None, (dy8.cuda(), hw.cuda())):
+        dZ = torch.zeros(N, T + 2, E, 4 * H, device='cuda')
+        db, dh0, dc0 = ops.bptt_seq(G[:, 1:T + 1], C[:, 1:T + 2], done.cuda(), dhs.cuda() if head_dy is None else None, img, dZ[:, 1:T + 1],
+                                    want_state_grad=True, head_dy=head_dy)
+        assert torch.all(dZ[:, 0] == 0) and torch.all(dZ[:, T + 1] == 0)
+        out.append((dZ[:, 1:T + 1].clone(), db, dh0, dc0))
+    for a, b in zip(*out):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=2e-6 * float(b.abs().max()))
+
+
+@pytest.mark.parametrize('N,rows,A,m_max', [(8, 4096, 4, 2), (25, 1003, 5, 4), (3, 1, 4, 2), (8, 70001, 4, 2), (5, 129, 3, 2), (2, 300, 7, 1)])
+@pytest.mark.parametrize('want_dh', [True, False])
+def test_heads_loss_one_pass_vs_torch(N, rows, A, m_max, want_dh):
+    """nmarl_heads_loss (round 6): the update's actor / critic heads (policies.py:50-77), the A2C loss (policies.py:20-30: softmax,
+    log of the clamped probabilities, entropy, value loss with the neighbour-action term) and the heads' backward in one pass over
+    h, against float64 torch autograd on the reference's formulas: the three loss terms, d logits | d v (dy8), dL/dh and the
+    gradients of pi_w, pi_b, v_w (h part and neighbour-action part), v_b.  A = 4 / 5: the compile-time forms; 3 / 7: the generic one."""
+    from deeprl_network_amd import ops
+    H = 64
+    g = torch.Generator().manual_seed(N * 5 + rows + A)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    h = torch.tanh(r(N, rows, H))
+    nbr = torch.tensor([[(i + k + 1) % N if k < 1 + (i % m_max) else -1 for k in range(m_max)] for i in range(N)], dtype=torch.int32)
+    pi_w, pi_b, v_w, v_b = r(N, H, A) * .3, r(N, A) * .1, r(N, H + m_max * A, 1) * .2, r(N, 1) * .1
+    action = torch.randint(0, A, (rows, N), generator=g).to(torch.uint8)
+    adv, R = r(N, rows), r(N, rows)
+    v_coef, e_coef = 0.5, 0.01
+    # float64 reference (agents/models.py `_loss` fallback = the reference's prepare_loss)
+    P = [t.double().requires_grad_(True) for t in (h, pi_w, pi_b, v_w, v_b)]
+    hd, pw, pb, vw, vb = P
+    logits = torch.baddbmm(pb.unsqueeze(1), hd, pw)
+    na = torch.zeros(N, rows, m_max * A, dtype=torch.float64)
+    for i in range(N):
+        for k in range(m_max):
+            j = int(nbr[i, k])
+            if j >= 0:
+                na[i, torch.arange(rows), k * A + action[:, j].long()] = 1.0
+    v = (torch.baddbmm(vb.unsqueeze(1), hd, vw[:, :H]) + torch.bmm(na, vw[:, H:])).squeeze(-1)
+    pi = torch.softmax(logits, dim=-1)
+    log_pi = torch.log(torch.clamp(pi, 1e-10, 1.0))
+    ent = -(pi * log_pi).sum(-1)
+    logp_a = log_pi.gather(-1, action.t().long().unsqueeze(-1)).squeeze(-1)
+    terms_r = torch.stack([-(logp_a * adv.double()).mean(-1), (R.double() - v).pow(2).mean(-1) * 0.5 * v_coef, -ent.mean(-1) * e_coef], dim=1)
+    logits.retain_grad(); v.retain_grad()
+    terms_r.sum().backward()
+    c = lambda t: t.cuda()                                                              # noqa: E731
+    out = ops.heads_loss(c(h), c(pi_w), c(pi_b), c(v_w), c(v_b), c(action), c(nbr), A, c(adv), c(R), v_coef, e_coef, want_dh=want_dh)
+    tol = dict(rtol=2e-4, atol=1e-6)
+    torch.testing.assert_close(out['terms'].cpu().double(), terms_r.detach(), rtol=2e-5, atol=1e-7)
+    dy8 = out['dy8'].cpu().double()
+    scale = float(logits.grad.abs().max())
+    torch.testing.assert_close(dy8[:, :, :A], logits.grad, rtol=2e-4, atol=2e-6 * scale)
+    torch.testing.assert_close(dy8[:, :, A], v.grad, rtol=2e-4, atol=2e-6 * float(v.grad.abs().max()))
+    assert float(dy8[:, :, A + 1:].abs().max() if A + 1 < 8 else 0.0) == 0.0
+    assert (out['dh'] is not None) == want_dh
+    if want_dh:
+        torch.testing.assert_close(out['dh'].cpu().double(), hd.grad, rtol=2e-4, atol=2e-6 * float(hd.grad.abs().max()))
+    for key, ref in (('pi_w', pw.grad), ('pi_b', pb.grad), ('v_w', vw.grad), ('v_b', vb.grad)):
+        torch.testing.assert_close(out[key].cpu().double().reshape(ref.shape), ref, rtol=2e-4, atol=3e-6 * float(ref.abs().max()) + 1e-9), key
+
+
 @pytest.mark.parametrize('N,E,A,m_max', [(8, 4096, 4, 2), (25, 130, 5, 4), (5, 127, 4, 2), (25, 1024, 5, 4)])
 @pytest.mark.parametrize('kind', [1, 2])
 def test_lstm_step_x_in_kernel_message_term(N, E, A, m_max, kind):

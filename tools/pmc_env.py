@@ -109,9 +109,24 @@ Gs = torch.cat([torch.sigmoid(rd(N, T, El, 3 * H)), torch.tanh(rd(N, T, El, H))]
 Cs, Ds, dZs = rd(N, T + 1, El, H), rd(N, T, El, H), torch.empty(N, T, El, 4 * H, device='cuda')
 dones = torch.zeros(T, El, device='cuda')
 bimg = ops.lstm_bptt_wimage(None, wh)
+# (round 6: the product form takes the heads' dL/dh as dy8 and expands it inside -- lstm_bptt_seq_kernel<true>)
+hd = (rd(N, T * El, 8) * 1e-3, rd(N, H, 5) * 0.1)
 for s in range(5):
-    ops.bptt_seq(Gs, Cs, dones, Ds, bimg, dZs)
+    ops.bptt_seq(Gs, Cs, dones, None, bimg, dZs, head_dy=hd)
 torch.cuda.synchronize()
+# the update's heads + loss + heads' backward in one pass over h (nmarl_heads_loss) at the bench shape
+try:
+    A_ = 4
+    nbr2 = torch.tensor([[max(i - 1, 0), min(i + 1, N - 1)] for i in range(N)], dtype=torch.int32, device='cuda')
+    hh = torch.tanh(rd(N, T * El, H))
+    acts = torch.randint(0, A_, (T * El, N), device='cuda').to(torch.uint8)
+    for s in range(5):
+        ops.heads_loss(hh, rd(N, H, A_) * .1, rd(N, A_) * .1, rd(N, H + 2 * A_, 1) * .1, rd(N, 1) * .1, acts, nbr2, A_, rd(N, T * El), rd(N, T * El),
+                       0.5, 0.01, want_dh=False)
+    torch.cuda.synchronize()
+    del hh, acts
+except Exception as ex:
+    print('heads_loss skipped:', ex)
 # the coupled nets' reverse recurrence in one launch (nmarl_lstm_bptt_coupled, NeurComm on the line graph) at the bench shape
 import sys as _sys
 _sys.path.insert(0, os.path.join(ROOT, 'tests'))

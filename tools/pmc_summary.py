@@ -88,15 +88,25 @@ try:        # the coupled nets' lock-step in one launch (NeurComm, line graph): 
 except (AssertionError, ZeroDivisionError) as ex:
     print('no one-launch coupled step in this collection:', ex)
 try:        # the whole reverse recurrence in one launch: "replica" = one (agent, replica, step) row of T = 60 steps;
-    # algorithmic bytes per row: gates 1024 + c 256 + dL/dh 256 read, dz 1024 written
-    s = stat('lstm_bptt_seq_kernel')
+    # algorithmic bytes per row: gates 1024 + c 256 + dy8 32 read (round 6: the heads' dL/dh is expanded inside), dz 1024 written
+    s = stat('lstm_bptt_seq_kernel<true>')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096 * 60
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
-             algorithmic_bytes_per_replica=2560, traffic_over_algorithmic=traffic / rows / 2560)
+             algorithmic_bytes_per_replica=2336, traffic_over_algorithmic=traffic / rows / 2336)
     res['kernels']['lstm_bptt_seq_N8_E4096_T60'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no bptt_seq in this collection:', ex)
+try:        # the update's heads + loss + heads' backward in one pass: per (agent, replica, step) row h 256 + va / adv / R 12 + action 1 read,
+    # dy8 32 + dv 4 written
+    s = stat('heads_loss_kernel<false, 5>')
+    traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
+    rows = 8 * 4096 * 60
+    s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
+             algorithmic_bytes_per_replica=305, traffic_over_algorithmic=traffic / rows / 305)
+    res['kernels']['heads_loss_N8_E4096_T60'] = s
+except (AssertionError, ZeroDivisionError) as ex:
+    print('no heads_loss in this collection:', ex)
 try:        # the coupled nets' reverse recurrence in one launch (NeurComm, line graph): per (agent, replica, step) row gates 1024 +
     # c 256 + dL/dh 256 + relu mask 256 + 2 neighbours' message slots 512 read; dz 1024 + d1 256 + message row 512 written
     s = stat('lstm_bptt_coupled_kernel<8, 2, true>')

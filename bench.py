@@ -173,13 +173,18 @@ def measure_lstm_step(model, n=60, reps=10):
             for _ in range(n):
                 p.step_policy_value(enc, h, c, done, pi, act, v, h_out=ho, c_out=co, gates=gates, defer_action_term=True,
                                     mode=ops.SAMPLE_PHILOX, seed=1, env_id_base=0, step=0, **kw)
-        flops = N * E * (2 * (KX + H) * 4 * H + 2 * (2 * H) * 4 * H + 2 * 2 * Km * H + (2 * H * H if in_step else 0))
+        # (round 6: the re-step's message term is handed to the next lock-step's policy step -- ONE message product per lock-step
+        # is algorithmic work, the second one the reference's two forward passes repeat is not counted when it is not done)
+        carry_on = os.environ.get('NMARL_MSG_CARRY', '1') != '0' and p.msg_kind in (ops.MSG_GATHER_RELU, ops.MSG_MEAN_ADD)
+        flops = N * E * (2 * (KX + H) * 4 * H + 2 * (2 * H) * 4 * H + (1 if carry_on else 2) * 2 * Km * H + (2 * H * H if in_step else 0))
         # read x (KX - 64 gathered columns), own h, c, the neighbours' h (old, then new) [, the compact observation of self and
         # neighbours]; write h', c', gates, message term, pi, v, action [, the encoder's output]
         nbytes = N * E * ((KX - H + 2 * H) * 4 + 2 * Km * 4 + 2 * H * 4 + 4 * H * 4 + H * 4 + A * 4 + 4 + 1 +
                           ((p.n_obs + H) * 4 if in_step else 0))
-        name = 'lstm_step_x_kernel<4,%d> (nmarl_lstm_step_x_msg, policy + value of the coupled net in one launch%s)' % (
-            p.msg_kind, ', observation encoder inside' if in_step else '')
+        name = 'lstm_step_x_kernel<4,%d,%d,%s> (nmarl_lstm_step_x_msg%s, policy + value of the coupled net in one launch%s%s)' % (
+            p.msg_kind, 1 if getattr(p, 'enc_in_kernel', lambda *a: False)(E, model.compact_obs) else 0, '1|2' if carry_on else '0',
+            '_grid' if in_step and hasattr(model, '_msg_carry') and N == 25 else '',
+            ', observation encoder inside' if in_step else '', ', message term carried between lock-steps' if carry_on else '')
     elif p.can_save_acts:
         # coupled nets: the policy step (kind 1) with the message term computed in its pre-phase where it fits
         KX = p.params[p.k_wx].shape[1]

@@ -57,7 +57,7 @@ for key, part, E, balg in ((pk + '_E2p21', 'cacc_step4_kernel<256' if COMPACT el
     res['kernels'][key] = s
 try:        # fused MFMA LSTM lock-step (x-side, policy + value heads): "replica" = one (agent, replica) row;
     # algorithmic bytes per row: x 512 + h, c in 512 + h', c' out 512 + gates 1024 + pi 16 + v 4 + action 1
-    s = stat('lstm_step_x_kernel<3, 0, 0>')
+    s = stat('lstm_step_x_kernel<3, 0, 0,')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
@@ -68,7 +68,7 @@ except (AssertionError, ZeroDivisionError) as ex:
 try:        # round 5, the whole lock-step in one launch (encoders + policy + value + env step): per (agent, replica) row -- own compact
     # observation 20 + own previous policy 16 + h, c 512 read; encoded LSTM input 512 + h', c' 512 + gates 1024 + pi 16 + v 4 + action 1
     # written; the hand-off word's atomic 8; the env step's 351 B per replica = 44 per row
-    s = stat('lstm_step_x_kernel<3, 0, 1>')
+    s = stat('lstm_step_x_kernel<3, 0, 1,')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096
     balg = 36 + 512 + 512 + 512 + 1024 + 21 + 8 + 44

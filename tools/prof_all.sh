@@ -13,6 +13,11 @@ python tools/clock_power.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_clock_
 bash tools/ab_lockstep.sh > gpurun_out/${TAG}_ab_lockstep.txt 2>&1
 bash tools/ab_lockstep_nc.sh > gpurun_out/${TAG}_ab_lockstep_nc.txt 2>&1
 python tools/e1_path.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_e1_path.txt
+bash tools/ab_round6_switches.sh > gpurun_out/${TAG}_ab_round6_switches.txt 2>&1
+( python tools/time_heads_loss.py; python tools/time_heads_loss.py 25 1024 120 5 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_heads_loss.txt
+( echo "# Captured-graph node census: python tools/graph_nodes.py <env> <agent> <E> [--phases] -- node types read back through hipGraphGetNodes / hipGraphNodeGetType"
+  echo "# (round 5's tree: rollout graphs held 1 (ia2c_fp) / 11 (ma2c_nc) / 10 (grid) memcpy nodes, update graphs 1-2)"
+  python tools/graph_nodes.py cacc ia2c_fp 4096; python tools/graph_nodes.py grid ma2c_ic3 1024; python tools/graph_nodes.py cacc ma2c_nc 4096 --phases ) 2>&1 | grep -v amdgpu.ids | grep -v Warning | grep -v run_backward > gpurun_out/${TAG}_graph_nodes.txt
 bash tools/prof_cfg.sh $TAG ia2c_fp_catchup ma2c_nc_slowdown ma2c_cnet_grid ma2c_dial_catchup
 fi
 if [ "$PART" = 1 ]; then exit 0; fi

@@ -272,6 +272,14 @@ def main():
                   ('epilogue', tr._epilogue),
                   ('rollout', tr._rollout)]
         from deeprl_network_amd import ops
+        # (trace_non_kernel runs autograd on THIS thread; its GEMM library handle must exist before a capture -- since round 6 the
+        # update has no forward GEMM on the main thread that would have made one)
+        with torch.autograd.set_multithreading_enabled(False):
+            m.load_rewards(tr.buf_rraw)
+            m.update_grads(tr.R_end)
+        torch.cuda.synchronize()
+        for k, v in flags.items():
+            setattr(m.policy, k, v)
         keep = []
         ops.keepalive_begin(keep)
         try:

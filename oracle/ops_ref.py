@@ -199,8 +199,14 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
             x = xs[3] if x is None else torch.cat([x, xs[3]], dim=-1)
         if len(xs) > 4 and xs[4] is not None:          # [x | message term] from the neighbours' un-masked h (quirk Q3)
             m = xs[4]
+            # the product's one-launch lock-steps hand the value re-step's message term to the next lock-step's policy step
+            # (nmarl_msg_t.carry_in / carry_out / mean_next): `_carry_role` says which of the two steps this call restates
+            role = m.get('_carry_role')
+            cin = m.get('carry_in') if role == 'policy' else None
             if m['kind'] == 1:                         # lstm_comm: relu([h_j] W_msg + b)   (agents/utils.py:182-199)
-                t = torch.relu(torch.bmm(nbr_gather(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1))
+                t = torch.relu(torch.bmm(nbr_gather(h, m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1)) if cin is None else cin.clone()
+                if role == 'value' and m.get('carry_out') is not None:
+                    m['carry_out'].copy_(t)
             elif m['kind'] == 3:                       # lstm_dial: relu([msg_j] W_msg + b) + enc, msg_j the senders' vectors (agents/utils.py:560-580)
                 t = torch.relu(torch.bmm(nbr_gather(m['src'], m['nbr_idx']), m['w_msg']) + m['b_msg'].unsqueeze(1))
                 if m.get('out2') is not None:
@@ -213,10 +219,18 @@ def lstm_step_fused(h, wh, bias, zadd1, zadd2, c_prev, done, gates, c_out, h_out
                     g = ob['x'][:, idx.clamp(min=0), :] * (idx >= 0).to(ob['x'].dtype).unsqueeze(-1)        # [E,N,slots,F]
                     g = g.reshape(g.shape[0], g.shape[1], -1).transpose(0, 1).to(ob['w'].dtype)             # [N,E,n_obs]
                     m['enc'].copy_(torch.tanh(torch.bmm(g, ob['w']) + ob['b'].unsqueeze(1)))
-                mm_ = nbr_mean(h, m['nbr_idx'])
-                if m.get('mean_out') is not None:
-                    m['mean_out'].copy_(mm_)
-                t = torch.bmm(mm_, m['w_msg']) + m['b_msg'].unsqueeze(1) + m['enc']
+                if cin is None:
+                    mm_ = nbr_mean(h, m['nbr_idx'])
+                    if m.get('mean_out') is not None:
+                        m['mean_out'].copy_(mm_)
+                    if role == 'value' and m.get('mean_next') is not None:
+                        m['mean_next'].copy_(mm_)
+                    t0 = torch.bmm(mm_, m['w_msg']) + m['b_msg'].unsqueeze(1)
+                else:                                  # (the previous launch wrote this lock-step's mean rows: mean_next)
+                    t0 = cin.clone()
+                if role == 'value' and m.get('carry_out') is not None:
+                    m['carry_out'].copy_(t0)
+                t = t0 + m['enc']
             if m.get('out') is not None:
                 m['out'].copy_(t)
             x = t if x is None else torch.cat([x, t], dim=-1)
@@ -402,9 +416,13 @@ def lstm_step_policy_value(h, wh, bias, zadd1, zadd2, c, done, pi_w, pi_b, pi_ou
     xs_p = xs
     if xs is not None and len(xs) > 4 and xs[4] is not None:
         # coupled net: only the POLICY step's message term is kept (`out`); the re-step's comes from the new h of all agents
-        xs = tuple(xs[:4]) + ({k: v for k, v in xs[4].items() if k not in ('out', 'mean_out')},)
+        xs_p = tuple(xs[:4]) + (dict(xs[4], _carry_role='policy'),)
+        xs = tuple(xs[:4]) + (dict({k: v for k, v in xs[4].items() if k not in ('out', 'mean_out')}, _carry_role='value'),)
     if gates is not None:
-        lstm_step_fused(h, wh, bias, zadd1, zadd2, c, done, gates, torch.empty_like(c), torch.empty_like(h), xs=xs)
+        xs_g = xs
+        if xs_p is not xs:                   # (the gates are the POLICY step's: its message term, without its outputs)
+            xs_g = tuple(xs[:4]) + (dict(xs[4], _carry_role='policy'),)
+        lstm_step_fused(h, wh, bias, zadd1, zadd2, c, done, gates, torch.empty_like(c), torch.empty_like(h), xs=xs_g)
         if xs_p is not xs:                   # the step below writes (h_out, c_out); the message term needs the OLD h of all agents
             assert h_out.data_ptr() != h.data_ptr()
     lstm_step_policy(h, wh, bias, zadd1, zadd2, c, done, c_out, h_out, pi_w, pi_b, pi_out, act_out, mode, u=u, seed=seed,

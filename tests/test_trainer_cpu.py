@@ -83,6 +83,44 @@ def test_coupled_one_launch_branch_equals_two_launch_branch(agent, monkeypatch):
         torch.testing.assert_close(m_one.policy.params.flat, m_two.policy.params.flat, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('agent', ['ma2c_nc', 'ma2c_ic3'])
+def test_message_term_carry_host_logic(agent, monkeypatch):
+    """Host side of the round-6 carry (agents/models.py `_msg_carry`): lock-step t's value re-step hands its message term (and
+    CommNet's mean rows, into slot t + 1 of the saved means) to lock-step t + 1's policy step; lock-step 0 of a batch computes its
+    own, the bootstrap step takes but does not hand on, the zero padding slab of the saved means stays zero.  On the restated ops the
+    carried and the recomputed term are the same numbers: everything bit-identical after 4 batches."""
+    out = []
+    for carry in ('1', '0'):
+        monkeypatch.setenv('NMARL_MSG_CARRY', carry)
+        with cpu_ops():
+            _, m, t = build(agent, E=3)
+            seen = []
+            def spy(self, step, orig=type(m)._msg_carry, seen=seen):
+                d = orig(self, step)
+                seen.append((step, None if d is None else (d.get('carry_in') is not None, d.get('carry_out') is not None, d.get('mean_next') is not None)))
+                return d
+            monkeypatch.setattr(type(m), '_msg_carry', spy)
+            for _ in range(4):
+                t.run_batch()
+            monkeypatch.undo()
+            monkeypatch.setenv('NMARL_MSG_CARRY', carry)
+            T = m.n_step
+            assert m.policy.pv_one_launch(3) and len(seen) == 4 * (T + 1)
+            if carry == '1':
+                per_batch = seen[:T + 1]
+                assert per_batch[0] == (0, (False, True, agent == 'ma2c_ic3' and T > 1))
+                assert all(per_batch[k] == (k, (True, True, agent == 'ma2c_ic3' and k + 1 < T)) for k in range(1, T))
+                assert per_batch[T] == (T, (True, False, False))
+            else:
+                assert all(d is None for _, d in seen)
+            if 'MM' in m.policy._extra_full:
+                assert float(m.policy._extra_full['MM'][:, -1].abs().max()) == 0.0
+            out.append((m.buf_act.clone(), m.buf_v.clone(), m.policy.params.flat.clone(), {k: v.clone() for k, v in m.policy._extra_full.items()}))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+    for k in out[0][3]:
+        assert torch.equal(out[0][3][k], out[1][3][k]), k
+
+
 def test_dial_sender_layer_in_the_policy_step_equals_fc_launches(monkeypatch):
     """lstm_dial: the policy step also runs the sender layer on the new h (msg['next']), the value re-step and the next
     lock-step's policy step re-use its output (DIALMultiAgentPolicy._cached_msg) -- ONE fc launch on h per batch (lock-step 0:

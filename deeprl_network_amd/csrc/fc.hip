@@ -918,29 +918,32 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, con
     const float* hn = h + (int64_t)n * h_sn + k4;
     float* dhn = DH ? dh + (int64_t)n * dh_sn + k4 : nullptr;
     // the NEXT tile's h rows and per-row scalars are requested before this tile's arithmetic (no global latency between two tiles)
+    // (the per-row scalars of ONE row per lane: lane ki computes the loss of row pass ki & 3 only)
     float4 hv[4];
-    float r_va[4], r_adv[4], r_R[4];
-    int r_a[4];
+    float r_va, r_adv, r_R;
+    int r_a;
+    const int ip = ki & 3;
 #define NMARL_HL_LOAD(tile_)                                                               \
     {                                                                                      \
         const int64_t r0_ = ((int64_t)blockIdx.x * tiles_per_block + (tile_)) * TILE;      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
             const int64_t row = r0_ + rl + 16 * i, rc = row < rows ? row : rows - 1;       \
             hv[i] = *reinterpret_cast<const float4*>(hn + rc * J);                         \
-            const int64_t ix = (int64_t)n * rows + rc;                                     \
-            r_va[i] = va[ix]; r_adv[i] = adv[ix]; r_R[i] = R[ix];                          \
-            r_a[i] = action[rc * N + n];                                                   \
         }                                                                                  \
+        const int64_t rw_ = r0_ + rl + 16 * ip, rs_ = rw_ < rows ? rw_ : rows - 1;         \
+        const int64_t ix_ = (int64_t)n * rows + rs_;                                       \
+        r_va = va[ix_]; r_adv = adv[ix_]; r_R = R[ix_];                                    \
+        r_a = action[rs_ * N + n];                                                         \
     }
     NMARL_HL_LOAD(0)
     for (int tile = 0; tile < tiles_per_block; ++tile) {
         const int64_t row0 = ((int64_t)blockIdx.x * tiles_per_block + tile) * TILE;
         if (row0 >= rows) break;
         float4 hc[4];
-        float c_va[4], c_adv[4], c_R[4];
-        int c_a[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { hc[i] = hv[i]; c_va[i] = r_va[i]; c_adv[i] = r_adv[i]; c_R[i] = r_R[i]; c_a[i] = r_a[i]; }
+        for (int i = 0; i < 4; ++i) hc[i] = hv[i];
+        const float s_va = r_va, s_ad = r_adv, s_R = r_R;
+        const int a = r_a;
         NMARL_HL_LOAD(tile + 1)
         // ---- the A + 1 dots of the tile's four row passes: 4 FMAs per lane, then the row's 16 lanes (one DPP row) add up by four
         // shifted adds -- lane 15 holds the sum -- and take it back by a row broadcast (full-rate VALU, no LDS crossbar)
@@ -963,14 +966,9 @@ __global__ __launch_bounds__(256) void heads_loss_kernel(const int64_t rows, con
         // ---- the loss of ONE row per lane and its gradient (a2c_loss_kernel's arithmetic, upstream gradient 1): lane ki takes row
         // pass ki & 3 (lanes 0..3 of the row are the ones whose result is used) -- all four passes in every lane would be 4 x the
         // transcendental work for the same 64 rows per wave
-        const int ip = ki & 3;
         float z[OT];
 #pragma unroll
         for (int o = 0; o < OT; ++o) z[o] = ip == 0 ? zz[0][o] : ip == 1 ? zz[1][o] : ip == 2 ? zz[2][o] : zz[3][o];
-        const float s_va = ip == 0 ? c_va[0] : ip == 1 ? c_va[1] : ip == 2 ? c_va[2] : c_va[3];
-        const float s_ad = ip == 0 ? c_adv[0] : ip == 1 ? c_adv[1] : ip == 2 ? c_adv[2] : c_adv[3];
-        const float s_R = ip == 0 ? c_R[0] : ip == 1 ? c_R[1] : ip == 2 ? c_R[2] : c_R[3];
-        const int a = ip == 0 ? c_a[0] : ip == 1 ? c_a[1] : ip == 2 ? c_a[2] : c_a[3];
         const int64_t row = row0 + rl + 16 * ip;
         const bool live = row < rows;
         float d[OT];

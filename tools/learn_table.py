@@ -11,7 +11,7 @@ print('command: `python tools/learn_curve.py <agent> <scenario | ini> <E> <updat
       'same schedules: `profiles/r05_learning_curves.md` -- the curves are not bit-comparable (the fused heads + loss pass adds the 64-long head '
       'dots and the weight-gradient partial sums in another order), the levels they reach are.\n')
 for arg in sys.argv[1:]:
-    title, path = arg.split('=', 1)
+    title, path = arg.rsplit('=', 1)
     rows = [json.loads(l) for l in open(path) if l.startswith('{')]
     print('## %s\n' % title)
     print('| update | train episodes | train avg r | train collisions | test avg r | test std | test collisions / 64 | greedy action share | wall s |')

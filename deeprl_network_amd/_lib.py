@@ -131,7 +131,9 @@ class BpttCoupled(C.Structure):
                                            'dbm_part', 'dhr_io', 'dc_io', 'ws', 'status', 'rev_agent', 'rev_col', 'rev_w')] +
                 [(k, C.c_int64) for k in ('gates_sn', 'gates_st', 'c_sn', 'c_st', 'dh_sn', 'dh_st', 'img_sn', 'imgm_sn', 'mask_sn',
                                           'mask_st', 'mask_row', 'dz_sn', 'dz_st', 'd1_sn', 'd1_st', 'ring_sn', 'ring_slot', 'db_sn',
-                                          'dbm_sn', 'io_sn')])
+                                          'dbm_sn', 'io_sn')] +
+                [('dy8', C.c_void_p), ('hw', C.c_void_p), ('dy_sn', C.c_int64), ('dy_st', C.c_int64), ('hw_sn', C.c_int64),
+                 ('O', C.c_int32), ('pad2_', C.c_int32)])
 
 
 class GridParams(C.Structure):

@@ -497,8 +497,11 @@ class BatchedPolicy:
     @property
     def bptt_takes_head_dy(self):
         """The backward of `unroll_saved` understands ops.head_dy_placeholder (the heads' dL/dh as dy8, expanded inside the
-        one-launch BPTT kernel): the uncoupled nets' recurrence (ops._lstm_seq_x_backward)."""
-        return not self.coupled and self.xside
+        BPTT kernel): the uncoupled nets' recurrence (ops._lstm_seq_x_backward) and the coupled one (agents/sequence.py; DIAL's
+        step-wise recurrence turns it into the tensor first)."""
+        if self.coupled and os.environ.get('NMARL_BPTT_HEAD_DY_COUPLED', '1') == '0':      # (A/B switch for the coupled kernels alone)
+            return False
+        return self.xside
 
     @property
     def can_save_acts(self):
@@ -1048,6 +1051,8 @@ class DIALMultiAgentPolicy(BatchedPolicy):
     """DIAL (policies.py:479-525 + lstm_dial agents/utils.py:515-599):
     s_i = relu(x~_i W_ob) + relu([mfc_j(h_j) for j in nbr(i)] W_msg) + onehot_H(argmax pi_i(t-1)) -> LSTM(H);
     the message encoder mfc_j = relu(h_j W + b) acts on the sender's un-masked previous h."""
+    bptt_takes_head_dy = False      # (its reverse recurrence is step-wise launches taking dL/dh as a tensor: the fused pass writes it)
+
     name = 'dial'
     k_wh, k_b, k_wx = 'wh_hid', 'hid_b', 'wx_hid'
     k_ob = 'w_ob'

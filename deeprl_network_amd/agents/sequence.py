@@ -181,7 +181,9 @@ class CoupledSequenceSaved(torch.autograd.Function):
         H = H4 // 4
         dev = G.device
         R = T * E
-        dHs = dHs.contiguous()
+        head_dy = ops.take_head_dy(dHs)       # the heads' dL/dh as dy8 (ops.heads_loss): the coupled BPTT kernel expands it itself
+        if head_dy is None:
+            dHs = dHs.contiguous()
         # (T + 1)-slab operands: with the LSTM inputs handed over as the first T slabs of a (T + 1)-slab buffer (last slab
         # zero), dZ / D1 allocated the same way and the h sequence being (T + 1) slabs anyway, every weight-gradient GEMM
         # reads contiguous [N, (T+1) E, .] operands in place -- no masked copy of the h sequence, no gathered copy
@@ -230,12 +232,15 @@ class CoupledSequenceSaved(torch.autograd.Function):
             rev = _reverse_table(nbr_idx, ckind)
             if rev is not None and not ops.bptt_coupled_supported(ckind, nbr_idx.shape[1], H, rev=rev):
                 rev = None                    # e.g. lstm_comm with more than 2 sources per agent: the step-wise loop below
+        if head_dy is not None and rev is None:       # (recurrences without a dy8 form take the tensor it stands for)
+            dHs, head_dy = ops.head_dy_to_dh(*head_dy, (N, T, E, H)), None
         if rev is not None:
             # the WHOLE reverse recurrence in one launch: cell backward, [dx | dh] = dz @ [wxm; wh]^T, relu mask, the message
             # adjoint D1 @ w_msg^T handed between the agents' blocks inside the kernel, both bias gradients on the way
             ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
             wm = (w_msg, ops.lstm_bptt_msg_wimage(w_msg))
-            db, dbmsg = ops.bptt_coupled(ckind, rev, nbr_idx.shape[1], G, Call, done, dHs, ws, wm, hm if kind == 'nc' else None, dZ, D1)
+            db, dbmsg = ops.bptt_coupled(ckind, rev, nbr_idx.shape[1], G, Call, done, dHs if head_dy is None else None, ws, wm,
+                                         hm if kind == 'nc' else None, dZ, D1, head_dy=head_dy)
         elif fused:   # cell backward + [dx | dh] = dz @ [wxm; wh]^T (+ relu mask, + done mask) in one MFMA kernel per step
             ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
             dhd_buf = torch.empty(N, E, H, dtype=F32, device=dev)

@@ -612,6 +612,10 @@ struct CoupledArgs {
     int32_t* status;                        // may be NULL: hand-off status words ([0] <- 1 when a wave gives up, sticky)
     unsigned max_spins;
     int32_t fault;                          // test hook: block 0 never publishes (its neighbours time out)
+    // DY (round 6): the heads' dL/dh arrives as dy8 [N][T][E][8] + the heads' weights hw [N][64][O] (see lstm_bptt_seq_kernel)
+    const float *dy8, *hw;
+    int64_t dy_sn, dy_st, hw_sn;
+    int32_t O;
 };
 
 typedef __attribute__((address_space(1))) unsigned gu32;
@@ -628,7 +632,7 @@ __device__ __forceinline__ void bstore4_wt(const __amdgpu_buffer_rsrc_t r, const
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, off, 0, SC1);      // write-through (sc1)
 }
 
-template <int NTM, int RMAX, bool MASK>     // NTM: 16-column tiles of a message row (64 m_max / 16 or 4); RMAX: max sources
+template <int NTM, int RMAX, bool MASK, bool DY = false>     // NTM: 16-column tiles of a message row (64 m_max / 16 or 4); RMAX: max sources; DY: see CoupledArgs
 __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const CoupledArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int IMG8 = G4 * 16 * 8;                // [Wxm; Wh]^T image (NT = 8)
@@ -658,7 +662,8 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     const int T = a.T, t_hi = a.t_hi, t_lo = a.t_lo;
     const float* gA = a.gates + (int64_t)n * a.gates_sn;
     const float* cA = a.c_all + (int64_t)n * a.c_sn;
-    const float* eA = a.dh_ext + (int64_t)n * a.dh_sn;
+    const float* eA = DY ? nullptr : a.dh_ext + (int64_t)n * a.dh_sn;
+    const float* yA = DY ? a.dy8 + (int64_t)n * a.dy_sn : nullptr;
     float* zA = a.dz + (int64_t)n * a.dz_sn;
     float* d1A = a.d1 + (int64_t)n * a.d1_sn;
     const float* mkA = MASK ? a.mask + (int64_t)n * a.mask_sn : nullptr;
@@ -667,6 +672,19 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
     const uint32_t lom = MASK ? (uint32_t)(arow_raw * a.mask_row + 4 * q) * 4u : 0u;
     const uint32_t nbm = MASK ? (uint32_t)((a.E - 1) * a.mask_row + H) * 4u : 0u;
     const uint32_t lor = (uint32_t)(arow_ok ? arow_raw : a.E - 1);
+    const uint32_t lo8 = (uint32_t)(arow_raw * 8 + q) * 4u, nb8 = (uint32_t)(a.E * 8) * 4u;
+    // DY: the lane's A operands of the heads' two k-steps, kept in registers (the images fill the LDS): hw[unit 16 t + c][output 4 s + q]
+    float4 hp0 = float4{0.f, 0.f, 0.f, 0.f}, hp1 = hp0;
+    if (DY) {
+        const float* hwn = a.hw + (int64_t)n * a.hw_sn;
+        const int O = a.O, o0 = q, o1 = 4 + q;
+        const bool k0 = o0 < O, k1 = o1 < O;
+        const int i0 = k0 ? o0 : 0, i1 = k1 ? o1 : 0;
+        hp0 = float4{hwn[c * O + i0], hwn[(16 + c) * O + i0], hwn[(32 + c) * O + i0], hwn[(48 + c) * O + i0]};
+        hp1 = float4{hwn[c * O + i1], hwn[(16 + c) * O + i1], hwn[(32 + c) * O + i1], hwn[(48 + c) * O + i1]};
+        if (!k0) hp0 = float4{0.f, 0.f, 0.f, 0.f};
+        if (!k1) hp1 = float4{0.f, 0.f, 0.f, 0.f};
+    }
     const uint32_t loR = (uint32_t)(arow_raw * KMO + 4 * q) * 4u;      // my row of a message tensor, + 64 tau (+ 4 col)
     const uint32_t nbR = (uint32_t)(a.E * KMO) * 4u;
 
@@ -705,7 +723,13 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         S.cp = bload4i(rc_, lo1, (64 * (j)) * 1);                                          \
     }
 #define NMARL_CP_LOADH(t_)                                                                 \
-    {                                                                                      \
+    if (DY) {       /* the lane's two values of dy8[t_][row c] (outputs q, 4 + q); gh starts from zero: NMARL_CP_HEADS adds the heads' part */ \
+        const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);                            \
+        const __amdgpu_buffer_rsrc_t ry_ = make_rsrc(yA + ts_ * a.dy_st, nb8);             \
+        dya = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, lo8, 0, 0));       \
+        dyb = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry_, lo8, 16, 0));      \
+        gh[0] = gh[1] = gh[2] = gh[3] = float4{0.f, 0.f, 0.f, 0.f};                        \
+    } else {                                                                               \
         const int64_t ts_ = __builtin_amdgcn_readfirstlane(t_);                            \
         const __amdgpu_buffer_rsrc_t re_ = make_rsrc(eA + ts_ * a.dh_st, nb1);             \
         gh[0] = bload4i(re_, lo1, 0);                                                      \
@@ -713,8 +737,25 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         gh[2] = bload4i(re_, lo1, 128);                                                    \
         gh[3] = bload4i(re_, lo1, 192);                                                    \
     }
+    // gh += dy hw^T (two k-steps x four unit tiles; the heads read h_t itself: no done mask)
+#define NMARL_CP_HEADS()                                                                   \
+    {                                                                                      \
+        f32x4 g0_ = f32x4{gh[0].x, gh[0].y, gh[0].z, gh[0].w}, g1_ = f32x4{gh[1].x, gh[1].y, gh[1].z, gh[1].w};   \
+        f32x4 g2_ = f32x4{gh[2].x, gh[2].y, gh[2].z, gh[2].w}, g3_ = f32x4{gh[3].x, gh[3].y, gh[3].z, gh[3].w};   \
+        g0_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp0.x, dya, g0_, 0, 0, 0);              \
+        g1_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp0.y, dya, g1_, 0, 0, 0);              \
+        g2_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp0.z, dya, g2_, 0, 0, 0);              \
+        g3_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp0.w, dya, g3_, 0, 0, 0);              \
+        g0_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp1.x, dyb, g0_, 0, 0, 0);              \
+        g1_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp1.y, dyb, g1_, 0, 0, 0);              \
+        g2_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp1.z, dyb, g2_, 0, 0, 0);              \
+        g3_ = __builtin_amdgcn_mfma_f32_16x16x4f32(hp1.w, dyb, g3_, 0, 0, 0);              \
+        gh[0] = float4{g0_[0], g0_[1], g0_[2], g0_[3]}; gh[1] = float4{g1_[0], g1_[1], g1_[2], g1_[3]};             \
+        gh[2] = float4{g2_[0], g2_[1], g2_[2], g2_[3]}; gh[3] = float4{g3_[0], g3_[1], g3_[2], g3_[3]};             \
+    }
     GateGroup sA, sB;
     float4 gh[4], dc[4];
+    float dya = 0.0f, dyb = 0.0f;
     NMARL_CP_LOADG(sA, t_hi, 0)
     NMARL_CP_LOADG(sB, t_hi, 1)
     NMARL_CP_LOADH(t_hi)
@@ -731,6 +772,9 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         gh[1].x += h1.x; gh[1].y += h1.y; gh[1].z += h1.z; gh[1].w += h1.w;
         gh[2].x += h2.x; gh[2].y += h2.y; gh[2].z += h2.z; gh[2].w += h2.w;
         gh[3].x += h3.x; gh[3].y += h3.y; gh[3].z += h3.z; gh[3].w += h3.w;
+    }
+    if (DY) {                                        // + the heads' dL/dh of step t_hi
+        NMARL_CP_HEADS()
     }
     // bias-gradient partial sums, fully reduced over the wave's 16 rows every step: lane (c, q) keeps, per unit group j,
     // the column of gate 2 (c & 1) + ((c >> 1) & 1), unit 16 j + 4 q + 2 ((c >> 2) & 1) + ((c >> 3) & 1)  (4 registers), and of
@@ -1034,12 +1078,16 @@ __global__ __launch_bounds__(512, 1) void lstm_bptt_coupled_kernel(const Coupled
         gh[1].x += acc[5][0] * keepA; gh[1].y += acc[5][1] * keepA; gh[1].z += acc[5][2] * keepA; gh[1].w += acc[5][3] * keepA;
         gh[2].x += acc[6][0] * keepA; gh[2].y += acc[6][1] * keepA; gh[2].z += acc[6][2] * keepA; gh[2].w += acc[6][3] * keepA;
         gh[3].x += acc[7][0] * keepA; gh[3].y += acc[7][1] * keepA; gh[3].z += acc[7][2] * keepA; gh[3].w += acc[7][3] * keepA;
+        if (DY) {                                    // + the heads' dL/dh of step t - 1 (its dy8 was requested mid-step)
+            NMARL_CP_HEADS()
+        }
         keepA = keep_next;
         NMARL_BSTAMP_T(16)
     }
     NMARL_BSTAMP(17)
 #undef NMARL_CP_LOADG
 #undef NMARL_CP_LOADH
+#undef NMARL_CP_HEADS
 #undef NMARL_CP_BL
 #undef NMARL_CP_MF
 #undef NMARL_CP_KS
@@ -1258,12 +1306,15 @@ template <int NTM, int RMAX, bool MASK>
 int launch_coupled(const CoupledArgs& a, unsigned grid, size_t lds_bytes, hipStream_t st) {
     static NmarlPerDeviceOnce once;
     if (const unsigned long long bit = once.pending(); bit != ~0ull) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<NTM, RMAX, MASK>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<NTM, RMAX, MASK, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_coupled_kernel<NTM, RMAX, MASK, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
             return NMARL_EHIP;
         once.done(bit);
     }
-    hipLaunchKernelGGL((lstm_bptt_coupled_kernel<NTM, RMAX, MASK>), dim3(grid), dim3(512), lds_bytes, st, a);
+    if (a.dy8) hipLaunchKernelGGL((lstm_bptt_coupled_kernel<NTM, RMAX, MASK, true>), dim3(grid), dim3(512), lds_bytes, st, a);
+    else hipLaunchKernelGGL((lstm_bptt_coupled_kernel<NTM, RMAX, MASK, false>), dim3(grid), dim3(512), lds_bytes, st, a);
     return nmarl_check_launch();
 }
 }  // namespace
@@ -1317,20 +1368,24 @@ extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stre
     if (K != 64 && K != 128) return NMARL_EINVAL;
     if (E == 0) return NMARL_OK;
     if (E > (1 << 21) || ((uintptr_t)p->status % 4)) return NMARL_EINVAL;
-    if (!p->gates || !p->c_all || !p->done || !p->dh_ext || !p->img || !p->img_m || !p->dz || !p->d1 || !p->ring || !p->db_part ||
+    if ((!p->dh_ext) == (!p->dy8)) return NMARL_EINVAL;            // the heads' dL/dh: as a tensor, or as dy8 + the heads' weights
+    if (p->dy8 && (!p->hw || p->O <= 0 || p->O > 8 || p->hw_sn < (int64_t)H * p->O || p->dy_st < E * 8 || (p->dy_st % 4) ||
+                   !sn_ok(p->dy_sn, (T - 1) * p->dy_st + E * 8) || ((uintptr_t)p->dy8 % 16)))
+        return NMARL_EINVAL;
+    if (!p->gates || !p->c_all || !p->done || !p->img || !p->img_m || !p->dz || !p->d1 || !p->ring || !p->db_part ||
         !p->dbm_part || !p->dhr_io || !p->dc_io || !p->ws || !p->rev_agent || !p->rev_col || !p->rev_w || (p->kind == 1 && !p->mask))
         return NMARL_EINVAL;
     const int64_t tiles = (E + ROWS_B - 1) / ROWS_B;
     if (p->gates_st < E * G4 || (p->gates_st % 4) || !sn_ok(p->gates_sn, (T - 1) * p->gates_st + E * G4) || p->dz_st < E * G4 ||
         (p->dz_st % 4) || !sn_ok(p->dz_sn, (T - 1) * p->dz_st + E * G4) || p->c_st < E * H || (p->c_st % 4) ||
-        !sn_ok(p->c_sn, T * p->c_st + E * H) || p->dh_st < E * H || (p->dh_st % 4) || !sn_ok(p->dh_sn, (T - 1) * p->dh_st + E * H) ||
+        !sn_ok(p->c_sn, T * p->c_st + E * H) || (p->dh_ext && (p->dh_st < E * H || (p->dh_st % 4) || !sn_ok(p->dh_sn, (T - 1) * p->dh_st + E * H))) ||
         p->d1_st < E * H || (p->d1_st % 4) || !sn_ok(p->d1_sn, (T - 1) * p->d1_st + E * H) || p->img_sn < (int64_t)G4 * 2 * H ||
         (p->img_sn % 4) || p->imgm_sn < (int64_t)K * H || (p->imgm_sn % 4) || !sn_ok(p->ring_sn, E * K) ||
         !sn_ok(p->ring_slot, (N - 1) * p->ring_sn + E * K) || p->db_sn < tiles * G4 || p->dbm_sn < tiles * H || !sn_ok(p->io_sn, E * H) ||
         (p->kind == 1 && (p->mask_row < H || (p->mask_row % 4) || p->mask_st < (E - 1) * p->mask_row + H || (p->mask_st % 4) ||
                           !sn_ok(p->mask_sn, (T - 1) * p->mask_st + (E - 1) * p->mask_row + H) || ((uintptr_t)p->mask % 16))) ||
         ((uintptr_t)p->img % 16) || ((uintptr_t)p->img_m % 16) || ((uintptr_t)p->gates % 16) || ((uintptr_t)p->dz % 16) ||
-        ((uintptr_t)p->c_all % 16) || ((uintptr_t)p->dh_ext % 16) || ((uintptr_t)p->d1 % 16) || ((uintptr_t)p->ring % 16) ||
+        ((uintptr_t)p->c_all % 16) || (p->dh_ext && ((uintptr_t)p->dh_ext % 16)) || ((uintptr_t)p->d1 % 16) || ((uintptr_t)p->ring % 16) ||
         ((uintptr_t)p->dhr_io % 16) || ((uintptr_t)p->dc_io % 16) || ((uintptr_t)p->ws % 4))
         return NMARL_EINVAL;
     CoupledArgs a{};
@@ -1346,6 +1401,7 @@ extern "C" int nmarl_lstm_bptt_coupled(const nmarl_bptt_coupled_t* p, void* stre
     a.dz_st = p->dz_st; a.d1_sn = p->d1_sn; a.d1_st = p->d1_st; a.ring_sn = p->ring_sn; a.ring_slot = p->ring_slot;
     a.db_sn = p->db_sn; a.dbm_sn = p->dbm_sn; a.io_sn = p->io_sn;
     a.E = E; a.N = N; a.T = T; a.mask_row = (int32_t)p->mask_row; a.tiles = (int32_t)tiles;
+    a.dy8 = p->dy8; a.hw = p->hw; a.dy_sn = p->dy_sn; a.dy_st = p->dy_st; a.hw_sn = p->hw_sn; a.O = p->O;
     if (p->ring_slots < 2) return NMARL_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // every polled word starts at zero for every call (flags count the steps done WITHIN the call); the error word behind

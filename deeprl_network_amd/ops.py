@@ -1257,19 +1257,20 @@ def _coupled_workspace(dev, N, E, K, T):
     return w
 
 
-def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0):
+def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0, head_dy=None):
     """The whole reverse recurrence of a coupled net's update in one launch (nmarl_lstm_bptt_coupled; step-wise launches of
     the same kernel when the grid is not resident at once): G / dZ [N,T,E,4H], Call [N,T+1,E,H], done [T,E], dHs / D1
     [N,T,E,H], mask (lstm_comm) = the saved message term hm as an [N,T,E,H] view (unit column stride); ws = (wxm, wh,
     lstm_bptt_wimage(wxm, wh)), wm = (w_msg, lstm_bptt_msg_wimage(w_msg)); rev = reverse_neighbor_table(nbr_idx, kind).
-    -> (db [N,4H], dbmsg [N,H]); writes dZ and D1.  `ws['err']` semantics: see check_coupled_status()."""
+    -> (db [N,4H], dbmsg [N,H]); writes dZ and D1.  `ws['err']` semantics: see check_coupled_status().
+    head_dy = (dy8 [N,T*E,8], hw [N,64,O]) instead of dHs: the kernel forms the heads' dL/dh itself (as bptt_seq)."""
     N, T, E, H4 = G.shape
     H = H4 // 4
     K = H * m_max if kind == COUPLED_NC else H
     img, img_m = ws[2], wm[1]
     if mode == 0 and not handoff_enabled():
         mode = 2                              # the device is shared with other processes: step-wise launches (see step_handoff_supported)
-    for x, w_, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (dHs, H, 'dh_ext'), (D1, H, 'd1')):
+    for x, w_, what in ((G, H4, 'gates'), (dZ, H4, 'dz'), (Call, H, 'c_all'), (D1, H, 'd1')) + (((dHs, H, 'dh_ext'),) if head_dy is None else ()):
         if x.stride(3) != 1 or x.stride(2) != w_:
             raise ValueError('bptt_coupled: %s must have contiguous rows' % what)
     w = _coupled_workspace(G.device, N, E, K, T)
@@ -1280,7 +1281,14 @@ def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mod
     a.gates, a.gates_sn, a.gates_st = ptr(G, F32, strided=True), G.stride(0), G.stride(1)
     a.c_all, a.c_sn, a.c_st = ptr(Call, F32, strided=True), Call.stride(0), Call.stride(1)
     a.done = ptr(done, F32)
-    a.dh_ext, a.dh_sn, a.dh_st = ptr(dHs, F32, strided=True), dHs.stride(0), dHs.stride(1)
+    if head_dy is None:
+        a.dh_ext, a.dh_sn, a.dh_st = ptr(dHs, F32, strided=True), dHs.stride(0), dHs.stride(1)
+    else:
+        dy8, hw = head_dy
+        if dy8.shape != (N, T * E, 8) or not dy8.is_contiguous() or hw.shape[:2] != (N, H) or not hw.is_contiguous():
+            raise ValueError('bptt_coupled: head_dy = (dy8 [N,T*E,8], hw [N,64,O]) contiguous')
+        a.dy8, a.dy_sn, a.dy_st = ptr(dy8, F32), dy8.stride(0), E * 8
+        a.hw, a.hw_sn, a.O = ptr(hw, F32), hw.stride(0), hw.shape[2]
     a.img, a.img_sn = ptr(img, F32), img.stride(0)
     a.img_m, a.imgm_sn = ptr(img_m, F32), img_m.stride(0)
     if kind == COUPLED_NC:

@@ -639,6 +639,11 @@ typedef struct nmarl_bptt_coupled {
     const float* rev_w;
     int64_t gates_sn, gates_st, c_sn, c_st, dh_sn, dh_st, img_sn, imgm_sn, mask_sn, mask_st, mask_row, dz_sn, dz_st, d1_sn, d1_st,
         ring_sn, ring_slot, db_sn, dbm_sn, io_sn;
+    /* round 6: EITHER dh_ext (the heads' dL/dh as a tensor) OR dy8 [N][T][E][8] = [d logits | d v | 0] of nmarl_heads_loss + the
+     * heads' weights hw [N][64][O] (O <= 8): the kernel then forms dL/dh_t(heads) = dy_t hw^T itself (as nmarl_lstm_bptt_seq_dy) */
+    const float *dy8, *hw;
+    int64_t dy_sn, dy_st, hw_sn;
+    int32_t O, pad2_;
 } nmarl_bptt_coupled_t;
 int nmarl_lstm_bptt_msg_wimage(int32_t N, int32_t K, const float* w_msg, int64_t w_sn, float* img, int64_t img_sn, void* stream);
 int nmarl_lstm_bptt_coupled_ws_words(int64_t E, int32_t N);

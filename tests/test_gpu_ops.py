@@ -1325,6 +1325,50 @@ def test_lstm_bptt_coupled_one_launch(kind, topo, N, T, E):
                                atol=1e-6 * max(1.0, float(db_r.abs().max())) * (T * E) ** 0.5)
 
 
+@pytest.mark.parametrize('kind,topo,N,T,E,O', [(1, 'line', 8, 12, 4096, 5), (1, 'line', 3, 5, 127, 5), (2, 'grid', 25, 6, 1024, 6),
+                                               (2, 'line', 8, 7, 300, 5), (2, 'grid', 9, 4, 77, 8)])
+def test_lstm_bptt_coupled_expands_the_heads_gradient_itself(kind, topo, N, T, E, O):
+    """nmarl_lstm_bptt_coupled with the heads' dL/dh handed over as dy8 + the heads' weights (round 6; formed inside the launch by two
+    more k-steps of every step's transposed product, the operands in registers) against the same call on the tensor dL/dh = dy hw^T:
+    dz, D1 and both bias gradients at fp32 summation-order tolerance, in the one-launch form and in step-wise launches (whose
+    carried state crosses launches), which must agree with each other bit for bit."""
+    from deeprl_network_amd import ops
+    H = 64
+    nbr_idx, _ = ops.neighbor_table(_topology(N, topo), 'cuda')
+    m_max = nbr_idx.shape[1]
+    K = H * m_max if kind == 1 else H
+    g = torch.Generator().manual_seed(N * 31 + T * 5 + E + kind + O)
+    r = lambda *s: torch.randn(*s, generator=g)                                         # noqa: E731
+    gates = torch.cat([torch.sigmoid(r(N, T, E, 3 * H)), torch.tanh(r(N, T, E, H))], dim=-1)
+    done = (torch.rand(T, E, generator=g) < 0.2).float()
+    call = _forward_cells(gates, r(N, E, H) * 0.8, done)
+    dy8 = torch.zeros(N, T * E, 8)
+    dy8[:, :, :O] = r(N, T * E, O)
+    hw = r(N, H, O) * 0.3
+    dhs = torch.bmm(dy8[:, :, :O].double(), hw.double().transpose(1, 2)).float().view(N, T, E, H)
+    wxg, whg, wmg = (r(N, H, 4 * H) * 0.1).cuda(), (r(N, H, 4 * H) * 0.1).cuda(), (r(N, K, H) * 0.15).cuda()
+    Sg = torch.relu(r(N, T, E, 3 * H)).cuda()
+    G, C, doneg = gates.cuda(), call.cuda(), done.cuda()
+    ws = (wxg, whg, ops.lstm_bptt_wimage(wxg, whg))
+    wm = (wmg, ops.lstm_bptt_msg_wimage(wmg))
+    rev = ops.reverse_neighbor_table(nbr_idx, kind)
+    resident = N * -(-E // 128) <= torch.cuda.get_device_properties(0).multi_processor_count
+    out = {}
+    for form, head_dy in (('tensor', None), ('dy8', (dy8.cuda(), hw.cuda()))):
+        for mode in ((1, 2) if resident else (0, 2)):
+            dZ, D1 = torch.zeros(N, T, E, 4 * H, device='cuda'), torch.zeros(N, T, E, H, device='cuda')
+            db, dbm = ops.bptt_coupled(kind, rev, m_max, G, C, doneg, dhs.cuda() if head_dy is None else None, ws, wm,
+                                       Sg[..., 2 * H:] if kind == 1 else None, dZ, D1, mode=mode, head_dy=head_dy)
+            torch.cuda.synchronize()
+            ops.check_coupled_status()
+            out[form, mode] = (dZ, D1, db, dbm)
+    m1 = 1 if resident else 0
+    for x, y in zip(out['dy8', m1][:2], out['dy8', 2][:2]):
+        assert torch.equal(x, y), 'dy8 form: one launch and step-wise launches differ'
+    for x, y in zip(out['dy8', m1], out['tensor', m1]):
+        torch.testing.assert_close(x, y, rtol=5e-5, atol=5e-6 * float(y.abs().max()))
+
+
 def test_lstm_bptt_coupled_repeated_calls_under_load():
     """The in-kernel hand-off must not depend on timing: the same update twice while another stream keeps the chip busy
     with a bandwidth-bound kernel (uneven load between the agents' blocks), results identical to the quiet run."""

@@ -382,27 +382,30 @@ def measure_bptt_coupled(model, reps=3):
     G, C, S = model.G_buf, model.C_all, model.S_buf
     N, T, E, H4 = G.shape
     K = w_msg.shape[1]
-    dHs = torch.randn(N, T, E, H, device=G.device) * 1e-3
+    dy = bptt_seq_takes_dy(model)             # the form the update uses: the heads' dL/dh as dy8 (32 B per row-step) or as a tensor (256 B)
+    dHs = None if dy else torch.randn(N, T, E, H, device=G.device) * 1e-3
+    head_dy = (torch.randn(N, T * E, 8, device=G.device) * 1e-3, torch.randn(N, H, model.n_a + 1, device=G.device) * 0.1) if dy else None
     dZ, D1 = torch.empty_like(G), torch.empty(N, T, E, H, device=G.device)
     done = torch.zeros(T, E, device=G.device)
     ws = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh))
     wm = (w_msg, ops.lstm_bptt_msg_wimage(w_msg))
     mask = S[..., 2 * H:] if kind == ops.COUPLED_NC else None
-    ops.bptt_coupled(kind, rev, p.m_max, G, C, done, dHs, ws, wm, mask, dZ, D1)
+    ops.bptt_coupled(kind, rev, p.m_max, G, C, done, dHs, ws, wm, mask, dZ, D1, head_dy=head_dy)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        ops.bptt_coupled(kind, rev, p.m_max, G, C, done, dHs, ws, wm, mask, dZ, D1)
+        ops.bptt_coupled(kind, rev, p.m_max, G, C, done, dHs, ws, wm, mask, dZ, D1, head_dy=head_dy)
     e1.record()
     torch.cuda.synchronize()
     ops.check_coupled_status()
     sources = float((p.nbr_idx >= 0).sum().item()) / N                    # message rows read per agent (mean fan-in)
-    row = 1024 + 256 + 256 + (256 if mask is not None else 0) + sources * (K // p.m_max if kind == ops.COUPLED_NC else K) * 4 \
+    row = 1024 + 256 + (32 if dy else 256) + (256 if mask is not None else 0) + sources * (K // p.m_max if kind == ops.COUPLED_NC else K) * 4 \
         + 1024 + 256 + K * 4
     one = N * -(-E // 128) <= max(_lib_capacity(2, K), 0) and ops.handoff_enabled()
-    name = 'lstm_bptt_coupled_kernel<%d,%d,%s> (nmarl_lstm_bptt_coupled, %s)' % (
-        K // 16, rev['r_row'], 'true' if mask is not None else 'false', 'one launch' if one else '%d step-wise launches' % T)
+    name = 'lstm_bptt_coupled_kernel<%d,%d,%s,%s> (nmarl_lstm_bptt_coupled%s, %s)' % (
+        K // 16, rev['r_row'], 'true' if mask is not None else 'false', 'true' if dy else 'false', ', heads\' dL/dh from dy8' if dy else '',
+        'one launch' if one else '%d step-wise launches' % T)
     return e0.elapsed_time(e1) * 1e3 / reps, N * T * E * row, name
 
 

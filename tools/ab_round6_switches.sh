@@ -4,6 +4,7 @@
 #   NMARL_MSG_CARRY           the re-step's message term handed to the next lock-step (CARRY 1 | 2)               vs  recomputed
 #   NMARL_FUSED_HEADS_LOSS    heads + loss + heads' backward in one pass (nmarl_heads_loss)                       vs  GEMM + loss fwd / bwd + thin_bwd
 #   NMARL_BPTT_HEAD_DY        the one-launch BPTT expands dy8 itself (nmarl_lstm_bptt_seq_dy)                      vs  dL/dh as a tensor
+#   NMARL_BPTT_HEAD_DY_COUPLED  the same for the coupled BPTT kernels (nmarl_bptt_coupled_t.dy8)                    vs  dL/dh as a tensor
 cd "$(dirname "$0")/.."
 run() { env "${@:3}" python bench.py --no-cpu-baseline --no-other-configs --steps 20 --warmup 4 --config config/config_$1.ini 2>/dev/null | python -c "
 import json,sys
@@ -18,6 +19,8 @@ for i in 1 2 3; do
   run ia2c_fp_catchup  "IA2C-FP: autograd chain" NMARL_FUSED_HEADS_LOSS=0
   run ia2c_fp_catchup  "IA2C-FP: fused, dh tensor" NMARL_BPTT_HEAD_DY=0
   run ia2c_fp_catchup  "IA2C-FP: default"        NMARL_BPTT_HEAD_DY=1
+  run ma2c_nc_slowdown "NeurComm: fused, dh tensor" NMARL_BPTT_HEAD_DY_COUPLED=0
+  run ma2c_cnet_grid   "grid: fused, dh tensor"  NMARL_BPTT_HEAD_DY_COUPLED=0
   run ma2c_nc_slowdown "NeurComm: autograd chain" NMARL_FUSED_HEADS_LOSS=0
   run ma2c_cnet_grid   "grid: autograd chain"    NMARL_FUSED_HEADS_LOSS=0
 done

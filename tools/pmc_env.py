@@ -137,8 +137,8 @@ Ss = torch.relu(rd(N, T, El, 3 * H))
 D1s = torch.empty(N, T, El, H, device='cuda')
 ws_, wm_ = (wxm, wh, ops.lstm_bptt_wimage(wxm, wh)), (wmsg, ops.lstm_bptt_msg_wimage(wmsg))
 rev = ops.reverse_neighbor_table(nbr_idx, ops.COUPLED_NC)
-for s in range(4):
-    ops.bptt_coupled(ops.COUPLED_NC, rev, 2, Gs, Cs, dones, Ds, ws_, wm_, Ss[..., 2 * H:], dZs, D1s)
+for s in range(4):      # (the product form: the heads' dL/dh as dy8, expanded inside -- kernel<8,2,true,true>)
+    ops.bptt_coupled(ops.COUPLED_NC, rev, 2, Gs, Cs, dones, None, ws_, wm_, Ss[..., 2 * H:], dZs, D1s, head_dy=hd)
 torch.cuda.synchronize()
 ops.check_coupled_status()
 # the coupled nets' lock-step in ONE launch (lstm_step_x_kernel<4,1>: NeurComm on the line graph) at the bench shape
@@ -191,8 +191,9 @@ try:
     wxmg, wmsgg = rd(Ng, H, 4 * H) * 0.1, rd(Ng, H, H) * 0.15
     wsg, wmgg = (wxmg, whg, ops.lstm_bptt_wimage(wxmg, whg)), (wmsgg, ops.lstm_bptt_msg_wimage(wmsgg))
     revg = ops.reverse_neighbor_table(nbr_g, ops.COUPLED_IC3)
+    hdg = (rd(Ng, Tg * Egd, 8) * 1e-3, rd(Ng, H, 6) * 0.1)
     for s in range(4):
-        ops.bptt_coupled(ops.COUPLED_IC3, revg, nbr_g.shape[1], Gg, Cg, donesg, Dg, wsg, wmgg, None, dZg, D1g)
+        ops.bptt_coupled(ops.COUPLED_IC3, revg, nbr_g.shape[1], Gg, Cg, donesg, None, wsg, wmgg, None, dZg, D1g, head_dy=hdg)
     torch.cuda.synchronize()
     ops.check_coupled_status()
 except Exception as ex:                        # a side measurement: never fail the pass

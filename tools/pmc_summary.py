@@ -109,11 +109,11 @@ except (AssertionError, ZeroDivisionError) as ex:
     print('no heads_loss in this collection:', ex)
 try:        # the coupled nets' reverse recurrence in one launch (NeurComm, line graph): per (agent, replica, step) row gates 1024 +
     # c 256 + dL/dh 256 + relu mask 256 + 2 neighbours' message slots 512 read; dz 1024 + d1 256 + message row 512 written
-    s = stat('lstm_bptt_coupled_kernel<8, 2, true>')
+    s = stat('lstm_bptt_coupled_kernel<8, 2, true, true>')          # (dy8 form: 32 instead of 256 B of the heads' dL/dh per row-step)
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 8 * 4096 * 60
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
-             algorithmic_bytes_per_replica=4096, traffic_over_algorithmic=traffic / rows / 4096)
+             algorithmic_bytes_per_replica=3872, traffic_over_algorithmic=traffic / rows / 3872)
     res['kernels']['lstm_bptt_coupled_nc_N8_E4096_T60'] = s
 except (AssertionError, ZeroDivisionError) as ex:
     print('no bptt_coupled in this collection:', ex)
@@ -131,10 +131,10 @@ except (AssertionError, ZeroDivisionError) as ex:
     print('no one-launch grid step in this collection:', ex)
 try:        # its coupled BPTT (T = 120): per (agent, replica, step) row gates 1024 + c 256 + dL/dh 256 + 3.2 neighbours' message rows
     # 3.2 x 256 read; dz 1024 + d1 256 + message row 256 written
-    s = stat('lstm_bptt_coupled_kernel<4, 4, false>')
+    s = stat('lstm_bptt_coupled_kernel<4, 4, false, true>')
     traffic = (2.0 * s['fetch_KiB'] + s['write_KiB']) * 1024
     rows = 25 * 1024 * 120
-    balg = int(1024 + 256 + 256 + 3.2 * 256 + 1024 + 256 + 256)
+    balg = int(1024 + 256 + 32 + 3.2 * 256 + 1024 + 256 + 256)
     s.update(replicas=rows, traffic_bytes_per_launch=traffic, traffic_bytes_per_replica=traffic / rows,
              algorithmic_bytes_per_replica=balg, traffic_over_algorithmic=traffic / rows / balg)
     res['kernels']['lstm_bptt_coupled_ic3_N25_E1024_T120'] = s

@@ -100,10 +100,14 @@ def bptt_step(gates, c_prev, c_new, done, dh, dh2, dc, ws, dz, dc_prev, dhd, app
 BPTT_SEQ_MAX_E = 1 << 21
 
 
-def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False, wh=None):
+def bptt_seq(G, Call, done, dHs, img, dZ, want_db=True, want_state_grad=False, wh=None, head_dy=None):
     """T reverse steps of bptt_step (KM = 0, every step masked) -> (db, dh0, dc0); wh is the restatement's weight
-    operand (the product passes the kernel-side image `img`, which the restatement cannot read back)."""
+    operand (the product passes the kernel-side image `img`, which the restatement cannot read back).
+    head_dy = (dy8, hw): the heads' dL/dh = dy hw^T, as in bptt_coupled."""
     N, T, E, H4 = G.shape
+    if head_dy is not None:
+        dy8, hw = head_dy
+        dHs = torch.bmm(dy8[:, :, :hw.shape[2]].to(hw.dtype), hw.transpose(1, 2)).view(N, T, E, -1)
     H = H4 // 4
     wh = img if wh is None else wh
     dh_rec = None
@@ -640,9 +644,13 @@ def bptt_coupled_supported(kind, m_max, H, rev=None):
         rev is not None and kind == COUPLED_NC and rev['r_max'] > 2)
 
 
-def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0):
+def bptt_coupled(kind, rev, m_max, G, Call, done, dHs, ws, wm, mask, dZ, D1, mode=0, head_dy=None):
     """Restatement of nmarl_lstm_bptt_coupled: per reverse step cell backward, [dx | dh] = dz @ [wxm; wh]^T, D1 = dx (relu
-    mask for lstm_comm), message adjoint through the neighbour table; ws = (wxm, wh, .), wm = (w_msg, .)."""
+    mask for lstm_comm), message adjoint through the neighbour table; ws = (wxm, wh, .), wm = (w_msg, .).
+    head_dy = (dy8 [N,T*E,8], hw [N,64,O]): the heads' dL/dh = dy hw^T (the product's kernel forms it itself)."""
+    if head_dy is not None:
+        dy8, hw = head_dy
+        dHs = torch.bmm(dy8[:, :, :hw.shape[2]].to(hw.dtype), hw.transpose(1, 2)).view(G.shape[0], G.shape[1], G.shape[2], -1)
     wxm, wh, _ = ws
     w_msg = wm[0]
     nbr_idx = rev['nbr_idx']

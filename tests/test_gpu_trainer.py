@@ -330,6 +330,19 @@ def test_fused_heads_loss_pass_equals_the_autograd_chain(agent, scenario, E, mon
         torch.testing.assert_close(w, w0, rtol=1e-3, atol=1e-5)
 
 
+def test_a_recurrence_that_ignores_the_heads_dy8_fails_loudly(monkeypatch):
+    """The fused update hands the heads' dL/dh to the recurrence as dy8 behind a zero-stride placeholder gradient
+    (ops.head_dy_placeholder): a backward that does not take it (ops.take_head_dy) would silently train on a zero gradient -- the
+    model checks that it was consumed and raises."""
+    from deeprl_network_amd import ops
+    env, model, tr = build('ia2c_fp', 64, False, n_step=10)
+    tr.rollout()
+    model.load_rewards(tr.buf_rraw)
+    monkeypatch.setattr(ops, 'take_head_dy', lambda dHs: None)
+    with pytest.raises(RuntimeError, match='did not take'):
+        model.update_grads(tr.R_end)
+
+
 @pytest.mark.parametrize('use_graph', [True, False])
 @pytest.mark.parametrize('agent,scenario,E', [('ma2c_nc', 'slowdown', 4096), ('ma2c_nc', 'catchup', 1000), ('ma2c_ic3', 'slowdown', 77),
                                               ('ma2c_ic3', 'grid', 1024), ('ma2c_ic3', 'grid', 1000)])

@@ -268,10 +268,18 @@ __global__ __launch_bounds__(EPI_BLOCK) void epilogue_stats_kernel(const Epilogu
     double f0 = 0.0, f1 = 0.0, f2 = 0.0, f3 = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * EPI_BLOCK + threadIdx.x; e < a.E; e += (int64_t)gridDim.x * EPI_BLOCK) {
         double s = 0.0, q = 0.0;
-        for (int t = 0; t < a.T; ++t) {
-            const double v = (double)a.g[(int64_t)t * a.E + e];
-            s += v;
-            q += v * v;
+        constexpr int U = 12;                          // twelve steps' rewards requested together (one load latency per twelve steps); sums in
+        for (int t0 = 0; t0 < a.T; t0 += U) {          // the same order t = 0 .. T-1
+            float gv[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) gv[k] = a.g[(int64_t)(t0 + k < a.T ? t0 + k : a.T - 1) * a.E + e];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (t0 + k >= a.T) break;
+                const double v = (double)gv[k];
+                s += v;
+                q += v * v;
+            }
         }
         const double sum = a.ep_sum[e] + s, sq = a.ep_sq[e] + q, len = a.ep_len[e] + (double)a.T;
         const bool d = a.done[e] != 0;

@@ -112,7 +112,7 @@ for a, b in (('%s_pmc_traffic.json', '%s_pmc_traffic.json'), ('%s_pmc_traffic.md
              ('%s_grid_step.txt', '%s_grid_step.txt'), ('%s_determinism.txt', '%s_determinism.txt'),
              ('%s_ab_lockstep_nc.txt', '%s_ab_lockstep_nc_pass2.txt'), ('%s_e1_path.txt', '%s_e1_path.txt'),
              ('%s_ab_round6_switches.txt', '%s_ab_round6_switches.txt'), ('%s_heads_loss.txt', '%s_heads_loss.txt'),
-             ('%s_graph_nodes.txt', '%s_graph_nodes.txt')):
+             ('%s_graph_nodes.txt', '%s_graph_nodes.txt'), ('%s_pmc_sq.md', '%s_pmc_sq.md')):
     if os.path.exists(os.path.join(src, a % tag)):
         shutil.copy(os.path.join(src, a % tag), os.path.join(dst, b % tag))
 print('profiles/%s_* written' % tag)

@@ -28,6 +28,11 @@ mkdir -p /tmp/pmc
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc -o pmc_FETCH_SIZE --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc -o pmc_WRITE_SIZE --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_write.log 2>&1
 python tools/pmc_summary.py /tmp/pmc $TAG gpurun_out > gpurun_out/${TAG}_pmc_summary.log 2>&1
+# SQ counters (issue / stall / matrix-pipe busy, LDS conflicts) of the same harness: two more passes, counters only
+mkdir -p /tmp/pmcsq
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --kernel-trace -d /tmp/pmcsq -o sqa --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_sqa.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace -d /tmp/pmcsq -o sqb --output-format csv -- python tools/pmc_env.py > gpurun_out/${TAG}_pmc_sqb.log 2>&1
+python tools/pmc_sq.py /tmp/pmcsq > gpurun_out/${TAG}_pmc_sq.md 2>&1
 # shader-clock phase timelines of the lock-step kernels (instrumentation build of csrc/lstm_mfma.hip, tools/step_timeline.py)
 python tools/time_fc_pair.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_fc_pair.txt
 python tools/time_grid_step.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_grid_step.txt
